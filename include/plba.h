@@ -1,0 +1,182 @@
+/*
+ * plba.h — C ABI of the MI355X-native local bundle adjustment ("plba") hot path.
+ *
+ * This is the drop-in boundary between host C++ (the g2o-compatible facade used by
+ * MapHandler::localBundleAdjustmentWithImu / ...WithImuAndMarg, reference
+ * src/mapHandler.cpp:5086-5739 and :5741-6254) and the hand-written HIP kernels.
+ * Plain C linkage, plain pointers and sizes, no C++ or torch types.
+ *
+ * Conventions
+ *  - every function returns 0 (PLBA_OK) or a negative plba_status; text via plba_last_error().
+ *  - the caller owns every host buffer it passes in (copied during the call) and every
+ *    output buffer it supplies; the library owns all device memory.
+ *  - thread-compatible: one thread per plba_problem.
+ *  - all reals are IEEE double (the reference path is all-double); ids are int32.
+ *  - matrices are row-major unless a name says colmajor.
+ *  - keyframes are addressed by their index k in [0,K) in the arrays of plba_set_keyframes
+ *    (ascending vertex id); points/lines by their index in plba_set_points / plba_set_lines.
+ *
+ * What each entry point replaces in the reference is cited next to it.
+ */
+#ifndef PLBA_H
+#define PLBA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plba_problem plba_problem;
+
+typedef enum {
+    PLBA_OK = 0,
+    PLBA_ERR_INVALID = -1,   /* bad argument / inconsistent sizes / unsorted input   */
+    PLBA_ERR_STATE = -2,     /* call order violated (e.g. optimize before upload)    */
+    PLBA_ERR_DEVICE = -3,    /* HIP runtime error, no device, kernel image missing    */
+    PLBA_ERR_NUMERIC = -4,   /* non-finite input                                       */
+    PLBA_ERR_EXCHANGE = -5   /* the multi-GPU exchange callback failed                 */
+} plba_status;
+
+/* Edge families of the path. */
+typedef enum {
+    PLBA_EDGE_POINT = 0,     /* EdgeNavStatePVRPointXYZ  IMU/g2otypes.h:220, .cpp:286  */
+    PLBA_EDGE_LINE = 1,      /* EdgeNavStateLine         IMU/g2otypes.h:773, .cpp:1306 */
+    PLBA_EDGE_IMU_PVR = 2,   /* EdgeNavStatePVR          IMU/g2otypes.cpp:27,94        */
+    PLBA_EDGE_IMU_BIAS = 3,  /* EdgeNavStateBias         IMU/g2otypes.cpp:236,264      */
+    PLBA_EDGE_PRIOR = 4      /* EdgeMarginalization      IMU/g2otypes.cpp:1423,1477    */
+} plba_edge_kind;
+
+/* Hard-coded constants of the reference exposed as options with identical defaults. */
+typedef struct {
+    double tau;                 /* g2o LM: lambda_init = tau * max|H_jj|             (1e-5)  */
+    double good_step_lower;     /* g2o LM goodStepLowerScale                          (1/3)   */
+    double good_step_upper;     /* g2o LM goodStepUpperScale                          (2/3)   */
+    int    max_trials;          /* g2o LM maxTrialsAfterFailure                       (10)    */
+    double user_lambda_init;    /* g2o LM userLambdaInit, 0 = automatic               (0)     */
+    double marg_eps;            /* IMU/marginalization.h:99 pseudo-inverse threshold  (1e-8)  */
+    int    fix_line_position_jacobian; /* 0 = reproduce IMU/g2otypes.cpp:1347 (SURVEY B-Q1)   */
+    int    whiten_marg_factors; /* 0 = reproduce IMU/marginalization.cpp:67 (SURVEY B-Q4)     */
+    int    device;              /* HIP device ordinal, -1 = current device            (-1)    */
+    int    use_mfma;            /* 1 = fp64 MFMA trailing update in the dense solve    (1)    */
+    int    reserved[6];
+} plba_options;
+
+void plba_default_options(plba_options* o);
+
+/* Result of one optimize() call = g2o SparseOptimizer::optimize(n). */
+typedef struct {
+    int    iterations;          /* outer LM iterations executed (g2o return value)             */
+    int    trials;              /* total damped trial solves                                    */
+    int    stop_reason;         /* 0 ran all iterations, 1 LM Terminate, 2 abort flag           */
+    int    solver_failures;     /* trials whose reduced-camera Cholesky hit a pivot <= 0        */
+    double chi2_initial;        /* activeRobustChi2 before the first iteration                  */
+    double chi2_final;          /* activeRobustChi2 of the state left in the problem            */
+    double lambda_final;
+    double ms_total;            /* wall time of this call, device-synchronised                  */
+    double ms_phase[8];         /* linearize, pose-edges, schur, solve, backsubst, errors, exchange, host */
+} plba_stats;
+
+/* One row per LM trial, for golden traces (tests/golden). */
+typedef struct {
+    int    iteration, trial, accepted, solver_ok;
+    double lambda, chi2_current, chi2_trial, scale, rho;
+} plba_trace_row;
+
+/* Output of plba_marginalize = the state MarginalizationInfo carries between BA calls
+ * (IMU/marginalization.h:82-95).  J0 is n x n column-major like Eigen's linearized_jacobians. */
+typedef struct {
+    int      n;                 /* kept dimension                                              */
+    int      m;                 /* dropped dimension                                           */
+    int      nv;                /* kept vertices                                                */
+    int32_t* vid;               /* keep_vertex_id   [nv]                                        */
+    int32_t* size;              /* keep_vertex_size [nv] (9 PVR / 6 bias)                       */
+    int32_t* idx;               /* keep_vertex_idx - m [nv]                                     */
+    double*  x0;                /* keep_vertex_data packed: 10 doubles per PVR, 6 per bias      */
+    double*  J0;                /* linearized_jacobians  n*n colmajor                           */
+    double*  r0;                /* linearized_residuals  n                                      */
+    double*  Ar;                /* reduced information A' (n*n, row-major == col-major, symmetric) */
+    double*  br;                /* reduced b' (n)                                               */
+} plba_prior;
+
+/* Multi-GPU exchange hook.  Called on the problem's thread with a DEVICE buffer of n
+ * doubles that must be all-reduced in place over every rank (op 0 = sum, 1 = max), ordered on
+ * `stream` (a hipStream_t).  The host side supplies it (RCCL ncclAllReduce, or torch.distributed). */
+typedef int (*plba_allreduce_fn)(void* user, double* device_buf, size_t n, int op, void* stream);
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int  plba_create(const plba_options* opt, plba_problem** out);   /* g2o::SparseOptimizer ctor + solver chain, mapHandler.cpp:5787-5794 */
+void plba_destroy(plba_problem* p);
+const char* plba_last_error(const plba_problem* p);             /* p may be NULL: last create() error */
+const char* plba_backend_name(void);                             /* "hip-gfx950" */
+
+/* ---- problem upload (graph construction of mapHandler.cpp:5799-6034) ----------------------- */
+int plba_set_camera(plba_problem* p, double fx, double fy, double cx, double cy,
+                    const double Rbc[9], const double Pbc[3]);    /* SetParams, IMU/g2otypes.h:280-288 */
+int plba_set_gravity(plba_problem* p, const double gw[3]);       /* EdgeNavStatePVR::SetParams h:116 */
+/* vid_* ascending; vid_bias[k] = -1 when keyframe k has no bias vertex (configs 1-2). */
+int plba_set_keyframes(plba_problem* p, int K, const int32_t* vid_pvr, const int32_t* vid_bias,
+                       const double* P3, const double* V3, const double* q_xyzw4,
+                       const double* bg3, const double* ba3, const double* dbg3, const double* dba3,
+                       const uint8_t* fixed_pvr, const uint8_t* fixed_bias);
+int plba_set_points(plba_problem* p, int Np, const double* xyz3, const uint8_t* fixed /*may be NULL*/);
+int plba_set_lines(plba_problem* p, int Nl, const double* sPeP6, const uint8_t* fixed /*may be NULL*/);
+/* observations must be landmark-major (pt[] non-decreasing), the reference's edge insertion order */
+int plba_set_point_obs(plba_problem* p, int Ep, const int32_t* pt, const int32_t* kf,
+                       const double* uv2, const double* inv_sigma2);
+int plba_set_line_obs(plba_problem* p, int El, const int32_t* ln, const int32_t* kf,
+                      const double* l3, const double* inv_sigma2);
+/* preint142 = dP3 dV3 dR9 JPg9 JPa9 JVg9 JVa9 JRg9 cov81 dt (IMU/IMUPreintegrator.h:187-201);
+ * info_pvr81 = cov^-1 (mapHandler.cpp:5269); info_bias36 = InvCovBgaRW/dt (:5287). */
+int plba_set_imu_edges(plba_problem* p, int M, const int32_t* kf_i, const int32_t* kf_j,
+                       const double* preint142, const double* info_pvr81, const double* info_bias36);
+int plba_set_prior(plba_problem* p, int n, int nv, const int32_t* vid, const int32_t* size,
+                   const int32_t* idx_minus_m, const double* x0_packed,
+                   const double* J0_colmajor, const double* r0);  /* nv == 0 clears; mapHandler.cpp:6007-6034 */
+int plba_set_robust(plba_problem* p, plba_edge_kind kind, int enabled, double huber_delta); /* setRobustKernel/setDelta */
+int plba_set_levels(plba_problem* p, plba_edge_kind kind, const uint8_t* level);           /* setLevel, POINT/LINE only */
+int plba_get_levels(plba_problem* p, plba_edge_kind kind, uint8_t* level);
+
+/* ---- multi-GPU: this problem holds a landmark shard; pose-side edges are added by rank 0 only */
+int plba_set_shard(plba_problem* p, int rank, int world, plba_allreduce_fn fn, void* user);
+int plba_set_stream(plba_problem* p, void* hip_stream);           /* run on a caller stream (e.g. torch's) */
+
+/* ---- solve ---------------------------------------------------------------------------------- */
+/* = initializeOptimization(0); optimize(max_iters)  (mapHandler.cpp:6038-6039, 6068-6069). */
+int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_flag, plba_stats* out);
+/* chi2 > thresh || !isDepthPositive  =>  level 1, for POINT and LINE edges, then robust kernels
+ * off on both kinds (mapHandler.cpp:6047-6066).  Returns the number of edges moved to level 1. */
+int plba_gate_outliers(plba_problem* p, double chi2_thresh, int* n_point_out, int* n_line_out);
+int plba_recompute_errors(plba_problem* p);                       /* computeActiveErrors on the current state */
+/* per-edge chi2 (e^T Omega e, non-robustified) as of the last evaluation pass
+ * and isDepthPositive on the current estimates; either pointer may be NULL. */
+int plba_get_edge_chi2(plba_problem* p, plba_edge_kind kind, double* chi2, uint8_t* depth_positive);
+int plba_get_trace(plba_problem* p, plba_trace_row* rows, int cap, int* n);
+
+/* ---- results (write-back of mapHandler.cpp:6202-6239) --------------------------------------- */
+int plba_get_keyframes(plba_problem* p, double* P3, double* V3, double* q_xyzw4, double* dbg3, double* dba3);
+int plba_get_points(plba_problem* p, double* xyz3);
+int plba_get_lines(plba_problem* p, double* sPeP6);
+/* device-side snapshot/restore of all estimates (used by benches to replay a window) */
+int plba_save_state(plba_problem* p);
+int plba_restore_state(plba_problem* p);
+
+/* ---- marginalization (mapHandler.cpp:6075-6199, IMU/marginalization.cpp:128-147,291-384) ----- */
+int  plba_marginalize(plba_problem* p, int first_kf, int max_edges_per_kind /*NUM=50 admits 51*/,
+                      plba_prior* out);
+void plba_prior_free(plba_prior* pr);
+
+/* ---- diagnostics used by the parity tests (not needed by a drop-in caller) ------------------- */
+/* Runs computeActiveErrors + buildSystem + setLambda(lambda) + Schur on the current state without
+ * updating it, then exposes named internal buffers: "Hschur" (P*P row-major), "bschur" (P),
+ * "bp" (P), "x" (P + 3Np + 6Nl after a solve), "hll_pt" (Np*9), "bl_pt" (Np*3), "hll_ln" (Nl*36),
+ * "bl_ln" (Nl*6), "err_pvr" (M*9), "err_bias" (M*6), "err_prior" (n), "pose_dim" (1), "chi2" (1),
+ * "maxdiag" (1). */
+int plba_debug_build(plba_problem* p, double lambda, int do_solve);
+int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, size_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLBA_H */

@@ -1,0 +1,384 @@
+"""ctypes description of the C ABI declared in include/plba.h.
+
+The same signature table binds two different shared objects:
+  * the product:  pl-inertial-slam_amd/libplba_hip.so   (prefix ``plba_``), HIP kernels for gfx950;
+  * the checker:  oracle/_build/libplba_oracle.so        (prefix ``orc_``), loaded ONLY by tests/,
+    __graft_entry__.smoke() and bench.py's cpu_baseline leg (see oracle/oracle.py).
+Nothing in this file computes anything: it is the Python spelling of plba.h.
+"""
+import ctypes as C
+import numpy as np
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+EDGE_POINT, EDGE_LINE, EDGE_IMU_PVR, EDGE_IMU_BIAS, EDGE_PRIOR = range(5)
+
+STATUS = {0: "PLBA_OK", -1: "PLBA_ERR_INVALID", -2: "PLBA_ERR_STATE", -3: "PLBA_ERR_DEVICE",
+          -4: "PLBA_ERR_NUMERIC", -5: "PLBA_ERR_EXCHANGE"}
+
+
+class Options(C.Structure):
+    _fields_ = [("tau", C.c_double), ("good_step_lower", C.c_double), ("good_step_upper", C.c_double),
+                ("max_trials", C.c_int), ("user_lambda_init", C.c_double), ("marg_eps", C.c_double),
+                ("fix_line_position_jacobian", C.c_int), ("whiten_marg_factors", C.c_int),
+                ("device", C.c_int), ("use_mfma", C.c_int), ("reserved", C.c_int * 6)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("trials", C.c_int), ("stop_reason", C.c_int),
+                ("solver_failures", C.c_int), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
+                ("lambda_final", C.c_double), ("ms_total", C.c_double), ("ms_phase", C.c_double * 8)]
+
+
+class TraceRow(C.Structure):
+    _fields_ = [("iteration", C.c_int), ("trial", C.c_int), ("accepted", C.c_int), ("solver_ok", C.c_int),
+                ("lam", C.c_double), ("chi2_current", C.c_double), ("chi2_trial", C.c_double),
+                ("scale", C.c_double), ("rho", C.c_double)]
+
+
+class Prior(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("nv", C.c_int),
+                ("vid", c_int32_p), ("size", c_int32_p), ("idx", c_int32_p),
+                ("x0", c_double_p), ("J0", c_double_p), ("r0", c_double_p),
+                ("Ar", c_double_p), ("br", c_double_p)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+_P = C.c_void_p  # plba_problem*
+
+# name -> (restype, argtypes); every symbol plba.h declares
+SIGNATURES = {
+    "default_options": (None, [C.POINTER(Options)]),
+    "create": (C.c_int, [C.POINTER(Options), C.POINTER(_P)]),
+    "destroy": (None, [_P]),
+    "last_error": (C.c_char_p, [_P]),
+    "backend_name": (C.c_char_p, []),
+    "set_camera": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p, c_double_p]),
+    "set_gravity": (C.c_int, [_P, c_double_p]),
+    "set_keyframes": (C.c_int, [_P, C.c_int, c_int32_p, c_int32_p] + [c_double_p] * 7 + [c_uint8_p, c_uint8_p]),
+    "set_points": (C.c_int, [_P, C.c_int, c_double_p, c_uint8_p]),
+    "set_lines": (C.c_int, [_P, C.c_int, c_double_p, c_uint8_p]),
+    "set_point_obs": (C.c_int, [_P, C.c_int, c_int32_p, c_int32_p, c_double_p, c_double_p]),
+    "set_line_obs": (C.c_int, [_P, C.c_int, c_int32_p, c_int32_p, c_double_p, c_double_p]),
+    "set_imu_edges": (C.c_int, [_P, C.c_int, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]),
+    "set_prior": (C.c_int, [_P, C.c_int, C.c_int, c_int32_p, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]),
+    "set_robust": (C.c_int, [_P, C.c_int, C.c_int, C.c_double]),
+    "set_levels": (C.c_int, [_P, C.c_int, c_uint8_p]),
+    "get_levels": (C.c_int, [_P, C.c_int, c_uint8_p]),
+    "set_shard": (C.c_int, [_P, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]),
+    "set_stream": (C.c_int, [_P, C.c_void_p]),
+    "optimize": (C.c_int, [_P, C.c_int, c_uint8_p, C.POINTER(Stats)]),
+    "gate_outliers": (C.c_int, [_P, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "recompute_errors": (C.c_int, [_P]),
+    "get_edge_chi2": (C.c_int, [_P, C.c_int, c_double_p, c_uint8_p]),
+    "get_trace": (C.c_int, [_P, C.POINTER(TraceRow), C.c_int, C.POINTER(C.c_int)]),
+    "get_keyframes": (C.c_int, [_P] + [c_double_p] * 5),
+    "get_points": (C.c_int, [_P, c_double_p]),
+    "get_lines": (C.c_int, [_P, c_double_p]),
+    "save_state": (C.c_int, [_P]),
+    "restore_state": (C.c_int, [_P]),
+    "marginalize": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(Prior)]),
+    "prior_free": (None, [C.POINTER(Prior)]),
+    "debug_build": (C.c_int, [_P, C.c_double, C.c_int]),
+    "debug_get": (C.c_int, [_P, C.c_char_p, c_double_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+}
+
+
+class PlbaError(RuntimeError):
+    pass
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(c_int32_p)
+
+
+def _up(a):
+    return None if a is None else a.ctypes.data_as(c_uint8_p)
+
+
+def _f64(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _u8(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class Lib:
+    """A loaded implementation of plba.h (``prefix`` selects plba_* or orc_*)."""
+
+    def __init__(self, path, prefix):
+        self.path = str(path)
+        self.prefix = prefix
+        self.cdll = C.CDLL(self.path)
+        self.fn = {}
+        missing = []
+        for name, (res, args) in SIGNATURES.items():
+            sym = prefix + name
+            try:
+                f = getattr(self.cdll, sym)
+            except AttributeError:
+                missing.append(sym)
+                continue
+            f.restype = res
+            f.argtypes = args
+            self.fn[name] = f
+        if missing:
+            raise PlbaError("%s does not export: %s" % (self.path, ", ".join(missing)))
+
+    def backend_name(self):
+        return self.fn["backend_name"]().decode()
+
+    def default_options(self):
+        o = Options()
+        self.fn["default_options"](C.byref(o))
+        return o
+
+
+class Problem:
+    """One BA problem = one g2o::SparseOptimizer of the reference call site
+    (src/mapHandler.cpp:5787-5797), behind the C ABI."""
+
+    def __init__(self, lib, **opts):
+        self.lib = lib
+        o = lib.default_options()
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise PlbaError("unknown option %r" % k)
+            setattr(o, k, v)
+        self._h = _P()
+        rc = lib.fn["create"](C.byref(o), C.byref(self._h))
+        if rc != 0:
+            msg = lib.fn["last_error"](None)
+            raise PlbaError("create failed: %s (%s)" % (STATUS.get(rc, rc), msg.decode() if msg else ""))
+        self._cb = None
+        self.dims = {}
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.fn["destroy"](self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, allow_positive=False):
+        if rc < 0 or (rc > 0 and not allow_positive):
+            msg = self.lib.fn["last_error"](self._h)
+            raise PlbaError("%s: %s" % (STATUS.get(rc, rc), msg.decode() if msg else ""))
+        return rc
+
+    def call(self, name, *args, allow_positive=False):
+        return self._ck(self.lib.fn[name](self._h, *args), allow_positive)
+
+    # -- upload ------------------------------------------------------------------------------
+    def set_camera(self, fx, fy, cx, cy, Rbc, Pbc):
+        Rbc = _f64(Rbc, (9,)); Pbc = _f64(Pbc, (3,))
+        self.call("set_camera", fx, fy, cx, cy, _dp(Rbc), _dp(Pbc))
+
+    def set_gravity(self, gw):
+        gw = _f64(gw, (3,))
+        self.call("set_gravity", _dp(gw))
+
+    def set_keyframes(self, vid_pvr, vid_bias, P, V, q, bg=None, ba=None, dbg=None, dba=None,
+                      fixed_pvr=None, fixed_bias=None):
+        K = len(vid_pvr)
+        arrs = [_f64(a) for a in (P, V, q, bg, ba, dbg, dba)]
+        vp, vb = _i32(vid_pvr), _i32(vid_bias)
+        fp, fb = _u8(fixed_pvr), _u8(fixed_bias)
+        self.call("set_keyframes", K, _ip(vp), _ip(vb), *[_dp(a) for a in arrs], _up(fp), _up(fb))
+        self.dims["K"] = K
+
+    def set_points(self, xyz, fixed=None):
+        xyz = _f64(xyz, (-1, 3)); f = _u8(fixed)
+        self.call("set_points", len(xyz), _dp(xyz), _up(f))
+        self.dims["Np"] = len(xyz)
+
+    def set_lines(self, sPeP, fixed=None):
+        l = _f64(sPeP, (-1, 6)); f = _u8(fixed)
+        self.call("set_lines", len(l), _dp(l), _up(f))
+        self.dims["Nl"] = len(l)
+
+    def set_point_obs(self, pt, kf, uv, inv_sigma2=None):
+        pt, kf, uv, w = _i32(pt), _i32(kf), _f64(uv, (-1, 2)), _f64(inv_sigma2)
+        self.call("set_point_obs", len(pt), _ip(pt), _ip(kf), _dp(uv), _dp(w))
+        self.dims["Ep"] = len(pt)
+
+    def set_line_obs(self, ln, kf, l3, inv_sigma2=None):
+        ln, kf, l3, w = _i32(ln), _i32(kf), _f64(l3, (-1, 3)), _f64(inv_sigma2)
+        self.call("set_line_obs", len(ln), _ip(ln), _ip(kf), _dp(l3), _dp(w))
+        self.dims["El"] = len(ln)
+
+    def set_imu_edges(self, kf_i, kf_j, preint142, info_pvr, info_bias):
+        ki, kj = _i32(kf_i), _i32(kf_j)
+        pre, ip, ib = _f64(preint142, (-1, 142)), _f64(info_pvr, (-1, 81)), _f64(info_bias, (-1, 36))
+        self.call("set_imu_edges", len(ki), _ip(ki), _ip(kj), _dp(pre), _dp(ip), _dp(ib))
+        self.dims["M"] = len(ki)
+
+    def set_prior(self, prior):
+        """prior: dict(n, vid, size, idx, x0, J0 (n x n, J0[r, c]), r0) or None to clear."""
+        if prior is None or len(prior["vid"]) == 0:
+            self.call("set_prior", 0, 0, None, None, None, None, None, None)
+            self.dims["n_prior"] = 0
+            return
+        n = int(prior["n"])
+        vid, size, idx = _i32(prior["vid"]), _i32(prior["size"]), _i32(prior["idx"])
+        x0, r0 = _f64(prior["x0"]), _f64(prior["r0"])
+        J0 = np.asfortranarray(np.asarray(prior["J0"], dtype=np.float64).reshape(n, n))  # column-major
+        self.call("set_prior", n, len(vid), _ip(vid), _ip(size), _ip(idx), _dp(x0),
+                  J0.ctypes.data_as(c_double_p), _dp(r0))
+        self.dims["n_prior"] = n
+
+    def set_robust(self, kind, enabled, delta=0.0):
+        self.call("set_robust", kind, int(enabled), float(delta))
+
+    def set_levels(self, kind, level):
+        lv = _u8(level)
+        self.call("set_levels", kind, _up(lv))
+
+    def get_levels(self, kind):
+        n = self.dims["Ep"] if kind == EDGE_POINT else self.dims["El"]
+        lv = np.zeros(n, np.uint8)
+        self.call("get_levels", kind, _up(lv))
+        return lv
+
+    def set_shard(self, rank, world, allreduce):
+        """allreduce(dev_ptr:int, n:int, op:int, stream:int) -> None, raising on failure."""
+        def _tramp(user, buf, n, op, stream):
+            try:
+                allreduce(buf, n, op, stream)
+                return 0
+            except Exception as e:  # surfaced as PLBA_ERR_EXCHANGE
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = ALLREDUCE_FN(_tramp)
+        self.call("set_shard", rank, world, self._cb, None)
+
+    def set_stream(self, stream_handle):
+        self.call("set_stream", C.c_void_p(stream_handle))
+
+    # -- solve -------------------------------------------------------------------------------
+    def optimize(self, iters, abort=None):
+        st = Stats()
+        ab = _up(abort) if abort is not None else None
+        self.call("optimize", int(iters), ab, C.byref(st))
+        return st
+
+    def gate_outliers(self, thresh=5.991):
+        a, b = C.c_int(0), C.c_int(0)
+        self.call("gate_outliers", float(thresh), C.byref(a), C.byref(b), allow_positive=True)
+        return a.value, b.value
+
+    def recompute_errors(self):
+        self.call("recompute_errors")
+
+    def edge_chi2(self, kind):
+        n = {EDGE_POINT: self.dims.get("Ep", 0), EDGE_LINE: self.dims.get("El", 0),
+             EDGE_IMU_PVR: self.dims.get("M", 0), EDGE_IMU_BIAS: self.dims.get("M", 0), EDGE_PRIOR: 1}[kind]
+        chi = np.zeros(n); dp = np.zeros(n, np.uint8)
+        self.call("get_edge_chi2", kind, _dp(chi), _up(dp))
+        return chi, dp
+
+    def trace(self):
+        n = C.c_int(0)
+        self.call("get_trace", None, 0, C.byref(n))
+        rows = (TraceRow * max(n.value, 1))()
+        self.call("get_trace", rows, n.value, C.byref(n))
+        return [dict(iteration=r.iteration, trial=r.trial, accepted=r.accepted, solver_ok=r.solver_ok,
+                     lam=r.lam, chi2_current=r.chi2_current, chi2_trial=r.chi2_trial, scale=r.scale, rho=r.rho)
+                for r in rows[:n.value]]
+
+    # -- results -----------------------------------------------------------------------------
+    def get_keyframes(self):
+        K = self.dims["K"]
+        P, V, q, dbg, dba = np.zeros((K, 3)), np.zeros((K, 3)), np.zeros((K, 4)), np.zeros((K, 3)), np.zeros((K, 3))
+        self.call("get_keyframes", _dp(P), _dp(V), _dp(q), _dp(dbg), _dp(dba))
+        return dict(P=P, V=V, q=q, dbg=dbg, dba=dba)
+
+    def get_points(self):
+        a = np.zeros((self.dims.get("Np", 0), 3))
+        if len(a):
+            self.call("get_points", _dp(a))
+        return a
+
+    def get_lines(self):
+        a = np.zeros((self.dims.get("Nl", 0), 6))
+        if len(a):
+            self.call("get_lines", _dp(a))
+        return a
+
+    def save_state(self):
+        self.call("save_state")
+
+    def restore_state(self):
+        self.call("restore_state")
+
+    def marginalize(self, first_kf=0, max_edges=50):
+        pr = Prior()
+        self.call("marginalize", int(first_kf), int(max_edges), C.byref(pr))
+        n, nv = pr.n, pr.nv
+
+        def arr(p, cnt, dt):
+            return np.ctypeslib.as_array(p, shape=(cnt,)).astype(dt).copy() if cnt else np.zeros(0, dt)
+        size = arr(pr.size, nv, np.int32)
+        nx = int(sum(10 if s == 9 else 6 for s in size))
+        out = dict(n=n, m=pr.m, vid=arr(pr.vid, nv, np.int32), size=size, idx=arr(pr.idx, nv, np.int32),
+                   x0=arr(pr.x0, nx, np.float64),
+                   J0=arr(pr.J0, n * n, np.float64).reshape(n, n).T.copy(),  # colmajor -> J0[r, c]
+                   r0=arr(pr.r0, n, np.float64),
+                   Ar=arr(pr.Ar, n * n, np.float64).reshape(n, n), br=arr(pr.br, n, np.float64))
+        self.lib.fn["prior_free"](C.byref(pr))
+        return out
+
+    # -- diagnostics -------------------------------------------------------------------------
+    def debug_build(self, lam, do_solve=False):
+        self.call("debug_build", float(lam), int(do_solve))
+
+    def debug_get(self, what):
+        n = C.c_size_t(0)
+        self.call("debug_get", what.encode(), None, 0, C.byref(n))
+        a = np.zeros(max(n.value, 1))
+        self.call("debug_get", what.encode(), _dp(a), n.value, C.byref(n))
+        return a[:n.value]
+
+    # -- convenience -------------------------------------------------------------------------
+    def upload_window(self, w):
+        """Upload a synthetic window (window.make_window) following the reference's graph
+        construction order (mapHandler.cpp:5799-6034)."""
+        c = w["cam"]
+        self.set_camera(c["fx"], c["fy"], c["cx"], c["cy"], c["Rbc"], c["Pbc"])
+        self.set_gravity(w["gw"])
+        k = w["kf"]
+        self.set_keyframes(k["vid_pvr"], k["vid_bias"], k["P"], k["V"], k["q"], k["bg"], k["ba"], k["dbg"], k["dba"],
+                           k["fixed_pvr"], k["fixed_bias"])
+        self.set_points(w["points"])
+        self.set_lines(w["lines"])
+        self.set_point_obs(w["po_pt"], w["po_kf"], w["po_uv"], w["po_w"])
+        self.set_line_obs(w["lo_ln"], w["lo_kf"], w["lo_l"], w["lo_w"])
+        if w.get("imu") is not None:
+            im = w["imu"]
+            self.set_imu_edges(im["kf_i"], im["kf_j"], im["preint"], im["info_pvr"], im["info_bias"])
+        self.set_prior(w.get("prior"))
+        for kind, d in w["huber"].items():
+            self.set_robust(kind, True, d)

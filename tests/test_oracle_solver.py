@@ -1,0 +1,207 @@
+"""CPU tests of the oracle's g2o restatement: block assembly + Schur complement +
+dense Cholesky + back-substitution against a flat numpy normal-equation solve, LM control flow,
+two-stage gating protocol, save/restore, input validation."""
+import numpy as np
+import pytest
+
+
+def _flat_system(orc, pkg, w, lam, robust=True):
+    """Independent assembly: full J (all active edges x all free parameters) from the per-edge
+    evaluators, H = J^T W J, b = -J^T W e, solve (H + lam I) x = b densely."""
+    abi = pkg.abi
+    K = len(w["kf"]["P"])
+    cam = orc.cam_vec(w["cam"])
+    kf = w["kf"]
+    navs = [orc.nav_vec(kf["P"][k], kf["V"][k], kf["q"][k], kf["bg"][k], kf["ba"][k], kf["dbg"][k], kf["dba"][k]) for k in range(K)]
+    has_bias = kf["vid_bias"][0] >= 0
+    off_pvr, off_bias, P = {}, {}, 0
+    for k in range(K):
+        if not kf["fixed_pvr"][k]:
+            off_pvr[k] = P; P += 9
+        if has_bias and not kf["fixed_bias"][k]:
+            off_bias[k] = P; P += 6
+    Np, Nl = len(w["points"]), len(w["lines"])
+    N = P + 3 * Np + 6 * Nl
+    H = np.zeros((N, N)); b = np.zeros(N)
+    hub = w["huber"]
+
+    def add(blocks, e, Om, kind):
+        chi = e @ Om @ e
+        wgt = 1.0
+        if robust and kind in hub:
+            wgt = orc.huber(chi, hub[kind])[1]
+        Om = Om * wgt
+        for (oa, Ja) in blocks:
+            b[oa:oa + Ja.shape[1]] += -Ja.T @ Om @ e
+            for (ob, Jb) in blocks:
+                H[oa:oa + Ja.shape[1], ob:ob + Jb.shape[1]] += Ja.T @ Om @ Jb
+    if w["imu"] is not None:
+        im = w["imu"]
+        for m in range(len(im["kf_i"])):
+            i, j = im["kf_i"][m], im["kf_j"][m]
+            e, J0, J1, J2 = orc.eval_pvr_edge(w["gw"], navs[i], navs[j], navs[i], im["preint"][m])
+            blocks = [(o, J) for o, J in ((off_pvr.get(i), J0), (off_pvr.get(j), J1), (off_bias.get(i), J2)) if o is not None]
+            add(blocks, e, im["info_pvr"][m].reshape(9, 9), abi.EDGE_IMU_PVR)
+            eb = np.concatenate([(navs[j][10:13] + navs[j][16:19]) - (navs[i][10:13] + navs[i][16:19]),
+                                 (navs[j][13:16] + navs[j][19:22]) - (navs[i][13:16] + navs[i][19:22])])
+            blocks = [(o, J) for o, J in ((off_bias.get(i), -np.eye(6)), (off_bias.get(j), np.eye(6))) if o is not None]
+            add(blocks, eb, im["info_bias"][m].reshape(6, 6), abi.EDGE_IMU_BIAS)
+    for e_i in range(len(w["po_pt"])):
+        l, k = w["po_pt"][e_i], w["po_kf"][e_i]
+        e, Ji, Jj, _ = orc.eval_point_edge(cam, navs[k], w["points"][l], w["po_uv"][e_i])
+        blocks = [(P + 3 * l, Ji)] + ([(off_pvr[k], Jj)] if k in off_pvr else [])
+        add(blocks, e, np.eye(2) * w["po_w"][e_i], abi.EDGE_POINT)
+    for e_i in range(len(w["lo_ln"])):
+        l, k = w["lo_ln"][e_i], w["lo_kf"][e_i]
+        e, Ji, Jj, _ = orc.eval_line_edge(cam, navs[k], w["lines"][l], w["lo_l"][e_i])
+        blocks = [(P + 3 * Np + 6 * l, Ji)] + ([(off_pvr[k], Jj)] if k in off_pvr else [])
+        add(blocks, e, np.eye(3) * w["lo_w"][e_i], abi.EDGE_LINE)
+    x = np.linalg.solve(H + lam * np.eye(N), b)
+    return H, b, x, P
+
+
+@pytest.mark.parametrize("imu", [True, False])
+def test_schur_solve_equals_flat_normal_equations(orc, pkg, imu):
+    w = pkg.window.make_window(5, 40, 10, imu=imu, seed=11)
+    p = orc.new_problem()
+    p.upload_window(w)
+    lam = 37.5
+    p.debug_build(lam, True)
+    H, b, x, P = _flat_system(orc, pkg, w, lam)
+    assert int(p.debug_get("pose_dim")[0]) == P
+    xo = p.debug_get("x")
+    assert xo.shape == x.shape
+    assert np.allclose(xo, x, rtol=1e-7, atol=1e-9 * np.abs(x).max())
+    # Hschur = Hpp + lam I - Hpl (Hll + lam I)^-1 Hlp ; bschur likewise
+    Hpp, Hpl, Hll = H[:P, :P], H[:P, P:], H[P:, P:]
+    Hs = Hpp + lam * np.eye(P) - Hpl @ np.linalg.solve(Hll + lam * np.eye(len(Hll)), Hpl.T)
+    bs = b[:P] - Hpl @ np.linalg.solve(Hll + lam * np.eye(len(Hll)), b[P:])
+    Ho = p.debug_get("Hschur").reshape(P, P)
+    assert np.allclose(Ho, Hs, rtol=1e-9, atol=1e-9 * np.abs(Hs).max())
+    assert np.allclose(p.debug_get("bschur"), bs, rtol=1e-9, atol=1e-9 * np.abs(bs).max())
+    assert np.allclose(p.debug_get("bp"), b[:P], rtol=1e-10, atol=1e-10 * np.abs(b).max())
+    assert p.debug_get("maxdiag")[0] == pytest.approx(np.abs(np.diag(H)).max(), rel=1e-12)
+    p.close()
+
+
+def test_lm_control_flow_follows_g2o(orc, pkg):
+    w = pkg.window.make_window(6, 80, 20, imu=True, seed=12)
+    p = orc.new_problem()
+    p.upload_window(w)
+    st = p.optimize(5)
+    tr = p.trace()
+    assert st.iterations == 5 and st.trials == len(tr)
+    # lambda_init = tau * max diag (computeLambdaInit), nu = 2
+    p2 = orc.new_problem(); p2.upload_window(w); p2.debug_build(0.0, False)
+    assert tr[0]["lam"] == pytest.approx(1e-5 * p2.debug_get("maxdiag")[0], rel=1e-12)
+    assert tr[0]["chi2_current"] == pytest.approx(p2.debug_get("chi2")[0], rel=1e-12)
+    lam, ni = tr[0]["lam"], 2.0
+    for r in tr:
+        assert r["lam"] == pytest.approx(lam, rel=1e-12)
+        assert r["rho"] == pytest.approx((r["chi2_current"] - r["chi2_trial"]) / r["scale"], rel=1e-12)
+        if r["accepted"]:
+            assert r["rho"] > 0 and r["chi2_trial"] < r["chi2_current"]
+            alpha = min(1 - (2 * r["rho"] - 1) ** 3, 2 / 3)
+            lam *= max(1 / 3, alpha); ni = 2.0
+        else:
+            lam *= ni; ni *= 2
+    assert st.lambda_final == pytest.approx(lam, rel=1e-12)
+    assert st.chi2_final == pytest.approx([r for r in tr if r["accepted"]][-1]["chi2_trial"])
+    p.close(); p2.close()
+
+
+def test_rejected_trial_restores_state_and_raises_lambda(orc, pkg):
+    """A hopeless user lambda (tiny) on a strongly perturbed window forces rejected trials."""
+    w = pkg.window.make_window(5, 60, 10, imu=False, seed=13)
+    w["points"] = w["points"] + np.random.default_rng(0).normal(size=w["points"].shape) * 1.5
+    p = orc.new_problem(user_lambda_init=1e-9)
+    p.upload_window(w)
+    before = p.get_keyframes()
+    st = p.optimize(3)
+    tr = p.trace()
+    if any(not r["accepted"] for r in tr):
+        i = [r["accepted"] for r in tr].index(0)
+        assert tr[i + 1]["lam"] == pytest.approx(tr[i]["lam"] * 2) if i + 1 < len(tr) and tr[i + 1]["iteration"] == tr[i]["iteration"] else True
+    assert st.chi2_final <= st.chi2_initial
+    # first keyframe is fixed: never moves
+    after = p.get_keyframes()
+    assert np.array_equal(before["P"][0], after["P"][0]) and np.array_equal(before["q"][0], after["q"][0])
+    p.close()
+
+
+def test_two_stage_protocol_and_gating(orc, pkg):
+    w = pkg.window.make_window(8, 150, 30, imu=True, seed=14)
+    p = orc.new_problem()
+    p.upload_window(w)
+    out = pkg.protocol.local_ba(p)
+    assert out["stage1"].iterations == 5 and out["stage2"].iterations == 10
+    lv_p, lv_l = p.get_levels(pkg.abi.EDGE_POINT), p.get_levels(pkg.abi.EDGE_LINE)
+    assert (lv_p.sum(), lv_l.sum()) == out["gated"]
+    # every synthetic gross outlier (>= 20 px) must have been gated
+    assert lv_p[w["truth"]["point_outlier"]].all()
+    # stage 2 runs without Huber on point/line edges: its chi2 is the plain sum over level-0 edges + IMU terms
+    chi_p, _ = p.edge_chi2(pkg.abi.EDGE_POINT)
+    chi_l, _ = p.edge_chi2(pkg.abi.EDGE_LINE)
+    c_pvr, _ = p.edge_chi2(pkg.abi.EDGE_IMU_PVR)
+    c_b, _ = p.edge_chi2(pkg.abi.EDGE_IMU_BIAS)
+    hub = lambda c, d: np.array([orc.huber(v, d)[0] for v in c]).sum()
+    total = chi_p[lv_p == 0].sum() + chi_l[lv_l == 0].sum() + hub(c_pvr, w["huber"][2]) + hub(c_b, w["huber"][3])
+    last = p.trace()[-1]
+    assert total == pytest.approx(last["chi2_trial"], rel=1e-9)   # errors cached from the last evaluation pass (App. A.7)
+    # result is closer to the truth than the initial estimate
+    k = p.get_keyframes()
+    assert np.abs(k["P"] - w["truth"]["P"]).max() < np.abs(w["kf"]["P"] - w["truth"]["P"]).max()
+    p.close()
+
+
+def test_abort_flag_stops_between_iterations(orc, pkg):
+    w = pkg.window.make_window(5, 40, 8, imu=True, seed=15)
+    p = orc.new_problem(); p.upload_window(w)
+    flag = np.ones(1, np.uint8)
+    st = p.optimize(5, flag)
+    assert st.iterations == 0 and st.stop_reason == 2
+    p.close()
+
+
+def test_save_restore_and_determinism(orc, pkg):
+    w = pkg.window.make_window(5, 40, 8, imu=True, seed=16)
+    p = orc.new_problem(); p.upload_window(w)
+    p.save_state()
+    a = p.optimize(4); ka = p.get_keyframes()
+    p.restore_state()
+    b = p.optimize(4); kb = p.get_keyframes()
+    assert a.chi2_final == b.chi2_final and np.array_equal(ka["P"], kb["P"]) and np.array_equal(ka["q"], kb["q"])
+    p.close()
+
+
+def test_input_validation(orc, pkg):
+    w = pkg.window.make_window(4, 20, 5, imu=True, seed=17)
+    p = orc.new_problem()
+    with pytest.raises(pkg.abi.PlbaError):
+        p.optimize(1)                                   # nothing uploaded
+    p.upload_window(w)
+    bad = w["po_pt"].copy(); bad[0], bad[-1] = bad[-1], bad[0]
+    with pytest.raises(pkg.abi.PlbaError):
+        p.set_point_obs(bad, w["po_kf"], w["po_uv"], w["po_w"])   # not landmark-major
+    kf = w["po_kf"].copy(); kf[0] = 99
+    with pytest.raises(pkg.abi.PlbaError):
+        p.set_point_obs(w["po_pt"], kf, w["po_uv"], w["po_w"])
+    pts = w["points"].copy(); pts[0, 0] = np.nan
+    with pytest.raises(pkg.abi.PlbaError):
+        p.set_points(pts)
+    p.close()
+
+
+def test_empty_and_ragged_inputs(orc, pkg):
+    """no lines at all; a landmark whose every edge is gated drops out of stage 2 (App. A.1)."""
+    w = pkg.window.make_window(5, 30, 0 + 1, imu=True, seed=18)
+    w["lines"] = np.zeros((0, 6)); w["lo_ln"] = np.zeros(0, np.int32); w["lo_kf"] = np.zeros(0, np.int32)
+    w["lo_l"] = np.zeros((0, 3)); w["lo_w"] = np.zeros(0)
+    p = orc.new_problem(); p.upload_window(w)
+    lv = np.zeros(len(w["po_pt"]), np.uint8); lv[w["po_pt"] == 3] = 1
+    p.set_levels(pkg.abi.EDGE_POINT, lv)
+    before = p.get_points()[3].copy()
+    st = p.optimize(3)
+    assert st.iterations == 3 and np.isfinite(st.chi2_final)
+    assert np.array_equal(p.get_points()[3], before)     # inactive landmark untouched
+    p.close()
