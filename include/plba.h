@@ -175,6 +175,9 @@ void plba_prior_free(plba_prior* pr);
  * "maxdiag" (1). */
 int plba_debug_build(plba_problem* p, double lambda, int do_solve);
 int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, size_t* n);
+/* Stand-alone run of the dense reduced-camera solver (K7): solves A x = b for a symmetric positive
+ * definite n x n row-major A with the same kernels optimize() uses; *ok = 0 on a non-positive pivot. */
+int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double* b, double* x, int* ok);
 
 #ifdef __cplusplus
 }

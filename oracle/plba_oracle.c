@@ -1540,6 +1540,16 @@ int orc_debug_get(plba_problem* p, const char* what, double* out, size_t cap, si
     return PLBA_OK;
 }
 
+int orc_debug_dense_solve(plba_problem* p, int n, const double* A, const double* b, double* x, int* ok) {
+    if (!p || n <= 0 || !A || !b || !x) return PLBA_ERR_INVALID;
+    double* L = (double*)xdup(A, (size_t)n * n * 8);
+    int good = chol_factor(L, n);
+    if (good) chol_solve(L, n, b, x);
+    free(L);
+    if (ok) *ok = good;
+    return PLBA_OK;
+}
+
 /* ============================================================================================
  * 7. marginalization (IMU/marginalization.cpp:38-147, 291-384; call site mapHandler.cpp:6075-6199)
  * ========================================================================================== */

@@ -84,6 +84,7 @@ SIGNATURES = {
     "prior_free": (None, [C.POINTER(Prior)]),
     "debug_build": (C.c_int, [_P, C.c_double, C.c_int]),
     "debug_get": (C.c_int, [_P, C.c_char_p, c_double_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "debug_dense_solve": (C.c_int, [_P, C.c_int, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
 }
 
 
@@ -361,6 +362,13 @@ class Problem:
         a = np.zeros(max(n.value, 1))
         self.call("debug_get", what.encode(), _dp(a), n.value, C.byref(n))
         return a[:n.value]
+
+    def debug_dense_solve(self, A, b):
+        A = _f64(A); b = _f64(b)
+        n = len(b)
+        x = np.zeros(n); ok = C.c_int(0)
+        self.call("debug_dense_solve", n, _dp(A), _dp(b), _dp(x), C.byref(ok))
+        return x, bool(ok.value)
 
     # -- convenience -------------------------------------------------------------------------
     def upload_window(self, w):

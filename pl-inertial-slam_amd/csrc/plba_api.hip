@@ -1,0 +1,845 @@
+// plba_api.hip — the C ABI of include/plba.h on top of the HIP kernels (gfx950).
+//
+// Host side of the hot path: flattens the uploaded graph into device SoA buffers, builds the static
+// structure (landmark CSR, keyframe-pair lists for the Schur complement, pose-side index map), and
+// drives g2o's Levenberg-Marquardt control flow with every arithmetic step on
+// the device; only the control block (a few scalars) crosses PCIe once per damped trial.
+// No CPU fallback exists: every entry point that computes needs a HIP device.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+#include "plba_problem.h"
+
+using namespace plba;
+
+namespace {
+char g_create_err[256] = "";
+}  // namespace
+
+#define FAIL(p, code, ...)                                  \
+    do {                                                    \
+        snprintf((p)->err, sizeof((p)->err), __VA_ARGS__);  \
+        return (code);                                      \
+    } while (0)
+#define HIPCK(p, call)                                                                                        \
+    do {                                                                                                      \
+        hipError_t e__ = (call);                                                                              \
+        if (e__ != hipSuccess) FAIL(p, PLBA_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+static const int TRACE_CAP = 4096;
+
+static bool all_finite(const double* a, size_t n) {
+    for (size_t i = 0; i < n; ++i) if (!std::isfinite(a[i])) return false;
+    return true;
+}
+
+extern "C" {
+
+void plba_default_options(plba_options* o) {
+    memset(o, 0, sizeof(*o));
+    o->tau = 1e-5;
+    o->good_step_lower = 1. / 3.;
+    o->good_step_upper = 2. / 3.;
+    o->max_trials = 10;
+    o->user_lambda_init = 0.0;
+    o->marg_eps = 1e-8;
+    o->device = -1;
+    o->use_mfma = 1;
+}
+const char* plba_backend_name(void) { return "hip-gfx950"; }
+const char* plba_last_error(const plba_problem* p) { return p ? p->err : g_create_err; }
+
+int plba_create(const plba_options* opt, plba_problem** out) {
+    if (!out) { snprintf(g_create_err, sizeof g_create_err, "out is NULL"); return PLBA_ERR_INVALID; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        snprintf(g_create_err, sizeof g_create_err, "no HIP device available (%s); the plba product path has no CPU fallback",
+                 e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return PLBA_ERR_DEVICE;
+    }
+    plba_problem* p = new plba_problem();
+    p->err[0] = 0;
+    if (opt) p->opt = *opt; else plba_default_options(&p->opt);
+    memset(&p->rob, 0, sizeof p->rob);
+    if (p->opt.device >= 0) {
+        if ((e = hipSetDevice(p->opt.device)) != hipSuccess) {
+            snprintf(g_create_err, sizeof g_create_err, "hipSetDevice(%d): %s", p->opt.device, hipGetErrorString(e));
+            delete p;
+            return PLBA_ERR_DEVICE;
+        }
+    }
+    (void)hipGetDevice(&p->device);
+    if ((e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&p->h_ctrl, sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess) {
+        snprintf(g_create_err, sizeof g_create_err, "device initialisation failed: %s", hipGetErrorString(e));
+        delete p;
+        return PLBA_ERR_DEVICE;
+    }
+    p->own_stream = true;
+    *out = p;
+    return PLBA_OK;
+}
+
+void plba_destroy(plba_problem* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+    if (p->h_ctrl) (void)hipHostFree(p->h_ctrl);
+    delete p;
+}
+
+int plba_set_stream(plba_problem* p, void* s) {
+    if (!p) return PLBA_ERR_INVALID;
+    if (p->own_stream && p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+    p->stream = (hipStream_t)s;
+    p->own_stream = false;
+    return PLBA_OK;
+}
+
+int plba_set_camera(plba_problem* p, double fx, double fy, double cx, double cy, const double* Rbc, const double* Pbc) {
+    if (!p || !Rbc || !Pbc) return PLBA_ERR_INVALID;
+    p->fx = fx; p->fy = fy; p->cx = cx; p->cy = cy;
+    memcpy(p->Rbc, Rbc, 72); memcpy(p->Pbc, Pbc, 24);
+    p->have_cam = true; p->dirty = true;
+    return PLBA_OK;
+}
+int plba_set_gravity(plba_problem* p, const double* gw) {
+    if (!p || !gw) return PLBA_ERR_INVALID;
+    memcpy(p->gw, gw, 24);
+    p->dirty = true;
+    return PLBA_OK;
+}
+int plba_set_keyframes(plba_problem* p, int K, const int32_t* vid_pvr, const int32_t* vid_bias, const double* P3, const double* V3,
+                       const double* q4, const double* bg3, const double* ba3, const double* dbg3, const double* dba3,
+                       const uint8_t* fixed_pvr, const uint8_t* fixed_bias) {
+    if (!p || K <= 0 || !vid_pvr || !P3 || !V3 || !q4) return PLBA_ERR_INVALID;
+    for (int k = 1; k < K; ++k) if (vid_pvr[k] <= vid_pvr[k - 1]) FAIL(p, PLBA_ERR_INVALID, "keyframe vertex ids must be ascending");
+    if (!all_finite(P3, 3 * (size_t)K) || !all_finite(V3, 3 * (size_t)K) || !all_finite(q4, 4 * (size_t)K)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite keyframe state");
+    p->K = K;
+    p->vid_pvr.assign(vid_pvr, vid_pvr + K);
+    p->vid_bias.assign(K, -1);
+    p->kf0.assign((size_t)K * KF_STRIDE, 0.0);
+    p->fix_pvr.assign(K, 0); p->fix_bias.assign(K, 0);
+    for (int k = 0; k < K; ++k) {
+        double* s = &p->kf0[(size_t)k * KF_STRIDE];
+        if (vid_bias) p->vid_bias[k] = vid_bias[k];
+        memcpy(s, P3 + 3 * k, 24); memcpy(s + 3, V3 + 3 * k, 24); memcpy(s + 6, q4 + 4 * k, 32);
+        if (bg3) memcpy(s + 10, bg3 + 3 * k, 24);
+        if (ba3) memcpy(s + 13, ba3 + 3 * k, 24);
+        if (dbg3) memcpy(s + 16, dbg3 + 3 * k, 24);
+        if (dba3) memcpy(s + 19, dba3 + 3 * k, 24);
+        if (fixed_pvr) p->fix_pvr[k] = fixed_pvr[k];
+        if (fixed_bias) p->fix_bias[k] = fixed_bias[k];
+    }
+    p->dirty = true;
+    return PLBA_OK;
+}
+int plba_set_points(plba_problem* p, int Np, const double* xyz, const uint8_t* fixed) {
+    if (!p || Np < 0 || (Np && !xyz)) return PLBA_ERR_INVALID;
+    if (!all_finite(xyz, 3 * (size_t)Np)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite point");
+    p->Np = Np;
+    p->pts.assign(xyz, xyz + 3 * (size_t)Np);
+    p->pt_fixed.assign(Np, 0);
+    if (fixed) p->pt_fixed.assign(fixed, fixed + Np);
+    p->dirty = true;
+    return PLBA_OK;
+}
+int plba_set_lines(plba_problem* p, int Nl, const double* l, const uint8_t* fixed) {
+    if (!p || Nl < 0 || (Nl && !l)) return PLBA_ERR_INVALID;
+    if (!all_finite(l, 6 * (size_t)Nl)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite line");
+    p->Nl = Nl;
+    p->lns.assign(l, l + 6 * (size_t)Nl);
+    p->ln_fixed.assign(Nl, 0);
+    if (fixed) p->ln_fixed.assign(fixed, fixed + Nl);
+    p->dirty = true;
+    return PLBA_OK;
+}
+static int check_obs(plba_problem* p, int E, const int32_t* lm, const int32_t* kf, int Nlm) {
+    for (int e = 0; e < E; ++e) {
+        if (lm[e] < 0 || lm[e] >= Nlm) FAIL(p, PLBA_ERR_INVALID, "observation %d: landmark index out of range", e);
+        if (kf[e] < 0 || kf[e] >= p->K) FAIL(p, PLBA_ERR_INVALID, "observation %d: keyframe index out of range", e);
+        if (e && lm[e] < lm[e - 1]) FAIL(p, PLBA_ERR_INVALID, "observations must be landmark-major (sorted by landmark)");
+    }
+    for (int e = 0; e < E; ++e)
+        for (int f = e + 1; f < E && lm[f] == lm[e]; ++f)
+            if (kf[f] == kf[e]) FAIL(p, PLBA_ERR_INVALID, "landmark %d observed twice by keyframe %d", lm[e], kf[e]);
+    return PLBA_OK;
+}
+int plba_set_point_obs(plba_problem* p, int Ep, const int32_t* pt, const int32_t* kf, const double* uv, const double* w) {
+    if (!p || Ep < 0 || (Ep && (!pt || !kf || !uv))) return PLBA_ERR_INVALID;
+    if (!p->K) FAIL(p, PLBA_ERR_STATE, "set_keyframes first");
+    int rc = check_obs(p, Ep, pt, kf, p->Np);
+    if (rc) return rc;
+    if (!all_finite(uv, 2 * (size_t)Ep)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite observation");
+    p->Ep = Ep;
+    p->po_pt.assign(pt, pt + Ep); p->po_kf.assign(kf, kf + Ep);
+    p->po_uv.assign(uv, uv + 2 * (size_t)Ep);
+    p->po_w.assign(Ep, 1.0);
+    if (w) for (int e = 0; e < Ep; ++e) p->po_w[e] = (double)(float)w[e];   // const float& invSigma2 (mapHandler.cpp:5340)
+    p->dirty = true;
+    return PLBA_OK;
+}
+int plba_set_line_obs(plba_problem* p, int El, const int32_t* ln, const int32_t* kf, const double* l3, const double* w) {
+    if (!p || El < 0 || (El && (!ln || !kf || !l3))) return PLBA_ERR_INVALID;
+    if (!p->K) FAIL(p, PLBA_ERR_STATE, "set_keyframes first");
+    int rc = check_obs(p, El, ln, kf, p->Nl);
+    if (rc) return rc;
+    if (!all_finite(l3, 3 * (size_t)El)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite observation");
+    p->El = El;
+    p->lo_ln.assign(ln, ln + El); p->lo_kf.assign(kf, kf + El);
+    p->lo_l.assign(l3, l3 + 3 * (size_t)El);
+    p->lo_w.assign(El, 1.0);
+    if (w) for (int e = 0; e < El; ++e) p->lo_w[e] = (double)(float)w[e];
+    p->dirty = true;
+    return PLBA_OK;
+}
+int plba_set_imu_edges(plba_problem* p, int M, const int32_t* ki, const int32_t* kj, const double* pre, const double* ipvr, const double* ibias) {
+    if (!p || M < 0 || (M && (!ki || !kj || !pre || !ipvr || !ibias))) return PLBA_ERR_INVALID;
+    for (int m = 0; m < M; ++m) {
+        if (ki[m] < 0 || ki[m] >= p->K || kj[m] < 0 || kj[m] >= p->K) FAIL(p, PLBA_ERR_INVALID, "imu edge %d: keyframe index", m);
+        if (p->vid_bias[ki[m]] < 0 || p->vid_bias[kj[m]] < 0) FAIL(p, PLBA_ERR_INVALID, "imu edge %d: keyframe without bias vertex", m);
+    }
+    if (!all_finite(pre, 142 * (size_t)M) || !all_finite(ipvr, 81 * (size_t)M)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite IMU edge");
+    p->M = M;
+    p->imu_i.assign(ki, ki + M); p->imu_j.assign(kj, kj + M);
+    p->imu_pre.assign(pre, pre + 142 * (size_t)M);
+    p->imu_ipvr.assign(ipvr, ipvr + 81 * (size_t)M);
+    p->imu_ibias.assign(ibias, ibias + 36 * (size_t)M);
+    p->dirty = true;
+    return PLBA_OK;
+}
+int plba_set_prior(plba_problem* p, int n, int nv, const int32_t* vid, const int32_t* size, const int32_t* idx, const double* x0,
+                   const double* J0, const double* r0) {
+    if (!p) return PLBA_ERR_INVALID;
+    p->dirty = true;
+    if (nv == 0) { p->pr_n = 0; p->pr_nv = 0; return PLBA_OK; }
+    if (n <= 0 || nv < 0 || !vid || !size || !idx || !x0 || !J0 || !r0) return PLBA_ERR_INVALID;
+    int tot = 0, nx = 0;
+    for (int i = 0; i < nv; ++i) {
+        if (size[i] != 9 && size[i] != 6) FAIL(p, PLBA_ERR_INVALID, "Undefined size of marginalization vertex: %d", size[i]);
+        if (idx[i] < 0 || idx[i] + size[i] > n) FAIL(p, PLBA_ERR_INVALID, "prior vertex %d: idx out of range", i);
+        nx += size[i] == 9 ? 10 : 6;
+        tot += size[i];
+    }
+    if (tot != n) FAIL(p, PLBA_ERR_INVALID, "prior: sum of kept sizes %d != n %d", tot, n);
+    p->pr_n = n; p->pr_nv = nv;
+    p->pr_vid.assign(vid, vid + nv); p->pr_size.assign(size, size + nv); p->pr_idx.assign(idx, idx + nv);
+    p->pr_x0.assign(x0, x0 + nx);
+    p->pr_J0.assign(J0, J0 + (size_t)n * n);
+    p->pr_r0.assign(r0, r0 + n);
+    return PLBA_OK;
+}
+int plba_set_robust(plba_problem* p, plba_edge_kind kind, int enabled, double delta) {
+    if (!p || kind < 0 || kind > 4) return PLBA_ERR_INVALID;
+    p->rob.on[kind] = enabled;
+    p->rob.delta[kind] = delta;
+    return PLBA_OK;
+}
+int plba_set_shard(plba_problem* p, int rank, int world, plba_allreduce_fn fn, void* user) {
+    if (!p || world < 1 || rank < 0 || rank >= world) return PLBA_ERR_INVALID;
+    if (world > 1 && !fn) FAIL(p, PLBA_ERR_INVALID, "a sharded problem needs an all-reduce callback");
+    p->rank = rank; p->world = world; p->xfn = fn; p->xuser = user;
+    p->dirty = true;
+    return PLBA_OK;
+}
+
+
+int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double* b, double* x, int* ok) {
+    if (!p || n <= 0 || !A || !b || !x) return PLBA_ERR_INVALID;
+    HIPCK(p, hipSetDevice(p->device));
+    const int Ppad = std::max(TILE, (n + TILE - 1) / TILE * TILE), ld = Ppad;
+    const size_t sysn = (size_t)(Ppad + TILE) * ld;
+    std::vector<double> h(sysn, 0.0);
+    for (int r = 0; r < n; ++r) memcpy(&h[(size_t)r * ld], A + (size_t)r * n, (size_t)n * 8);
+    for (int r = n; r < Ppad; ++r) h[(size_t)r * ld + r] = 1.0;
+    memcpy(&h[(size_t)Ppad * ld], b, (size_t)n * 8);
+    DArr<double> sys, Lfac, xx;
+    DArr<Ctrl> ctrl;
+    HIPCK(p, sys.upload(h)); HIPCK(p, Lfac.alloc(sysn)); HIPCK(p, xx.alloc(ld)); HIPCK(p, ctrl.alloc(1));
+    Ctrl c0; memset(&c0, 0, sizeof c0); c0.solver_ok = 1;
+    HIPCK(p, hipMemcpy(ctrl.p, &c0, sizeof c0, hipMemcpyHostToDevice));
+    DevBuf d; memset(&d, 0, sizeof d);
+    d.P = n; d.Ppad = Ppad; d.ld = ld; d.sys = sys.p; d.Lfac = Lfac.p; d.x = xx.p; d.ctrl = ctrl.p;
+    launch_cholesky(d, p->opt.use_mfma != 0, p->stream);
+    launch_trsv_back(d, p->stream);
+    HIPCK(p, hipStreamSynchronize(p->stream));
+    HIPCK(p, hipGetLastError());
+    HIPCK(p, hipMemcpy(x, xx.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCK(p, hipMemcpy(&c0, ctrl.p, sizeof c0, hipMemcpyDeviceToHost));
+    if (ok) *ok = c0.solver_ok;
+    return PLBA_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// structure + device image
+// =================================================================================================
+static int prepare(plba_problem* p) {
+    if (!p->dirty) return PLBA_OK;
+    if (!p->have_cam || !p->K) FAIL(p, PLBA_ERR_STATE, "camera and keyframes must be set before optimize");
+    if ((int)p->po_pt.size() != p->Ep) p->Ep = 0;
+    HIPCK(p, hipSetDevice(p->device));
+    const int K = p->K, Np = p->Np, Nl = p->Nl, Ep = p->Ep, El = p->El, M = p->M;
+    const int L = Np + Nl, E = Ep + El;
+    p->L = L; p->E = E;
+    // the observation arrays may refer to landmarks uploaded later/earlier: re-check ranges
+    for (int e = 0; e < Ep; ++e) if (p->po_pt[e] >= Np) FAIL(p, PLBA_ERR_INVALID, "point observation %d refers to point %d of %d", e, p->po_pt[e], Np);
+    for (int e = 0; e < El; ++e) if (p->lo_ln[e] >= Nl) FAIL(p, PLBA_ERR_INVALID, "line observation %d refers to line %d of %d", e, p->lo_ln[e], Nl);
+    if ((int)p->level.size() != E) p->level.assign(E, 0);
+    // ---- pose-side index map: non-fixed vertices by ascending id ----------------
+    p->off_pvr.assign(K, -1); p->off_bias.assign(K, -1);
+    int off = 0;
+    for (int k = 0; k < K; ++k) {
+        const bool pv = !p->fix_pvr[k];
+        const bool bv = p->vid_bias[k] >= 0 && !p->fix_bias[k];
+        if (pv && bv && p->vid_bias[k] < p->vid_pvr[k]) { p->off_bias[k] = off; off += 6; p->off_pvr[k] = off; off += 9; }
+        else {
+            if (pv) { p->off_pvr[k] = off; off += 9; }
+            if (bv) { p->off_bias[k] = off; off += 6; }
+        }
+    }
+    p->P = off;
+    p->Ppad = std::max(TILE, (off + TILE - 1) / TILE * TILE);
+    p->ld = p->Ppad;
+    // ---- unified landmark slots / observation arrays ----------------------------------------------------
+    std::vector<int32_t> ob_kf(E), ob_slot(E), lm_start(L + 1, 0);
+    std::vector<double> ob_w(E);
+    for (int e = 0; e < Ep; ++e) { ob_kf[e] = p->po_kf[e]; ob_slot[e] = p->po_pt[e]; ob_w[e] = p->po_w[e]; lm_start[p->po_pt[e] + 1]++; }
+    for (int e = 0; e < El; ++e) { ob_kf[Ep + e] = p->lo_kf[e]; ob_slot[Ep + e] = Np + p->lo_ln[e]; ob_w[Ep + e] = p->lo_w[e]; lm_start[Np + p->lo_ln[e] + 1]++; }
+    for (int s = 0; s < L; ++s) lm_start[s + 1] += lm_start[s];
+    p->lm0.assign((size_t)L * 6, 0.0);
+    p->lm_fixed.assign(L, 0);
+    for (int i = 0; i < Np; ++i) { memcpy(&p->lm0[(size_t)i * 6], &p->pts[(size_t)i * 3], 24); p->lm_fixed[i] = p->pt_fixed[i]; }
+    for (int i = 0; i < Nl; ++i) { memcpy(&p->lm0[(size_t)(Np + i) * 6], &p->lns[(size_t)i * 6], 48); p->lm_fixed[Np + i] = p->ln_fixed[i]; }
+    // ---- keyframe-pair lists for the Schur complement --------------------------------------------------
+    std::vector<int64_t> cnt((size_t)K * K + 1, 0);
+    for (int s = 0; s < L; ++s)
+        for (int a = lm_start[s]; a < lm_start[s + 1]; ++a) {
+            if (p->off_pvr[ob_kf[a]] < 0) continue;
+            for (int b = a; b < lm_start[s + 1]; ++b) {
+                if (p->off_pvr[ob_kf[b]] < 0) continue;
+                const int i = std::min(ob_kf[a], ob_kf[b]), j = std::max(ob_kf[a], ob_kf[b]);
+                cnt[(size_t)i * K + j + 1]++;
+            }
+        }
+    std::vector<int32_t> pair_i, pair_j, pair_start;
+    std::vector<int64_t> pos((size_t)K * K, -1);
+    int64_t nent = 0;
+    for (int i = 0; i < K; ++i)
+        for (int j = i; j < K; ++j) {
+            const int64_t c = cnt[(size_t)i * K + j + 1];
+            if (c == 0) continue;
+            pos[(size_t)i * K + j] = nent;
+            pair_i.push_back(i); pair_j.push_back(j); pair_start.push_back((int32_t)nent);
+            nent += c;
+        }
+    if (nent > 0x7fffffff) FAIL(p, PLBA_ERR_INVALID, "too many Schur pair entries");
+    pair_start.push_back((int32_t)nent);
+    std::vector<int32_t> ent_ei((size_t)nent), ent_ej((size_t)nent);
+    for (int s = 0; s < L; ++s)
+        for (int a = lm_start[s]; a < lm_start[s + 1]; ++a) {
+            if (p->off_pvr[ob_kf[a]] < 0) continue;
+            for (int b = a; b < lm_start[s + 1]; ++b) {
+                if (p->off_pvr[ob_kf[b]] < 0) continue;
+                int ea = a, eb = b;
+                if (ob_kf[ea] > ob_kf[eb]) std::swap(ea, eb);
+                int64_t& w = pos[(size_t)ob_kf[ea] * K + ob_kf[eb]];
+                ent_ei[(size_t)w] = ea; ent_ej[(size_t)w] = eb;
+                ++w;
+            }
+        }
+    // ---- prior bookkeeping ----------------------------------------------------------------------------------------
+    std::vector<int32_t> pr_kf(p->pr_nv), pr_isb(p->pr_nv), pr_x0off(p->pr_nv), pr_off(p->pr_nv);
+    {
+        std::map<int, std::pair<int, int>> by_vid;
+        for (int k = 0; k < K; ++k) { by_vid[p->vid_pvr[k]] = {k, 0}; if (p->vid_bias[k] >= 0) by_vid[p->vid_bias[k]] = {k, 1}; }
+        int xo = 0;
+        for (int i = 0; i < p->pr_nv; ++i) {
+            auto it = by_vid.find(p->pr_vid[i]);
+            if (it == by_vid.end()) FAIL(p, PLBA_ERR_INVALID, "prior vertex id %d not in the window", p->pr_vid[i]);
+            pr_kf[i] = it->second.first; pr_isb[i] = it->second.second;
+            if ((pr_isb[i] ? 6 : 9) != p->pr_size[i]) FAIL(p, PLBA_ERR_INVALID, "prior vertex %d: size %d does not match its vertex type", i, p->pr_size[i]);
+            pr_x0off[i] = xo; xo += p->pr_size[i] == 9 ? 10 : 6;
+            pr_off[i] = pr_isb[i] ? p->off_bias[pr_kf[i]] : p->off_pvr[pr_kf[i]];
+        }
+    }
+    // ---- upload ----------------------------------------------------------------------------------------------------
+    const size_t sysn = (size_t)(p->Ppad + TILE) * p->ld;
+    HIPCK(p, p->d_kf[0].upload(p->kf0)); HIPCK(p, p->d_kf[1].upload(p->kf0)); HIPCK(p, p->d_kf_saved.upload(p->kf0));
+    HIPCK(p, p->d_lm[0].upload(p->lm0)); HIPCK(p, p->d_lm[1].upload(p->lm0)); HIPCK(p, p->d_lm_saved.upload(p->lm0));
+    HIPCK(p, p->d_po_uv.upload(p->po_uv)); HIPCK(p, p->d_lo_l.upload(p->lo_l)); HIPCK(p, p->d_ob_w.upload(ob_w));
+    HIPCK(p, p->d_ob_kf.upload(ob_kf)); HIPCK(p, p->d_ob_slot.upload(ob_slot)); HIPCK(p, p->d_lm_start.upload(lm_start));
+    HIPCK(p, p->d_level.upload(p->level)); HIPCK(p, p->d_lm_fixed.upload(p->lm_fixed));
+    HIPCK(p, p->d_ob_chi2.alloc(E)); HIPCK(p, p->d_erec.alloc((size_t)E * EREC)); HIPCK(p, p->d_depth.alloc(E));
+    HIPCK(p, p->d_lm_active.alloc(L));
+    HIPCK(p, p->d_hll.alloc((size_t)L * 12)); HIPCK(p, p->d_bl.alloc((size_t)L * 6)); HIPCK(p, p->d_dinv.alloc((size_t)L * 12));
+    HIPCK(p, p->d_tv.alloc((size_t)L * 6)); HIPCK(p, p->d_xl.alloc((size_t)L * 6));
+    HIPCK(p, p->d_off_pvr.upload(p->off_pvr)); HIPCK(p, p->d_off_bias.upload(p->off_bias));
+    HIPCK(p, p->d_pair_i.upload(pair_i)); HIPCK(p, p->d_pair_j.upload(pair_j)); HIPCK(p, p->d_pair_start.upload(pair_start));
+    HIPCK(p, p->d_ent_ei.upload(ent_ei)); HIPCK(p, p->d_ent_ej.upload(ent_ej));
+    HIPCK(p, p->d_imu_i.upload(p->imu_i)); HIPCK(p, p->d_imu_j.upload(p->imu_j)); HIPCK(p, p->d_imu_pre.upload(p->imu_pre));
+    HIPCK(p, p->d_imu_ipvr.upload(p->imu_ipvr)); HIPCK(p, p->d_imu_ibias.upload(p->imu_ibias));
+    HIPCK(p, p->d_imu_err.alloc((size_t)M * 16)); HIPCK(p, p->d_imu_chi.alloc((size_t)M * 4));
+    HIPCK(p, p->d_pr_kf.upload(pr_kf)); HIPCK(p, p->d_pr_isbias.upload(pr_isb)); HIPCK(p, p->d_pr_size.upload(p->pr_size));
+    HIPCK(p, p->d_pr_idx.upload(p->pr_idx)); HIPCK(p, p->d_pr_x0off.upload(pr_x0off)); HIPCK(p, p->d_pr_off.upload(pr_off));
+    HIPCK(p, p->d_pr_x0.upload(p->pr_x0)); HIPCK(p, p->d_pr_J0.upload(p->pr_J0)); HIPCK(p, p->d_pr_r0.upload(p->pr_r0));
+    HIPCK(p, p->d_pr_err.alloc(p->pr_n)); HIPCK(p, p->d_pr_dx.alloc(p->pr_n)); HIPCK(p, p->d_pr_chi.alloc(1));
+    HIPCK(p, p->d_Hconst.alloc((size_t)p->Ppad * p->ld)); HIPCK(p, p->d_Himu.alloc((size_t)p->Ppad * p->ld));
+    HIPCK(p, p->d_bimu.alloc(p->ld)); HIPCK(p, p->d_sys.alloc(sysn)); HIPCK(p, p->d_Lfac.alloc(sysn));
+    HIPCK(p, p->d_bpg.alloc(p->ld)); HIPCK(p, p->d_x.alloc(p->ld));
+    HIPCK(p, p->d_chi_part.alloc((size_t)(E + 255) / 256 + 1)); HIPCK(p, p->d_scale_part.alloc((size_t)(L + 255) / 256 + 1));
+    HIPCK(p, p->d_maxd_part.alloc((size_t)(L + 255) / 256 + 1)); HIPCK(p, p->d_kfdiag.alloc((size_t)K * 6));
+    HIPCK(p, p->d_red.alloc(8)); HIPCK(p, p->d_ctrl.alloc(1)); HIPCK(p, p->d_trace.alloc(TRACE_CAP)); HIPCK(p, p->d_trace_n.alloc(1));
+    // ---- kernel argument block -------------------------------------------------------------------------------------
+    DevBuf& d = p->dv;
+    memset(&d, 0, sizeof d);
+    d.K = K; d.Np = Np; d.Nl = Nl; d.L = L; d.Ep = Ep; d.El = El; d.E = E; d.M = M;
+    d.P = p->P; d.Ppad = p->Ppad; d.ld = p->ld; d.npairs = (int)pair_i.size(); d.nent = (int)nent;
+    d.cam.fx = p->fx; d.cam.fy = p->fy; d.cam.cx = p->cx; d.cam.cy = p->cy;
+    M3 Rbc; for (int i = 0; i < 9; ++i) Rbc.a[i] = p->Rbc[i];
+    d.cam.Rcb = transpose(Rbc);
+    d.cam.c0 = mul(d.cam.Rcb, v3(p->Pbc[0], p->Pbc[1], p->Pbc[2]));
+    d.gw = v3(p->gw[0], p->gw[1], p->gw[2]);
+    d.fix_q1 = p->opt.fix_line_position_jacobian;
+    d.kf[0] = p->d_kf[0].p; d.kf[1] = p->d_kf[1].p; d.lm[0] = p->d_lm[0].p; d.lm[1] = p->d_lm[1].p;
+    d.po_uv = p->d_po_uv.p; d.lo_l = p->d_lo_l.p; d.ob_w = p->d_ob_w.p; d.ob_kf = p->d_ob_kf.p; d.ob_slot = p->d_ob_slot.p;
+    d.ob_level = p->d_level.p; d.ob_chi2 = p->d_ob_chi2.p; d.erec = p->d_erec.p;
+    d.lm_start = p->d_lm_start.p; d.lm_fixed = p->d_lm_fixed.p;
+    d.hll = p->d_hll.p; d.bl = p->d_bl.p; d.dinv = p->d_dinv.p; d.tv = p->d_tv.p; d.xl = p->d_xl.p; d.lm_active = p->d_lm_active.p;
+    d.kf_off_pvr = p->d_off_pvr.p; d.kf_off_bias = p->d_off_bias.p;
+    d.pair_i = p->d_pair_i.p; d.pair_j = p->d_pair_j.p; d.pair_start = p->d_pair_start.p; d.ent_ei = p->d_ent_ei.p; d.ent_ej = p->d_ent_ej.p;
+    d.imu_i = p->d_imu_i.p; d.imu_j = p->d_imu_j.p; d.imu_pre = p->d_imu_pre.p; d.imu_info_pvr = p->d_imu_ipvr.p; d.imu_info_bias = p->d_imu_ibias.p;
+    d.imu_err = p->d_imu_err.p; d.imu_chi = p->d_imu_chi.p;
+    d.pr_n = p->pr_n; d.pr_nv = p->pr_nv;
+    d.pr_kf = p->d_pr_kf.p; d.pr_isbias = p->d_pr_isbias.p; d.pr_size = p->d_pr_size.p; d.pr_idx = p->d_pr_idx.p;
+    d.pr_x0off = p->d_pr_x0off.p; d.pr_off = p->d_pr_off.p; d.pr_x0 = p->d_pr_x0.p; d.pr_J0 = p->d_pr_J0.p; d.pr_r0 = p->d_pr_r0.p;
+    d.pr_err = p->d_pr_err.p; d.pr_dx = p->d_pr_dx.p; d.pr_chi = p->d_pr_chi.p;
+    d.Hconst = p->d_Hconst.p; d.Himu = p->d_Himu.p; d.bimu = p->d_bimu.p; d.sys = p->d_sys.p; d.Lfac = p->d_Lfac.p; d.bpg = p->d_bpg.p; d.x = p->d_x.p;
+    d.chi_part = p->d_chi_part.p; d.scale_part = p->d_scale_part.p; d.maxd_part = p->d_maxd_part.p; d.kfdiag = p->d_kfdiag.p;
+    d.ctrl = p->d_ctrl.p; d.trace = p->d_trace.p; d.trace_cap = TRACE_CAP; d.trace_n = p->d_trace_n.p;
+    // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
+    if (p->pr_nv > 0 && p->rank == 0) {
+        const int n = p->pr_n;
+        HIPCK(p, p->d_pr_H.alloc((size_t)n * n));
+        launch_ata(p->d_pr_J0.p, n, n, p->d_pr_H.p, n, p->stream);
+        std::vector<double> H((size_t)n * n), Hc((size_t)p->Ppad * p->ld, 0.0);
+        HIPCK(p, hipStreamSynchronize(p->stream));
+        HIPCK(p, hipMemcpy(H.data(), p->d_pr_H.p, H.size() * 8, hipMemcpyDeviceToHost));
+        for (int a = 0; a < p->pr_nv; ++a) {
+            if (pr_off[a] < 0) continue;
+            for (int b = 0; b < p->pr_nv; ++b) {
+                if (pr_off[b] < 0) continue;
+                for (int c = 0; c < p->pr_size[a]; ++c)
+                    for (int e = 0; e < p->pr_size[b]; ++e)
+                        Hc[(size_t)(pr_off[a] + c) * p->ld + pr_off[b] + e] = H[(size_t)(p->pr_idx[a] + c) * n + p->pr_idx[b] + e];
+            }
+        }
+        HIPCK(p, hipMemcpy(p->d_Hconst.p, Hc.data(), Hc.size() * 8, hipMemcpyHostToDevice));
+    }
+    p->cur = 0;
+    p->saved_valid = true;
+    p->dirty = false;
+    return PLBA_OK;
+}
+
+static int exchange(plba_problem* p, double* dev, size_t n, int op) {
+    if (p->world <= 1) return PLBA_OK;
+    int rc = p->xfn(p->xuser, dev, n, op, (void*)p->stream);
+    if (rc) FAIL(p, PLBA_ERR_EXCHANGE, "all-reduce callback failed (%d)", rc);
+    return PLBA_OK;
+}
+static bool owns_pose_edges(const plba_problem* p) { return p->rank == 0; }
+
+static LmParams lm_params(const plba_problem* p) {
+    LmParams lp;
+    lp.tau = p->opt.tau; lp.lower = p->opt.good_step_lower; lp.upper = p->opt.good_step_upper;
+    lp.user_lambda = p->opt.user_lambda_init; lp.max_trials = p->opt.max_trials;
+    return lp;
+}
+
+// computeActiveErrors + buildSystem for the current estimate (everything lambda-independent)
+static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
+    const DevBuf& d = p->dv;
+    hipStream_t s = p->stream;
+    launch_linearize(d, p->cur, true, p->rob, s);
+    HIPCK(p, hipMemcpyAsync(d.Himu, d.Hconst, (size_t)d.Ppad * d.ld * 8, hipMemcpyDeviceToDevice, s));
+    HIPCK(p, hipMemsetAsync(d.bimu, 0, (size_t)d.ld * 8, s));
+    launch_pose_edges(d, p->cur, true, p->rob, owns_pose_edges(p), s);
+    launch_landmark_hll(d, s);
+    if (first_iter) {
+        HIPCK(p, hipMemsetAsync(d.kfdiag, 0, (size_t)d.K * 6 * 8, s));
+        launch_kfdiag(d, s);
+    }
+    launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
+    if (p->world > 1) {
+        int rc;
+        if ((rc = exchange(p, p->d_red.p, 1, 0))) return rc;
+        if (first_iter) {
+            if ((rc = exchange(p, p->d_red.p + 2, 1, 1))) return rc;
+            if ((rc = exchange(p, d.kfdiag, (size_t)d.K * 6, 0))) return rc;
+        }
+    }
+    launch_lambda_init2(d, lm_params(p), p->d_red.p, first_iter, iteration, s);
+    return PLBA_OK;
+}
+// setLambda + Schur complement (+ optional dense solve, back-substitution, trial update)
+static int enqueue_solve(plba_problem* p, bool do_solve) {
+    const DevBuf& d = p->dv;
+    hipStream_t s = p->stream;
+    launch_landmark_dinv(d, s);
+    launch_assemble(d, owns_pose_edges(p), s);
+    launch_schur_pairs(d, s);
+    if (p->world > 1) { int rc = exchange(p, d.sys, (size_t)(d.Ppad + 2) * d.ld, 0); if (rc) return rc; }
+    HIPCK(p, hipMemcpyAsync(d.bpg, d.sys + (size_t)(d.Ppad + 1) * d.ld, (size_t)d.ld * 8, hipMemcpyDeviceToDevice, s));
+    if (!do_solve) return PLBA_OK;
+    launch_cholesky(d, p->opt.use_mfma != 0, s);
+    launch_trsv_back(d, s);
+    launch_backsub(d, p->cur, p->cur ^ 1, s);
+    launch_update_kf(d, p->cur, p->cur ^ 1, s);
+    return PLBA_OK;
+}
+
+extern "C" {
+
+int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_flag, plba_stats* out) {
+    if (!p) return PLBA_ERR_INVALID;
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = prepare(p);
+    if (rc) return rc;
+    HIPCK(p, hipSetDevice(p->device));
+    const DevBuf& d = p->dv;
+    hipStream_t s = p->stream;
+    plba_stats st;
+    memset(&st, 0, sizeof st);
+    Ctrl c0;
+    memset(&c0, 0, sizeof c0);
+    c0.solver_ok = 1; c0.ni = 2.0;
+    HIPCK(p, hipMemcpyAsync(d.ctrl, &c0, sizeof c0, hipMemcpyHostToDevice, s));
+    HIPCK(p, hipMemsetAsync(d.trace_n, 0, sizeof(int), s));
+    HIPCK(p, hipStreamSynchronize(s));   // c0 lives on the stack
+    const LmParams lp = lm_params(p);
+    bool ok = true;
+    double last_chi = 0.0, lambda = 0.0;
+    for (int it = 0; it < max_iters && !(abort_flag && *abort_flag) && ok; ++it) {
+        if ((rc = enqueue_linearize(p, it == 0, it))) return rc;
+        double rho = 0.0;
+        int qmax = 0;
+        do {
+            if ((rc = enqueue_solve(p, true))) return rc;
+            const int trial = p->cur ^ 1;
+            launch_linearize(d, trial, false, p->rob, s);
+            launch_pose_edges(d, trial, false, p->rob, owns_pose_edges(p), s);
+            launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
+            if (p->world > 1 && (rc = exchange(p, p->d_red.p, 2, 0))) return rc;
+            launch_decide(d, lp, p->d_red.p, s);
+            HIPCK(p, hipMemcpyAsync(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+            HIPCK(p, hipStreamSynchronize(s));
+            const Ctrl& c = *p->h_ctrl;
+            rho = c.rho;
+            lambda = c.lambda;
+            st.trials++;
+            if (c.accepted) { p->cur ^= 1; last_chi = c.current_chi; }
+            else if (!std::isfinite(lambda)) break;
+            qmax++;
+        } while (rho < 0 && qmax < lp.max_trials && !(abort_flag && *abort_flag));
+        st.iterations++;
+        if (qmax == lp.max_trials || rho == 0 || !std::isfinite(lambda)) { ok = false; st.stop_reason = 1; }
+    }
+    if (abort_flag && *abort_flag && st.stop_reason == 0 && st.iterations < max_iters) st.stop_reason = 2;
+    // trace + stats
+    int ntr = 0;
+    HIPCK(p, hipMemcpy(&ntr, d.trace_n, sizeof(int), hipMemcpyDeviceToHost));
+    ntr = std::min(ntr, TRACE_CAP);
+    p->trace.resize(ntr);
+    if (ntr) HIPCK(p, hipMemcpy(p->trace.data(), d.trace, sizeof(plba_trace_row) * ntr, hipMemcpyDeviceToHost));
+    if (ntr) {
+        st.chi2_initial = p->trace[0].chi2_current;
+        st.chi2_final = p->trace[0].chi2_current;
+        for (const auto& r : p->trace) if (r.accepted) st.chi2_final = r.chi2_trial;
+        HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+        st.solver_failures = p->h_ctrl->n_fail;
+        st.lambda_final = p->h_ctrl->lambda;
+    } else {
+        // no iteration ran: report the chi2 of the current estimate (computeActiveErrors only)
+        launch_linearize(d, p->cur, false, p->rob, s);
+        launch_pose_edges(d, p->cur, false, p->rob, owns_pose_edges(p), s);
+        launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
+        if (p->world > 1 && (rc = exchange(p, p->d_red.p, 1, 0))) return rc;
+        double chi = 0.0;
+        HIPCK(p, hipMemcpyAsync(&chi, p->d_red.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCK(p, hipStreamSynchronize(s));
+        st.chi2_initial = st.chi2_final = chi;
+    }
+    (void)last_chi;
+    st.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (out) *out = st;
+    return PLBA_OK;
+}
+
+int plba_recompute_errors(plba_problem* p) {
+    if (!p) return PLBA_ERR_INVALID;
+    int rc = prepare(p);
+    if (rc) return rc;
+    HIPCK(p, hipSetDevice(p->device));
+    launch_linearize(p->dv, p->cur, false, p->rob, p->stream);
+    launch_pose_edges(p->dv, p->cur, false, p->rob, owns_pose_edges(p), p->stream);
+    HIPCK(p, hipStreamSynchronize(p->stream));
+    return PLBA_OK;
+}
+
+int plba_set_levels(plba_problem* p, plba_edge_kind kind, const uint8_t* level) {
+    if (!p || !level) return PLBA_ERR_INVALID;
+    if (kind != PLBA_EDGE_POINT && kind != PLBA_EDGE_LINE) FAIL(p, PLBA_ERR_INVALID, "levels only for point/line edges");
+    const int E = p->Ep + p->El;
+    if ((int)p->level.size() != E) p->level.assign(E, 0);
+    if (!p->dirty) {   // device copy may have been changed by gate_outliers: refresh the host mirror first
+        HIPCK(p, hipSetDevice(p->device));
+        HIPCK(p, hipStreamSynchronize(p->stream));
+        if (E) HIPCK(p, hipMemcpy(p->level.data(), p->d_level.p, E, hipMemcpyDeviceToHost));
+    }
+    if (kind == PLBA_EDGE_POINT) memcpy(p->level.data(), level, p->Ep);
+    else memcpy(p->level.data() + p->Ep, level, p->El);
+    if (!p->dirty && E) HIPCK(p, hipMemcpy(p->d_level.p, p->level.data(), E, hipMemcpyHostToDevice));
+    return PLBA_OK;
+}
+int plba_get_levels(plba_problem* p, plba_edge_kind kind, uint8_t* level) {
+    if (!p || !level) return PLBA_ERR_INVALID;
+    if (kind != PLBA_EDGE_POINT && kind != PLBA_EDGE_LINE) return PLBA_ERR_INVALID;
+    const int E = p->Ep + p->El;
+    if ((int)p->level.size() != E) p->level.assign(E, 0);
+    if (!p->dirty && E) {
+        HIPCK(p, hipSetDevice(p->device));
+        HIPCK(p, hipStreamSynchronize(p->stream));
+        HIPCK(p, hipMemcpy(p->level.data(), p->d_level.p, E, hipMemcpyDeviceToHost));
+    }
+    if (kind == PLBA_EDGE_POINT) memcpy(level, p->level.data(), p->Ep);
+    else memcpy(level, p->level.data() + p->Ep, p->El);
+    return PLBA_OK;
+}
+
+int plba_gate_outliers(plba_problem* p, double thresh, int* np_out, int* nl_out) {
+    if (!p) return PLBA_ERR_INVALID;
+    int rc = prepare(p);
+    if (rc) return rc;
+    HIPCK(p, hipSetDevice(p->device));
+    const DevBuf& d = p->dv;
+    Ctrl* c = d.ctrl;
+    HIPCK(p, hipMemsetAsync(&c->n_gate_pt, 0, 2 * sizeof(int), p->stream));
+    launch_gate(d, p->cur, thresh, p->stream);
+    HIPCK(p, hipMemcpyAsync(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, p->stream));
+    HIPCK(p, hipStreamSynchronize(p->stream));
+    p->rob.on[PLBA_EDGE_POINT] = 0;    // setRobustKernel(0) on every point / line edge (mapHandler.cpp:6055,6065)
+    p->rob.on[PLBA_EDGE_LINE] = 0;
+    if (np_out) *np_out = p->h_ctrl->n_gate_pt;
+    if (nl_out) *nl_out = p->h_ctrl->n_gate_ln;
+    return p->h_ctrl->n_gate_pt + p->h_ctrl->n_gate_ln;
+}
+
+int plba_get_edge_chi2(plba_problem* p, plba_edge_kind kind, double* chi2, uint8_t* dpos) {
+    if (!p) return PLBA_ERR_INVALID;
+    int rc = prepare(p);
+    if (rc) return rc;
+    HIPCK(p, hipSetDevice(p->device));
+    const DevBuf& d = p->dv;
+    HIPCK(p, hipStreamSynchronize(p->stream));
+    if (kind == PLBA_EDGE_POINT || kind == PLBA_EDGE_LINE) {
+        const int o = kind == PLBA_EDGE_POINT ? 0 : p->Ep, n = kind == PLBA_EDGE_POINT ? p->Ep : p->El;
+        if (chi2 && n) HIPCK(p, hipMemcpy(chi2, d.ob_chi2 + o, (size_t)n * 8, hipMemcpyDeviceToHost));
+        if (dpos && n) {
+            launch_depth(d, p->cur, p->d_depth.p, p->stream);
+            HIPCK(p, hipStreamSynchronize(p->stream));
+            HIPCK(p, hipMemcpy(dpos, p->d_depth.p + o, n, hipMemcpyDeviceToHost));
+        }
+    } else if (kind == PLBA_EDGE_IMU_PVR || kind == PLBA_EDGE_IMU_BIAS) {
+        std::vector<double> c((size_t)p->M * 4);
+        if (p->M) HIPCK(p, hipMemcpy(c.data(), d.imu_chi, c.size() * 8, hipMemcpyDeviceToHost));
+        for (int m = 0; m < p->M; ++m) { if (chi2) chi2[m] = c[(size_t)m * 4 + (kind == PLBA_EDGE_IMU_PVR ? 0 : 1)]; if (dpos) dpos[m] = 1; }
+    } else if (kind == PLBA_EDGE_PRIOR) {
+        double c = 0.0;
+        if (p->pr_nv) HIPCK(p, hipMemcpy(&c, d.pr_chi, 8, hipMemcpyDeviceToHost));
+        if (chi2) chi2[0] = c;
+        if (dpos) dpos[0] = 1;
+    } else return PLBA_ERR_INVALID;
+    return PLBA_OK;
+}
+
+int plba_get_trace(plba_problem* p, plba_trace_row* rows, int cap, int* n) {
+    if (!p) return PLBA_ERR_INVALID;
+    const int c = std::min((int)p->trace.size(), cap);
+    if (rows && c > 0) memcpy(rows, p->trace.data(), sizeof(plba_trace_row) * c);
+    if (n) *n = (int)p->trace.size();
+    return PLBA_OK;
+}
+
+int plba_get_keyframes(plba_problem* p, double* P3, double* V3, double* q4, double* dbg3, double* dba3) {
+    if (!p) return PLBA_ERR_INVALID;
+    int rc = prepare(p);
+    if (rc) return rc;
+    HIPCK(p, hipSetDevice(p->device));
+    HIPCK(p, hipStreamSynchronize(p->stream));
+    std::vector<double> h((size_t)p->K * KF_STRIDE);
+    HIPCK(p, hipMemcpy(h.data(), p->dv.kf[p->cur], h.size() * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < p->K; ++k) {
+        const double* s = &h[(size_t)k * KF_STRIDE];
+        if (P3) memcpy(P3 + 3 * k, s, 24);
+        if (V3) memcpy(V3 + 3 * k, s + 3, 24);
+        if (q4) memcpy(q4 + 4 * k, s + 6, 32);
+        if (dbg3) memcpy(dbg3 + 3 * k, s + 16, 24);
+        if (dba3) memcpy(dba3 + 3 * k, s + 19, 24);
+    }
+    return PLBA_OK;
+}
+static int get_lm(plba_problem* p, std::vector<double>& h) {
+    int rc = prepare(p);
+    if (rc) return rc;
+    HIPCK(p, hipSetDevice(p->device));
+    HIPCK(p, hipStreamSynchronize(p->stream));
+    h.resize((size_t)p->L * 6);
+    if (p->L) HIPCK(p, hipMemcpy(h.data(), p->dv.lm[p->cur], h.size() * 8, hipMemcpyDeviceToHost));
+    return PLBA_OK;
+}
+int plba_get_points(plba_problem* p, double* xyz) {
+    if (!p || !xyz) return PLBA_ERR_INVALID;
+    std::vector<double> h;
+    int rc = get_lm(p, h);
+    if (rc) return rc;
+    for (int i = 0; i < p->Np; ++i) memcpy(xyz + 3 * (size_t)i, &h[(size_t)i * 6], 24);
+    return PLBA_OK;
+}
+int plba_get_lines(plba_problem* p, double* l) {
+    if (!p || !l) return PLBA_ERR_INVALID;
+    std::vector<double> h;
+    int rc = get_lm(p, h);
+    if (rc) return rc;
+    for (int i = 0; i < p->Nl; ++i) memcpy(l + 6 * (size_t)i, &h[(size_t)(p->Np + i) * 6], 48);
+    return PLBA_OK;
+}
+int plba_save_state(plba_problem* p) {
+    if (!p) return PLBA_ERR_INVALID;
+    int rc = prepare(p);
+    if (rc) return rc;
+    HIPCK(p, hipSetDevice(p->device));
+    HIPCK(p, hipMemcpyAsync(p->d_kf_saved.p, p->dv.kf[p->cur], (size_t)p->K * KF_STRIDE * 8, hipMemcpyDeviceToDevice, p->stream));
+    if (p->L) HIPCK(p, hipMemcpyAsync(p->d_lm_saved.p, p->dv.lm[p->cur], (size_t)p->L * 6 * 8, hipMemcpyDeviceToDevice, p->stream));
+    return PLBA_OK;
+}
+int plba_restore_state(plba_problem* p) {
+    if (!p) return PLBA_ERR_INVALID;
+    int rc = prepare(p);
+    if (rc) return rc;
+    HIPCK(p, hipSetDevice(p->device));
+    HIPCK(p, hipMemcpyAsync(p->dv.kf[p->cur], p->d_kf_saved.p, (size_t)p->K * KF_STRIDE * 8, hipMemcpyDeviceToDevice, p->stream));
+    if (p->L) HIPCK(p, hipMemcpyAsync(p->dv.lm[p->cur], p->d_lm_saved.p, (size_t)p->L * 6 * 8, hipMemcpyDeviceToDevice, p->stream));
+    return PLBA_OK;
+}
+
+int plba_marginalize(plba_problem* p, int first_kf, int max_edges, plba_prior* out) {
+    if (!p || !out) return PLBA_ERR_INVALID;
+    int rc = prepare(p);
+    if (rc) return rc;
+    HIPCK(p, hipSetDevice(p->device));
+    return marginalize_device(p, first_kf, max_edges, out);
+}
+void plba_prior_free(plba_prior* pr) {
+    if (!pr) return;
+    free(pr->vid); free(pr->size); free(pr->idx); free(pr->x0); free(pr->J0); free(pr->r0); free(pr->Ar); free(pr->br);
+    memset(pr, 0, sizeof *pr);
+}
+
+// ---- diagnostics ------------------------------------------------------------------------------------------------------
+int plba_debug_build(plba_problem* p, double lambda, int do_solve) {
+    if (!p) return PLBA_ERR_INVALID;
+    int rc = prepare(p);
+    if (rc) return rc;
+    HIPCK(p, hipSetDevice(p->device));
+    const DevBuf& d = p->dv;
+    Ctrl c0;
+    memset(&c0, 0, sizeof c0);
+    c0.solver_ok = 1; c0.ni = 2.0;
+    HIPCK(p, hipMemcpy(d.ctrl, &c0, sizeof c0, hipMemcpyHostToDevice));
+    if ((rc = enqueue_linearize(p, true, 0))) return rc;
+    HIPCK(p, hipStreamSynchronize(p->stream));
+    HIPCK(p, hipMemcpy(&c0, d.ctrl, sizeof c0, hipMemcpyDeviceToHost));
+    c0.lambda = lambda;
+    HIPCK(p, hipMemcpy(d.ctrl, &c0, sizeof c0, hipMemcpyHostToDevice));
+    if ((rc = enqueue_solve(p, do_solve != 0))) return rc;
+    HIPCK(p, hipStreamSynchronize(p->stream));
+    HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+    return PLBA_OK;
+}
+
+int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, size_t* n) {
+    if (!p || !what) return PLBA_ERR_INVALID;
+    if (p->dirty) FAIL(p, PLBA_ERR_STATE, "debug_get before debug_build/optimize");
+    HIPCK(p, hipSetDevice(p->device));
+    HIPCK(p, hipStreamSynchronize(p->stream));
+    const DevBuf& d = p->dv;
+    std::vector<double> v;
+    const std::string w(what);
+    auto fetch = [&](const double* dev, size_t cnt, std::vector<double>& h) -> hipError_t {
+        h.resize(cnt);
+        return cnt ? hipMemcpy(h.data(), dev, cnt * 8, hipMemcpyDeviceToHost) : hipSuccess;
+    };
+    const size_t P = p->P, ld = p->ld;
+    if (w == "Hschur") {
+        std::vector<double> h;
+        HIPCK(p, fetch(d.sys, (size_t)p->Ppad * ld, h));
+        v.resize(P * P);
+        for (size_t r = 0; r < P; ++r) for (size_t c = 0; c < P; ++c) v[r * P + c] = h[r * ld + c];
+    } else if (w == "bschur") { std::vector<double> h; HIPCK(p, fetch(d.sys + (size_t)p->Ppad * ld, ld, h)); v.assign(h.begin(), h.begin() + P); }
+    else if (w == "bp") { std::vector<double> h; HIPCK(p, fetch(d.bpg, ld, h)); v.assign(h.begin(), h.begin() + P); }
+    else if (w == "x") {
+        std::vector<double> hx, hl; std::vector<uint8_t> act(p->L);
+        HIPCK(p, fetch(d.x, ld, hx)); HIPCK(p, fetch(d.xl, (size_t)p->L * 6, hl));
+        if (p->L) HIPCK(p, hipMemcpy(act.data(), d.lm_active, p->L, hipMemcpyDeviceToHost));
+        v.assign(hx.begin(), hx.begin() + P);
+        for (int s = 0; s < p->L; ++s) if (act[s]) for (int t = 0; t < (s < p->Np ? 3 : 6); ++t) v.push_back(hl[(size_t)s * 6 + t]);
+    } else if (w == "hll_pt" || w == "hll_ln") {
+        std::vector<double> h; HIPCK(p, fetch(d.hll, (size_t)p->L * 12, h));
+        if (w == "hll_pt") {
+            v.resize((size_t)p->Np * 9);
+            for (int i = 0; i < p->Np; ++i) { const double* u = &h[(size_t)i * 12]; double* o = &v[(size_t)i * 9];
+                o[0] = u[0]; o[1] = u[1]; o[2] = u[2]; o[3] = u[1]; o[4] = u[3]; o[5] = u[4]; o[6] = u[2]; o[7] = u[4]; o[8] = u[5]; }
+        } else {
+            v.assign((size_t)p->Nl * 36, 0.0);
+            for (int i = 0; i < p->Nl; ++i) { const double* u = &h[(size_t)(p->Np + i) * 12]; double* o = &v[(size_t)i * 36];
+                for (int b = 0; b < 2; ++b) { const double* q = u + 6 * b; const int z = b * 3;
+                    o[(z + 0) * 6 + z + 0] = q[0]; o[(z + 0) * 6 + z + 1] = q[1]; o[(z + 0) * 6 + z + 2] = q[2];
+                    o[(z + 1) * 6 + z + 0] = q[1]; o[(z + 1) * 6 + z + 1] = q[3]; o[(z + 1) * 6 + z + 2] = q[4];
+                    o[(z + 2) * 6 + z + 0] = q[2]; o[(z + 2) * 6 + z + 1] = q[4]; o[(z + 2) * 6 + z + 2] = q[5]; } }
+        }
+    } else if (w == "bl_pt" || w == "bl_ln") {
+        std::vector<double> h; HIPCK(p, fetch(d.bl, (size_t)p->L * 6, h));
+        if (w == "bl_pt") { v.resize((size_t)p->Np * 3); for (int i = 0; i < p->Np; ++i) memcpy(&v[(size_t)i * 3], &h[(size_t)i * 6], 24); }
+        else { v.resize((size_t)p->Nl * 6); for (int i = 0; i < p->Nl; ++i) memcpy(&v[(size_t)i * 6], &h[(size_t)(p->Np + i) * 6], 48); }
+    } else if (w == "err_pvr" || w == "err_bias") {
+        std::vector<double> h; HIPCK(p, fetch(d.imu_err, (size_t)p->M * 16, h));
+        const int o = w == "err_pvr" ? 0 : 9, nn = w == "err_pvr" ? 9 : 6;
+        v.resize((size_t)p->M * nn);
+        for (int m = 0; m < p->M; ++m) memcpy(&v[(size_t)m * nn], &h[(size_t)m * 16 + o], nn * 8);
+    } else if (w == "err_prior") { HIPCK(p, fetch(d.pr_err, p->pr_nv ? p->pr_n : 0, v)); }
+    else if (w == "err_pt" || w == "err_ln") {
+        std::vector<double> h; HIPCK(p, fetch(d.erec, (size_t)p->E * EREC, h));
+        if (w == "err_pt") { v.resize((size_t)p->Ep * 2); for (int e = 0; e < p->Ep; ++e) { v[2 * (size_t)e] = h[(size_t)e * EREC + 19]; v[2 * (size_t)e + 1] = h[(size_t)e * EREC + 20]; } }
+        else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { v[3 * (size_t)e] = h[(size_t)(p->Ep + e) * EREC + 19]; v[3 * (size_t)e + 1] = h[(size_t)(p->Ep + e) * EREC + 20]; } }
+    } else if (w == "erec") { HIPCK(p, fetch(d.erec, (size_t)p->E * EREC, v)); }
+    else if (w == "pose_dim") v = {(double)p->P};
+    else if (w == "chi2") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {p->h_ctrl->current_chi}; }
+    else if (w == "maxdiag") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {p->h_ctrl->maxdiag}; }
+    else if (w == "solver_ok") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {(double)p->h_ctrl->solver_ok}; }
+    else FAIL(p, PLBA_ERR_INVALID, "debug_get: unknown buffer '%s'", what);
+    if (n) *n = v.size();
+    if (out) { const size_t c = std::min(v.size(), cap); if (c) memcpy(out, v.data(), c * 8); }
+    return PLBA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// plba_internal.h — device-resident problem layout shared by the HIP translation units.
+//
+// HBM layout (all fp64 unless noted; E = Ep + El observations, L = Np + Nl landmark "slots",
+// points first; P = pose-side dimension, Ppad = P rounded up to the 64-wide dense tile):
+//   kf[2]    K x 24      keyframe records, double-buffered (current / trial) + one saved copy
+//   lm[2]    L x 6       landmark estimates (points use 3), double-buffered + saved
+//   obs_*    E           landmark-major observation arrays: uv / l3, inv_sigma2, kf, slot, level
+//   erec     E x 24      per-observation linearisation record (plba_math.h: EREC)
+//   hll,bl   L x 12, L x 6   landmark blocks (points: 6 upper; lines: two 3x3 uppers)
+//   dinv,tv  L x 12, L x 6   (Hll + lambda I)^-1 and (Hll + lambda I)^-1 bl
+//   pairs    CSR of keyframe pairs sharing landmarks -> (edge_i, edge_j) entries for the Schur complement
+//   Himu     Ppad x ld   pose-side edges (IMU + prior) of this iteration; Hconst = prior J0^T J0 scattered
+//   sys      (Ppad+64) x ld  reduced camera system, augmented: row Ppad = bschur, row Ppad+1 = bp
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "plba.h"
+#include "plba_math.h"
+
+namespace plba {
+
+constexpr int TILE = 64;          // dense tile edge (wavefront-wide)
+constexpr int MAX_PART = 8192;    // per-block partial sums for deterministic reductions
+
+// LM control block, device-resident; copied back once per trial.
+struct Ctrl {
+    double lambda, ni, current_chi, temp_chi, scale, rho, maxdiag, pad0;
+    int accepted, solver_ok, iteration, trial, n_gate_pt, n_gate_ln, n_fail, pad1;
+};
+
+struct DevBuf {  // trivially-copyable view of device pointers passed to kernels by value
+    // sizes
+    int K, Np, Nl, L, Ep, El, E, M, P, Ppad, ld, npairs, nent;
+    // camera / gravity
+    Cam cam;
+    V3 gw;
+    int fix_q1;
+    // state
+    double* kf[2];
+    double* lm[2];
+    // observations
+    const double* po_uv;   // Ep x 2
+    const double* lo_l;    // El x 3
+    const double* ob_w;    // E inv_sigma2 (float-rounded)
+    const int32_t* ob_kf;  // E
+    const int32_t* ob_slot;  // E
+    uint8_t* ob_level;     // E
+    double* ob_chi2;       // E   cached e^T Omega e of the last evaluation pass
+    double* erec;          // E x 24
+    // landmarks
+    const int32_t* lm_start;  // L + 1 (unified edge index)
+    const uint8_t* lm_fixed;  // L
+    double *hll, *bl, *dinv, *tv, *xl;
+    uint8_t* lm_active;
+    // keyframes
+    const int32_t *kf_off_pvr, *kf_off_bias;
+    // pairs
+    const int32_t *pair_i, *pair_j, *pair_start, *ent_ei, *ent_ej;
+    // IMU
+    const int32_t *imu_i, *imu_j;
+    const double *imu_pre, *imu_info_pvr, *imu_info_bias;
+    double* imu_err;    // M x 16 (9 pvr + 6 bias + pad)
+    double* imu_chi;    // M x 4  (raw pvr, raw bias, robust pvr, robust bias)
+    // prior
+    int pr_n, pr_nv;
+    const int32_t *pr_kf, *pr_isbias, *pr_size, *pr_idx, *pr_x0off, *pr_off;
+    const double *pr_x0, *pr_J0, *pr_r0;
+    double *pr_err, *pr_dx, *pr_chi;
+    // dense
+    double *Hconst, *Himu, *bimu, *sys, *Lfac, *bpg, *x;   // Lfac: Cholesky factor (same shape as sys)
+    // reductions / control
+    double *chi_part, *scale_part, *maxd_part, *kfdiag;
+    Ctrl* ctrl;
+    plba_trace_row* trace;
+    int trace_cap;
+    int* trace_n;
+};
+
+struct Robust { int on[5]; double delta[5]; };
+
+}  // namespace plba
+
+// ---- launchers implemented in plba_kernels.hip / plba_dense.hip / plba_marg.hip -----------------------
+namespace plba {
+struct LmParams { double tau, lower, upper, user_lambda; int max_trials; };
+
+void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, hipStream_t s);
+void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, bool owns_pose_edges, hipStream_t s);
+void launch_landmark_hll(const DevBuf& d, hipStream_t s);
+void launch_kfdiag(const DevBuf& d, hipStream_t s);
+void launch_landmark_dinv(const DevBuf& d, hipStream_t s);
+void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s);
+void launch_schur_pairs(const DevBuf& d, hipStream_t s);
+void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s);
+void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s);
+// red[0] = activeRobustChi2 (local), red[1] = landmark part of computeScale (local), red[2] = max |Hll_jj| (local)
+void launch_reduce(const DevBuf& d, bool owns_pose_edges, double* red, hipStream_t s);
+void launch_lambda_init2(const DevBuf& d, const LmParams& lp, const double* red, bool first_iter, int iteration, hipStream_t s);
+void launch_decide(const DevBuf& d, const LmParams& lp, const double* red, hipStream_t s);
+void launch_gate(const DevBuf& d, int state, double thresh, hipStream_t s);
+void launch_depth(const DevBuf& d, int state, uint8_t* out, hipStream_t s);
+int  edge_blocks(const DevBuf& d);
+
+// dense
+void launch_cholesky(const DevBuf& d, bool use_mfma, hipStream_t s);   // sys -> Lfac (lower) incl. the augmented rows
+void launch_trsv_back(const DevBuf& d, hipStream_t s);                 // x = L^-T y
+void launch_ata(const double* A_colmajor, int rows, int cols, double* out_rowmajor, int ldo, hipStream_t s);  // A^T A
+
+// marginalization
+int marginalize_device(struct plba_problem* p, int first_kf, int max_edges, plba_prior* out);
+}  // namespace plba

@@ -1,0 +1,103 @@
+// plba_problem.h — host-side problem object behind the opaque plba_problem* of include/plba.h.
+#pragma once
+#include <vector>
+
+#include "plba_internal.h"
+
+namespace plba {
+
+template <class T>
+struct DArr {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t cnt, bool zero = true) {
+        if (cnt == 0) cnt = 1;
+        if (cnt != n || !p) {
+            if (p) (void)hipFree(p);
+            p = nullptr; n = 0;
+            hipError_t e = hipMalloc((void**)&p, cnt * sizeof(T));
+            if (e != hipSuccess) return e;
+            n = cnt;
+        }
+        if (zero) return hipMemset(p, 0, n * sizeof(T));
+        return hipSuccess;
+    }
+    hipError_t upload(const std::vector<T>& h) {
+        hipError_t e = alloc(h.size(), h.empty());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    ~DArr() { release(); }
+};
+
+}  // namespace plba
+
+struct plba_problem {
+    plba_options opt;
+    char err[512];
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // ---- host copy of the uploaded graph -------------------------------------------------------
+    bool have_cam = false;
+    double fx, fy, cx, cy, Rbc[9], Pbc[3], gw[3] = {0, 0, 0};
+    int K = 0, Np = 0, Nl = 0, Ep = 0, El = 0, M = 0;
+    std::vector<int32_t> vid_pvr, vid_bias;
+    std::vector<double> kf0;              // K x 24 initial records
+    std::vector<uint8_t> fix_pvr, fix_bias;
+    std::vector<double> lm0;              // L x 6
+    std::vector<uint8_t> lm_fixed;        // L
+    std::vector<double> pts, lns;
+    std::vector<uint8_t> pt_fixed, ln_fixed;
+    std::vector<int32_t> po_pt, po_kf, lo_ln, lo_kf;
+    std::vector<double> po_uv, po_w, lo_l, lo_w;
+    std::vector<uint8_t> level;           // E (points then lines)
+    std::vector<int32_t> imu_i, imu_j;
+    std::vector<double> imu_pre, imu_ipvr, imu_ibias;
+    int pr_n = 0, pr_nv = 0;
+    std::vector<int32_t> pr_vid, pr_size, pr_idx;
+    std::vector<double> pr_x0, pr_J0, pr_r0;
+    plba::Robust rob;
+    // shard
+    int rank = 0, world = 1;
+    plba_allreduce_fn xfn = nullptr;
+    void* xuser = nullptr;
+    // ---- derived structure ---------------------------------------------------------------------
+    bool dirty = true;                    // device image must be rebuilt
+    int P = 0, Ppad = 0, ld = 0, L = 0, E = 0;
+    std::vector<int32_t> off_pvr, off_bias;
+    int cur = 0;                          // index of the current estimate buffers
+    // ---- device ----------------------------------------------------------------------------------
+    plba::DArr<double> d_kf[2], d_kf_saved, d_lm[2], d_lm_saved;
+    plba::DArr<double> d_po_uv, d_lo_l, d_ob_w, d_ob_chi2, d_erec;
+    plba::DArr<int32_t> d_ob_kf, d_ob_slot, d_lm_start, d_off_pvr, d_off_bias;
+    plba::DArr<uint8_t> d_level, d_lm_fixed, d_lm_active, d_depth;
+    plba::DArr<double> d_hll, d_bl, d_dinv, d_tv, d_xl;
+    plba::DArr<int32_t> d_pair_i, d_pair_j, d_pair_start, d_ent_ei, d_ent_ej;
+    plba::DArr<int32_t> d_imu_i, d_imu_j;
+    plba::DArr<double> d_imu_pre, d_imu_ipvr, d_imu_ibias, d_imu_err, d_imu_chi;
+    plba::DArr<int32_t> d_pr_kf, d_pr_isbias, d_pr_size, d_pr_idx, d_pr_x0off, d_pr_off;
+    plba::DArr<double> d_pr_x0, d_pr_J0, d_pr_r0, d_pr_err, d_pr_dx, d_pr_chi, d_pr_H;
+    plba::DArr<double> d_Hconst, d_Himu, d_bimu, d_sys, d_Lfac, d_bpg, d_x;
+    plba::DArr<double> d_chi_part, d_scale_part, d_maxd_part, d_kfdiag, d_red;
+    plba::DArr<plba::Ctrl> d_ctrl;
+    plba::DArr<plba_trace_row> d_trace;
+    plba::DArr<int> d_trace_n;
+    plba::Ctrl* h_ctrl = nullptr;               // pinned
+    plba::DevBuf dv;
+    std::vector<plba_trace_row> trace;
+    bool saved_valid = false;
+};
+
+
+#define PLBA_FAIL(p, code, ...)                             \
+    do {                                                    \
+        snprintf((p)->err, sizeof((p)->err), __VA_ARGS__);  \
+        return (code);                                      \
+    } while (0)
+#define PLBA_HIPCK(p, call)                                                                                   \
+    do {                                                                                                      \
+        hipError_t e__ = (call);                                                                              \
+        if (e__ != hipSuccess) PLBA_FAIL(p, PLBA_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)

@@ -1,0 +1,217 @@
+"""GPU parity tests: every stage of the HIP hot path against the CPU oracle on identical seeded
+windows, through the C ABI (include/plba.h).  Tolerances are fp64 rounding scaled by magnitude."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-5      # BASELINE.json north_star: final pose deltas within 1e-5 of the reference path
+
+
+def _pair(pkg, orc, w, **opts):
+    g = pkg.new_problem(**opts); g.upload_window(w)
+    o = orc.new_problem(**opts); o.upload_window(w)
+    return g, o
+
+
+def _close(a, b, rtol=1e-9, name=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    sc = max(np.abs(b).max(), 1e-300) if b.size else 1.0
+    err = np.abs(a - b).max() / sc if b.size else 0.0
+    assert err < rtol, "%s: max rel err %.3e (scale %.3e)" % (name, err, sc)
+
+
+def _pose_delta(a, b, pkg):
+    dP = np.abs(a["P"] - b["P"]).max()
+    dV = np.abs(a["V"] - b["V"]).max()
+    dphi = 0.0
+    for qa, qb in zip(a["q"], b["q"]):
+        Ra, Rb = pkg.window.R_from_quat(qa), pkg.window.R_from_quat(qb)
+        dphi = max(dphi, np.linalg.norm(pkg.window.log_so3(Rb.T @ Ra)))
+    db = max(np.abs(a["dbg"] - b["dbg"]).max(), np.abs(a["dba"] - b["dba"]).max())
+    return dP, dV, dphi, db
+
+
+def test_backend_is_the_hip_library(hip):
+    assert hip.backend_name() == "hip-gfx950"
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 200, 750])
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_dense_solver_vs_numpy(pkg, hip, n, mfma):
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n)); A = A @ A.T + n * np.eye(n)
+    b = rng.normal(size=n)
+    p = pkg.new_problem(use_mfma=mfma)
+    x, ok = p.debug_dense_solve(A, b)
+    assert ok
+    _close(x, np.linalg.solve(A, b), 1e-9, "x")
+    # a non positive definite matrix must be reported, not silently solved
+    A[n // 2, n // 2] = -1.0
+    _, ok = p.debug_dense_solve(A, b)
+    assert not ok
+    p.close()
+
+
+@pytest.mark.parametrize("imu", [True, False])
+def test_edge_errors_and_depth(pkg, orc, hip, imu):
+    w = pkg.window.make_window(8, 300, 70, imu=imu, seed=101)
+    g, o = _pair(pkg, orc, w)
+    g.recompute_errors(); o.recompute_errors()
+    for kind in (pkg.abi.EDGE_POINT, pkg.abi.EDGE_LINE) + ((pkg.abi.EDGE_IMU_PVR, pkg.abi.EDGE_IMU_BIAS) if imu else ()):
+        cg, dg = g.edge_chi2(kind); co, do = o.edge_chi2(kind)
+        _close(cg, co, 1e-9, "chi2 kind %d" % kind)
+        assert np.array_equal(dg, do)
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("imu", [True, False])
+def test_build_system_and_schur(pkg, orc, hip, imu):
+    w = pkg.window.make_window(7, 200, 50, imu=imu, seed=102)
+    g, o = _pair(pkg, orc, w)
+    lam = 12.5
+    g.debug_build(lam, False); o.debug_build(lam, False)
+    assert g.debug_get("pose_dim")[0] == o.debug_get("pose_dim")[0]
+    for name in ("err_pt", "err_ln", "hll_pt", "bl_pt", "hll_ln", "bl_ln", "chi2", "maxdiag", "bp", "bschur", "Hschur") + \
+            (("err_pvr", "err_bias") if imu else ()):
+        _close(g.debug_get(name), o.debug_get(name), 1e-9, name)
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_one_damped_solve(pkg, orc, hip, mfma):
+    w = pkg.window.make_window(7, 200, 50, imu=True, seed=103)
+    g, o = _pair(pkg, orc, w, use_mfma=mfma)
+    g.debug_build(3.0, True); o.debug_build(3.0, True)
+    assert g.debug_get("solver_ok")[0] == 1
+    _close(g.debug_get("x"), o.debug_get("x"), 1e-7, "x")
+    g.close(); o.close()
+
+
+def test_lm_trace_and_final_state(pkg, orc, hip):
+    w = pkg.window.make_window(10, 400, 80, imu=True, seed=104)
+    g, o = _pair(pkg, orc, w)
+    sg, so = g.optimize(5), o.optimize(5)
+    assert (sg.iterations, sg.trials, sg.stop_reason) == (so.iterations, so.trials, so.stop_reason)
+    tg, to = g.trace(), o.trace()
+    assert len(tg) == len(to)
+    for a, b in zip(tg, to):
+        assert (a["iteration"], a["trial"], a["accepted"], a["solver_ok"]) == (b["iteration"], b["trial"], b["accepted"], b["solver_ok"])
+        for k in ("lam", "chi2_current", "chi2_trial", "scale"):
+            assert a[k] == pytest.approx(b[k], rel=1e-7), k
+    kg, ko = g.get_keyframes(), o.get_keyframes()
+    assert max(_pose_delta(kg, ko, pkg)) < 1e-8
+    _close(g.get_points(), o.get_points(), 1e-8, "points")
+    _close(g.get_lines(), o.get_lines(), 1e-8, "lines")
+    assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-8)
+    g.close(); o.close()
+
+
+def _two_stage(pkg, orc, w, tol=POSE_TOL):
+    g, o = _pair(pkg, orc, w)
+    rg, ro = pkg.protocol.local_ba(g), pkg.protocol.local_ba(o)
+    assert rg["gated"] == ro["gated"]
+    assert np.array_equal(g.get_levels(pkg.abi.EDGE_POINT), o.get_levels(pkg.abi.EDGE_POINT))
+    assert np.array_equal(g.get_levels(pkg.abi.EDGE_LINE), o.get_levels(pkg.abi.EDGE_LINE))
+    assert rg["stage2"].iterations == ro["stage2"].iterations and rg["stage2"].trials == ro["stage2"].trials
+    d = _pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)
+    assert max(d) < tol, d
+    assert np.abs(g.get_points() - o.get_points()).max() < 10 * tol
+    assert np.abs(g.get_lines() - o.get_lines()).max() < 10 * tol
+    assert rg["stage2"].chi2_final == pytest.approx(ro["stage2"].chi2_final, rel=1e-6)
+    g.close(); o.close()
+    return d
+
+
+def test_two_stage_protocol_small(pkg, orc, hip):
+    _two_stage(pkg, orc, pkg.window.make_window(12, 500, 100, imu=True, seed=105))
+
+
+def test_config1_full_size_no_imu(pkg, orc, hip):
+    """BASELINE configs[0]: 10 KF / 2k points / 500 lines, no IMU, no marg."""
+    _two_stage(pkg, orc, pkg.window.make_config(1))
+
+
+def test_config2_no_imu_reduced(pkg, orc, hip):
+    _two_stage(pkg, orc, pkg.window.make_config(2, scale=0.2))
+
+
+def test_config3_imu_reduced(pkg, orc, hip):
+    _two_stage(pkg, orc, pkg.window.make_config(3, scale=0.1))
+
+
+def test_levels_and_inactive_landmarks(pkg, orc, hip):
+    w = pkg.window.make_window(6, 120, 30, imu=True, seed=106)
+    g, o = _pair(pkg, orc, w)
+    lv = np.zeros(len(w["po_pt"]), np.uint8); lv[(w["po_pt"] == 3) | (w["po_pt"] % 7 == 0)] = 1
+    ll = np.zeros(len(w["lo_ln"]), np.uint8); ll[w["lo_ln"] == 2] = 1
+    for p in (g, o):
+        p.set_levels(pkg.abi.EDGE_POINT, lv); p.set_levels(pkg.abi.EDGE_LINE, ll)
+    sg, so = g.optimize(3), o.optimize(3)
+    assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-8)
+    _close(g.get_points(), o.get_points(), 1e-8, "points")
+    assert np.array_equal(g.get_points()[3], w["points"][3])
+    g.close(); o.close()
+
+
+def test_rejected_trials_follow_the_oracle(pkg, orc, hip):
+    w = pkg.window.make_window(5, 60, 10, imu=False, seed=13)
+    w["points"] = w["points"] + np.random.default_rng(0).normal(size=w["points"].shape) * 1.5
+    g, o = _pair(pkg, orc, w, user_lambda_init=1e-9)
+    sg, so = g.optimize(4), o.optimize(4)
+    tg, to = g.trace(), o.trace()
+    assert [r["accepted"] for r in tg] == [r["accepted"] for r in to]
+    assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-6)
+    g.close(); o.close()
+
+
+def test_prior_edge_parity(pkg, orc, hip):
+    """BA with a marginalization prior: the oracle's prior on both sides (SURVEY B-Q3 decision)."""
+    w0 = pkg.window.make_window(12, 260, 50, imu=True, seed=22)
+    o = orc.new_problem(); o.upload_window(w0)
+    pkg.protocol.local_ba(o)
+    pr = o.marginalize(0, 50)
+    o.close()
+    w0["prior"] = pr        # kept vertices all exist in w0 as well; KF0 itself is not among them
+    w0["kf"]["fixed_pvr"] = np.zeros(12, np.uint8); w0["kf"]["fixed_pvr"][0] = 1
+    g, o = _pair(pkg, orc, w0)
+    g.debug_build(5.0, False); o.debug_build(5.0, False)
+    for name in ("err_prior", "bp", "bschur", "Hschur", "chi2", "maxdiag"):
+        _close(g.debug_get(name), o.debug_get(name), 1e-9, name)
+    sg, so = g.optimize(4), o.optimize(4)
+    assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-8)
+    assert max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)) < 1e-8
+    g.close(); o.close()
+
+
+def test_save_restore_replays_identically(pkg, hip):
+    w = pkg.window.make_window(8, 200, 40, imu=True, seed=107)
+    g = pkg.new_problem(); g.upload_window(w)
+    g.save_state()
+    a = g.optimize(4); ka = g.get_keyframes()
+    g.restore_state()
+    b = g.optimize(4); kb = g.get_keyframes()
+    assert a.chi2_final == pytest.approx(b.chi2_final, rel=1e-12)
+    assert np.abs(ka["P"] - kb["P"]).max() < 1e-12
+    g.close()
+
+
+def test_abort_and_errors(pkg, hip):
+    w = pkg.window.make_window(5, 40, 8, imu=True, seed=15)
+    g = pkg.new_problem(); g.upload_window(w)
+    st = g.optimize(5, np.ones(1, np.uint8))
+    assert st.iterations == 0 and st.stop_reason == 2
+    bad = w["po_pt"].copy(); bad[0], bad[-1] = bad[-1], bad[0]
+    with pytest.raises(pkg.abi.PlbaError):
+        g.set_point_obs(bad, w["po_kf"], w["po_uv"], w["po_w"])
+    g.close()
+    e = pkg.new_problem()
+    with pytest.raises(pkg.abi.PlbaError):
+        e.optimize(1)
+    e.close()
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
