@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""bench.py — local-BA LM iterations/second on a synthetic EuRoC-shaped window (BASELINE.json metric).
+
+A "step" is one outer Levenberg-Marquardt iteration of the local bundle adjustment (one g2o
+OptimizationAlgorithmLevenberg::solve(): one linearisation + >= 1 damped trial solve) on a
+device-resident window.  Protocol per window (reference call site src/mapHandler.cpp:6038-6069):
+stage 1 optimize(5) with Huber + chi2/depth gating run once untimed; the timed region replays
+stage 2 (optimize(10), no Huber on point/line edges) from the saved post-gating state until exactly
+K iterations have run.
+
+N = 1  : BASELINE configs[2] — 50 KF / 20k points / 4k lines + IMU (the metric's configuration).
+N > 1  : landmarks sharded over ranks, one RCCL all-reduce of the reduced camera system
+         per trial; weak scaling: every rank holds a 20k-point / 4k-line shard of a window whose
+         landmark count grows with N (N = 8, K = 200 is BASELINE configs[4]); `value` counts
+         shard-iterations (N per global LM iteration) so that it aggregates like a throughput.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (spec), v_mfma_f64_16x16x4_f64
+
+
+def stage1_and_gate(prob, pkg):
+    prob.optimize(pkg.protocol.STAGE1_ITERS)
+    prob.gate_outliers(pkg.window.CHI2_GATE)
+    prob.save_state()
+
+
+def run_iterations(prob, n_iters, per_call=10):
+    """Replay stage 2 from the saved state until exactly n_iters LM iterations ran."""
+    done, trials, phases = 0, 0, np.zeros(8)
+    guard = 0
+    while done < n_iters:
+        prob.restore_state()
+        st = prob.optimize(min(per_call, n_iters - done))
+        if st.iterations == 0:
+            guard += 1
+            if guard > 3:
+                raise RuntimeError("optimize() makes no progress")
+        done += st.iterations
+        trials += st.trials
+        phases += np.array(list(st.ms_phase))
+    return done, trials, phases
+
+
+def cpu_baseline(w, pkg, budget_s=20.0):
+    """The CPU oracle (restatement of the reference's g2o path) timed on this box's host cores on a
+    bounded sample of the same window: stage-2 LM iterations until ~budget_s of CPU work."""
+    from oracle import oracle as orc
+    p = orc.new_problem()
+    p.upload_window(w)
+    stage1_and_gate(p, pkg)
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        p.restore_state()
+        st = p.optimize(2)
+        iters += st.iterations
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= 200:
+            break
+    p.close()
+    return dict(value=iters / el, unit="iterations/s", cores=1, kind="port",
+                sample="%d stage-2 LM iterations of the same window on 1 host thread (%.1f s); %d host cores present" % (
+                    iters, el, os.cpu_count() or 0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink landmark counts (debug only; invalidates the number)")
+    ap.add_argument("--kf", type=int, default=0, help="override the keyframe count (debug only)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    ge.build_hip()
+    pkg = ge.load_package()
+    win = pkg.window
+
+    # ---- workload -------------------------------------------------------------------------------
+    if world == 1:
+        cfg = dict(win.CONFIGS[3])
+        name = "configs[2]: 50 KF / 20k points / 4k lines + IMU preintegration edges (9-DoF PVR + 6-DoF bias vertices)"
+    else:
+        cfg = dict(K=200 if world == 8 else 50, Np=25000 * world if world == 8 else 20000 * world,
+                   Nl=5000 * world if world == 8 else 4000 * world, imu=True)
+        name = "%d KF / %d points / %d lines + IMU, landmarks sharded over %d ranks" % (cfg["K"], cfg["Np"], cfg["Nl"], world)
+    if args.kf:
+        cfg["K"] = args.kf
+    cfg["Np"] = max(1, int(cfg["Np"] * args.scale)); cfg["Nl"] = max(1, int(cfg["Nl"] * args.scale))
+    w_full = win.make_window(cfg["K"], cfg["Np"], cfg["Nl"], imu=cfg["imu"], seed=0x5EED0003 if world == 1 else 0x5EED0005)
+    w = win.shard_window(w_full, rank, world) if world > 1 else w_full
+
+    stream = torch.cuda.Stream()
+    prob = pkg.new_problem(profile=1)
+    prob.set_stream(stream.cuda_stream)
+    prob.upload_window(w)
+    if world > 1:
+        prob.set_shard(rank, world, pkg.distributed.make_allreduce(dist, local_rank, stream))
+
+    stage1_and_gate(prob, pkg)
+    run_iterations(prob, max(args.warmup, 1))
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    done, trials, phases = run_iterations(prob, args.steps)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    m = w["meta"] if world == 1 else dict(Ep=len(w["po_pt"]), El=len(w["lo_ln"]), Np=len(w["points"]), Nl=len(w["lines"]))
+    Ep, El, Npl, Nll = (m["Ep"], m["El"], m["Np"], m["Nl"])
+    # algorithmic bytes: 32 B per point observation, 40 B per line observation, landmarks 24 / 48 B
+    bytes_lin = 32 * Ep + 40 * El + 24 * Npl + 48 * Nll                 # one k_linearize launch
+    b_iter = 2 * (32 * Ep + 40 * El) + 3 * (24 * Npl + 48 * Nll)        # one LM iteration
+    lin_ms = phases[0] / max(done, 1)
+    solve_ms = phases[3] / max(trials, 1)
+    P = int(prob.debug_get("pose_dim")[0])
+    flops_solve = P ** 3 / 3.0 + 2.0 * P * P
+    phase_names = ["linearize_kernel", "pose_edges", "schur", "dense_solve", "backsub_update", "trial_errors", "exchange", "landmark_blocks_and_reductions"]
+    per_iter = {k: float(v / max(done, 1)) for k, v in zip(phase_names, phases)}
+    dominant = max(per_iter, key=per_iter.get)
+    roof_hbm = dict(bound="hbm", kernel="k_linearize<true>", achieved=bytes_lin / (lin_ms * 1e-3) / 1e9 if lin_ms > 0 else None,
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=(bytes_lin / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lin_ms > 0 else None,
+                    traffic=None, algorithmic_bytes_per_launch=bytes_lin, avg_launch_ms=lin_ms)
+    roof_mfma = dict(bound="mfma", kernel="dense solve: k_chol_diag + k_chol_step<MFMA> + k_trsv_back (P=%d)" % P,
+                     achieved=flops_solve / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else None, peak=FP64_MFMA_PEAK_TFLOPS,
+                     unit="TFLOP/s", frac=(flops_solve / (solve_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS) if solve_ms > 0 else None,
+                     traffic=None, algorithmic_flops_per_launch=flops_solve, avg_launch_ms=solve_ms)
+    roofline = roof_mfma if dominant == "dense_solve" else roof_hbm
+
+    out = {
+        "metric": "local-BA iterations/sec (50 KF, 20k pts, 4k lines, IMU)",
+        "value": world * done / dt,
+        "unit": "iterations/s" if world == 1 else "shard-iterations/s (N per global LM iteration)",
+        "n_gpus": world, "steps": done, "warmup": args.warmup, "ms_per_step": dt / done * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": name, "K": cfg["K"], "points": cfg["Np"], "lines": cfg["Nl"], "point_obs": int(Ep), "line_obs": int(El),
+                   "pose_dim": P, "trials_per_iteration": trials / max(done, 1), "protocol": "stage-2 LM iterations (no Huber on point/line edges) replayed from the post-gating state",
+                   "global_iterations_per_s": done / dt, "algorithmic_bytes_per_iteration": b_iter,
+                   "hbm_frac_whole_iteration": b_iter / (dt / done) / 1e9 / HBM_PEAK_GBS},
+        "roofline": roofline,
+        "roofline_hbm_kernel": roof_hbm,
+        "roofline_dense_solve": roof_mfma,
+        "phase_ms_per_iteration": per_iter,
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w_full, pkg)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    prob.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,7 @@ The directory name contains a hyphen (it mirrors the reference repository's name
 """
 import os
 
-from . import abi, window, protocol  # noqa: F401
+from . import abi, window, protocol, distributed  # noqa: F401
 from .abi import (EDGE_POINT, EDGE_LINE, EDGE_IMU_PVR, EDGE_IMU_BIAS, EDGE_PRIOR, PlbaError,  # noqa: F401
                   Problem)
 

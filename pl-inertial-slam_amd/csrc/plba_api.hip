@@ -92,6 +92,7 @@ void plba_destroy(plba_problem* p) {
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+    if (p->ev_ready) for (auto& e : p->ev) (void)hipEventDestroy(e);
     if (p->h_ctrl) (void)hipHostFree(p->h_ctrl);
     delete p;
 }
@@ -467,13 +468,17 @@ static LmParams lm_params(const plba_problem* p) {
 }
 
 // computeActiveErrors + buildSystem for the current estimate (everything lambda-independent)
+#define MARK(p, i) do { if ((p)->opt.profile) HIPCK(p, hipEventRecord((p)->ev[i], (p)->stream)); } while (0)
 static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
     const DevBuf& d = p->dv;
     hipStream_t s = p->stream;
+    MARK(p, 0);
     launch_linearize(d, p->cur, true, p->rob, s);
+    MARK(p, 1);
     HIPCK(p, hipMemcpyAsync(d.Himu, d.Hconst, (size_t)d.Ppad * d.ld * 8, hipMemcpyDeviceToDevice, s));
     HIPCK(p, hipMemsetAsync(d.bimu, 0, (size_t)d.ld * 8, s));
     launch_pose_edges(d, p->cur, true, p->rob, owns_pose_edges(p), s);
+    MARK(p, 2);
     launch_landmark_hll(d, s);
     if (first_iter) {
         HIPCK(p, hipMemsetAsync(d.kfdiag, 0, (size_t)d.K * 6 * 8, s));
@@ -489,22 +494,28 @@ static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
         }
     }
     launch_lambda_init2(d, lm_params(p), p->d_red.p, first_iter, iteration, s);
+    MARK(p, 3);
     return PLBA_OK;
 }
 // setLambda + Schur complement (+ optional dense solve, back-substitution, trial update)
 static int enqueue_solve(plba_problem* p, bool do_solve) {
     const DevBuf& d = p->dv;
     hipStream_t s = p->stream;
+    MARK(p, 4);
     launch_landmark_dinv(d, s);
     launch_assemble(d, owns_pose_edges(p), s);
     launch_schur_pairs(d, s);
+    MARK(p, 5);
     if (p->world > 1) { int rc = exchange(p, d.sys, (size_t)(d.Ppad + 2) * d.ld, 0); if (rc) return rc; }
     HIPCK(p, hipMemcpyAsync(d.bpg, d.sys + (size_t)(d.Ppad + 1) * d.ld, (size_t)d.ld * 8, hipMemcpyDeviceToDevice, s));
+    MARK(p, 6);
     if (!do_solve) return PLBA_OK;
     launch_cholesky(d, p->opt.use_mfma != 0, s);
     launch_trsv_back(d, s);
+    MARK(p, 7);
     launch_backsub(d, p->cur, p->cur ^ 1, s);
     launch_update_kf(d, p->cur, p->cur ^ 1, s);
+    MARK(p, 8);
     return PLBA_OK;
 }
 
@@ -529,6 +540,11 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
     const LmParams lp = lm_params(p);
     bool ok = true;
     double last_chi = 0.0, lambda = 0.0;
+    if (p->opt.profile && !p->ev_ready) {
+        for (auto& e : p->ev) HIPCK(p, hipEventCreate(&e));
+        p->ev_ready = true;
+    }
+    auto span = [&](int a, int b) -> double { float ms = 0.f; return hipEventElapsedTime(&ms, p->ev[a], p->ev[b]) == hipSuccess ? (double)ms : 0.0; };
     for (int it = 0; it < max_iters && !(abort_flag && *abort_flag) && ok; ++it) {
         if ((rc = enqueue_linearize(p, it == 0, it))) return rc;
         double rho = 0.0;
@@ -538,11 +554,18 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             const int trial = p->cur ^ 1;
             launch_linearize(d, trial, false, p->rob, s);
             launch_pose_edges(d, trial, false, p->rob, owns_pose_edges(p), s);
+            MARK(p, 9);
             launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
             if (p->world > 1 && (rc = exchange(p, p->d_red.p, 2, 0))) return rc;
             launch_decide(d, lp, p->d_red.p, s);
+            MARK(p, 10);
             HIPCK(p, hipMemcpyAsync(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
             HIPCK(p, hipStreamSynchronize(s));
+            if (p->opt.profile) {
+                if (qmax == 0) { st.ms_phase[0] += span(0, 1); st.ms_phase[1] += span(1, 2); st.ms_phase[7] += span(2, 3); }
+                st.ms_phase[2] += span(4, 5); st.ms_phase[6] += span(5, 6); st.ms_phase[3] += span(6, 7);
+                st.ms_phase[4] += span(7, 8); st.ms_phase[5] += span(8, 9); st.ms_phase[7] += span(9, 10);
+            }
             const Ctrl& c = *p->h_ctrl;
             rho = c.rho;
             lambda = c.lambda;

@@ -88,6 +88,8 @@ struct plba_problem {
     plba::DevBuf dv;
     std::vector<plba_trace_row> trace;
     bool saved_valid = false;
+    hipEvent_t ev[18] = {};               // phase boundaries of one trial (options.profile)
+    bool ev_ready = false;
 };
 
 
