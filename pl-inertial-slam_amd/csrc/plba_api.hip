@@ -262,15 +262,18 @@ int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double
     for (int r = 0; r < n; ++r) memcpy(&h[(size_t)r * ld], A + (size_t)r * n, (size_t)n * 8);
     for (int r = n; r < Ppad; ++r) h[(size_t)r * ld + r] = 1.0;
     memcpy(&h[(size_t)Ppad * ld], b, (size_t)n * 8);
-    DArr<double> sys, Lfac, xx;
+    DArr<double> sys, Lfac, xx, Linv, LT32, rd32;
     DArr<Ctrl> ctrl;
+    DArr<int> flags;
     HIPCK(p, sys.upload(h)); HIPCK(p, Lfac.alloc(sysn)); HIPCK(p, xx.alloc(ld)); HIPCK(p, ctrl.alloc(1));
+    HIPCK(p, Linv.alloc((size_t)(Ppad / TILE) * TILE * TILE)); HIPCK(p, flags.alloc(Ppad / TILE));
+    HIPCK(p, LT32.alloc((size_t)(Ppad / 32) * 32 * 32)); HIPCK(p, rd32.alloc(Ppad));
     Ctrl c0; memset(&c0, 0, sizeof c0); c0.solver_ok = 1;
     HIPCK(p, hipMemcpy(ctrl.p, &c0, sizeof c0, hipMemcpyHostToDevice));
     DevBuf d; memset(&d, 0, sizeof d);
-    d.P = n; d.Ppad = Ppad; d.ld = ld; d.sys = sys.p; d.Lfac = Lfac.p; d.x = xx.p; d.ctrl = ctrl.p;
+    d.P = n; d.Ppad = Ppad; d.ld = ld; d.sys = sys.p; d.Lfac = Lfac.p; d.x = xx.p; d.ctrl = ctrl.p; d.Linv = Linv.p; d.flow_flags = flags.p; d.LT32 = LT32.p; d.rd32 = rd32.p;
     launch_cholesky(d, p->opt.use_mfma != 0, p->stream);
-    launch_trsv_back(d, p->stream);
+    launch_trsv_back(d, 1, p->stream);
     HIPCK(p, hipStreamSynchronize(p->stream));
     HIPCK(p, hipGetLastError());
     HIPCK(p, hipMemcpy(x, xx.p, (size_t)n * 8, hipMemcpyDeviceToHost));
@@ -397,8 +400,10 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_Hconst.alloc((size_t)p->Ppad * p->ld)); HIPCK(p, p->d_Himu.alloc((size_t)p->Ppad * p->ld));
     HIPCK(p, p->d_bimu.alloc(p->ld)); HIPCK(p, p->d_sys.alloc(sysn)); HIPCK(p, p->d_Lfac.alloc(sysn));
     HIPCK(p, p->d_bpg.alloc(p->ld)); HIPCK(p, p->d_x.alloc(p->ld));
+    HIPCK(p, p->d_Linv.alloc((size_t)(p->Ppad / TILE) * TILE * TILE)); HIPCK(p, p->d_flow_flags.alloc(p->Ppad / TILE)); p->flow_epoch = 0;
+    HIPCK(p, p->d_LT32.alloc((size_t)(p->Ppad / 32) * 32 * 32)); HIPCK(p, p->d_rd32.alloc(p->Ppad));
     HIPCK(p, p->d_chi_part.alloc((size_t)(E + 255) / 256 + 1)); HIPCK(p, p->d_scale_part.alloc((size_t)(L + 255) / 256 + 1));
-    HIPCK(p, p->d_maxd_part.alloc((size_t)(L + 255) / 256 + 1)); HIPCK(p, p->d_kfdiag.alloc((size_t)K * 6));
+    HIPCK(p, p->d_maxd_part.alloc((size_t)(L + 255) / 256 + 1)); HIPCK(p, p->d_kfdiag.alloc((size_t)K * 6)); HIPCK(p, p->d_posediag.alloc(p->ld));
     HIPCK(p, p->d_red.alloc(8)); HIPCK(p, p->d_ctrl.alloc(1)); HIPCK(p, p->d_trace.alloc(TRACE_CAP)); HIPCK(p, p->d_trace_n.alloc(1));
     // ---- kernel argument block -------------------------------------------------------------------------------------
     DevBuf& d = p->dv;
@@ -425,7 +430,8 @@ static int prepare(plba_problem* p) {
     d.pr_x0off = p->d_pr_x0off.p; d.pr_off = p->d_pr_off.p; d.pr_x0 = p->d_pr_x0.p; d.pr_J0 = p->d_pr_J0.p; d.pr_r0 = p->d_pr_r0.p;
     d.pr_err = p->d_pr_err.p; d.pr_dx = p->d_pr_dx.p; d.pr_chi = p->d_pr_chi.p;
     d.Hconst = p->d_Hconst.p; d.Himu = p->d_Himu.p; d.bimu = p->d_bimu.p; d.sys = p->d_sys.p; d.Lfac = p->d_Lfac.p; d.bpg = p->d_bpg.p; d.x = p->d_x.p;
-    d.chi_part = p->d_chi_part.p; d.scale_part = p->d_scale_part.p; d.maxd_part = p->d_maxd_part.p; d.kfdiag = p->d_kfdiag.p;
+    d.Linv = p->d_Linv.p; d.flow_flags = p->d_flow_flags.p; d.LT32 = p->d_LT32.p; d.rd32 = p->d_rd32.p;
+    d.chi_part = p->d_chi_part.p; d.scale_part = p->d_scale_part.p; d.maxd_part = p->d_maxd_part.p; d.kfdiag = p->d_kfdiag.p; d.posediag = p->d_posediag.p;
     d.ctrl = p->d_ctrl.p; d.trace = p->d_trace.p; d.trace_cap = TRACE_CAP; d.trace_n = p->d_trace_n.p;
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
     if (p->pr_nv > 0 && p->rank == 0) {
@@ -490,7 +496,7 @@ static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
         if ((rc = exchange(p, p->d_red.p, 1, 0))) return rc;
         if (first_iter) {
             if ((rc = exchange(p, p->d_red.p + 2, 1, 1))) return rc;
-            if ((rc = exchange(p, d.kfdiag, (size_t)d.K * 6, 0))) return rc;
+            if ((rc = exchange(p, d.posediag, (size_t)d.P, 0))) return rc;
         }
     }
     launch_lambda_init2(d, lm_params(p), p->d_red.p, first_iter, iteration, s);
@@ -511,7 +517,7 @@ static int enqueue_solve(plba_problem* p, bool do_solve) {
     MARK(p, 6);
     if (!do_solve) return PLBA_OK;
     launch_cholesky(d, p->opt.use_mfma != 0, s);
-    launch_trsv_back(d, s);
+    launch_trsv_back(d, ++p->flow_epoch, s);
     MARK(p, 7);
     launch_backsub(d, p->cur, p->cur ^ 1, s);
     launch_update_kf(d, p->cur, p->cur ^ 1, s);

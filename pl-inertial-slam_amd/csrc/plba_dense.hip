@@ -15,74 +15,106 @@
 namespace plba {
 
 typedef double double4v __attribute__((ext_vector_type(4)));
+typedef const double __attribute__((address_space(4))) cdouble;   // constant address space: uniform loads take the scalar path
 
-constexpr int LS = 65;    // LDS row stride of the L tile (conflict-free column walks)
-constexpr int XS = 80;    // LDS row stride of the transposed panel tiles XT[k][row]
+constexpr int FB = 32;    // factorisation block (in-wave potrf / trsm); the back-substitution works on 64-wide tiles
+constexpr int XS = 80;    // LDS row stride of the transposed panel tiles XT[k][row]  (rows 0..31 = X_r, 32..63 = X_c)
+constexpr int CS = FB + 1;
 
-__global__ __launch_bounds__(256) void k_chol_diag(DevBuf d, int k) {
-    __shared__ double sA[TILE * LS];
-    const int ld = d.ld;
-    const double* A = d.sys + (size_t)(k * TILE) * ld + k * TILE;
-    double* Lo = d.Lfac + (size_t)(k * TILE) * ld + k * TILE;
-    for (int idx = threadIdx.x; idx < TILE * TILE; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        sA[r * LS + c] = A[(size_t)r * ld + c];
+// broadcast lane `l` (compile-time constant after unrolling) of a double: two v_readlane_b32 -> SGPR pair
+__device__ __forceinline__ double bcast(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+
+// x L^T = a for the row held in this lane's registers.  LTg[j*NB + t] = L[t][j] and rdg[j] = 1/L[j][j] live in
+// global memory written by an EARLIER kernel; they are wave-uniform, so the loads go through the scalar cache
+// (s_load_dwordx16) and feed v_fma_f64 as SGPR operands: no LDS traffic, no dependent accumulation chain.
+template <int NB>
+__device__ __forceinline__ void trsm_row_scalar(double* x, const double* LTg, const double* rdg) {
+    cdouble* LT = (cdouble*)(uintptr_t)LTg;
+    cdouble* rd = (cdouble*)(uintptr_t)rdg;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        x[j] *= rd[j];
+        const double xj = x[j];
+#pragma unroll
+        for (int t = j + 1; t < NB; ++t) x[t] = fma(-xj, LT[j * NB + t], x[t]);
     }
-    const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
+}
+
+// Right-looking Cholesky of an NB x NB tile inside ONE wavefront, lane i holding the full symmetric row i in
+// registers.  Column j: lane j's entries are broadcast with v_readlane (no LDS, no barrier) and every lane applies
+//   a[i][c] -= a[i][j] * a[j][c] / a[j][j];
+// only a reciprocal sits on the dependency chain.  On return a[j] = L[i][j] for j <= i.
+template <int NB>
+__device__ __forceinline__ bool potrf_inwave(double* a, int lane) {
     bool bad = false;
-    for (int j = 0; j < TILE; ++j) {
-        __syncthreads();
-        const double djj = sA[j * LS + j];
-        const bool bj = !(djj > 0.0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double sj = bcast(a[j], j);
+        const bool bj = !(sj > 0.0);
         bad = bad || bj;
-        const double ljj = bj ? 1.0 : sqrt(djj);
-        const double lij = sA[i * LS + j] / ljj;
-        __syncthreads();
-        if (g == 0) {
-            if (i > j) sA[i * LS + j] = lij;
-            else if (i == j) sA[j * LS + j] = ljj;
+        const double rinv = 1.0 / (bj ? 1.0 : sj);
+        const double f = a[j] * rinv;
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) {
+            const double sc = bcast(a[c], j);
+            a[c] = fma(-f, sc, a[c]);
         }
-        __syncthreads();
-        if (i > j)
-            for (int c = j + 1 + g; c <= i; c += 4) sA[i * LS + c] -= lij * sA[c * LS + j];
     }
-    __syncthreads();
-    if (bad && threadIdx.x == 0) d.ctrl->solver_ok = 0;
-    for (int idx = threadIdx.x; idx < TILE * TILE; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        Lo[(size_t)r * ld + c] = (c <= r) ? sA[r * LS + c] : 0.0;
-    }
+    double dg = 1.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) if (lane == j) dg = a[j];
+    const double rs = 1.0 / sqrt(dg > 0.0 ? dg : 1.0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) a[j] *= bcast(rs, j);
+    return bad;
 }
 
-// X L^T = A  for one 64-row panel tile: lane `row` keeps its row in registers.
-__device__ __forceinline__ void trsm_row(const double* __restrict__ grow, const double* sL, double* sXT, int row, double* __restrict__ gout) {
-    double x[TILE];
+// store the factor of diagonal block kb: L rows into Lfac (zero above the diagonal), the transposed copy and the
+// reciprocal diagonal for the scalar-path TRSM of the next step
+__device__ __forceinline__ void store_factor(const DevBuf& d, int kb, const double* a, int lane, bool bad) {
+    const int ld = d.ld;
+    double* Lrow = d.Lfac + (size_t)(kb * FB + lane) * ld + kb * FB;
+    double* LT = d.LT32 + (size_t)kb * FB * FB;
 #pragma unroll
-    for (int j = 0; j < TILE; j += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(grow + j);
-        x[j] = v.x; x[j + 1] = v.y;
+    for (int j = 0; j < FB; j += 2) {
+        const double v0 = (j <= lane) ? a[j] : 0.0, v1 = (j + 1 <= lane) ? a[j + 1] : 0.0;
+        *reinterpret_cast<double2*>(Lrow + j) = make_double2(v0, v1);
     }
 #pragma unroll
-    for (int j = 0; j < TILE; ++j) {
-        double s = x[j];
+    for (int j = 0; j < FB; ++j) LT[j * FB + lane] = (lane > j) ? a[j] : 0.0;
+    double dg = 1.0;
 #pragma unroll
-        for (int t = 0; t < j; ++t) s -= x[t] * sL[j * LS + t];
-        x[j] = s / sL[j * LS + j];
-    }
-#pragma unroll
-    for (int j = 0; j < TILE; ++j) sXT[j * XS + row] = x[j];
-    if (gout) {
-#pragma unroll
-        for (int j = 0; j < TILE; j += 2) *reinterpret_cast<double2*>(gout + j) = make_double2(x[j], x[j + 1]);
-    }
+    for (int j = 0; j < FB; ++j) if (lane == j) dg = a[j];
+    d.rd32[kb * FB + lane] = 1.0 / dg;
+    if (bad && lane == 0) d.ctrl->solver_ok = 0;
 }
 
+__global__ __launch_bounds__(64) void k_potrf0(DevBuf d) {
+    const int lane = threadIdx.x;
+    if (lane >= FB) return;
+    double a[FB];
+    const double* row = d.sys + (size_t)lane * d.ld;
+#pragma unroll
+    for (int j = 0; j < FB; j += 2) { const double2 v = *reinterpret_cast<const double2*>(row + j); a[j] = v.x; a[j + 1] = v.y; }
+    const bool bad = potrf_inwave<FB>(a, lane);
+    store_factor(d, 0, a, lane, bad);
+}
+
+// One launch per block step k (right-looking, 32-wide blocks).  Workgroup (r,c), k < c <= r <= T (r == T is the
+// right-hand-side block row):
+//   wave 0, lanes 0-31 : X_r = A(r,k) L(k,k)^-T     lanes 32-63 : X_c = A(c,k) L(k,k)^-T     (scalar-path TRSM)
+//   all 4 waves        : A(r,c) -= X_r X_c^T  on the matrix cores (v_mfma_f64_16x16x4_f64), one 16x16 tile per wave
+//   look-ahead         : the workgroup of (k+1,k+1) factors its freshly updated tile in-wave and publishes
+//                        L(k+1,k+1), so the next launch can start its TRSMs immediately.
 template <bool MFMA>
 __global__ __launch_bounds__(256) void k_chol_step(DevBuf d, int k, int T) {
-    extern __shared__ double s_dyn[];
-    double* sL = s_dyn;                       // 64 x LS
-    double* sXr = sL + TILE * LS;             // 64 x XS  (transposed: [kk][row])
-    double* sXc = sXr + TILE * XS;
+    __shared__ double sXT[FB * XS];
+    __shared__ double sC[FB * CS];
     const int ld = d.ld;
     const int nt = T - k - 1;
     const int b = blockIdx.x;
@@ -97,144 +129,206 @@ __global__ __launch_bounds__(256) void k_chol_step(DevBuf d, int k, int T) {
         rr = nt;
         cc = b - ntri;
     }
-    const int r = k + 1 + rr, c = k + 1 + cc;   // r == T is the right-hand-side tile row
-    const double* Lkk = d.Lfac + (size_t)(k * TILE) * ld + k * TILE;
-    for (int idx = threadIdx.x; idx < TILE * TILE; idx += 256) {
-        const int rw = idx >> 6, cl = idx & 63;
-        sL[rw * LS + cl] = Lkk[(size_t)rw * ld + cl];
-    }
-    __syncthreads();
+    const int r = k + 1 + rr, c = k + 1 + cc;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool have_update = (c < T);
     if (wv == 0) {
-        // the solved panel tile is the final L(r,k); it goes to Lfac, never back into sys, because other
-        // workgroups of this launch still read the unsolved panel from sys
-        const double* grow = d.sys + (size_t)(r * TILE + lane) * ld + k * TILE;
-        double* gout = d.Lfac + (size_t)(r * TILE + lane) * ld + k * TILE;
-        trsm_row(grow, sL, sXr, lane, (c == k + 1) ? gout : nullptr);
-    } else if (wv == 1 && have_update && c != r) {
-        const double* grow = d.sys + (size_t)(c * TILE + lane) * ld + k * TILE;
-        trsm_row(grow, sL, sXc, lane, nullptr);
+        const bool upper = lane >= FB;
+        const int rl = lane & (FB - 1);
+        const bool active = !upper || (have_update && c != r);
+        if (active) {
+            const int br = upper ? c : r;
+            const double* grow = d.sys + (size_t)(br * FB + rl) * ld + k * FB;
+            double x[FB];
+#pragma unroll
+            for (int j = 0; j < FB; j += 2) { const double2 v = *reinterpret_cast<const double2*>(grow + j); x[j] = v.x; x[j + 1] = v.y; }
+            trsm_row_scalar<FB>(x, d.LT32 + (size_t)k * FB * FB, d.rd32 + k * FB);
+#pragma unroll
+            for (int j = 0; j < FB; ++j) sXT[j * XS + lane] = x[j];
+            if (!upper && c == k + 1) {
+                // the solved panel block is the final L(r,k); it goes to Lfac, never back into sys: other
+                // workgroups of this launch still read the unsolved panel from sys
+                double* gout = d.Lfac + (size_t)(r * FB + rl) * ld + k * FB;
+#pragma unroll
+                for (int j = 0; j < FB; j += 2) *reinterpret_cast<double2*>(gout + j) = make_double2(x[j], x[j + 1]);
+            }
+        }
     }
     if (!have_update) return;
     __syncthreads();
-    const double* XC = (c == r) ? sXr : sXc;
-    double* C = d.sys + (size_t)(r * TILE) * ld + c * TILE;
+    const int cb = (c == r) ? 0 : FB;
+    double* C = d.sys + (size_t)(r * FB) * ld + c * FB;
+    const bool lookahead = (r == k + 1 && c == k + 1);
     if (MFMA) {
-        // wave wv owns rows 16wv..16wv+15; 4 column tiles of 16
-        double4v acc[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[n] = (double4v){0.0, 0.0, 0.0, 0.0};
+        const int tr = wv >> 1, tc = wv & 1;
         const int li = lane & 15, lk = lane >> 4;
-#pragma unroll 4
-        for (int kk = 0; kk < TILE / 4; ++kk) {
-            const double a = sXr[(kk * 4 + lk) * XS + wv * 16 + li];
+        double4v acc = (double4v){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const double bv = XC[(kk * 4 + lk) * XS + n * 16 + li];
-                acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[n], 0, 0, 0);
-            }
+        for (int kk = 0; kk < FB / 4; ++kk) {
+            const double av = sXT[(kk * 4 + lk) * XS + tr * 16 + li];
+            const double bv = sXT[(kk * 4 + lk) * XS + cb + tc * 16 + li];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
         }
         // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int row = wv * 16 + lk + 4 * v, col = n * 16 + li;
-                C[(size_t)row * ld + col] -= acc[n][v];
-            }
+        for (int v = 0; v < 4; ++v) {
+            const int row = tr * 16 + lk + 4 * v, col = tc * 16 + li;
+            const double nv = C[(size_t)row * ld + col] - acc[v];
+            if (lookahead) sC[row * CS + col] = nv;
+            else C[(size_t)row * ld + col] = nv;
+        }
     } else {
-        const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-        double acc[4][4];
+        const int row = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int kk = 0; kk < FB; ++kk) {
+            const double av = sXT[kk * XS + row];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[a][q] = 0.0;
-        for (int kk = 0; kk < TILE; ++kk) {
-            double ar[4], bc[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) { ar[a] = sXr[kk * XS + ty * 4 + a]; bc[a] = XC[kk * XS + tx * 4 + a]; }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[a][q] += ar[a] * bc[q];
+            for (int q = 0; q < 4; ++q) acc[q] += av * sXT[kk * XS + cb + c0 + q];
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int q = 0; q < 4; ++q) {
+            const double nv = C[(size_t)row * ld + c0 + q] - acc[q];
+            if (lookahead) sC[row * CS + c0 + q] = nv;
+            else C[(size_t)row * ld + c0 + q] = nv;
+        }
+    }
+    if (!lookahead) return;
+    __syncthreads();
+    if (wv == 0 && lane < FB) {
+        double a[FB];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) C[(size_t)(ty * 4 + a) * ld + tx * 4 + q] -= acc[a][q];
+        for (int j = 0; j < FB; ++j) a[j] = sC[lane * CS + j];
+        const bool bad = potrf_inwave<FB>(a, lane);
+        store_factor(d, k + 1, a, lane, bad);
     }
 }
 
-// L^T x = y, y = row Ppad of the factored augmented system.  One 1024-thread workgroup, blocks from last to first.
-__global__ __launch_bounds__(1024) void k_trsv_back(DevBuf d, int T) {
-    extern __shared__ double s_dyn[];
-    double* z = s_dyn;                     // Ppad
-    double* sD = z + d.Ppad;               // 64 x LS diagonal tile
+// Linv[k] = L(k,k)^-1 for every 64x64 diagonal tile of the factor, assembled from its two 32-blocks:
+//   [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1]   (A^-1, C^-1 by scalar-path TRSM on the identity)
+__global__ __launch_bounds__(256) void k_inv_diag(DevBuf d) {
+    __shared__ double sAi[FB * CS], sCi[FB * CS], sB[FB * CS], sT[FB * CS];
+    const int k = blockIdx.x, ld = d.ld;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wv == 0) {
+        const int blk = 2 * k + (lane >= FB ? 1 : 0), cidx = lane & (FB - 1);
+        double y[FB];
+#pragma unroll
+        for (int t = 0; t < FB; ++t) y[t] = (t == cidx) ? 1.0 : 0.0;
+        trsm_row_scalar<FB>(y, d.LT32 + (size_t)blk * FB * FB, d.rd32 + blk * FB);
+        double* dst = (lane >= FB) ? sCi : sAi;          // dst[t][c] = (L^-1)(t, c)
+#pragma unroll
+        for (int t = 0; t < FB; ++t) dst[t * CS + cidx] = y[t];
+    }
+    for (int idx = threadIdx.x; idx < FB * FB; idx += 256) {
+        const int rw = idx >> 5, cl = idx & 31;
+        sB[rw * CS + cl] = d.Lfac[(size_t)(k * TILE + FB + rw) * ld + k * TILE + cl];
+    }
+    __syncthreads();
+    const int row = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    {
+        double acc[4] = {0, 0, 0, 0};
+        for (int q = 0; q < FB; ++q) { const double bv = sB[row * CS + q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += bv * sAi[q * CS + c0 + e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sT[row * CS + c0 + e] = acc[e];
+    }
+    __syncthreads();
+    double* out = d.Linv + (size_t)k * TILE * TILE;
+    {
+        double acc[4] = {0, 0, 0, 0};
+        for (int q = 0; q < FB; ++q) { const double cv = sCi[row * CS + q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += cv * sT[q * CS + c0 + e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            out[(FB + row) * TILE + c0 + e] = -acc[e];
+            out[row * TILE + c0 + e] = sAi[row * CS + c0 + e];
+            out[(FB + row) * TILE + FB + c0 + e] = sCi[row * CS + c0 + e];
+            out[row * TILE + FB + c0 + e] = 0.0;
+        }
+    }
+}
+
+// L^T x = y as a dataflow over tile columns, one workgroup per column c (launched in descending c):
+//   x_c = L(c,c)^-T ( y_c - sum_{k>c} L(k,c)^T x_k )
+// Workgroup c folds in x_k as soon as workgroup k has published it (agent-scope release/acquire on a flag
+// word per column, epoch-stamped so no reset is needed); tiles of one column are streamed by their own CU.
+__global__ __launch_bounds__(256) void k_trsv_flow(DevBuf d, int T, int epoch) {
+    __shared__ double z[TILE];
     __shared__ double sx[TILE];
-    const int ld = d.ld, n = d.Ppad;
-    const double* y = d.Lfac + (size_t)n * ld;
-    for (int i = threadIdx.x; i < n; i += 1024) z[i] = y[i];
-    for (int kb = T - 1; kb >= 0; --kb) {
-        __syncthreads();
-        const double* Lkk = d.Lfac + (size_t)(kb * TILE) * ld + kb * TILE;
-        for (int idx = threadIdx.x; idx < TILE * TILE; idx += 1024) {
-            const int r = idx >> 6, c = idx & 63;
-            sD[r * LS + c] = Lkk[(size_t)r * ld + c];
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {            // wave 0: in-tile back substitution, column oriented
-            const int t = threadIdx.x;
-            double zt = z[kb * TILE + t];
-            for (int j = TILE - 1; j >= 0; --j) {
-                const double xj = __shfl(zt, j, 64) / sD[j * LS + j];
-                if (t == j) zt = xj;
-                else if (t < j) zt -= sD[j * LS + t] * xj;
+    __shared__ double part[4][TILE];
+    __shared__ int s_fail;
+    const int c = T - 1 - blockIdx.x;
+    const int ld = d.ld;
+    const int t = threadIdx.x & 63, jg = threadIdx.x >> 6;
+    if (threadIdx.x < TILE) z[threadIdx.x] = d.Lfac[(size_t)d.Ppad * ld + c * TILE + threadIdx.x];
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+    for (int k = T - 1; k > c; --k) {
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&d.flow_flags[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 22)) { s_fail = 1; break; }     // never hang the device on a logic error
             }
-            sx[t] = zt;
-            d.x[kb * TILE + t] = zt;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        // z[c] -= sum_j L[kb*64 + j][c] * x[j]  for every column c left of the diagonal tile
-        const int ncol = kb * TILE;
-        for (int c = threadIdx.x; c < ncol; c += 1024) {
-            const double* Lr = d.Lfac + (size_t)(kb * TILE) * ld + c;
-            double s = 0.0;
-#pragma unroll 8
-            for (int j = 0; j < TILE; ++j) s += Lr[(size_t)j * ld] * sx[j];
-            z[c] -= s;
-        }
+        if (s_fail) break;
+        // agent-scope (sc1) loads on top of the acquire: never served from a stale L1 line
+        if (threadIdx.x < TILE) sx[threadIdx.x] = __hip_atomic_load(&d.x[k * TILE + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const double* Lt = d.Lfac + (size_t)(k * TILE + jg * 16) * ld + c * TILE + t;
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += Lt[(size_t)j * ld] * sx[jg * 16 + j];
+        part[jg][t] = s;
+        __syncthreads();
+        if (threadIdx.x < TILE) z[threadIdx.x] -= (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        __syncthreads();
+    }
+    // x_c[t] = sum_r Linv[r][t] z[r]
+    {
+        const double* Li = d.Linv + (size_t)c * TILE * TILE + (size_t)(jg * 16) * TILE + t;
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += Li[r * TILE] * z[jg * 16 + r];
+        part[jg][t] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < TILE) {
+        double v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (s_fail) v = 0.0;
+        __hip_atomic_store(&d.x[c * TILE + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_fail) d.ctrl->solver_ok = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&d.flow_flags[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 void launch_cholesky(const DevBuf& d, bool use_mfma, hipStream_t s) {
-    const int T = d.Ppad / TILE;
-    const size_t sh = (size_t)(TILE * LS + 2 * TILE * XS) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_step<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_step<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        attr_set = true;
-    }
+    const int T = d.Ppad / FB;
+    hipLaunchKernelGGL(k_potrf0, dim3(1), dim3(64), 0, s, d);
     for (int k = 0; k < T; ++k) {
-        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(256), 0, s, d, k);
         const int nt = T - k - 1;
         const int tiles = nt * (nt + 1) / 2 + nt;
         const int grid = tiles > 0 ? tiles : 1;
-        if (use_mfma) hipLaunchKernelGGL(k_chol_step<true>, dim3(grid), dim3(256), sh, s, d, k, T);
-        else hipLaunchKernelGGL(k_chol_step<false>, dim3(grid), dim3(256), sh, s, d, k, T);
+        if (use_mfma) hipLaunchKernelGGL(k_chol_step<true>, dim3(grid), dim3(256), 0, s, d, k, T);
+        else hipLaunchKernelGGL(k_chol_step<false>, dim3(grid), dim3(256), 0, s, d, k, T);
     }
 }
 
-void launch_trsv_back(const DevBuf& d, hipStream_t s) {
+void launch_trsv_back(const DevBuf& d, int epoch, hipStream_t s) {
     const int T = d.Ppad / TILE;
-    const size_t sh = (size_t)(d.Ppad + TILE * LS) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsv_back), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_trsv_back, dim3(1), dim3(1024), sh, s, d, T);
+    hipLaunchKernelGGL(k_inv_diag, dim3(T), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_trsv_flow, dim3(T), dim3(256), 0, s, d, T, epoch);
 }
 
 // out (cols x cols, row-major, leading dimension ldo) = A^T A for a column-major rows x cols matrix

@@ -71,8 +71,12 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     double *pr_err, *pr_dx, *pr_chi;
     // dense
     double *Hconst, *Himu, *bimu, *sys, *Lfac, *bpg, *x;   // Lfac: Cholesky factor (same shape as sys)
+    double* Linv;          // T x 64 x 64 inverses of the diagonal tiles of Lfac
+    double* LT32;          // (Ppad/32) x 32 x 32 transposed diagonal blocks of the factor, LT[j][t] = L[t][j]
+    double* rd32;          // Ppad reciprocals of the factor's diagonal
+    int* flow_flags;       // T epoch-stamped flags of the back-substitution dataflow
     // reductions / control
-    double *chi_part, *scale_part, *maxd_part, *kfdiag;
+    double *chi_part, *scale_part, *maxd_part, *kfdiag, *posediag;
     Ctrl* ctrl;
     plba_trace_row* trace;
     int trace_cap;
@@ -106,7 +110,7 @@ int  edge_blocks(const DevBuf& d);
 
 // dense
 void launch_cholesky(const DevBuf& d, bool use_mfma, hipStream_t s);   // sys -> Lfac (lower) incl. the augmented rows
-void launch_trsv_back(const DevBuf& d, hipStream_t s);                 // x = L^-T y
+void launch_trsv_back(const DevBuf& d, int epoch, hipStream_t s);      // x = L^-T y; epoch must differ from the previous call's
 void launch_ata(const double* A_colmajor, int rows, int cols, double* out_rowmajor, int ldo, hipStream_t s);  // A^T A
 
 // marginalization

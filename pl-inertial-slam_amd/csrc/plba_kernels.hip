@@ -586,18 +586,22 @@ __global__ __launch_bounds__(256) void k_reduce(DevBuf d, int nblk_edges, int nb
     if (threadIdx.x == 0) { red[0] = C; red[1] = S; red[2] = Mx; }
 }
 
+// diagonal of the pose-side Hessian held by this rank: pose-side edges (Himu) + sum_e Jp^T w Jp (kfdiag);
+// in a sharded run the vector is all-reduced (sum) before the max, so every rank derives the same lambda
+__global__ __launch_bounds__(256) void k_posediag(DevBuf d) {
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < d.ld; r += gridDim.x * 256) d.posediag[r] = (r < d.P) ? d.Himu[(size_t)r * d.ld + r] : 0.0;
+}
+__global__ __launch_bounds__(256) void k_posediag_kf(DevBuf d) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= d.K * 6) return;
+    const int o = d.kf_off_pvr[t / 6];
+    if (o >= 0) d.posediag[o + pmap(t % 6)] += d.kfdiag[t];
+}
 // start of an outer iteration: currentChi, and on the first one computeLambdaInit (tau * max |H_jj|)
 __global__ __launch_bounds__(256) void k_lambda_init(DevBuf d, LmParams lp, const double* red, int first_iter, int iteration) {
     __shared__ double s4[4];
     double md = 0.0;
-    if (first_iter) {
-        for (int r = threadIdx.x; r < d.P; r += 256) md = fmax(md, fabs(d.Himu[(size_t)r * d.ld + r]));
-        for (int t = threadIdx.x; t < d.K * 6; t += 256) {
-            const int k = t / 6, c = t % 6;
-            const int o = d.kf_off_pvr[k];
-            if (o >= 0) md = fmax(md, fabs(d.Himu[(size_t)(o + pmap(c)) * d.ld + o + pmap(c)] + d.kfdiag[t]));
-        }
-    }
+    if (first_iter) for (int r = threadIdx.x; r < d.P; r += 256) md = fmax(md, fabs(d.posediag[r]));
     double mx = block_max_256(md, s4);
     if (threadIdx.x == 0) {
         Ctrl* c = d.ctrl;
@@ -702,6 +706,8 @@ void launch_landmark_hll(const DevBuf& d, hipStream_t s) {
 }
 void launch_kfdiag(const DevBuf& d, hipStream_t s) {
     if (d.npairs) hipLaunchKernelGGL(k_kfdiag, dim3(d.npairs), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_posediag, dim3((d.ld + 255) / 256), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_posediag_kf, dim3((d.K * 6 + 255) / 256), dim3(256), 0, s, d);
 }
 void launch_landmark_dinv(const DevBuf& d, hipStream_t s) {
     if (d.L) hipLaunchKernelGGL(k_landmark_dinv, dim3(lm_blocks(d)), dim3(256), 0, s, d);

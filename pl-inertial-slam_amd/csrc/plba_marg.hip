@@ -1,12 +1,411 @@
-// plba_marg.hip — K9: marginalization of the oldest keyframe (IMU/marginalization.cpp:291-384) on the device.
+// plba_marg.hip — K9: marginalization of the oldest keyframe on the device.
+//
+// Replaces MarginalizationInfo::preMarginalize / marginalizeWithoutThread (IMU/marginalization.cpp:128-147,
+// 291-384) and the factor selection of the call site (src/mapHandler.cpp:6075-6188).
+//
+//   host   : factor selection + parameter ordering (pure index work on the uploaded graph)
+//   device : (1) every selected factor re-evaluated at the final estimate, raw Jacobians, no information
+//                matrix and no robust weight (marginalization.cpp:67), written as columns of one stacked
+//                Jacobian  J (R x pos, column-major);  each factor's OWN (r, J): SURVEY B-Q3 decision
+//            (2) A = J^T J, b = J^T r                                   (ThreadsConstructA, cpp:8-36)
+//            (3) Schur elimination of the dropped block with the eigen pseudo-inverse, eigenvalues <= eps -> 0
+//                (cpp:351-362).  The dropped block is [oldest keyframe (<= 15) | landmark blocks (3 / 6)] and
+//                the landmark blocks do not couple, so the pseudo-inverse is taken block by block (landmarks,
+//                then the keyframe block of the reduced system) — identical to the dense pseudo-inverse
+//                whenever the discarded eigen-directions are block-local null spaces (rank-deficient landmark
+//                blocks), which is the case the threshold exists for.
+//            (4) A' = V S V^T by one-sided Jacobi (one workgroup per column pair, one launch per round),
+//                J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b'              (cpp:364-372)
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+
 #include "plba_problem.h"
 
 namespace plba {
 
+#define MDEV __device__ __forceinline__
+
+namespace {
+
+constexpr int MAXB = 15;   // largest block eliminated at once (PVR 9 + bias 6)
+
+// ---- (1) factor evaluation -------------------------------------------------------------------------------------
+struct MargObs { int edge; int row; int col_lm; int col_kf; };
+
+__global__ void k_marg_obs(DevBuf d, int state, const MargObs* f, int nf, double* J, double* r, int R) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf) return;
+    const MargObs o = f[i];
+    const int e = o.edge;
+    const double* s = d.kf[state] + (size_t)d.ob_kf[e] * KF_STRIDE;
+    double kc[KFCAM_STRIDE];
+    kfcam_make(d.cam, s, kc);
+    const double* L = d.lm[state] + (size_t)d.ob_slot[e] * 6;
+    double e2[2], Jp[12], Jl[6];
+    bool dp;
+    const bool is_pt = e < d.Ep;
+    if (is_pt) {
+        point_edge(d.cam, kc, v3(L[0], L[1], L[2]), d.po_uv[2 * (size_t)e], d.po_uv[2 * (size_t)e + 1], e2, Jp, Jl, dp, true);
+    } else {
+        const double* l = d.lo_l + (size_t)(e - d.Ep) * 3;
+        line_edge(d.cam, kc, v3(L[0], L[1], L[2]), v3(L[3], L[4], L[5]), l[0], l[1], l[2], d.fix_q1 != 0, e2, Jp, Jl, dp, true);
+    }
+    r[o.row] = e2[0]; r[o.row + 1] = e2[1];
+    for (int a = 0; a < 2; ++a) {
+        for (int c = 0; c < 3; ++c) {
+            J[(size_t)(o.col_kf + c) * R + o.row + a] = Jp[a * 6 + c];          // dp
+            J[(size_t)(o.col_kf + 6 + c) * R + o.row + a] = Jp[a * 6 + 3 + c];  // dphi (velocity columns stay zero)
+        }
+        if (is_pt) for (int c = 0; c < 3; ++c) J[(size_t)(o.col_lm + c) * R + o.row + a] = Jl[a * 3 + c];
+        else for (int c = 0; c < 3; ++c) J[(size_t)(o.col_lm + 3 * a + c) * R + o.row + a] = Jl[a * 3 + c];
+    }
+}
+
+__global__ void k_marg_imu(DevBuf d, int state, int m, int row, int c_pi, int c_pj, int c_bi, int c_bj, double* J, double* r, int R) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double* si = d.kf[state] + (size_t)d.imu_i[m] * KF_STRIDE;
+    const double* sj = d.kf[state] + (size_t)d.imu_j[m] * KF_STRIDE;
+    const double* pre = d.imu_pre + (size_t)m * PRE_STRIDE;
+    double e9[9], e6[6], J0[81], J1[81], J2[54];
+    pvr_error(si, sj, pre, d.gw, e9);
+    for (int t = 0; t < 81; ++t) { J0[t] = 0.0; J1[t] = 0.0; }
+    for (int t = 0; t < 54; ++t) J2[t] = 0.0;
+    pvr_jacobians(si, sj, pre, d.gw, e9, J0, J1, J2);
+    bias_error(si, sj, e6);
+    for (int a = 0; a < 9; ++a) {
+        r[row + a] = e9[a];
+        for (int c = 0; c < 9; ++c) { J[(size_t)(c_pi + c) * R + row + a] = J0[a * 9 + c]; J[(size_t)(c_pj + c) * R + row + a] = J1[a * 9 + c]; }
+        for (int c = 0; c < 6; ++c) J[(size_t)(c_bi + c) * R + row + a] = J2[a * 6 + c];
+    }
+    for (int a = 0; a < 6; ++a) {
+        r[row + 9 + a] = e6[a];
+        J[(size_t)(c_bi + a) * R + row + 9 + a] = -1.0;
+        J[(size_t)(c_bj + a) * R + row + 9 + a] = 1.0;
+    }
+}
+
+// old prior as a factor: residual = EdgeMarginalization error at the final estimate, Jacobian = J0 columns
+__global__ void k_marg_prior(DevBuf d, int row, const int* vcol, double* J, double* r, int R) {
+    const int n = d.pr_n;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) r[row + t] = d.pr_err[t];
+    for (int v = 0; v < d.pr_nv; ++v) {
+        const int sz = d.pr_size[v], ix = d.pr_idx[v], col = vcol[v];
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < sz * n; t += gridDim.x * blockDim.x) {
+            const int c = t / n, rr = t % n;
+            J[(size_t)(col + c) * R + row + rr] = d.pr_J0[(size_t)(ix + c) * n + rr];
+        }
+    }
+}
+
+__global__ void k_jt_r(const double* J, const double* r, int R, int pos, double* b) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= pos) return;
+    const double* col = J + (size_t)c * R;
+    double s = 0.0;
+    for (int t = 0; t < R; ++t) s += col[t] * r[t];
+    b[c] = s;
+}
+
+// ---- (3) block pseudo-inverse + Schur update --------------------------------------------------------------------
+// in-thread cyclic Jacobi eigen-decomposition of an s x s symmetric block (s <= 15), pinv with threshold eps
+__global__ void k_block_pinv(const double* A, int pos, const int* boff, const int* bsize, int nblk, double eps, double* Pinv) {
+    const int bi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bi >= nblk) return;
+    const int s = bsize[bi], o = boff[bi];
+    double M[MAXB * MAXB], V[MAXB * MAXB];
+    for (int i = 0; i < s; ++i)
+        for (int j = 0; j < s; ++j) {
+            M[i * MAXB + j] = 0.5 * (A[(size_t)(o + i) * pos + o + j] + A[(size_t)(o + j) * pos + o + i]);   // cpp:351
+            V[i * MAXB + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = 0; i < s; ++i) { dg += M[i * MAXB + i] * M[i * MAXB + i]; for (int j = i + 1; j < s; ++j) off += M[i * MAXB + j] * M[i * MAXB + j]; }
+        if (off <= 1e-32 * (dg + off) || off == 0.0) break;
+        for (int p = 0; p < s - 1; ++p)
+            for (int q = p + 1; q < s; ++q) {
+                const double apq = M[p * MAXB + q];
+                if (apq == 0.0) continue;
+                const double th = (M[q * MAXB + q] - M[p * MAXB + p]) / (2.0 * apq);
+                const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < s; ++k) { const double a = M[k * MAXB + p], b = M[k * MAXB + q]; M[k * MAXB + p] = c * a - sn * b; M[k * MAXB + q] = sn * a + c * b; }
+                for (int k = 0; k < s; ++k) { const double a = M[p * MAXB + k], b = M[q * MAXB + k]; M[p * MAXB + k] = c * a - sn * b; M[q * MAXB + k] = sn * a + c * b; }
+                for (int k = 0; k < s; ++k) { const double a = V[k * MAXB + p], b = V[k * MAXB + q]; V[k * MAXB + p] = c * a - sn * b; V[k * MAXB + q] = sn * a + c * b; }
+            }
+    }
+    double* out = Pinv + (size_t)bi * MAXB * MAXB;
+    for (int i = 0; i < s; ++i)
+        for (int j = 0; j < s; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < s; ++k) { const double w = M[k * MAXB + k]; if (w > eps) acc += V[i * MAXB + k] * V[j * MAXB + k] / w; }
+            out[i * MAXB + j] = acc;
+        }
+}
+// Z[row][o + c] = sum_t A[row][o + t] Pinv_b[t][c]     (only the eliminated columns of Z are written)
+__global__ void k_block_Z(const double* A, int pos, const int* boff, const int* bsize, int nblk, const double* Pinv, double* Z) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x, bi = blockIdx.y;
+    if (row >= pos || bi >= nblk) return;
+    const int s = bsize[bi], o = boff[bi];
+    const double* P = Pinv + (size_t)bi * MAXB * MAXB;
+    for (int c = 0; c < s; ++c) {
+        double acc = 0.0;
+        for (int t = 0; t < s; ++t) acc += A[(size_t)row * pos + o + t] * P[t * MAXB + c];
+        Z[(size_t)row * pos + o + c] = acc;
+    }
+}
+// A[r][c] -= sum_{k in elim} Z[r][k] A[k][c],  b[r] -= sum Z[r][k] b[k]   for r, c in `rest`
+__global__ void k_schur_apply(double* A, double* b, int pos, const double* Z, const int* elim, int nelim, const uint8_t* is_rest) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y * blockDim.y + threadIdx.y;
+    if (r >= pos || c > pos || !is_rest[r]) return;
+    if (c < pos && !is_rest[c]) return;
+    double acc = 0.0;
+    if (c == pos) { for (int t = 0; t < nelim; ++t) { const int k = elim[t]; acc += Z[(size_t)r * pos + k] * b[k]; } b[r] -= acc; }
+    else { for (int t = 0; t < nelim; ++t) { const int k = elim[t]; acc += Z[(size_t)r * pos + k] * A[(size_t)k * pos + c]; } A[(size_t)r * pos + c] -= acc; }
+}
+
+// ---- (4) one-sided Jacobi (Hestenes) on the symmetric positive semi-definite A' ---------------------------------------
+// G (n x n, column-major, starts as A') and V (starts as I); a round rotates n/2 disjoint column pairs.
+__global__ __launch_bounds__(256) void k_jacobi_round(double* G, double* V, int n, int npad, int round, double tol, int* rotated) {
+    __shared__ double s4[3][4];
+    const int i = blockIdx.x;
+    const int mm = npad - 1;
+    int p, q;
+    if (i == 0) { p = mm; q = round % mm; }
+    else { p = (round + i) % mm; q = (round - i + mm) % mm; }
+    if (p > q) { const int t = p; p = q; q = t; }
+    if (q >= n) return;                                  // padding column: bye
+    double* gp = G + (size_t)p * n; double* gq = G + (size_t)q * n;
+    double a = 0.0, b = 0.0, g = 0.0;
+    for (int t = threadIdx.x; t < n; t += 256) { const double x = gp[t], y = gq[t]; a += x * x; b += y * y; g += x * y; }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); g += __shfl_down(g, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s4[0][threadIdx.x >> 6] = a; s4[1][threadIdx.x >> 6] = b; s4[2][threadIdx.x >> 6] = g; }
+    __syncthreads();
+    a = (s4[0][0] + s4[0][1]) + (s4[0][2] + s4[0][3]);
+    b = (s4[1][0] + s4[1][1]) + (s4[1][2] + s4[1][3]);
+    g = (s4[2][0] + s4[2][1]) + (s4[2][2] + s4[2][3]);
+    if (!(fabs(g) > tol * sqrt(a * b)) || g == 0.0) return;
+    if (threadIdx.x == 0) atomicAdd(rotated, 1);
+    const double zeta = (b - a) / (2.0 * g);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+    double* vp = V + (size_t)p * n; double* vq = V + (size_t)q * n;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const double x = gp[k], y = gq[k];
+        gp[k] = c * x - s * y; gq[k] = s * x + c * y;
+        const double u = vp[k], w = vq[k];
+        vp[k] = c * u - s * w; vq[k] = s * u + c * w;
+    }
+}
+// eigenvalue_j = v_j . g_j  (>= 0 up to rounding), J0 = diag(sqrt(S)) V^T (column-major), r0 = diag(sqrt(S^-1)) V^T b'
+__global__ void k_eigen_sqrt(const double* G, const double* V, const double* bq, int n, double eps, double* J0, double* r0) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double* g = G + (size_t)j * n; const double* v = V + (size_t)j * n;
+    double lam = 0.0, vb = 0.0;
+    for (int t = 0; t < n; ++t) { lam += v[t] * g[t]; vb += v[t] * bq[t]; }
+    const double S = lam > eps ? lam : 0.0, Si = lam > eps ? 1.0 / lam : 0.0;
+    const double ss = sqrt(S);
+    for (int c = 0; c < n; ++c) J0[(size_t)c * n + j] = ss * v[c];
+    r0[j] = sqrt(Si) * vb;
+}
+__global__ void k_set_identity(double* V, int n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)n * n) V[i] = (i / n == i % n) ? 1.0 : 0.0;
+}
+__global__ void k_extract_cm(const double* A, int pos, int m, int n, double* G) {   // G (col-major n x n) = A[m.., m..]
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * n) return;
+    const int c = (int)(i / n), r = (int)(i % n);
+    G[i] = 0.5 * (A[(size_t)(m + r) * pos + m + c] + A[(size_t)(m + c) * pos + m + r]);
+}
+
+struct Param { int pid, size, drop, kf, isbias; };
+
+void est_pvr(const double* s, double* o) {   // GetEstData: P, V, Quaterniond(Rwb) as (x,y,z,w)   (IMU/g2otypes.h:127-168)
+    memcpy(o, s, 24); memcpy(o + 3, s + 3, 24);
+    Q4 q; q.x = s[6]; q.y = s[7]; q.z = s[8]; q.w = s[9];
+    const Q4 c = R_to_q(q_to_R(q));
+    o[6] = c.x; o[7] = c.y; o[8] = c.z; o[9] = c.w;
+}
+void est_bias(const double* s, double* o) { for (int c = 0; c < 3; ++c) { o[c] = s[10 + c] + s[16 + c]; o[3 + c] = s[13 + c] + s[19 + c]; } }
+
+}  // namespace
+
+#define PID_PT(i) ((1 << 28) + (i))
+#define PID_LN(i) ((1 << 29) + (i))
+
 int marginalize_device(plba_problem* p, int first_kf, int max_edges, plba_prior* out) {
-    (void)first_kf; (void)max_edges; (void)out;
-    PLBA_FAIL(p, PLBA_ERR_STATE, "plba_marginalize: device marginalization is not built yet");
+    if (first_kf < 0 || first_kf >= p->K) PLBA_FAIL(p, PLBA_ERR_INVALID, "marginalize: first_kf out of range");
+    memset(out, 0, sizeof *out);
+    const DevBuf& d = p->dv;
+    hipStream_t s = p->stream;
+    const int NUM = max_edges;
+    const int vid0 = p->vid_pvr[first_kf], vidb0 = p->vid_bias[first_kf];
+    // ---- factor selection (mapHandler.cpp:6075-6188) -------------------------------------------------------------------
+    std::map<int, Param> params;     // keyed by pid: ascending order == SURVEY B-Q6 decision
+    auto touch = [&](int pid, int size, bool drop, int kf, int isb) {
+        auto it = params.find(pid);
+        if (it == params.end()) params[pid] = Param{pid, size, drop ? 1 : 0, kf, isb};
+        else if (drop) it->second.drop = 1;
+    };
+    int R = 0;
+    const bool have_imu = p->M > 0;
+    int imu_row = -1;
+    if (have_imu) {   // vpEdgesNavStatePVR[0] / vpEdgesNavStateBias[0]: the first IMU edge, drop_set = {0}
+        const int ki = p->imu_i[0], kj = p->imu_j[0];
+        touch(p->vid_pvr[ki], 9, true, ki, 0); touch(p->vid_pvr[kj], 9, false, kj, 0);
+        touch(p->vid_bias[ki], 6, true, ki, 1); touch(p->vid_bias[kj], 6, false, kj, 1);
+        imu_row = R; R += 15;
+    }
+    std::vector<MargObs> obs;
+    auto select = [&](const std::vector<int32_t>& lm_of, const std::vector<int32_t>& kf_of, int E, int ebase, bool is_pt) {
+        int num = 0, e = 0;
+        const int N = is_pt ? p->Np : p->Nl;
+        for (int l = 0; l < N && num <= NUM; ++l) {
+            const int e0 = e;
+            while (e < E && lm_of[e] == l) ++e;
+            if (e0 == e || kf_of[e0] != first_kf) continue;      // kf_obs_list[0] == first_kf_idx
+            for (int a = e0; a < e; ++a) {
+                const int k = kf_of[a];
+                touch(is_pt ? PID_PT(l) : PID_LN(l), is_pt ? 3 : 6, true, -1, 0);
+                touch(p->vid_pvr[k], 9, p->vid_pvr[k] == vid0, k, 0);
+                obs.push_back(MargObs{ebase + a, R, is_pt ? PID_PT(l) : PID_LN(l), p->vid_pvr[k]});   // pids for now
+                R += 2;
+                if (++num > NUM) break;                           // `num>NUM` after the increment admits NUM+1 (B-Q10)
+            }
+        }
+    };
+    select(p->po_pt, p->po_kf, p->Ep, 0, true);
+    select(p->lo_ln, p->lo_kf, p->El, p->Ep, false);
+    int prior_row = -1;
+    if (p->pr_nv > 0) {
+        std::map<int, std::pair<int, int>> by_vid;
+        for (int k = 0; k < p->K; ++k) { by_vid[p->vid_pvr[k]] = {k, 0}; if (p->vid_bias[k] >= 0) by_vid[p->vid_bias[k]] = {k, 1}; }
+        for (int i = 0; i < p->pr_nv; ++i) {
+            const auto& kv = by_vid[p->pr_vid[i]];
+            touch(p->pr_vid[i], p->pr_size[i], p->pr_vid[i] == vid0 || p->pr_vid[i] == vidb0, kv.first, kv.second);
+        }
+        prior_row = R; R += p->pr_n;
+    }
+    if (params.empty() || R == 0) PLBA_FAIL(p, PLBA_ERR_STATE, "marginalize: no factor touches keyframe %d", first_kf);
+    // ---- parameter order: dropped first (keyframe block, then landmark blocks), then kept; ascending id inside ---------
+    std::map<int, int> col;          // pid -> column offset
+    int pos = 0;
+    std::vector<int> blk_off, blk_size;      // landmark blocks
+    int pose_off = 0, pose_size = 0;
+    for (auto& kv : params) if (kv.second.drop && kv.second.kf >= 0) { col[kv.first] = pos; pos += kv.second.size; }
+    pose_size = pos;
+    if (pose_size > MAXB) PLBA_FAIL(p, PLBA_ERR_INVALID, "marginalize: dropped keyframe block of %d dims", pose_size);
+    for (auto& kv : params) if (kv.second.drop && kv.second.kf < 0) { col[kv.first] = pos; blk_off.push_back(pos); blk_size.push_back(kv.second.size); pos += kv.second.size; }
+    const int m = pos;
+    std::vector<const Param*> kept;
+    for (auto& kv : params) if (!kv.second.drop) {
+        if (kv.second.kf < 0) PLBA_FAIL(p, PLBA_ERR_INVALID, "marginalize: a landmark would be kept");
+        col[kv.first] = pos; pos += kv.second.size; kept.push_back(&kv.second);
+    }
+    const int n = pos - m;
+    for (auto& o : obs) { o.col_lm = col[o.col_lm]; o.col_kf = col[o.col_kf]; }
+    // ---- device work -------------------------------------------------------------------------------------------------------
+    DArr<double> dJ, dr, dA, db, dZ, dPinv, dG, dV, dJ0, dr0;
+    DArr<MargObs> dobs;
+    DArr<int> dboff, dbsize, delim, dvcol, drot;
+    DArr<uint8_t> drest;
+    PLBA_HIPCK(p, dJ.alloc((size_t)R * pos)); PLBA_HIPCK(p, dr.alloc(R)); PLBA_HIPCK(p, dA.alloc((size_t)pos * pos)); PLBA_HIPCK(p, db.alloc(pos));
+    PLBA_HIPCK(p, dZ.alloc((size_t)pos * pos)); PLBA_HIPCK(p, dobs.upload(obs));
+    PLBA_HIPCK(p, hipStreamSynchronize(s));
+    const int state = p->cur;
+    if (!obs.empty()) hipLaunchKernelGGL(k_marg_obs, dim3(((int)obs.size() + 63) / 64), dim3(64), 0, s, d, state, dobs.p, (int)obs.size(), dJ.p, dr.p, R);
+    if (have_imu) {
+        const int ki = p->imu_i[0], kj = p->imu_j[0];
+        hipLaunchKernelGGL(k_marg_imu, dim3(1), dim3(64), 0, s, d, state, 0, imu_row, col[p->vid_pvr[ki]], col[p->vid_pvr[kj]], col[p->vid_bias[ki]], col[p->vid_bias[kj]], dJ.p, dr.p, R);
+    }
+    if (p->pr_nv > 0) {
+        Robust rb = p->rob;
+        launch_pose_edges(d, state, false, rb, true, s);       // refreshes pr_err = EdgeMarginalization::computeError at the final estimate
+        std::vector<int> vcol(p->pr_nv);
+        for (int i = 0; i < p->pr_nv; ++i) vcol[i] = col[p->pr_vid[i]];
+        PLBA_HIPCK(p, dvcol.upload(vcol));
+        hipLaunchKernelGGL(k_marg_prior, dim3(64), dim3(256), 0, s, d, prior_row, dvcol.p, dJ.p, dr.p, R);
+    }
+    launch_ata(dJ.p, R, pos, dA.p, pos, s);
+    hipLaunchKernelGGL(k_jt_r, dim3((pos + 63) / 64), dim3(64), 0, s, dJ.p, dr.p, R, pos, db.p);
+    const double eps = p->opt.marg_eps;
+    auto eliminate = [&](const std::vector<int>& boff, const std::vector<int>& bsize, const std::vector<uint8_t>& rest) -> int {
+        const int nb = (int)boff.size();
+        if (nb == 0) return PLBA_OK;
+        std::vector<int> elim;
+        for (int b = 0; b < nb; ++b) for (int t = 0; t < bsize[b]; ++t) elim.push_back(boff[b] + t);
+        PLBA_HIPCK(p, dboff.upload(boff)); PLBA_HIPCK(p, dbsize.upload(bsize)); PLBA_HIPCK(p, delim.upload(elim)); PLBA_HIPCK(p, drest.upload(rest));
+        PLBA_HIPCK(p, dPinv.alloc((size_t)nb * MAXB * MAXB));
+        hipLaunchKernelGGL(k_block_pinv, dim3((nb + 63) / 64), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, nb, eps, dPinv.p);
+        hipLaunchKernelGGL(k_block_Z, dim3((pos + 63) / 64, nb), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, nb, dPinv.p, dZ.p);
+        hipLaunchKernelGGL(k_schur_apply, dim3((pos + 1 + 15) / 16, (pos + 15) / 16), dim3(16, 16), 0, s, dA.p, db.p, pos, dZ.p, delim.p, (int)elim.size(), drest.p);
+        PLBA_HIPCK(p, hipStreamSynchronize(s));   // the uploaded index vectors are reused by the next call
+        return PLBA_OK;
+    };
+    {
+        std::vector<uint8_t> rest(pos, 1);
+        for (size_t b = 0; b < blk_off.size(); ++b) for (int t = 0; t < blk_size[b]; ++t) rest[blk_off[b] + t] = 0;
+        int rc = eliminate(blk_off, blk_size, rest);
+        if (rc) return rc;
+        if (pose_size > 0) {
+            for (int t = 0; t < pose_size; ++t) rest[pose_off + t] = 0;
+            rc = eliminate(std::vector<int>{pose_off}, std::vector<int>{pose_size}, rest);
+            if (rc) return rc;
+        }
+    }
+    // ---- eigen square root of the reduced system ------------------------------------------------------------------------------
+    PLBA_HIPCK(p, dG.alloc((size_t)n * n)); PLBA_HIPCK(p, dV.alloc((size_t)n * n)); PLBA_HIPCK(p, dJ0.alloc((size_t)n * n)); PLBA_HIPCK(p, dr0.alloc(n));
+    PLBA_HIPCK(p, drot.alloc(1));
+    const int nn_blocks = (int)(((size_t)n * n + 255) / 256);
+    hipLaunchKernelGGL(k_extract_cm, dim3(nn_blocks), dim3(256), 0, s, dA.p, pos, m, n, dG.p);
+    std::vector<double> Ar((size_t)n * n), br(n), Afull;
+    PLBA_HIPCK(p, hipStreamSynchronize(s));
+    PLBA_HIPCK(p, hipMemcpy(Ar.data(), dG.p, Ar.size() * 8, hipMemcpyDeviceToHost));      // symmetric: col-major == row-major
+    PLBA_HIPCK(p, hipMemcpy(br.data(), db.p + m, (size_t)n * 8, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(k_set_identity, dim3(nn_blocks), dim3(256), 0, s, dV.p, n);
+    const int npad = (n % 2) ? n + 1 : n;
+    if (n > 1) {
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            PLBA_HIPCK(p, hipMemsetAsync(drot.p, 0, sizeof(int), s));
+            for (int round = 0; round < npad - 1; ++round)
+                hipLaunchKernelGGL(k_jacobi_round, dim3(npad / 2), dim3(256), 0, s, dG.p, dV.p, n, npad, round, 1e-15, drot.p);
+            int rotated = 0;
+            PLBA_HIPCK(p, hipMemcpyAsync(&rotated, drot.p, sizeof(int), hipMemcpyDeviceToHost, s));
+            PLBA_HIPCK(p, hipStreamSynchronize(s));
+            if (rotated == 0) break;
+        }
+    }
+    hipLaunchKernelGGL(k_eigen_sqrt, dim3((n + 63) / 64), dim3(64), 0, s, dG.p, dV.p, db.p + m, n, eps, dJ0.p, dr0.p);
+    PLBA_HIPCK(p, hipStreamSynchronize(s));
+    PLBA_HIPCK(p, hipGetLastError());
+    // ---- output (host buffers owned by the caller until plba_prior_free) ----------------------------------------------------------
+    out->n = n; out->m = m; out->nv = (int)kept.size();
+    out->vid = (int32_t*)calloc(kept.size() + 1, 4); out->size = (int32_t*)calloc(kept.size() + 1, 4); out->idx = (int32_t*)calloc(kept.size() + 1, 4);
+    out->J0 = (double*)calloc((size_t)n * n + 1, 8); out->r0 = (double*)calloc(n + 1, 8);
+    out->Ar = (double*)calloc((size_t)n * n + 1, 8); out->br = (double*)calloc(n + 1, 8);
+    memcpy(out->Ar, Ar.data(), Ar.size() * 8); memcpy(out->br, br.data(), (size_t)n * 8);
+    PLBA_HIPCK(p, hipMemcpy(out->J0, dJ0.p, (size_t)n * n * 8, hipMemcpyDeviceToHost));
+    PLBA_HIPCK(p, hipMemcpy(out->r0, dr0.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    std::vector<double> kfh((size_t)p->K * KF_STRIDE);
+    PLBA_HIPCK(p, hipMemcpy(kfh.data(), d.kf[state], kfh.size() * 8, hipMemcpyDeviceToHost));
+    size_t nx = 0;
+    for (auto* k : kept) nx += k->size == 9 ? 10 : 6;
+    out->x0 = (double*)calloc(nx + 1, 8);
+    nx = 0;
+    for (size_t i = 0; i < kept.size(); ++i) {
+        const Param* k = kept[i];
+        out->vid[i] = k->pid; out->size[i] = k->size; out->idx[i] = col[k->pid] - m;
+        const double* st = &kfh[(size_t)k->kf * KF_STRIDE];
+        if (k->size == 9) { est_pvr(st, out->x0 + nx); nx += 10; } else { est_bias(st, out->x0 + nx); nx += 6; }
+    }
+    return PLBA_OK;
 }
 
 }  // namespace plba

@@ -23,7 +23,7 @@ def host_array(ptr, n):
     return np.ctypeslib.as_array(C.cast(C.c_void_p(ptr), C.POINTER(C.c_double)), shape=(int(n),))
 
 
-def make_allreduce(dist, device_index=None, stream=None):
+def make_allreduce(dist, device_index=None, stream=None, via_host=False):
     """Build the callback for Problem.set_shard.  device_index=None: the buffer is host memory
     (gloo tests against a CPU implementation of plba.h); otherwise a device buffer all-reduced by
     RCCL, ordered on `stream` (the torch stream handed to plba_set_stream)."""
@@ -36,6 +36,19 @@ def make_allreduce(dist, device_index=None, stream=None):
         def fn(ptr, n, op, _stream):
             t = torch.from_numpy(host_array(ptr, n))
             dist.all_reduce(t, op=_op(op))
+        return fn
+
+    if via_host:   # gloo over host staging: lets several ranks share one GPU in the tests
+        def fn(ptr, n, op, _stream):
+            t = as_tensor(ptr, n, device_index)
+            if stream is not None:
+                stream.synchronize()
+            else:
+                torch.cuda.synchronize()
+            h = t.cpu()
+            dist.all_reduce(h, op=_op(op))
+            t.copy_(h)
+            torch.cuda.synchronize()
         return fn
 
     def fn(ptr, n, op, _stream):

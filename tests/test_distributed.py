@@ -1,0 +1,120 @@
+"""N > 1: landmarks sharded over ranks, pose-side edges on rank 0, one all-reduce of the reduced
+camera system per LM trial.  World size 2 over gloo:
+  * CPU (not gpu): the oracle implementation of plba.h on each rank's shard == the unsharded oracle.
+  * GPU: two processes share cuda:0, HIP problems on the shards, gloo through host staging."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, use_hip, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from oracle import oracle as orc
+    pkg = ge.load_package()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = pkg.window.make_window(8, 240, 50, imu=True, seed=0xD157)
+        ws = pkg.window.shard_window(w, rank, world)
+        if use_hip:
+            torch.cuda.set_device(0)
+            p = pkg.new_problem()
+            p.upload_window(ws)
+            p.set_shard(rank, world, pkg.distributed.make_allreduce(dist, 0, None, via_host=True))
+        else:
+            p = orc.new_problem()
+            p.upload_window(ws)
+            p.set_shard(rank, world, pkg.distributed.make_allreduce(dist))
+        r = pkg.protocol.local_ba(p)
+        res = pkg.protocol.results(p)
+        tr = p.trace()
+        lo, hi = ws["shard"]["pt_range"]
+        out.put((rank, res["P"], res["V"], res["q"], res["dbg"], res["points"], (lo, hi), r["gated"], r["stage2"].chi2_final,
+                 [t["accepted"] for t in tr]))
+        p.close()
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as e:   # report instead of dead-locking the peer in a collective
+        import traceback
+        out.put(("error", rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+        out.close(); out.join_thread()
+        os._exit(1)
+
+
+def _run(world, use_hip):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, use_hip, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    try:
+        for _ in range(world):
+            g = q.get(timeout=240)
+            if g[0] == "error":
+                raise AssertionError("rank %d failed:\n%s" % (g[1], g[2]))
+            got.append(g)
+    finally:
+        for p in procs:
+            p.join(20)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    return sorted(got, key=lambda g: g[0])
+
+
+def _check(got, pkg, orc):
+    w = pkg.window.make_window(8, 240, 50, imu=True, seed=0xD157)
+    ref = orc.new_problem(); ref.upload_window(w)
+    rr = pkg.protocol.local_ba(ref)
+    res = pkg.protocol.results(ref)
+    # every rank holds the same keyframe estimates, equal to the unsharded solve
+    for g in got:
+        assert np.abs(g[1] - res["P"]).max() < 1e-8 and np.abs(g[2] - res["V"]).max() < 1e-8
+        assert np.abs(g[3] - res["q"]).max() < 1e-8 and np.abs(g[4] - res["dbg"]).max() < 1e-8
+        lo, hi = g[6]
+        assert np.abs(g[5] - res["points"][lo:hi]).max() < 1e-7
+        assert g[8] == pytest.approx(rr["stage2"].chi2_final, rel=1e-8)
+    assert got[0][1].tobytes() == got[1][1].tobytes()            # bit-identical pose blocks across ranks
+    assert got[0][9] == got[1][9]                                # identical LM decisions
+    assert tuple(sum(g[7][i] for g in got) for i in range(2)) == rr["gated"]
+    ref.close()
+
+
+def test_sharded_oracle_world2_gloo(pkg, orc):
+    _check(_run(2, False), pkg, orc)
+
+
+@pytest.mark.gpu
+def test_sharded_hip_world2_gloo_host_staged(pkg, orc, hip):
+    _check(_run(2, True), pkg, orc)
+
+
+def test_shard_window_partitions_landmarks(pkg):
+    w = pkg.window.make_window(6, 101, 23, imu=True, seed=3)
+    parts = [pkg.window.shard_window(w, r, 3) for r in range(3)]
+    assert sum(len(p["points"]) for p in parts) == 101 and sum(len(p["lines"]) for p in parts) == 23
+    assert sum(len(p["po_pt"]) for p in parts) == len(w["po_pt"])
+    for p in parts:
+        assert p["imu"] is w["imu"] and (np.diff(p["po_pt"]) >= 0).all()
+        lo, hi = p["shard"]["pt_range"]
+        assert p["po_pt"].max() < hi - lo
