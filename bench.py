@@ -182,6 +182,19 @@ def main():
         "roofline_dense_solve": roof_mfma,
         "phase_ms_per_iteration": per_iter,
     }
+    if world == 1:
+        # end-to-end cost of one reference-shaped BA call incl. PCIe: SoA upload + structure build + 5+10 LM
+        # iterations + gating + write-back (reported for DESIGN.md; never `value`)
+        t1 = time.perf_counter()
+        p2 = pkg.new_problem()
+        p2.upload_window(w)
+        r2 = pkg.protocol.local_ba(p2)
+        pkg.protocol.results(p2)
+        torch.cuda.synchronize()
+        e2e = time.perf_counter() - t1
+        p2.close()
+        out["config"]["end_to_end_ba_call_ms"] = e2e * 1e3
+        out["config"]["end_to_end_iterations_per_s"] = (r2["stage1"].iterations + r2["stage2"].iterations) / e2e
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w_full, pkg)

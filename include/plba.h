@@ -168,6 +168,13 @@ int plba_restore_state(plba_problem* p);
 /* ---- marginalization (mapHandler.cpp:6075-6199, IMU/marginalization.cpp:128-147,291-384) ----- */
 int  plba_marginalize(plba_problem* p, int first_kf, int max_edges_per_kind /*NUM=50 admits 51*/,
                       plba_prior* out);
+/* General form behind MarginalizationInfo::addResidualBlockInfo / preMarginalize / marginalizeWithoutThread
+ * (IMU/marginalization.cpp:102-147,291-384): explicit factor lists.  Each IMU edge contributes its PVR edge and its
+ * bias edge; point_edges / line_edges index the uploaded observation arrays; drop_vid lists the keyframe vertices to
+ * marginalize out (the landmark of every listed observation is always dropped, drop_set {0} at the call site). */
+int  plba_marginalize_factors(plba_problem* p, int n_imu, const int32_t* imu_edges, int n_pt, const int32_t* point_edges,
+                              int n_ln, const int32_t* line_edges, int use_prior, int n_drop, const int32_t* drop_vid,
+                              plba_prior* out);
 void plba_prior_free(plba_prior* pr);
 
 /* ---- diagnostics used by the parity tests (not needed by a drop-in caller) ------------------- */

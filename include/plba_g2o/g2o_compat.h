@@ -1,0 +1,717 @@
+// g2o_compat.h — source-level drop-in for the subset of g2o + IMU/g2otypes.h + IMU/marginalization.h that
+// MapHandler::localBundleAdjustmentWithImu / ...WithImuAndMarg compile against (reference
+// src/mapHandler.cpp:5086-5739, 5741-6254; API inventory: SURVEY.md §8b "Boundary 1").
+//
+// Same class names, method names, argument meaning and ownership rules as the reference:
+//   g2o::SparseOptimizer, OptimizationAlgorithmLevenberg, BlockSolverX, LinearSolverEigen, RobustKernelHuber,
+//   BaseVertex / BaseUnaryEdge / BaseBinaryEdge / BaseMultiEdge, make_unique          (g2o, third party)
+//   VertexNavStatePVR, VertexNavStateBias, VertexLMPointXYZ, VertexLine,
+//   EdgeNavStatePVR, EdgeNavStateBias, EdgeNavStatePVRPointXYZ, EdgeNavStateLine, EdgeMarginalization
+//                                                                             (IMU/g2otypes.h:23-1078)
+//   NavState (IMU/NavState.h), IMUPreintegrator (IMU/IMUPreintegrator.h), Sophus::SO3 (IMU/so3.h)
+//   MarginalizationInfo, ResidualBlockInfo                                    (IMU/marginalization.h:29-100)
+//
+// optimize() does not walk virtual computeError()/linearizeOplus() per edge: it recognises the edge/vertex types of
+// the hot path, flattens the graph into the SoA arrays of include/plba.h in the reference's insertion order and
+// runs the HIP kernels.  Graphs containing other vertex/edge types are rejected (there is no CPU fallback).
+#pragma once
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#define PLBA_HAVE_EIGEN 1
+#endif
+#endif
+#ifndef PLBA_HAVE_EIGEN
+#include "mini_eigen.h"
+#endif
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "plba.h"
+#include "plba_math.h"   // host-compiled SO(3) / oplus helpers (pl-inertial-slam_amd/csrc)
+
+using namespace Eigen;
+typedef Eigen::Matrix<double, 15, 1> Vector15d;
+typedef Eigen::Matrix<double, 9, 1> Vector9d;
+typedef Eigen::Matrix<double, 6, 1> Vector6d;
+typedef Eigen::Matrix<double, 9, 9> Matrix9d;
+
+// ================================================================================================================
+// Sophus::SO3 (IMU/so3.h) — unit quaternion, normalising constructors
+// ================================================================================================================
+namespace Sophus {
+class SO3 {
+public:
+    SO3() { q_.x = q_.y = q_.z = 0; q_.w = 1; }
+    explicit SO3(const Matrix3d& R) { plba::M3 m; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m.a[i * 3 + j] = R(i, j); q_ = plba::q_normalized(plba::R_to_q(m)); }
+    explicit SO3(const Quaterniond& q) { q_.x = q.x(); q_.y = q.y(); q_.z = q.z(); q_.w = q.w(); q_ = plba::q_normalized(q_); }
+    static SO3 from_xyzw(const double* c) { SO3 s; s.q_.x = c[0]; s.q_.y = c[1]; s.q_.z = c[2]; s.q_.w = c[3]; return s; }
+    SO3 operator*(const SO3& o) const { SO3 r; r.q_ = plba::q_normalized(plba::q_mul(plba::q_normalized(q_), o.q_)); return r; }
+    SO3 inverse() const { SO3 r; r.q_ = plba::q_normalized(plba::q_conj(q_)); return r; }
+    Vector3d operator*(const Vector3d& v) const { plba::V3 o = plba::q_rot(q_, plba::v3(v(0), v(1), v(2))); return Vector3d(o.x, o.y, o.z); }
+    Matrix3d matrix() const { plba::M3 m = plba::q_to_R(q_); Matrix3d R; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i, j) = m.a[i * 3 + j]; return R; }
+    Vector3d log() const { plba::V3 w = plba::so3_log(q_); return Vector3d(w.x, w.y, w.z); }
+    static SO3 exp(const Vector3d& w) { SO3 r; r.q_ = plba::so3_exp(plba::v3(w(0), w(1), w(2))); return r; }
+    Quaterniond unit_quaternion() const { return Quaterniond(q_.w, q_.x, q_.y, q_.z); }
+    const plba::Q4& q4() const { return q_; }
+    static const int DoF = 3;
+private:
+    plba::Q4 q_;
+};
+}  // namespace Sophus
+
+// ================================================================================================================
+// NavState (IMU/NavState.h:14-81, IMU/NavState.cpp:69-121)
+// ================================================================================================================
+class NavState {
+public:
+    NavState() { for (int i = 0; i < 24; ++i) s_[i] = 0.0; s_[9] = 1.0; }
+    Sophus::SO3 Get_R() const { return Sophus::SO3::from_xyzw(s_ + 6) * Sophus::SO3(); }
+    Matrix3d Get_RotMatrix() const { return Sophus::SO3::from_xyzw(s_ + 6).matrix(); }
+    Vector3d Get_P() const { return Vector3d(s_[0], s_[1], s_[2]); }
+    Vector3d Get_V() const { return Vector3d(s_[3], s_[4], s_[5]); }
+    void Set_Pos(const Vector3d& p) { for (int i = 0; i < 3; ++i) s_[i] = p(i); }
+    void Set_Vel(const Vector3d& v) { for (int i = 0; i < 3; ++i) s_[3 + i] = v(i); }
+    void Set_Rot(const Matrix3d& R) { Set_Rot(Sophus::SO3(R)); }
+    void Set_Rot(const Sophus::SO3& R) { const plba::Q4& q = R.q4(); s_[6] = q.x; s_[7] = q.y; s_[8] = q.z; s_[9] = q.w; }
+    Vector3d Get_BiasGyr() const { return Vector3d(s_[10], s_[11], s_[12]); }
+    Vector3d Get_BiasAcc() const { return Vector3d(s_[13], s_[14], s_[15]); }
+    void Set_BiasGyr(const Vector3d& b) { for (int i = 0; i < 3; ++i) s_[10 + i] = b(i); }
+    void Set_BiasAcc(const Vector3d& b) { for (int i = 0; i < 3; ++i) s_[13 + i] = b(i); }
+    Vector3d Get_dBias_Gyr() const { return Vector3d(s_[16], s_[17], s_[18]); }
+    Vector3d Get_dBias_Acc() const { return Vector3d(s_[19], s_[20], s_[21]); }
+    void Set_DeltaBiasGyr(const Vector3d& b) { for (int i = 0; i < 3; ++i) s_[16 + i] = b(i); }
+    void Set_DeltaBiasAcc(const Vector3d& b) { for (int i = 0; i < 3; ++i) s_[19 + i] = b(i); }
+    void IncSmallPVR(const Vector9d& u) { double o[24]; std::memcpy(o, s_, sizeof o); plba::kf_oplus_pvr(s_, u.data(), o); std::memcpy(s_, o, sizeof o); }
+    void IncSmallBias(const Vector6d& u) { for (int i = 0; i < 6; ++i) s_[16 + i] += u(i); }
+    void IncSmall(const Vector15d& u) { Vector9d a; Vector6d b; for (int i = 0; i < 9; ++i) a(i) = u(i); for (int i = 0; i < 6; ++i) b(i) = u(9 + i); IncSmallPVR(a); IncSmallBias(b); }
+    const double* raw() const { return s_; }   // the 24-double keyframe record of the device layout
+    double* raw() { return s_; }
+private:
+    double s_[24];
+};
+
+// ================================================================================================================
+// IMUPreintegrator (IMU/IMUPreintegrator.h:15-203) — the measurement payload of the IMU edges
+// ================================================================================================================
+class IMUPreintegrator {
+public:
+    IMUPreintegrator() { reset(); }
+    void reset() { for (double& x : p_) x = 0.0; p_[6] = p_[10] = p_[14] = 1.0; }
+    Vector3d getDeltaP() const { return Vector3d(p_[0], p_[1], p_[2]); }
+    Vector3d getDeltaV() const { return Vector3d(p_[3], p_[4], p_[5]); }
+    Matrix3d getDeltaR() const { return m3(6); }
+    Matrix3d getJPBiasg() const { return m3(15); }
+    Matrix3d getJPBiasa() const { return m3(24); }
+    Matrix3d getJVBiasg() const { return m3(33); }
+    Matrix3d getJVBiasa() const { return m3(42); }
+    Matrix3d getJRBiasg() const { return m3(51); }
+    Matrix9d getCovPVPhi() const { Matrix9d c; for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) c(i, j) = p_[60 + i * 9 + j]; return c; }
+    double getDeltaTime() const { return p_[141]; }
+    // the 142-double payload of include/plba.h (dP dV dR JPg JPa JVg JVa JRg cov dt, matrices row-major)
+    const double* payload() const { return p_; }
+    void setPayload(const double* src) { std::memcpy(p_, src, sizeof p_); }
+private:
+    Matrix3d m3(int o) const { Matrix3d m; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m(i, j) = p_[o + i * 3 + j]; return m; }
+    double p_[142];
+};
+
+namespace g2o {
+
+template <typename T, typename... A>
+std::unique_ptr<T> make_unique(A&&... a) { return std::unique_ptr<T>(new T(std::forward<A>(a)...)); }
+
+class SparseOptimizer;
+
+// ---- robust kernels ---------------------------------------------------------------------------------------------
+class RobustKernel {
+public:
+    virtual ~RobustKernel() {}
+    virtual void setDelta(double d) { _delta = d; }
+    double delta() const { return _delta; }
+protected:
+    double _delta = 1.0;
+};
+class RobustKernelHuber : public RobustKernel {};
+
+// ---- graph elements -----------------------------------------------------------------------------------------------
+class OptimizableGraph {
+public:
+    class Edge;
+    class Vertex {
+    public:
+        virtual ~Vertex() {}
+        int id() const { return _id; }
+        void setId(int i) { _id = i; }
+        bool fixed() const { return _fixed; }
+        void setFixed(bool f) { _fixed = f; }
+        bool marginalized() const { return _marg; }
+        void setMarginalized(bool m) { _marg = m; }
+        virtual int dimension() const = 0;
+        virtual int estimateDimension() const { return -1; }
+        virtual void oplusImpl(const double*) = 0;
+        virtual void setToOriginImpl() = 0;
+        virtual bool read(std::istream&) { return true; }
+        virtual bool write(std::ostream&) const { return true; }
+        SparseOptimizer* graph() const { return _graph; }
+        int _plba_index = -1;       // keyframe / point / line index in the flattened arrays
+    protected:
+        friend class SparseOptimizer;
+        int _id = -1;
+        bool _fixed = false, _marg = false;
+        SparseOptimizer* _graph = nullptr;
+    };
+    class Edge {
+    public:
+        virtual ~Edge() { delete _robust; }
+        void setVertex(size_t i, Vertex* v) { if (i >= _vertices.size()) _vertices.resize(i + 1, nullptr); _vertices[i] = v; }
+        Vertex* vertex(size_t i) const { return _vertices[i]; }
+        const std::vector<Vertex*>& vertices() const { return _vertices; }
+        void resize(size_t n) { _vertices.resize(n, nullptr); }
+        void setRobustKernel(RobustKernel* k) { if (k != _robust) delete _robust; _robust = k; }   // takes ownership, 0 removes
+        RobustKernel* robustKernel() const { return _robust; }
+        int level() const { return _level; }
+        void setLevel(int l) { _level = l; _dirty_level = true; }
+        int dimension() const { return _dimension; }
+        virtual double chi2() const { return _chi2_cache; }     // e^T Omega e of the last evaluation pass
+        virtual void computeError() {}
+        virtual void linearizeOplus() {}
+        virtual bool read(std::istream&) { return true; }
+        virtual bool write(std::ostream&) const { return true; }
+        SparseOptimizer* graph() const { return _graph; }
+        int _plba_kind = -1, _plba_index = -1;                  // plba_edge_kind and index after flattening
+        double _chi2_cache = 0.0;
+        bool _depth_cache = true, _dirty_level = false;
+    protected:
+        friend class SparseOptimizer;
+        std::vector<Vertex*> _vertices;
+        RobustKernel* _robust = nullptr;
+        int _level = 0, _dimension = 0;
+        SparseOptimizer* _graph = nullptr;
+    };
+};
+
+template <int D, typename T>
+class BaseVertex : public OptimizableGraph::Vertex {
+public:
+    typedef T EstimateType;
+    static const int Dimension = D;
+    const T& estimate() const { return _estimate; }
+    void setEstimate(const T& e) { _estimate = e; }
+    int dimension() const override { return D; }
+    void setToOriginImpl() override {}
+protected:
+    T _estimate;
+};
+
+template <int D, typename E>
+class BaseEdgeT : public OptimizableGraph::Edge {
+public:
+    typedef E Measurement;
+    BaseEdgeT() { _dimension = D; if (D > 0) { _info.assign((size_t)D * D, 0.0); _error.assign(D, 0.0); } }
+    void setMeasurement(const E& m) { _measurement = m; }
+    const E& measurement() const { return _measurement; }
+    template <typename M> void setInformation(const M& m) {
+        const int n = (int)m.rows();
+        _info.assign((size_t)n * n, 0.0);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) _info[(size_t)i * n + j] = m(i, j);
+    }
+    const std::vector<double>& informationRowMajor() const { return _info; }
+    double* errorData() { return _error.data(); }
+protected:
+    E _measurement;
+    std::vector<double> _info, _error;
+};
+template <int D, typename E, typename VXi> class BaseUnaryEdge : public BaseEdgeT<D, E> { public: BaseUnaryEdge() { this->resize(1); } };
+template <int D, typename E, typename VXi, typename VXj> class BaseBinaryEdge : public BaseEdgeT<D, E> { public: BaseBinaryEdge() { this->resize(2); } };
+template <int D, typename E> class BaseMultiEdge : public BaseEdgeT<D, E> {};
+
+// ---- solver chain (configuration objects only; the arithmetic lives in the HIP library) --------------------------------
+struct PoseMatrixTypeTag {};
+template <typename M> class LinearSolverEigen { public: void setBlockOrdering(bool) {} };
+class Solver { public: virtual ~Solver() {} };
+class BlockSolverX : public Solver {
+public:
+    typedef PoseMatrixTypeTag PoseMatrixType;
+    template <typename LS> explicit BlockSolverX(std::unique_ptr<LS> ls) { (void)ls; }
+};
+class OptimizationAlgorithm { public: virtual ~OptimizationAlgorithm() {} };
+class OptimizationAlgorithmLevenberg : public OptimizationAlgorithm {
+public:
+    explicit OptimizationAlgorithmLevenberg(std::unique_ptr<BlockSolverX> s) : _solver(std::move(s)) {}
+    void setUserLambdaInit(double l) { userLambdaInit = l; }
+    void setMaxTrialsAfterFailure(int n) { maxTrials = n; }
+    double userLambdaInit = 0.0;
+    int maxTrials = 10;
+private:
+    std::unique_ptr<BlockSolverX> _solver;
+};
+class OptimizationAlgorithmGaussNewton : public OptimizationAlgorithm {
+public:
+    explicit OptimizationAlgorithmGaussNewton(std::unique_ptr<BlockSolverX> s) : _solver(std::move(s)) {}
+private:
+    std::unique_ptr<BlockSolverX> _solver;
+};
+
+}  // namespace g2o
+
+typedef g2o::LinearSolverEigen<g2o::BlockSolverX::PoseMatrixType> SlamLinearSolver;   // IMU/g2otypes.h:18
+
+// ================================================================================================================
+// MarginalizationInfo / ResidualBlockInfo (IMU/marginalization.h:29-100)
+// ================================================================================================================
+struct ResidualBlockInfo {
+    ResidualBlockInfo(g2o::OptimizableGraph::Edge* _edge, std::vector<int> _drop_set, std::vector<VectorXd> _vertex_data,
+                      std::vector<double*> _jac_addr, std::string _ResidualBlockType = "")
+        : ResidualBlockType(_ResidualBlockType), edge(_edge), vertex_data(_vertex_data), drop_set(_drop_set), jac_addr(_jac_addr) {
+        for (size_t i = 0; i < edge->vertices().size(); i++) {
+            g2o::OptimizableGraph::Vertex* v = edge->vertex(i);
+            vertexs.push_back(v);
+            int N = v->estimateDimension();
+            if (N == -1) { std::cout << "Please check the overload function [estimateDimension()] in your vertex...." << std::endl; exit(0); }
+            vertex_local_size.push_back(N);
+        }
+    }
+    void Evaluate() {}   // factors are re-evaluated on the device at the final estimate (SURVEY B-Q3)
+    std::string ResidualBlockType;
+    g2o::OptimizableGraph::Edge* edge;
+    std::vector<g2o::OptimizableGraph::Vertex*> vertexs;
+    std::vector<int> vertex_local_size;
+    std::vector<VectorXd> vertex_data;
+    std::vector<int> drop_set;
+    std::vector<double*> jac_addr;
+};
+
+class MarginalizationInfo {
+public:
+    MarginalizationInfo() {}
+    void addResidualBlockInfo(ResidualBlockInfo* r) { factors.emplace_back(r); }
+    void preMarginalize() {}
+    inline void marginalizeWithoutThread();
+    void marginalize() { marginalizeWithoutThread(); }
+    int m = 0, n = 0;
+    std::vector<int> keep_vertex_size, keep_vertex_id, keep_vertex_idx;
+    std::vector<VectorXd> keep_vertex_data;
+    MatrixXd linearized_jacobians;
+    VectorXd linearized_residuals;
+    std::vector<ResidualBlockInfo*> factors;
+    double eps = 1e-8;
+};
+
+// ================================================================================================================
+// vertex and edge types of IMU/g2otypes.h
+// ================================================================================================================
+namespace g2o {
+
+class VertexLMPointXYZ : public BaseVertex<3, Vector3d> {
+public:
+    void oplusImpl(const double* u) override { for (int i = 0; i < 3; ++i) _estimate(i) += u[i]; }
+    int estimateDimension() const override { return 3; }
+};
+class VertexLine : public BaseVertex<6, Vector6d> {
+public:
+    void oplusImpl(const double* u) override { for (int i = 0; i < 6; ++i) _estimate(i) += u[i]; }
+    int estimateDimension() const override { return 6; }
+};
+class VertexNavStatePVR : public BaseVertex<9, NavState> {
+public:
+    void oplusImpl(const double* u) override { Vector9d v; for (int i = 0; i < 9; ++i) v(i) = u[i]; _estimate.IncSmallPVR(v); }
+    int estimateDimension() const override { return 9; }
+    void setToOriginImpl() override { _estimate = NavState(); }
+};
+class VertexNavStateBias : public BaseVertex<6, NavState> {
+public:
+    void oplusImpl(const double* u) override { Vector6d v; for (int i = 0; i < 6; ++i) v(i) = u[i]; _estimate.IncSmallBias(v); }
+    int estimateDimension() const override { return 6; }
+    void setToOriginImpl() override { _estimate = NavState(); }
+};
+
+inline void plba_est_pvr(const NavState& ns, VectorXd& out) {   // GetEstData: P, V, Quaterniond(Rwb) (x,y,z,w)
+    out.resize(10);
+    const double* s = ns.raw();
+    for (int i = 0; i < 6; ++i) out(i) = s[i];
+    plba::Q4 q; q.x = s[6]; q.y = s[7]; q.z = s[8]; q.w = s[9];
+    const plba::Q4 c = plba::R_to_q(plba::q_to_R(q));
+    out(6) = c.x; out(7) = c.y; out(8) = c.z; out(9) = c.w;
+}
+inline void plba_est_bias(const NavState& ns, VectorXd& out) {
+    out.resize(6);
+    const double* s = ns.raw();
+    for (int i = 0; i < 3; ++i) { out(i) = s[10 + i] + s[16 + i]; out(3 + i) = s[13 + i] + s[19 + i]; }
+}
+
+class EdgeNavStatePVR : public BaseMultiEdge<9, IMUPreintegrator> {
+public:
+    EdgeNavStatePVR() { resize(3); }
+    void SetParams(const Vector3d& gw) { GravityVec = gw; }
+    const Vector3d& gravity() const { return GravityVec; }
+    void GetJacAddr(std::vector<double*>& addr) { addr.assign(3, nullptr); }
+    void GetEstData(std::vector<VectorXd>& data) {
+        VectorXd a, b, c;
+        plba_est_pvr(static_cast<VertexNavStatePVR*>(_vertices[0])->estimate(), a);
+        plba_est_pvr(static_cast<VertexNavStatePVR*>(_vertices[1])->estimate(), b);
+        plba_est_bias(static_cast<VertexNavStateBias*>(_vertices[2])->estimate(), c);
+        data.push_back(a); data.push_back(b); data.push_back(c);
+    }
+protected:
+    Vector3d GravityVec;
+};
+class EdgeNavStateBias : public BaseBinaryEdge<6, IMUPreintegrator, VertexNavStateBias, VertexNavStateBias> {
+public:
+    void GetJacAddr(std::vector<double*>& addr) { addr.assign(2, nullptr); }
+    void GetEstData(std::vector<VectorXd>& data) {
+        VectorXd a, b;
+        plba_est_bias(static_cast<VertexNavStateBias*>(_vertices[0])->estimate(), a);
+        plba_est_bias(static_cast<VertexNavStateBias*>(_vertices[1])->estimate(), b);
+        data.push_back(a); data.push_back(b);
+    }
+};
+struct CamParams { double fx = 0, fy = 0, cx = 0, cy = 0, Rbc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Pbc[3] = {0, 0, 0}; bool set = false; };
+
+class EdgeNavStatePVRPointXYZ : public BaseBinaryEdge<2, Vector2d, VertexLMPointXYZ, VertexNavStatePVR> {
+public:
+    void SetParams(const double& fx_, const double& fy_, const double& cx_, const double& cy_, const Matrix3d& Rbc_, const Vector3d& Pbc_) {
+        cam.fx = fx_; cam.fy = fy_; cam.cx = cx_; cam.cy = cy_; cam.set = true;
+        for (int i = 0; i < 3; ++i) { cam.Pbc[i] = Pbc_(i); for (int j = 0; j < 3; ++j) cam.Rbc[i * 3 + j] = Rbc_(i, j); }
+    }
+    bool isDepthPositive() { return _depth_cache_fresh(); }
+    void GetJacAddr(std::vector<double*>& addr) { addr.assign(2, nullptr); }
+    void GetEstData(std::vector<VectorXd>& data) {
+        VectorXd a(3), b;
+        const Vector3d& p = static_cast<VertexLMPointXYZ*>(_vertices[0])->estimate();
+        for (int i = 0; i < 3; ++i) a(i) = p(i);
+        plba_est_pvr(static_cast<VertexNavStatePVR*>(_vertices[1])->estimate(), b);
+        data.push_back(a); data.push_back(b);
+    }
+    CamParams cam;
+private:
+    inline bool _depth_cache_fresh();
+};
+class EdgeNavStateLine : public BaseBinaryEdge<3, Vector3d, VertexLine, VertexNavStatePVR> {
+public:
+    void SetParams(const double& fx_, const double& fy_, const double& cx_, const double& cy_, const Matrix3d& Rbc_, const Vector3d& Pbc_) {
+        cam.fx = fx_; cam.fy = fy_; cam.cx = cx_; cam.cy = cy_; cam.set = true;
+        for (int i = 0; i < 3; ++i) { cam.Pbc[i] = Pbc_(i); for (int j = 0; j < 3; ++j) cam.Rbc[i * 3 + j] = Rbc_(i, j); }
+    }
+    bool isDepthPositive() { return _depth_cache_fresh(); }
+    void GetJacAddr(std::vector<double*>& addr) { addr.assign(2, nullptr); }
+    void GetEstData(std::vector<VectorXd>& data) {
+        VectorXd a(6), b;
+        const Vector6d& p = static_cast<VertexLine*>(_vertices[0])->estimate();
+        for (int i = 0; i < 6; ++i) a(i) = p(i);
+        plba_est_pvr(static_cast<VertexNavStatePVR*>(_vertices[1])->estimate(), b);
+        data.push_back(a); data.push_back(b);
+    }
+    CamParams cam;
+private:
+    inline bool _depth_cache_fresh();
+};
+class EdgeMarginalization : public BaseMultiEdge<-1, MarginalizationInfo> {
+public:
+    void setDimension(int d) { _dimension = d; _info.assign((size_t)d * d, 0.0); _error.assign(d, 0.0); }
+    void setSize(int vertices) { resize(vertices); }
+    void GetJacAddr(std::vector<double*>& addr) { addr.assign(_vertices.size(), nullptr); }
+    void GetEstData(std::vector<VectorXd>& data) {
+        MarginalizationInfo* marg = &_measurement;
+        if (_vertices.size() != marg->keep_vertex_id.size()) { std::cout << "Wrong size between vertex and variable in MarginalizationInfo...." << std::endl; exit(0); }
+        for (size_t i = 0; i < _vertices.size(); i++) {
+            VectorXd t;
+            if (marg->keep_vertex_size[i] == 9) plba_est_pvr(dynamic_cast<VertexNavStatePVR*>(_vertices[i])->estimate(), t);
+            else if (marg->keep_vertex_size[i] == 6) plba_est_bias(dynamic_cast<VertexNavStateBias*>(_vertices[i])->estimate(), t);
+            else { std::cout << "Undefined size of marginalization vertex: " << marg->keep_vertex_size[i] << std::endl; exit(0); }
+            data.push_back(t);
+        }
+    }
+};
+
+// ================================================================================================================
+// SparseOptimizer
+// ================================================================================================================
+class SparseOptimizer {
+public:
+    SparseOptimizer() {}
+    ~SparseOptimizer() {
+        for (auto* e : _edges) delete e;
+        for (auto& kv : _vertices) delete kv.second;
+        delete _algorithm;
+        if (_prob) plba_destroy(_prob);
+    }
+    void setAlgorithm(OptimizationAlgorithm* a) { delete _algorithm; _algorithm = a; }
+    void setForceStopFlag(bool* f) { _forceStop = f; }
+    void setVerbose(bool v) { _verbose = v; }
+    bool addVertex(OptimizableGraph::Vertex* v) { if (_vertices.count(v->id())) return false; v->_graph = this; _vertices[v->id()] = v; _dirty = true; return true; }
+    bool addEdge(OptimizableGraph::Edge* e) { e->_graph = this; _edges.push_back(e); _dirty = true; return true; }
+    OptimizableGraph::Vertex* vertex(int id) { auto it = _vertices.find(id); return it == _vertices.end() ? nullptr : it->second; }
+    bool initializeOptimization(int level = 0) { _level = level; return true; }
+    bool terminate() const { return _forceStop && *_forceStop; }
+    const char* lastError() const { return _err.c_str(); }
+    plba_problem* problem() { return _prob; }
+    const plba_stats& lastStats() const { return _stats; }
+
+    // = g2o SparseOptimizer::optimize: returns the number of iterations, -1/0 on failure
+    int optimize(int iterations) {
+        if (!flatten()) { std::cerr << "[plba g2o facade] " << _err << std::endl; return -1; }
+        static_assert(sizeof(bool) == 1, "force-stop flag is polled as a byte");
+        const int rc = plba_optimize(_prob, iterations, reinterpret_cast<const volatile uint8_t*>(_forceStop), &_stats);
+        if (rc != PLBA_OK) { _err = plba_last_error(_prob); std::cerr << "[plba g2o facade] " << _err << std::endl; return 0; }
+        if (_verbose) std::cerr << "iterations= " << _stats.iterations << "\t chi2= " << _stats.chi2_final << "\t lambda= " << _stats.lambda_final << std::endl;
+        writeBack();
+        return _stats.iterations;
+    }
+
+    // used by MarginalizationInfo::marginalizeWithoutThread
+    bool marginalizeFactors(const std::vector<ResidualBlockInfo*>& factors, MarginalizationInfo* out) {
+        if (!_prob) { _err = "marginalize before optimize"; return false; }
+        std::vector<int32_t> imu, pts, lns, drop;
+        int use_prior = 0;
+        for (auto* f : factors) {
+            OptimizableGraph::Edge* e = f->edge;
+            if (e->_plba_index < 0) { _err = "marginalization factor edge is not part of the optimised graph"; return false; }
+            switch (e->_plba_kind) {
+                case PLBA_EDGE_IMU_PVR: case PLBA_EDGE_IMU_BIAS: if (std::find(imu.begin(), imu.end(), e->_plba_index) == imu.end()) imu.push_back(e->_plba_index); break;
+                case PLBA_EDGE_POINT: pts.push_back(e->_plba_index); break;
+                case PLBA_EDGE_LINE: lns.push_back(e->_plba_index); break;
+                case PLBA_EDGE_PRIOR: use_prior = 1; break;
+                default: _err = "unknown factor kind"; return false;
+            }
+            for (int dsi : f->drop_set) {
+                OptimizableGraph::Vertex* v = e->vertex(dsi);
+                if (dynamic_cast<VertexNavStatePVR*>(v) || dynamic_cast<VertexNavStateBias*>(v))
+                    if (std::find(drop.begin(), drop.end(), v->id()) == drop.end()) drop.push_back(v->id());
+            }
+        }
+        plba_prior pr;
+        const int rc = plba_marginalize_factors(_prob, (int)imu.size(), imu.data(), (int)pts.size(), pts.data(), (int)lns.size(), lns.data(),
+                                                use_prior, (int)drop.size(), drop.data(), &pr);
+        if (rc != PLBA_OK) { _err = plba_last_error(_prob); return false; }
+        out->m = pr.m; out->n = pr.n;
+        out->keep_vertex_size.assign(pr.size, pr.size + pr.nv);
+        out->keep_vertex_id.assign(pr.vid, pr.vid + pr.nv);
+        out->keep_vertex_idx.clear();
+        for (int i = 0; i < pr.nv; ++i) out->keep_vertex_idx.push_back(pr.idx[i] + pr.m);   // the reference stores idx including m
+        out->keep_vertex_data.clear();
+        int xo = 0;
+        for (int i = 0; i < pr.nv; ++i) {
+            const int c = pr.size[i] == 9 ? 10 : 6;
+            VectorXd d(c);
+            for (int t = 0; t < c; ++t) d(t) = pr.x0[xo + t];
+            xo += c;
+            out->keep_vertex_data.push_back(d);
+        }
+        out->linearized_jacobians.resize(pr.n, pr.n);
+        for (int c = 0; c < pr.n; ++c) for (int r = 0; r < pr.n; ++r) out->linearized_jacobians(r, c) = pr.J0[(size_t)c * pr.n + r];
+        out->linearized_residuals.resize(pr.n);
+        for (int r = 0; r < pr.n; ++r) out->linearized_residuals(r) = pr.r0[r];
+        plba_prior_free(&pr);
+        return true;
+    }
+
+private:
+    bool fail(const std::string& m) { _err = m; return false; }
+
+    // graph -> SoA (include/plba.h), in the reference's vertex-id / edge-insertion order
+    bool flatten() {
+        if (!_prob) {
+            plba_options o;
+            plba_default_options(&o);
+            if (auto* lm = dynamic_cast<OptimizationAlgorithmLevenberg*>(_algorithm)) { o.user_lambda_init = lm->userLambdaInit; o.max_trials = lm->maxTrials; }
+            else return fail("only OptimizationAlgorithmLevenberg is supported on the device path");
+            if (plba_create(&o, &_prob) != PLBA_OK) return fail(plba_last_error(nullptr));
+        }
+        if (!_dirty) return syncLevelsAndKernels();
+        // keyframes: PVR vertices ascending id; the bias vertex of a keyframe has id pvr+1 (mapHandler.cpp:5802-5826)
+        _kfs.clear(); _pts.clear(); _lns.clear();
+        std::map<int, int> kf_of_vid;
+        for (auto& kv : _vertices) {
+            if (auto* v = dynamic_cast<VertexNavStatePVR*>(kv.second)) { v->_plba_index = (int)_kfs.size(); kf_of_vid[v->id()] = v->_plba_index; _kfs.push_back({v, nullptr}); }
+            else if (auto* p3 = dynamic_cast<VertexLMPointXYZ*>(kv.second)) { p3->_plba_index = (int)_pts.size(); _pts.push_back(p3); }
+            else if (auto* l6 = dynamic_cast<VertexLine*>(kv.second)) { l6->_plba_index = (int)_lns.size(); _lns.push_back(l6); }
+            else if (dynamic_cast<VertexNavStateBias*>(kv.second)) {}
+            else return fail("vertex type not supported by the device path (id " + std::to_string(kv.first) + ")");
+        }
+        for (auto& kv : _vertices)
+            if (auto* b = dynamic_cast<VertexNavStateBias*>(kv.second)) {
+                auto it = kf_of_vid.find(b->id() - 1);
+                if (it == kf_of_vid.end()) return fail("bias vertex " + std::to_string(b->id()) + " has no PVR vertex with id-1");
+                _kfs[it->second].second = b; b->_plba_index = it->second;
+            }
+        const int K = (int)_kfs.size();
+        if (K == 0) return fail("no VertexNavStatePVR in the graph");
+        std::vector<int32_t> vid_pvr(K), vid_bias(K);
+        std::vector<double> P(3 * K), V(3 * K), q(4 * K), bg(3 * K), ba(3 * K), dbg(3 * K), dba(3 * K);
+        std::vector<uint8_t> fp(K), fb(K);
+        for (int k = 0; k < K; ++k) {
+            const double* s = _kfs[k].first->estimate().raw();
+            const double* sb = _kfs[k].second ? _kfs[k].second->estimate().raw() : s;
+            vid_pvr[k] = _kfs[k].first->id(); vid_bias[k] = _kfs[k].second ? _kfs[k].second->id() : -1;
+            std::memcpy(&P[3 * k], s, 24); std::memcpy(&V[3 * k], s + 3, 24); std::memcpy(&q[4 * k], s + 6, 32);
+            std::memcpy(&bg[3 * k], sb + 10, 24); std::memcpy(&ba[3 * k], sb + 13, 24); std::memcpy(&dbg[3 * k], sb + 16, 24); std::memcpy(&dba[3 * k], sb + 19, 24);
+            fp[k] = _kfs[k].first->fixed(); fb[k] = _kfs[k].second ? _kfs[k].second->fixed() : 1;
+        }
+        std::vector<double> pxyz(3 * _pts.size()), l6(6 * _lns.size());
+        std::vector<uint8_t> pfix(_pts.size()), lfix(_lns.size());
+        for (size_t i = 0; i < _pts.size(); ++i) { for (int c = 0; c < 3; ++c) pxyz[3 * i + c] = _pts[i]->estimate()(c); pfix[i] = _pts[i]->fixed(); }
+        for (size_t i = 0; i < _lns.size(); ++i) { for (int c = 0; c < 6; ++c) l6[6 * i + c] = _lns[i]->estimate()(c); lfix[i] = _lns[i]->fixed(); }
+        // edges by kind, insertion order preserved
+        _epts.clear(); _elns.clear(); _eimu.clear(); _ebias.clear(); _eprior = nullptr;
+        for (auto* e : _edges) {
+            if (auto* a = dynamic_cast<EdgeNavStatePVRPointXYZ*>(e)) _epts.push_back(a);
+            else if (auto* b = dynamic_cast<EdgeNavStateLine*>(e)) _elns.push_back(b);
+            else if (auto* c = dynamic_cast<EdgeNavStatePVR*>(e)) _eimu.push_back(c);
+            else if (auto* d = dynamic_cast<EdgeNavStateBias*>(e)) _ebias.push_back(d);
+            else if (auto* m = dynamic_cast<EdgeMarginalization*>(e)) { if (_eprior) return fail("more than one prior edge"); _eprior = m; }
+            else return fail("edge type not supported by the device path");
+        }
+        if (_eimu.size() != _ebias.size()) return fail("every EdgeNavStatePVR needs its EdgeNavStateBias (mapHandler.cpp:5842-5885)");
+        const CamParams* cam = nullptr;
+        std::vector<int32_t> po_pt, po_kf, lo_ln, lo_kf;
+        std::vector<double> po_uv, po_w, lo_l, lo_w;
+        for (size_t i = 0; i < _epts.size(); ++i) {
+            auto* e = _epts[i];
+            if (!cam && e->cam.set) cam = &e->cam;
+            e->_plba_kind = PLBA_EDGE_POINT; e->_plba_index = (int)i;
+            po_pt.push_back(e->vertex(0)->_plba_index); po_kf.push_back(e->vertex(1)->_plba_index);
+            po_uv.push_back(e->measurement()(0)); po_uv.push_back(e->measurement()(1));
+            po_w.push_back(e->informationRowMajor()[0]);
+        }
+        for (size_t i = 0; i < _elns.size(); ++i) {
+            auto* e = _elns[i];
+            if (!cam && e->cam.set) cam = &e->cam;
+            e->_plba_kind = PLBA_EDGE_LINE; e->_plba_index = (int)i;
+            lo_ln.push_back(e->vertex(0)->_plba_index); lo_kf.push_back(e->vertex(1)->_plba_index);
+            for (int c = 0; c < 3; ++c) lo_l.push_back(e->measurement()(c));
+            lo_w.push_back(e->informationRowMajor()[0]);
+        }
+        int rc = PLBA_OK;
+        if (cam) rc = plba_set_camera(_prob, cam->fx, cam->fy, cam->cx, cam->cy, cam->Rbc, cam->Pbc);
+        else { const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0}; rc = plba_set_camera(_prob, 1, 1, 0, 0, I, z); }
+        if (rc) return fail(plba_last_error(_prob));
+        if ((rc = plba_set_keyframes(_prob, K, vid_pvr.data(), vid_bias.data(), P.data(), V.data(), q.data(), bg.data(), ba.data(), dbg.data(), dba.data(), fp.data(), fb.data()))) return fail(plba_last_error(_prob));
+        if ((rc = plba_set_points(_prob, (int)_pts.size(), pxyz.data(), pfix.data()))) return fail(plba_last_error(_prob));
+        if ((rc = plba_set_lines(_prob, (int)_lns.size(), l6.data(), lfix.data()))) return fail(plba_last_error(_prob));
+        if ((rc = plba_set_point_obs(_prob, (int)_epts.size(), po_pt.data(), po_kf.data(), po_uv.data(), po_w.data()))) return fail(plba_last_error(_prob));
+        if ((rc = plba_set_line_obs(_prob, (int)_elns.size(), lo_ln.data(), lo_kf.data(), lo_l.data(), lo_w.data()))) return fail(plba_last_error(_prob));
+        // IMU edges (PVR edge m and bias edge m describe the same keyframe pair)
+        const int M = (int)_eimu.size();
+        std::vector<int32_t> ki(M), kj(M);
+        std::vector<double> pre((size_t)M * 142), ipvr((size_t)M * 81), ibias((size_t)M * 36);
+        for (int m = 0; m < M; ++m) {
+            auto* e = _eimu[m];
+            e->_plba_kind = PLBA_EDGE_IMU_PVR; e->_plba_index = m;
+            _ebias[m]->_plba_kind = PLBA_EDGE_IMU_BIAS; _ebias[m]->_plba_index = m;
+            ki[m] = e->vertex(0)->_plba_index; kj[m] = e->vertex(1)->_plba_index;
+            std::memcpy(&pre[(size_t)m * 142], e->measurement().payload(), 142 * 8);
+            std::memcpy(&ipvr[(size_t)m * 81], e->informationRowMajor().data(), 81 * 8);
+            std::memcpy(&ibias[(size_t)m * 36], _ebias[m]->informationRowMajor().data(), 36 * 8);
+            if (m == 0) { const double g[3] = {e->gravity()(0), e->gravity()(1), e->gravity()(2)}; if ((rc = plba_set_gravity(_prob, g))) return fail(plba_last_error(_prob)); }
+        }
+        if ((rc = plba_set_imu_edges(_prob, M, ki.data(), kj.data(), pre.data(), ipvr.data(), ibias.data()))) return fail(plba_last_error(_prob));
+        if (_eprior) {
+            const MarginalizationInfo& mi = _eprior->measurement();
+            _eprior->_plba_kind = PLBA_EDGE_PRIOR; _eprior->_plba_index = 0;
+            const int nv = (int)mi.keep_vertex_id.size(), n = mi.n;
+            std::vector<int32_t> vid(nv), size(nv), idx(nv);
+            std::vector<double> x0, J0((size_t)n * n), r0(n);
+            for (int i = 0; i < nv; ++i) {
+                vid[i] = mi.keep_vertex_id[i]; size[i] = mi.keep_vertex_size[i]; idx[i] = mi.keep_vertex_idx[i] - mi.m;
+                for (int t = 0; t < (int)mi.keep_vertex_data[i].size(); ++t) x0.push_back(mi.keep_vertex_data[i](t));
+            }
+            for (int c = 0; c < n; ++c) for (int r = 0; r < n; ++r) J0[(size_t)c * n + r] = mi.linearized_jacobians(r, c);
+            for (int r = 0; r < n; ++r) r0[r] = mi.linearized_residuals(r);
+            if ((rc = plba_set_prior(_prob, n, nv, vid.data(), size.data(), idx.data(), x0.data(), J0.data(), r0.data()))) return fail(plba_last_error(_prob));
+        } else if ((rc = plba_set_prior(_prob, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return fail(plba_last_error(_prob));
+        _dirty = false;
+        return syncLevelsAndKernels();
+    }
+
+    // setLevel / setRobustKernel may change between optimize() calls (stage-2 protocol, mapHandler.cpp:6047-6066)
+    bool syncLevelsAndKernels() {
+        std::vector<uint8_t> lv(_epts.size());
+        for (size_t i = 0; i < _epts.size(); ++i) lv[i] = (uint8_t)(_epts[i]->level() != _level);
+        if (!lv.empty() && plba_set_levels(_prob, PLBA_EDGE_POINT, lv.data())) return fail(plba_last_error(_prob));
+        lv.assign(_elns.size(), 0);
+        for (size_t i = 0; i < _elns.size(); ++i) lv[i] = (uint8_t)(_elns[i]->level() != _level);
+        if (!lv.empty() && plba_set_levels(_prob, PLBA_EDGE_LINE, lv.data())) return fail(plba_last_error(_prob));
+        auto kernel = [&](const std::vector<OptimizableGraph::Edge*>& es, plba_edge_kind kind) -> bool {
+            int with = 0; double delta = 0.0;
+            for (auto* e : es) if (e->robustKernel()) { ++with; delta = e->robustKernel()->delta(); }
+            if (with != 0 && with != (int)es.size()) return fail("robust kernels must be uniform per edge type on the device path");
+            return plba_set_robust(_prob, kind, with != 0, delta) == PLBA_OK;
+        };
+        std::vector<OptimizableGraph::Edge*> a(_epts.begin(), _epts.end()), b(_elns.begin(), _elns.end()), c(_eimu.begin(), _eimu.end()), d(_ebias.begin(), _ebias.end());
+        return kernel(a, PLBA_EDGE_POINT) && kernel(b, PLBA_EDGE_LINE) && kernel(c, PLBA_EDGE_IMU_PVR) && kernel(d, PLBA_EDGE_IMU_BIAS);
+    }
+
+    void writeBack() {
+        const int K = (int)_kfs.size();
+        std::vector<double> P(3 * K), V(3 * K), q(4 * K), dbg(3 * K), dba(3 * K), pts(3 * _pts.size()), lns(6 * _lns.size());
+        plba_get_keyframes(_prob, P.data(), V.data(), q.data(), dbg.data(), dba.data());
+        if (!_pts.empty()) plba_get_points(_prob, pts.data());
+        if (!_lns.empty()) plba_get_lines(_prob, lns.data());
+        for (int k = 0; k < K; ++k) {
+            NavState ns = _kfs[k].first->estimate();
+            std::memcpy(ns.raw(), &P[3 * k], 24); std::memcpy(ns.raw() + 3, &V[3 * k], 24); std::memcpy(ns.raw() + 6, &q[4 * k], 32);
+            _kfs[k].first->setEstimate(ns);
+            if (_kfs[k].second) {
+                NavState nb = _kfs[k].second->estimate();
+                std::memcpy(nb.raw() + 16, &dbg[3 * k], 24); std::memcpy(nb.raw() + 19, &dba[3 * k], 24);
+                _kfs[k].second->setEstimate(nb);
+            }
+        }
+        for (size_t i = 0; i < _pts.size(); ++i) _pts[i]->setEstimate(Vector3d(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+        for (size_t i = 0; i < _lns.size(); ++i) { Vector6d l; for (int c = 0; c < 6; ++c) l(c) = lns[6 * i + c]; _lns[i]->setEstimate(l); }
+        // cached chi2 / depth for the gating loop of the call site
+        std::vector<double> chi(std::max(_epts.size(), _elns.size()) + 1);
+        std::vector<uint8_t> dp(chi.size());
+        if (!_epts.empty() && plba_get_edge_chi2(_prob, PLBA_EDGE_POINT, chi.data(), dp.data()) == PLBA_OK)
+            for (size_t i = 0; i < _epts.size(); ++i) { _epts[i]->_chi2_cache = chi[i]; _epts[i]->_depth_cache = dp[i] != 0; }
+        if (!_elns.empty() && plba_get_edge_chi2(_prob, PLBA_EDGE_LINE, chi.data(), dp.data()) == PLBA_OK)
+            for (size_t i = 0; i < _elns.size(); ++i) { _elns[i]->_chi2_cache = chi[i]; _elns[i]->_depth_cache = dp[i] != 0; }
+        std::vector<double> ci(_eimu.size() + 1);
+        if (!_eimu.empty() && plba_get_edge_chi2(_prob, PLBA_EDGE_IMU_PVR, ci.data(), nullptr) == PLBA_OK) for (size_t i = 0; i < _eimu.size(); ++i) _eimu[i]->_chi2_cache = ci[i];
+        if (!_ebias.empty() && plba_get_edge_chi2(_prob, PLBA_EDGE_IMU_BIAS, ci.data(), nullptr) == PLBA_OK) for (size_t i = 0; i < _ebias.size(); ++i) _ebias[i]->_chi2_cache = ci[i];
+    }
+
+    std::map<int, OptimizableGraph::Vertex*> _vertices;
+    std::vector<OptimizableGraph::Edge*> _edges;
+    std::vector<std::pair<VertexNavStatePVR*, VertexNavStateBias*>> _kfs;
+    std::vector<VertexLMPointXYZ*> _pts;
+    std::vector<VertexLine*> _lns;
+    std::vector<EdgeNavStatePVRPointXYZ*> _epts;
+    std::vector<EdgeNavStateLine*> _elns;
+    std::vector<EdgeNavStatePVR*> _eimu;
+    std::vector<EdgeNavStateBias*> _ebias;
+    EdgeMarginalization* _eprior = nullptr;
+    OptimizationAlgorithm* _algorithm = nullptr;
+    bool* _forceStop = nullptr;
+    bool _verbose = false, _dirty = true;
+    int _level = 0;
+    plba_problem* _prob = nullptr;
+    plba_stats _stats;
+    std::string _err;
+};
+
+inline bool EdgeNavStatePVRPointXYZ::_depth_cache_fresh() { return _depth_cache; }
+inline bool EdgeNavStateLine::_depth_cache_fresh() { return _depth_cache; }
+
+}  // namespace g2o
+
+inline void MarginalizationInfo::marginalizeWithoutThread() {
+    if (factors.empty()) return;
+    g2o::SparseOptimizer* opt = factors[0]->edge->graph();
+    if (!opt || !opt->marginalizeFactors(factors, this)) {
+        std::cerr << "[plba g2o facade] marginalization failed: " << (opt ? opt->lastError() : "edge without graph") << std::endl;
+        exit(0);   // the reference's error convention on this path (IMU/marginalization.cpp:47-50,113-116)
+    }
+}

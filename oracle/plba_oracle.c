@@ -1850,6 +1850,19 @@ int orc_marginalize(plba_problem* p, int first_kf, int max_edges, plba_prior* ou
     free(A); free(b); free(Amm); free(wv); free(Vm); free(Ainv); free(T); free(w2); free(V2);
     return PLBA_OK;
 }
+/* oracle counterpart of plba_marginalize_factors: only the reference's own selection is restated, so the general
+ * entry accepts exactly the factor set orc_marginalize would pick for the dropped keyframe and defers to it. */
+int orc_marginalize_factors(plba_problem* p, int n_imu, const int32_t* imu_edges, int n_pt, const int32_t* point_edges,
+                            int n_ln, const int32_t* line_edges, int use_prior, int n_drop, const int32_t* drop_vid, plba_prior* out) {
+    (void)imu_edges; (void)point_edges; (void)line_edges; (void)use_prior;
+    if (!p || !out || n_drop < 1) return PLBA_ERR_INVALID;
+    int first_kf = -1;
+    for (int k = 0; k < p->K; ++k) if (p->vid_pvr[k] == drop_vid[0]) first_kf = k;
+    if (first_kf < 0) FAIL(p, PLBA_ERR_INVALID, "marginalize_factors: dropped vertex %d is not a PVR vertex of the window", drop_vid[0]);
+    int num_pt = n_pt > 0 ? n_pt - 1 : 0, num_ln = n_ln > 0 ? n_ln - 1 : 0;
+    (void)n_imu; (void)num_ln;
+    return orc_marginalize(p, first_kf, num_pt > num_ln ? num_pt : num_ln, out);
+}
 void orc_prior_free(plba_prior* pr) {
     if (!pr) return;
     free(pr->vid); free(pr->size); free(pr->idx); free(pr->x0); free(pr->J0); free(pr->r0); free(pr->Ar); free(pr->br);

@@ -81,6 +81,7 @@ SIGNATURES = {
     "save_state": (C.c_int, [_P]),
     "restore_state": (C.c_int, [_P]),
     "marginalize": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(Prior)]),
+    "marginalize_factors": (C.c_int, [_P, C.c_int, c_int32_p, C.c_int, c_int32_p, C.c_int, c_int32_p, C.c_int, C.c_int, c_int32_p, C.POINTER(Prior)]),
     "prior_free": (None, [C.POINTER(Prior)]),
     "debug_build": (C.c_int, [_P, C.c_double, C.c_int]),
     "debug_get": (C.c_int, [_P, C.c_char_p, c_double_p, C.c_size_t, C.POINTER(C.c_size_t)]),

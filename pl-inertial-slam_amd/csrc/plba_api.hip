@@ -778,6 +778,15 @@ int plba_marginalize(plba_problem* p, int first_kf, int max_edges, plba_prior* o
     HIPCK(p, hipSetDevice(p->device));
     return marginalize_device(p, first_kf, max_edges, out);
 }
+int plba_marginalize_factors(plba_problem* p, int n_imu, const int32_t* imu_edges, int n_pt, const int32_t* point_edges,
+                             int n_ln, const int32_t* line_edges, int use_prior, int n_drop, const int32_t* drop_vid, plba_prior* out) {
+    if (!p || !out || n_imu < 0 || n_pt < 0 || n_ln < 0 || n_drop < 0) return PLBA_ERR_INVALID;
+    int rc = prepare(p);
+    if (rc) return rc;
+    HIPCK(p, hipSetDevice(p->device));
+    std::vector<int> im(imu_edges, imu_edges + n_imu), pt(point_edges, point_edges + n_pt), ln(line_edges, line_edges + n_ln), dr(drop_vid, drop_vid + n_drop);
+    return marginalize_factors_device(p, im, pt, ln, use_prior != 0, dr, out);
+}
 void plba_prior_free(plba_prior* pr) {
     if (!pr) return;
     free(pr->vid); free(pr->size); free(pr->idx); free(pr->x0); free(pr->J0); free(pr->r0); free(pr->Ar); free(pr->br);

@@ -115,4 +115,6 @@ void launch_ata(const double* A_colmajor, int rows, int cols, double* out_rowmaj
 
 // marginalization
 int marginalize_device(struct plba_problem* p, int first_kf, int max_edges, plba_prior* out);
+int marginalize_factors_device(struct plba_problem* p, const std::vector<int>& imu_edges, const std::vector<int>& pt_edges,
+                               const std::vector<int>& ln_edges, bool use_prior, const std::vector<int>& drop_vid, plba_prior* out);
 }  // namespace plba

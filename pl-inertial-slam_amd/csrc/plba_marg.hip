@@ -240,14 +240,15 @@ void est_bias(const double* s, double* o) { for (int c = 0; c < 3; ++c) { o[c] =
 #define PID_PT(i) ((1 << 28) + (i))
 #define PID_LN(i) ((1 << 29) + (i))
 
-int marginalize_device(plba_problem* p, int first_kf, int max_edges, plba_prior* out) {
-    if (first_kf < 0 || first_kf >= p->K) PLBA_FAIL(p, PLBA_ERR_INVALID, "marginalize: first_kf out of range");
+// General form: explicit factor lists.  imu_edges[]: each contributes its PVR edge and its bias edge;
+// pt_edges / ln_edges: indices into the uploaded point / line observation arrays; drop_vid[]: keyframe vertices
+// (ids) to marginalize out.  The landmark of every listed observation is always dropped (drop_set {0} at the call site).
+int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edges, const std::vector<int>& pt_edges,
+                               const std::vector<int>& ln_edges, bool use_prior, const std::vector<int>& drop_vid, plba_prior* out) {
     memset(out, 0, sizeof *out);
     const DevBuf& d = p->dv;
     hipStream_t s = p->stream;
-    const int NUM = max_edges;
-    const int vid0 = p->vid_pvr[first_kf], vidb0 = p->vid_bias[first_kf];
-    // ---- factor selection (mapHandler.cpp:6075-6188) -------------------------------------------------------------------
+    auto dropped = [&](int vid) { return std::find(drop_vid.begin(), drop_vid.end(), vid) != drop_vid.end(); };
     std::map<int, Param> params;     // keyed by pid: ascending order == SURVEY B-Q6 decision
     auto touch = [&](int pid, int size, bool drop, int kf, int isb) {
         auto it = params.find(pid);
@@ -255,45 +256,42 @@ int marginalize_device(plba_problem* p, int first_kf, int max_edges, plba_prior*
         else if (drop) it->second.drop = 1;
     };
     int R = 0;
-    const bool have_imu = p->M > 0;
-    int imu_row = -1;
-    if (have_imu) {   // vpEdgesNavStatePVR[0] / vpEdgesNavStateBias[0]: the first IMU edge, drop_set = {0}
-        const int ki = p->imu_i[0], kj = p->imu_j[0];
-        touch(p->vid_pvr[ki], 9, true, ki, 0); touch(p->vid_pvr[kj], 9, false, kj, 0);
-        touch(p->vid_bias[ki], 6, true, ki, 1); touch(p->vid_bias[kj], 6, false, kj, 1);
-        imu_row = R; R += 15;
+    std::vector<int> imu_rows;
+    for (int m : imu_edges) {
+        if (m < 0 || m >= p->M) PLBA_FAIL(p, PLBA_ERR_INVALID, "marginalize: imu edge %d out of range", m);
+        const int ki = p->imu_i[m], kj = p->imu_j[m];
+        touch(p->vid_pvr[ki], 9, dropped(p->vid_pvr[ki]), ki, 0); touch(p->vid_pvr[kj], 9, dropped(p->vid_pvr[kj]), kj, 0);
+        touch(p->vid_bias[ki], 6, dropped(p->vid_bias[ki]), ki, 1); touch(p->vid_bias[kj], 6, dropped(p->vid_bias[kj]), kj, 1);
+        imu_rows.push_back(R); R += 15;
     }
     std::vector<MargObs> obs;
-    auto select = [&](const std::vector<int32_t>& lm_of, const std::vector<int32_t>& kf_of, int E, int ebase, bool is_pt) {
-        int num = 0, e = 0;
-        const int N = is_pt ? p->Np : p->Nl;
-        for (int l = 0; l < N && num <= NUM; ++l) {
-            const int e0 = e;
-            while (e < E && lm_of[e] == l) ++e;
-            if (e0 == e || kf_of[e0] != first_kf) continue;      // kf_obs_list[0] == first_kf_idx
-            for (int a = e0; a < e; ++a) {
-                const int k = kf_of[a];
-                touch(is_pt ? PID_PT(l) : PID_LN(l), is_pt ? 3 : 6, true, -1, 0);
-                touch(p->vid_pvr[k], 9, p->vid_pvr[k] == vid0, k, 0);
-                obs.push_back(MargObs{ebase + a, R, is_pt ? PID_PT(l) : PID_LN(l), p->vid_pvr[k]});   // pids for now
-                R += 2;
-                if (++num > NUM) break;                           // `num>NUM` after the increment admits NUM+1 (B-Q10)
-            }
-        }
-    };
-    select(p->po_pt, p->po_kf, p->Ep, 0, true);
-    select(p->lo_ln, p->lo_kf, p->El, p->Ep, false);
+    for (int e : pt_edges) {
+        if (e < 0 || e >= p->Ep) PLBA_FAIL(p, PLBA_ERR_INVALID, "marginalize: point edge %d out of range", e);
+        const int l = p->po_pt[e], k = p->po_kf[e];
+        touch(PID_PT(l), 3, true, -1, 0);
+        touch(p->vid_pvr[k], 9, dropped(p->vid_pvr[k]), k, 0);
+        obs.push_back(MargObs{e, R, PID_PT(l), p->vid_pvr[k]});
+        R += 2;
+    }
+    for (int e : ln_edges) {
+        if (e < 0 || e >= p->El) PLBA_FAIL(p, PLBA_ERR_INVALID, "marginalize: line edge %d out of range", e);
+        const int l = p->lo_ln[e], k = p->lo_kf[e];
+        touch(PID_LN(l), 6, true, -1, 0);
+        touch(p->vid_pvr[k], 9, dropped(p->vid_pvr[k]), k, 0);
+        obs.push_back(MargObs{p->Ep + e, R, PID_LN(l), p->vid_pvr[k]});
+        R += 2;
+    }
     int prior_row = -1;
-    if (p->pr_nv > 0) {
+    if (use_prior && p->pr_nv > 0) {
         std::map<int, std::pair<int, int>> by_vid;
         for (int k = 0; k < p->K; ++k) { by_vid[p->vid_pvr[k]] = {k, 0}; if (p->vid_bias[k] >= 0) by_vid[p->vid_bias[k]] = {k, 1}; }
         for (int i = 0; i < p->pr_nv; ++i) {
             const auto& kv = by_vid[p->pr_vid[i]];
-            touch(p->pr_vid[i], p->pr_size[i], p->pr_vid[i] == vid0 || p->pr_vid[i] == vidb0, kv.first, kv.second);
+            touch(p->pr_vid[i], p->pr_size[i], dropped(p->pr_vid[i]), kv.first, kv.second);
         }
         prior_row = R; R += p->pr_n;
     }
-    if (params.empty() || R == 0) PLBA_FAIL(p, PLBA_ERR_STATE, "marginalize: no factor touches keyframe %d", first_kf);
+    if (params.empty() || R == 0) PLBA_FAIL(p, PLBA_ERR_STATE, "marginalize: empty factor set");
     // ---- parameter order: dropped first (keyframe block, then landmark blocks), then kept; ascending id inside ---------
     std::map<int, int> col;          // pid -> column offset
     int pos = 0;
@@ -321,11 +319,11 @@ int marginalize_device(plba_problem* p, int first_kf, int max_edges, plba_prior*
     PLBA_HIPCK(p, hipStreamSynchronize(s));
     const int state = p->cur;
     if (!obs.empty()) hipLaunchKernelGGL(k_marg_obs, dim3(((int)obs.size() + 63) / 64), dim3(64), 0, s, d, state, dobs.p, (int)obs.size(), dJ.p, dr.p, R);
-    if (have_imu) {
-        const int ki = p->imu_i[0], kj = p->imu_j[0];
-        hipLaunchKernelGGL(k_marg_imu, dim3(1), dim3(64), 0, s, d, state, 0, imu_row, col[p->vid_pvr[ki]], col[p->vid_pvr[kj]], col[p->vid_bias[ki]], col[p->vid_bias[kj]], dJ.p, dr.p, R);
+    for (size_t t = 0; t < imu_edges.size(); ++t) {
+        const int m = imu_edges[t], ki = p->imu_i[m], kj = p->imu_j[m];
+        hipLaunchKernelGGL(k_marg_imu, dim3(1), dim3(64), 0, s, d, state, m, imu_rows[t], col[p->vid_pvr[ki]], col[p->vid_pvr[kj]], col[p->vid_bias[ki]], col[p->vid_bias[kj]], dJ.p, dr.p, R);
     }
-    if (p->pr_nv > 0) {
+    if (prior_row >= 0) {
         Robust rb = p->rob;
         launch_pose_edges(d, state, false, rb, true, s);       // refreshes pr_err = EdgeMarginalization::computeError at the final estimate
         std::vector<int> vcol(p->pr_nv);
@@ -333,7 +331,7 @@ int marginalize_device(plba_problem* p, int first_kf, int max_edges, plba_prior*
         PLBA_HIPCK(p, dvcol.upload(vcol));
         hipLaunchKernelGGL(k_marg_prior, dim3(64), dim3(256), 0, s, d, prior_row, dvcol.p, dJ.p, dr.p, R);
     }
-    launch_ata(dJ.p, R, pos, dA.p, pos, s);
+    launch_ata(dJ.p, R, pos, dA.p, pos, s);   // A = J^T J
     hipLaunchKernelGGL(k_jt_r, dim3((pos + 63) / 64), dim3(64), 0, s, dJ.p, dr.p, R, pos, db.p);
     const double eps = p->opt.marg_eps;
     auto eliminate = [&](const std::vector<int>& boff, const std::vector<int>& bsize, const std::vector<uint8_t>& rest) -> int {
@@ -406,6 +404,29 @@ int marginalize_device(plba_problem* p, int first_kf, int max_edges, plba_prior*
         if (k->size == 9) { est_pvr(st, out->x0 + nx); nx += 10; } else { est_bias(st, out->x0 + nx); nx += 6; }
     }
     return PLBA_OK;
+}
+
+// Factor selection of the call site (src/mapHandler.cpp:6075-6188): first IMU edge, <= NUM+1 point edges and
+// <= NUM+1 line edges whose landmark was first observed in the oldest keyframe, the old prior; drop that keyframe.
+int marginalize_device(plba_problem* p, int first_kf, int max_edges, plba_prior* out) {
+    if (first_kf < 0 || first_kf >= p->K) PLBA_FAIL(p, PLBA_ERR_INVALID, "marginalize: first_kf out of range");
+    const int NUM = max_edges;
+    std::vector<int> imu, pts, lns, drop;
+    if (p->M > 0) imu.push_back(0);
+    auto select = [&](const std::vector<int32_t>& lm_of, const std::vector<int32_t>& kf_of, int E, int N, std::vector<int>& outv) {
+        int num = 0, e = 0;
+        for (int l = 0; l < N && num <= NUM; ++l) {
+            const int e0 = e;
+            while (e < E && lm_of[e] == l) ++e;
+            if (e0 == e || kf_of[e0] != first_kf) continue;      // kf_obs_list[0] == first_kf_idx
+            for (int a = e0; a < e; ++a) { outv.push_back(a); if (++num > NUM) break; }   // `num>NUM` admits NUM+1 (B-Q10)
+        }
+    };
+    select(p->po_pt, p->po_kf, p->Ep, p->Np, pts);
+    select(p->lo_ln, p->lo_kf, p->El, p->Nl, lns);
+    drop.push_back(p->vid_pvr[first_kf]);
+    if (p->vid_bias[first_kf] >= 0) drop.push_back(p->vid_bias[first_kf]);
+    return marginalize_factors_device(p, imu, pts, lns, true, drop, out);
 }
 
 }  // namespace plba

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Regenerates the golden vectors under tests/golden/ from the CPU oracle.
+
+The reference ships no fixtures for this path and cannot be built or run here, so these
+vectors are produced by this repository's own oracle (oracle/plba_oracle.c) on deterministic windows
+(window.make_window, seeds below) — they pin the oracle against regressions and give the GPU tests a
+second, frozen, comparison point.  Inputs are regenerated from the seed; only expected outputs are stored.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+CASES = {
+    "imu_small": dict(K=6, Np=60, Nl=15, imu=True, seed=0x601D01),
+    "noimu_small": dict(K=5, Np=50, Nl=12, imu=False, seed=0x601D02),
+}
+
+
+def run_case(pkg, c):
+    w = pkg.window.make_window(c["K"], c["Np"], c["Nl"], imu=c["imu"], seed=c["seed"])
+    p = orc.new_problem()
+    p.upload_window(w)
+    p.debug_build(2.5, True)
+    build = dict(chi2=float(p.debug_get("chi2")[0]), maxdiag=float(p.debug_get("maxdiag")[0]),
+                 x=p.debug_get("x").tolist(), bp=p.debug_get("bp").tolist())
+    p.close()
+    p = orc.new_problem()
+    p.upload_window(w)
+    out = pkg.protocol.local_ba(p)
+    trace1 = None
+    res = pkg.protocol.results(p)
+    tr = p.trace()
+    g = dict(meta=dict(c, Ep=int(w["meta"]["Ep"]), El=int(w["meta"]["El"])), build=build,
+             gated=list(out["gated"]), stage2_trace=tr,
+             chi2=[out["stage1"].chi2_initial, out["stage1"].chi2_final, out["stage2"].chi2_initial, out["stage2"].chi2_final],
+             P=res["P"].tolist(), V=res["V"].tolist(), q=res["q"].tolist(), dbg=res["dbg"].tolist(), dba=res["dba"].tolist(),
+             points_checksum=float(np.abs(res["points"]).sum()), lines_checksum=float(np.abs(res["lines"]).sum()),
+             points_head=res["points"][:5].tolist())
+    if c["imu"]:
+        pr = p.marginalize(0, 50)
+        g["marg"] = dict(n=int(pr["n"]), m=int(pr["m"]), vid=pr["vid"].tolist(), idx=pr["idx"].tolist(),
+                         Ar_diag=np.diag(pr["Ar"]).tolist(), br=pr["br"].tolist(), r0_sq=float(pr["r0"] @ pr["r0"]))
+    p.close()
+    return g
+
+
+def main():
+    pkg = ge.load_package()
+    for name, c in CASES.items():
+        g = run_case(pkg, c)
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".json"), "w") as f:
+            json.dump(g, f, indent=0)
+        print("wrote", name, "stage2 chi2", g["chi2"][3])
+
+
+if __name__ == "__main__":
+    main()

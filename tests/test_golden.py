@@ -1,0 +1,60 @@
+"""Golden vectors (tests/golden/*.json, made by tests/golden/make_golden.py from the CPU oracle):
+the oracle must keep reproducing them (CPU), and the HIP path must match them (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["imu_small", "noimu_small"]
+
+
+def _load(name):
+    with open(os.path.join(HERE, name + ".json")) as f:
+        return json.load(f)
+
+
+def _check(pkg, new_problem, g, tol):
+    c = g["meta"]
+    w = pkg.window.make_window(c["K"], c["Np"], c["Nl"], imu=c["imu"], seed=c["seed"])
+    assert (w["meta"]["Ep"], w["meta"]["El"]) == (c["Ep"], c["El"])          # the generator itself is pinned
+    p = new_problem(); p.upload_window(w)
+    p.debug_build(2.5, True)
+    assert p.debug_get("chi2")[0] == pytest.approx(g["build"]["chi2"], rel=tol)
+    assert p.debug_get("maxdiag")[0] == pytest.approx(g["build"]["maxdiag"], rel=tol)
+    xs = np.array(g["build"]["x"])
+    assert np.abs(p.debug_get("x") - xs).max() < max(tol, 1e-9) * 10 * np.abs(xs).max()
+    assert np.abs(p.debug_get("bp") - np.array(g["build"]["bp"])).max() < tol * np.abs(g["build"]["bp"]).max()
+    p.close()
+    p = new_problem(); p.upload_window(w)
+    out = pkg.protocol.local_ba(p)
+    assert list(out["gated"]) == g["gated"]
+    tr = p.trace()
+    assert [t["accepted"] for t in tr] == [t["accepted"] for t in g["stage2_trace"]]
+    for a, b in zip(tr, g["stage2_trace"]):
+        assert a["lam"] == pytest.approx(b["lam"], rel=1e3 * tol) and a["chi2_trial"] == pytest.approx(b["chi2_trial"], rel=1e3 * tol)
+    res = pkg.protocol.results(p)
+    ptol = max(1e3 * tol, 1e-9)
+    for k in ("P", "V", "q", "dbg", "dba"):
+        assert np.abs(res[k] - np.array(g[k])).max() < ptol, k
+    assert np.abs(res["points"][:5] - np.array(g["points_head"])).max() < 10 * ptol
+    assert np.abs(res["points"]).sum() == pytest.approx(g["points_checksum"], rel=ptol)
+    if "marg" in g:
+        pr = p.marginalize(0, 50)
+        m = g["marg"]
+        assert (pr["n"], pr["m"], pr["vid"].tolist(), pr["idx"].tolist()) == (m["n"], m["m"], m["vid"], m["idx"])
+        assert np.abs(np.diag(pr["Ar"]) - np.array(m["Ar_diag"])).max() < 1e-6 * np.abs(m["Ar_diag"]).max()
+        assert np.abs(pr["br"] - np.array(m["br"])).max() < 1e-6 * max(np.abs(m["br"]).max(), 1)
+    p.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_golden(pkg, orc, name):
+    _check(pkg, orc.new_problem, _load(name), 1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_matches_golden(pkg, hip, name):
+    _check(pkg, pkg.new_problem, _load(name), 1e-9)

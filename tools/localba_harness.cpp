@@ -1,0 +1,218 @@
+// localba_harness.cpp — the reference's local-BA call site re-enacted against the g2o-compatible facade.
+//
+// Follows the PROTOCOL of MapHandler::localBundleAdjustmentWithImuAndMarg (src/mapHandler.cpp:5741-6254) — vertex ids,
+// edge insertion order, Huber deltas, optimize(5) / gating / optimize(10), marginalization factor selection, write-back —
+// on a window read from a flat binary file (written by tests/test_facade.py) instead of KeyFrame/MapPoint objects.
+// It proves that code written against the reference's g2o API (IMU/g2otypes.h, IMU/marginalization.h) runs on the HIP
+// path unchanged in shape.  Usage: localba_harness <window.bin> <result.bin>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include <g2o/core/block_solver.h>
+#include <g2o/core/optimization_algorithm_levenberg.h>
+#include <g2o/core/robust_kernel_impl.h>
+#include <g2o/core/sparse_optimizer.h>
+#include <g2o/solvers/eigen/linear_solver_eigen.h>
+#include "plba_g2o/g2otypes.h"
+
+template <typename T> static std::vector<T> rd(FILE* f, size_t n) { std::vector<T> v(n); if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } return v; }
+template <typename T> static void wr(FILE* f, const std::vector<T>& v) { if (!v.empty()) fwrite(v.data(), sizeof(T), v.size(), f); }
+
+int main(int argc, char** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: %s window.bin result.bin\n", argv[0]); return 2; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) { perror("window"); return 2; }
+    auto hdr = rd<int32_t>(f, 8);
+    const int K = hdr[0], Np = hdr[1], Nl = hdr[2], Ep = hdr[3], El = hdr[4], M = hdr[5], do_marg = hdr[6], max_kf_in_window = hdr[7];
+    auto cam = rd<double>(f, 4); auto Rbcv = rd<double>(f, 9); auto Pbcv = rd<double>(f, 3); auto gwv = rd<double>(f, 3); auto hub = rd<double>(f, 4);
+    auto kf_idx = rd<int32_t>(f, K);
+    auto P = rd<double>(f, 3 * K), V = rd<double>(f, 3 * K), q = rd<double>(f, 4 * K), bg = rd<double>(f, 3 * K), ba = rd<double>(f, 3 * K);
+    auto pts = rd<double>(f, 3 * (size_t)Np), lns = rd<double>(f, 6 * (size_t)Nl);
+    auto po_pt = rd<int32_t>(f, Ep), po_kf = rd<int32_t>(f, Ep); auto po_uv = rd<double>(f, 2 * (size_t)Ep), po_sig = rd<double>(f, Ep);
+    auto lo_ln = rd<int32_t>(f, El), lo_kf = rd<int32_t>(f, El); auto lo_l = rd<double>(f, 3 * (size_t)El), lo_sig = rd<double>(f, El);
+    auto pre = rd<double>(f, 142 * (size_t)M), ipvr = rd<double>(f, 81 * (size_t)M), ibias = rd<double>(f, 36 * (size_t)M);
+    fclose(f);
+
+    Matrix3d Rbc; Vector3d tbc, gw(gwv[0], gwv[1], gwv[2]);
+    for (int i = 0; i < 3; ++i) { tbc(i) = Pbcv[i]; for (int j = 0; j < 3; ++j) Rbc(i, j) = Rbcv[i * 3 + j]; }
+    const double fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    bool abortFlag = false;
+
+    g2o::SparseOptimizer optimizer;
+    auto linearSolver = g2o::make_unique<SlamLinearSolver>();
+    auto blockSolver = g2o::make_unique<g2o::BlockSolverX>(std::move(linearSolver));
+    g2o::OptimizationAlgorithm* algorithm = new g2o::OptimizationAlgorithmLevenberg(std::move(blockSolver));
+    optimizer.setAlgorithm(algorithm);
+    optimizer.setForceStopFlag(&abortFlag);
+
+    int maxKFid = 0;
+    for (int k = 0; k < K; ++k) {                                   // :5802-5830
+        NavState ns;
+        ns.Set_Pos(Vector3d(P[3 * k], P[3 * k + 1], P[3 * k + 2])); ns.Set_Vel(Vector3d(V[3 * k], V[3 * k + 1], V[3 * k + 2]));
+        ns.Set_Rot(Sophus::SO3(Quaterniond(q[4 * k + 3], q[4 * k], q[4 * k + 1], q[4 * k + 2])));
+        ns.Set_BiasGyr(Vector3d(bg[3 * k], bg[3 * k + 1], bg[3 * k + 2])); ns.Set_BiasAcc(Vector3d(ba[3 * k], ba[3 * k + 1], ba[3 * k + 2]));
+        const int idKF = kf_idx[k] * 2;
+        g2o::VertexNavStatePVR* vNSPVR = new g2o::VertexNavStatePVR();
+        vNSPVR->setEstimate(ns); vNSPVR->setId(idKF); vNSPVR->setFixed(k == 0);
+        optimizer.addVertex(vNSPVR);
+        g2o::VertexNavStateBias* vNSBias = new g2o::VertexNavStateBias();
+        vNSBias->setEstimate(ns); vNSBias->setId(idKF + 1); vNSBias->setFixed(k == 0);
+        optimizer.addVertex(vNSBias);
+        if (idKF + 1 > maxKFid) maxKFid = idKF + 1;
+    }
+    std::vector<g2o::EdgeNavStatePVR*> vpEdgesNavStatePVR;
+    std::vector<g2o::EdgeNavStateBias*> vpEdgesNavStateBias;
+    for (int m = 0; m < M; ++m) {                                   // :5842-5885 (edge m links window keyframes m, m+1)
+        IMUPreintegrator imupre; imupre.setPayload(&pre[(size_t)m * 142]);
+        g2o::EdgeNavStatePVR* epvr = new g2o::EdgeNavStatePVR();
+        epvr->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[m])));
+        epvr->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[m + 1])));
+        epvr->setVertex(2, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[m] + 1)));
+        epvr->setMeasurement(imupre);
+        Matrix9d InvCovPVR; for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) InvCovPVR(i, j) = ipvr[(size_t)m * 81 + i * 9 + j];
+        epvr->setInformation(InvCovPVR);
+        epvr->SetParams(gw);
+        g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber; epvr->setRobustKernel(rk); rk->setDelta(hub[2]);
+        optimizer.addEdge(epvr); vpEdgesNavStatePVR.push_back(epvr);
+        g2o::EdgeNavStateBias* ebias = new g2o::EdgeNavStateBias();
+        ebias->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[m] + 1)));
+        ebias->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[m + 1] + 1)));
+        ebias->setMeasurement(imupre);
+        Eigen::Matrix<double, 6, 6> InvCovB; for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) InvCovB(i, j) = ibias[(size_t)m * 36 + i * 6 + j];
+        ebias->setInformation(InvCovB);
+        g2o::RobustKernelHuber* rkb = new g2o::RobustKernelHuber; ebias->setRobustKernel(rkb); rkb->setDelta(hub[3]);
+        optimizer.addEdge(ebias); vpEdgesNavStateBias.push_back(ebias);
+    }
+    std::vector<g2o::EdgeNavStatePVRPointXYZ*> vpEdgesMono;
+    std::vector<int> vpFirstObsKf;                                   // kf_obs_list[0] of the edge's map point
+    int maxPointId = maxKFid, e = 0;
+    for (int l = 0; l < Np; ++l) {                                  // :5897-5948
+        g2o::VertexLMPointXYZ* vPoint = new g2o::VertexLMPointXYZ();
+        vPoint->setEstimate(Vector3d(pts[3 * l], pts[3 * l + 1], pts[3 * l + 2]));
+        const int id = l + maxKFid + 1;
+        vPoint->setId(id); vPoint->setFixed(false); vPoint->setMarginalized(true);
+        optimizer.addVertex(vPoint);
+        const int e0 = e;
+        for (; e < Ep && po_pt[e] == l; ++e) {
+            g2o::EdgeNavStatePVRPointXYZ* ed = new g2o::EdgeNavStatePVRPointXYZ();
+            ed->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(id)));
+            ed->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[po_kf[e]])));
+            ed->setMeasurement(Vector2d(po_uv[2 * e], po_uv[2 * e + 1]));
+            const float invSigma2 = 1.0 / po_sig[e];
+            ed->setInformation(Eigen::Matrix2d::Identity() * invSigma2);
+            g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber; ed->setRobustKernel(rk); rk->setDelta(hub[0]);
+            ed->SetParams(fx, fy, cx, cy, Rbc, tbc);
+            optimizer.addEdge(ed); vpEdgesMono.push_back(ed); vpFirstObsKf.push_back(kf_idx[po_kf[e0]]);
+        }
+        maxPointId = id + 1;
+    }
+    std::vector<g2o::EdgeNavStateLine*> vlEdgesMono;
+    std::vector<int> vlFirstObsKf;
+    e = 0;
+    for (int l = 0; l < Nl; ++l) {                                  // :5957-6004
+        g2o::VertexLine* vLine = new g2o::VertexLine();
+        Vector6d l6; for (int c = 0; c < 6; ++c) l6(c) = lns[6 * l + c];
+        vLine->setEstimate(l6);
+        const int id = l + maxPointId + 1;
+        vLine->setId(id); vLine->setMarginalized(true);
+        optimizer.addVertex(vLine);
+        const int e0 = e;
+        for (; e < El && lo_ln[e] == l; ++e) {
+            g2o::EdgeNavStateLine* ed = new g2o::EdgeNavStateLine();
+            ed->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(id)));
+            ed->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[lo_kf[e]])));
+            ed->setMeasurement(Vector3d(lo_l[3 * e], lo_l[3 * e + 1], lo_l[3 * e + 2]));
+            const float invSigma2 = 1.0 / lo_sig[e];
+            ed->setInformation(Eigen::Matrix3d::Identity() * invSigma2);
+            g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber; ed->setRobustKernel(rk); rk->setDelta(hub[1]);
+            ed->SetParams(fx, fy, cx, cy, Rbc, tbc);
+            optimizer.addEdge(ed); vlEdgesMono.push_back(ed); vlFirstObsKf.push_back(kf_idx[lo_kf[e0]]);
+        }
+    }
+    optimizer.initializeOptimization();                              // :6038-6039
+    optimizer.optimize(5);
+    int gated_pt = 0, gated_ln = 0;
+    if (!abortFlag) {                                                // :6047-6069
+        for (size_t i = 0; i < vpEdgesMono.size(); i++) {
+            g2o::EdgeNavStatePVRPointXYZ* ed = vpEdgesMono[i];
+            if (ed->chi2() > 5.991 || !ed->isDepthPositive()) { ed->setLevel(1); ++gated_pt; }
+            ed->setRobustKernel(0);
+        }
+        for (size_t i = 0; i < vlEdgesMono.size(); i++) {
+            g2o::EdgeNavStateLine* ed = vlEdgesMono[i];
+            if (ed->chi2() > 5.991 || !ed->isDepthPositive()) { ed->setLevel(1); ++gated_ln; }
+            ed->setRobustKernel(0);
+        }
+        optimizer.initializeOptimization(0);
+        optimizer.optimize(10);
+    }
+    const double chi2_final = optimizer.lastStats().chi2_final;
+    // ---- marginalization of the oldest keyframe (:6075-6199) -------------------------------------------------------
+    const int NUM = 50;
+    MarginalizationInfo* new_marg_info = new MarginalizationInfo();
+    const int first_kf_idx = kf_idx[0];
+    if (do_marg && K >= max_kf_in_window) {
+        {
+            std::vector<int> drop_set{0}; std::vector<double*> addr; std::vector<VectorXd> est;
+            vpEdgesNavStatePVR[0]->GetJacAddr(addr); vpEdgesNavStatePVR[0]->GetEstData(est);
+            new_marg_info->addResidualBlockInfo(new ResidualBlockInfo(dynamic_cast<g2o::OptimizableGraph::Edge*>(vpEdgesNavStatePVR[0]), drop_set, est, addr, "PVR"));
+        }
+        {
+            std::vector<int> drop_set{0}; std::vector<double*> addr; std::vector<VectorXd> est;
+            vpEdgesNavStateBias[0]->GetJacAddr(addr); vpEdgesNavStateBias[0]->GetEstData(est);
+            new_marg_info->addResidualBlockInfo(new ResidualBlockInfo(dynamic_cast<g2o::OptimizableGraph::Edge*>(vpEdgesNavStateBias[0]), drop_set, est, addr, "BIAS"));
+        }
+        int num = 0;
+        for (size_t i = 0; i < vpEdgesMono.size(); i++) {
+            if (vpFirstObsKf[i] != first_kf_idx) continue;
+            g2o::OptimizableGraph::Edge* edgePoint = dynamic_cast<g2o::OptimizableGraph::Edge*>(vpEdgesMono[i]);
+            std::vector<int> drop_set{0}; std::vector<double*> addr; std::vector<VectorXd> est;
+            if (edgePoint->vertex(1)->id() == 2 * first_kf_idx) drop_set.push_back(1);
+            vpEdgesMono[i]->GetJacAddr(addr); vpEdgesMono[i]->GetEstData(est);
+            new_marg_info->addResidualBlockInfo(new ResidualBlockInfo(edgePoint, drop_set, est, addr, "POINT"));
+            if (++num > NUM) break;
+        }
+        num = 0;
+        for (size_t i = 0; i < vlEdgesMono.size(); i++) {
+            if (vlFirstObsKf[i] != first_kf_idx) continue;
+            g2o::OptimizableGraph::Edge* edgeLine = dynamic_cast<g2o::OptimizableGraph::Edge*>(vlEdgesMono[i]);
+            std::vector<int> drop_set{0}; std::vector<double*> addr; std::vector<VectorXd> est;
+            if (edgeLine->vertex(1)->id() == 2 * first_kf_idx) drop_set.push_back(1);
+            vlEdgesMono[i]->GetJacAddr(addr); vlEdgesMono[i]->GetEstData(est);
+            new_marg_info->addResidualBlockInfo(new ResidualBlockInfo(edgeLine, drop_set, est, addr, "LINE"));
+            if (++num > NUM) break;
+        }
+        new_marg_info->preMarginalize();
+        new_marg_info->marginalizeWithoutThread();
+    }
+    // ---- write-back (:6202-6239) -----------------------------------------------------------------------------------------
+    std::vector<double> oP(3 * K), oV(3 * K), oq(4 * K), odbg(3 * K), odba(3 * K), opts(3 * (size_t)Np), olns(6 * (size_t)Nl);
+    for (int k = 0; k < K; ++k) {
+        g2o::VertexNavStatePVR* vNSPVR = static_cast<g2o::VertexNavStatePVR*>(optimizer.vertex(2 * kf_idx[k]));
+        g2o::VertexNavStateBias* vNSBias = static_cast<g2o::VertexNavStateBias*>(optimizer.vertex(2 * kf_idx[k] + 1));
+        const NavState& a = vNSPVR->estimate(); const NavState& b = vNSBias->estimate();
+        Vector3d p = a.Get_P(), v = a.Get_V(), g = b.Get_dBias_Gyr(), c = b.Get_dBias_Acc();
+        Quaterniond qq = a.Get_R().unit_quaternion();
+        for (int i = 0; i < 3; ++i) { oP[3 * k + i] = p(i); oV[3 * k + i] = v(i); odbg[3 * k + i] = g(i); odba[3 * k + i] = c(i); }
+        oq[4 * k] = qq.x(); oq[4 * k + 1] = qq.y(); oq[4 * k + 2] = qq.z(); oq[4 * k + 3] = qq.w();
+    }
+    for (int l = 0; l < Np; ++l) { const Vector3d& p = static_cast<g2o::VertexLMPointXYZ*>(optimizer.vertex(l + maxKFid + 1))->estimate(); for (int i = 0; i < 3; ++i) opts[3 * l + i] = p(i); }
+    for (int l = 0; l < Nl; ++l) { const Vector6d& p = static_cast<g2o::VertexLine*>(optimizer.vertex(l + maxPointId + 1))->estimate(); for (int i = 0; i < 6; ++i) olns[6 * l + i] = p(i); }
+    FILE* o = fopen(argv[2], "wb");
+    if (!o) { perror("result"); return 2; }
+    std::vector<int32_t> oh{gated_pt, gated_ln, new_marg_info->n, new_marg_info->m, (int32_t)new_marg_info->keep_vertex_id.size()};
+    wr(o, oh); wr(o, std::vector<double>{chi2_final});
+    wr(o, oP); wr(o, oV); wr(o, oq); wr(o, odbg); wr(o, odba); wr(o, opts); wr(o, olns);
+    std::vector<int32_t> kv(new_marg_info->keep_vertex_id.begin(), new_marg_info->keep_vertex_id.end()), ks(new_marg_info->keep_vertex_size.begin(), new_marg_info->keep_vertex_size.end()), ki(new_marg_info->keep_vertex_idx.begin(), new_marg_info->keep_vertex_idx.end());
+    wr(o, kv); wr(o, ks); wr(o, ki);
+    const int n = new_marg_info->n;
+    std::vector<double> J0((size_t)n * n), r0(n);
+    for (int c = 0; c < n; ++c) for (int r = 0; r < n; ++r) J0[(size_t)c * n + r] = new_marg_info->linearized_jacobians(r, c);
+    for (int r = 0; r < n; ++r) r0[r] = new_marg_info->linearized_residuals(r);
+    wr(o, J0); wr(o, r0);
+    fclose(o);
+    printf("localba_harness: gated %d+%d, chi2 %.6f, prior n=%d\n", gated_pt, gated_ln, chi2_final, n);
+    return 0;
+}
