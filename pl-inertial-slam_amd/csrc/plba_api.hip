@@ -320,6 +320,14 @@ static int prepare(plba_problem* p) {
     for (int e = 0; e < Ep; ++e) { ob_kf[e] = p->po_kf[e]; ob_slot[e] = p->po_pt[e]; ob_w[e] = p->po_w[e]; lm_start[p->po_pt[e] + 1]++; }
     for (int e = 0; e < El; ++e) { ob_kf[Ep + e] = p->lo_kf[e]; ob_slot[Ep + e] = Np + p->lo_ln[e]; ob_w[Ep + e] = p->lo_w[e]; lm_start[Np + p->lo_ln[e] + 1]++; }
     for (int s = 0; s < L; ++s) lm_start[s + 1] += lm_start[s];
+    // keyframe-major record positions (stable: landmark order inside a keyframe)
+    p->ob_pos.assign(E, 0);
+    {
+        std::vector<int32_t> cntk(K + 1, 0);
+        for (int e = 0; e < E; ++e) cntk[ob_kf[e] + 1]++;
+        for (int k = 0; k < K; ++k) cntk[k + 1] += cntk[k];
+        for (int e = 0; e < E; ++e) p->ob_pos[e] = cntk[ob_kf[e]]++;
+    }
     p->lm0.assign((size_t)L * 6, 0.0);
     p->lm_fixed.assign(L, 0);
     for (int i = 0; i < Np; ++i) { memcpy(&p->lm0[(size_t)i * 6], &p->pts[(size_t)i * 3], 24); p->lm_fixed[i] = p->pt_fixed[i]; }
@@ -348,7 +356,7 @@ static int prepare(plba_problem* p) {
         }
     if (nent > 0x7fffffff) FAIL(p, PLBA_ERR_INVALID, "too many Schur pair entries");
     pair_start.push_back((int32_t)nent);
-    std::vector<int32_t> ent_ei((size_t)nent), ent_ej((size_t)nent);
+    std::vector<int32_t> ent_ei((size_t)nent), ent_ej((size_t)nent), ent_slot((size_t)nent);
     for (int s = 0; s < L; ++s)
         for (int a = lm_start[s]; a < lm_start[s + 1]; ++a) {
             if (p->off_pvr[ob_kf[a]] < 0) continue;
@@ -357,7 +365,7 @@ static int prepare(plba_problem* p) {
                 int ea = a, eb = b;
                 if (ob_kf[ea] > ob_kf[eb]) std::swap(ea, eb);
                 int64_t& w = pos[(size_t)ob_kf[ea] * K + ob_kf[eb]];
-                ent_ei[(size_t)w] = ea; ent_ej[(size_t)w] = eb;
+                ent_ei[(size_t)w] = p->ob_pos[ea]; ent_ej[(size_t)w] = p->ob_pos[eb]; ent_slot[(size_t)w] = s;
                 ++w;
             }
         }
@@ -389,7 +397,7 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_tv.alloc((size_t)L * 6)); HIPCK(p, p->d_xl.alloc((size_t)L * 6));
     HIPCK(p, p->d_off_pvr.upload(p->off_pvr)); HIPCK(p, p->d_off_bias.upload(p->off_bias));
     HIPCK(p, p->d_pair_i.upload(pair_i)); HIPCK(p, p->d_pair_j.upload(pair_j)); HIPCK(p, p->d_pair_start.upload(pair_start));
-    HIPCK(p, p->d_ent_ei.upload(ent_ei)); HIPCK(p, p->d_ent_ej.upload(ent_ej));
+    HIPCK(p, p->d_ent_pi.upload(ent_ei)); HIPCK(p, p->d_ent_pj.upload(ent_ej)); HIPCK(p, p->d_ent_slot.upload(ent_slot)); HIPCK(p, p->d_ob_pos.upload(p->ob_pos));
     HIPCK(p, p->d_imu_i.upload(p->imu_i)); HIPCK(p, p->d_imu_j.upload(p->imu_j)); HIPCK(p, p->d_imu_pre.upload(p->imu_pre));
     HIPCK(p, p->d_imu_ipvr.upload(p->imu_ipvr)); HIPCK(p, p->d_imu_ibias.upload(p->imu_ibias));
     HIPCK(p, p->d_imu_err.alloc((size_t)M * 16)); HIPCK(p, p->d_imu_chi.alloc((size_t)M * 4));
@@ -422,7 +430,7 @@ static int prepare(plba_problem* p) {
     d.lm_start = p->d_lm_start.p; d.lm_fixed = p->d_lm_fixed.p;
     d.hll = p->d_hll.p; d.bl = p->d_bl.p; d.dinv = p->d_dinv.p; d.tv = p->d_tv.p; d.xl = p->d_xl.p; d.lm_active = p->d_lm_active.p;
     d.kf_off_pvr = p->d_off_pvr.p; d.kf_off_bias = p->d_off_bias.p;
-    d.pair_i = p->d_pair_i.p; d.pair_j = p->d_pair_j.p; d.pair_start = p->d_pair_start.p; d.ent_ei = p->d_ent_ei.p; d.ent_ej = p->d_ent_ej.p;
+    d.pair_i = p->d_pair_i.p; d.pair_j = p->d_pair_j.p; d.pair_start = p->d_pair_start.p; d.ent_pi = p->d_ent_pi.p; d.ent_pj = p->d_ent_pj.p; d.ent_slot = p->d_ent_slot.p; d.ob_pos = p->d_ob_pos.p;
     d.imu_i = p->d_imu_i.p; d.imu_j = p->d_imu_j.p; d.imu_pre = p->d_imu_pre.p; d.imu_info_pvr = p->d_imu_ipvr.p; d.imu_info_bias = p->d_imu_ibias.p;
     d.imu_err = p->d_imu_err.p; d.imu_chi = p->d_imu_chi.p;
     d.pr_n = p->pr_n; d.pr_nv = p->pr_nv;
@@ -485,10 +493,10 @@ static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
     HIPCK(p, hipMemsetAsync(d.bimu, 0, (size_t)d.ld * 8, s));
     launch_pose_edges(d, p->cur, true, p->rob, owns_pose_edges(p), s);
     MARK(p, 2);
-    launch_landmark_hll(d, s);
+    launch_landmark_hll(d, p->cur, s);
     if (first_iter) {
         HIPCK(p, hipMemsetAsync(d.kfdiag, 0, (size_t)d.K * 6 * 8, s));
-        launch_kfdiag(d, s);
+        launch_kfdiag(d, p->cur, s);
     }
     launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
     if (p->world > 1) {
@@ -510,7 +518,7 @@ static int enqueue_solve(plba_problem* p, bool do_solve) {
     MARK(p, 4);
     launch_landmark_dinv(d, s);
     launch_assemble(d, owns_pose_edges(p), s);
-    launch_schur_pairs(d, s);
+    launch_schur_pairs(d, p->cur, s);
     MARK(p, 5);
     if (p->world > 1) { int rc = exchange(p, d.sys, (size_t)(d.Ppad + 2) * d.ld, 0); if (rc) return rc; }
     HIPCK(p, hipMemcpyAsync(d.bpg, d.sys + (size_t)(d.Ppad + 1) * d.ld, (size_t)d.ld * 8, hipMemcpyDeviceToDevice, s));
@@ -867,8 +875,8 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     } else if (w == "err_prior") { HIPCK(p, fetch(d.pr_err, p->pr_nv ? p->pr_n : 0, v)); }
     else if (w == "err_pt" || w == "err_ln") {
         std::vector<double> h; HIPCK(p, fetch(d.erec, (size_t)p->E * EREC, h));
-        if (w == "err_pt") { v.resize((size_t)p->Ep * 2); for (int e = 0; e < p->Ep; ++e) { v[2 * (size_t)e] = h[(size_t)e * EREC + 19]; v[2 * (size_t)e + 1] = h[(size_t)e * EREC + 20]; } }
-        else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { v[3 * (size_t)e] = h[(size_t)(p->Ep + e) * EREC + 19]; v[3 * (size_t)e + 1] = h[(size_t)(p->Ep + e) * EREC + 20]; } }
+        if (w == "err_pt") { v.resize((size_t)p->Ep * 2); for (int e = 0; e < p->Ep; ++e) { const size_t o = (size_t)p->ob_pos[e] * EREC; v[2 * (size_t)e] = h[o + 13]; v[2 * (size_t)e + 1] = h[o + 14]; } }
+        else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { const size_t o = (size_t)p->ob_pos[p->Ep + e] * EREC; v[3 * (size_t)e] = h[o + 13]; v[3 * (size_t)e + 1] = h[o + 14]; } }
     } else if (w == "erec") { HIPCK(p, fetch(d.erec, (size_t)p->E * EREC, v)); }
     else if (w == "pose_dim") v = {(double)p->P};
     else if (w == "chi2") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {p->h_ctrl->current_chi}; }

@@ -21,17 +21,20 @@ constexpr int FB = 32;    // factorisation block (in-wave potrf / trsm); the bac
 constexpr int XS = 80;    // LDS row stride of the transposed panel tiles XT[k][row]  (rows 0..31 = X_r, 32..63 = X_c)
 constexpr int CS = FB + 1;
 
-// broadcast lane `l` (compile-time constant after unrolling) of a double: two v_readlane_b32 -> SGPR pair
-__device__ __forceinline__ double bcast(double v, int l) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, l);
-    hi = __builtin_amdgcn_readlane(hi, l);
-    return __hiloint2double(hi, lo);
+// x L^T = a for the row held in this lane's registers, column oriented: once x[j] is final every later entry
+// is updated independently (no dependent accumulation chain).  sLT[j*NB + t] = L[t][j] and srd[j] = 1/L[j][j] sit in
+// LDS; every lane reads the same address (broadcast), and since nothing writes them the reads pipeline freely.
+template <int NB>
+__device__ __forceinline__ void trsm_row_lds(double* x, const double* sLT, const double* srd) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        x[j] *= srd[j];
+        const double xj = x[j];
+#pragma unroll
+        for (int t = j + 1; t < NB; ++t) x[t] = fma(-xj, sLT[j * NB + t], x[t]);
+    }
 }
-
-// x L^T = a for the row held in this lane's registers.  LTg[j*NB + t] = L[t][j] and rdg[j] = 1/L[j][j] live in
-// global memory written by an EARLIER kernel; they are wave-uniform, so the loads go through the scalar cache
-// (s_load_dwordx16) and feed v_fma_f64 as SGPR operands: no LDS traffic, no dependent accumulation chain.
+// scalar-path variant (operands through s_load / SGPRs) used where the L block is not staged in LDS
 template <int NB>
 __device__ __forceinline__ void trsm_row_scalar(double* x, const double* LTg, const double* rdg) {
     cdouble* LT = (cdouble*)(uintptr_t)LTg;
@@ -45,32 +48,34 @@ __device__ __forceinline__ void trsm_row_scalar(double* x, const double* LTg, co
     }
 }
 
-// Right-looking Cholesky of an NB x NB tile inside ONE wavefront, lane i holding the full symmetric row i in
-// registers.  Column j: lane j's entries are broadcast with v_readlane (no LDS, no barrier) and every lane applies
-//   a[i][c] -= a[i][j] * a[j][c] / a[j][j];
-// only a reciprocal sits on the dependency chain.  On return a[j] = L[i][j] for j <= i.
+// Right-looking Cholesky of an NB x NB tile inside ONE wavefront, lane i (< NB) holding the full SYMMETRIC row i in
+// registers.  Because the tile stays symmetric, the column needed at step j (A[c][j] for all c) is register j across
+// the lanes: one ds_write_b64 publishes it, broadcast ds_reads fetch it back, and every lane applies
+//   a[i][c] -= a[i][j] * a[c][j] / a[j][j].
+// No barrier (single wave, LDS operations of a wave execute in order), no cross-lane VALU traffic, only a reciprocal
+// on the dependency chain.  sbuf: 2*NB doubles of LDS (double-buffered by column parity).  On return a[j] = L[i][j], j <= i.
 template <int NB>
-__device__ __forceinline__ bool potrf_inwave(double* a, int lane) {
+__device__ __forceinline__ bool potrf_inwave(double* a, int lane, double* sbuf) {
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const double sj = bcast(a[j], j);
+        double* buf = sbuf + (j & 1) * NB;
+        buf[lane] = a[j];
+        const double sj = buf[j];
         const bool bj = !(sj > 0.0);
         bad = bad || bj;
         const double rinv = 1.0 / (bj ? 1.0 : sj);
         const double f = a[j] * rinv;
 #pragma unroll
-        for (int c = j + 1; c < NB; ++c) {
-            const double sc = bcast(a[c], j);
-            a[c] = fma(-f, sc, a[c]);
-        }
+        for (int c = j + 1; c < NB; ++c) a[c] = fma(-f, buf[c], a[c]);
     }
+    // L[i][j] = a[j] / sqrt(pivot_j); the pivots are the diagonal entries a[i][i] left by the sweep
     double dg = 1.0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) if (lane == j) dg = a[j];
-    const double rs = 1.0 / sqrt(dg > 0.0 ? dg : 1.0);
+    sbuf[lane] = 1.0 / sqrt(dg > 0.0 ? dg : 1.0);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) a[j] *= bcast(rs, j);
+    for (int j = 0; j < NB; ++j) a[j] *= sbuf[j];
     return bad;
 }
 
@@ -95,13 +100,14 @@ __device__ __forceinline__ void store_factor(const DevBuf& d, int kb, const doub
 }
 
 __global__ __launch_bounds__(64) void k_potrf0(DevBuf d) {
+    __shared__ double sbuf[2 * FB];
     const int lane = threadIdx.x;
     if (lane >= FB) return;
     double a[FB];
     const double* row = d.sys + (size_t)lane * d.ld;
 #pragma unroll
     for (int j = 0; j < FB; j += 2) { const double2 v = *reinterpret_cast<const double2*>(row + j); a[j] = v.x; a[j + 1] = v.y; }
-    const bool bad = potrf_inwave<FB>(a, lane);
+    const bool bad = potrf_inwave<FB>(a, lane, sbuf);
     store_factor(d, 0, a, lane, bad);
 }
 
@@ -115,6 +121,9 @@ template <bool MFMA>
 __global__ __launch_bounds__(256) void k_chol_step(DevBuf d, int k, int T) {
     __shared__ double sXT[FB * XS];
     __shared__ double sC[FB * CS];
+    __shared__ double sLT[FB * FB];
+    __shared__ double srd[FB];
+    __shared__ double sbuf[2 * FB];
     const int ld = d.ld;
     const int nt = T - k - 1;
     const int b = blockIdx.x;
@@ -132,17 +141,27 @@ __global__ __launch_bounds__(256) void k_chol_step(DevBuf d, int k, int T) {
     const int r = k + 1 + rr, c = k + 1 + cc;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool have_update = (c < T);
-    if (wv == 0) {
-        const bool upper = lane >= FB;
-        const int rl = lane & (FB - 1);
-        const bool active = !upper || (have_update && c != r);
-        if (active) {
-            const int br = upper ? c : r;
-            const double* grow = d.sys + (size_t)(br * FB + rl) * ld + k * FB;
-            double x[FB];
+    // stage L(k,k)^T and its reciprocal diagonal in LDS (4 doubles per thread, coalesced)
+    {
+        const double* LTg = d.LT32 + (size_t)k * FB * FB;
+        const double4 v = reinterpret_cast<const double4*>(LTg)[threadIdx.x];
+        reinterpret_cast<double4*>(sLT)[threadIdx.x] = v;
+        if (threadIdx.x < FB) srd[threadIdx.x] = d.rd32[k * FB + threadIdx.x];
+    }
+    const bool upper = lane >= FB;
+    const int rl = lane & (FB - 1);
+    const bool active = (wv == 0) && (!upper || (have_update && c != r));
+    double x[FB];
+    if (active) {   // panel rows are fetched while the L tile lands in LDS
+        const int br = upper ? c : r;
+        const double* grow = d.sys + (size_t)(br * FB + rl) * ld + k * FB;
 #pragma unroll
-            for (int j = 0; j < FB; j += 2) { const double2 v = *reinterpret_cast<const double2*>(grow + j); x[j] = v.x; x[j + 1] = v.y; }
-            trsm_row_scalar<FB>(x, d.LT32 + (size_t)k * FB * FB, d.rd32 + k * FB);
+        for (int j = 0; j < FB; j += 2) { const double2 v = *reinterpret_cast<const double2*>(grow + j); x[j] = v.x; x[j + 1] = v.y; }
+    }
+    __syncthreads();
+    if (wv == 0) {
+        if (active) {
+            trsm_row_lds<FB>(x, sLT, srd);
 #pragma unroll
             for (int j = 0; j < FB; ++j) sXT[j * XS + lane] = x[j];
             if (!upper && c == k + 1) {
@@ -198,7 +217,7 @@ __global__ __launch_bounds__(256) void k_chol_step(DevBuf d, int k, int T) {
         double a[FB];
 #pragma unroll
         for (int j = 0; j < FB; ++j) a[j] = sC[lane * CS + j];
-        const bool bad = potrf_inwave<FB>(a, lane);
+        const bool bad = potrf_inwave<FB>(a, lane, sbuf);
         store_factor(d, k + 1, a, lane, bad);
     }
 }
@@ -252,8 +271,8 @@ __global__ __launch_bounds__(256) void k_inv_diag(DevBuf d) {
 
 // L^T x = y as a dataflow over tile columns, one workgroup per column c (launched in descending c):
 //   x_c = L(c,c)^-T ( y_c - sum_{k>c} L(k,c)^T x_k )
-// Workgroup c folds in x_k as soon as workgroup k has published it (agent-scope release/acquire on a flag
-// word per column, epoch-stamped so no reset is needed); tiles of one column are streamed by their own CU.
+// Workgroup c folds in x_k as soon as workgroup k has published it (sc1 stores + epoch-stamped flag word per
+// column, sc1 loads on the consumer: no fences, no reset); tiles of one column are streamed by their own CU.
 __global__ __launch_bounds__(256) void k_trsv_flow(DevBuf d, int T, int epoch) {
     __shared__ double z[TILE];
     __shared__ double sx[TILE];
@@ -272,8 +291,6 @@ __global__ __launch_bounds__(256) void k_trsv_flow(DevBuf d, int T, int epoch) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1 << 22)) { s_fail = 1; break; }     // never hang the device on a logic error
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         if (s_fail) break;
@@ -307,8 +324,9 @@ __global__ __launch_bounds__(256) void k_trsv_flow(DevBuf d, int T, int epoch) {
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_fail) d.ctrl->solver_ok = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // x_c went out with sc1 (write-through) stores and this wave drained them (vmcnt(0) above) before the barrier;
+        // consumers read it with sc1 loads only, so no release / acquire fence is needed (MI355X_MICROARCH.md,
+        // 'Valid forms': 8-byte agent atomics on both sides, flag after the storing wave's wait)
         __hip_atomic_store(&d.flow_flags[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

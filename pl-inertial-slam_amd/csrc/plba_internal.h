@@ -5,7 +5,8 @@
 //   kf[2]    K x 24      keyframe records, double-buffered (current / trial) + one saved copy
 //   lm[2]    L x 6       landmark estimates (points use 3), double-buffered + saved
 //   obs_*    E           landmark-major observation arrays: uv / l3, inv_sigma2, kf, slot, level
-//   erec     E x 24      per-observation linearisation record (plba_math.h: EREC)
+//   erec     E x 16      compact per-observation linearisation record = one 128-byte line (plba_math.h: EREC),
+//                        stored KEYFRAME-major (ob_pos) so the Schur gathers of a keyframe pair are ascending streams
 //   hll,bl   L x 12, L x 6   landmark blocks (points: 6 upper; lines: two 3x3 uppers)
 //   dinv,tv  L x 12, L x 6   (Hll + lambda I)^-1 and (Hll + lambda I)^-1 bl
 //   pairs    CSR of keyframe pairs sharing landmarks -> (edge_i, edge_j) entries for the Schur complement
@@ -49,7 +50,8 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     const int32_t* ob_slot;  // E
     uint8_t* ob_level;     // E
     double* ob_chi2;       // E   cached e^T Omega e of the last evaluation pass
-    double* erec;          // E x 24
+    double* erec;          // E x 16, indexed by ob_pos[e]
+    const int32_t* ob_pos; // E  keyframe-major position of observation e's record
     // landmarks
     const int32_t* lm_start;  // L + 1 (unified edge index)
     const uint8_t* lm_fixed;  // L
@@ -58,7 +60,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     // keyframes
     const int32_t *kf_off_pvr, *kf_off_bias;
     // pairs
-    const int32_t *pair_i, *pair_j, *pair_start, *ent_ei, *ent_ej;
+    const int32_t *pair_i, *pair_j, *pair_start, *ent_pi, *ent_pj, *ent_slot;   // entries: record positions + landmark slot
     // IMU
     const int32_t *imu_i, *imu_j;
     const double *imu_pre, *imu_info_pvr, *imu_info_bias;
@@ -93,11 +95,11 @@ struct LmParams { double tau, lower, upper, user_lambda; int max_trials; };
 
 void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, hipStream_t s);
 void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, bool owns_pose_edges, hipStream_t s);
-void launch_landmark_hll(const DevBuf& d, hipStream_t s);
-void launch_kfdiag(const DevBuf& d, hipStream_t s);
+void launch_landmark_hll(const DevBuf& d, int state, hipStream_t s);
+void launch_kfdiag(const DevBuf& d, int state, hipStream_t s);
 void launch_landmark_dinv(const DevBuf& d, hipStream_t s);
 void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s);
-void launch_schur_pairs(const DevBuf& d, hipStream_t s);
+void launch_schur_pairs(const DevBuf& d, int state, hipStream_t s);
 void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s);
 void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s);
 // red[0] = activeRobustChi2 (local), red[1] = landmark part of computeScale (local), red[2] = max |Hll_jj| (local)

@@ -74,38 +74,35 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
             const double w0 = d.ob_w[e];
             const double* L = d.lm[state] + (size_t)slot * 6;
             const double* kc = s_kc + k * KFCAM_STRIDE;
-            double e2[2], Jp[12], Jl[6];
+            double e2[2], rec[12];
             bool dpos;
             int kind;
             if (e < d.Ep) {
                 kind = PLBA_EDGE_POINT;
                 const double2 uv = reinterpret_cast<const double2*>(d.po_uv)[e];
-                point_edge(d.cam, kc, v3(L[0], L[1], L[2]), uv.x, uv.y, e2, Jp, Jl, dpos, JAC);
+                point_edge_rec(d.cam, kc, v3(L[0], L[1], L[2]), uv.x, uv.y, e2, rec, dpos, JAC);
             } else {
                 kind = PLBA_EDGE_LINE;
-                const int le = e - d.Ep;
-                const double* l = d.lo_l + (size_t)le * 3;
-                line_edge(d.cam, kc, v3(L[0], L[1], L[2]), v3(L[3], L[4], L[5]), l[0], l[1], l[2], d.fix_q1 != 0, e2, Jp, Jl, dpos, JAC);
+                const double* l = d.lo_l + (size_t)(e - d.Ep) * 3;
+                line_edge_rec(d.cam, kc, v3(L[0], L[1], L[2]), v3(L[3], L[4], L[5]), l[0], l[1], l[2], e2, rec, dpos, JAC);
             }
             const double chi = w0 * (e2[0] * e2[0] + e2[1] * e2[1]);
             double r0 = chi, r1 = 1.0;
             if (rb.on[kind]) huber(chi, rb.delta[kind], r0, r1);
             rho = r0;
             d.ob_chi2[e] = chi;
-            if (JAC) {
-                double4* rec = reinterpret_cast<double4*>(d.erec + (size_t)e * EREC);
-                rec[0] = make_double4(Jp[0], Jp[1], Jp[2], Jp[3]);
-                rec[1] = make_double4(Jp[4], Jp[5], Jp[6], Jp[7]);
-                rec[2] = make_double4(Jp[8], Jp[9], Jp[10], Jp[11]);
-                rec[3] = make_double4(Jl[0], Jl[1], Jl[2], Jl[3]);
-                rec[4] = make_double4(Jl[4], Jl[5], w0 * r1, e2[0]);
-                rec[5] = make_double4(e2[1], chi, 0.0, 0.0);
+            if (JAC) {   // one full 128-byte line per observation, at its keyframe-major position
+                double4* out = reinterpret_cast<double4*>(d.erec + (size_t)d.ob_pos[e] * EREC);
+                out[0] = make_double4(rec[0], rec[1], rec[2], rec[3]);
+                out[1] = make_double4(rec[4], rec[5], rec[6], rec[7]);
+                out[2] = make_double4(rec[8], rec[9], rec[10], rec[11]);
+                out[3] = make_double4(w0 * r1, e2[0], e2[1], chi);
             }
         } else if (JAC) {
-            double4* rec = reinterpret_cast<double4*>(d.erec + (size_t)e * EREC);
+            double4* out = reinterpret_cast<double4*>(d.erec + (size_t)d.ob_pos[e] * EREC);
             const double4 z = make_double4(0, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) rec[i] = z;
+            for (int i = 0; i < 4; ++i) out[i] = z;
         }
     }
     double bs = block_sum_256(rho, s4);
@@ -115,8 +112,12 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
 // -------------------------------------------------------------------------------------------------
 // K5: landmark blocks.  Thread per landmark slot, fixed edge order (deterministic).
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_landmark_hll(DevBuf d) {
+__global__ __launch_bounds__(256) void k_landmark_hll(DevBuf d, int state) {
+    extern __shared__ double s_dyn[];
+    double* s_kc = s_dyn;
     __shared__ double s4[4];
+    for (int k = threadIdx.x; k < d.K; k += 256) kfcam_make(d.cam, d.kf[state] + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
+    __syncthreads();
     const int slot = blockIdx.x * 256 + threadIdx.x;
     double md = 0.0;
     if (slot < d.L) {
@@ -129,21 +130,27 @@ __global__ __launch_bounds__(256) void k_landmark_hll(DevBuf d) {
         int nact = 0;
         const bool is_pt = slot < d.Np;
         for (int ed = s; ed < en; ++ed) {
-            const double* r = d.erec + (size_t)ed * EREC;
-            const double w = r[18];
             if (d.ob_level[ed] == 0) ++nact;
+            const double4* r4 = reinterpret_cast<const double4*>(d.erec + (size_t)d.ob_pos[ed] * EREC);
+            const double4 q3 = r4[3];
+            const double w = q3.x;
             if (w == 0.0) continue;
-            const double a0 = r[12], a1 = r[13], a2 = r[14], b0 = r[15], b1 = r[16], b2 = r[17];
-            const double e0 = r[19], e1 = r[20];
-            if (is_pt) {   // Jl = [a; b] both on the same 3 coordinates
-                h[0] += w * (a0 * a0 + b0 * b0); h[1] += w * (a0 * a1 + b0 * b1); h[2] += w * (a0 * a2 + b0 * b2);
-                h[3] += w * (a1 * a1 + b1 * b1); h[4] += w * (a1 * a2 + b1 * b2); h[5] += w * (a2 * a2 + b2 * b2);
-                b[0] -= w * (a0 * e0 + b0 * e1); b[1] -= w * (a1 * e0 + b1 * e1); b[2] -= w * (a2 * e0 + b2 * e1);
-            } else {       // row0 on sP, row1 on eP: block-diagonal 6x6
-                h[0] += w * a0 * a0; h[1] += w * a0 * a1; h[2] += w * a0 * a2; h[3] += w * a1 * a1; h[4] += w * a1 * a2; h[5] += w * a2 * a2;
-                h[6] += w * b0 * b0; h[7] += w * b0 * b1; h[8] += w * b0 * b2; h[9] += w * b1 * b1; h[10] += w * b1 * b2; h[11] += w * b2 * b2;
-                b[0] -= w * a0 * e0; b[1] -= w * a1 * e0; b[2] -= w * a2 * e0;
-                b[3] -= w * b0 * e1; b[4] -= w * b1 * e1; b[5] -= w * b2 * e1;
+            const double4 q0 = r4[0], q1 = r4[1], q2 = r4[2];
+            const double* kc = s_kc + d.ob_kf[ed] * KFCAM_STRIDE;
+            M3 M;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) M.a[i] = kc[i];
+            const V3 va = mulT(M, v3(q0.x, q0.y, q0.z)), vb = mulT(M, v3(q1.z, q1.w, q2.x));   // M^T uA, M^T uB
+            const double e0 = q3.y, e1 = q3.z;
+            if (is_pt) {   // Jl rows = -va^T, -vb^T on the same 3 coordinates
+                h[0] += w * (va.x * va.x + vb.x * vb.x); h[1] += w * (va.x * va.y + vb.x * vb.y); h[2] += w * (va.x * va.z + vb.x * vb.z);
+                h[3] += w * (va.y * va.y + vb.y * vb.y); h[4] += w * (va.y * va.z + vb.y * vb.z); h[5] += w * (va.z * va.z + vb.z * vb.z);
+                b[0] += w * (va.x * e0 + vb.x * e1); b[1] += w * (va.y * e0 + vb.y * e1); b[2] += w * (va.z * e0 + vb.z * e1);
+            } else {       // row0 = +va^T on sP, row1 = +vb^T on eP: block-diagonal 6x6
+                h[0] += w * va.x * va.x; h[1] += w * va.x * va.y; h[2] += w * va.x * va.z; h[3] += w * va.y * va.y; h[4] += w * va.y * va.z; h[5] += w * va.z * va.z;
+                h[6] += w * vb.x * vb.x; h[7] += w * vb.x * vb.y; h[8] += w * vb.x * vb.z; h[9] += w * vb.y * vb.y; h[10] += w * vb.y * vb.z; h[11] += w * vb.z * vb.z;
+                b[0] -= w * va.x * e0; b[1] -= w * va.y * e0; b[2] -= w * va.z * e0;
+                b[3] -= w * vb.x * e1; b[4] -= w * vb.y * e1; b[5] -= w * vb.z * e1;
             }
         }
         const bool active = (nact > 0) && !d.lm_fixed[slot];
@@ -197,18 +204,53 @@ __global__ __launch_bounds__(256) void k_landmark_dinv(DevBuf d) {
     }
 }
 
+// wavefront sum with DPP row shifts / broadcasts (VALU only, no LDS permute traffic); total lands in lane 63
+template <int CTRL, int ROW_MASK>
+DEV double dpp_get(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+DEV double wave_sum_dpp(double v) {      // row_shr:1,2,4,8 (inclusive scan inside each 16-lane row), row_bcast:15, row_bcast:31
+    v += dpp_get<0x111, 0xf>(v);
+    v += dpp_get<0x112, 0xf>(v);
+    v += dpp_get<0x114, 0xf>(v);
+    v += dpp_get<0x118, 0xf>(v);
+    v += dpp_get<0x142, 0xa>(v);
+    v += dpp_get<0x143, 0xc>(v);
+    return v;
+}
+
+struct EdgeRows { V3 va, vb; double ga[6], gb[6], w, e0, e1; };
+DEV EdgeRows load_rows(const DevBuf& d, const double* rec, const double* kc, bool is_pt) {
+    const double4* r4 = reinterpret_cast<const double4*>(rec);
+    const double4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
+    EdgeRows o;
+    rec_row(is_pt, d.fix_q1 != 0, kc, d.cam.Rcb, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o.va, o.ga);
+    rec_row(is_pt, d.fix_q1 != 0, kc, d.cam.Rcb, v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), o.vb, o.gb);
+    o.w = q3.x; o.e0 = q3.y; o.e1 = q3.z;
+    return o;
+}
+
 // per-keyframe diagonal of sum Jp^T w Jp (only needed for lambda_init at iteration 0)
-__global__ __launch_bounds__(256) void k_kfdiag(DevBuf d) {
+__global__ __launch_bounds__(256) void k_kfdiag(DevBuf d, int state) {
     __shared__ double s4[4];
+    __shared__ double s_kc[KFCAM_STRIDE];
     const int p = blockIdx.x;
     const int i = d.pair_i[p];
     if (i != d.pair_j[p]) return;
+    if (threadIdx.x == 0) kfcam_make(d.cam, d.kf[state] + (size_t)i * KF_STRIDE, s_kc);
+    __syncthreads();
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int n = d.pair_start[p] + threadIdx.x; n < d.pair_start[p + 1]; n += 256) {
-        const double* r = d.erec + (size_t)d.ent_ei[n] * EREC;
-        const double w = r[18];
+        const bool is_pt = d.ent_slot[n] < d.Np;
+        const EdgeRows r = load_rows(d, d.erec + (size_t)d.ent_pi[n] * EREC, s_kc, is_pt);
+        double ja[6], jb[6];
+        basis_apply(d.cam.Rcb, r.ga, ja);
+        basis_apply(d.cam.Rcb, r.gb, jb);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) acc[c] += w * (r[c] * r[c] + r[6 + c] * r[6 + c]);
+        for (int c = 0; c < 6; ++c) acc[c] += r.w * (ja[c] * ja[c] + jb[c] * jb[c]);
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -220,16 +262,22 @@ __global__ __launch_bounds__(256) void k_kfdiag(DevBuf d) {
 // -------------------------------------------------------------------------------------------------
 // K6: Schur complement over keyframe pairs.
 //   Hschur(i,j) = Hpp(i,j) - sum_l Hpl(i,l) D_l Hpl(j,l)^T  with Hpl(i,l) = Jp_i^T w_i Jl_i
-//               = [pose-side edges + lambda] + sum_entries Jp_i^T Q Jp_j,   Q = [ei==ej] w I2 - w_i w_j Jl_i D Jl_j^T
-//   bschur_i   = b_i - sum Hpl D bl = [pose-side] + sum_{e in kf i} -w Jp^T (e + Jl t_l),  t_l = D_l bl_l
-// One 256-thread workgroup per pair; each lane accumulates a 6x6 (+2x6 for diagonal pairs) in registers,
-// then wavefront shuffles + LDS; the owning workgroup read-modify-writes its exclusive blocks of `sys`.
+//               = [pose-side edges + lambda] + C^T ( sum_entries sum_ab g_ia Q_ab g_jb^T ) C
+//   Q = [ei==ej] w I2 - w_i w_j Jl_i D Jl_j^T   (2x2),   C = blkdiag(Rcb, Rcb)  (applied once per pair)
+//   bschur_i   = [pose-side] + C^T sum_{e in kf i} -w (g_a (e_a + Jl_a t_l)),   t_l = D_l bl_l
+// One 256-thread workgroup per pair; records are one 128-byte line each, stored keyframe-major, so both gather
+// streams of a pair are ascending and dense.  Each lane accumulates 6x6 (+2x6 for diagonal pairs) in registers,
+// DPP wave reduction, LDS across the 4 waves; the owning workgroup read-modify-writes its exclusive blocks of `sys`.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d) {
+__global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state) {
     __shared__ double s_red[4][48];
+    __shared__ double s_in[48], s_tmp[36];
+    __shared__ double s_kc[2 * KFCAM_STRIDE];
     const int p = blockIdx.x;
     const int i = d.pair_i[p], j = d.pair_j[p];
     const bool diag = (i == j);
+    if (threadIdx.x < 2) kfcam_make(d.cam, d.kf[state] + (size_t)(threadIdx.x == 0 ? i : j) * KF_STRIDE, s_kc + threadIdx.x * KFCAM_STRIDE);
+    __syncthreads();
     double acc[36];
     double gb[6], gp[6];
 #pragma unroll
@@ -238,86 +286,89 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d) {
     for (int t = 0; t < 6; ++t) { gb[t] = 0.0; gp[t] = 0.0; }
     const int s = d.pair_start[p], en = d.pair_start[p + 1];
     for (int n = s + threadIdx.x; n < en; n += 256) {
-        const int ei = d.ent_ei[n], ej = d.ent_ej[n];
-        const double* ri = d.erec + (size_t)ei * EREC;
-        const double wi = ri[18];
+        const int pi = d.ent_pi[n], pj = d.ent_pj[n], slot = d.ent_slot[n];
+        const double wi = d.erec[(size_t)pi * EREC + 12];
         if (wi == 0.0) continue;
-        const double* rj = d.erec + (size_t)ej * EREC;
-        const double wj = rj[18];
+        const double wj = d.erec[(size_t)pj * EREC + 12];
         if (wj == 0.0) continue;
-        const int slot = d.ob_slot[ei];
+        const bool is_pt = slot < d.Np;
+        const EdgeRows ri = load_rows(d, d.erec + (size_t)pi * EREC, s_kc, is_pt);
+        const EdgeRows rj = load_rows(d, d.erec + (size_t)pj * EREC, s_kc + KFCAM_STRIDE, is_pt);
         const double* D = d.dinv + (size_t)slot * 12;
-        double Ji[12], Jj[12];
-#pragma unroll
-        for (int t = 0; t < 12; ++t) { Ji[t] = ri[t]; Jj[t] = rj[t]; }
-        const V3 ai = v3(ri[12], ri[13], ri[14]), bi = v3(ri[15], ri[16], ri[17]);
-        const V3 aj = v3(rj[12], rj[13], rj[14]), bj = v3(rj[15], rj[16], rj[17]);
         double q00, q01, q10, q11;
         const double ww = wi * wj;
-        if (slot < d.Np) {
-            const V3 Daj = sym3_mul(D, aj), Dbj = sym3_mul(D, bj);
-            q00 = -ww * dot(ai, Daj); q01 = -ww * dot(ai, Dbj);
-            q10 = -ww * dot(bi, Daj); q11 = -ww * dot(bi, Dbj);
+        if (is_pt) {
+            const V3 Da = sym3_mul(D, rj.va), Db = sym3_mul(D, rj.vb);
+            q00 = -ww * dot(ri.va, Da); q01 = -ww * dot(ri.va, Db);
+            q10 = -ww * dot(ri.vb, Da); q11 = -ww * dot(ri.vb, Db);
         } else {
-            q00 = -ww * dot(ai, sym3_mul(D, aj)); q11 = -ww * dot(bi, sym3_mul(D + 6, bj));
+            q00 = -ww * dot(ri.va, sym3_mul(D, rj.va)); q11 = -ww * dot(ri.vb, sym3_mul(D + 6, rj.vb));
             q01 = 0.0; q10 = 0.0;
         }
-        if (ei == ej) { q00 += wi; q11 += wi; }
+        if (pi == pj) { q00 += wi; q11 += wi; }
         double T0[6], T1[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            T0[c] = q00 * Jj[c] + q01 * Jj[6 + c];
-            T1[c] = q10 * Jj[c] + q11 * Jj[6 + c];
+            T0[c] = q00 * rj.ga[c] + q01 * rj.gb[c];
+            T1[c] = q10 * rj.ga[c] + q11 * rj.gb[c];
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += Ji[r] * T0[c] + Ji[6 + r] * T1[c];
+            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += ri.ga[r] * T0[c] + ri.gb[r] * T1[c];
         if (diag) {
             const double* t = d.tv + (size_t)slot * 6;
-            const double e0 = ri[19], e1 = ri[20];
-            double f0, f1;
-            if (slot < d.Np) {
-                const V3 tt = v3(t[0], t[1], t[2]);
-                f0 = e0 + dot(ai, tt); f1 = e1 + dot(bi, tt);
-            } else {
-                f0 = e0 + dot(ai, v3(t[0], t[1], t[2])); f1 = e1 + dot(bi, v3(t[3], t[4], t[5]));
-            }
+            const double sl = is_pt ? -1.0 : 1.0;
+            const V3 ta = v3(t[0], t[1], t[2]);
+            const V3 tb = is_pt ? ta : v3(t[3], t[4], t[5]);
+            const double f0 = ri.e0 + sl * dot(ri.va, ta), f1 = ri.e1 + sl * dot(ri.vb, tb);
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
-                gp[r] -= wi * (Ji[r] * e0 + Ji[6 + r] * e1);
-                gb[r] -= wi * (Ji[r] * f0 + Ji[6 + r] * f1);
+                gp[r] -= wi * (ri.ga[r] * ri.e0 + ri.gb[r] * ri.e1);
+                gb[r] -= wi * (ri.ga[r] * f0 + ri.gb[r] * f1);
             }
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int t = 0; t < 36; ++t) {
-        double v = wave_sum(acc[t]);
-        if (lane == 0) s_red[wv][t] = v;
+        const double v = wave_sum_dpp(acc[t]);
+        if (lane == 63) s_red[wv][t] = v;
     }
     if (diag) {
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            double v = wave_sum(gb[t]);
-            double u = wave_sum(gp[t]);
-            if (lane == 0) { s_red[wv][36 + t] = v; s_red[wv][42 + t] = u; }
+            const double v = wave_sum_dpp(gb[t]);
+            const double u = wave_sum_dpp(gp[t]);
+            if (lane == 63) { s_red[wv][36 + t] = v; s_red[wv][42 + t] = u; }
         }
     }
     __syncthreads();
     const int t = threadIdx.x;
+    const int nred = diag ? 48 : 36;
+    if (t < nred) s_in[t] = (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]);
+    __syncthreads();
+    // S = C^T Inner C with C = blkdiag(Rcb, Rcb):  tmp = Inner C, S = C^T tmp
+    const double* Rcb = d.cam.Rcb.a;
+    if (t < 36) {
+        const int r = t / 6, c = t % 6, cb = (c / 3) * 3, cc = c % 3;
+        s_tmp[t] = s_in[r * 6 + cb] * Rcb[cc] + s_in[r * 6 + cb + 1] * Rcb[3 + cc] + s_in[r * 6 + cb + 2] * Rcb[6 + cc];
+    }
+    __syncthreads();
     const int oi = d.kf_off_pvr[i], oj = d.kf_off_pvr[j];
     const int ld = d.ld;
     if (t < 36) {
-        const double v = (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]);
-        const int r = pmap(t / 6), c = pmap(t % 6);
-        d.sys[(size_t)(oi + r) * ld + oj + c] += v;
-        if (!diag) d.sys[(size_t)(oj + c) * ld + oi + r] += v;
+        const int r = t / 6, c = t % 6, rb = (r / 3) * 3, rr = r % 3;
+        const double v = Rcb[rr] * s_tmp[rb * 6 + c] + Rcb[3 + rr] * s_tmp[(rb + 1) * 6 + c] + Rcb[6 + rr] * s_tmp[(rb + 2) * 6 + c];
+        const int R = pmap(r), Cc = pmap(c);
+        d.sys[(size_t)(oi + R) * ld + oj + Cc] += v;
+        if (!diag) d.sys[(size_t)(oj + Cc) * ld + oi + R] += v;
     } else if (diag && t < 48) {
-        const double v = (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]);
-        const int r = pmap((t - 36) % 6);
+        const int q = t - 36, r = q % 6, rb = (r / 3) * 3, rr = r % 3;
+        const double* g = s_in + 36 + (q / 6) * 6;
+        const double v = Rcb[rr] * g[rb] + Rcb[3 + rr] * g[rb + 1] + Rcb[6 + rr] * g[rb + 2];
         const int row = (t < 42) ? d.Ppad : d.Ppad + 1;     // bschur row / bp row of the augmented system
-        d.sys[(size_t)row * ld + oi + r] += v;
+        d.sys[(size_t)row * ld + oi + pmap(r)] += v;
     }
 }
 
@@ -343,7 +394,19 @@ __global__ __launch_bounds__(256) void k_assemble(DevBuf d, int add_lambda) {
 //   xl = D (bl - sum_e w Jl^T Jp x_kf)      trial_lm = cur_lm + xl
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_backsub(DevBuf d, int cur, int trial) {
+    extern __shared__ double s_dyn[];
+    double* s_kc = s_dyn;                       // K x 12 camera blocks of the CURRENT (linearisation) state
+    double* s_y = s_dyn + d.K * KFCAM_STRIDE;   // K x 6: blkdiag(Rcb,Rcb) * (dp, dphi) of every keyframe's step
     __shared__ double s4[4];
+    for (int k = threadIdx.x; k < d.K; k += 256) {
+        kfcam_make(d.cam, d.kf[cur] + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
+        const int o = d.kf_off_pvr[k];
+        V3 yp = v3(0, 0, 0), yr = v3(0, 0, 0);
+        if (o >= 0) { yp = mul(d.cam.Rcb, v3(d.x[o], d.x[o + 1], d.x[o + 2])); yr = mul(d.cam.Rcb, v3(d.x[o + 6], d.x[o + 7], d.x[o + 8])); }
+        double* y = s_y + k * 6;
+        y[0] = yp.x; y[1] = yp.y; y[2] = yp.z; y[3] = yr.x; y[4] = yr.y; y[5] = yr.z;
+    }
+    __syncthreads();
     const int slot = blockIdx.x * 256 + threadIdx.x;
     double sc = 0.0;
     if (slot < d.L) {
@@ -354,22 +417,20 @@ __global__ __launch_bounds__(256) void k_backsub(DevBuf d, int cur, int trial) {
         if (d.lm_active[slot] && d.ctrl->solver_ok) {
             const double* b = d.bl + (size_t)slot * 6;
             double c[6] = {b[0], b[1], b[2], b[3], b[4], b[5]};
+            const double sl = is_pt ? -1.0 : 1.0;
             for (int ed = d.lm_start[slot]; ed < d.lm_start[slot + 1]; ++ed) {
-                const double* r = d.erec + (size_t)ed * EREC;
-                const double w = r[18];
-                if (w == 0.0) continue;
-                const int o = d.kf_off_pvr[d.ob_kf[ed]];
-                if (o < 0) continue;
-                const double* xp = d.x + o;
-                const double x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[6], x4 = xp[7], x5 = xp[8];
-                const double s0 = r[0] * x0 + r[1] * x1 + r[2] * x2 + r[3] * x3 + r[4] * x4 + r[5] * x5;
-                const double s1 = r[6] * x0 + r[7] * x1 + r[8] * x2 + r[9] * x3 + r[10] * x4 + r[11] * x5;
-                if (is_pt) {
-                    c[0] -= w * (r[12] * s0 + r[15] * s1); c[1] -= w * (r[13] * s0 + r[16] * s1); c[2] -= w * (r[14] * s0 + r[17] * s1);
-                } else {
-                    c[0] -= w * r[12] * s0; c[1] -= w * r[13] * s0; c[2] -= w * r[14] * s0;
-                    c[3] -= w * r[15] * s1; c[4] -= w * r[16] * s1; c[5] -= w * r[17] * s1;
-                }
+                const double* rec = d.erec + (size_t)d.ob_pos[ed] * EREC;
+                if (rec[12] == 0.0) continue;
+                const int k = d.ob_kf[ed];
+                if (d.kf_off_pvr[k] < 0) continue;
+                const EdgeRows r = load_rows(d, rec, s_kc + k * KFCAM_STRIDE, is_pt);
+                const double* y = s_y + k * 6;
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { s0 += r.ga[q] * y[q]; s1 += r.gb[q] * y[q]; }
+                const double a0 = r.w * sl * s0, a1 = r.w * sl * s1;    // w * Jl_a^T s_a with Jl_a = sl * v_a^T
+                if (is_pt) { c[0] -= r.va.x * a0 + r.vb.x * a1; c[1] -= r.va.y * a0 + r.vb.y * a1; c[2] -= r.va.z * a0 + r.vb.z * a1; }
+                else { c[0] -= r.va.x * a0; c[1] -= r.va.y * a0; c[2] -= r.va.z * a0; c[3] -= r.vb.x * a1; c[4] -= r.vb.y * a1; c[5] -= r.vb.z * a1; }
             }
             const double* D = d.dinv + (size_t)slot * 12;
             V3 a = sym3_mul(D, v3(c[0], c[1], c[2]));
@@ -701,11 +762,11 @@ void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, b
         else hipLaunchKernelGGL(k_prior<false>, dim3(1), dim3(256), 0, s, d, state);
     }
 }
-void launch_landmark_hll(const DevBuf& d, hipStream_t s) {
-    if (d.L) hipLaunchKernelGGL(k_landmark_hll, dim3(lm_blocks(d)), dim3(256), 0, s, d);
+void launch_landmark_hll(const DevBuf& d, int state, hipStream_t s) {
+    if (d.L) hipLaunchKernelGGL(k_landmark_hll, dim3(lm_blocks(d)), dim3(256), (size_t)d.K * KFCAM_STRIDE * sizeof(double), s, d, state);
 }
-void launch_kfdiag(const DevBuf& d, hipStream_t s) {
-    if (d.npairs) hipLaunchKernelGGL(k_kfdiag, dim3(d.npairs), dim3(256), 0, s, d);
+void launch_kfdiag(const DevBuf& d, int state, hipStream_t s) {
+    if (d.npairs) hipLaunchKernelGGL(k_kfdiag, dim3(d.npairs), dim3(256), 0, s, d, state);
     hipLaunchKernelGGL(k_posediag, dim3((d.ld + 255) / 256), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_posediag_kf, dim3((d.K * 6 + 255) / 256), dim3(256), 0, s, d);
 }
@@ -718,11 +779,11 @@ void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s) {
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, d, add_lambda ? 1 : 0);
 }
-void launch_schur_pairs(const DevBuf& d, hipStream_t s) {
-    if (d.npairs) hipLaunchKernelGGL(k_schur_pairs, dim3(d.npairs), dim3(256), 0, s, d);
+void launch_schur_pairs(const DevBuf& d, int state, hipStream_t s) {
+    if (d.npairs) hipLaunchKernelGGL(k_schur_pairs, dim3(d.npairs), dim3(256), 0, s, d, state);
 }
 void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s) {
-    if (d.L) hipLaunchKernelGGL(k_backsub, dim3(lm_blocks(d)), dim3(256), 0, s, d, cur, trial);
+    if (d.L) hipLaunchKernelGGL(k_backsub, dim3(lm_blocks(d)), dim3(256), (size_t)d.K * (KFCAM_STRIDE + 6) * sizeof(double), s, d, cur, trial);
 }
 void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s) {
     hipLaunchKernelGGL(k_update_kf, dim3((d.K + 63) / 64), dim3(64), 0, s, d, cur, trial);

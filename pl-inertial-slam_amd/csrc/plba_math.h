@@ -251,13 +251,64 @@ PLBA_HD ProjJac proj_jac(const Cam& cam, const double* kc, V3 Pc) {
     return J;
 }
 
-// ---- edge record written by the linearisation kernel (24 doubles per observation) --------------
-// [0..11]  Jp : 2 x 6 Jacobian w.r.t. the keyframe's (dp, dphi)  (velocity columns are identically zero)
-// [12..17] Jl : points: 2 x 3 w.r.t. the point;  lines: row0 = d e0/d sP (3), row1 = d e1/d eP (3)
-// [18]     w  : rho1 * inv_sigma2 (0 for level-1 edges)
-// [19,20]  e  : residual
-// [21]     chi2 = inv_sigma2 * |e|^2 (non-robustified)
-constexpr int EREC = 24;
+// ---- compact edge record written by the linearisation kernel: 16 doubles = one 128-byte line -------------
+// Both residual rows a = 0,1 are described in the CAMERA frame by a 3-vector u_a (= row of the projection
+// Jacobian; for a line end-point already contracted with the line normal l12) and the point P_a = M (Pw - Pwb):
+//   [0..2] uA  [3..5] PA  [6..8] uB  [9..11] PB  [12] w = rho1 * inv_sigma2 (0: inactive)  [13] e0  [14] e1  [15] chi2
+// From these and the per-keyframe block M = Rcb Rwb^T every consumer rebuilds what it needs:
+//   landmark Jacobian row   Jl_a = sl * (M^T u_a)^T             sl = -1 point edge, +1 line edge
+//   pose Jacobian row       Jp_a = g_a^T * blkdiag(Rcb, Rcb)    g_a = [ u_a ; P_a x u_a ]                 (point)
+//                                                               g_a = [ -Rcb M^T u_a ; -(P_a x u_a) ]     (line, reference
+//                            world-frame position block, SURVEY B-Q1;  [ -u_a ; ... ] with fix_line_position_jacobian)
+// (derivation: -u^T hat(P) = (P x u)^T, and -u^T M = -(Rcb M^T u)^T Rcb.)
+constexpr int EREC = 16;
+
+PLBA_HD void point_edge_rec(const Cam& cam, const double* kc, V3 Pw, double u, double v, double* e2, double* rec12, bool& depth_pos, bool jac) {
+    V3 Pc = cam_Pc(cam, kc, Pw);
+    const double iz = 1.0 / Pc.z;
+    e2[0] = u - (Pc.x * iz * cam.fx + cam.cx);
+    e2[1] = v - (Pc.y * iz * cam.fy + cam.cy);
+    depth_pos = Pc.z > 0.0;
+    if (!jac) return;
+    const V3 P = Pc + cam.c0;
+    rec12[0] = cam.fx * iz; rec12[1] = 0.0; rec12[2] = -cam.fx * Pc.x * iz * iz;
+    rec12[3] = P.x; rec12[4] = P.y; rec12[5] = P.z;
+    rec12[6] = 0.0; rec12[7] = cam.fy * iz; rec12[8] = -cam.fy * Pc.y * iz * iz;
+    rec12[9] = P.x; rec12[10] = P.y; rec12[11] = P.z;
+}
+PLBA_HD void line_edge_rec(const Cam& cam, const double* kc, V3 Ps_w, V3 Pe_w, double lx, double ly, double lz,
+                           double* e2, double* rec12, bool& depth_pos, bool jac) {
+    V3 Ps = cam_Pc(cam, kc, Ps_w), Pe = cam_Pc(cam, kc, Pe_w);
+    const double izs = 1.0 / Ps.z, ize = 1.0 / Pe.z;
+    e2[0] = lx * (Ps.x * izs * cam.fx + cam.cx) + ly * (Ps.y * izs * cam.fy + cam.cy) + lz;
+    e2[1] = lx * (Pe.x * ize * cam.fx + cam.cx) + ly * (Pe.y * ize * cam.fy + cam.cy) + lz;
+    depth_pos = (Ps.z > 0.0) && (Pe.z > 0.0);
+    if (!jac) return;
+    const V3 A = Ps + cam.c0, B = Pe + cam.c0;
+    rec12[0] = lx * cam.fx * izs; rec12[1] = ly * cam.fy * izs; rec12[2] = -(lx * cam.fx * Ps.x + ly * cam.fy * Ps.y) * izs * izs;
+    rec12[3] = A.x; rec12[4] = A.y; rec12[5] = A.z;
+    rec12[6] = lx * cam.fx * ize; rec12[7] = ly * cam.fy * ize; rec12[8] = -(lx * cam.fx * Pe.x + ly * cam.fy * Pe.y) * ize * ize;
+    rec12[9] = B.x; rec12[10] = B.y; rec12[11] = B.z;
+}
+// one residual row rebuilt from its record half: v = M^T u (world frame), g = pose coefficients in the blkdiag(Rcb,Rcb) basis
+PLBA_HD void rec_row(bool is_pt, bool fix_q1, const double* kc, const M3& Rcb, V3 u, V3 P, V3& v, double* g6) {
+    M3 M;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M.a[i] = kc[i];
+    v = mulT(M, u);
+    const V3 px = cross(P, u);
+    if (is_pt) {
+        g6[0] = u.x; g6[1] = u.y; g6[2] = u.z; g6[3] = px.x; g6[4] = px.y; g6[5] = px.z;
+    } else {
+        const V3 dp = fix_q1 ? u : mul(Rcb, v);
+        g6[0] = -dp.x; g6[1] = -dp.y; g6[2] = -dp.z; g6[3] = -px.x; g6[4] = -px.y; g6[5] = -px.z;
+    }
+}
+// Jp row (6) = g^T blkdiag(Rcb, Rcb)
+PLBA_HD void basis_apply(const M3& Rcb, const double* g6, double* jp6) {
+    const V3 a = mulT(Rcb, v3(g6[0], g6[1], g6[2])), b = mulT(Rcb, v3(g6[3], g6[4], g6[5]));
+    jp6[0] = a.x; jp6[1] = a.y; jp6[2] = a.z; jp6[3] = b.x; jp6[4] = b.y; jp6[5] = b.z;
+}
 
 // Point edge: e = obs - proj  =>  Jl = -Jpi M, Jp(dp) = +Jpi Rcb, Jp(dphi) = -Jpi hat(Paux) Rcb   (g2otypes.cpp:286-341)
 PLBA_HD void point_edge(const Cam& cam, const double* kc, V3 Pw, double u, double v, double* e2, double* Jp12, double* Jl6, bool& depth_pos, bool jac) {
@@ -404,15 +455,26 @@ PLBA_HD void prior_dx_bias(const double* s, const double* x0 /*6*/, double* dx6)
     for (int c = 0; c < 3; ++c) { dx6[c] = (s[10 + c] + s[16 + c]) - x0[c]; dx6[3 + c] = (s[13 + c] + s[19 + c]) - x0[3 + c]; }
 }
 
-// symmetric 3x3 inverse of (H + lambda I); H given as upper triangle [h00 h01 h02 h11 h12 h22]
+// symmetric 3x3 inverse of (H + lambda I) by LDL^T (backward stable for the SPD blocks of the path; the cofactor
+// form loses digits on poorly triangulated landmarks when lambda is small); H given as upper triangle
+// [h00 h01 h02 h11 h12 h22], result in the same packing
 PLBA_HD bool sym3_inv(const double* h, double lambda, double* d /*6 upper*/) {
-    double a = h[0] + lambda, b = h[1], c = h[2], e = h[3] + lambda, f = h[4], g = h[5] + lambda;
-    double c00 = e * g - f * f, c01 = c * f - b * g, c02 = b * f - c * e;
-    double det = a * c00 + b * c01 + c * c02;
-    if (!(det != 0.0)) { d[0] = d[1] = d[2] = d[3] = d[4] = d[5] = 0.0; return false; }
-    double id = 1.0 / det;
-    d[0] = c00 * id; d[1] = c01 * id; d[2] = c02 * id;
-    d[3] = (a * g - c * c) * id; d[4] = (b * c - a * f) * id; d[5] = (a * e - b * b) * id;
+    const double a = h[0] + lambda, b = h[1], c = h[2], e = h[3] + lambda, f = h[4], g = h[5] + lambda;
+    const double i0 = 1.0 / a;
+    const double l10 = b * i0, l20 = c * i0;
+    const double d1 = e - l10 * b;
+    const double i1 = 1.0 / d1;
+    const double l21 = (f - l20 * b) * i1;
+    const double d2 = g - l20 * c - l21 * l21 * d1;
+    const double i2 = 1.0 / d2;
+    if (!(a != 0.0) || !(d1 != 0.0) || !(d2 != 0.0)) { d[0] = d[1] = d[2] = d[3] = d[4] = d[5] = 0.0; return false; }
+    const double m10 = -l10, m21 = -l21, m20 = l10 * l21 - l20;      // L^-1 below the diagonal
+    d[5] = i2;
+    d[4] = m21 * i2;
+    d[3] = i1 + m21 * m21 * i2;
+    d[2] = m20 * i2;
+    d[1] = m10 * i1 + m20 * m21 * i2;
+    d[0] = i0 + m10 * m10 * i1 + m20 * m20 * i2;
     return true;
 }
 PLBA_HD V3 sym3_mul(const double* d, V3 v) {

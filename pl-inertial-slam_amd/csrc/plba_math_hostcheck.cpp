@@ -51,6 +51,23 @@ void hc_prior_dx_pvr(const double* nav22, const double* x0, double* dx9) {
     memcpy(s, nav22, 22 * 8);
     prior_dx_pvr(s, x0, dx9);
 }
+// compact record path (what the kernels actually use): record -> rows -> Jp (2x6), Jl (2x3)
+void hc_rec_edge(const double* camv, const double* nav22, const double* L, const double* obs, int is_pt, int fix_q1, double* e2, double* Jp12, double* Jl6) {
+    Cam cam = mk_cam(camv);
+    double s[24] = {0}, kc[12], rec[12];
+    memcpy(s, nav22, 22 * 8);
+    kfcam_make(cam, s, kc);
+    bool d;
+    if (is_pt) point_edge_rec(cam, kc, v3(L[0], L[1], L[2]), obs[0], obs[1], e2, rec, d, true);
+    else line_edge_rec(cam, kc, v3(L[0], L[1], L[2]), v3(L[3], L[4], L[5]), obs[0], obs[1], obs[2], e2, rec, d, true);
+    V3 va, vb; double ga[6], gb[6];
+    rec_row(is_pt != 0, fix_q1 != 0, kc, cam.Rcb, v3(rec[0], rec[1], rec[2]), v3(rec[3], rec[4], rec[5]), va, ga);
+    rec_row(is_pt != 0, fix_q1 != 0, kc, cam.Rcb, v3(rec[6], rec[7], rec[8]), v3(rec[9], rec[10], rec[11]), vb, gb);
+    basis_apply(cam.Rcb, ga, Jp12);
+    basis_apply(cam.Rcb, gb, Jp12 + 6);
+    const double sl = is_pt ? -1.0 : 1.0;
+    Jl6[0] = sl * va.x; Jl6[1] = sl * va.y; Jl6[2] = sl * va.z; Jl6[3] = sl * vb.x; Jl6[4] = sl * vb.y; Jl6[5] = sl * vb.z;
+}
 void hc_sym3_inv(const double* h6, double lambda, double* d6) { sym3_inv(h6, lambda, d6); }
 void hc_huber(double e, double delta, double* r) { huber(e, delta, r[0], r[1]); }
 }

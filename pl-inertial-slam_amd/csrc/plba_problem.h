@@ -19,7 +19,13 @@ struct DArr {
             if (e != hipSuccess) return e;
             n = cnt;
         }
-        if (zero) return hipMemset(p, 0, n * sizeof(T));
+        if (zero) {
+            // hipMemset runs on the legacy null stream and may return before it completes; the library's
+            // kernels run on a NON-blocking stream that does not order against it, so drain it here.
+            hipError_t e = hipMemset(p, 0, n * sizeof(T));
+            if (e != hipSuccess) return e;
+            return hipStreamSynchronize(nullptr);
+        }
         return hipSuccess;
     }
     hipError_t upload(const std::vector<T>& h) {
@@ -74,7 +80,8 @@ struct plba_problem {
     plba::DArr<int32_t> d_ob_kf, d_ob_slot, d_lm_start, d_off_pvr, d_off_bias;
     plba::DArr<uint8_t> d_level, d_lm_fixed, d_lm_active, d_depth;
     plba::DArr<double> d_hll, d_bl, d_dinv, d_tv, d_xl;
-    plba::DArr<int32_t> d_pair_i, d_pair_j, d_pair_start, d_ent_ei, d_ent_ej;
+    plba::DArr<int32_t> d_pair_i, d_pair_j, d_pair_start, d_ent_pi, d_ent_pj, d_ent_slot, d_ob_pos;
+    std::vector<int32_t> ob_pos;          // keyframe-major record position of every observation
     plba::DArr<int32_t> d_imu_i, d_imu_j;
     plba::DArr<double> d_imu_pre, d_imu_ipvr, d_imu_ibias, d_imu_err, d_imu_chi;
     plba::DArr<int32_t> d_pr_kf, d_pr_isbias, d_pr_size, d_pr_idx, d_pr_x0off, d_pr_off;

@@ -71,6 +71,39 @@ def test_point_and_line_edges(hc, orc, pkg):
             assert np.allclose(J[:, :3], Jj[:2, 0:3], atol=1e-11 * sc) and np.allclose(J[:, 3:], Jj[:2, 6:9], atol=1e-11 * sc)
 
 
+def test_compact_record_reconstruction(hc, orc, pkg):
+    """The 128-byte record (u_a, P_a) + per-keyframe M rebuilds exactly the reference Jacobians (both edge kinds,
+    including the line edge's world-frame position block B-Q1 and its fixed variant)."""
+    rng = np.random.default_rng(3)
+    cam = _cam(pkg, orc)
+    Rbc, Pbc = pkg.window.T_BS[:3, :3], pkg.window.T_BS[:3, 3]
+    for _ in range(20):
+        nav = _nav(orc, pkg, rng)
+        R = orc.quat_to_R(nav[6:10])
+        Pc = np.array([rng.uniform(-2, 2), rng.uniform(-1, 1), rng.uniform(0.5, 8)])
+        Pw = R @ (Rbc @ Pc + Pbc) + nav[:3]
+        obs = np.concatenate([rng.uniform(0, 700, 2), [0.0]])
+        e, Ji, Jj, _ = orc.eval_point_edge(cam, nav, Pw, obs[:2])
+        e2, Jp, Jl = np.zeros(2), np.zeros(12), np.zeros(6)
+        L = np.concatenate([Pw, Pw])
+        hc.hc_rec_edge(_d(cam), _d(nav), _d(L), _d(obs), 1, 0, _d(e2), _d(Jp), _d(Jl))
+        sc = np.abs(Jj).max()
+        assert np.allclose(e2, e, atol=1e-9)
+        assert np.allclose(Jl.reshape(2, 3), Ji, atol=1e-11 * sc)
+        assert np.allclose(Jp.reshape(2, 6)[:, :3], Jj[:, 0:3], atol=1e-11 * sc) and np.allclose(Jp.reshape(2, 6)[:, 3:], Jj[:, 6:9], atol=1e-11 * sc)
+        Pce = Pc + rng.normal(size=3) * 0.4
+        L = np.concatenate([Pw, R @ (Rbc @ Pce + Pbc) + nav[:3]])
+        l = rng.normal(size=3); l /= np.hypot(l[0], l[1])
+        for fix in (0, 1):
+            e, Ji, Jj, _ = orc.eval_line_edge(cam, nav, L, l, fix_q1=fix)
+            hc.hc_rec_edge(_d(cam), _d(nav), _d(L), _d(l), 0, fix, _d(e2), _d(Jp), _d(Jl))
+            sc = max(np.abs(Jj).max(), 1)
+            assert np.allclose(e2, e[:2], atol=1e-9 * max(1, np.abs(e).max()))
+            assert np.allclose(Jl[:3], Ji[0, :3], atol=1e-11 * sc) and np.allclose(Jl[3:], Ji[1, 3:], atol=1e-11 * sc)
+            J = Jp.reshape(2, 6)
+            assert np.allclose(J[:, :3], Jj[:2, 0:3], atol=1e-10 * sc) and np.allclose(J[:, 3:], Jj[:2, 6:9], atol=1e-10 * sc)
+
+
 def test_pvr_edge_and_oplus(hc, orc, pkg):
     rng = np.random.default_rng(1)
     gw = np.array([0, 0, -9.81])
