@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink landmark counts (debug only; invalidates the number)")
     ap.add_argument("--kf", type=int, default=0, help="override the keyframe count (debug only)")
+    ap.add_argument("--fb", type=int, default=0, help="dense factorisation block width (32/64); 0 = library default")
     args = ap.parse_args()
 
     import torch
@@ -121,7 +122,7 @@ def main():
     w = win.shard_window(w_full, rank, world) if world > 1 else w_full
 
     stream = torch.cuda.Stream()
-    prob = pkg.new_problem(profile=1)
+    prob = pkg.new_problem(profile=1, **({"factor_block": args.fb} if args.fb else {}))
     prob.set_stream(stream.cuda_stream)
     prob.upload_window(w)
     if world > 1:

@@ -61,7 +61,8 @@ typedef struct {
     int    device;              /* HIP device ordinal, -1 = current device            (-1)    */
     int    use_mfma;            /* 1 = fp64 MFMA trailing update in the dense solve    (1)    */
     int    profile;             /* 1 = HIP-event timing of the phases into plba_stats.ms_phase (0) */
-    int    reserved[5];
+    int    factor_block;        /* block width of the dense factorisation: 32 or 64                (32)   */
+    int    reserved[4];
 } plba_options;
 
 void plba_default_options(plba_options* o);

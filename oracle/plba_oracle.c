@@ -318,6 +318,7 @@ void orc_default_options(plba_options* o) {
     o->marg_eps = 1e-8;            /* IMU/marginalization.h:99 */
     o->device = -1;
     o->use_mfma = 1;
+    o->factor_block = 32;
 }
 const char* orc_backend_name(void) { return "cpu-oracle"; }
 

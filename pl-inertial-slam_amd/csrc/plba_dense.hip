@@ -1,73 +1,112 @@
 // plba_dense.hip — K7: dense fp64 solve of the reduced camera system on gfx950.
 //
-// Replaces g2o::LinearSolverEigen (sparse simplicial Cholesky of Hschur) by an exact
-// dense LL^T on the padded (Ppad x Ppad, 64-wide tiles) symmetric matrix `sys`, right-looking:
-//   step k:  k_chol_diag   one workgroup factors the 64x64 diagonal tile in LDS
-//            k_chol_step   one workgroup per trailing tile (r,c): both panel tiles are solved by
-//                          substitution (a lane per row, row in registers), then the tile update
-//                          C -= X_r X_c^T runs on the matrix cores (v_mfma_f64_16x16x4_f64), or on
-//                          the VALU when use_mfma = 0 (cross-check path for the tests)
-// The right-hand side rides along as an extra tile row (row Ppad = bschur), so the forward solve
-// L y = b is a by-product of the factorisation; k_trsv_back finishes with L^T x = y.
+// Replaces g2o::LinearSolverEigen (sparse simplicial Cholesky of Hschur) by an exact dense LL^T on
+// the padded (Ppad x Ppad) symmetric matrix `sys`, right-looking with NB-wide blocks (NB = 32 or 64), ONE launch per
+// block step k.  Workgroup (r,c), k < c <= r <= T (r == T is the right-hand-side block row):
+//   waves 0/1   X_r = A(r,k) L(k,k)^-T, X_c = A(c,k) L(k,k)^-T : a lane per row, row in registers, L(k,k)^T staged in
+//               LDS and read as broadcasts (column oriented: no dependent accumulation chain)
+//   all waves   A(r,c) -= X_r X_c^T on the matrix cores (v_mfma_f64_16x16x4_f64; VALU when use_mfma = 0: test path)
+//   look-ahead  the workgroup of (k+1,k+1) factors its freshly updated tile inside ONE wavefront and publishes
+//               L(k+1,k+1) (+ transposed copy and reciprocal diagonal), so the next launch starts its TRSMs at once.
+// The right-hand side rides along as an extra block row (row Ppad = bschur), so the forward solve L y = b is a
+// by-product of the factorisation; k_trsv_flow finishes with L^T x = y as a single dataflow launch.
 // A pivot <= 0 (or NaN) clears ctrl->solver_ok, which g2o reports as a failed linear solve.
+//
+// Why it looks like this (rocprofv3, MI355X): the path is a chain of P dependent pivots, so everything is about the
+// latency of one dependent step.  LDS + s_barrier per pivot column cost ~1300 cycles; v_readlane broadcasts ~2600
+// instructions per 32x32 tile; scalar-path TRSM operands ~11 dependent s_load batches per tile.  The in-wave potrf
+// below has ~150-200 cycles per column: the symmetric tile makes "column j" = register j across lanes (one
+// ds_write_b64), the pivot comes straight from lane j's register (v_readlane), the reciprocal is rcp + 2 Newton steps,
+// and the next column is published before the bulk of the current column's FMAs.
 #include "plba_internal.h"
 
 namespace plba {
 
 typedef double double4v __attribute__((ext_vector_type(4)));
-typedef const double __attribute__((address_space(4))) cdouble;   // constant address space: uniform loads take the scalar path
 
-constexpr int FB = 32;    // factorisation block (in-wave potrf / trsm); the back-substitution works on 64-wide tiles
-constexpr int XS = 80;    // LDS row stride of the transposed panel tiles XT[k][row]  (rows 0..31 = X_r, 32..63 = X_c)
-constexpr int CS = FB + 1;
+template <int NB> struct Blk {
+    static constexpr int XS = 2 * NB + 16;   // LDS row stride of the transposed panel tiles XT[k][row]: rows [0,NB) = X_r, [NB,2NB) = X_c
+    static constexpr int CS = NB + 2;        // LDS row stride of the look-ahead tile (even: keeps every sub-array 16-byte aligned)
+    static constexpr size_t lds_bytes = (size_t)(NB * XS + NB * CS + NB * NB + NB + 2 * NB) * sizeof(double);
+};
+
+__device__ __forceinline__ double bcast_lane(double v, int l) {   // lane l (compile-time) -> SGPR pair
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fast_rcp(double d) {            // v_rcp_f64 (2^-23) + two Newton steps -> full fp64
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return r;
+}
 
 // x L^T = a for the row held in this lane's registers, column oriented: once x[j] is final every later entry
-// is updated independently (no dependent accumulation chain).  sLT[j*NB + t] = L[t][j] and srd[j] = 1/L[j][j] sit in
-// LDS; every lane reads the same address (broadcast), and since nothing writes them the reads pipeline freely.
+// is updated independently.  sLT[j*NB + t] = L[t][j] and srd[j] = 1/L[j][j] sit in LDS; every lane reads the same
+// address (broadcast), and since nothing writes them the reads pipeline freely.
 template <int NB>
 __device__ __forceinline__ void trsm_row_lds(double* x, const double* sLT, const double* srd) {
+    // software pipelined by hand: the broadcast reads of column j+1 are issued before the FMAs of column j; all reads
+    // are 16-byte aligned pairs (ds_read_b128, immediate offsets): a row is read from the even index at or below j+1
+    double lc[NB], ln[NB];
+    const double2* L2 = reinterpret_cast<const double2*>(sLT);
+#pragma unroll
+    for (int t2 = 0; t2 < NB / 2; ++t2) { const double2 v = L2[t2]; lc[2 * t2] = v.x; lc[2 * t2 + 1] = v.y; }
+    double rd = srd[0];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        x[j] *= srd[j];
+        double rdn = 0.0;
+        if (j + 1 < NB) {
+            rdn = srd[j + 1];
+#pragma unroll
+            for (int t2 = (j + 2) / 2; t2 < NB / 2; ++t2) { const double2 v = L2[(j + 1) * (NB / 2) + t2]; ln[2 * t2] = v.x; ln[2 * t2 + 1] = v.y; }
+        }
+        x[j] *= rd;
         const double xj = x[j];
 #pragma unroll
-        for (int t = j + 1; t < NB; ++t) x[t] = fma(-xj, sLT[j * NB + t], x[t]);
-    }
-}
-// scalar-path variant (operands through s_load / SGPRs) used where the L block is not staged in LDS
-template <int NB>
-__device__ __forceinline__ void trsm_row_scalar(double* x, const double* LTg, const double* rdg) {
-    cdouble* LT = (cdouble*)(uintptr_t)LTg;
-    cdouble* rd = (cdouble*)(uintptr_t)rdg;
+        for (int t = j + 1; t < NB; ++t) x[t] = fma(-xj, lc[t], x[t]);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        x[j] *= rd[j];
-        const double xj = x[j];
-#pragma unroll
-        for (int t = j + 1; t < NB; ++t) x[t] = fma(-xj, LT[j * NB + t], x[t]);
+        for (int t = ((j + 2) / 2) * 2; t < NB; ++t) lc[t] = ln[t];
+        rd = rdn;
     }
 }
 
 // Right-looking Cholesky of an NB x NB tile inside ONE wavefront, lane i (< NB) holding the full SYMMETRIC row i in
-// registers.  Because the tile stays symmetric, the column needed at step j (A[c][j] for all c) is register j across
-// the lanes: one ds_write_b64 publishes it, broadcast ds_reads fetch it back, and every lane applies
-//   a[i][c] -= a[i][j] * a[c][j] / a[j][j].
-// No barrier (single wave, LDS operations of a wave execute in order), no cross-lane VALU traffic, only a reciprocal
-// on the dependency chain.  sbuf: 2*NB doubles of LDS (double-buffered by column parity).  On return a[j] = L[i][j], j <= i.
+// registers.  Column j of the current matrix (A[c][j], all c) is register j across the lanes: one ds_write_b64
+// publishes it, broadcast reads fetch it back, and every lane applies  a[i][c] -= a[i][j] * a[c][j] / a[j][j].
+// Software pipelined: column j+1 is updated and published first, then the rest of column j's update runs while that
+// write travels; the pivot is taken from lane j's register (no LDS wait).  sbuf: 2*NB doubles (double-buffered by
+// column parity; single wave, LDS operations of a wave execute in order).  On return a[j] = L[i][j] for j <= i.
 template <int NB>
 __device__ __forceinline__ bool potrf_inwave(double* a, int lane, double* sbuf) {
     bool bad = false;
+    sbuf[lane] = a[0];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        double* buf = sbuf + (j & 1) * NB;
-        buf[lane] = a[j];
-        const double sj = buf[j];
+        const double* buf = sbuf + (j & 1) * NB;
+        double* nbuf = sbuf + ((j + 1) & 1) * NB;
+        // the two values the NEXT column depends on come straight from registers (v_readlane): the pivot A[j][j] and
+        // A[j+1][j]; the LDS copy of column j only feeds the bulk update below, off the dependency chain
+        const double sj = bcast_lane(a[j], j);
         const bool bj = !(sj > 0.0);
         bad = bad || bj;
-        const double rinv = 1.0 / (bj ? 1.0 : sj);
-        const double f = a[j] * rinv;
+        const double f = a[j] * fast_rcp(bj ? 1.0 : sj);
+        if (j + 1 < NB) {
+            const double s1 = bcast_lane(a[j], j + 1);
+            a[j + 1] = fma(-f, s1, a[j + 1]);
+            nbuf[lane] = a[j + 1];
+        }
+        {   // bulk update from the LDS copy of column j, read as aligned pairs
+            const double2* b2 = reinterpret_cast<const double2*>(buf);
 #pragma unroll
-        for (int c = j + 1; c < NB; ++c) a[c] = fma(-f, buf[c], a[c]);
+            for (int c2 = (j + 2) / 2; c2 < NB / 2; ++c2) {
+                const double2 v = b2[c2];
+                if (2 * c2 >= j + 2) a[2 * c2] = fma(-f, v.x, a[2 * c2]);
+                a[2 * c2 + 1] = fma(-f, v.y, a[2 * c2 + 1]);
+            }
+        }
     }
     // L[i][j] = a[j] / sqrt(pivot_j); the pivots are the diagonal entries a[i][i] left by the sweep
     double dg = 1.0;
@@ -80,50 +119,48 @@ __device__ __forceinline__ bool potrf_inwave(double* a, int lane, double* sbuf) 
 }
 
 // store the factor of diagonal block kb: L rows into Lfac (zero above the diagonal), the transposed copy and the
-// reciprocal diagonal for the scalar-path TRSM of the next step
+// reciprocal diagonal for the TRSMs of the next step
+template <int NB>
 __device__ __forceinline__ void store_factor(const DevBuf& d, int kb, const double* a, int lane, bool bad) {
     const int ld = d.ld;
-    double* Lrow = d.Lfac + (size_t)(kb * FB + lane) * ld + kb * FB;
-    double* LT = d.LT32 + (size_t)kb * FB * FB;
+    double* Lrow = d.Lfac + (size_t)(kb * NB + lane) * ld + kb * NB;
+    double* LT = d.LTblk + (size_t)kb * NB * NB;
 #pragma unroll
-    for (int j = 0; j < FB; j += 2) {
+    for (int j = 0; j < NB; j += 2) {
         const double v0 = (j <= lane) ? a[j] : 0.0, v1 = (j + 1 <= lane) ? a[j + 1] : 0.0;
         *reinterpret_cast<double2*>(Lrow + j) = make_double2(v0, v1);
     }
 #pragma unroll
-    for (int j = 0; j < FB; ++j) LT[j * FB + lane] = (lane > j) ? a[j] : 0.0;
+    for (int j = 0; j < NB; ++j) LT[j * NB + lane] = (lane > j) ? a[j] : 0.0;
     double dg = 1.0;
 #pragma unroll
-    for (int j = 0; j < FB; ++j) if (lane == j) dg = a[j];
-    d.rd32[kb * FB + lane] = 1.0 / dg;
+    for (int j = 0; j < NB; ++j) if (lane == j) dg = a[j];
+    d.rdblk[kb * NB + lane] = 1.0 / dg;
     if (bad && lane == 0) d.ctrl->solver_ok = 0;
 }
 
+template <int NB>
 __global__ __launch_bounds__(64) void k_potrf0(DevBuf d) {
-    __shared__ double sbuf[2 * FB];
+    __shared__ __attribute__((aligned(16))) double sbuf[2 * NB];
     const int lane = threadIdx.x;
-    if (lane >= FB) return;
-    double a[FB];
+    if (lane >= NB) return;
+    double a[NB];
     const double* row = d.sys + (size_t)lane * d.ld;
 #pragma unroll
-    for (int j = 0; j < FB; j += 2) { const double2 v = *reinterpret_cast<const double2*>(row + j); a[j] = v.x; a[j + 1] = v.y; }
-    const bool bad = potrf_inwave<FB>(a, lane, sbuf);
-    store_factor(d, 0, a, lane, bad);
+    for (int j = 0; j < NB; j += 2) { const double2 v = *reinterpret_cast<const double2*>(row + j); a[j] = v.x; a[j + 1] = v.y; }
+    const bool bad = potrf_inwave<NB>(a, lane, sbuf);
+    store_factor<NB>(d, 0, a, lane, bad);
 }
 
-// One launch per block step k (right-looking, 32-wide blocks).  Workgroup (r,c), k < c <= r <= T (r == T is the
-// right-hand-side block row):
-//   wave 0, lanes 0-31 : X_r = A(r,k) L(k,k)^-T     lanes 32-63 : X_c = A(c,k) L(k,k)^-T     (scalar-path TRSM)
-//   all 4 waves        : A(r,c) -= X_r X_c^T  on the matrix cores (v_mfma_f64_16x16x4_f64), one 16x16 tile per wave
-//   look-ahead         : the workgroup of (k+1,k+1) factors its freshly updated tile in-wave and publishes
-//                        L(k+1,k+1), so the next launch can start its TRSMs immediately.
-template <bool MFMA>
+template <bool MFMA, int NB>
 __global__ __launch_bounds__(256) void k_chol_step(DevBuf d, int k, int T) {
-    __shared__ double sXT[FB * XS];
-    __shared__ double sC[FB * CS];
-    __shared__ double sLT[FB * FB];
-    __shared__ double srd[FB];
-    __shared__ double sbuf[2 * FB];
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];   // 16-byte alignment: ds_read_b128 with immediate offsets
+    constexpr int XS = Blk<NB>::XS, CS = Blk<NB>::CS;
+    double* sXT = s_dyn;                    // NB x XS
+    double* sC = sXT + NB * XS;             // NB x CS
+    double* sLT = sC + NB * CS;             // NB x NB
+    double* srd = sLT + NB * NB;            // NB
+    double* sbuf = srd + NB;                // 2 NB
     const int ld = d.ld;
     const int nt = T - k - 1;
     const int b = blockIdx.x;
@@ -141,71 +178,106 @@ __global__ __launch_bounds__(256) void k_chol_step(DevBuf d, int k, int T) {
     const int r = k + 1 + rr, c = k + 1 + cc;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool have_update = (c < T);
-    // stage L(k,k)^T and its reciprocal diagonal in LDS (4 doubles per thread, coalesced)
+#ifdef PLBA_STAMPS   // diagnostic build only: cycle stamps of the look-ahead workgroup into maxd_part[0..7] (never in the product build)
+    const bool stamp = (blockIdx.x == 0 && threadIdx.x == 0 && k == 5);
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) do { if (blockIdx.x == 0 && k == 5 && wv == 0) ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+    STAMP(0);
+    // stage L(k,k)^T and its reciprocal diagonal in LDS (coalesced)
     {
-        const double* LTg = d.LT32 + (size_t)k * FB * FB;
-        const double4 v = reinterpret_cast<const double4*>(LTg)[threadIdx.x];
-        reinterpret_cast<double4*>(sLT)[threadIdx.x] = v;
-        if (threadIdx.x < FB) srd[threadIdx.x] = d.rd32[k * FB + threadIdx.x];
+        const double4* LTg = reinterpret_cast<const double4*>(d.LTblk + (size_t)k * NB * NB);
+        for (int i = threadIdx.x; i < NB * NB / 4; i += 256) reinterpret_cast<double4*>(sLT)[i] = LTg[i];
+        if (threadIdx.x < NB) srd[threadIdx.x] = d.rdblk[k * NB + threadIdx.x];
     }
-    const bool upper = lane >= FB;
-    const int rl = lane & (FB - 1);
-    const bool active = (wv == 0) && (!upper || (have_update && c != r));
-    double x[FB];
-    if (active) {   // panel rows are fetched while the L tile lands in LDS
-        const int br = upper ? c : r;
-        const double* grow = d.sys + (size_t)(br * FB + rl) * ld + k * FB;
+    // panel rows: NB == 32: wave 0 solves both panels (lanes 0-31 -> X_r, 32-63 -> X_c); NB == 64: wave 0 -> X_r, wave 1 -> X_c
+    const bool second = (NB == 32) ? (lane >= NB) : (wv == 1);
+    const bool solver_wave = (NB == 32) ? (wv == 0) : (wv < 2);
+    const int rl = lane & (NB - 1);
+    const bool active = solver_wave && (!second || (have_update && c != r));
+    double x[NB];
+    if (active) {   // fetched while the L tile lands in LDS
+        const int br = second ? c : r;
+        const double* grow = d.sys + (size_t)(br * NB + rl) * ld + k * NB;
 #pragma unroll
-        for (int j = 0; j < FB; j += 2) { const double2 v = *reinterpret_cast<const double2*>(grow + j); x[j] = v.x; x[j + 1] = v.y; }
+        for (int j = 0; j < NB; j += 2) { const double2 v = *reinterpret_cast<const double2*>(grow + j); x[j] = v.x; x[j + 1] = v.y; }
+    }
+    // the C tile this workgroup updates is fetched now, in the shadow of the TRSM
+    constexpr int TPD = NB / 16, TPW = TPD * TPD / 4;
+    double cold[TPW * 4];
+    if (MFMA && have_update) {
+        const double* Cg = d.sys + (size_t)(r * NB) * ld + c * NB;
+        const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int t = wv * TPW + q, tr = t / TPD, tc = t % TPD;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cold[q * 4 + v] = Cg[(size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li];
+        }
     }
     __syncthreads();
-    if (wv == 0) {
-        if (active) {
-            trsm_row_lds<FB>(x, sLT, srd);
+    STAMP(1);
+    if (active) {
+        trsm_row_lds<NB>(x, sLT, srd);
+        const int xrow = second ? NB + rl : rl;
 #pragma unroll
-            for (int j = 0; j < FB; ++j) sXT[j * XS + lane] = x[j];
-            if (!upper && c == k + 1) {
-                // the solved panel block is the final L(r,k); it goes to Lfac, never back into sys: other
-                // workgroups of this launch still read the unsolved panel from sys
-                double* gout = d.Lfac + (size_t)(r * FB + rl) * ld + k * FB;
+        for (int j = 0; j < NB; ++j) sXT[j * XS + xrow] = x[j];
+        if (!second && c == k + 1) {
+            // the solved panel block is the final L(r,k); it goes to Lfac, never back into sys: other
+            // workgroups of this launch still read the unsolved panel from sys
+            double* gout = d.Lfac + (size_t)(r * NB + rl) * ld + k * NB;
 #pragma unroll
-                for (int j = 0; j < FB; j += 2) *reinterpret_cast<double2*>(gout + j) = make_double2(x[j], x[j + 1]);
-            }
+            for (int j = 0; j < NB; j += 2) *reinterpret_cast<double2*>(gout + j) = make_double2(x[j], x[j + 1]);
         }
     }
     if (!have_update) return;
     __syncthreads();
-    const int cb = (c == r) ? 0 : FB;
-    double* C = d.sys + (size_t)(r * FB) * ld + c * FB;
+    STAMP(2);
+    const int cb = (c == r) ? 0 : NB;
+    double* C = d.sys + (size_t)(r * NB) * ld + c * NB;
     const bool lookahead = (r == k + 1 && c == k + 1);
     if (MFMA) {
-        const int tr = wv >> 1, tc = wv & 1;
         const int li = lane & 15, lk = lane >> 4;
-        double4v acc = (double4v){0.0, 0.0, 0.0, 0.0};
+        double4v acc[TPW];
 #pragma unroll
-        for (int kk = 0; kk < FB / 4; ++kk) {
-            const double av = sXT[(kk * 4 + lk) * XS + tr * 16 + li];
-            const double bv = sXT[(kk * 4 + lk) * XS + cb + tc * 16 + li];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        for (int q = 0; q < TPW; ++q) acc[q] = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int kk = 0; kk < NB / 4; ++kk) {
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                const int t = wv * TPW + q, tr = t / TPD, tc = t % TPD;
+                const double av = sXT[(kk * 4 + lk) * XS + tr * 16 + li];
+                const double bv = sXT[(kk * 4 + lk) * XS + cb + tc * 16 + li];
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q], 0, 0, 0);
+            }
         }
         // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int row = tr * 16 + lk + 4 * v, col = tc * 16 + li;
-            const double nv = C[(size_t)row * ld + col] - acc[v];
-            if (lookahead) sC[row * CS + col] = nv;
-            else C[(size_t)row * ld + col] = nv;
+        for (int q = 0; q < TPW; ++q) {
+            const int t = wv * TPW + q, tr = t / TPD, tc = t % TPD;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = tr * 16 + lk + 4 * v, col = tc * 16 + li;
+                const double nv = cold[q * 4 + v] - acc[q][v];
+                if (lookahead) sC[row * CS + col] = nv;
+                else C[(size_t)row * ld + col] = nv;
+            }
         }
     } else {
-        const int row = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int kk = 0; kk < FB; ++kk) {
+        constexpr int PER = NB * NB / 256;           // outputs per thread, consecutive in a row
+        const int row = (threadIdx.x * PER) / NB, c0 = (threadIdx.x * PER) % NB;
+        double acc[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) acc[q] = 0.0;
+        for (int kk = 0; kk < NB; ++kk) {
             const double av = sXT[kk * XS + row];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] += av * sXT[kk * XS + cb + c0 + q];
+            for (int q = 0; q < PER; ++q) acc[q] += av * sXT[kk * XS + cb + c0 + q];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < PER; ++q) {
             const double nv = C[(size_t)row * ld + c0 + q] - acc[q];
             if (lookahead) sC[row * CS + c0 + q] = nv;
             else C[(size_t)row * ld + c0 + q] = nv;
@@ -213,48 +285,80 @@ __global__ __launch_bounds__(256) void k_chol_step(DevBuf d, int k, int T) {
     }
     if (!lookahead) return;
     __syncthreads();
-    if (wv == 0 && lane < FB) {
-        double a[FB];
+    STAMP(3);
+    if (wv == 0 && lane < NB) {
+        double a[NB];
 #pragma unroll
-        for (int j = 0; j < FB; ++j) a[j] = sC[lane * CS + j];
-        const bool bad = potrf_inwave<FB>(a, lane, sbuf);
-        store_factor(d, k + 1, a, lane, bad);
+        for (int j = 0; j < NB; ++j) a[j] = sC[lane * CS + j];
+        STAMP(4);
+        const bool bad = potrf_inwave<NB>(a, lane, sbuf);
+        STAMP(5);
+        store_factor<NB>(d, k + 1, a, lane, bad);
+        STAMP(6);
+#ifdef PLBA_STAMPS
+        if (stamp) for (int i = 0; i < 7; ++i) d.maxd_part[i] = (double)(ts[i] - ts[0]);
+#endif
     }
 }
 
-// Linv[k] = L(k,k)^-1 for every 64x64 diagonal tile of the factor, assembled from its two 32-blocks:
-//   [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1]   (A^-1, C^-1 by scalar-path TRSM on the identity)
+// Linv[k] = L(k,k)^-1 for every 64x64 diagonal tile of the factor (for the back-substitution).
+// NB == 64: one solve against the staged tile (lane c = column c).  NB == 32: assembled from the two 32-blocks,
+//   [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1].
+template <int NB>
 __global__ __launch_bounds__(256) void k_inv_diag(DevBuf d) {
-    __shared__ double sAi[FB * CS], sCi[FB * CS], sB[FB * CS], sT[FB * CS];
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     const int k = blockIdx.x, ld = d.ld;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wv == 0) {
-        const int blk = 2 * k + (lane >= FB ? 1 : 0), cidx = lane & (FB - 1);
-        double y[FB];
-#pragma unroll
-        for (int t = 0; t < FB; ++t) y[t] = (t == cidx) ? 1.0 : 0.0;
-        trsm_row_scalar<FB>(y, d.LT32 + (size_t)blk * FB * FB, d.rd32 + blk * FB);
-        double* dst = (lane >= FB) ? sCi : sAi;          // dst[t][c] = (L^-1)(t, c)
-#pragma unroll
-        for (int t = 0; t < FB; ++t) dst[t * CS + cidx] = y[t];
-    }
-    for (int idx = threadIdx.x; idx < FB * FB; idx += 256) {
-        const int rw = idx >> 5, cl = idx & 31;
-        sB[rw * CS + cl] = d.Lfac[(size_t)(k * TILE + FB + rw) * ld + k * TILE + cl];
-    }
-    __syncthreads();
-    const int row = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
-    {
-        double acc[4] = {0, 0, 0, 0};
-        for (int q = 0; q < FB; ++q) { const double bv = sB[row * CS + q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += bv * sAi[q * CS + c0 + e]; }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sT[row * CS + c0 + e] = acc[e];
-    }
-    __syncthreads();
     double* out = d.Linv + (size_t)k * TILE * TILE;
-    {
+    if (NB == 64) {
+        double* sLT = s_dyn;                 // 64 x 64
+        double* srd = sLT + 64 * 64;
+        const double4* LTg = reinterpret_cast<const double4*>(d.LTblk + (size_t)k * 64 * 64);
+        for (int i = threadIdx.x; i < 64 * 64 / 4; i += 256) reinterpret_cast<double4*>(sLT)[i] = LTg[i];
+        if (threadIdx.x < 64) srd[threadIdx.x] = d.rdblk[k * 64 + threadIdx.x];
+        __syncthreads();
+        if (wv == 0) {
+            double y[64];
+#pragma unroll
+            for (int t = 0; t < 64; ++t) y[t] = (t == lane) ? 1.0 : 0.0;
+            trsm_row_lds<64>(y, sLT, srd);
+#pragma unroll
+            for (int t = 0; t < 64; ++t) out[t * TILE + lane] = y[t];      // Linv[t][c]
+        }
+    } else {
+        constexpr int FB = 32, CS = 34;
+        double* sAi = s_dyn; double* sCi = sAi + FB * CS; double* sB = sCi + FB * CS; double* sT = sB + FB * CS;
+        double* sLT = sT + FB * CS;          // 2 x 32 x 32
+        double* srd = sLT + 2 * FB * FB;     // 2 x 32
+        const double4* LTg = reinterpret_cast<const double4*>(d.LTblk + (size_t)(2 * k) * FB * FB);
+        for (int i = threadIdx.x; i < 2 * FB * FB / 4; i += 256) reinterpret_cast<double4*>(sLT)[i] = LTg[i];
+        if (threadIdx.x < 2 * FB) srd[threadIdx.x] = d.rdblk[2 * k * FB + threadIdx.x];
+        for (int idx = threadIdx.x; idx < FB * FB; idx += 256) {
+            const int rw = idx >> 5, cl = idx & 31;
+            sB[rw * CS + cl] = d.Lfac[(size_t)(k * TILE + FB + rw) * ld + k * TILE + cl];
+        }
+        __syncthreads();
+        if (wv == 0) {
+            const int hi = lane >= FB ? 1 : 0, cidx = lane & (FB - 1);
+            double y[FB];
+#pragma unroll
+            for (int t = 0; t < FB; ++t) y[t] = (t == cidx) ? 1.0 : 0.0;
+            trsm_row_lds<FB>(y, sLT + hi * FB * FB, srd + hi * FB);
+            double* dst = hi ? sCi : sAi;          // dst[t][c] = (L^-1)(t, c)
+#pragma unroll
+            for (int t = 0; t < FB; ++t) dst[t * CS + cidx] = y[t];
+        }
+        __syncthreads();
+        const int row = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+        {
+            double acc[4] = {0, 0, 0, 0};
+            for (int q = 0; q < FB; ++q) { const double bv = sB[row * CS + q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += bv * sAi[q * CS + c0 + e]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sT[row * CS + c0 + e] = acc[e];
+        }
+        __syncthreads();
         double acc[4] = {0, 0, 0, 0};
         for (int q = 0; q < FB; ++q) { const double cv = sCi[row * CS + q];
 #pragma unroll
@@ -331,21 +435,41 @@ __global__ __launch_bounds__(256) void k_trsv_flow(DevBuf d, int T, int epoch) {
     }
 }
 
-void launch_cholesky(const DevBuf& d, bool use_mfma, hipStream_t s) {
-    const int T = d.Ppad / FB;
-    hipLaunchKernelGGL(k_potrf0, dim3(1), dim3(64), 0, s, d);
+template <int NB>
+static void launch_cholesky_nb(const DevBuf& d, bool use_mfma, hipStream_t s) {
+    const int T = d.Ppad / NB;
+    const size_t sh = Blk<NB>::lds_bytes;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_step<true, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_step<false, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_potrf0<NB>, dim3(1), dim3(64), 0, s, d);
     for (int k = 0; k < T; ++k) {
         const int nt = T - k - 1;
         const int tiles = nt * (nt + 1) / 2 + nt;
         const int grid = tiles > 0 ? tiles : 1;
-        if (use_mfma) hipLaunchKernelGGL(k_chol_step<true>, dim3(grid), dim3(256), 0, s, d, k, T);
-        else hipLaunchKernelGGL(k_chol_step<false>, dim3(grid), dim3(256), 0, s, d, k, T);
+        if (use_mfma) hipLaunchKernelGGL((k_chol_step<true, NB>), dim3(grid), dim3(256), sh, s, d, k, T);
+        else hipLaunchKernelGGL((k_chol_step<false, NB>), dim3(grid), dim3(256), sh, s, d, k, T);
     }
+}
+void launch_cholesky(const DevBuf& d, bool use_mfma, hipStream_t s) {
+    if (d.fb == 64) launch_cholesky_nb<64>(d, use_mfma, s);
+    else launch_cholesky_nb<32>(d, use_mfma, s);
 }
 
 void launch_trsv_back(const DevBuf& d, int epoch, hipStream_t s) {
     const int T = d.Ppad / TILE;
-    hipLaunchKernelGGL(k_inv_diag, dim3(T), dim3(256), 0, s, d);
+    static bool attr_set = false;
+    const size_t sh64 = (size_t)(64 * 64 + 64) * sizeof(double), sh32 = (size_t)(4 * 32 * 34 + 2 * 32 * 32 + 64) * sizeof(double);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_inv_diag<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh64);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_inv_diag<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh32);
+        attr_set = true;
+    }
+    if (d.fb == 64) hipLaunchKernelGGL(k_inv_diag<64>, dim3(T), dim3(256), sh64, s, d);
+    else hipLaunchKernelGGL(k_inv_diag<32>, dim3(T), dim3(256), sh32, s, d);
     hipLaunchKernelGGL(k_trsv_flow, dim3(T), dim3(256), 0, s, d, T, epoch);
 }
 

@@ -74,8 +74,9 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     // dense
     double *Hconst, *Himu, *bimu, *sys, *Lfac, *bpg, *x;   // Lfac: Cholesky factor (same shape as sys)
     double* Linv;          // T x 64 x 64 inverses of the diagonal tiles of Lfac
-    double* LT32;          // (Ppad/32) x 32 x 32 transposed diagonal blocks of the factor, LT[j][t] = L[t][j]
-    double* rd32;          // Ppad reciprocals of the factor's diagonal
+    double* LTblk;         // (Ppad/fb) x fb x fb transposed diagonal blocks of the factor, LT[j][t] = L[t][j]
+    double* rdblk;         // Ppad reciprocals of the factor's diagonal
+    int fb;                // factorisation block width (32 or 64)
     int* flow_flags;       // T epoch-stamped flags of the back-substitution dataflow
     // reductions / control
     double *chi_part, *scale_part, *maxd_part, *kfdiag, *posediag;

@@ -38,12 +38,12 @@ def test_backend_is_the_hip_library(hip):
 
 
 @pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 200, 750])
-@pytest.mark.parametrize("mfma", [1, 0])
-def test_dense_solver_vs_numpy(pkg, hip, n, mfma):
+@pytest.mark.parametrize("mfma,fb", [(1, 32), (0, 32), (1, 64), (0, 64)])
+def test_dense_solver_vs_numpy(pkg, hip, n, mfma, fb):
     rng = np.random.default_rng(n)
     A = rng.normal(size=(n, n)); A = A @ A.T + n * np.eye(n)
     b = rng.normal(size=n)
-    p = pkg.new_problem(use_mfma=mfma)
+    p = pkg.new_problem(use_mfma=mfma, factor_block=fb)
     x, ok = p.debug_dense_solve(A, b)
     assert ok
     _close(x, np.linalg.solve(A, b), 1e-9, "x")
@@ -79,10 +79,10 @@ def test_build_system_and_schur(pkg, orc, hip, imu):
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("mfma", [1, 0])
-def test_one_damped_solve(pkg, orc, hip, mfma):
+@pytest.mark.parametrize("mfma,fb", [(1, 32), (0, 32), (1, 64)])
+def test_one_damped_solve(pkg, orc, hip, mfma, fb):
     w = pkg.window.make_window(7, 200, 50, imu=True, seed=103)
-    g, o = _pair(pkg, orc, w, use_mfma=mfma)
+    g, o = _pair(pkg, orc, w, use_mfma=mfma, factor_block=fb)
     g.debug_build(3.0, True); o.debug_build(3.0, True)
     assert g.debug_get("solver_ok")[0] == 1
     _close(g.debug_get("x"), o.debug_get("x"), 1e-7, "x")
