@@ -406,7 +406,7 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_pr_idx.upload(p->pr_idx)); HIPCK(p, p->d_pr_x0off.upload(pr_x0off)); HIPCK(p, p->d_pr_off.upload(pr_off));
     HIPCK(p, p->d_pr_x0.upload(p->pr_x0)); HIPCK(p, p->d_pr_J0.upload(p->pr_J0)); HIPCK(p, p->d_pr_r0.upload(p->pr_r0));
     HIPCK(p, p->d_pr_err.alloc(p->pr_n)); HIPCK(p, p->d_pr_dx.alloc(p->pr_n)); HIPCK(p, p->d_pr_chi.alloc(1));
-    HIPCK(p, p->d_Hconst.alloc((size_t)p->Ppad * p->ld)); HIPCK(p, p->d_Himu.alloc((size_t)p->Ppad * p->ld));
+    HIPCK(p, p->d_Hconst.alloc((size_t)p->Ppad * p->ld)); HIPCK(p, p->d_Himu.alloc((size_t)p->Ppad * p->ld)); HIPCK(p, p->d_Himu2.alloc((size_t)p->Ppad * p->ld)); HIPCK(p, p->d_bimu2.alloc(p->ld));
     HIPCK(p, p->d_bimu.alloc(p->ld)); HIPCK(p, p->d_sys.alloc(sysn)); HIPCK(p, p->d_Lfac.alloc(sysn));
     HIPCK(p, p->d_bpg.alloc(p->ld)); HIPCK(p, p->d_x.alloc(p->ld));
     HIPCK(p, p->d_Linv.alloc((size_t)(p->Ppad / TILE) * TILE * TILE)); HIPCK(p, p->d_flow_flags.alloc(p->Ppad / TILE)); p->flow_epoch = 0;
@@ -438,7 +438,7 @@ static int prepare(plba_problem* p) {
     d.pr_kf = p->d_pr_kf.p; d.pr_isbias = p->d_pr_isbias.p; d.pr_size = p->d_pr_size.p; d.pr_idx = p->d_pr_idx.p;
     d.pr_x0off = p->d_pr_x0off.p; d.pr_off = p->d_pr_off.p; d.pr_x0 = p->d_pr_x0.p; d.pr_J0 = p->d_pr_J0.p; d.pr_r0 = p->d_pr_r0.p;
     d.pr_err = p->d_pr_err.p; d.pr_dx = p->d_pr_dx.p; d.pr_chi = p->d_pr_chi.p;
-    d.Hconst = p->d_Hconst.p; d.Himu = p->d_Himu.p; d.bimu = p->d_bimu.p; d.sys = p->d_sys.p; d.Lfac = p->d_Lfac.p; d.bpg = p->d_bpg.p; d.x = p->d_x.p;
+    d.Hconst = p->d_Hconst.p; d.Himu = p->d_Himu.p; d.bimu = p->d_bimu.p; d.Himu_alt = p->d_Himu2.p; d.bimu_alt = p->d_bimu2.p; d.sys = p->d_sys.p; d.Lfac = p->d_Lfac.p; d.bpg = p->d_bpg.p; d.x = p->d_x.p;
     d.Linv = p->d_Linv.p; d.flow_flags = p->d_flow_flags.p; d.LTblk = p->d_LT32.p; d.rdblk = p->d_rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32;
     d.chi_part = p->d_chi_part.p; d.scale_part = p->d_scale_part.p; d.maxd_part = p->d_maxd_part.p; d.kfdiag = p->d_kfdiag.p; d.posediag = p->d_posediag.p;
     d.ctrl = p->d_ctrl.p; d.trace = p->d_trace.p; d.trace_cap = TRACE_CAP; d.trace_n = p->d_trace_n.p;
@@ -487,42 +487,46 @@ static LmParams lm_params(const plba_problem* p) {
 static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
     const DevBuf& d = p->dv;
     hipStream_t s = p->stream;
+    if (first_iter) {   // later iterations start from the accumulator k_assemble cleared (swapped in on accept)
+        HIPCK(p, hipMemsetAsync(d.Himu, 0, (size_t)d.Ppad * d.ld * 8, s));
+        HIPCK(p, hipMemsetAsync(d.bimu, 0, (size_t)d.ld * 8, s));
+    }
     MARK(p, 0);
-    launch_linearize(d, p->cur, true, p->rob, s);
+    launch_linearize(d, p->cur, true, p->rob, owns_pose_edges(p), s);   // observations + IMU / prior edges, one launch
     MARK(p, 1);
-    HIPCK(p, hipMemcpyAsync(d.Himu, d.Hconst, (size_t)d.Ppad * d.ld * 8, hipMemcpyDeviceToDevice, s));
-    HIPCK(p, hipMemsetAsync(d.bimu, 0, (size_t)d.ld * 8, s));
-    launch_pose_edges(d, p->cur, true, p->rob, owns_pose_edges(p), s);
     MARK(p, 2);
-    launch_landmark_hll(d, p->cur, s);
+    launch_landmark_hll(d, p->cur, !first_iter, s);
     if (first_iter) {
         HIPCK(p, hipMemsetAsync(d.kfdiag, 0, (size_t)d.K * 6 * 8, s));
         launch_kfdiag(d, p->cur, s);
     }
-    launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
     if (p->world > 1) {
         int rc;
+        launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
         if ((rc = exchange(p, p->d_red.p, 1, 0))) return rc;
         if (first_iter) {
             if ((rc = exchange(p, p->d_red.p + 2, 1, 1))) return rc;
             if ((rc = exchange(p, d.posediag, (size_t)d.P, 0))) return rc;
         }
     }
-    launch_lambda_init2(d, lm_params(p), p->d_red.p, first_iter, iteration, s);
+    launch_lambda_init2(d, lm_params(p), p->d_red.p, first_iter, iteration, p->world <= 1, s);
     MARK(p, 3);
     return PLBA_OK;
 }
 // setLambda + Schur complement (+ optional dense solve, back-substitution, trial update)
-static int enqueue_solve(plba_problem* p, bool do_solve) {
+static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
     const DevBuf& d = p->dv;
     hipStream_t s = p->stream;
     MARK(p, 4);
-    launch_landmark_dinv(d, s);
+    if (need_dinv) launch_landmark_dinv(d, s);   // otherwise k_landmark_hll<true> already formed (Hll + lambda I)^-1
     launch_assemble(d, owns_pose_edges(p), s);
     launch_schur_pairs(d, p->cur, s);
     MARK(p, 5);
-    if (p->world > 1) { int rc = exchange(p, d.sys, (size_t)(d.Ppad + 2) * d.ld, 0); if (rc) return rc; }
-    HIPCK(p, hipMemcpyAsync(d.bpg, d.sys + (size_t)(d.Ppad + 1) * d.ld, (size_t)d.ld * 8, hipMemcpyDeviceToDevice, s));
+    if (p->world > 1) {   // single GPU: k_assemble / k_schur_pairs wrote bp into bpg directly
+        int rc = exchange(p, d.sys, (size_t)(d.Ppad + 2) * d.ld, 0);
+        if (rc) return rc;
+        HIPCK(p, hipMemcpyAsync(d.bpg, d.sys + (size_t)(d.Ppad + 1) * d.ld, (size_t)d.ld * 8, hipMemcpyDeviceToDevice, s));
+    }
     MARK(p, 6);
     if (!do_solve) return PLBA_OK;
     launch_cholesky(d, p->opt.use_mfma != 0, s);
@@ -565,14 +569,15 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
         double rho = 0.0;
         int qmax = 0;
         do {
-            if ((rc = enqueue_solve(p, true))) return rc;
+            if ((rc = enqueue_solve(p, true, it == 0 || qmax > 0))) return rc;
             const int trial = p->cur ^ 1;
-            launch_linearize(d, trial, false, p->rob, s);
-            launch_pose_edges(d, trial, false, p->rob, owns_pose_edges(p), s);
+            launch_linearize(d, trial, false, p->rob, owns_pose_edges(p), s);
             MARK(p, 9);
-            launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
-            if (p->world > 1 && (rc = exchange(p, p->d_red.p, 2, 0))) return rc;
-            launch_decide(d, lp, p->d_red.p, s);
+            if (p->world > 1) {
+                launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
+                if ((rc = exchange(p, p->d_red.p, 2, 0))) return rc;
+            }
+            launch_decide(d, lp, p->d_red.p, p->world <= 1, s);
             MARK(p, 10);
             HIPCK(p, hipMemcpyAsync(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
             HIPCK(p, hipStreamSynchronize(s));
@@ -585,7 +590,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             rho = c.rho;
             lambda = c.lambda;
             st.trials++;
-            if (c.accepted) { p->cur ^= 1; last_chi = c.current_chi; }
+            if (c.accepted) { p->cur ^= 1; last_chi = c.current_chi; std::swap(p->dv.Himu, p->dv.Himu_alt); std::swap(p->dv.bimu, p->dv.bimu_alt); }
             else if (!std::isfinite(lambda)) break;
             qmax++;
         } while (rho < 0 && qmax < lp.max_trials && !(abort_flag && *abort_flag));
@@ -608,8 +613,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
         st.lambda_final = p->h_ctrl->lambda;
     } else {
         // no iteration ran: report the chi2 of the current estimate (computeActiveErrors only)
-        launch_linearize(d, p->cur, false, p->rob, s);
-        launch_pose_edges(d, p->cur, false, p->rob, owns_pose_edges(p), s);
+        launch_linearize(d, p->cur, false, p->rob, owns_pose_edges(p), s);
         launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
         if (p->world > 1 && (rc = exchange(p, p->d_red.p, 1, 0))) return rc;
         double chi = 0.0;
@@ -628,8 +632,7 @@ int plba_recompute_errors(plba_problem* p) {
     int rc = prepare(p);
     if (rc) return rc;
     HIPCK(p, hipSetDevice(p->device));
-    launch_linearize(p->dv, p->cur, false, p->rob, p->stream);
-    launch_pose_edges(p->dv, p->cur, false, p->rob, owns_pose_edges(p), p->stream);
+    launch_linearize(p->dv, p->cur, false, p->rob, owns_pose_edges(p), p->stream);
     HIPCK(p, hipStreamSynchronize(p->stream));
     return PLBA_OK;
 }
@@ -818,7 +821,7 @@ int plba_debug_build(plba_problem* p, double lambda, int do_solve) {
     HIPCK(p, hipMemcpy(&c0, d.ctrl, sizeof c0, hipMemcpyDeviceToHost));
     c0.lambda = lambda;
     HIPCK(p, hipMemcpy(d.ctrl, &c0, sizeof c0, hipMemcpyHostToDevice));
-    if ((rc = enqueue_solve(p, do_solve != 0))) return rc;
+    if ((rc = enqueue_solve(p, do_solve != 0, true))) return rc;
     HIPCK(p, hipStreamSynchronize(p->stream));
     HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
     return PLBA_OK;

@@ -10,7 +10,8 @@
 //   hll,bl   L x 12, L x 6   landmark blocks (points: 6 upper; lines: two 3x3 uppers)
 //   dinv,tv  L x 12, L x 6   (Hll + lambda I)^-1 and (Hll + lambda I)^-1 bl
 //   pairs    CSR of keyframe pairs sharing landmarks -> (edge_i, edge_j) entries for the Schur complement
-//   Himu     Ppad x ld   pose-side edges (IMU + prior) of this iteration; Hconst = prior J0^T J0 scattered
+//   Himu     Ppad x ld   IMU edges of this iteration (Himu_alt: zeroed by k_assemble, swapped in when a step is accepted);
+//                        Hconst = prior J0^T J0 scattered (constant), added by k_assemble
 //   sys      (Ppad+64) x ld  reduced camera system, augmented: row Ppad = bschur, row Ppad+1 = bp
 #pragma once
 #include <hip/hip_runtime.h>
@@ -72,7 +73,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     const double *pr_x0, *pr_J0, *pr_r0;
     double *pr_err, *pr_dx, *pr_chi;
     // dense
-    double *Hconst, *Himu, *bimu, *sys, *Lfac, *bpg, *x;   // Lfac: Cholesky factor (same shape as sys)
+    double *Hconst, *Himu, *bimu, *Himu_alt, *bimu_alt, *sys, *Lfac, *bpg, *x;   // Lfac: Cholesky factor (same shape as sys)
     double* Linv;          // T x 64 x 64 inverses of the diagonal tiles of Lfac
     double* LTblk;         // (Ppad/fb) x fb x fb transposed diagonal blocks of the factor, LT[j][t] = L[t][j]
     double* rdblk;         // Ppad reciprocals of the factor's diagonal
@@ -94,9 +95,9 @@ struct Robust { int on[5]; double delta[5]; };
 namespace plba {
 struct LmParams { double tau, lower, upper, user_lambda; int max_trials; };
 
-void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, hipStream_t s);
+void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s);
 void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, bool owns_pose_edges, hipStream_t s);
-void launch_landmark_hll(const DevBuf& d, int state, hipStream_t s);
+void launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv, hipStream_t s);
 void launch_kfdiag(const DevBuf& d, int state, hipStream_t s);
 void launch_landmark_dinv(const DevBuf& d, hipStream_t s);
 void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s);
@@ -105,8 +106,8 @@ void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s);
 void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s);
 // red[0] = activeRobustChi2 (local), red[1] = landmark part of computeScale (local), red[2] = max |Hll_jj| (local)
 void launch_reduce(const DevBuf& d, bool owns_pose_edges, double* red, hipStream_t s);
-void launch_lambda_init2(const DevBuf& d, const LmParams& lp, const double* red, bool first_iter, int iteration, hipStream_t s);
-void launch_decide(const DevBuf& d, const LmParams& lp, const double* red, hipStream_t s);
+void launch_lambda_init2(const DevBuf& d, const LmParams& lp, double* red, bool first_iter, int iteration, bool fused, hipStream_t s);
+void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, hipStream_t s);
 void launch_gate(const DevBuf& d, int state, double thresh, hipStream_t s);
 void launch_depth(const DevBuf& d, int state, uint8_t* out, hipStream_t s);
 int  edge_blocks(const DevBuf& d);

@@ -57,11 +57,23 @@ DEV int pmap(int r) { return r < 3 ? r : r + 3; }   // (dp, dphi) -> position in
 // -------------------------------------------------------------------------------------------------
 // K1/K2: per-observation residual / Jacobian / robust weight
 // -------------------------------------------------------------------------------------------------
+template <bool JAC, int NT> DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane);
+template <bool JAC> DEV void prior_block(const DevBuf& d, int state);
+
+// Blocks [0, nblk_edges) handle observations.  Blocks beyond evaluate the pose-side edges inside the SAME launch
+// (one IMU PVR+bias edge pair per block, then one block for the prior), so the serial per-edge IMU math overlaps the
+// observation pass instead of following it.
 template <bool JAC>
-__global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust rb) {
+__global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust rb, int nblk_edges) {
     extern __shared__ double s_dyn[];
     double* s_kc = s_dyn;               // K x 12 staged camera blocks
     __shared__ double s4[4];
+    if ((int)blockIdx.x >= nblk_edges) {
+        const int m = blockIdx.x - nblk_edges;
+        if (m < d.M) pose_edge_block<JAC, 256>(d, state, rb, m, threadIdx.x);
+        else prior_block<JAC>(d, state);
+        return;
+    }
     const double* kf = d.kf[state];
     for (int k = threadIdx.x; k < d.K; k += 256) kfcam_make(d.cam, kf + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
     __syncthreads();
@@ -112,6 +124,35 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
 // -------------------------------------------------------------------------------------------------
 // K5: landmark blocks.  Thread per landmark slot, fixed edge order (deterministic).
 // -------------------------------------------------------------------------------------------------
+// (Hll + lambda I)^-1 and D*bl of one landmark slot from its undamped blocks
+DEV void landmark_dinv_one(const DevBuf& d, int slot, const double* h, const double* b, bool active, bool is_pt) {
+    double dd[12], tt[6];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dd[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tt[i] = 0.0;
+    if (active) {
+        const double lambda = d.ctrl->lambda;
+        sym3_inv(h, lambda, dd);
+        const V3 t0 = sym3_mul(dd, v3(b[0], b[1], b[2]));
+        tt[0] = t0.x; tt[1] = t0.y; tt[2] = t0.z;
+        if (!is_pt) {
+            sym3_inv(h + 6, lambda, dd + 6);
+            const V3 t1 = sym3_mul(dd + 6, v3(b[3], b[4], b[5]));
+            tt[3] = t1.x; tt[4] = t1.y; tt[5] = t1.z;
+        }
+    }
+    double* D = d.dinv + (size_t)slot * 12;
+    double* t = d.tv + (size_t)slot * 6;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) D[i] = dd[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i] = tt[i];
+}
+
+// FUSE_DINV: lambda of this iteration is already known (every outer iteration but the first), so the damped inverse
+// is formed right here from the registers instead of by a second pass over hll/bl.
+template <bool FUSE_DINV>
 __global__ __launch_bounds__(256) void k_landmark_hll(DevBuf d, int state) {
     extern __shared__ double s_dyn[];
     double* s_kc = s_dyn;
@@ -165,6 +206,7 @@ __global__ __launch_bounds__(256) void k_landmark_hll(DevBuf d, int state) {
             md = fmax(fmax(fabs(h[0]), fabs(h[3])), fabs(h[5]));
             if (!is_pt) md = fmax(md, fmax(fmax(fabs(h[6]), fabs(h[9])), fabs(h[11])));
         }
+        if (FUSE_DINV) landmark_dinv_one(d, slot, h, b, active, is_pt);
     }
     double bm = block_max_256(md, s4);
     if (threadIdx.x == 0) d.maxd_part[blockIdx.x] = bm;
@@ -173,38 +215,14 @@ __global__ __launch_bounds__(256) void k_landmark_hll(DevBuf d, int state) {
 __global__ __launch_bounds__(256) void k_landmark_dinv(DevBuf d) {
     const int slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= d.L) return;
-    double* D = d.dinv + (size_t)slot * 12;
-    double* t = d.tv + (size_t)slot * 6;
-    if (!d.lm_active[slot]) {
+    double h[12], b[6];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) D[i] = 0.0;
+    for (int i = 0; i < 12; ++i) h[i] = d.hll[(size_t)slot * 12 + i];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) t[i] = 0.0;
-        return;
-    }
-    const double lambda = d.ctrl->lambda;
-    const double* h = d.hll + (size_t)slot * 12;
-    const double* b = d.bl + (size_t)slot * 6;
-    double dd[6];
-    sym3_inv(h, lambda, dd);
-    V3 t0 = sym3_mul(dd, v3(b[0], b[1], b[2]));
-#pragma unroll
-    for (int i = 0; i < 6; ++i) D[i] = dd[i];
-    t[0] = t0.x; t[1] = t0.y; t[2] = t0.z;
-    if (slot >= d.Np) {
-        sym3_inv(h + 6, lambda, dd);
-        V3 t1 = sym3_mul(dd, v3(b[3], b[4], b[5]));
-#pragma unroll
-        for (int i = 0; i < 6; ++i) D[6 + i] = dd[i];
-        t[3] = t1.x; t[4] = t1.y; t[5] = t1.z;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) D[6 + i] = 0.0;
-        t[3] = t[4] = t[5] = 0.0;
-    }
+    for (int i = 0; i < 6; ++i) b[i] = d.bl[(size_t)slot * 6 + i];
+    landmark_dinv_one(d, slot, h, b, d.lm_active[slot] != 0, slot < d.Np);
 }
 
-// wavefront sum with DPP row shifts / broadcasts (VALU only, no LDS permute traffic); total lands in lane 63
 template <int CTRL, int ROW_MASK>
 DEV double dpp_get(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -369,10 +387,11 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state) {
         const double v = Rcb[rr] * g[rb] + Rcb[3 + rr] * g[rb + 1] + Rcb[6 + rr] * g[rb + 2];
         const int row = (t < 42) ? d.Ppad : d.Ppad + 1;     // bschur row / bp row of the augmented system
         d.sys[(size_t)row * ld + oi + pmap(r)] += v;
+        if (t >= 42) d.bpg[oi + pmap(r)] += v;     // bp is consumed by the factorisation in sys; computeScale needs it afterwards
     }
 }
 
-// sys = Himu (+ lambda I on the real diagonal, 1 on the padded diagonal) ; row Ppad = row Ppad+1 = pose-side gradient
+// sys = Himu + Hconst (+ lambda I on the real diagonal, 1 on the padded diagonal) ; row Ppad = row Ppad+1 = pose-side gradient
 __global__ __launch_bounds__(256) void k_assemble(DevBuf d, int add_lambda) {
     const size_t n = (size_t)(d.Ppad + TILE) * d.ld;
     const double lambda = d.ctrl->lambda;
@@ -380,13 +399,38 @@ __global__ __launch_bounds__(256) void k_assemble(DevBuf d, int add_lambda) {
         const int r = (int)(idx / d.ld), c = (int)(idx % d.ld);
         double v = 0.0;
         if (r < d.Ppad) {
-            v = d.Himu[idx];
+            v = d.Himu[idx] + d.Hconst[idx];      // IMU edges of this iteration + the constant prior J0^T J0
             if (r == c && add_lambda) v += (r < d.P) ? lambda : 1.0;
+            d.Himu_alt[idx] = 0.0;                // the accumulator the NEXT outer iteration's pose-side edges add into
         } else if (r <= d.Ppad + 1) {
             v = d.bimu[c];
+            if (r == d.Ppad) { d.bpg[c] = v; d.bimu_alt[c] = 0.0; }
         }
         d.sys[idx] = v;
     }
+}
+
+// SparseOptimizer::update for one keyframe (oplusImpl of VertexNavStatePVR / VertexNavStateBias)
+DEV void update_kf_one(const DevBuf& d, int cur, int trial, int k) {
+    const double* s = d.kf[cur] + (size_t)k * KF_STRIDE;
+    double* o = d.kf[trial] + (size_t)k * KF_STRIDE;
+    double tmp[KF_STRIDE];
+#pragma unroll
+    for (int i = 0; i < KF_STRIDE; ++i) tmp[i] = s[i];
+    const bool ok = d.ctrl->solver_ok != 0;
+    const int op = d.kf_off_pvr[k], ob = d.kf_off_bias[k];
+    if (ok && op >= 0) {
+        double u[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) u[i] = d.x[op + i];
+        kf_oplus_pvr(s, u, tmp);
+    }
+    if (ok && ob >= 0) {   // IMU/NavState.cpp:100-121
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[16 + i] = s[16 + i] + d.x[ob + i];
+    }
+#pragma unroll
+    for (int i = 0; i < KF_STRIDE; ++i) o[i] = tmp[i];
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -407,6 +451,7 @@ __global__ __launch_bounds__(256) void k_backsub(DevBuf d, int cur, int trial) {
         y[0] = yp.x; y[1] = yp.y; y[2] = yp.z; y[3] = yr.x; y[4] = yr.y; y[5] = yr.z;
     }
     __syncthreads();
+    if (blockIdx.x == 0) for (int k = threadIdx.x; k < d.K; k += 256) update_kf_one(d, cur, trial, k);   // keyframe part of update()
     const int slot = blockIdx.x * 256 + threadIdx.x;
     double sc = 0.0;
     if (slot < d.L) {
@@ -447,29 +492,9 @@ __global__ __launch_bounds__(256) void k_backsub(DevBuf d, int cur, int trial) {
     if (threadIdx.x == 0) d.scale_part[blockIdx.x] = bs;
 }
 
-// SparseOptimizer::update for the keyframe vertices (oplusImpl of VertexNavStatePVR / VertexNavStateBias)
 __global__ void k_update_kf(DevBuf d, int cur, int trial) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= d.K) return;
-    const double* s = d.kf[cur] + (size_t)k * KF_STRIDE;
-    double* o = d.kf[trial] + (size_t)k * KF_STRIDE;
-    double tmp[KF_STRIDE];
-#pragma unroll
-    for (int i = 0; i < KF_STRIDE; ++i) tmp[i] = s[i];
-    const bool ok = d.ctrl->solver_ok != 0;
-    const int op = d.kf_off_pvr[k], ob = d.kf_off_bias[k];
-    if (ok && op >= 0) {
-        double u[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) u[i] = d.x[op + i];
-        kf_oplus_pvr(s, u, tmp);
-    }
-    if (ok && ob >= 0) {   // IMU/NavState.cpp:100-121
-#pragma unroll
-        for (int i = 0; i < 6; ++i) tmp[16 + i] = s[16 + i] + d.x[ob + i];
-    }
-#pragma unroll
-    for (int i = 0; i < KF_STRIDE; ++i) o[i] = tmp[i];
+    if (k < d.K) update_kf_one(d, cur, trial, k);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -478,14 +503,12 @@ __global__ void k_update_kf(DevBuf d, int cur, int trial) {
 // Omega' J and J^T Omega' J (24 x 24 over [PVR_i | PVR_j | Bias_i]) and add them into the dense
 // pose-side system with fp64 atomics (a handful of edges share a destination block).
 // -------------------------------------------------------------------------------------------------
-template <bool JAC>
-__global__ __launch_bounds__(64) void k_pose_edges(DevBuf d, int state, Robust rb) {
+template <bool JAC, int NT>
+DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane) {
     __shared__ double sJ[9 * 24];     // [J0 | J1 | J2] row-major 9 x 24
     __shared__ double sOJ[9 * 24];
     __shared__ double sE[16];
     __shared__ double sW[2];
-    const int m = blockIdx.x;
-    const int lane = threadIdx.x;
     const int ki = d.imu_i[m], kj = d.imu_j[m];
     const double* si = d.kf[state] + (size_t)ki * KF_STRIDE;
     const double* sj = d.kf[state] + (size_t)kj * KF_STRIDE;
@@ -521,10 +544,10 @@ __global__ __launch_bounds__(64) void k_pose_edges(DevBuf d, int state, Robust r
         }
     }
     if (!JAC) return;
-    __syncthreads();
+    __syncthreads();     // every thread of the NT-thread block reaches both barriers
     const double w = sW[0], wb = sW[1];
     // OJ = w * Omega * J   (9 x 24)
-    for (int t = lane; t < 9 * 24; t += 64) {
+    for (int t = lane; t < 9 * 24; t += NT) {
         const int r = t / 24, c = t % 24;
         double s = 0.0;
 #pragma unroll
@@ -542,7 +565,7 @@ __global__ __launch_bounds__(64) void k_pose_edges(DevBuf d, int state, Robust r
     }
     const int ld = d.ld;
     // H += J^T OJ (24 x 24), g += -J^T (w Omega e) = -OJ^T e
-    for (int t = lane; t < 24 * 24; t += 64) {
+    for (int t = lane; t < 24 * 24; t += NT) {
         const int a = t / 24, b = t % 24;
         int oa = -1, ob = -1;
 #pragma unroll
@@ -589,11 +612,15 @@ __global__ __launch_bounds__(64) void k_pose_edges(DevBuf d, int state, Robust r
         }
     }
 }
+template <bool JAC>
+__global__ __launch_bounds__(64) void k_pose_edges(DevBuf d, int state, Robust rb) {
+    pose_edge_block<JAC, 64>(d, state, rb, blockIdx.x, threadIdx.x);
+}
 
 // K4: marginalization prior edge (one workgroup): dx, e = r0 + J0 dx, chi2 = |e|^2, g += -J0^T e.
 // Its Hessian J0^T J0 is constant and pre-scattered into Hconst at upload.
 template <bool JAC>
-__global__ __launch_bounds__(256) void k_prior(DevBuf d, int state) {
+DEV void prior_block(const DevBuf& d, int state) {
     __shared__ double s4[4];
     const int n = d.pr_n;
     for (int v = threadIdx.x; v < d.pr_nv; v += 256) {
@@ -627,6 +654,8 @@ __global__ __launch_bounds__(256) void k_prior(DevBuf d, int state) {
         }
     }
 }
+template <bool JAC>
+__global__ __launch_bounds__(256) void k_prior(DevBuf d, int state) { prior_block<JAC>(d, state); }
 
 // -------------------------------------------------------------------------------------------------
 // K8: reductions and LM control (single workgroup, fixed summation order)
@@ -650,7 +679,7 @@ __global__ __launch_bounds__(256) void k_reduce(DevBuf d, int nblk_edges, int nb
 // diagonal of the pose-side Hessian held by this rank: pose-side edges (Himu) + sum_e Jp^T w Jp (kfdiag);
 // in a sharded run the vector is all-reduced (sum) before the max, so every rank derives the same lambda
 __global__ __launch_bounds__(256) void k_posediag(DevBuf d) {
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < d.ld; r += gridDim.x * 256) d.posediag[r] = (r < d.P) ? d.Himu[(size_t)r * d.ld + r] : 0.0;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < d.ld; r += gridDim.x * 256) d.posediag[r] = (r < d.P) ? d.Himu[(size_t)r * d.ld + r] + d.Hconst[(size_t)r * d.ld + r] : 0.0;
 }
 __global__ __launch_bounds__(256) void k_posediag_kf(DevBuf d) {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -659,8 +688,22 @@ __global__ __launch_bounds__(256) void k_posediag_kf(DevBuf d) {
     if (o >= 0) d.posediag[o + pmap(t % 6)] += d.kfdiag[t];
 }
 // start of an outer iteration: currentChi, and on the first one computeLambdaInit (tau * max |H_jj|)
-__global__ __launch_bounds__(256) void k_lambda_init(DevBuf d, LmParams lp, const double* red, int first_iter, int iteration) {
+// k_reduce inlined into the LM control kernels for the single-GPU path (no exchange between reduce and control)
+DEV void reduce_inline(const DevBuf& d, int nblk_edges, int nblk_lm, double* red, double* s4) {
+    double c = 0.0, sc = 0.0, md = 0.0;
+    for (int i = threadIdx.x; i < nblk_edges; i += 256) c += d.chi_part[i];
+    for (int i = threadIdx.x; i < d.M; i += 256) c += d.imu_chi[(size_t)i * 4 + 2] + d.imu_chi[(size_t)i * 4 + 3];
+    if (threadIdx.x == 0 && d.pr_nv > 0) c += d.pr_chi[0];
+    for (int i = threadIdx.x; i < nblk_lm; i += 256) { sc += d.scale_part[i]; md = fmax(md, d.maxd_part[i]); }
+    const double C = block_sum_256(c, s4);
+    const double S = block_sum_256(sc, s4);
+    const double Mx = block_max_256(md, s4);
+    if (threadIdx.x == 0) { red[0] = C; red[1] = S; red[2] = Mx; }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void k_lambda_init(DevBuf d, LmParams lp, double* red, int first_iter, int iteration, int fused, int nblk_edges, int nblk_lm) {
     __shared__ double s4[4];
+    if (fused) reduce_inline(d, nblk_edges, nblk_lm, red, s4);
     double md = 0.0;
     if (first_iter) for (int r = threadIdx.x; r < d.P; r += 256) md = fmax(md, fabs(d.posediag[r]));
     double mx = block_max_256(md, s4);
@@ -679,14 +722,15 @@ __global__ __launch_bounds__(256) void k_lambda_init(DevBuf d, LmParams lp, cons
 }
 
 // end of a trial: rho test and lambda schedule of OptimizationAlgorithmLevenberg::solve
-__global__ __launch_bounds__(256) void k_decide(DevBuf d, LmParams lp, const double* red) {
+__global__ __launch_bounds__(256) void k_decide(DevBuf d, LmParams lp, double* red, int fused, int nblk_edges, int nblk_lm) {
     __shared__ double s4[4];
+    if (fused) reduce_inline(d, nblk_edges, nblk_lm, red, s4);
     Ctrl* c = d.ctrl;
     const double lambda = c->lambda;
     double sp = 0.0;
     if (c->solver_ok) for (int j = threadIdx.x; j < d.P; j += 256) { const double xj = d.x[j]; sp += xj * (lambda * xj + d.bpg[j]); }
     double SP = block_sum_256(sp, s4);
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x == 0) {
     double tempChi = red[0];
     if (!c->solver_ok) tempChi = 1.7976931348623157e308;
     double scale = SP + red[1];
@@ -717,6 +761,7 @@ __global__ __launch_bounds__(256) void k_decide(DevBuf d, LmParams lp, const dou
     c->trial += 1;
     if (!c->solver_ok) c->n_fail += 1;
     c->solver_ok = 1;
+    }
 }
 
 // chi2() > thresh || !isDepthPositive()  =>  setLevel(1)   (mapHandler.cpp:6047-6066)
@@ -745,11 +790,14 @@ __global__ __launch_bounds__(256) void k_gate(DevBuf d, int state, double thresh
 int edge_blocks(const DevBuf& d) { return (d.E + 255) / 256; }
 static int lm_blocks(const DevBuf& d) { return (d.L + 255) / 256; }
 
-void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, hipStream_t s) {
-    if (d.E == 0) return;
+// with_pose_edges: this rank owns the IMU / prior edges; they are evaluated by extra blocks of the same launch
+void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s) {
+    const int nb = d.E ? edge_blocks(d) : 0;
+    const int pose_blocks = with_pose_edges ? d.M + (d.pr_nv > 0 ? 1 : 0) : 0;
+    if (nb + pose_blocks == 0) return;
     const size_t sh = (size_t)d.K * KFCAM_STRIDE * sizeof(double);
-    if (jac) hipLaunchKernelGGL(k_linearize<true>, dim3(edge_blocks(d)), dim3(256), sh, s, d, state, rb);
-    else hipLaunchKernelGGL(k_linearize<false>, dim3(edge_blocks(d)), dim3(256), sh, s, d, state, rb);
+    if (jac) hipLaunchKernelGGL(k_linearize<true>, dim3(nb + pose_blocks), dim3(256), sh, s, d, state, rb, nb);
+    else hipLaunchKernelGGL(k_linearize<false>, dim3(nb + pose_blocks), dim3(256), sh, s, d, state, rb, nb);
 }
 void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, bool owns, hipStream_t s) {
     if (!owns) return;
@@ -762,8 +810,11 @@ void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, b
         else hipLaunchKernelGGL(k_prior<false>, dim3(1), dim3(256), 0, s, d, state);
     }
 }
-void launch_landmark_hll(const DevBuf& d, int state, hipStream_t s) {
-    if (d.L) hipLaunchKernelGGL(k_landmark_hll, dim3(lm_blocks(d)), dim3(256), (size_t)d.K * KFCAM_STRIDE * sizeof(double), s, d, state);
+void launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv, hipStream_t s) {
+    if (!d.L) return;
+    const size_t sh = (size_t)d.K * KFCAM_STRIDE * sizeof(double);
+    if (fuse_dinv) hipLaunchKernelGGL(k_landmark_hll<true>, dim3(lm_blocks(d)), dim3(256), sh, s, d, state);
+    else hipLaunchKernelGGL(k_landmark_hll<false>, dim3(lm_blocks(d)), dim3(256), sh, s, d, state);
 }
 void launch_kfdiag(const DevBuf& d, int state, hipStream_t s) {
     if (d.npairs) hipLaunchKernelGGL(k_kfdiag, dim3(d.npairs), dim3(256), 0, s, d, state);
@@ -786,16 +837,18 @@ void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s) {
     if (d.L) hipLaunchKernelGGL(k_backsub, dim3(lm_blocks(d)), dim3(256), (size_t)d.K * (KFCAM_STRIDE + 6) * sizeof(double), s, d, cur, trial);
 }
 void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s) {
+    if (d.L) return;   // done by block 0 of k_backsub whenever there are landmarks
     hipLaunchKernelGGL(k_update_kf, dim3((d.K + 63) / 64), dim3(64), 0, s, d, cur, trial);
 }
 void launch_reduce(const DevBuf& d, bool owns_pose_edges, double* red, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, d, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0, owns_pose_edges ? 1 : 0, red);
 }
-void launch_lambda_init2(const DevBuf& d, const LmParams& lp, const double* red, bool first_iter, int iteration, hipStream_t s) {
-    hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(256), 0, s, d, lp, red, first_iter ? 1 : 0, iteration);
+// fused: the per-block partials are summed inside the control kernel (single-GPU path, no exchange in between)
+void launch_lambda_init2(const DevBuf& d, const LmParams& lp, double* red, bool first_iter, int iteration, bool fused, hipStream_t s) {
+    hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(256), 0, s, d, lp, red, first_iter ? 1 : 0, iteration, fused ? 1 : 0, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0);
 }
-void launch_decide(const DevBuf& d, const LmParams& lp, const double* red, hipStream_t s) {
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, s, d, lp, red);
+void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, hipStream_t s) {
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, s, d, lp, red, fused ? 1 : 0, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0);
 }
 void launch_gate(const DevBuf& d, int state, double thresh, hipStream_t s) {
     if (d.E == 0) return;
