@@ -272,9 +272,9 @@ int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double
     Ctrl c0; memset(&c0, 0, sizeof c0); c0.solver_ok = 1;
     HIPCK(p, hipMemcpy(ctrl.p, &c0, sizeof c0, hipMemcpyHostToDevice));
     DevBuf d; memset(&d, 0, sizeof d);
-    d.P = n; d.Ppad = Ppad; d.ld = ld; d.sys = sys.p; d.Lfac = Lfac.p; d.x = xx.p; d.ctrl = ctrl.p; d.Linv = Linv.p; d.flow_flags = flags.p; d.LTblk = LT32.p; d.rdblk = rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32;
+    d.P = n; d.Ppad = Ppad; d.ld = ld; d.sys = sys.p; d.Lfac = Lfac.p; d.x = xx.p; d.ctrl = ctrl.p; d.Linv = Linv.p; d.flow_flags = flags.p; d.LTblk = LT32.p; d.Linv32 = LT32.p; d.rdblk = rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32;
     launch_cholesky(d, p->opt.use_mfma != 0, p->stream);
-    launch_trsv_back(d, 1, p->stream);
+    launch_trsv_back(d, p->opt.use_mfma != 0, 1, p->stream);
     HIPCK(p, hipStreamSynchronize(p->stream));
     HIPCK(p, hipGetLastError());
     HIPCK(p, hipMemcpy(x, xx.p, (size_t)n * 8, hipMemcpyDeviceToHost));
@@ -439,7 +439,7 @@ static int prepare(plba_problem* p) {
     d.pr_x0off = p->d_pr_x0off.p; d.pr_off = p->d_pr_off.p; d.pr_x0 = p->d_pr_x0.p; d.pr_J0 = p->d_pr_J0.p; d.pr_r0 = p->d_pr_r0.p;
     d.pr_err = p->d_pr_err.p; d.pr_dx = p->d_pr_dx.p; d.pr_chi = p->d_pr_chi.p;
     d.Hconst = p->d_Hconst.p; d.Himu = p->d_Himu.p; d.bimu = p->d_bimu.p; d.Himu_alt = p->d_Himu2.p; d.bimu_alt = p->d_bimu2.p; d.sys = p->d_sys.p; d.Lfac = p->d_Lfac.p; d.bpg = p->d_bpg.p; d.x = p->d_x.p;
-    d.Linv = p->d_Linv.p; d.flow_flags = p->d_flow_flags.p; d.LTblk = p->d_LT32.p; d.rdblk = p->d_rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32;
+    d.Linv = p->d_Linv.p; d.flow_flags = p->d_flow_flags.p; d.LTblk = p->d_LT32.p; d.Linv32 = p->d_LT32.p; d.rdblk = p->d_rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32;
     d.chi_part = p->d_chi_part.p; d.scale_part = p->d_scale_part.p; d.maxd_part = p->d_maxd_part.p; d.kfdiag = p->d_kfdiag.p; d.posediag = p->d_posediag.p;
     d.ctrl = p->d_ctrl.p; d.trace = p->d_trace.p; d.trace_cap = TRACE_CAP; d.trace_n = p->d_trace_n.p;
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
@@ -530,7 +530,7 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
     MARK(p, 6);
     if (!do_solve) return PLBA_OK;
     launch_cholesky(d, p->opt.use_mfma != 0, s);
-    launch_trsv_back(d, ++p->flow_epoch, s);
+    launch_trsv_back(d, p->opt.use_mfma != 0, ++p->flow_epoch, s);
     MARK(p, 7);
     launch_backsub(d, p->cur, p->cur ^ 1, s);
     launch_update_kf(d, p->cur, p->cur ^ 1, s);

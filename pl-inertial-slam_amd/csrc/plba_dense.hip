@@ -301,6 +301,295 @@ __global__ __launch_bounds__(256) void k_chol_step(DevBuf d, int k, int T) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// 32-wide steps with inverse-based panels (the default path: factor_block = 32, use_mfma = 1)
+//
+// Same right-looking schedule as k_chol_step, but nothing in a step is a substitution any more:
+//   * the look-ahead wavefront factors its 32x32 tile with ALL 64 lanes (lane = (row, column parity), 16 registers)
+//     and immediately forms L(k,k)^-1: two 16x16 triangular inverses in the lanes, the off-diagonal block
+//     -I22 L21 I11 as eight v_mfma_f64_16x16x4_f64;
+//   * every panel block is X = A(r,k) L(k,k)^-T as a 32x32x32 product on the matrix cores, operands straight from
+//     global memory (each lane reads 64 contiguous bytes), result scattered into LDS in the operand layout of
+//   * the trailing update A(r,c) -= X_r X_c^T (matrix cores again).
+// -------------------------------------------------------------------------------------------------
+constexpr int LS = 34;   // LDS row stride of a 32 x 32 tile: conflict-free operand reads (68 dwords = 4 mod 64), rows 16-byte aligned
+
+__device__ __forceinline__ double bcast_half(double v, int hsel) {   // lanes of half `hsel` (compile time) -> both halves
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    // v_permlane32_swap a, b: a[32..63] <-> b[0..31]; with a == b the first result is the low half everywhere, the second the high half
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(hsel ? r1[1] : r1[0], hsel ? r0[1] : r0[0]);
+}
+
+// Cholesky of a symmetric 32 x 32 tile in one wavefront: lane = (row i = lane & 31, parity h = lane >> 5) holds
+// a[q] = A[i][2q + h].  Column j lives in register j/2 of the lanes of parity j%2; by symmetry it is also row j, so
+// one ds_write publishes what every lane needs for its rank-1 update; the LDS copy is de-interleaved
+// (slot(c) = (c&1)*16 + c/2) so that each parity reads its own columns as aligned pairs.  The pivot, A[j+1][j] and
+// A[j+2][j] come from v_readlane and the multiplier crosses the halves with v_permlane32_swap, so the dependent chain
+// never waits on LDS.  colbuf: 64 doubles, sc: 32 doubles.  On return a[q] = L[i][2q+h] where 2q+h <= i.
+__device__ __forceinline__ bool potrf32_w64(double* a, int lane, double* colbuf, double* sc) {
+    const int i = lane & 31, h = lane >> 5;
+    const int pos = ((i & 1) << 4) | (i >> 1);
+    bool bad = false;
+    if (h == 0) colbuf[pos] = a[0];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const int qj = j >> 1, hj = j & 1;
+        const double* buf = colbuf + (j & 1) * 32;
+        double* nbuf = colbuf + ((j + 1) & 1) * 32;
+        const double sj = bcast_lane(a[qj], j + 32 * hj);
+        const bool bj = !(sj > 0.0);
+        bad = bad || bj;
+        const double f = bcast_half(a[qj] * fast_rcp(bj ? 1.0 : sj), hj);
+        if (j + 1 < 32) {
+            const int q1 = (j + 1) >> 1;
+            const double s1 = bcast_lane(a[qj], j + 1 + 32 * hj);
+            if (hj == 0) {          // column j+1 is register qj of parity 1
+                if (h == 1) { a[q1] = fma(-f, s1, a[q1]); nbuf[pos] = a[q1]; }
+            } else {                // register qj+1: column j+1 (parity 0) and column j+2 (parity 1)
+                const double s2 = (j + 2 < 32) ? bcast_lane(a[qj], j + 2 + 32 * hj) : 0.0;
+                a[q1] = fma(-f, h == 0 ? s1 : s2, a[q1]);
+                if (h == 0) nbuf[pos] = a[q1];
+            }
+        }
+        {   // bulk: registers qs..15 of both parities from the LDS copy of column j
+            const int qs = hj == 0 ? qj + 1 : qj + 2;
+            const double2* b2 = reinterpret_cast<const double2*>(buf + h * 16);
+#pragma unroll
+            for (int q2 = qs / 2; q2 < 8; ++q2) {
+                const double2 v = b2[q2];
+                if (2 * q2 >= qs) a[2 * q2] = fma(-f, v.x, a[2 * q2]);
+                a[2 * q2 + 1] = fma(-f, v.y, a[2 * q2 + 1]);
+            }
+        }
+    }
+    // L[i][c] = a / sqrt(pivot_c); pivot_c is the diagonal entry left by the sweep, held by lane (c, c & 1)
+    double dg = 1.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) if ((i >> 1) == q) dg = a[q];
+    if (h == (i & 1)) sc[pos] = 1.0 / sqrt(dg > 0.0 ? dg : 1.0);
+    const double2* s2 = reinterpret_cast<const double2*>(sc + h * 16);
+#pragma unroll
+    for (int q2 = 0; q2 < 8; ++q2) { const double2 v = s2[q2]; a[2 * q2] *= v.x; a[2 * q2 + 1] *= v.y; }
+    return bad;
+}
+
+// L^-1 of the tile potrf32_w64 left in registers (sc[slot(c)] = 1 / L[c][c]).  Leaves sLT[c][i] = L[i][c] and
+// sInv[r][c] = (L^-1)[r][c] in LDS (row stride LS).
+__device__ __forceinline__ void inv32_inwave(const double* a, int lane, double* sLT, double* sInv, const double* sc) {
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const int c = 2 * q + h; sLT[c * LS + i] = (c <= i) ? a[q] : 0.0; }
+    if (lane < 32) {
+        // the two 16 x 16 diagonal inverses: lane = (block b, column cc), column-oriented forward substitution
+        const int b = lane >> 4, cc = lane & 15;
+        double x[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) x[t] = (t == cc) ? 1.0 : 0.0;
+        const double* Lb = sLT + (16 * b) * LS + 16 * b;     // Lb[j * LS + t] = L_b[t][j]
+        const double* scb = sc + 8 * b;                      // slot(16 b + j) = (j & 1) * 16 + 8 b + j / 2
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            x[j] *= scb[((j & 1) << 4) + (j >> 1)];
+            const double xj = x[j];
+            const double2* r2 = reinterpret_cast<const double2*>(Lb + j * LS);
+#pragma unroll
+            for (int t2 = (j + 1) / 2; t2 < 8; ++t2) {
+                const double2 v = r2[t2];
+                if (2 * t2 >= j + 1) x[2 * t2] = fma(-xj, v.x, x[2 * t2]);
+                x[2 * t2 + 1] = fma(-xj, v.y, x[2 * t2 + 1]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) sInv[(16 * b + t) * LS + 16 * b + cc] = x[t];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int idx = e * 32 + lane; sInv[(idx >> 4) * LS + 16 + (idx & 15)] = 0.0; }
+    }
+    // lower-left block: -I22 (L21 I11).  The first product lands in the C/D layout (col = lane & 15, row = (lane >> 4) + 4 v),
+    // which is exactly a B operand of the second when its k index is enumerated as (lane >> 4) + 4 v.
+    const int li = lane & 15, lk = lane >> 4;
+    double4v m = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) m = __builtin_amdgcn_mfma_f64_16x16x4f64(sLT[(4 * s + lk) * LS + 16 + li], sInv[(4 * s + lk) * LS + li], m, 0, 0, 0);
+    double4v w = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) w = __builtin_amdgcn_mfma_f64_16x16x4f64(sInv[(16 + li) * LS + 16 + lk + 4 * v], m[v], w, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) sInv[(16 + lk + 4 * v) * LS + li] = -w[v];
+}
+
+// factor + invert diagonal block kb (tile already in registers) and publish L(kb,kb) (into Lfac) and L(kb,kb)^-1
+__device__ __forceinline__ void factor_diag32(const DevBuf& d, int kb, double* a, int lane, double* sLT, double* sInv, double* colbuf, double* sc) {
+    const bool bad = potrf32_w64(a, lane, colbuf, sc);
+    inv32_inwave(a, lane, sLT, sInv, sc);
+    double* Ig = d.Linv32 + (size_t)kb * 1024;
+    double* Lg = d.Lfac + (size_t)(kb * 32) * d.ld + kb * 32;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int idx = e * 64 + lane, rw = idx >> 5, cl = idx & 31;
+        Ig[idx] = sInv[rw * LS + cl];
+        Lg[(size_t)rw * d.ld + cl] = sLT[cl * LS + rw];
+    }
+    if (bad && lane == 0) d.ctrl->solver_ok = 0;
+}
+
+__global__ __launch_bounds__(64) void k_potrf0_32(DevBuf d) {
+    __shared__ __attribute__((aligned(16))) double sLT[32 * LS], sInv[32 * LS], colbuf[64], sc[32];
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    double a[16];
+    const double* row = d.sys + (size_t)i * d.ld + h;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = row[2 * q];
+    factor_diag32(d, 0, a, lane, sLT, sInv, colbuf, sc);
+}
+
+__global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
+    __shared__ __attribute__((aligned(16))) double sX[64 * LS];      // rows [0,32) = X_r, [32,64) = X_c, [row][k]
+    __shared__ __attribute__((aligned(16))) double sC[32 * LS];      // look-ahead tile
+    __shared__ __attribute__((aligned(16))) double sLT[32 * LS], sInv[32 * LS], colbuf[64], sc[32];
+    const int ld = d.ld;
+    const int nt = T - k - 1;
+    const int b = blockIdx.x;
+    const int ntri = nt * (nt + 1) / 2;
+    int rr, cc;
+    if (b < ntri) {
+        rr = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
+        while ((rr + 1) * (rr + 2) / 2 <= b) ++rr;
+        while (rr * (rr + 1) / 2 > b) --rr;
+        cc = b - rr * (rr + 1) / 2;
+    } else {
+        rr = nt;
+        cc = b - ntri;
+    }
+    const int r = k + 1 + rr, c = k + 1 + cc;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const bool diag = (r == c);
+#ifdef PLBA_STAMPS
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
+#define STAMP32(i) do { if (blockIdx.x == 0 && k == 5 && wv == 0) ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP32(i) do {} while (0)
+#endif
+    STAMP32(0);
+    // panel products: wave (p, th) forms rows [16 th, 16 th + 16) of X_r (p = 0) or X_c (p = 1)
+    const int p = wv >> 1, th = wv & 1;
+    const bool act = !(p == 1 && diag);
+    double4v x0 = (double4v){0.0, 0.0, 0.0, 0.0}, x1 = x0;
+    if (act) {
+        const int br = p ? c : r;
+        const double2* Ag = reinterpret_cast<const double2*>(d.sys + (size_t)(br * 32 + th * 16 + li) * ld + k * 32 + lk * 8);
+        const double2* B0 = reinterpret_cast<const double2*>(d.Linv32 + (size_t)k * 1024 + li * 32 + lk * 8);
+        const double2* B1 = B0 + 16 * 32 / 2;
+        double av[8], b0[8], b1[8];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double2 va = Ag[s], v0 = B0[s], v1 = B1[s];
+            av[2 * s] = va.x; av[2 * s + 1] = va.y; b0[2 * s] = v0.x; b0[2 * s + 1] = v0.y; b1[2 * s] = v1.x; b1[2 * s + 1] = v1.y;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {     // k index enumerated as 8 * (lane >> 4) + s on both operands
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], b0[s], x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], b1[s], x1, 0, 0, 0);
+        }
+    }
+    // the C tile this workgroup updates, fetched in the shadow of the panel products
+    const int tr = wv >> 1, tc = wv & 1;
+    double* C = d.sys + (size_t)(r * 32) * ld + c * 32;
+    const bool have_update = (c < T);      // false only for the last step's right-hand-side block
+    double cold[4] = {0.0, 0.0, 0.0, 0.0};
+    if (have_update) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) cold[v] = C[(size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li];
+    }
+    if (act) {
+        const int xr = p * 32 + th * 16 + lk;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { sX[(xr + 4 * v) * LS + li] = x0[v]; sX[(xr + 4 * v) * LS + 16 + li] = x1[v]; }
+        if (p == 0 && c == k + 1) {
+            // the finished panel block L(r,k) goes to Lfac, never back into sys: other workgroups still read the unsolved panel
+            double* g = d.Lfac + (size_t)(r * 32 + th * 16 + lk) * ld + k * 32 + li;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { g[(size_t)(4 * v) * ld] = x0[v]; g[(size_t)(4 * v) * ld + 16] = x1[v]; }
+        }
+    }
+    if (!have_update) return;
+    __syncthreads();
+    STAMP32(1);
+    const bool lookahead = (r == k + 1 && diag);
+    {
+        const int cb = diag ? 0 : 32;
+        double4v acc = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[(tr * 16 + li) * LS + kk * 4 + lk], sX[(cb + tc * 16 + li) * LS + kk * 4 + lk], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = tr * 16 + lk + 4 * v, col = tc * 16 + li;
+            const double nv = cold[v] - acc[v];
+            if (lookahead) sC[row * LS + col] = nv;
+            else C[(size_t)row * ld + col] = nv;
+        }
+    }
+    if (!lookahead) return;
+    __syncthreads();
+    STAMP32(2);
+    if (wv == 0) {
+        const int i = lane & 31, h = lane >> 5;
+        double a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = sC[i * LS + 2 * q + h];
+        STAMP32(3);
+#ifdef PLBA_STAMPS
+        const bool bad = potrf32_w64(a, lane, colbuf, sc);
+        STAMP32(4);
+        inv32_inwave(a, lane, sLT, sInv, sc);
+        STAMP32(5);
+        (void)bad;
+        if (lane == 0) for (int q = 0; q < 7; ++q) d.maxd_part[q] = (double)(ts[q] - ts[0]);
+#else
+        factor_diag32(d, k + 1, a, lane, sLT, sInv, colbuf, sc);
+#endif
+    }
+}
+
+// Linv[k] (64 x 64, for the back-substitution) from the 32 x 32 inverses the factorisation published:
+//   [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1]
+__global__ __launch_bounds__(256) void k_inv_diag32(DevBuf d) {
+    constexpr int FB = 32, CS = 34;
+    __shared__ double sAi[FB * CS], sCi[FB * CS], sB[FB * CS], sT[FB * CS];
+    const int k = blockIdx.x, ld = d.ld;
+    double* out = d.Linv + (size_t)k * TILE * TILE;
+    for (int idx = threadIdx.x; idx < FB * FB; idx += 256) {
+        const int rw = idx >> 5, cl = idx & 31;
+        sAi[rw * CS + cl] = d.Linv32[(size_t)(2 * k) * 1024 + idx];
+        sCi[rw * CS + cl] = d.Linv32[(size_t)(2 * k + 1) * 1024 + idx];
+        sB[rw * CS + cl] = d.Lfac[(size_t)(k * TILE + FB + rw) * ld + k * TILE + cl];
+    }
+    __syncthreads();
+    const int row = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    {
+        double acc[4] = {0, 0, 0, 0};
+        for (int q = 0; q < FB; ++q) { const double bv = sB[row * CS + q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += bv * sAi[q * CS + c0 + e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sT[row * CS + c0 + e] = acc[e];
+    }
+    __syncthreads();
+    double acc[4] = {0, 0, 0, 0};
+    for (int q = 0; q < FB; ++q) { const double cv = sCi[row * CS + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += cv * sT[q * CS + c0 + e]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        out[(FB + row) * TILE + c0 + e] = -acc[e];
+        out[row * TILE + c0 + e] = sAi[row * CS + c0 + e];
+        out[(FB + row) * TILE + FB + c0 + e] = sCi[row * CS + c0 + e];
+        out[row * TILE + FB + c0 + e] = 0.0;
+    }
+}
+
 // Linv[k] = L(k,k)^-1 for every 64x64 diagonal tile of the factor (for the back-substitution).
 // NB == 64: one solve against the staged tile (lane c = column c).  NB == 32: assembled from the two 32-blocks,
 //   [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1].
@@ -454,13 +743,29 @@ static void launch_cholesky_nb(const DevBuf& d, bool use_mfma, hipStream_t s) {
         else hipLaunchKernelGGL((k_chol_step<false, NB>), dim3(grid), dim3(256), sh, s, d, k, T);
     }
 }
+static bool inverse_panels(const DevBuf& d, bool use_mfma) { return d.fb == 32 && use_mfma; }
 void launch_cholesky(const DevBuf& d, bool use_mfma, hipStream_t s) {
+    if (inverse_panels(d, use_mfma)) {
+        const int T = d.Ppad / 32;
+        hipLaunchKernelGGL(k_potrf0_32, dim3(1), dim3(64), 0, s, d);
+        for (int k = 0; k < T; ++k) {
+            const int nt = T - k - 1;
+            const int tiles = nt * (nt + 1) / 2 + nt;
+            hipLaunchKernelGGL(k_chol32, dim3(tiles > 0 ? tiles : 1), dim3(256), 0, s, d, k, T);
+        }
+        return;
+    }
     if (d.fb == 64) launch_cholesky_nb<64>(d, use_mfma, s);
     else launch_cholesky_nb<32>(d, use_mfma, s);
 }
 
-void launch_trsv_back(const DevBuf& d, int epoch, hipStream_t s) {
+void launch_trsv_back(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s) {
     const int T = d.Ppad / TILE;
+    if (inverse_panels(d, use_mfma)) {
+        hipLaunchKernelGGL(k_inv_diag32, dim3(T), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_trsv_flow, dim3(T), dim3(256), 0, s, d, T, epoch);
+        return;
+    }
     static bool attr_set = false;
     const size_t sh64 = (size_t)(64 * 64 + 64) * sizeof(double), sh32 = (size_t)(4 * 32 * 34 + 2 * 32 * 32 + 64) * sizeof(double);
     if (!attr_set) {

@@ -73,10 +73,11 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     const double *pr_x0, *pr_J0, *pr_r0;
     double *pr_err, *pr_dx, *pr_chi;
     // dense
-    double *Hconst, *Himu, *bimu, *Himu_alt, *bimu_alt, *sys, *Lfac, *bpg, *x;   // Lfac: Cholesky factor (same shape as sys)
+    double *Hconst, *Himu, *bimu, *Himu_alt, *bimu_alt, *sys, *Lfac, *bpg, *x, *Linv32;   // Lfac: Cholesky factor (same shape as sys)
     double* Linv;          // T x 64 x 64 inverses of the diagonal tiles of Lfac
     double* LTblk;         // (Ppad/fb) x fb x fb transposed diagonal blocks of the factor, LT[j][t] = L[t][j]
     double* rdblk;         // Ppad reciprocals of the factor's diagonal
+    // Linv32 (declared above; shares LTblk's storage): (Ppad/32) x 32 x 32 inverses of the diagonal blocks, row-major
     int fb;                // factorisation block width (32 or 64)
     int* flow_flags;       // T epoch-stamped flags of the back-substitution dataflow
     // reductions / control
@@ -114,7 +115,7 @@ int  edge_blocks(const DevBuf& d);
 
 // dense
 void launch_cholesky(const DevBuf& d, bool use_mfma, hipStream_t s);   // sys -> Lfac (lower) incl. the augmented rows
-void launch_trsv_back(const DevBuf& d, int epoch, hipStream_t s);      // x = L^-T y; epoch must differ from the previous call's
+void launch_trsv_back(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s);      // x = L^-T y; epoch must differ from the previous call's
 void launch_ata(const double* A_colmajor, int rows, int cols, double* out_rowmajor, int ldo, hipStream_t s);  // A^T A
 
 // marginalization
