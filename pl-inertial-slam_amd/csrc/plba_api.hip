@@ -882,7 +882,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
         if (w == "err_pt") { v.resize((size_t)p->Ep * 2); for (int e = 0; e < p->Ep; ++e) { const size_t o = (size_t)p->ob_pos[e] * EREC; v[2 * (size_t)e] = h[o + 13]; v[2 * (size_t)e + 1] = h[o + 14]; } }
         else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { const size_t o = (size_t)p->ob_pos[p->Ep + e] * EREC; v[3 * (size_t)e] = h[o + 13]; v[3 * (size_t)e + 1] = h[o + 14]; } }
     } else if (w == "erec") { HIPCK(p, fetch(d.erec, (size_t)p->E * EREC, v)); }
-    else if (w == "stamps") { HIPCK(p, fetch(d.maxd_part, 8, v)); }
+    else if (w == "stamps") { HIPCK(p, fetch(d.maxd_part, 32, v)); }
     else if (w == "pose_dim") v = {(double)p->P};
     else if (w == "chi2") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {p->h_ctrl->current_chi}; }
     else if (w == "maxdiag") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {p->h_ctrl->maxdiag}; }

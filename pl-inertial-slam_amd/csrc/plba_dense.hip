@@ -322,37 +322,73 @@ __device__ __forceinline__ double bcast_half(double v, int hsel) {   // lanes of
     return __hiloint2double(hsel ? r1[1] : r1[0], hsel ? r0[1] : r0[0]);
 }
 
-// Cholesky of a symmetric 32 x 32 tile in one wavefront: lane = (row i = lane & 31, parity h = lane >> 5) holds
-// a[q] = A[i][2q + h].  Column j lives in register j/2 of the lanes of parity j%2; by symmetry it is also row j, so
-// one ds_write publishes what every lane needs for its rank-1 update; the LDS copy is de-interleaved
-// (slot(c) = (c&1)*16 + c/2) so that each parity reads its own columns as aligned pairs.  The pivot, A[j+1][j] and
-// A[j+2][j] come from v_readlane and the multiplier crosses the halves with v_permlane32_swap, so the dependent chain
-// never waits on LDS.  colbuf: 64 doubles, sc: 32 doubles.  On return a[q] = L[i][2q+h] where 2q+h <= i.
-__device__ __forceinline__ bool potrf32_w64(double* a, int lane, double* colbuf, double* sc) {
+// Look-ahead factorisation of a 32 x 32 tile by one workgroup, as a pipeline of wavefronts over LDS.
+// With A = Lu D Lu^T (Lu unit lower, D = diag(pivots)) the Cholesky factor is L = Lu D^1/2 and L^-1 = D^-1/2 Lu^-1:
+//   wave 0  the pivot chain.  Lane = (row i = lane & 31, parity h = lane >> 5) holds a[q] = A[i][2q + h].  Column j
+//           lives in register j/2 of the lanes of parity j%2; by symmetry it is also row j, so one ds_write publishes
+//           what every lane needs for its rank-1 update.  The LDS copy is de-interleaved (slot(c) = (c&1)*16 + c/2) so
+//           each parity reads its own columns as aligned pairs, and every column keeps its own 32 slots: after the
+//           sweep cols[j][slot(r)] = Lu[r][j] * pivot_j.  Pivot, A[j+1][j] and A[j+2][j] come from v_readlane and
+//           the multiplier crosses the halves with v_permlane32_swap: the dependent chain never waits on LDS.  The
+//           multipliers themselves are column j of Lu: they are stored (lu) and flagged for the other waves.
+//   wave 1  Lu11^-1 by column-oriented substitution, a step per flagged column, then Mu = Lu21 Lu11^-1 (matrix cores)
+//   wave 3  Lu22^-1 the same way (in lock-step with columns 16..31), Wu = -Lu22^-1 Mu, then the row scaling D^-1/2;
+//           a few hundred cycles after the last pivot L^-1 is on its way to global memory for the next launch
+//   wave 2  1/sqrt(pivot) for every pivot as it appears (a lane per pivot), L into Lfac, pivot check (<= 0 or NaN
+//           clears solver_ok).
+// Cross-wave hand-off is by relaxed atomic LDS stores/loads only: a wave's LDS operations execute in order, so a flag
+// written after the data is seen after the data, and the compiler keeps atomics in program order.  No fences, no
+// s_waitcnt on the pivot chain.
+__device__ __forceinline__ int slot32(int c) { return ((c & 1) << 4) | (c >> 1); }
+__device__ __forceinline__ double fast_rsqrt(double d) {          // v_rsq_f64 + two Newton steps
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * fma(-0.5 * d * y, y, 1.5);
+    y = y * fma(-0.5 * d * y, y, 1.5);
+    return y;
+}
+// relaxed workgroup-scope atomics: emitted in program order (ordered memory references for the scheduler) but, unlike
+// volatile accesses, without an s_waitcnt after each one
+template <typename T> __device__ __forceinline__ void vstore(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <typename T> __device__ __forceinline__ T vload(const T* p) { return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+constexpr int SPIN_LIMIT = 1 << 18;     // never hang on a logic error: give up, the result is flagged as a failed solve
+
+struct Look32 {            // LDS of the look-ahead pipeline
+    double cols[32 * 32];  // cols[j][slot(r)] = A(j)[r][j]
+    double lu[32 * 32];    // lu[j][slot(r)] = Lu[r][j]
+    double sInv[32 * LS];  // Lu^-1 diagonal blocks (operand staging)
+    double sM[256];        // Mu in MFMA B-operand order
+    double pivd[32];
+    double rs[32];         // 1 / sqrt(pivot)
+    int flag[32];          // column j of lu and pivd[j] are valid
+    int rsflag[32];
+    int mflag;
+    int fail;
+};
+
+__device__ __forceinline__ void potrf32_stream(double* a, int lane, Look32& S) {
     const int i = lane & 31, h = lane >> 5;
-    const int pos = ((i & 1) << 4) | (i >> 1);
-    bool bad = false;
-    if (h == 0) colbuf[pos] = a[0];
+    const int pos = slot32(i);
+    if (h == 0) S.cols[pos] = a[0];
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const int qj = j >> 1, hj = j & 1;
-        const double* buf = colbuf + (j & 1) * 32;
-        double* nbuf = colbuf + ((j + 1) & 1) * 32;
+        const double* buf = S.cols + j * 32;
+        double* nbuf = S.cols + (j + 1) * 32;
         const double sj = bcast_lane(a[qj], j + 32 * hj);
-        const bool bj = !(sj > 0.0);
-        bad = bad || bj;
-        const double f = bcast_half(a[qj] * fast_rcp(bj ? 1.0 : sj), hj);
+        const double f = bcast_half(a[qj] * fast_rcp(sj), hj);      // Lu[i][j], valid in both halves
         if (j + 1 < 32) {
             const int q1 = (j + 1) >> 1;
             const double s1 = bcast_lane(a[qj], j + 1 + 32 * hj);
             if (hj == 0) {          // column j+1 is register qj of parity 1
-                if (h == 1) { a[q1] = fma(-f, s1, a[q1]); nbuf[pos] = a[q1]; }
+                if (h == 1) { a[q1] = fma(-f, s1, a[q1]); nbuf[pos] = a[q1]; vstore(&S.lu[j * 32 + pos], f); }
             } else {                // register qj+1: column j+1 (parity 0) and column j+2 (parity 1)
                 const double s2 = (j + 2 < 32) ? bcast_lane(a[qj], j + 2 + 32 * hj) : 0.0;
                 a[q1] = fma(-f, h == 0 ? s1 : s2, a[q1]);
-                if (h == 0) nbuf[pos] = a[q1];
+                if (h == 0) { nbuf[pos] = a[q1]; vstore(&S.lu[j * 32 + pos], f); }
             }
         }
+        vstore(&S.pivd[j], sj);
+        vstore(&S.flag[j], 1);
         {   // bulk: registers qs..15 of both parities from the LDS copy of column j
             const int qs = hj == 0 ? qj + 1 : qj + 2;
             const double2* b2 = reinterpret_cast<const double2*>(buf + h * 16);
@@ -364,90 +400,164 @@ __device__ __forceinline__ bool potrf32_w64(double* a, int lane, double* colbuf,
             }
         }
     }
-    // L[i][c] = a / sqrt(pivot_c); pivot_c is the diagonal entry left by the sweep, held by lane (c, c & 1)
-    double dg = 1.0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) if ((i >> 1) == q) dg = a[q];
-    if (h == (i & 1)) sc[pos] = 1.0 / sqrt(dg > 0.0 ? dg : 1.0);
-    const double2* s2 = reinterpret_cast<const double2*>(sc + h * 16);
-#pragma unroll
-    for (int q2 = 0; q2 < 8; ++q2) { const double2 v = s2[q2]; a[2 * q2] *= v.x; a[2 * q2 + 1] *= v.y; }
-    return bad;
 }
 
-// L^-1 of the tile potrf32_w64 left in registers (sc[slot(c)] = 1 / L[c][c]).  Leaves sLT[c][i] = L[i][c] and
-// sInv[r][c] = (L^-1)[r][c] in LDS (row stride LS).
-__device__ __forceinline__ void inv32_inwave(const double* a, int lane, double* sLT, double* sInv, const double* sc) {
-    const int i = lane & 31, h = lane >> 5;
+// One 16 x 16 diagonal block (block B) of Lu^-1: a substitution step per column as wave 0 flags it.  The flag and
+// the column are read in one batch (flag first: LDS returns in order), so a ready column costs a single LDS latency.
+// x[t] = (Lu^-1)[16 B + t][16 B + (lane & 15)].
+template <int B>
+__device__ __forceinline__ void inv16_follow(Look32& S, double* x, int lane) {
+    const int cc = lane & 15;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { const int c = 2 * q + h; sLT[c * LS + i] = (c <= i) ? a[q] : 0.0; }
-    if (lane < 32) {
-        // the two 16 x 16 diagonal inverses: lane = (block b, column cc), column-oriented forward substitution
-        const int b = lane >> 4, cc = lane & 15;
-        double x[16];
+    for (int t = 0; t < 16; ++t) x[t] = (t == cc) ? 1.0 : 0.0;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) x[t] = (t == cc) ? 1.0 : 0.0;
-        const double* Lb = sLT + (16 * b) * LS + 16 * b;     // Lb[j * LS + t] = L_b[t][j]
-        const double* scb = sc + 8 * b;                      // slot(16 b + j) = (j & 1) * 16 + 8 b + j / 2
+    for (int j = 0; j < 15; ++j) {
+        const int J = 16 * B + j;
+        const double* u = S.lu + J * 32 + 8 * B;
+        double uv[16];
+        int spins = 0;
+        while (true) {
+            const int fl = vload(&S.flag[J]);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            x[j] *= scb[((j & 1) << 4) + (j >> 1)];
-            const double xj = x[j];
-            const double2* r2 = reinterpret_cast<const double2*>(Lb + j * LS);
+            for (int t = j + 1; t < 16; ++t) uv[t] = vload(&u[((t & 1) << 4) + (t >> 1)]);
+            if (fl) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { vstore(&S.fail, 1); break; }
+        }
+        const double m = x[j];
 #pragma unroll
-            for (int t2 = (j + 1) / 2; t2 < 8; ++t2) {
-                const double2 v = r2[t2];
-                if (2 * t2 >= j + 1) x[2 * t2] = fma(-xj, v.x, x[2 * t2]);
-                x[2 * t2 + 1] = fma(-xj, v.y, x[2 * t2 + 1]);
+        for (int t = j + 1; t < 16; ++t) x[t] = fma(-m, uv[t], x[t]);
+    }
+}
+// every lane waits for rs[base + (lane & 15)]; afterwards all 16 values of the block are readable
+__device__ __forceinline__ void wait_rs16(Look32& S, int base, int lane) {
+    int spins = 0;
+    while (!vload(&S.rsflag[base + (lane & 15)])) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > SPIN_LIMIT) { vstore(&S.fail, 1); break; }
+    }
+    asm volatile("" ::: "memory");     // plain loads of S.rs below this point stay below it
+}
+
+#ifdef PLBA_STAMPS
+__device__ unsigned long long g_lstamp[32];
+#define LSTAMP(i) do { if (lane == 0) g_lstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LSTAMP(i) do {} while (0)
+#endif
+// tile in sC (row stride LS, complete and visible: call after a barrier that also saw S.flag / rsflag / mflag / fail
+// zeroed); all four waves enter.
+__device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, const double* sC, Look32& S, int wv, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    double* Ig = d.Linv32 + (size_t)kb * 1024;
+    if (wv == 0) {
+        const int i = lane & 31, h = lane >> 5;
+        double a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = sC[i * LS + 2 * q + h];
+        LSTAMP(0);
+        potrf32_stream(a, lane, S);
+        LSTAMP(1);
+    } else if (wv == 2) {
+        LSTAMP(8);
+        const int j = lane & 31;
+        bool done = false, bad = false;
+        int spins = 0;
+        while (!__all(done)) {
+            if (!done && vload(&S.flag[j])) {
+                const double pv = vload(&S.pivd[j]);
+                bad = !(pv > 0.0);
+                vstore(&S.rs[j], fast_rsqrt(bad ? 1.0 : pv));
+                vstore(&S.rsflag[j], 1);
+                done = true;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { bad = true; break; }
+        }
+        LSTAMP(10);
+        asm volatile("" ::: "memory");
+        double* Lg = d.Lfac + (size_t)(kb * 32) * d.ld + kb * 32;
+        {
+            const int cl = lane & 31;
+            const double rsc = S.rs[cl];
+            const double* cc = S.cols + cl * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rw = 2 * e + (lane >> 5);
+                Lg[(size_t)rw * d.ld + cl] = (cl <= rw) ? cc[slot32(rw)] * rsc : 0.0;
             }
         }
+        if ((__any(bad) || S.fail) && lane == 0) d.ctrl->solver_ok = 0;
+        LSTAMP(11);
+    } else if (wv == 1) {
+        LSTAMP(4);
+        double x[16];
+        inv16_follow<0>(S, x, lane);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) sInv[(16 * b + t) * LS + 16 * b + cc] = x[t];
+        for (int t = 0; t < 16; ++t) S.sInv[t * LS + li] = x[t];
+        LSTAMP(5);
+        // Mu = Lu21 Lu11^-1 lands in the C/D layout (col = lane & 15, row = (lane >> 4) + 4 v), which is exactly a
+        // B operand of wave 3's product when its k index is enumerated as (lane >> 4) + 4 v
+        double4v m = (double4v){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const int idx = e * 32 + lane; sInv[(idx >> 4) * LS + 16 + (idx & 15)] = 0.0; }
+        for (int s = 0; s < 4; ++s) {
+            const int t = 4 * s + lk;
+            m = __builtin_amdgcn_mfma_f64_16x16x4f64(vload(&S.lu[t * 32 + ((li & 1) << 4) + 8 + (li >> 1)]), S.sInv[t * LS + li], m, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) S.sM[v * 64 + lane] = m[v];
+        asm volatile("" ::: "memory");
+        vstore(&S.mflag, 1);
+        LSTAMP(6);
+        wait_rs16(S, 0, lane);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {      // rows 0-15 of L^-1: [D1^-1/2 Lu11^-1 | 0]
+            const int idx = e * 64 + lane, rw = idx >> 5, cl = idx & 31;
+            Ig[idx] = (cl < 16) ? S.sInv[rw * LS + cl] * S.rs[rw] : 0.0;
+        }
+        LSTAMP(7);
+    } else {
+        double x[16];
+        inv16_follow<1>(S, x, lane);
+        LSTAMP(12);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) S.sInv[(16 + t) * LS + 16 + li] = x[t];
+        int spins = 0;
+        while (!vload(&S.mflag)) { __builtin_amdgcn_s_sleep(1); if (++spins > SPIN_LIMIT) { vstore(&S.fail, 1); break; } }
+        asm volatile("" ::: "memory");
+        double4v w = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) w = __builtin_amdgcn_mfma_f64_16x16x4f64(S.sInv[(16 + li) * LS + 16 + lk + 4 * v], S.sM[v * 64 + lane], w, 0, 0, 0);
+        LSTAMP(13);
+        wait_rs16(S, 16, lane);
+        // rows 16-31 of L^-1 = D2^-1/2 [ -Lu22^-1 Mu | Lu22^-1 ], straight from the registers
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Ig[(16 + lk + 4 * v) * 32 + li] = -w[v] * S.rs[16 + lk + 4 * v];
+        if (lane < 16) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) Ig[(16 + t) * 32 + 16 + li] = x[t] * S.rs[16 + t];
+        }
+        LSTAMP(14);
     }
-    // lower-left block: -I22 (L21 I11).  The first product lands in the C/D layout (col = lane & 15, row = (lane >> 4) + 4 v),
-    // which is exactly a B operand of the second when its k index is enumerated as (lane >> 4) + 4 v.
-    const int li = lane & 15, lk = lane >> 4;
-    double4v m = (double4v){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) m = __builtin_amdgcn_mfma_f64_16x16x4f64(sLT[(4 * s + lk) * LS + 16 + li], sInv[(4 * s + lk) * LS + li], m, 0, 0, 0);
-    double4v w = (double4v){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int v = 0; v < 4; ++v) w = __builtin_amdgcn_mfma_f64_16x16x4f64(sInv[(16 + li) * LS + 16 + lk + 4 * v], m[v], w, 0, 0, 0);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) sInv[(16 + lk + 4 * v) * LS + li] = -w[v];
+}
+__device__ __forceinline__ void look32_reset(Look32& S, int tid) {
+    if (tid < 32) { S.flag[tid] = 0; S.rsflag[tid] = 0; }
+    if (tid == 32) { S.mflag = 0; S.fail = 0; }
 }
 
-// factor + invert diagonal block kb (tile already in registers) and publish L(kb,kb) (into Lfac) and L(kb,kb)^-1
-__device__ __forceinline__ void factor_diag32(const DevBuf& d, int kb, double* a, int lane, double* sLT, double* sInv, double* colbuf, double* sc) {
-    const bool bad = potrf32_w64(a, lane, colbuf, sc);
-    inv32_inwave(a, lane, sLT, sInv, sc);
-    double* Ig = d.Linv32 + (size_t)kb * 1024;
-    double* Lg = d.Lfac + (size_t)(kb * 32) * d.ld + kb * 32;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int idx = e * 64 + lane, rw = idx >> 5, cl = idx & 31;
-        Ig[idx] = sInv[rw * LS + cl];
-        Lg[(size_t)rw * d.ld + cl] = sLT[cl * LS + rw];
-    }
-    if (bad && lane == 0) d.ctrl->solver_ok = 0;
-}
-
-__global__ __launch_bounds__(64) void k_potrf0_32(DevBuf d) {
-    __shared__ __attribute__((aligned(16))) double sLT[32 * LS], sInv[32 * LS], colbuf[64], sc[32];
-    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
-    double a[16];
-    const double* row = d.sys + (size_t)i * d.ld + h;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) a[q] = row[2 * q];
-    factor_diag32(d, 0, a, lane, sLT, sInv, colbuf, sc);
+__global__ __launch_bounds__(256) void k_potrf0_32(DevBuf d) {
+    __shared__ __attribute__((aligned(16))) double sC[32 * LS];
+    __shared__ __attribute__((aligned(16))) Look32 S;
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) sC[(idx >> 5) * LS + (idx & 31)] = d.sys[(size_t)(idx >> 5) * d.ld + (idx & 31)];
+    look32_reset(S, threadIdx.x);
+    __syncthreads();
+    lookahead_factor32(d, 0, sC, S, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
 __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
     __shared__ __attribute__((aligned(16))) double sX[64 * LS];      // rows [0,32) = X_r, [32,64) = X_c, [row][k]
     __shared__ __attribute__((aligned(16))) double sC[32 * LS];      // look-ahead tile
-    __shared__ __attribute__((aligned(16))) double sLT[32 * LS], sInv[32 * LS], colbuf[64], sc[32];
+    __shared__ __attribute__((aligned(16))) Look32 S;
     const int ld = d.ld;
     const int nt = T - k - 1;
     const int b = blockIdx.x;
@@ -467,7 +577,7 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
     const bool diag = (r == c);
 #ifdef PLBA_STAMPS
     unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
-#define STAMP32(i) do { if (blockIdx.x == 0 && k == 5 && wv == 0) ts[i] = __builtin_readcyclecounter(); } while (0)
+#define STAMP32(i) do { if (blockIdx.x == 0 && k == 5) ts[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define STAMP32(i) do {} while (0)
 #endif
@@ -532,25 +642,16 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
         }
     }
     if (!lookahead) return;
+    look32_reset(S, threadIdx.x);
     __syncthreads();
     STAMP32(2);
-    if (wv == 0) {
-        const int i = lane & 31, h = lane >> 5;
-        double a[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) a[q] = sC[i * LS + 2 * q + h];
-        STAMP32(3);
+    lookahead_factor32(d, k + 1, sC, S, wv, lane);
+    STAMP32(3);
 #ifdef PLBA_STAMPS
-        const bool bad = potrf32_w64(a, lane, colbuf, sc);
-        STAMP32(4);
-        inv32_inwave(a, lane, sLT, sInv, sc);
-        STAMP32(5);
-        (void)bad;
-        if (lane == 0) for (int q = 0; q < 7; ++q) d.maxd_part[q] = (double)(ts[q] - ts[0]);
-#else
-        factor_diag32(d, k + 1, a, lane, sLT, sInv, colbuf, sc);
+    if (lane == 0 && blockIdx.x == 0 && k == 5) for (int q = 0; q < 4; ++q) d.maxd_part[4 * wv + q] = (double)(ts[q] - ts[0]);
+    __syncthreads();
+    if (threadIdx.x < 16 && blockIdx.x == 0 && k == 5) d.maxd_part[16 + threadIdx.x] = (double)(long long)(g_lstamp[threadIdx.x] - ts[0]);
 #endif
-    }
 }
 
 // Linv[k] (64 x 64, for the back-substitution) from the 32 x 32 inverses the factorisation published:
@@ -747,7 +848,7 @@ static bool inverse_panels(const DevBuf& d, bool use_mfma) { return d.fb == 32 &
 void launch_cholesky(const DevBuf& d, bool use_mfma, hipStream_t s) {
     if (inverse_panels(d, use_mfma)) {
         const int T = d.Ppad / 32;
-        hipLaunchKernelGGL(k_potrf0_32, dim3(1), dim3(64), 0, s, d);
+        hipLaunchKernelGGL(k_potrf0_32, dim3(1), dim3(256), 0, s, d);
         for (int k = 0; k < T; ++k) {
             const int nt = T - k - 1;
             const int tiles = nt * (nt + 1) / 2 + nt;

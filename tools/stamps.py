@@ -7,7 +7,9 @@ g = pkg.new_problem(); g.upload_window(w)
 g.debug_build(100.0, True)
 g.debug_build(100.0, True)
 st = g.debug_get("stamps")
-names = ["start", "LT/x loaded+barrier", "trsm+XT write+barrier", "mfma+C rmw+barrier", "sC->regs", "potrf", "store_factor"]
-print("cycle stamps (100 MHz s_memtime ticks? or shader clock):", st[:7])
-for i in range(1, 7):
-    print("%-28s %8.0f" % (names[i], st[i] - st[i - 1]))
+st = g.debug_get("stamps")
+print("per wave: [start, panel products+barrier, update+barrier, look-ahead end] (cycles)")
+for w in range(4):
+    print("wave", w, st[4 * w:4 * w + 4])
+names = {0: "w0 start", 1: "w0 potrf end", 4: "w1 start", 5: "w1 I11 done", 6: "w1 M published", 7: "w1 end", 8: "w2 start", 10: "w2 all rs out", 11: "w2 end", 12: "w3 subst done", 13: "w3 Wu done", 14: "w3 end"}
+for i in sorted(names): print("%-18s %8.0f" % (names[i], st[16 + i]))
