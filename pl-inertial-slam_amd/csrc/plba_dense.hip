@@ -352,14 +352,15 @@ template <typename T> __device__ __forceinline__ void vstore(T* p, T v) { __hip_
 template <typename T> __device__ __forceinline__ T vload(const T* p) { return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 constexpr int SPIN_LIMIT = 1 << 18;     // never hang on a logic error: give up, the result is flagged as a failed solve
 
+__device__ __forceinline__ double piv_empty() { return __longlong_as_double(-1ll); }    // a NaN no computation produces
+__device__ __forceinline__ bool published(double v) { return __double_as_longlong(v) != -1ll; }
 struct Look32 {            // LDS of the look-ahead pipeline
     double cols[32 * 32];  // cols[j][slot(r)] = A(j)[r][j]
     double lu[32 * 32];    // lu[j][slot(r)] = Lu[r][j]
     double sInv[32 * LS];  // Lu^-1 diagonal blocks (operand staging)
     double sM[256];        // Mu in MFMA B-operand order
-    double pivd[32];
+    double pivd[32];       // pivot j; written last, so it doubles as "column j of lu is valid"
     double rs[32];         // 1 / sqrt(pivot)
-    int flag[32];          // column j of lu and pivd[j] are valid
     int rsflag[32];
     int mflag;
     int fail;
@@ -369,16 +370,23 @@ __device__ __forceinline__ void potrf32_stream(double* a, int lane, Look32& S) {
     const int i = lane & 31, h = lane >> 5;
     const int pos = slot32(i);
     if (h == 0) S.cols[pos] = a[0];
+    // The pivots run ahead of the matrix on a uniform (all lanes redundant) recurrence,
+    //   pivot_{j+1} = A[j+1][j+1] - A[j+1][j]^2 / pivot_j,
+    // whose inputs are read (v_readlane) BEFORE step j's multipliers exist: the dependent chain per column is
+    // rcp + 2 fma, and the multiplier broadcast, the rank-1 update and all LDS traffic hang off it with slack.
+    double sj = bcast_lane(a[0], 0);
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const int qj = j >> 1, hj = j & 1;
         const double* buf = S.cols + j * 32;
         double* nbuf = S.cols + (j + 1) * 32;
-        const double sj = bcast_lane(a[qj], j + 32 * hj);
-        const double f = bcast_half(a[qj] * fast_rcp(sj), hj);      // Lu[i][j], valid in both halves
+        const double rj = fast_rcp(sj);
+        const double pj = sj;
+        const double s1 = (j + 1 < 32) ? bcast_lane(a[qj], j + 1 + 32 * hj) : 0.0;                       // A[j+1][j]
+        if (j + 1 < 32) sj = fma(-(s1 * rj), s1, bcast_lane(a[(j + 1) >> 1], j + 1 + 32 * ((j + 1) & 1)));   // next pivot
+        const double f = bcast_half(a[qj] * rj, hj);      // Lu[i][j], valid in both halves
         if (j + 1 < 32) {
             const int q1 = (j + 1) >> 1;
-            const double s1 = bcast_lane(a[qj], j + 1 + 32 * hj);
             if (hj == 0) {          // column j+1 is register qj of parity 1
                 if (h == 1) { a[q1] = fma(-f, s1, a[q1]); nbuf[pos] = a[q1]; vstore(&S.lu[j * 32 + pos], f); }
             } else {                // register qj+1: column j+1 (parity 0) and column j+2 (parity 1)
@@ -387,8 +395,7 @@ __device__ __forceinline__ void potrf32_stream(double* a, int lane, Look32& S) {
                 if (h == 0) { nbuf[pos] = a[q1]; vstore(&S.lu[j * 32 + pos], f); }
             }
         }
-        vstore(&S.pivd[j], sj);
-        vstore(&S.flag[j], 1);
+        vstore(&S.pivd[j], pj);      // also the "column j is published" flag (reset value: PIV_EMPTY bits)
         {   // bulk: registers qs..15 of both parities from the LDS copy of column j
             const int qs = hj == 0 ? qj + 1 : qj + 2;
             const double2* b2 = reinterpret_cast<const double2*>(buf + h * 16);
@@ -417,7 +424,7 @@ __device__ __forceinline__ void inv16_follow(Look32& S, double* x, int lane) {
         double uv[16];
         int spins = 0;
         while (true) {
-            const int fl = vload(&S.flag[J]);
+            const bool fl = published(vload(&S.pivd[J]));
 #pragma unroll
             for (int t = j + 1; t < 16; ++t) uv[t] = vload(&u[((t & 1) << 4) + (t >> 1)]);
             if (fl) break;
@@ -445,8 +452,8 @@ __device__ unsigned long long g_lstamp[32];
 #else
 #define LSTAMP(i) do {} while (0)
 #endif
-// tile in sC (row stride LS, complete and visible: call after a barrier that also saw S.flag / rsflag / mflag / fail
-// zeroed); all four waves enter.
+// tile in sC (row stride LS, complete and visible: call after a barrier that also saw S.pivd / rsflag / mflag / fail
+// reset by look32_reset); all four waves enter.
 __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, const double* sC, Look32& S, int wv, int lane) {
     const int li = lane & 15, lk = lane >> 4;
     double* Ig = d.Linv32 + (size_t)kb * 1024;
@@ -464,8 +471,8 @@ __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, cons
         bool done = false, bad = false;
         int spins = 0;
         while (!__all(done)) {
-            if (!done && vload(&S.flag[j])) {
-                const double pv = vload(&S.pivd[j]);
+            const double pv = vload(&S.pivd[j]);
+            if (!done && published(pv)) {
                 bad = !(pv > 0.0);
                 vstore(&S.rs[j], fast_rsqrt(bad ? 1.0 : pv));
                 vstore(&S.rsflag[j], 1);
@@ -476,15 +483,14 @@ __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, cons
         }
         LSTAMP(10);
         asm volatile("" ::: "memory");
-        double* Lg = d.Lfac + (size_t)(kb * 32) * d.ld + kb * 32;
-        {
-            const int cl = lane & 31;
+        {   // columns 16-31 of L (rows 16-31; wave 1 wrote the left half)
+            double* Lg = d.Lfac + (size_t)(kb * 32) * d.ld + kb * 32;
+            const int cl = 16 + li;
             const double rsc = S.rs[cl];
-            const double* cc = S.cols + cl * 32;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int rw = 2 * e + (lane >> 5);
-                Lg[(size_t)rw * d.ld + cl] = (cl <= rw) ? cc[slot32(rw)] * rsc : 0.0;
+            for (int e = 0; e < 4; ++e) {
+                const int rw = 16 + 4 * e + lk;
+                Lg[(size_t)rw * d.ld + cl] = (cl <= rw) ? S.cols[cl * 32 + slot32(rw)] * rsc : 0.0;
             }
         }
         if ((__any(bad) || S.fail) && lane == 0) d.ctrl->solver_ok = 0;
@@ -515,6 +521,16 @@ __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, cons
             const int idx = e * 64 + lane, rw = idx >> 5, cl = idx & 31;
             Ig[idx] = (cl < 16) ? S.sInv[rw * LS + cl] * S.rs[rw] : 0.0;
         }
+        {   // columns 0-15 of L (all rows) and the zero block above the diagonal
+            double* Lg = d.Lfac + (size_t)(kb * 32) * d.ld + kb * 32;
+            const double rsc = S.rs[li];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int rw = 4 * e + lk;
+                Lg[(size_t)rw * d.ld + li] = (li <= rw) ? S.cols[li * 32 + slot32(rw)] * rsc : 0.0;
+                if (rw < 16) Lg[(size_t)rw * d.ld + 16 + li] = 0.0;
+            }
+        }
         LSTAMP(7);
     } else {
         double x[16];
@@ -541,7 +557,7 @@ __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, cons
     }
 }
 __device__ __forceinline__ void look32_reset(Look32& S, int tid) {
-    if (tid < 32) { S.flag[tid] = 0; S.rsflag[tid] = 0; }
+    if (tid < 32) { S.pivd[tid] = piv_empty(); S.rsflag[tid] = 0; }
     if (tid == 32) { S.mflag = 0; S.fail = 0; }
 }
 
