@@ -38,6 +38,20 @@ def stage1_and_gate(prob, pkg):
     prob.save_state()
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r01_pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied); None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        ks = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for name, v in ks.items():
+        if kernel_prefix in name and "traffic_bytes_per_launch" in v:
+            return v["traffic_bytes_per_launch"]
+    return None
+
+
 def run_iterations(prob, n_iters, per_call=10):
     """Replay stage 2 from the saved state until exactly n_iters LM iterations ran."""
     done, trials, phases = 0, 0, np.zeros(8)
@@ -122,6 +136,8 @@ def main():
     w = win.shard_window(w_full, rank, world) if world > 1 else w_full
 
     stream = torch.cuda.Stream()
+    # profile=1: two HIP events per LM trial (on the stream the kernels run on) bracket the dense factorisation launches,
+    # the dominant kernel; the full per-phase table comes from a second, untimed problem below
     prob = pkg.new_problem(profile=1, **({"factor_block": args.fb} if args.fb else {}))
     prob.set_stream(stream.cuda_stream)
     prob.upload_window(w)
@@ -152,21 +168,35 @@ def main():
     # algorithmic bytes: 32 B per point observation, 40 B per line observation, landmarks 24 / 48 B
     bytes_lin = 32 * Ep + 40 * El + 24 * Npl + 48 * Nll                 # one k_linearize launch
     b_iter = 2 * (32 * Ep + 40 * El) + 3 * (24 * Npl + 48 * Nll)        # one LM iteration
-    lin_ms = phases[0] / max(done, 1)
-    solve_ms = phases[3] / max(trials, 1)
     P = int(prob.debug_get("pose_dim")[0])
-    flops_solve = P ** 3 / 3.0 + 2.0 * P * P
-    phase_names = ["linearize_kernel", "pose_edges", "schur", "dense_solve", "backsub_update", "trial_errors", "exchange", "landmark_blocks_and_reductions"]
-    per_iter = {k: float(v / max(done, 1)) for k, v in zip(phase_names, phases)}
-    dominant = max(per_iter, key=per_iter.get)
-    roof_hbm = dict(bound="hbm", kernel="k_linearize<true>", achieved=bytes_lin / (lin_ms * 1e-3) / 1e9 if lin_ms > 0 else None,
+    fb = args.fb if args.fb else 32
+    n_fact_launches = ((P + 63) // 64) * 64 // fb + 1                    # first-block launch + one per block step
+    flops_fact = P ** 3 / 3.0 + P * P                                    # LL^T of the P x P system + the forward solve riding along
+    fact_ms = phases[1] / max(trials, 1) / n_fact_launches               # live: HIP events over the timed region
+    # second, untimed pass with every phase bracketed (profile=2): phase table + the HBM-bound kernel's launch time
+    prob2 = pkg.new_problem(profile=2, **({"factor_block": args.fb} if args.fb else {}))
+    prob2.set_stream(stream.cuda_stream)
+    prob2.upload_window(w)
+    if world > 1:
+        prob2.set_shard(rank, world, pkg.distributed.make_allreduce(dist, local_rank, stream))
+    stage1_and_gate(prob2, pkg)
+    done2, trials2, phases2 = run_iterations(prob2, min(args.steps, 50))
+    sync()
+    prob2.close()
+    lin_ms = phases2[0] / max(done2, 1)
+    phase_names = ["linearize_launch", "factorisation_launches", "schur", "dense_solve", "backsub_update", "trial_errors", "exchange", "landmark_blocks_and_reductions"]
+    per_iter = {k: float(v / max(done2, 1)) for k, v in zip(phase_names, phases2)}
+    roof_hbm = dict(bound="hbm", kernel="k_linearize<true> (observation pass; IMU / prior edge blocks ride in the same launch)",
+                    achieved=bytes_lin / (lin_ms * 1e-3) / 1e9 if lin_ms > 0 else None,
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=(bytes_lin / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lin_ms > 0 else None,
-                    traffic=None, algorithmic_bytes_per_launch=bytes_lin, avg_launch_ms=lin_ms)
-    roof_mfma = dict(bound="mfma", kernel="dense solve: k_chol_diag + k_chol_step<MFMA> + k_trsv_back (P=%d)" % P,
-                     achieved=flops_solve / (solve_ms * 1e-3) / 1e12 if solve_ms > 0 else None, peak=FP64_MFMA_PEAK_TFLOPS,
-                     unit="TFLOP/s", frac=(flops_solve / (solve_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS) if solve_ms > 0 else None,
-                     traffic=None, algorithmic_flops_per_launch=flops_solve, avg_launch_ms=solve_ms)
-    roofline = roof_mfma if dominant == "dense_solve" else roof_hbm
+                    traffic=pmc_traffic("k_linearize<true>"), algorithmic_bytes_per_launch=bytes_lin, avg_launch_ms=lin_ms)
+    kname = "k_chol32" if fb == 32 else "k_chol_step"
+    ach = flops_fact / n_fact_launches / (fact_ms * 1e-3) / 1e12 if fact_ms > 0 else None
+    roof_mfma = dict(bound="mfma", kernel="%s: one block step of the dense fp64 LL^T of the reduced camera system (P=%d, %d launches per solve)" % (kname, P, n_fact_launches),
+                     achieved=ach, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=(ach / FP64_MFMA_PEAK_TFLOPS) if ach else None,
+                     traffic=pmc_traffic(kname), algorithmic_flops_per_launch=flops_fact / n_fact_launches, avg_launch_ms=fact_ms)
+    # the factorisation launches are the largest single consumer of an iteration (profiles/r01_*_kernel_stats.csv)
+    roofline = roof_mfma
 
     out = {
         "metric": "local-BA iterations/sec (50 KF, 20k pts, 4k lines, IMU)",
@@ -180,7 +210,6 @@ def main():
                    "hbm_frac_whole_iteration": b_iter / (dt / done) / 1e9 / HBM_PEAK_GBS},
         "roofline": roofline,
         "roofline_hbm_kernel": roof_hbm,
-        "roofline_dense_solve": roof_mfma,
         "phase_ms_per_iteration": per_iter,
     }
     if world == 1:

@@ -60,7 +60,8 @@ typedef struct {
     int    whiten_marg_factors; /* 0 = reproduce IMU/marginalization.cpp:67 (SURVEY B-Q4)     */
     int    device;              /* HIP device ordinal, -1 = current device            (-1)    */
     int    use_mfma;            /* 1 = fp64 MFMA trailing update in the dense solve    (1)    */
-    int    profile;             /* 1 = HIP-event timing of the phases into plba_stats.ms_phase (0) */
+    int    profile;             /* HIP-event timing into plba_stats.ms_phase: 1 = the dense factorisation launches only
+                                   (two events per trial), 2 = every phase (0 = off)            */
     int    factor_block;        /* block width of the dense factorisation: 32 or 64                (32)   */
     int    reserved[4];
 } plba_options;
@@ -77,8 +78,9 @@ typedef struct {
     double chi2_final;          /* activeRobustChi2 of the state left in the problem            */
     double lambda_final;
     double ms_total;            /* wall time of this call, device-synchronised                  */
-    double ms_phase[8];         /* device ms by HIP events when options.profile: [0] linearize kernel (jac), [1] pose-side edges,
-                                   [2] landmark inverse + assemble + Schur pairs, [3] dense solve (Cholesky + back-substitution),
+    double ms_phase[8];         /* device ms by HIP events when options.profile: [0] linearize launch (observations + IMU / prior
+                                   edges, Jacobians), [1] the dense factorisation launches alone (first-block launch + one per block
+                                   step; profile >= 1), [2] landmark inverse + assemble + Schur pairs, [3] dense solve (factorisation + back-substitution),
                                    [4] landmark back-substitution + state update, [5] trial error pass, [6] exchange, [7] landmark Hll + reductions */
 } plba_stats;
 

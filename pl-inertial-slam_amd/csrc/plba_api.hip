@@ -483,7 +483,8 @@ static LmParams lm_params(const plba_problem* p) {
 }
 
 // computeActiveErrors + buildSystem for the current estimate (everything lambda-independent)
-#define MARK(p, i) do { if ((p)->opt.profile) HIPCK(p, hipEventRecord((p)->ev[i], (p)->stream)); } while (0)
+#define MARK(p, i) do { if ((p)->opt.profile >= 2) HIPCK(p, hipEventRecord((p)->ev[i], (p)->stream)); } while (0)
+#define MARKF(p, i) do { if ((p)->opt.profile >= 1) HIPCK(p, hipEventRecord((p)->ev[i], (p)->stream)); } while (0)
 static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
     const DevBuf& d = p->dv;
     hipStream_t s = p->stream;
@@ -493,7 +494,6 @@ static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
     }
     MARK(p, 0);
     launch_linearize(d, p->cur, true, p->rob, owns_pose_edges(p), s);   // observations + IMU / prior edges, one launch
-    MARK(p, 1);
     MARK(p, 2);
     launch_landmark_hll(d, p->cur, !first_iter, s);
     if (first_iter) {
@@ -529,7 +529,9 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
     }
     MARK(p, 6);
     if (!do_solve) return PLBA_OK;
+    MARKF(p, 11);
     launch_cholesky(d, p->opt.use_mfma != 0, s);
+    MARKF(p, 12);
     launch_trsv_back(d, p->opt.use_mfma != 0, ++p->flow_epoch, s);
     MARK(p, 7);
     launch_backsub(d, p->cur, p->cur ^ 1, s);
@@ -581,8 +583,9 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             MARK(p, 10);
             HIPCK(p, hipMemcpyAsync(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
             HIPCK(p, hipStreamSynchronize(s));
-            if (p->opt.profile) {
-                if (qmax == 0) { st.ms_phase[0] += span(0, 1); st.ms_phase[1] += span(1, 2); st.ms_phase[7] += span(2, 3); }
+            if (p->opt.profile >= 1) st.ms_phase[1] += span(11, 12);
+            if (p->opt.profile >= 2) {
+                if (qmax == 0) { st.ms_phase[0] += span(0, 2); st.ms_phase[7] += span(2, 3); }
                 st.ms_phase[2] += span(4, 5); st.ms_phase[6] += span(5, 6); st.ms_phase[3] += span(6, 7);
                 st.ms_phase[4] += span(7, 8); st.ms_phase[5] += span(8, 9); st.ms_phase[7] += span(9, 10);
             }

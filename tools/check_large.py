@@ -5,7 +5,7 @@ import __graft_entry__ as ge
 from oracle import oracle as orc
 pkg = ge.load_package()
 t = time.time(); w = pkg.window.make_window(200, 6000, 1200, imu=True, seed=0x5EED0005); print("gen %.1fs" % (time.time() - t), w["meta"])
-g = pkg.new_problem(profile=1); g.upload_window(w)
+g = pkg.new_problem(profile=2); g.upload_window(w)
 t = time.time(); sg = g.optimize(3); tg = time.time() - t
 print("hip: %d iters %d trials %.1f ms/iter chi %.1f -> %.1f fails %d phases(ms/iter) %s" % (sg.iterations, sg.trials, tg / sg.iterations * 1e3, sg.chi2_initial, sg.chi2_final, sg.solver_failures, np.round(np.array(list(sg.ms_phase)) / sg.iterations, 3)))
 t = time.time(); sg2 = g.optimize(3); tg = time.time() - t
