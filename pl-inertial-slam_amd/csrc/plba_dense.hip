@@ -1,23 +1,24 @@
 // plba_dense.hip — K7: dense fp64 solve of the reduced camera system on gfx950.
 //
 // Replaces g2o::LinearSolverEigen (sparse simplicial Cholesky of Hschur) by an exact dense LL^T on
-// the padded (Ppad x Ppad) symmetric matrix `sys`, right-looking with NB-wide blocks (NB = 32 or 64), ONE launch per
-// block step k.  Workgroup (r,c), k < c <= r <= T (r == T is the right-hand-side block row):
-//   waves 0/1   X_r = A(r,k) L(k,k)^-T, X_c = A(c,k) L(k,k)^-T : a lane per row, row in registers, L(k,k)^T staged in
-//               LDS and read as broadcasts (column oriented: no dependent accumulation chain)
-//   all waves   A(r,c) -= X_r X_c^T on the matrix cores (v_mfma_f64_16x16x4_f64; VALU when use_mfma = 0: test path)
-//   look-ahead  the workgroup of (k+1,k+1) factors its freshly updated tile inside ONE wavefront and publishes
-//               L(k+1,k+1) (+ transposed copy and reciprocal diagonal), so the next launch starts its TRSMs at once.
+// the padded (Ppad x Ppad) symmetric matrix `sys`, right-looking with NB-wide blocks, ONE launch per block step k.
+// Workgroup (r,c), k < c <= r <= T (r == T is the right-hand-side block row), forms the panel blocks
+// X_r = A(r,k) L(k,k)^-T and X_c, updates A(r,c) -= X_r X_c^T on the matrix cores (v_mfma_f64_16x16x4_f64), and the
+// workgroup of (k+1,k+1) factors its freshly updated tile (look-ahead), so the next launch starts at once.
 // The right-hand side rides along as an extra block row (row Ppad = bschur), so the forward solve L y = b is a
 // by-product of the factorisation; k_trsv_flow finishes with L^T x = y as a single dataflow launch.
 // A pivot <= 0 (or NaN) clears ctrl->solver_ok, which g2o reports as a failed linear solve.
 //
-// Why it looks like this (rocprofv3, MI355X): the path is a chain of P dependent pivots, so everything is about the
-// latency of one dependent step.  LDS + s_barrier per pivot column cost ~1300 cycles; v_readlane broadcasts ~2600
-// instructions per 32x32 tile; scalar-path TRSM operands ~11 dependent s_load batches per tile.  The in-wave potrf
-// below has ~150-200 cycles per column: the symmetric tile makes "column j" = register j across lanes (one
-// ds_write_b64), the pivot comes straight from lane j's register (v_readlane), the reciprocal is rcp + 2 Newton steps,
-// and the next column is published before the bulk of the current column's FMAs.
+// Two implementations of a step:
+//   k_chol32 (default: factor_block = 32, use_mfma = 1)  panels as products with the published inverse L(k,k)^-1,
+//       look-ahead tile factored AND inverted by a four-wave LDS pipeline (see "Look-ahead factorisation" below)
+//   k_chol_step<MFMA, NB> (factor_block = 64, or use_mfma = 0: the VALU check path)  panels by substitution against
+//       L(k,k)^T staged in LDS, look-ahead by a single-wave potrf
+//
+// Why it looks like this (rocprofv3 + cycle stamps, MI355X): the path is a chain of P dependent pivots, so everything
+// is about the latency of one dependent step.  LDS + s_barrier per pivot column cost ~1300 cycles; one in-order
+// wavefront issues an instruction every ~5-8 cycles whatever it is, so the pivot wave must execute as few
+// instructions as possible and everything that is not the pivot recurrence belongs to another wave.
 #include "plba_internal.h"
 
 namespace plba {
