@@ -180,6 +180,21 @@ int  plba_marginalize_factors(plba_problem* p, int n_imu, const int32_t* imu_edg
                               plba_prior* out);
 void plba_prior_free(plba_prior* pr);
 
+/* ---- IMU preintegration producer (upstream of plba_set_imu_edges) --------------------------
+ * KeyFrame::ComputeIMUPreIntSinceLastFrame (src/keyFrame.cpp:139-172) for M keyframe intervals at once: per interval
+ * IMUPreintegrator::reset (IMU/IMUPreintegrator.cpp:47-76), then one IMUPreintegrator::update (:80-139) per selected
+ * sample.  Interval m owns the samples [sample_start[m], sample_start[m+1]) of t / gyr3 / acc3 (the keyframe's `imus`
+ * vector); t_prev / t_curr are the two image times, bg3 / ba3 the previous keyframe's biases
+ * (NavState::Get_BiasGyr / Get_BiasAcc).  Time stamps are `long double` as in the reference (IMU/imudata.h:58): every
+ * dt is formed in long double on the host and rounded to double exactly where `double dt = ...` does there.  Sample
+ * selection follows the reference literally, including the last partial step `dt = curr_t - t[i]` taken with the first
+ * sample PAST curr_t (a negative dt; keyFrame.cpp:162-167).  gyr_meas_cov / acc_meas_cov: the diagonal value of
+ * IMUData::getGyrMeasCov / getAccMeasCov (IMU/imudata.cpp:27-28).  out142: M x 142 payloads in the
+ * plba_set_imu_edges layout.  `p` supplies the device, the stream and the error text; nothing needs to be uploaded. */
+int plba_preintegrate(plba_problem* p, int M, const int32_t* sample_start, const long double* t, const double* gyr3,
+                      const double* acc3, const long double* t_prev, const long double* t_curr, const double* bg3,
+                      const double* ba3, double gyr_meas_cov, double acc_meas_cov, double* out142);
+
 /* ---- diagnostics used by the parity tests (not needed by a drop-in caller) ------------------- */
 /* Runs computeActiveErrors + buildSystem + setLambda(lambda) + Schur on the current state without
  * updating it, then exposes named internal buffers: "Hschur" (P*P row-major), "bschur" (P),

@@ -119,6 +119,13 @@ public:
     Matrix3d getJRBiasg() const { return m3(51); }
     Matrix9d getCovPVPhi() const { Matrix9d c; for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) c(i, j) = p_[60 + i * 9 + j]; return c; }
     double getDeltaTime() const { return p_[141]; }
+    // IMU/IMUPreintegrator.cpp:80-139 (omega / acc bias-corrected); one step on the host with the same arithmetic the
+    // batched device producer plba_preintegrate uses.  Noise: IMUData::_gyrMeasCov / _accMeasCov (IMU/imudata.cpp:27-28).
+    void update(const Vector3d& omega, const Vector3d& acc, const double& dt) {
+        plba::preint_update(p_, plba::v3(omega[0], omega[1], omega[2]), plba::v3(acc[0], acc[1], acc[2]), dt, gyrMeasCov(), accMeasCov());
+    }
+    static double gyrMeasCov() { return 1.7e-4 * 1.7e-4 / 0.005; }
+    static double accMeasCov() { return 2.0e-3 * 2.0e-3 / 0.005 * 100; }
     // the 142-double payload of include/plba.h (dP dV dR JPg JPa JVg JVa JRg cov dt, matrices row-major)
     const double* payload() const { return p_; }
     void setPayload(const double* src) { std::memcpy(p_, src, sizeof p_); }

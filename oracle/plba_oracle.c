@@ -1994,3 +1994,29 @@ void orc_preint_update(double* pre142, const double* omega, const double* acc, d
     M.dt += dt;
     memcpy(pre142, &M, 142 * 8);
 }
+
+/* KeyFrame::ComputeIMUPreIntSinceLastFrame (src/keyFrame.cpp:139-172) batched over M keyframe intervals; same
+ * contract as plba_preintegrate (include/plba.h).  p is unused. */
+int orc_preintegrate(void* p, int M, const int32_t* sample_start, const long double* t, const double* gyr3, const double* acc3,
+                     const long double* t_prev, const long double* t_curr, const double* bg3, const double* ba3,
+                     double gyr_meas_cov, double acc_meas_cov, double* out142) {
+    (void)p;
+    for (int m = 0; m < M; ++m) {
+        double* pre = out142 + (size_t)m * 142;
+        memset(pre, 0, 142 * 8);                 /* IMUPreintegrator::reset, IMU/IMUPreintegrator.cpp:47-76 */
+        pre[6] = pre[10] = pre[14] = 1.0;
+        const int end = sample_start[m + 1];
+        int i = sample_start[m];
+        const double* bg = bg3 + 3 * m; const double* ba = ba3 + 3 * m;
+        double w[3], a[3], dt;
+#define ORC_STEP(ii, DT) do { for (int q = 0; q < 3; ++q) { w[q] = gyr3[3 * (size_t)(ii) + q] - bg[q]; a[q] = acc3[3 * (size_t)(ii) + q] - ba[q]; } \
+        dt = (double)(DT); orc_preint_update(pre, w, a, dt, gyr_meas_cov, acc_meas_cov); } while (0)
+        while (i < end && t[i] < t_prev[m]) ++i;             /* keyFrame.cpp:147-149 */
+        if (i >= end) continue;
+        ORC_STEP(i, t[i] - t_prev[m]); ++i;                  /* :150-154 */
+        while (i < end && t[i] <= t_curr[m]) { ORC_STEP(i, t[i] - t[i - 1]); ++i; }   /* :155-161 */
+        if (i < end) ORC_STEP(i, t_curr[m] - t[i]);          /* :162-167, dt as coded */
+#undef ORC_STEP
+    }
+    return 0;
+}

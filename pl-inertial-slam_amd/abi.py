@@ -82,6 +82,7 @@ SIGNATURES = {
     "restore_state": (C.c_int, [_P]),
     "marginalize": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(Prior)]),
     "marginalize_factors": (C.c_int, [_P, C.c_int, c_int32_p, C.c_int, c_int32_p, C.c_int, c_int32_p, C.c_int, C.c_int, c_int32_p, C.POINTER(Prior)]),
+    "preintegrate": (C.c_int, [_P, C.c_int, c_int32_p, C.POINTER(C.c_longdouble), c_double_p, c_double_p, C.POINTER(C.c_longdouble), C.POINTER(C.c_longdouble), c_double_p, c_double_p, C.c_double, C.c_double, c_double_p]),
     "prior_free": (None, [C.POINTER(Prior)]),
     "debug_build": (C.c_int, [_P, C.c_double, C.c_int]),
     "debug_get": (C.c_int, [_P, C.c_char_p, c_double_p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -370,6 +371,19 @@ class Problem:
         x = np.zeros(n); ok = C.c_int(0)
         self.call("debug_dense_solve", n, _dp(A), _dp(b), _dp(x), C.byref(ok))
         return x, bool(ok.value)
+
+    def preintegrate(self, sample_start, t, gyr, acc, t_prev, t_curr, bg, ba, gyr_meas_cov, acc_meas_cov):
+        """KeyFrame::ComputeIMUPreIntSinceLastFrame for M intervals (plba_preintegrate); time stamps as np.longdouble."""
+        ss = np.ascontiguousarray(sample_start, dtype=np.int32)
+        M = len(ss) - 1
+        ld = lambda v: np.ascontiguousarray(v, dtype=np.longdouble)
+        t, t_prev, t_curr = ld(t), ld(t_prev), ld(t_curr)
+        gyr, acc, bg, ba = _f64(gyr), _f64(acc), _f64(bg), _f64(ba)
+        out = np.zeros((M, 142))
+        lp = lambda v: v.ctypes.data_as(C.POINTER(C.c_longdouble))
+        self.call("preintegrate", M, ss.ctypes.data_as(c_int32_p), lp(t), _dp(gyr), _dp(acc), lp(t_prev), lp(t_curr), _dp(bg), _dp(ba),
+                  float(gyr_meas_cov), float(acc_meas_cov), _dp(out))
+        return out
 
     # -- convenience -------------------------------------------------------------------------
     def upload_window(self, w):

@@ -458,6 +458,125 @@ PLBA_HD void prior_dx_bias(const double* s, const double* x0 /*6*/, double* dx6)
 // symmetric 3x3 inverse of (H + lambda I) by LDL^T (backward stable for the SPD blocks of the path; the cofactor
 // form loses digits on poorly triangulated landmarks when lambda is small); H given as upper triangle
 // [h00 h01 h02 h11 h12 h22], result in the same packing
+// -------------------------------------------------------------------------------------------------
+// IMU preintegration producer: one IMUPreintegrator::update step
+// (IMU/IMUPreintegrator.cpp:80-139) on the 142-double payload
+//   [dP3 dV3 dR9 JPg9 JPa9 JVg9 JVa9 JRg9 cov81 dt]   (IMU/IMUPreintegrator.h:187-201)
+// omega / acc are bias-corrected; gcov / acov = diagonal value of IMUData::getGyrMeasCov / getAccMeasCov.
+// The 9 x 9 covariance propagation cov' = A cov A^T + Bg Sg Bg^T + Ca Sa Ca^T uses the block structure
+//   A = [I dt.I a13; 0 I a23; 0 0 a33],  a13 = -dR skew(acc) dt^2/2, a23 = -dR skew(acc) dt, a33 = Exp(w dt)^T
+// with the reference's summation order inside every entry (540 multiply-adds instead of 1458).
+// -------------------------------------------------------------------------------------------------
+constexpr int PREINT_DOUBLES = 142;
+PLBA_HD void st_m3(double* p, const M3& A) {
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+#endif
+    for (int i = 0; i < 9; ++i) p[i] = A.a[i];
+}
+PLBA_HD void preint_reset(double* pre) {   // IMU/IMUPreintegrator.cpp:47-76
+    for (int i = 0; i < PREINT_DOUBLES; ++i) pre[i] = 0.0;
+    pre[6] = 1.0; pre[10] = 1.0; pre[14] = 1.0;
+}
+PLBA_HD void preint_update(double* pre, V3 omega, V3 acc, double dt, double gcov, double acov) {
+    const double dt2 = dt * dt;
+    const V3 wdt = dt * omega;
+    const M3 dRk = (norm(wdt) < 1e-10) ? eye3() : q_to_R(so3_exp(wdt));     // Expmap, IMU/IMUPreintegrator.h:85-90
+    const M3 Jr = so3_Jr(wdt);
+    const M3 dR = ld_m3(pre + 6);
+    const M3 RS = mul(dR, hat(acc));
+    double* C = pre + 60;
+    double a13[9], a23[9], a33[9];
+    {
+        const M3 dRkT = transpose(dRk);
+        for (int i = 0; i < 9; ++i) { a13[i] = -0.5 * RS.a[i] * dt2; a23[i] = -RS.a[i] * dt; a33[i] = dRkT.a[i]; }
+    }
+    // cov <- (A cov) A^T, one row of T = A cov at a time; rows are overwritten only after every later row that needs
+    // them has been formed (A is block upper triangular), rows 6-8 together
+    double T[27];
+    for (int r = 0; r < 6; ++r) {
+        const int i = r % 3;
+        const double* arow = (r < 3) ? a13 + 3 * i : a23 + 3 * i;
+        for (int c = 0; c < 9; ++c) {
+            double s = C[r * 9 + c];
+            if (r < 3) s += dt * C[(3 + r) * 9 + c];
+            s += arow[0] * C[54 + c];
+            s += arow[1] * C[63 + c];
+            s += arow[2] * C[72 + c];
+            T[c] = s;
+        }
+        for (int c = 0; c < 3; ++c) {
+            double s = T[c] + dt * T[3 + c];
+            s += T[6] * a13[3 * c]; s += T[7] * a13[3 * c + 1]; s += T[8] * a13[3 * c + 2];
+            C[r * 9 + c] = s;
+            double u = T[3 + c];
+            u += T[6] * a23[3 * c]; u += T[7] * a23[3 * c + 1]; u += T[8] * a23[3 * c + 2];
+            C[r * 9 + 3 + c] = u;
+            double v = T[6] * a33[3 * c];
+            v += T[7] * a33[3 * c + 1]; v += T[8] * a33[3 * c + 2];
+            C[r * 9 + 6 + c] = v;
+        }
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int c = 0; c < 9; ++c) {
+            double s = a33[3 * i] * C[54 + c];
+            s += a33[3 * i + 1] * C[63 + c];
+            s += a33[3 * i + 2] * C[72 + c];
+            T[i * 9 + c] = s;
+        }
+    for (int i = 0; i < 3; ++i) {
+        const double* t = T + i * 9;
+        for (int c = 0; c < 3; ++c) {
+            double s = t[c] + dt * t[3 + c];
+            s += t[6] * a13[3 * c]; s += t[7] * a13[3 * c + 1]; s += t[8] * a13[3 * c + 2];
+            C[(6 + i) * 9 + c] = s;
+            double u = t[3 + c];
+            u += t[6] * a23[3 * c]; u += t[7] * a23[3 * c + 1]; u += t[8] * a23[3 * c + 2];
+            C[(6 + i) * 9 + 3 + c] = u;
+            double v = t[6] * a33[3 * c];
+            v += t[7] * a33[3 * c + 1]; v += t[8] * a33[3 * c + 2];
+            C[(6 + i) * 9 + 6 + c] = v;
+        }
+    }
+    {   // + Bg Sg Bg^T (rotation block) + Ca Sa Ca^T (position / velocity blocks)
+        const M3 JJ = mulABt(Jr, Jr), RR = mulABt(dR, dR);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                const double rr = RR.a[r * 3 + c];
+                C[(6 + r) * 9 + 6 + c] += (dt * dt * gcov) * JJ.a[r * 3 + c];
+                C[r * 9 + c] += (0.5 * dt2) * (0.5 * dt2) * acov * rr;
+                C[r * 9 + 3 + c] += (0.5 * dt2) * dt * acov * rr;
+                C[(3 + r) * 9 + c] += dt * (0.5 * dt2) * acov * rr;
+                C[(3 + r) * 9 + 3 + c] += dt * dt * acov * rr;
+            }
+    }
+    // Jacobians w.r.t. the biases: P first, then V, then R (cpp:104-110)
+    const M3 JRg = ld_m3(pre + 51);
+    const M3 RSJ = mul(RS, JRg);
+    for (int i = 0; i < 9; ++i) {
+        pre[24 + i] += pre[42 + i] * dt - 0.5 * dR.a[i] * dt2;       // JPa += JVa dt - dR dt^2/2
+        pre[15 + i] += pre[33 + i] * dt - 0.5 * RSJ.a[i] * dt2;      // JPg += JVg dt - dR skew(a) JRg dt^2/2
+    }
+    for (int i = 0; i < 9; ++i) {
+        pre[42 + i] += -dR.a[i] * dt;
+        pre[33 + i] += -RSJ.a[i] * dt;
+    }
+    {
+        const M3 t9 = mulAtB(dRk, JRg);
+        for (int i = 0; i < 9; ++i) pre[51 + i] = t9.a[i] - Jr.a[i] * dt;
+    }
+    // delta measurements: P first, then V, then R (cpp:112-116)
+    const V3 Ra = mul(dR, acc);
+    pre[0] += pre[3] * dt + 0.5 * Ra.x * dt2; pre[1] += pre[4] * dt + 0.5 * Ra.y * dt2; pre[2] += pre[5] * dt + 0.5 * Ra.z * dt2;
+    pre[3] += Ra.x * dt; pre[4] += Ra.y * dt; pre[5] += Ra.z * dt;
+    {   // normalizeRotationM (IMU/IMUPreintegrator.h:163-178): through a w >= 0 unit quaternion
+        Q4 q = R_to_q(mul(dR, dRk));
+        if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+        st_m3(pre + 6, q_to_R(q_normalized(q)));
+    }
+    pre[141] += dt;
+}
+
 PLBA_HD bool sym3_inv(const double* h, double lambda, double* d /*6 upper*/) {
     const double a = h[0] + lambda, b = h[1], c = h[2], e = h[3] + lambda, f = h[4], g = h[5] + lambda;
     const double i0 = 1.0 / a;

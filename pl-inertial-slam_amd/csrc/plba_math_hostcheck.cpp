@@ -70,4 +70,7 @@ void hc_rec_edge(const double* camv, const double* nav22, const double* L, const
 }
 void hc_sym3_inv(const double* h6, double lambda, double* d6) { sym3_inv(h6, lambda, d6); }
 void hc_huber(double e, double delta, double* r) { huber(e, delta, r[0], r[1]); }
+void hc_preint_update(double* pre142, const double* w, const double* a, double dt, double gcov, double acov) {
+    preint_update(pre142, ld_v3(w), ld_v3(a), dt, gcov, acov);
+}
 }
