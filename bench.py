@@ -126,8 +126,8 @@ def main():
         cfg = dict(win.CONFIGS[3])
         name = "configs[2]: 50 KF / 20k points / 4k lines + IMU preintegration edges (9-DoF PVR + 6-DoF bias vertices)"
     else:
-        cfg = dict(K=200 if world == 8 else 50, Np=25000 * world if world == 8 else 20000 * world,
-                   Nl=5000 * world if world == 8 else 4000 * world, imu=True)
+        # weak scaling: the configs[2] keyframe window with configs[2]'s landmark count PER RANK (landmarks are what shards)
+        cfg = dict(K=50, Np=20000 * world, Nl=4000 * world, imu=True)
         name = "%d KF / %d points / %d lines + IMU, landmarks sharded over %d ranks" % (cfg["K"], cfg["Np"], cfg["Nl"], world)
     if args.kf:
         cfg["K"] = args.kf
