@@ -69,6 +69,46 @@ def run_iterations(prob, n_iters, per_call=10):
     return done, trials, phases
 
 
+def pose_delta(a, b, win):
+    """max over the window keyframes of |dP|_inf (m), |dV|_inf (m/s), |Log(R_ref^T R)| (rad), |d(b+db)|_inf"""
+    dphi = 0.0
+    for qa, qb in zip(a["q"], b["q"]):
+        dphi = max(dphi, float(np.linalg.norm(win.log_so3(win.R_from_quat(qb).T @ win.R_from_quat(qa)))))
+    return dict(P_m=float(np.abs(a["P"] - b["P"]).max()), V_mps=float(np.abs(a["V"] - b["V"]).max()), rot_rad=dphi,
+                bias=float(max(np.abs(a["dbg"] - b["dbg"]).max(), np.abs(a["dba"] - b["dba"]).max())))
+
+
+def parity_and_config4(w, pkg):
+    """The second half of BASELINE's metric (max |delta pose| vs the CPU path) on the benchmarked window: the whole
+    reference protocol (5 + 10 iterations, gating) on the GPU and on the oracle; then configs[3]: marginalize the
+    oldest keyframe on the GPU and time the next BA call, which carries the prior edge."""
+    from oracle import oracle as orc
+    g, o = pkg.new_problem(), orc.new_problem()
+    g.upload_window(w); o.upload_window(w)
+    pkg.protocol.local_ba(g); pkg.protocol.local_ba(o)
+    d = pose_delta(g.get_keyframes(), o.get_keyframes(), pkg.window)
+    d["landmarks_m"] = float(max(np.abs(g.get_points() - o.get_points()).max(), np.abs(g.get_lines() - o.get_lines()).max()))
+    d["tolerance"] = 1e-5
+    o.close()
+    t0 = time.perf_counter()
+    prior = g.marginalize(0, pkg.protocol.MARG_NUM)
+    t_marg = time.perf_counter() - t0
+    g.close()
+    w2 = dict(w); w2["prior"] = prior
+    g2 = pkg.new_problem()
+    g2.upload_window(w2)
+    g2.optimize(1)                      # structure build + first touch outside the timed call
+    g2.upload_window(w2)
+    t0 = time.perf_counter()
+    r = pkg.protocol.local_ba(g2)
+    t_ba = time.perf_counter() - t0
+    its = r["stage1"].iterations + r["stage2"].iterations
+    g2.close()
+    c4 = dict(workload="configs[3]: configs[2] + marginalization prior", marginalize_ms=t_marg * 1e3, prior_dim=int(prior["n"]),
+              ba_call_with_prior_ms=t_ba * 1e3, iterations=int(its), iterations_per_s=its / t_ba)
+    return d, c4
+
+
 def cpu_baseline(w, pkg, budget_s=20.0):
     """The CPU oracle (restatement of the reference's g2o path) timed on this box's host cores on a
     bounded sample of the same window: stage-2 LM iterations until ~budget_s of CPU work."""
@@ -227,6 +267,7 @@ def main():
         out["config"]["end_to_end_iterations_per_s"] = (r2["stage1"].iterations + r2["stage2"].iterations) / e2e
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
+            out["max_pose_delta_vs_cpu"], out["config4_sliding_window"] = parity_and_config4(w_full, pkg)
             out["cpu_baseline"] = cpu_baseline(w_full, pkg)
         else:
             out["cpu_baseline"] = None
