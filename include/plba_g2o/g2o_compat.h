@@ -45,6 +45,7 @@ using namespace Eigen;
 typedef Eigen::Matrix<double, 15, 1> Vector15d;
 typedef Eigen::Matrix<double, 9, 1> Vector9d;
 typedef Eigen::Matrix<double, 6, 1> Vector6d;
+typedef Eigen::Matrix<double, 7, 1> Vector7d;
 typedef Eigen::Matrix<double, 9, 9> Matrix9d;
 
 // ================================================================================================================
@@ -235,10 +236,29 @@ public:
         for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) _info[(size_t)i * n + j] = m(i, j);
     }
     const std::vector<double>& informationRowMajor() const { return _info; }
+    void setInformationRowMajor(const std::vector<double>& m) { _info = m; }
     double* errorData() { return _error.data(); }
+    const std::vector<double>& error() const { return _error; }
+    // e^T Omega e of the residual held in _error: what chi2() means for the host-evaluated (API-surface) edge types
+    double chi2FromError() const {
+        const int n = (int)_error.size();
+        double c = 0.0;
+        for (int i = 0; i < n; ++i) { double t = 0.0; for (int j = 0; j < n; ++j) t += _info[(size_t)i * n + j] * _error[j]; c += _error[i] * t; }
+        return c;
+    }
+    // Jacobian blocks of the host-evaluated edge types, row-major D x dim(vertex k) (g2o's _jacobianOplusXi / Xj / _jacobianOplus[k])
+    const std::vector<double>& jacobianOplus(size_t k) const { return _jac[k]; }
+    const std::vector<double>& jacobianOplusXi() const { return _jac[0]; }
+    const std::vector<double>& jacobianOplusXj() const { return _jac[1]; }
 protected:
+    double& J(size_t k, int cols, int r, int c) { return _jac[k][(size_t)r * cols + c]; }
+    void allocJacobians(std::initializer_list<int> dims) {
+        _jac.clear();
+        for (int d : dims) _jac.emplace_back((size_t)(D > 0 ? D : this->_dimension) * d, 0.0);
+    }
     E _measurement;
     std::vector<double> _info, _error;
+    std::vector<std::vector<double>> _jac;
 };
 template <int D, typename E, typename VXi> class BaseUnaryEdge : public BaseEdgeT<D, E> { public: BaseUnaryEdge() { this->resize(1); } };
 template <int D, typename E, typename VXi, typename VXj> class BaseBinaryEdge : public BaseEdgeT<D, E> { public: BaseBinaryEdge() { this->resize(2); } };

@@ -51,6 +51,9 @@ def lib():
             "orc_huber": [C.c_double, C.c_double, dp],
             "orc_sym_eig": [dp, C.c_int, dp, dp],
             "orc_preint_update": [dp, dp, dp, C.c_double, C.c_double, C.c_double],
+            "orc_se3_exp": [dp, dp, dp], "orc_se3_mul": [dp] * 6, "orc_se3_map": [dp] * 4, "orc_se3_log": [dp, dp, dp],
+            "orc_se3_oplus": [dp] * 5,
+            "orc_eval_se3_edge": [C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip],
         }
         for name, args in sigs.items():
             f = getattr(c, name)

@@ -2020,3 +2020,123 @@ int orc_preintegrate(void* p, int M, const int32_t* sample_start, const long dou
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * API-surface types of IMU/types_six_dof_expmap.{h,cpp} and IMU/se3quat.h (named by the task, no call
+ * site in the local-BA path).  Plain restatements used only to check the host-side facade classes.
+ * SE3 = unit quaternion (x,y,z,w; w >= 0) + translation.
+ * ------------------------------------------------------------------------------------------------ */
+static void se3_normalize(double* q) { /* SE3Quat::normalizeRotation, IMU/se3quat.h:283-288 */
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    q_normalize(q);
+}
+/* SE3Quat::exp, IMU/se3quat.h:223-257: update = (omega, upsilon) */
+void orc_se3_exp(const double* u6, double* q, double* t) {
+    const double* om = u6; const double* up = u6 + 3;
+    double theta = v3_norm(om), W[9], W2[9], R[9], V[9];
+    static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    so3_hat(om, W);
+    m3_mul(W, W, W2);
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; ++i) { R[i] = I3[i] + W[i] + W2[i]; V[i] = R[i]; }
+    } else {
+        double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3);
+        for (int i = 0; i < 9; ++i) { R[i] = I3[i] + a * W[i] + b * W2[i]; V[i] = I3[i] + b * W[i] + c * W2[i]; }
+    }
+    R_to_q(R, q);
+    m3_v(V, up, t);
+    se3_normalize(q);
+}
+/* SE3Quat::operator*, IMU/se3quat.h:101-107 */
+void orc_se3_mul(const double* qa, const double* ta, const double* qb, const double* tb, double* qo, double* to) {
+    double r[3];
+    q_rotate(qa, tb, r);
+    for (int i = 0; i < 3; ++i) to[i] = ta[i] + r[i];
+    q_mul(qa, qb, qo);
+    se3_normalize(qo);
+}
+/* SE3Quat::map, IMU/se3quat.h:217-220 */
+void orc_se3_map(const double* q, const double* t, const double* x, double* out) {
+    q_rotate(q, x, out);
+    for (int i = 0; i < 3; ++i) out[i] += t[i];
+}
+/* SE3Quat::log, IMU/se3quat.h:178-215 */
+void orc_se3_log(const double* q, const double* t, double* out6) {
+    double R[9], om[3], W[9], W2[9], Vi[9], dR[3];
+    static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    q_to_R(q, R);
+    double d = 0.5 * (R[0] + R[4] + R[8] - 1);
+    dR[0] = R[7] - R[5]; dR[1] = R[2] - R[6]; dR[2] = R[3] - R[1];
+    if (d > 0.99999) {
+        for (int i = 0; i < 3; ++i) om[i] = 0.5 * dR[i];
+        so3_hat(om, W); m3_mul(W, W, W2);
+        for (int i = 0; i < 9; ++i) Vi[i] = I3[i] - 0.5 * W[i] + (1. / 12.) * W2[i];
+    } else {
+        double theta = acos(d);
+        for (int i = 0; i < 3; ++i) om[i] = theta / (2 * sqrt(1 - d * d)) * dR[i];
+        so3_hat(om, W); m3_mul(W, W, W2);
+        double k = (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+        for (int i = 0; i < 9; ++i) Vi[i] = I3[i] - 0.5 * W[i] + k * W2[i];
+    }
+    out6[0] = om[0]; out6[1] = om[1]; out6[2] = om[2];
+    m3_v(Vi, t, out6 + 3);
+}
+/* VertexSE3Expmap::oplusImpl, IMU/types_six_dof_expmap.h:73-76: estimate <- exp(update) * estimate */
+void orc_se3_oplus(const double* q, const double* t, const double* u6, double* qo, double* to) {
+    double qe[4], te[3];
+    orc_se3_exp(u6, qe, te);
+    orc_se3_mul(qe, te, q, t, qo, to);
+}
+/* The four reprojection edges.  kind: 0 EdgeSE3ProjectXYZ (cpp:103-145), 1 EdgeStereoSE3ProjectXYZ (:150-235),
+ * 2 EdgeSE3ProjectXYZOnlyPose (:258-289), 3 EdgeStereoSE3ProjectXYZOnlyPose (:299-358).  cam = fx fy cx cy bf.
+ * err: 2 or 3; Jpoint: D x 3 row-major (kinds 0/1; untouched otherwise); Jpose: D x 6 row-major; depth_pos: map(X).z > 0. */
+void orc_eval_se3_edge(int kind, const double* cam, const double* q, const double* t, const double* X, const double* obs,
+                       double* err, double* Jpoint, double* Jpose, int* depth_pos) {
+    const double fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3], bf = cam[4];
+    double p[3], R[9];
+    orc_se3_map(q, t, X, p);
+    q_to_R(q, R);
+    const double x = p[0], y = p[1], z = p[2];
+    const int stereo = (kind == 1 || kind == 3), D = stereo ? 3 : 2;
+    if (depth_pos) *depth_pos = z > 0.0;
+    if (!stereo) {
+        err[0] = obs[0] - (x / z * fx + cx);        /* project2d then scale, cpp:139-145 / 283-289 */
+        err[1] = obs[1] - (y / z * fy + cy);
+    } else {
+        const float invz = (float)(1.0f / z);        /* cpp:151 / 300: invz is a float */
+        double r0 = x * invz * fx + cx, r1 = y * invz * fy + cy, r2;
+        if (kind == 1) { const float bff = (float)bf; r2 = r0 - bff * invz; }   /* float * float, cam_project(xyz, const float& bf) */
+        else r2 = r0 - bf * invz;                                              /* double member * float */
+        err[0] = obs[0] - r0; err[1] = obs[1] - r1; err[2] = obs[2] - r2;
+    }
+    if (kind == 0) {
+        const double z_2 = z * z;
+        const double tmp[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < 3; ++k) s += (-1. / z * tmp[r * 3 + k]) * R[k * 3 + c];
+            Jpoint[r * 3 + c] = s;
+        }
+        double* j = Jpose;
+        j[0] = x * y / z_2 * fx; j[1] = -(1 + (x * x / z_2)) * fx; j[2] = y / z * fx; j[3] = -1. / z * fx; j[4] = 0; j[5] = x / z_2 * fx;
+        j[6] = (1 + y * y / z_2) * fy; j[7] = -x * y / z_2 * fy; j[8] = -x / z * fy; j[9] = 0; j[10] = -1. / z * fy; j[11] = y / z_2 * fy;
+    } else if (kind == 1) {
+        const double z_2 = z * z;
+        for (int c = 0; c < 3; ++c) {
+            Jpoint[c] = -fx * R[c] / z + fx * x * R[6 + c] / z_2;
+            Jpoint[3 + c] = -fy * R[3 + c] / z + fy * y * R[6 + c] / z_2;
+            Jpoint[6 + c] = Jpoint[c] - bf * R[6 + c] / z_2;
+        }
+        double* j = Jpose;
+        j[0] = x * y / z_2 * fx; j[1] = -(1 + (x * x / z_2)) * fx; j[2] = y / z * fx; j[3] = -1. / z * fx; j[4] = 0; j[5] = x / z_2 * fx;
+        j[6] = (1 + y * y / z_2) * fy; j[7] = -x * y / z_2 * fy; j[8] = -x / z * fy; j[9] = 0; j[10] = -1. / z * fy; j[11] = y / z_2 * fy;
+        j[12] = j[0] - bf * y / z_2; j[13] = j[1] + bf * x / z_2; j[14] = j[2]; j[15] = j[3]; j[16] = 0; j[17] = j[5] - bf / z_2;
+    } else {
+        const double invz = 1.0 / z, invz_2 = invz * invz;
+        double* j = Jpose;
+        j[0] = x * y * invz_2 * fx; j[1] = -(1 + (x * x * invz_2)) * fx; j[2] = y * invz * fx; j[3] = -invz * fx; j[4] = 0; j[5] = x * invz_2 * fx;
+        j[6] = (1 + y * y * invz_2) * fy; j[7] = -x * y * invz_2 * fy; j[8] = -x * invz * fy; j[9] = 0; j[10] = -invz * fy; j[11] = y * invz_2 * fy;
+        if (kind == 3) { j[12] = j[0] - bf * y * invz_2; j[13] = j[1] + bf * x * invz_2; j[14] = j[2]; j[15] = j[3]; j[16] = 0; j[17] = j[5] - bf * invz_2; }
+    }
+    (void)D;
+}

@@ -32,3 +32,11 @@ def hip(pkg):
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU is visible")
     return pkg.hip_lib()
+
+
+@pytest.fixture(scope="session")
+def hip_lib_path():
+    """Path of the built product library (CPU tests only link against / dlopen it; no compute calls without a GPU)."""
+    import __graft_entry__ as g
+    g.build_hip()
+    return g.HIP_LIB

@@ -1,0 +1,130 @@
+"""API-surface types (SURVEY §8a footnote: named by the task, no local-BA call site): the host-evaluated classes of
+include/plba_g2o/{se3quat,types_sba,types_six_dof_expmap}.h against the oracle's restatement of
+IMU/se3quat.h / IMU/types_six_dof_expmap.{h,cpp} and against finite differences through the vertices' own oplus."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dp = C.POINTER(C.c_double)
+
+
+def _d(a):
+    return a.ctypes.data_as(dp)
+
+
+@pytest.fixture(scope="module")
+def shim(pkg, hip_lib_path):
+    out_dir = os.path.join(ROOT, "tools", "_build_api_shim")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libapi_shim.so")
+    src = os.path.join(ROOT, "tools", "api_surface_shim.cpp")
+    pkgdir = os.path.dirname(hip_lib_path)
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-unknown-pragmas", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(pkgdir, "csrc"), src, "-o", so, "-L", pkgdir, "-lplba_hip", "-Wl,-rpath," + pkgdir]
+    subprocess.run(cmd, check=True, capture_output=True)
+    lib = C.CDLL(so)
+    for f in ("shim_se3_exp", "shim_se3_log", "shim_se3_oplus", "shim_se3_inverse_mul", "shim_se3_vertex_io", "shim_eval_se3_edge"):
+        getattr(lib, f).restype = None
+    return lib
+
+
+def _rand_se3(rng, orc):
+    u = np.concatenate([rng.normal(size=3) * 0.6, rng.normal(size=3) * 2.0])
+    q, t = np.zeros(4), np.zeros(3)
+    orc.lib().cdll.orc_se3_exp(_d(u), _d(q), _d(t))
+    return q, t
+
+
+def test_se3quat_exp_log_oplus(shim, orc):
+    rng = np.random.default_rng(3)
+    o = orc.lib().cdll
+    for k in range(40):
+        u = np.concatenate([rng.normal(size=3), rng.normal(size=3) * 3.0])
+        if k % 7 == 0:
+            u[:3] *= 1e-7                      # the theta < 1e-5 branch (R = I + W + W^2, IMU/se3quat.h:237-243)
+        qs, ts, qo, to = np.zeros(4), np.zeros(3), np.zeros(4), np.zeros(3)
+        shim.shim_se3_exp(_d(u), _d(qs), _d(ts)); o.orc_se3_exp(_d(u), _d(qo), _d(to))
+        assert np.allclose(qs, qo, atol=1e-15) and np.allclose(ts, to, atol=1e-14)
+        assert qs[3] >= 0 and abs(np.linalg.norm(qs) - 1) < 1e-15
+        ls, lo = np.zeros(6), np.zeros(6)
+        shim.shim_se3_log(_d(qs), _d(ts), _d(ls)); o.orc_se3_log(_d(qo), _d(to), _d(lo))
+        assert np.allclose(ls, lo, atol=1e-13)
+        if np.linalg.norm(u[:3]) < 3.0 and k % 7:
+            assert np.allclose(ls, u, atol=1e-9)                        # log(exp(u)) = u away from pi
+        q, t = _rand_se3(rng, orc)
+        d = rng.normal(size=6) * 0.05
+        a, b, c, e = np.zeros(4), np.zeros(3), np.zeros(4), np.zeros(3)
+        shim.shim_se3_oplus(_d(q), _d(t), _d(d), _d(a), _d(b)); o.orc_se3_oplus(_d(q), _d(t), _d(d), _d(c), _d(e))
+        assert np.allclose(a, c, atol=1e-15) and np.allclose(b, e, atol=1e-14)
+        shim.shim_se3_inverse_mul(_d(q), _d(t), _d(a), _d(b))
+        assert np.allclose(a, [0, 0, 0, 1], atol=1e-15) and np.allclose(b, 0, atol=1e-14)
+        shim.shim_se3_vertex_io(_d(q), _d(t), _d(a), _d(b))            # write (camera -> world) then read back
+        assert np.allclose(a, q, atol=1e-15) and np.allclose(b, t, atol=1e-13)
+
+
+CAM = np.array([458.654, 457.296, 367.215, 248.375, 47.9])
+
+
+def _eval(shim, kind, q, t, X, obs):
+    D = 3 if kind in (1, 3) else 2
+    err, Jp, Jx = np.zeros(D), np.zeros((D, 3)), np.zeros((D, 6))
+    dpos, chi = C.c_int(0), C.c_double(0)
+    shim.shim_eval_se3_edge(kind, _d(CAM), _d(q), _d(t), _d(X), _d(obs), _d(err), _d(Jp), _d(Jx), C.byref(dpos), C.byref(chi))
+    return err, Jp, Jx, bool(dpos.value), chi.value
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_se3_projection_edges(shim, orc, kind):
+    rng = np.random.default_rng(10 + kind)
+    o = orc.lib().cdll
+    D = 3 if kind in (1, 3) else 2
+    for _ in range(25):
+        q, t = _rand_se3(rng, orc)
+        Pc = np.array([rng.uniform(-2, 2), rng.uniform(-1.5, 1.5), rng.uniform(1.0, 8.0)])
+        R = orc.quat_to_R(q)
+        X = R.T @ (Pc - t)
+        obs = rng.normal(size=3) * 3 + np.array([CAM[0] * Pc[0] / Pc[2] + CAM[2], CAM[1] * Pc[1] / Pc[2] + CAM[3], CAM[0] * Pc[0] / Pc[2] + CAM[2] - CAM[4] / Pc[2]])
+        err, Jp, Jx, dpos, chi = _eval(shim, kind, q, t, X, obs)
+        eo, Jpo, Jxo, dpo = np.zeros(D), np.zeros((D, 3)), np.zeros((D, 6)), C.c_int(0)
+        o.orc_eval_se3_edge(kind, _d(CAM), _d(q), _d(t), _d(X), _d(obs), _d(eo), _d(Jpo), _d(Jxo), C.byref(dpo))
+        assert np.allclose(err, eo, rtol=0, atol=1e-10) and np.allclose(Jx, Jxo, rtol=1e-12, atol=1e-12) and dpos == bool(dpo.value) and dpos
+        if kind < 2:
+            assert np.allclose(Jp, Jpo, rtol=1e-12, atol=1e-12)
+        assert chi == pytest.approx(2.0 * float(err @ err), rel=1e-14)
+        # finite differences through the vertices' own updates (point: +=, pose: exp(delta) * T); the stereo rows see
+        # the float rounding of 1/z, hence the step and tolerance
+        h = 1e-6 if D == 2 else 2e-3
+        tol = 1e-5 if D == 2 else 2e-2
+        scale = max(1.0, np.abs(Jx).max())
+        for c in range(6):
+            d = np.zeros(6); d[c] = h
+            qa, ta, qb, tb = np.zeros(4), np.zeros(3), np.zeros(4), np.zeros(3)
+            shim.shim_se3_oplus(_d(q), _d(t), _d(d), _d(qa), _d(ta)); shim.shim_se3_oplus(_d(q), _d(t), _d(-d), _d(qb), _d(tb))
+            fd = (_eval(shim, kind, qa, ta, X, obs)[0] - _eval(shim, kind, qb, tb, X, obs)[0]) / (2 * h)
+            assert np.abs(fd - Jx[:, c]).max() < tol * scale, (kind, c)
+        if kind < 2:
+            for c in range(3):
+                d = np.zeros(3); d[c] = h
+                fd = (_eval(shim, kind, q, t, X + d, obs)[0] - _eval(shim, kind, q, t, X - d, obs)[0]) / (2 * h)
+                assert np.abs(fd - Jp[:, c]).max() < tol * scale, (kind, c)
+    # behind the camera
+    q, t = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    assert _eval(shim, kind, q, t, np.array([0.1, 0.1, -2.0]), np.zeros(3))[3] is False
+
+
+def test_stereo_projection_keeps_the_float_inverse_depth(shim, orc):
+    """IMU/types_six_dof_expmap.cpp:150-157, 299-306: invz is a float; for the two-vertex edge so is bf * invz"""
+    q, t = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    X = np.array([0.3, -0.2, 3.0])
+    obs = np.zeros(3)
+    invz = np.float32(1.0 / X[2])
+    for kind in (1, 3):
+        err = _eval(shim, kind, q, t, X, obs)[0]
+        u = X[0] * float(invz) * CAM[0] + CAM[2]
+        ur = u - (float(np.float32(CAM[4]) * invz) if kind == 1 else CAM[4] * float(invz))
+        assert err[0] == -u and err[2] == -ur
+        assert err[0] != -(X[0] / X[2] * CAM[0] + CAM[2])       # a double 1/z would give a different pixel

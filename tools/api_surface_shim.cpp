@@ -1,0 +1,70 @@
+// C entry points over the host-evaluated ("API surface only") vertex / edge classes of the g2o facade, so
+// that tests/test_api_surface.py can compare them with the oracle's restatements and with finite differences.
+// Built by the test with plain g++ against libplba_hip.so; not part of the product library.
+#include <sstream>
+
+#include "plba_g2o/types_six_dof_expmap.h"
+#include "plba_g2o/g2otypes.h"
+
+using namespace g2o;
+
+static SE3Quat make_se3(const double* q, const double* t) {
+    plba::Q4 qq; qq.x = q[0]; qq.y = q[1]; qq.z = q[2]; qq.w = q[3];
+    return SE3Quat::fromRaw(qq, plba::v3(t[0], t[1], t[2]));
+}
+static void put_se3(const SE3Quat& T, double* q, double* t) {
+    q[0] = T.rawRotation().x; q[1] = T.rawRotation().y; q[2] = T.rawRotation().z; q[3] = T.rawRotation().w;
+    t[0] = T.rawTranslation().x; t[1] = T.rawTranslation().y; t[2] = T.rawTranslation().z;
+}
+
+extern "C" {
+
+void shim_se3_exp(const double* u6, double* q, double* t) { Vector6d u; for (int i = 0; i < 6; ++i) u[i] = u6[i]; put_se3(SE3Quat::exp(u), q, t); }
+void shim_se3_log(const double* q, const double* t, double* out6) { const Vector6d l = make_se3(q, t).log(); for (int i = 0; i < 6; ++i) out6[i] = l[i]; }
+void shim_se3_oplus(const double* q, const double* t, const double* u6, double* qo, double* to) {
+    VertexSE3Expmap v;
+    v.setEstimate(make_se3(q, t));
+    v.oplusImpl(u6);
+    put_se3(v.estimate(), qo, to);
+}
+void shim_se3_inverse_mul(const double* q, const double* t, double* qo, double* to) { const SE3Quat T = make_se3(q, t); put_se3(T.inverse() * T, qo, to); }
+void shim_se3_vertex_io(const double* q, const double* t, double* qo, double* to) {
+    VertexSE3Expmap a, b;
+    a.setEstimate(make_se3(q, t));
+    std::stringstream ss;
+    ss.precision(17);
+    a.write(ss);
+    b.read(ss);
+    put_se3(b.estimate(), qo, to);
+}
+void shim_eval_se3_edge(int kind, const double* cam, const double* q, const double* t, const double* X, const double* obs,
+                        double* err, double* Jpoint, double* Jpose, int* depth_pos, double* chi2) {
+    VertexSE3Expmap pose; pose.setEstimate(make_se3(q, t)); pose.setId(1);
+    VertexSBAPointXYZ pt; pt.setEstimate(Vector3d(X[0], X[1], X[2])); pt.setId(0);
+    auto copy = [](const std::vector<double>& s, double* d) { if (d) for (size_t i = 0; i < s.size(); ++i) d[i] = s[i]; };
+    Matrix2d I2; I2.setIdentity();
+    Matrix3d I3; I3.setIdentity();
+    if (kind == 0) {
+        EdgeSE3ProjectXYZ e; e.fx = cam[0]; e.fy = cam[1]; e.cx = cam[2]; e.cy = cam[3];
+        e.setVertex(0, &pt); e.setVertex(1, &pose); e.setMeasurement(Vector2d(obs[0], obs[1])); e.setInformation(I2 * 2.0);
+        e.computeError(); e.linearizeOplus();
+        copy(e.error(), err); copy(e.jacobianOplusXi(), Jpoint); copy(e.jacobianOplusXj(), Jpose); *depth_pos = e.isDepthPositive(); *chi2 = e.chi2();
+    } else if (kind == 1) {
+        EdgeStereoSE3ProjectXYZ e; e.fx = cam[0]; e.fy = cam[1]; e.cx = cam[2]; e.cy = cam[3]; e.bf = cam[4];
+        e.setVertex(0, &pt); e.setVertex(1, &pose); e.setMeasurement(Vector3d(obs[0], obs[1], obs[2])); e.setInformation(I3 * 2.0);
+        e.computeError(); e.linearizeOplus();
+        copy(e.error(), err); copy(e.jacobianOplusXi(), Jpoint); copy(e.jacobianOplusXj(), Jpose); *depth_pos = e.isDepthPositive(); *chi2 = e.chi2();
+    } else if (kind == 2) {
+        EdgeSE3ProjectXYZOnlyPose e; e.fx = cam[0]; e.fy = cam[1]; e.cx = cam[2]; e.cy = cam[3]; e.Xw = Vector3d(X[0], X[1], X[2]);
+        e.setVertex(0, &pose); e.setMeasurement(Vector2d(obs[0], obs[1])); e.setInformation(I2 * 2.0);
+        e.computeError(); e.linearizeOplus();
+        copy(e.error(), err); copy(e.jacobianOplusXi(), Jpose); *depth_pos = e.isDepthPositive(); *chi2 = e.chi2();
+    } else {
+        EdgeStereoSE3ProjectXYZOnlyPose e; e.fx = cam[0]; e.fy = cam[1]; e.cx = cam[2]; e.cy = cam[3]; e.bf = cam[4]; e.Xw = Vector3d(X[0], X[1], X[2]);
+        e.setVertex(0, &pose); e.setMeasurement(Vector3d(obs[0], obs[1], obs[2])); e.setInformation(I3 * 2.0);
+        e.computeError(); e.linearizeOplus();
+        copy(e.error(), err); copy(e.jacobianOplusXi(), Jpose); *depth_pos = e.isDepthPositive(); *chi2 = e.chi2();
+    }
+}
+
+}  // extern "C"
