@@ -444,6 +444,115 @@ public:
 private:
     inline bool _depth_cache_fresh();
 };
+// ---- API-surface types of IMU/g2otypes.h: declared by the reference, no call site in the local-BA path.
+// Evaluated on the host with the same arithmetic the device uses for their on-path siblings (plba_math.h); a graph
+// containing them is not accepted by SparseOptimizer::optimize.
+inline plba::Cam plba_make_cam(const CamParams& c) {
+    plba::Cam cam;
+    cam.fx = c.fx; cam.fy = c.fy; cam.cx = c.cx; cam.cy = c.cy;
+    plba::M3 Rbc; for (int i = 0; i < 9; ++i) Rbc.a[i] = c.Rbc[i];
+    cam.Rcb = plba::transpose(Rbc);
+    cam.c0 = plba::mul(cam.Rcb, plba::v3(c.Pbc[0], c.Pbc[1], c.Pbc[2]));
+    return cam;
+}
+
+// pose-only variant of the point edge: fixed world point Pw (IMU/g2otypes.h:329-406, .cpp:343-394)
+class EdgeNavStatePVRPointXYZOnlyPose : public BaseUnaryEdge<2, Vector2d, VertexNavStatePVR> {
+public:
+    EdgeNavStatePVRPointXYZOnlyPose() { allocJacobians({9}); }
+    void SetParams(const double& fx_, const double& fy_, const double& cx_, const double& cy_, const Matrix3d& Rbc_, const Vector3d& Pbc_, const Vector3d& Pw_) {
+        cam.fx = fx_; cam.fy = fy_; cam.cx = cx_; cam.cy = cy_; cam.set = true;
+        for (int i = 0; i < 3; ++i) { cam.Pbc[i] = Pbc_(i); Pw[i] = Pw_(i); for (int j = 0; j < 3; ++j) cam.Rbc[i * 3 + j] = Rbc_(i, j); }
+    }
+    void computeError() override { eval(false); }
+    void linearizeOplus() override { eval(true); }
+    bool isDepthPositive() { eval(false); return _depth_cache; }
+    double chi2() const override { return chi2FromError(); }
+    CamParams cam;
+    double Pw[3] = {0, 0, 0};
+private:
+    void eval(bool jac) {
+        const plba::Cam c = plba_make_cam(cam);
+        double kc[12], Jp[12], Jl[6];
+        plba::kfcam_make(c, static_cast<const VertexNavStatePVR*>(_vertices[0])->estimate().raw(), kc);
+        bool dpos = true;
+        plba::point_edge(c, kc, plba::v3(Pw[0], Pw[1], Pw[2]), _measurement[0], _measurement[1], _error.data(), Jp, Jl, dpos, jac);
+        _depth_cache = dpos;
+        if (jac) for (int r = 0; r < 2; ++r) for (int k = 0; k < 3; ++k) { J(0, 9, r, k) = Jp[r * 6 + k]; J(0, 9, r, 3 + k) = 0.0; J(0, 9, r, 6 + k) = Jp[r * 6 + 3 + k]; }
+    }
+};
+
+// one line end point as its own vertex (IMU/g2otypes.h:899-1000, .cpp:1364-1421): e0 = l . (proj(P), 1), e1 = e2 = 0
+class VertexLinePoint : public BaseVertex<3, Vector3d> {
+public:
+    void setToOriginImpl() override { for (int i = 0; i < 3; ++i) _estimate[i] = 0.0; }
+    void oplusImpl(const double* u) override { for (int i = 0; i < 3; ++i) _estimate[i] += u[i]; }
+    int estimateDimension() const override { return 3; }
+};
+class EdgeNavStateLinePoint : public BaseBinaryEdge<3, Vector3d, VertexLinePoint, VertexNavStatePVR> {
+public:
+    EdgeNavStateLinePoint() { allocJacobians({3, 9}); }
+    void SetParams(const double& fx_, const double& fy_, const double& cx_, const double& cy_, const Matrix3d& Rbc_, const Vector3d& Pbc_) {
+        cam.fx = fx_; cam.fy = fy_; cam.cx = cx_; cam.cy = cy_; cam.set = true;
+        for (int i = 0; i < 3; ++i) { cam.Pbc[i] = Pbc_(i); for (int j = 0; j < 3; ++j) cam.Rbc[i * 3 + j] = Rbc_(i, j); }
+    }
+    void computeError() override { eval(false); }
+    void linearizeOplus() override { eval(true); }
+    bool isDepthPositive() { eval(false); return _depth_cache; }
+    double chi2() const override { return chi2FromError(); }
+    CamParams cam;
+private:
+    void eval(bool jac) {
+        const plba::Cam c = plba_make_cam(cam);
+        double kc[12], e2[2], Jp[12], Jl[6];
+        plba::kfcam_make(c, static_cast<const VertexNavStatePVR*>(_vertices[1])->estimate().raw(), kc);
+        const Vector3d& P = static_cast<const VertexLinePoint*>(_vertices[0])->estimate();
+        const plba::V3 Pw = plba::v3(P[0], P[1], P[2]);
+        bool dpos = true;
+        // the first row of the two-end-point line edge with both ends at this point; reference's world-frame dp (B-Q1)
+        plba::line_edge(c, kc, Pw, Pw, _measurement[0], _measurement[1], _measurement[2], false, e2, Jp, Jl, dpos, jac);
+        _error[0] = e2[0]; _error[1] = 0.0; _error[2] = 0.0;
+        _depth_cache = dpos;
+        if (jac) {
+            std::fill(_jac[0].begin(), _jac[0].end(), 0.0); std::fill(_jac[1].begin(), _jac[1].end(), 0.0);
+            for (int k = 0; k < 3; ++k) { J(0, 3, 0, k) = Jl[k]; J(1, 9, 0, k) = Jp[k]; J(1, 9, 0, 6 + k) = Jp[3 + k]; }
+        }
+    }
+};
+
+// gyroscope-bias vertex / edge of the VIO initialisation (IMU/g2otypes.h:702-741, .cpp:1217-1287)
+class VertexGyrBias : public BaseVertex<3, Vector3d> {
+public:
+    void setToOriginImpl() override { for (int i = 0; i < 3; ++i) _estimate[i] = 0.0; }
+    void oplusImpl(const double* u) override { for (int i = 0; i < 3; ++i) _estimate[i] += u[i]; }
+    int estimateDimension() const override { return 3; }
+    bool read(std::istream& is) override { for (int i = 0; i < 3; ++i) is >> _estimate[i]; return true; }
+    bool write(std::ostream& os) const override { for (int i = 0; i < 3; ++i) os << _estimate[i] << " "; return os.good(); }
+};
+class EdgeGyrBias : public BaseUnaryEdge<3, Vector3d, VertexGyrBias> {
+public:
+    EdgeGyrBias() { allocJacobians({3}); }
+    Matrix3d dRbij, J_dR_bg, Rwbi, Rwbj;
+    void computeError() override {                    // cpp:1263-1275: Log((dRbij Exp(J bg))^T Rwbi^T Rwbj)
+        const Vector3d& bg = static_cast<const VertexGyrBias*>(_vertices[0])->estimate();
+        const plba::M3 Jm = m3(J_dR_bg);
+        const plba::M3 dRbg = plba::q_to_R(plba::so3_exp(plba::mul(Jm, plba::v3(bg[0], bg[1], bg[2]))));
+        const plba::M3 E = plba::mul(plba::mulAtB(plba::mul(m3(dRbij), dRbg), plba::transpose(m3(Rwbi))), m3(Rwbj));
+        const plba::V3 w = plba::so3_log(plba::q_normalized(plba::R_to_q(E)));       // Sophus::SO3(Matrix3d) normalises
+        _error[0] = w.x; _error[1] = w.y; _error[2] = w.z;
+    }
+    void linearizeOplus() override {                  // cpp:1277-1287: evaluated WITHOUT the bias term, as the reference does
+        const plba::M3 E = plba::mul(plba::mulAtB(m3(dRbij), plba::transpose(m3(Rwbi))), m3(Rwbj));
+        const plba::V3 w = plba::so3_log(plba::q_normalized(plba::R_to_q(E)));
+        const plba::M3 Jlinv = plba::so3_JrInv(plba::v3(-w.x, -w.y, -w.z));          // JacobianLInv(w) = JacobianRInv(-w)
+        const plba::M3 Jx = plba::mul(Jlinv, m3(J_dR_bg));
+        for (int i = 0; i < 9; ++i) _jac[0][i] = -Jx.a[i];
+    }
+    double chi2() const override { return chi2FromError(); }
+private:
+    static plba::M3 m3(const Matrix3d& A) { plba::M3 m; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m.a[i * 3 + j] = A(i, j); return m; }
+};
+
 class EdgeMarginalization : public BaseMultiEdge<-1, MarginalizationInfo> {
 public:
     void setDimension(int d) { _dimension = d; _info.assign((size_t)d * d, 0.0); _error.assign(d, 0.0); }

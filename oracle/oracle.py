@@ -53,6 +53,7 @@ def lib():
             "orc_preint_update": [dp, dp, dp, C.c_double, C.c_double, C.c_double],
             "orc_se3_exp": [dp, dp, dp], "orc_se3_mul": [dp] * 6, "orc_se3_map": [dp] * 4, "orc_se3_log": [dp, dp, dp],
             "orc_se3_oplus": [dp] * 5,
+            "orc_eval_gyrbias_edge": [dp] * 7,
             "orc_eval_se3_edge": [C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip],
         }
         for name, args in sigs.items():

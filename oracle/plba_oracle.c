@@ -2140,3 +2140,24 @@ void orc_eval_se3_edge(int kind, const double* cam, const double* q, const doubl
     }
     (void)D;
 }
+
+/* EdgeGyrBias (IMU/g2otypes.cpp:1263-1287): err = Log((dRbij Exp(J bg))^T Rwbi^T Rwbj); J = -JlInv(Log(dRbij^T Rwbi^T Rwbj)) J_dR_bg
+ * (the Jacobian is evaluated without the bias term, as coded). All matrices row-major. */
+void orc_eval_gyrbias_edge(const double* dRbij, const double* JdRbg, const double* Rwbi, const double* Rwbj, const double* bg,
+                           double* err3, double* J9) {
+    double w[3], q[4], dRbg[9], A[9], At[9], RiT[9], B[9], E[9];
+    m3_v(JdRbg, bg, w);
+    so3_exp(w, q); q_to_R(q, dRbg);
+    m3_mul(dRbij, dRbg, A); m3_T(A, At); m3_T(Rwbi, RiT);
+    m3_mul(At, RiT, B); m3_mul(B, Rwbj, E);
+    R_to_q(E, q); q_normalize(q); so3_log(q, err3);
+    if (J9) {
+        double l[3], nl[3], Jl[9], Jx[9];
+        m3_T(dRbij, At); m3_mul(At, RiT, B); m3_mul(B, Rwbj, E);
+        R_to_q(E, q); q_normalize(q); so3_log(q, l);
+        nl[0] = -l[0]; nl[1] = -l[1]; nl[2] = -l[2];
+        so3_JrInv(nl, Jl);                      /* JacobianLInv(w) = JacobianRInv(-w), IMU/so3.h */
+        m3_mul(Jl, JdRbg, Jx);
+        for (int i = 0; i < 9; ++i) J9[i] = -Jx[i];
+    }
+}

@@ -128,3 +128,88 @@ def test_stereo_projection_keeps_the_float_inverse_depth(shim, orc):
         ur = u - (float(np.float32(CAM[4]) * invz) if kind == 1 else CAM[4] * float(invz))
         assert err[0] == -u and err[2] == -ur
         assert err[0] != -(X[0] / X[2] * CAM[0] + CAM[2])       # a double 1/z would give a different pixel
+
+
+# ---- API-surface types of IMU/g2otypes.h ---------------------------------------------------------------------------
+def _cam_vec(pkg, orc):
+    w = pkg.window
+    return orc.cam_vec(dict(fx=w.FX, fy=w.FY, cx=w.CX, cy=w.CY, Rbc=w.T_BS[:3, :3], Pbc=w.T_BS[:3, 3]))
+
+
+def _nav_in_front(pkg, orc, rng):
+    """a keyframe state and a world point 1-8 m in front of its camera"""
+    w = pkg.window
+    Rwb = w.exp_so3(rng.normal(size=3) * 0.8)
+    Pwb = rng.normal(size=3)
+    nav = orc.nav_vec(Pwb, rng.normal(size=3), w.quat_from_R(Rwb))
+    Rbc, Pbc = w.T_BS[:3, :3], w.T_BS[:3, 3]
+    Pc = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1, 1), rng.uniform(1, 8)])
+    Pw = Rwb @ (Rbc @ Pc + Pbc) + Pwb
+    return nav, Pw
+
+
+def test_pvr_point_only_pose_edge(shim, orc, pkg):
+    """EdgeNavStatePVRPointXYZOnlyPose == the pose block of EdgeNavStatePVRPointXYZ (IMU/g2otypes.cpp:343-394 vs 286-341)"""
+    rng = np.random.default_rng(21)
+    cam = _cam_vec(pkg, orc)
+    shim.shim_eval_pvr_point_onlypose.restype = None
+    for _ in range(20):
+        nav, Pw = _nav_in_front(pkg, orc, rng)
+        obs = rng.uniform(100, 400, size=2)
+        e, J, dpos = np.zeros(2), np.zeros((2, 9)), C.c_int(0)
+        shim.shim_eval_pvr_point_onlypose(_d(cam), _d(nav), _d(Pw), _d(obs), _d(e), _d(J), C.byref(dpos))
+        eo, Ji, Jj, dpo = orc.eval_point_edge(cam, nav, Pw, obs)
+        assert np.allclose(e, eo, atol=1e-10) and np.allclose(J, Jj.reshape(2, 9), rtol=1e-11, atol=1e-11) and dpos.value == 1 == int(dpo)
+        assert np.all(J[:, 3:6] == 0)
+
+
+def test_line_point_edge(shim, orc, pkg):
+    """EdgeNavStateLinePoint (IMU/g2otypes.h:919-1000, .cpp:1383-1421) == row 0 of the two-end-point line edge; the
+    reference's own test/test.cpp scenario is the known answer (603, 0, 0)"""
+    rng = np.random.default_rng(22)
+    cam = _cam_vec(pkg, orc)
+    shim.shim_eval_linepoint.restype = None
+    for _ in range(20):
+        nav, Pw = _nav_in_front(pkg, orc, rng)
+        l = rng.normal(size=3); l /= np.linalg.norm(l[:2])
+        e, Ji, Jj, dpos = np.zeros(3), np.zeros((3, 3)), np.zeros((3, 9)), C.c_int(0)
+        shim.shim_eval_linepoint(_d(cam), _d(nav), _d(Pw), _d(l), _d(e), _d(Ji), _d(Jj), C.byref(dpos))
+        assert np.allclose(e, orc.eval_linepoint_edge(cam, nav, Pw, l), atol=1e-10) and e[1] == 0 and e[2] == 0
+        eo, Jio, Jjo, _ = orc.eval_line_edge(cam, nav, np.concatenate([Pw, Pw]), l, fix_q1=0)
+        assert np.allclose(Ji[0], Jio.reshape(3, 6)[0, :3], rtol=1e-11, atol=1e-11)
+        assert np.allclose(Jj[0], Jjo.reshape(3, 9)[0], rtol=1e-11, atol=1e-11)
+        assert np.all(Ji[1:] == 0) and np.all(Jj[1:] == 0) and dpos.value == 1
+    # /root/reference/test/test.cpp:15-48: identity pose and extrinsics, fx=fy=cx=cy=100, P=(5,5,5), measurement (1,2,3)
+    camt = orc.cam_vec(dict(fx=100.0, fy=100.0, cx=100.0, cy=100.0, Rbc=np.eye(3), Pbc=np.zeros(3)))
+    navt = orc.nav_vec(np.zeros(3), np.zeros(3), np.array([0, 0, 0, 1.0]))
+    e, Ji, Jj, dpos = np.zeros(3), np.zeros((3, 3)), np.zeros((3, 9)), C.c_int(0)
+    shim.shim_eval_linepoint(_d(camt), _d(navt), _d(np.array([5.0, 5.0, 5.0])), _d(np.array([1.0, 2.0, 3.0])), _d(e), _d(Ji), _d(Jj), C.byref(dpos))
+    assert np.array_equal(e, [603.0, 0.0, 0.0])
+
+
+def test_gyr_bias_edge(shim, orc, pkg):
+    rng = np.random.default_rng(23)
+    w = pkg.window
+    o = orc.lib().cdll
+    shim.shim_eval_gyrbias.restype = None
+    for _ in range(20):
+        Ri, Rj = w.exp_so3(rng.normal(size=3)), None
+        dR = w.exp_so3(rng.normal(size=3) * 0.3)
+        Rj = Ri @ dR @ w.exp_so3(rng.normal(size=3) * 0.02)
+        Jg = -np.eye(3) * 0.25 + rng.normal(size=(3, 3)) * 0.01
+        bg = rng.normal(size=3) * 0.01
+        args = [np.ascontiguousarray(a) for a in (dR, Jg, Ri, Rj, bg)]
+        e, J, eo, Jo = np.zeros(3), np.zeros((3, 3)), np.zeros(3), np.zeros((3, 3))
+        shim.shim_eval_gyrbias(*[_d(a) for a in args], _d(e), _d(J))
+        o.orc_eval_gyrbias_edge(*[_d(a) for a in args], _d(eo), _d(Jo))
+        assert np.allclose(e, eo, atol=1e-13) and np.allclose(J, Jo, rtol=1e-12, atol=1e-13)
+        # the analytic Jacobian is the derivative at bg = 0 (IMU/g2otypes.cpp:1277-1287 drops the bias term)
+        z = np.zeros(3)
+        fd = np.zeros((3, 3))
+        for c in range(3):
+            h = np.zeros(3); h[c] = 1e-6
+            ep, em = np.zeros(3), np.zeros(3)
+            shim.shim_eval_gyrbias(*[_d(a) for a in args[:4]], _d(z + h), _d(ep), _d(J))
+            shim.shim_eval_gyrbias(*[_d(a) for a in args[:4]], _d(z - h), _d(em), _d(J))
+            fd[:, c] = (ep - em) / 2e-6
+        assert np.allclose(fd, J, atol=1e-6)

@@ -67,4 +67,52 @@ void shim_eval_se3_edge(int kind, const double* cam, const double* q, const doub
     }
 }
 
+
+static NavState make_nav(const double* nav22) {
+    NavState ns;
+    double* s = ns.raw();
+    for (int i = 0; i < 22; ++i) s[i] = nav22[i];
+    return ns;
+}
+static void set_cam(const double* camv, double& fx, double& fy, double& cx, double& cy, Matrix3d& Rbc, Vector3d& Pbc) {
+    fx = camv[0]; fy = camv[1]; cx = camv[2]; cy = camv[3];
+    for (int i = 0; i < 3; ++i) { Pbc[i] = camv[13 + i]; for (int j = 0; j < 3; ++j) Rbc(i, j) = camv[4 + i * 3 + j]; }
+}
+// camv = fx fy cx cy Rbc(9, row-major) Pbc(3)  (oracle.cam_vec); nav22 = P V q(xyzw) bg ba dbg dba
+void shim_eval_pvr_point_onlypose(const double* camv, const double* nav22, const double* Pw, const double* obs, double* err2, double* J18, int* dpos) {
+    double fx, fy, cx, cy; Matrix3d Rbc; Vector3d Pbc;
+    set_cam(camv, fx, fy, cx, cy, Rbc, Pbc);
+    VertexNavStatePVR v; v.setEstimate(make_nav(nav22));
+    EdgeNavStatePVRPointXYZOnlyPose e;
+    e.SetParams(fx, fy, cx, cy, Rbc, Pbc, Vector3d(Pw[0], Pw[1], Pw[2]));
+    e.setVertex(0, &v); e.setMeasurement(Vector2d(obs[0], obs[1]));
+    e.computeError(); e.linearizeOplus();
+    for (int i = 0; i < 2; ++i) err2[i] = e.error()[i];
+    for (int i = 0; i < 18; ++i) J18[i] = e.jacobianOplusXi()[i];
+    *dpos = e.isDepthPositive();
+}
+void shim_eval_linepoint(const double* camv, const double* nav22, const double* Pw, const double* obs3, double* err3, double* Ji9, double* Jj27, int* dpos) {
+    double fx, fy, cx, cy; Matrix3d Rbc; Vector3d Pbc;
+    set_cam(camv, fx, fy, cx, cy, Rbc, Pbc);
+    VertexNavStatePVR v; v.setEstimate(make_nav(nav22));
+    VertexLinePoint lp; lp.setEstimate(Vector3d(Pw[0], Pw[1], Pw[2]));
+    EdgeNavStateLinePoint e;
+    e.SetParams(fx, fy, cx, cy, Rbc, Pbc);
+    e.setVertex(0, &lp); e.setVertex(1, &v); e.setMeasurement(Vector3d(obs3[0], obs3[1], obs3[2]));
+    e.computeError(); e.linearizeOplus();
+    for (int i = 0; i < 3; ++i) err3[i] = e.error()[i];
+    for (int i = 0; i < 9; ++i) Ji9[i] = e.jacobianOplusXi()[i];
+    for (int i = 0; i < 27; ++i) Jj27[i] = e.jacobianOplusXj()[i];
+    *dpos = e.isDepthPositive();
+}
+void shim_eval_gyrbias(const double* dRbij, const double* JdRbg, const double* Rwbi, const double* Rwbj, const double* bg, double* err3, double* J9) {
+    VertexGyrBias v; v.setEstimate(Vector3d(bg[0], bg[1], bg[2]));
+    EdgeGyrBias e;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { e.dRbij(i, j) = dRbij[i * 3 + j]; e.J_dR_bg(i, j) = JdRbg[i * 3 + j]; e.Rwbi(i, j) = Rwbi[i * 3 + j]; e.Rwbj(i, j) = Rwbj[i * 3 + j]; }
+    e.setVertex(0, &v);
+    e.computeError(); e.linearizeOplus();
+    for (int i = 0; i < 3; ++i) err3[i] = e.error()[i];
+    for (int i = 0; i < 9; ++i) J9[i] = e.jacobianOplusXi()[i];
+}
+
 }  // extern "C"
