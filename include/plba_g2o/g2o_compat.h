@@ -553,6 +553,183 @@ private:
     static plba::M3 m3(const Matrix3d& A) { plba::M3 m; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m.a[i * 3 + j] = A(i, j); return m; }
 };
 
+// ---- the 15-DoF family (IMU/g2otypes.h:411-695, .cpp:396-1212): position, velocity, rotation and both biases in ONE
+// vertex.  The residual / Jacobian blocks are exactly those of the on-path 9-DoF + 6-DoF edges, re-assembled.
+class VertexNavState : public BaseVertex<15, NavState> {
+public:
+    void setToOriginImpl() override { _estimate = NavState(); }
+    void oplusImpl(const double* u) override { Vector15d v; for (int i = 0; i < 15; ++i) v(i) = u[i]; _estimate.IncSmall(v); }   // cpp:814-818
+    int estimateDimension() const override { return 15; }
+};
+class VertexGravityW : public BaseVertex<2, Vector3d> {      // gravity direction, 2-DoF rotation update (h:472-487, cpp:534-541)
+public:
+    VertexGravityW() { setToOriginImpl(); }
+    void setToOriginImpl() override { _estimate = Vector3d(0, 0, 9.81); }
+    void oplusImpl(const double* u) override {
+        const plba::V3 g = plba::q_rot(plba::so3_exp(plba::v3(u[0], u[1], 0.0)), plba::v3(_estimate[0], _estimate[1], _estimate[2]));
+        _estimate = Vector3d(g.x, g.y, g.z);
+    }
+    int estimateDimension() const override { return 2; }
+};
+
+namespace plba_detail {
+// 15-dim IMU residual (rP, rV, rPhi, rBg, rBa) between two full states, cpp:849-902
+inline void navstate_error(const NavState& i, const NavState& j, const IMUPreintegrator& M, const Vector3d& gw, double* e15) {
+    plba::pvr_error(i.raw(), j.raw(), M.payload(), plba::v3(gw[0], gw[1], gw[2]), e15);
+    plba::bias_error(i.raw(), j.raw(), e15 + 9);
+}
+// Jacobians w.r.t. the two 15-DoF states, cpp:936-1096; Ji, Jj: 15 x 15 row-major
+inline void navstate_jacobians(const NavState& i, const NavState& j, const IMUPreintegrator& M, const Vector3d& gw, const double* e15, double* Ji, double* Jj) {
+    double J0[81] = {0}, J1[81] = {0}, J2[54] = {0};
+    plba::pvr_jacobians(i.raw(), j.raw(), M.payload(), plba::v3(gw[0], gw[1], gw[2]), e15, J0, J1, J2);
+    for (int k = 0; k < 225; ++k) { Ji[k] = 0.0; Jj[k] = 0.0; }
+    for (int r = 0; r < 9; ++r) {
+        for (int c = 0; c < 9; ++c) { Ji[r * 15 + c] = J0[r * 9 + c]; Jj[r * 15 + c] = J1[r * 9 + c]; }
+        for (int c = 0; c < 6; ++c) Ji[r * 15 + 9 + c] = J2[r * 6 + c];
+    }
+    for (int d = 9; d < 15; ++d) { Ji[d * 15 + d] = -1.0; Jj[d * 15 + d] = 1.0; }
+}
+// error of a state against a prior state, cpp:396-433 / 458-495: (P, V, Log(Rprior^-1 R), bg+dbg, ba+dba) differences
+inline void prior_error(const NavState& prior, const NavState& pvr, const NavState& bias, double* e15) {
+    const double* p = prior.raw(); const double* a = pvr.raw(); const double* b = bias.raw();
+    for (int k = 0; k < 6; ++k) e15[k] = p[k] - a[k];
+    const Vector3d w = (prior.Get_R().inverse() * pvr.Get_R()).log();
+    for (int k = 0; k < 3; ++k) {
+        e15[6 + k] = w[k];
+        e15[9 + k] = (p[10 + k] + p[16 + k]) - (b[10 + k] + b[16 + k]);
+        e15[12 + k] = (p[13 + k] + p[19 + k]) - (b[13 + k] + b[19 + k]);
+    }
+}
+inline void prior_pvr_blocks(const NavState& est, const double* e15, double* J, int cols) {   // -R, -I, JrInv(rPhi)
+    const plba::Q4 q = {est.raw()[6], est.raw()[7], est.raw()[8], est.raw()[9]};
+    const plba::M3 R = plba::q_to_R(q), Ji = plba::so3_JrInv(plba::v3(e15[6], e15[7], e15[8]));
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+        J[r * cols + c] = -R.a[r * 3 + c];
+        J[(3 + r) * cols + 3 + c] = (r == c) ? -1.0 : 0.0;
+        J[(6 + r) * cols + 6 + c] = Ji.a[r * 3 + c];
+    }
+}
+}  // namespace plba_detail
+
+class EdgeNavState : public BaseBinaryEdge<15, IMUPreintegrator, VertexNavState, VertexNavState> {   // h:512-533
+public:
+    EdgeNavState() { allocJacobians({15, 15}); }
+    void SetParams(const Vector3d& gw) { GravityVec = gw; }
+    void computeError() override { plba_detail::navstate_error(st(0), st(1), _measurement, GravityVec, _error.data()); }
+    void linearizeOplus() override { plba_detail::navstate_jacobians(st(0), st(1), _measurement, GravityVec, _error.data(), _jac[0].data(), _jac[1].data()); }
+    double chi2() const override { return chi2FromError(); }
+protected:
+    const NavState& st(int k) const { return static_cast<const VertexNavState*>(_vertices[k])->estimate(); }
+    Vector3d GravityVec;
+};
+class EdgeNavStateGw : public BaseMultiEdge<15, IMUPreintegrator> {   // gravity as a third vertex, h:492-506, cpp:545-805
+public:
+    EdgeNavStateGw() { resize(3); allocJacobians({15, 15, 2}); }
+    void computeError() override { plba_detail::navstate_error(st(0), st(1), _measurement, gw(), _error.data()); }
+    void linearizeOplus() override {
+        plba_detail::navstate_jacobians(st(0), st(1), _measurement, gw(), _error.data(), _jac[0].data(), _jac[1].data());
+        const Vector3d g = gw();
+        const double dT = _measurement.getDeltaTime(), dT2 = dT * dT;
+        const plba::Q4 qi = {st(0).raw()[6], st(0).raw()[7], st(0).raw()[8], st(0).raw()[9]};
+        const plba::M3 RiT = plba::transpose(plba::q_to_R(qi)), GH = plba::hat(plba::v3(g[0], g[1], g[2]));
+        std::fill(_jac[2].begin(), _jac[2].end(), 0.0);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 2; ++c) {          // cpp:797-800
+            double s = 0.0;
+            for (int k = 0; k < 3; ++k) s += RiT.a[r * 3 + k] * GH.a[k * 3 + c];
+            J(2, 2, r, c) = 0.5 * dT2 * s;
+            J(2, 2, 3 + r, c) = dT * s;
+        }
+    }
+    double chi2() const override { return chi2FromError(); }
+private:
+    const NavState& st(int k) const { return static_cast<const VertexNavState*>(_vertices[k])->estimate(); }
+    Vector3d gw() const { return static_cast<const VertexGravityW*>(_vertices[2])->estimate(); }
+};
+class EdgeNavStatePrior : public BaseUnaryEdge<15, NavState, VertexNavState> {   // h:453-466, cpp:458-507
+public:
+    EdgeNavStatePrior() { allocJacobians({15}); }
+    void computeError() override { const NavState& e = static_cast<const VertexNavState*>(_vertices[0])->estimate(); plba_detail::prior_error(_measurement, e, e, _error.data()); }
+    void linearizeOplus() override {
+        std::fill(_jac[0].begin(), _jac[0].end(), 0.0);
+        plba_detail::prior_pvr_blocks(static_cast<const VertexNavState*>(_vertices[0])->estimate(), _error.data(), _jac[0].data(), 15);
+        for (int d = 9; d < 15; ++d) J(0, 15, d, d) = -1.0;
+    }
+    double chi2() const override { return chi2FromError(); }
+};
+class EdgeNavStatePriorPVRBias : public BaseBinaryEdge<15, NavState, VertexNavStatePVR, VertexNavStateBias> {   // h:411-427, cpp:396-450
+public:
+    EdgeNavStatePriorPVRBias() { allocJacobians({9, 6}); }
+    void computeError() override {
+        const NavState& a = static_cast<const VertexNavStatePVR*>(_vertices[0])->estimate();
+        const NavState& b = static_cast<const VertexNavStateBias*>(_vertices[1])->estimate();
+        plba_detail::prior_error(_measurement, a, b, _error.data());
+        double dg = 0, da = 0;
+        for (int k = 0; k < 3; ++k) { dg += (a.raw()[10 + k] - b.raw()[10 + k]) * (a.raw()[10 + k] - b.raw()[10 + k]); da += (a.raw()[13 + k] - b.raw()[13 + k]) * (a.raw()[13 + k] - b.raw()[13 + k]); }
+        if (std::sqrt(dg) > 1e-6 || std::sqrt(da) > 1e-6) std::cerr << "bias not equal for PVR/Bias vertex in EdgeNavStatePriorPVRBias" << std::endl;   // cpp:424-431
+    }
+    void linearizeOplus() override {
+        std::fill(_jac[0].begin(), _jac[0].end(), 0.0); std::fill(_jac[1].begin(), _jac[1].end(), 0.0);
+        plba_detail::prior_pvr_blocks(static_cast<const VertexNavStatePVR*>(_vertices[0])->estimate(), _error.data(), _jac[0].data(), 9);
+        for (int d = 0; d < 6; ++d) J(1, 6, 9 + d, d) = -1.0;
+    }
+    double chi2() const override { return chi2FromError(); }
+};
+// reprojection edges against the 15-DoF state (h:540-695, cpp:1105-1212): the 9-DoF edges' blocks in 15 columns
+class EdgeNavStatePointXYZ : public BaseBinaryEdge<2, Vector2d, VertexLMPointXYZ, VertexNavState> {
+public:
+    EdgeNavStatePointXYZ() { allocJacobians({3, 15}); }
+    void SetParams(const double& fx_, const double& fy_, const double& cx_, const double& cy_, const Matrix3d& Rbc_, const Vector3d& Pbc_) {
+        cam.fx = fx_; cam.fy = fy_; cam.cx = cx_; cam.cy = cy_; cam.set = true;
+        for (int i = 0; i < 3; ++i) { cam.Pbc[i] = Pbc_(i); for (int j = 0; j < 3; ++j) cam.Rbc[i * 3 + j] = Rbc_(i, j); }
+    }
+    void computeError() override { eval(false); }
+    void linearizeOplus() override { eval(true); }
+    bool isDepthPositive() { eval(false); return _depth_cache; }
+    double chi2() const override { return chi2FromError(); }
+    CamParams cam;
+private:
+    void eval(bool jac) {
+        const plba::Cam c = plba_make_cam(cam);
+        double kc[12], Jp[12], Jl[6];
+        plba::kfcam_make(c, static_cast<const VertexNavState*>(_vertices[1])->estimate().raw(), kc);
+        const Vector3d& P = static_cast<const VertexLMPointXYZ*>(_vertices[0])->estimate();
+        bool dpos = true;
+        plba::point_edge(c, kc, plba::v3(P[0], P[1], P[2]), _measurement[0], _measurement[1], _error.data(), Jp, Jl, dpos, jac);
+        _depth_cache = dpos;
+        if (jac) {
+            std::fill(_jac[1].begin(), _jac[1].end(), 0.0);
+            for (int r = 0; r < 2; ++r) for (int k = 0; k < 3; ++k) { J(0, 3, r, k) = Jl[r * 3 + k]; J(1, 15, r, k) = Jp[r * 6 + k]; J(1, 15, r, 6 + k) = Jp[r * 6 + 3 + k]; }
+        }
+    }
+};
+class EdgeNavStatePointXYZOnlyPose : public BaseUnaryEdge<2, Vector2d, VertexNavState> {
+public:
+    EdgeNavStatePointXYZOnlyPose() { allocJacobians({15}); }
+    void SetParams(const double& fx_, const double& fy_, const double& cx_, const double& cy_, const Matrix3d& Rbc_, const Vector3d& Pbc_, const Vector3d& Pw_) {
+        cam.fx = fx_; cam.fy = fy_; cam.cx = cx_; cam.cy = cy_; cam.set = true;
+        for (int i = 0; i < 3; ++i) { cam.Pbc[i] = Pbc_(i); Pw[i] = Pw_(i); for (int j = 0; j < 3; ++j) cam.Rbc[i * 3 + j] = Rbc_(i, j); }
+    }
+    void computeError() override { eval(false); }
+    void linearizeOplus() override { eval(true); }
+    bool isDepthPositive() { eval(false); return _depth_cache; }
+    double chi2() const override { return chi2FromError(); }
+    CamParams cam;
+    double Pw[3] = {0, 0, 0};
+private:
+    void eval(bool jac) {
+        const plba::Cam c = plba_make_cam(cam);
+        double kc[12], Jp[12], Jl[6];
+        plba::kfcam_make(c, static_cast<const VertexNavState*>(_vertices[0])->estimate().raw(), kc);
+        bool dpos = true;
+        plba::point_edge(c, kc, plba::v3(Pw[0], Pw[1], Pw[2]), _measurement[0], _measurement[1], _error.data(), Jp, Jl, dpos, jac);
+        _depth_cache = dpos;
+        if (jac) {
+            std::fill(_jac[0].begin(), _jac[0].end(), 0.0);
+            for (int r = 0; r < 2; ++r) for (int k = 0; k < 3; ++k) { J(0, 15, r, k) = Jp[r * 6 + k]; J(0, 15, r, 6 + k) = Jp[r * 6 + 3 + k]; }
+        }
+    }
+};
+
 class EdgeMarginalization : public BaseMultiEdge<-1, MarginalizationInfo> {
 public:
     void setDimension(int d) { _dimension = d; _info.assign((size_t)d * d, 0.0); _error.assign(d, 0.0); }

@@ -213,3 +213,118 @@ def test_gyr_bias_edge(shim, orc, pkg):
             shim.shim_eval_gyrbias(*[_d(a) for a in args[:4]], _d(z - h), _d(em), _d(J))
             fd[:, c] = (ep - em) / 2e-6
         assert np.allclose(fd, J, atol=1e-6)
+
+
+# ---- the 15-DoF family (IMU/g2otypes.h:411-695) ------------------------------------------------------------------------
+def _imu_pair(pkg, orc, rng):
+    """two consecutive full states roughly consistent with a 0.25 s preintegrated measurement"""
+    w = pkg.window
+    S = 50
+    om = rng.normal(size=(1, S, 3)) * 0.2
+    ac = rng.normal(size=(1, S, 3)) * 1.0 + np.array([0, 0, 9.81])
+    pre = w.preintegrate(om, ac, 0.005)[0]
+    Ri = w.exp_so3(rng.normal(size=3) * 0.5)
+    Pi, Vi = rng.normal(size=3), rng.normal(size=3)
+    gw = np.array([0, 0, -9.81])
+    dT = pre[141]
+    dR = pre[6:15].reshape(3, 3)
+    Pj = Pi + Vi * dT + 0.5 * gw * dT * dT + Ri @ pre[0:3] + rng.normal(size=3) * 0.02
+    Vj = Vi + gw * dT + Ri @ pre[3:6] + rng.normal(size=3) * 0.02
+    Rj = Ri @ dR @ w.exp_so3(rng.normal(size=3) * 0.02)
+    bg, ba = rng.normal(size=3) * 1e-3, rng.normal(size=3) * 1e-2
+    navi = orc.nav_vec(Pi, Vi, w.quat_from_R(Ri), bg, ba, rng.normal(size=3) * 1e-3, rng.normal(size=3) * 1e-2)
+    navj = orc.nav_vec(Pj, Vj, w.quat_from_R(Rj), bg, ba, rng.normal(size=3) * 1e-3, rng.normal(size=3) * 1e-2)
+    return gw, navi, navj, pre
+
+
+def _nav_edge(shim, gw, navi, navj, pre, with_gw):
+    e, Ji, Jj, Jg = np.zeros(15), np.zeros((15, 15)), np.zeros((15, 15)), np.zeros((15, 2))
+    shim.shim_navstate_edge(_d(gw), _d(navi), _d(navj), _d(pre), int(with_gw), _d(e), _d(Ji), _d(Jj), _d(Jg))
+    return e, Ji, Jj, Jg
+
+
+def _oplus(shim, fn, nav, u):
+    out = np.zeros(22)
+    getattr(shim, fn)(_d(nav), _d(np.ascontiguousarray(u)), _d(out))
+    return out
+
+
+@pytest.mark.parametrize("with_gw", [False, True])
+def test_navstate_imu_edges(shim, orc, pkg, with_gw):
+    """EdgeNavState / EdgeNavStateGw: residual = (EdgeNavStatePVR, EdgeNavStateBias) of the on-path oracle; Jacobians
+    against finite differences through VertexNavState::oplusImpl (and VertexGravityW's 2-DoF update)"""
+    rng = np.random.default_rng(31 + with_gw)
+    for f in ("shim_navstate_edge", "shim_navstate_oplus", "shim_gravity_oplus"):
+        getattr(shim, f).restype = None
+    for _ in range(6):
+        gw, navi, navj, pre = _imu_pair(pkg, orc, rng)
+        e, Ji, Jj, Jg = _nav_edge(shim, gw, navi, navj, pre, with_gw)
+        e9 = orc.eval_pvr_edge(gw, navi, navj, navi, pre)[0]
+        assert np.allclose(e[:9], e9, atol=1e-12)
+        assert np.allclose(e[9:12], (navj[10:13] + navj[16:19]) - (navi[10:13] + navi[16:19]), atol=1e-15)
+        assert np.allclose(e[12:15], (navj[13:16] + navj[19:22]) - (navi[13:16] + navi[19:22]), atol=1e-15)
+        h = 1e-6
+        for which, J in ((0, Ji), (1, Jj)):
+            for c in range(15):
+                u = np.zeros(15); u[c] = h
+                a = [navi, navj]; b = [navi, navj]
+                a[which] = _oplus(shim, "shim_navstate_oplus", a[which], u); b[which] = _oplus(shim, "shim_navstate_oplus", b[which], -u)
+                fd = (_nav_edge(shim, gw, a[0], a[1], pre, with_gw)[0] - _nav_edge(shim, gw, b[0], b[1], pre, with_gw)[0]) / (2 * h)
+                # the rotation-residual rows use the first-order JrInv forms of the paper: exact only for small residuals
+                assert np.abs(fd - J[:, c]).max() < 2e-3 * max(1.0, np.abs(J[:, c]).max()), (which, c)
+        if with_gw:
+            for c in range(2):
+                u = np.zeros(2); u[c] = h
+                ga, gb = np.zeros(3), np.zeros(3)
+                shim.shim_gravity_oplus(_d(gw), _d(u), _d(ga)); shim.shim_gravity_oplus(_d(gw), _d(-u), _d(gb))
+                fd = (_nav_edge(shim, ga, navi, navj, pre, True)[0] - _nav_edge(shim, gb, navi, navj, pre, True)[0]) / (2 * h)
+                assert np.abs(fd - Jg[:, c]).max() < 1e-6
+            assert np.all(Jg[6:] == 0)
+    # gravity vertex: 2-DoF rotation keeps the norm; origin is (0, 0, 9.81)
+    g = np.zeros(3)
+    shim.shim_gravity_oplus(_d(np.array([0, 0, 9.81])), _d(np.array([0.1, -0.2])), _d(g))
+    assert abs(np.linalg.norm(g) - 9.81) < 1e-12 and abs(g[0]) > 0.1
+
+
+def test_navstate_prior_edges(shim, orc, pkg):
+    rng = np.random.default_rng(33)
+    for f in ("shim_prior_edge", "shim_prior_pvrbias_edge", "shim_pvr_oplus", "shim_bias_oplus"):
+        getattr(shim, f).restype = None
+    w = pkg.window
+    for _ in range(6):
+        _, prior, _, _ = _imu_pair(pkg, orc, rng)
+        est = _oplus(shim, "shim_navstate_oplus", prior, rng.normal(size=15) * 0.05)
+        e, J = np.zeros(15), np.zeros((15, 15))
+        shim.shim_prior_edge(_d(prior), _d(est), _d(e), _d(J))
+        assert np.allclose(e[:6], prior[:6] - est[:6], atol=1e-15)
+        Rp, Re = orc.quat_to_R(prior[6:10]), orc.quat_to_R(est[6:10])
+        assert np.allclose(e[6:9], w.log_so3(Rp.T @ Re), atol=1e-10)
+        assert np.allclose(e[9:15], (prior[10:16] + prior[16:22]) - (est[10:16] + est[16:22]), atol=1e-15)
+        h = 1e-6
+        for c in range(15):
+            u = np.zeros(15); u[c] = h
+            ea, eb, Jt = np.zeros(15), np.zeros(15), np.zeros((15, 15))
+            shim.shim_prior_edge(_d(prior), _d(_oplus(shim, "shim_navstate_oplus", est, u)), _d(ea), _d(Jt))
+            shim.shim_prior_edge(_d(prior), _d(_oplus(shim, "shim_navstate_oplus", est, -u)), _d(eb), _d(Jt))
+            assert np.abs((ea - eb) / (2 * h) - J[:, c]).max() < 1e-6, c
+        # the two-vertex form: same residual, Jacobian split 9 | 6
+        e2, Ja, Jb = np.zeros(15), np.zeros((15, 9)), np.zeros((15, 6))
+        shim.shim_prior_pvrbias_edge(_d(prior), _d(est), _d(est), _d(e2), _d(Ja), _d(Jb))
+        assert np.array_equal(e2, e) and np.array_equal(Ja, J[:, :9]) and np.array_equal(Jb, J[:, 9:])
+
+
+def test_navstate_point_edges(shim, orc, pkg):
+    rng = np.random.default_rng(34)
+    cam = _cam_vec(pkg, orc)
+    shim.shim_navstate_point.restype = None
+    for _ in range(10):
+        nav, Pw = _nav_in_front(pkg, orc, rng)
+        obs = rng.uniform(100, 400, size=2)
+        eo, Jio, Jjo, _ = orc.eval_point_edge(cam, nav, Pw, obs)
+        for only_pose in (0, 1):
+            e, Ji, Jj, dpos = np.zeros(2), np.zeros((2, 3)), np.zeros((2, 15)), C.c_int(0)
+            shim.shim_navstate_point(_d(cam), _d(nav), _d(Pw), _d(obs), only_pose, _d(e), _d(Ji), _d(Jj), C.byref(dpos))
+            assert np.allclose(e, eo, atol=1e-10) and dpos.value == 1
+            assert np.allclose(Jj[:, :9], Jjo, rtol=1e-11, atol=1e-11) and np.all(Jj[:, 9:] == 0)
+            if not only_pose:
+                assert np.allclose(Ji, Jio, rtol=1e-11, atol=1e-11)

@@ -115,4 +115,65 @@ void shim_eval_gyrbias(const double* dRbij, const double* JdRbg, const double* R
     for (int i = 0; i < 9; ++i) J9[i] = e.jacobianOplusXi()[i];
 }
 
+
+static void put_nav(const NavState& ns, double* out22) { for (int i = 0; i < 22; ++i) out22[i] = ns.raw()[i]; }
+static void cp(const std::vector<double>& s, double* d) { if (d) for (size_t i = 0; i < s.size(); ++i) d[i] = s[i]; }
+
+void shim_navstate_oplus(const double* nav22, const double* u15, double* out22) {
+    VertexNavState v; v.setEstimate(make_nav(nav22)); v.oplusImpl(u15); put_nav(v.estimate(), out22);
+}
+void shim_gravity_oplus(const double* g3, const double* u2, double* out3) {
+    VertexGravityW v; v.setEstimate(Vector3d(g3[0], g3[1], g3[2])); v.oplusImpl(u2);
+    for (int i = 0; i < 3; ++i) out3[i] = v.estimate()[i];
+}
+void shim_navstate_edge(const double* gw, const double* navi, const double* navj, const double* pre142, int with_gw_vertex,
+                        double* err15, double* Ji225, double* Jj225, double* Jg30) {
+    VertexNavState vi, vj; vi.setEstimate(make_nav(navi)); vj.setEstimate(make_nav(navj));
+    IMUPreintegrator M; M.setPayload(pre142);
+    if (!with_gw_vertex) {
+        EdgeNavState e; e.SetParams(Vector3d(gw[0], gw[1], gw[2]));
+        e.setVertex(0, &vi); e.setVertex(1, &vj); e.setMeasurement(M);
+        e.computeError(); e.linearizeOplus();
+        cp(e.error(), err15); cp(e.jacobianOplusXi(), Ji225); cp(e.jacobianOplusXj(), Jj225);
+    } else {
+        VertexGravityW vg; vg.setEstimate(Vector3d(gw[0], gw[1], gw[2]));
+        EdgeNavStateGw e;
+        e.setVertex(0, &vi); e.setVertex(1, &vj); e.setVertex(2, &vg); e.setMeasurement(M);
+        e.computeError(); e.linearizeOplus();
+        cp(e.error(), err15); cp(e.jacobianOplus(0), Ji225); cp(e.jacobianOplus(1), Jj225); cp(e.jacobianOplus(2), Jg30);
+    }
+}
+void shim_prior_edge(const double* prior22, const double* est22, double* err15, double* J225) {
+    VertexNavState v; v.setEstimate(make_nav(est22));
+    EdgeNavStatePrior e; e.setVertex(0, &v); e.setMeasurement(make_nav(prior22));
+    e.computeError(); e.linearizeOplus();
+    cp(e.error(), err15); cp(e.jacobianOplusXi(), J225);
+}
+void shim_prior_pvrbias_edge(const double* prior22, const double* pvr22, const double* bias22, double* err15, double* Ji135, double* Jj90) {
+    VertexNavStatePVR a; a.setEstimate(make_nav(pvr22));
+    VertexNavStateBias b; b.setEstimate(make_nav(bias22));
+    EdgeNavStatePriorPVRBias e; e.setVertex(0, &a); e.setVertex(1, &b); e.setMeasurement(make_nav(prior22));
+    e.computeError(); e.linearizeOplus();
+    cp(e.error(), err15); cp(e.jacobianOplusXi(), Ji135); cp(e.jacobianOplusXj(), Jj90);
+}
+void shim_pvr_oplus(const double* nav22, const double* u9, double* out22) { VertexNavStatePVR v; v.setEstimate(make_nav(nav22)); v.oplusImpl(u9); put_nav(v.estimate(), out22); }
+void shim_bias_oplus(const double* nav22, const double* u6, double* out22) { VertexNavStateBias v; v.setEstimate(make_nav(nav22)); v.oplusImpl(u6); put_nav(v.estimate(), out22); }
+void shim_navstate_point(const double* camv, const double* nav22, const double* Pw, const double* obs, int only_pose, double* err2, double* Ji6, double* Jj30, int* dpos) {
+    double fx, fy, cx, cy; Matrix3d Rbc; Vector3d Pbc;
+    set_cam(camv, fx, fy, cx, cy, Rbc, Pbc);
+    VertexNavState v; v.setEstimate(make_nav(nav22));
+    if (only_pose) {
+        EdgeNavStatePointXYZOnlyPose e; e.SetParams(fx, fy, cx, cy, Rbc, Pbc, Vector3d(Pw[0], Pw[1], Pw[2]));
+        e.setVertex(0, &v); e.setMeasurement(Vector2d(obs[0], obs[1]));
+        e.computeError(); e.linearizeOplus();
+        cp(e.error(), err2); cp(e.jacobianOplusXi(), Jj30); *dpos = e.isDepthPositive();
+    } else {
+        VertexLMPointXYZ pt; pt.setEstimate(Vector3d(Pw[0], Pw[1], Pw[2]));
+        EdgeNavStatePointXYZ e; e.SetParams(fx, fy, cx, cy, Rbc, Pbc);
+        e.setVertex(0, &pt); e.setVertex(1, &v); e.setMeasurement(Vector2d(obs[0], obs[1]));
+        e.computeError(); e.linearizeOplus();
+        cp(e.error(), err2); cp(e.jacobianOplusXi(), Ji6); cp(e.jacobianOplusXj(), Jj30); *dpos = e.isDepthPositive();
+    }
+}
+
 }  // extern "C"
