@@ -63,7 +63,9 @@ typedef struct {
     int    profile;             /* HIP-event timing into plba_stats.ms_phase: 1 = the dense factorisation launches only
                                    (two events per trial), 2 = every phase (0 = off)            */
     int    factor_block;        /* block width of the dense factorisation: 32 or 64                (32)   */
-    int    reserved[4];
+    int    factor_flow;         /* 1 = the whole factorisation as ONE dataflow launch (factor_block 32 with use_mfma;
+                                   experimental: measured slower at P = 735), 0 = one launch per block step (0) */
+    int    reserved[3];
 } plba_options;
 
 void plba_default_options(plba_options* o);

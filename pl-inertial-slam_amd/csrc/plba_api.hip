@@ -51,6 +51,7 @@ void plba_default_options(plba_options* o) {
     o->device = -1;
     o->use_mfma = 1;
     o->factor_block = 32;
+    o->factor_flow = 0;
 }
 const char* plba_backend_name(void) { return "hip-gfx950"; }
 const char* plba_last_error(const plba_problem* p) { return p ? p->err : g_create_err; }
@@ -265,15 +266,16 @@ int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double
     memcpy(&h[(size_t)Ppad * ld], b, (size_t)n * 8);
     DArr<double> sys, Lfac, xx, Linv, LT32, rd32;
     DArr<Ctrl> ctrl;
-    DArr<int> flags;
+    DArr<int> flags, cflags;
     HIPCK(p, sys.upload(h)); HIPCK(p, Lfac.alloc(sysn)); HIPCK(p, xx.alloc(ld)); HIPCK(p, ctrl.alloc(1));
     HIPCK(p, Linv.alloc((size_t)(Ppad / TILE) * TILE * TILE)); HIPCK(p, flags.alloc(Ppad / TILE));
     HIPCK(p, LT32.alloc((size_t)Ppad * 64)); HIPCK(p, rd32.alloc(Ppad));
+    HIPCK(p, cflags.alloc((size_t)(Ppad / 32 + 2) * (Ppad / 32)));
     Ctrl c0; memset(&c0, 0, sizeof c0); c0.solver_ok = 1;
     HIPCK(p, hipMemcpy(ctrl.p, &c0, sizeof c0, hipMemcpyHostToDevice));
     DevBuf d; memset(&d, 0, sizeof d);
-    d.P = n; d.Ppad = Ppad; d.ld = ld; d.sys = sys.p; d.Lfac = Lfac.p; d.x = xx.p; d.ctrl = ctrl.p; d.Linv = Linv.p; d.flow_flags = flags.p; d.LTblk = LT32.p; d.Linv32 = LT32.p; d.rdblk = rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32;
-    launch_cholesky(d, p->opt.use_mfma != 0, p->stream);
+    d.P = n; d.Ppad = Ppad; d.ld = ld; d.sys = sys.p; d.Lfac = Lfac.p; d.x = xx.p; d.ctrl = ctrl.p; d.Linv = Linv.p; d.flow_flags = flags.p; d.LTblk = LT32.p; d.Linv32 = LT32.p; d.rdblk = rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32; d.chol_flags = cflags.p; d.flow = p->opt.factor_flow != 0;
+    launch_cholesky(d, p->opt.use_mfma != 0, 1, p->stream);
     launch_trsv_back(d, p->opt.use_mfma != 0, 1, p->stream);
     HIPCK(p, hipStreamSynchronize(p->stream));
     HIPCK(p, hipGetLastError());
@@ -410,6 +412,7 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_bimu.alloc(p->ld)); HIPCK(p, p->d_sys.alloc(sysn)); HIPCK(p, p->d_Lfac.alloc(sysn));
     HIPCK(p, p->d_bpg.alloc(p->ld)); HIPCK(p, p->d_x.alloc(p->ld));
     HIPCK(p, p->d_Linv.alloc((size_t)(p->Ppad / TILE) * TILE * TILE)); HIPCK(p, p->d_flow_flags.alloc(p->Ppad / TILE)); p->flow_epoch = 0;
+    HIPCK(p, p->d_chol_flags.alloc((size_t)(p->Ppad / 32 + 2) * (p->Ppad / 32)));
     HIPCK(p, p->d_LT32.alloc((size_t)p->Ppad * 64)); HIPCK(p, p->d_rd32.alloc(p->Ppad));
     HIPCK(p, p->d_chi_part.alloc((size_t)(E + 255) / 256 + 1)); HIPCK(p, p->d_scale_part.alloc((size_t)(L + 255) / 256 + 1));
     HIPCK(p, p->d_maxd_part.alloc((size_t)(L + 255) / 256 + 1)); HIPCK(p, p->d_kfdiag.alloc((size_t)K * 6)); HIPCK(p, p->d_posediag.alloc(p->ld));
@@ -439,7 +442,7 @@ static int prepare(plba_problem* p) {
     d.pr_x0off = p->d_pr_x0off.p; d.pr_off = p->d_pr_off.p; d.pr_x0 = p->d_pr_x0.p; d.pr_J0 = p->d_pr_J0.p; d.pr_r0 = p->d_pr_r0.p;
     d.pr_err = p->d_pr_err.p; d.pr_dx = p->d_pr_dx.p; d.pr_chi = p->d_pr_chi.p;
     d.Hconst = p->d_Hconst.p; d.Himu = p->d_Himu.p; d.bimu = p->d_bimu.p; d.Himu_alt = p->d_Himu2.p; d.bimu_alt = p->d_bimu2.p; d.sys = p->d_sys.p; d.Lfac = p->d_Lfac.p; d.bpg = p->d_bpg.p; d.x = p->d_x.p;
-    d.Linv = p->d_Linv.p; d.flow_flags = p->d_flow_flags.p; d.LTblk = p->d_LT32.p; d.Linv32 = p->d_LT32.p; d.rdblk = p->d_rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32;
+    d.Linv = p->d_Linv.p; d.flow_flags = p->d_flow_flags.p; d.LTblk = p->d_LT32.p; d.Linv32 = p->d_LT32.p; d.rdblk = p->d_rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32; d.chol_flags = p->d_chol_flags.p; d.flow = p->opt.factor_flow != 0;
     d.chi_part = p->d_chi_part.p; d.scale_part = p->d_scale_part.p; d.maxd_part = p->d_maxd_part.p; d.kfdiag = p->d_kfdiag.p; d.posediag = p->d_posediag.p;
     d.ctrl = p->d_ctrl.p; d.trace = p->d_trace.p; d.trace_cap = TRACE_CAP; d.trace_n = p->d_trace_n.p;
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
@@ -530,9 +533,10 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
     MARK(p, 6);
     if (!do_solve) return PLBA_OK;
     MARKF(p, 11);
-    launch_cholesky(d, p->opt.use_mfma != 0, s);
+    const int epoch = ++p->flow_epoch;
+    launch_cholesky(d, p->opt.use_mfma != 0, epoch, s);
     MARKF(p, 12);
-    launch_trsv_back(d, p->opt.use_mfma != 0, ++p->flow_epoch, s);
+    launch_trsv_back(d, p->opt.use_mfma != 0, epoch, s);
     MARK(p, 7);
     launch_backsub(d, p->cur, p->cur ^ 1, s);
     launch_update_kf(d, p->cur, p->cur ^ 1, s);

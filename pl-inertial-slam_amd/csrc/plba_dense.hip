@@ -449,13 +449,38 @@ __device__ __forceinline__ void wait_rs16(Look32& S, int base, int lane) {
 
 #ifdef PLBA_STAMPS
 __device__ unsigned long long g_lstamp[32];
-#define LSTAMP(i) do { if (lane == 0) g_lstamp[i] = __builtin_readcyclecounter(); } while (0)
+#define LSTAMP(i) do { if (lane == 0 && kb == 5) g_lstamp[i] = __builtin_readcyclecounter(); } while (0)
+#define CSTAMP(i) do { if (threadIdx.x == 0 && c == 5) g_lstamp[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define LSTAMP(i) do {} while (0)
+#define CSTAMP(i) do {} while (0)
 #endif
 // tile in sC (row stride LS, complete and visible: call after a barrier that also saw S.pivd / rsflag / mflag / fail
 // reset by look32_reset); all four waves enter.
-__device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, const double* sC, Look32& S, int wv, int lane) {
+// sc1 (agent-coherent, write-through) store / load of data other workgroups of the SAME launch consume
+__device__ __forceinline__ void gstore_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double gload_sc1(const double* p) { return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool FLOW> __device__ __forceinline__ void gput(double* p, double v) { if (FLOW) gstore_sc1(p, v); else *p = v; }
+
+// Side job of wave 2 in the dataflow factorisation: fetch the two tiles of the NEXT chain step into LDS as soon as
+// their helper workgroups have published them (polled between pivots).
+struct NextTiles {
+    const int* fa; const int* fd; int want;      // flags of pre(c+1,c) and diagpre(c+1)
+    const double* A; const double* D; int ld;    // their location in sys
+    double* sA; double* sD;                      // LDS destinations (row stride LS)
+    bool active, done, failed, stamp;
+};
+__device__ __forceinline__ bool flags_ready(const NextTiles& n) {
+    return __hip_atomic_load(const_cast<int*>(n.fa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n.want &&
+           __hip_atomic_load(const_cast<int*>(n.fd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n.want;
+}
+__device__ __forceinline__ void fetch_next_tiles(NextTiles& n, int lane);
+
+// FLOW: called from the single-launch dataflow factorisation: global results go out with sc1 stores, L^-1 is also
+// left in LDS (sLinv, row stride LS) for the same workgroup's next step, and wave 2 prefetches `next`.
+template <bool FLOW>
+__device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, const double* sC, Look32& S, int wv, int lane, double* sLinv = nullptr,
+                                                   NextTiles* next = nullptr) {
     const int li = lane & 15, lk = lane >> 4;
     double* Ig = d.Linv32 + (size_t)kb * 1024;
     if (wv == 0) {
@@ -479,6 +504,7 @@ __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, cons
                 vstore(&S.rsflag[j], 1);
                 done = true;
             }
+            if (FLOW && next->active && !next->done && flags_ready(*next)) fetch_next_tiles(*next, lane);
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SPIN_LIMIT) { bad = true; break; }
         }
@@ -491,10 +517,15 @@ __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int rw = 16 + 4 * e + lk;
-                Lg[(size_t)rw * d.ld + cl] = (cl <= rw) ? S.cols[cl * 32 + slot32(rw)] * rsc : 0.0;
+                gput<FLOW>(&Lg[(size_t)rw * d.ld + cl], (cl <= rw) ? S.cols[cl * 32 + slot32(rw)] * rsc : 0.0);
             }
         }
         if ((__any(bad) || S.fail) && lane == 0) d.ctrl->solver_ok = 0;
+        if (FLOW && next->active && !next->done) {      // the helpers were slower than the pivot sweep: wait for them now
+            int spins2 = 0;
+            while (!flags_ready(*next)) { __builtin_amdgcn_s_sleep(2); if (++spins2 > (1 << 18)) { next->failed = true; break; } }
+            fetch_next_tiles(*next, lane);
+        }
         LSTAMP(11);
     } else if (wv == 1) {
         LSTAMP(4);
@@ -520,7 +551,9 @@ __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, cons
 #pragma unroll
         for (int e = 0; e < 8; ++e) {      // rows 0-15 of L^-1: [D1^-1/2 Lu11^-1 | 0]
             const int idx = e * 64 + lane, rw = idx >> 5, cl = idx & 31;
-            Ig[idx] = (cl < 16) ? S.sInv[rw * LS + cl] * S.rs[rw] : 0.0;
+            const double v = (cl < 16) ? S.sInv[rw * LS + cl] * S.rs[rw] : 0.0;
+            gput<FLOW>(&Ig[idx], v);
+            if (FLOW) sLinv[rw * LS + cl] = v;
         }
         {   // columns 0-15 of L (all rows) and the zero block above the diagonal
             double* Lg = d.Lfac + (size_t)(kb * 32) * d.ld + kb * 32;
@@ -528,8 +561,8 @@ __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, cons
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int rw = 4 * e + lk;
-                Lg[(size_t)rw * d.ld + li] = (li <= rw) ? S.cols[li * 32 + slot32(rw)] * rsc : 0.0;
-                if (rw < 16) Lg[(size_t)rw * d.ld + 16 + li] = 0.0;
+                gput<FLOW>(&Lg[(size_t)rw * d.ld + li], (li <= rw) ? S.cols[li * 32 + slot32(rw)] * rsc : 0.0);
+                if (rw < 16) gput<FLOW>(&Lg[(size_t)rw * d.ld + 16 + li], 0.0);
             }
         }
         LSTAMP(7);
@@ -549,13 +582,33 @@ __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, cons
         wait_rs16(S, 16, lane);
         // rows 16-31 of L^-1 = D2^-1/2 [ -Lu22^-1 Mu | Lu22^-1 ], straight from the registers
 #pragma unroll
-        for (int v = 0; v < 4; ++v) Ig[(16 + lk + 4 * v) * 32 + li] = -w[v] * S.rs[16 + lk + 4 * v];
+        for (int v = 0; v < 4; ++v) {
+            const double val = -w[v] * S.rs[16 + lk + 4 * v];
+            gput<FLOW>(&Ig[(16 + lk + 4 * v) * 32 + li], val);
+            if (FLOW) sLinv[(16 + lk + 4 * v) * LS + li] = val;
+        }
         if (lane < 16) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) Ig[(16 + t) * 32 + 16 + li] = x[t] * S.rs[16 + t];
+            for (int t = 0; t < 16; ++t) {
+                const double val = x[t] * S.rs[16 + t];
+                gput<FLOW>(&Ig[(16 + t) * 32 + 16 + li], val);
+                if (FLOW) sLinv[(16 + t) * LS + 16 + li] = val;
+            }
         }
         LSTAMP(14);
     }
+}
+__device__ __forceinline__ void fetch_next_tiles(NextTiles& n, int lane) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int idx = e * 64 + lane, rw = idx >> 5, cl = idx & 31;
+        n.sA[rw * LS + cl] = gload_sc1(&n.A[(size_t)rw * n.ld + cl]);
+        n.sD[rw * LS + cl] = gload_sc1(&n.D[(size_t)rw * n.ld + cl]);
+    }
+    n.done = true;
+#ifdef PLBA_STAMPS
+    if (lane == 0 && n.want != 0 && n.stamp) g_lstamp[21] = __builtin_readcyclecounter();
+#endif
 }
 __device__ __forceinline__ void look32_reset(Look32& S, int tid) {
     if (tid < 32) { S.pivd[tid] = piv_empty(); S.rsflag[tid] = 0; }
@@ -568,7 +621,7 @@ __global__ __launch_bounds__(256) void k_potrf0_32(DevBuf d) {
     for (int idx = threadIdx.x; idx < 1024; idx += 256) sC[(idx >> 5) * LS + (idx & 31)] = d.sys[(size_t)(idx >> 5) * d.ld + (idx & 31)];
     look32_reset(S, threadIdx.x);
     __syncthreads();
-    lookahead_factor32(d, 0, sC, S, threadIdx.x >> 6, threadIdx.x & 63);
+    lookahead_factor32<false>(d, 0, sC, S, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
 __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
@@ -662,13 +715,186 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
     look32_reset(S, threadIdx.x);
     __syncthreads();
     STAMP32(2);
-    lookahead_factor32(d, k + 1, sC, S, wv, lane);
+    lookahead_factor32<false>(d, k + 1, sC, S, wv, lane);
     STAMP32(3);
 #ifdef PLBA_STAMPS
     if (lane == 0 && blockIdx.x == 0 && k == 5) for (int q = 0; q < 4; ++q) d.maxd_part[4 * wv + q] = (double)(ts[q] - ts[0]);
     __syncthreads();
     if (threadIdx.x < 16 && blockIdx.x == 0 && k == 5) d.maxd_part[16 + threadIdx.x] = (double)(long long)(g_lstamp[threadIdx.x] - ts[0]);
 #endif
+}
+
+// -------------------------------------------------------------------------------------------------
+// Single-launch dataflow factorisation (factor_flow = 1; experimental, NOT the default): the whole LL^T in ONE kernel.
+// Measured on MI355X at P = 735: the chain step itself drops to ~16k cycles (from 21.7k with a launch per step), but
+// the two tiles the next step needs arrive through three cross-workgroup hops of ~10k cycles each (sc1 store drain,
+// flag, poll, sc1 loads: ~4 us), i.e. later than the ~14k-cycle pivot sweep that should hide them, so the chain waits
+// and a step costs ~35k cycles (351 us per factorisation against 227 us).  Kept as an option: it is correct (parity
+// tests run both) and it is the starting point for a same-XCD / L2-coherent variant with cheaper hops.
+//
+// Left-looking by tiles: a workgroup per 32 x 32 tile (r,c) of the lower triangle (plus the right-hand-side row
+// r = T) accumulates A(r,c) - sum_{k<c} L(r,k) L(c,k)^T on the matrix cores as the L tiles of earlier columns are
+// published, then finishes with the inverse of its column's diagonal block, L(r,c) = (...) L(c,c)^-T, and publishes it.
+// The chain of diagonal factorisations never leaves ONE workgroup (block 0):
+//   step c:  X = pre(c,c-1) L(c-1,c-1)^-T   (L^-1 still in LDS from the previous step; publishes L(c,c-1))
+//            A(c,c) = diagpre(c) - X X^T,   then the four-wave pivot pipeline (lookahead_factor32) -> L(c,c)^-1
+//   where pre(c,c-1) and diagpre(c) are the two tiles with every OLDER panel already applied; their helper workgroups
+//   publish them instead of finishing, and wave 2 of the chain workgroup (the 1/sqrt(pivot) producer, mostly idle)
+//   prefetches them into LDS while the pivots of step c-1 run.  So one chain step costs two small products plus the pivot sweep: no kernel boundary, no
+//   global-memory latency, and the panel solves and trailing updates of all other tiles run in its shadow.
+// Hand-off between workgroups: payload with sc1 (write-through) stores, s_waitcnt vmcnt(0), barrier, then an
+// epoch-stamped flag word; consumers poll the flag and read the payload with sc1 loads (no fences, no resets:
+// MI355X_MICROARCH.md 'valid forms').  Workgroups are enumerated column-major behind the chain workgroup, so every
+// dependency points to a lower block index: with in-order dispatch a waiting workgroup only ever waits for one that is
+// resident or finished, whatever the grid size.  Every poll is bounded (SPIN_LIMIT_G): a logic error ends as a failed
+// solve, never as a hung device.
+// -------------------------------------------------------------------------------------------------
+constexpr int SPIN_LIMIT_G = 1 << 18;
+constexpr int FLOW_THREADS = 256;
+
+__device__ __forceinline__ bool wait_flag_ge(const int* f, int want) {
+    int spins = 0;
+    while (__hip_atomic_load(const_cast<int*>(f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > SPIN_LIMIT_G) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ void set_flag(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// tflag[r * T + c]: 2 e + 1 = "pre" (older panels applied, published into sys), 2 e + 2 = L(r,c) final in Lfac.
+// iflag[c]: 2 e + 2 = L(c,c)^-1 in Linv32.
+__global__ __launch_bounds__(FLOW_THREADS) void k_chol_flow(DevBuf d, int T, int epoch) {
+    __shared__ __attribute__((aligned(16))) double sX[32 * LS];       // X of the chain step / staging tile of a helper
+    __shared__ __attribute__((aligned(16))) double sC[32 * LS];
+    __shared__ __attribute__((aligned(16))) double sLinv[32 * LS];
+    __shared__ __attribute__((aligned(16))) double sPreA[32 * LS], sPreD[32 * LS];
+    __shared__ __attribute__((aligned(16))) Look32 S;
+    __shared__ int s_bad;
+    const int ld = d.ld;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int tr = wv >> 1, tc = wv & 1;
+    int* tflag = d.chol_flags;
+    int* iflag = d.chol_flags + (size_t)(T + 1) * T;
+    const int PRE = 2 * epoch + 1, FIN = 2 * epoch + 2;
+
+    if (blockIdx.x == 0) {
+        // ------------------------------------------------ the chain workgroup ------------------------------------------------
+        if (threadIdx.x == 0) s_bad = 0;
+        for (int c = 0; c < T; ++c) {
+            CSTAMP(16);
+#ifdef PLBA_STAMPS
+            if (threadIdx.x == 0 && c == 6) g_lstamp[20] = __builtin_readcyclecounter();
+#endif
+            if (c == 0) {
+                for (int idx = threadIdx.x; idx < 1024; idx += 256) sC[(idx >> 5) * LS + (idx & 31)] = d.sys[(size_t)(idx >> 5) * ld + (idx & 31)];
+            } else {
+                // X = pre(c,c-1) Linv(c-1)^T: tile (tr, tc), 8 k-steps, both operands already in LDS
+                double4v x = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(sPreA[(tr * 16 + li) * LS + 4 * s + lk], sLinv[(tc * 16 + li) * LS + 4 * s + lk], x, 0, 0, 0);
+                double* Lg = d.Lfac + (size_t)(c * 32) * ld + (c - 1) * 32;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = tr * 16 + lk + 4 * v, col = tc * 16 + li;
+                    sX[row * LS + col] = x[v];
+                    gstore_sc1(&Lg[(size_t)row * ld + col], x[v]);
+                }
+                __syncthreads();
+                double4v acc = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[(tr * 16 + li) * LS + 4 * s + lk], sX[(tc * 16 + li) * LS + 4 * s + lk], acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = tr * 16 + lk + 4 * v, col = tc * 16 + li;
+                    sC[row * LS + col] = sPreD[row * LS + col] - acc[v];
+                }
+                drain_stores();      // L(c,c-1) is out before the flag below
+            }
+            CSTAMP(17);
+            look32_reset(S, threadIdx.x);
+            __syncthreads();
+            CSTAMP(18);
+            if (c > 0 && threadIdx.x == 0) set_flag(&tflag[(size_t)c * T + c - 1], FIN);
+            NextTiles nt;
+            nt.active = (c + 1 < T); nt.done = false; nt.failed = false; nt.want = PRE; nt.ld = ld; nt.stamp = (c == 5);
+            nt.fa = &tflag[(size_t)(c + 1) * T + c]; nt.fd = &tflag[(size_t)(c + 1) * T + c + 1];
+            nt.A = d.sys + (size_t)((c + 1) * 32) * ld + c * 32; nt.D = nt.A + 32;
+            nt.sA = sPreA; nt.sD = sPreD;
+            lookahead_factor32<true>(d, c, sC, S, wv, lane, sLinv, &nt);
+            if (nt.failed && lane == 0) s_bad = 1;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            CSTAMP(19);
+            if (threadIdx.x == 0) set_flag(&iflag[c], FIN);
+        }
+#ifdef PLBA_STAMPS
+        __syncthreads();
+        if (threadIdx.x < 32) d.maxd_part[threadIdx.x] = (double)(long long)(g_lstamp[threadIdx.x] - g_lstamp[16]);
+#endif
+        if (threadIdx.x == 0 && s_bad) d.ctrl->solver_ok = 0;
+        return;
+    }
+
+    // ---------------------------------------------------- helper workgroups ----------------------------------------------------
+    int c = 0, off = (int)blockIdx.x - 1;
+    while (off >= T - c + 1) { off -= T - c + 1; ++c; }       // column-major enumeration: column c holds rows c..T
+    const int r = c + off;
+    if (r == 0) return;                                        // (0,0) belongs to the chain
+    const bool diagpre = (r == c), pre = (r == c + 1 && r < T);
+    const int kend = diagpre ? c - 1 : c;
+    bool ok = true;
+    double4v acc = (double4v){0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < kend; ++k) {
+        if (lane == 0) ok = wait_flag_ge(&tflag[(size_t)r * T + k], FIN) && (diagpre || wait_flag_ge(&tflag[(size_t)c * T + k], FIN)) && ok;
+        ok = __all(ok);
+        const double* Lr = d.Lfac + (size_t)(r * 32 + tr * 16 + li) * ld + k * 32 + lk * 8;
+        const double* Lc = d.Lfac + (size_t)(c * 32 + tc * 16 + li) * ld + k * 32 + lk * 8;
+        double a[8], b[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { a[s] = gload_sc1(Lr + s); b[s] = gload_sc1(Lc + s); }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);   // k enumerated as 8 (lane >> 4) + s
+    }
+    double val[4];
+    {
+        const double* A = d.sys + (size_t)(r * 32) * ld + c * 32;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) val[v] = A[(size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li] - acc[v];
+    }
+    if (diagpre || pre) {
+        double* A = d.sys + (size_t)(r * 32) * ld + c * 32;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gstore_sc1(&A[(size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li], val[v]);
+        drain_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) { set_flag(&tflag[(size_t)r * T + c], PRE); if (!ok) d.ctrl->solver_ok = 0; }
+        return;
+    }
+    // full tile: L(r,c) = val Linv(c)^T
+#pragma unroll
+    for (int v = 0; v < 4; ++v) sX[(tr * 16 + lk + 4 * v) * LS + tc * 16 + li] = val[v];
+    if (lane == 0) ok = wait_flag_ge(&iflag[c], FIN) && ok;
+    ok = __all(ok);
+    __syncthreads();
+    {
+        const double* Ig = d.Linv32 + (size_t)c * 1024 + (size_t)(tc * 16 + li) * 32 + lk * 8;
+        double b[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) b[s] = gload_sc1(Ig + s);
+        double4v x = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(sX[(tr * 16 + li) * LS + lk * 8 + s], b[s], x, 0, 0, 0);
+        double* Lg = d.Lfac + (size_t)(r * 32) * ld + c * 32;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) gstore_sc1(&Lg[(size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li], x[v]);
+    }
+    drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) { set_flag(&tflag[(size_t)r * T + c], FIN); if (!ok) d.ctrl->solver_ok = 0; }
 }
 
 // Linv[k] (64 x 64, for the back-substitution) from the 32 x 32 inverses the factorisation published:
@@ -862,7 +1088,13 @@ static void launch_cholesky_nb(const DevBuf& d, bool use_mfma, hipStream_t s) {
     }
 }
 static bool inverse_panels(const DevBuf& d, bool use_mfma) { return d.fb == 32 && use_mfma; }
-void launch_cholesky(const DevBuf& d, bool use_mfma, hipStream_t s) {
+void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s) {
+    if (inverse_panels(d, use_mfma) && d.flow) {
+        const int T = d.Ppad / 32;
+        const int tiles = (T + 1) * (T + 2) / 2 - 1;        // sum_{c<T} (T - c + 1): rows c..T of every column
+        hipLaunchKernelGGL(k_chol_flow, dim3(1 + tiles), dim3(FLOW_THREADS), 0, s, d, T, epoch);
+        return;
+    }
     if (inverse_panels(d, use_mfma)) {
         const int T = d.Ppad / 32;
         hipLaunchKernelGGL(k_potrf0_32, dim3(1), dim3(256), 0, s, d);

@@ -80,6 +80,8 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     // Linv32 (declared above; shares LTblk's storage): (Ppad/32) x 32 x 32 inverses of the diagonal blocks, row-major
     int fb;                // factorisation block width (32 or 64)
     int* flow_flags;       // T epoch-stamped flags of the back-substitution dataflow
+    int* chol_flags;       // (T32 + 1) x T32 tile flags + T32 inverse flags of the single-launch factorisation (epoch-stamped)
+    int flow;              // 1: single-launch dataflow factorisation (k_chol_flow), 0: one launch per block step
     // reductions / control
     double *chi_part, *scale_part, *maxd_part, *kfdiag, *posediag;
     Ctrl* ctrl;
@@ -114,7 +116,7 @@ void launch_depth(const DevBuf& d, int state, uint8_t* out, hipStream_t s);
 int  edge_blocks(const DevBuf& d);
 
 // dense
-void launch_cholesky(const DevBuf& d, bool use_mfma, hipStream_t s);   // sys -> Lfac (lower) incl. the augmented rows
+void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s);   // sys -> Lfac (lower) incl. the augmented rows
 void launch_trsv_back(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s);      // x = L^-T y; epoch must differ from the previous call's
 void launch_ata(const double* A_colmajor, int rows, int cols, double* out_rowmajor, int ldo, hipStream_t s);  // A^T A
 

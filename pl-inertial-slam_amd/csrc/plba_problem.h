@@ -87,7 +87,7 @@ struct plba_problem {
     plba::DArr<int32_t> d_pr_kf, d_pr_isbias, d_pr_size, d_pr_idx, d_pr_x0off, d_pr_off;
     plba::DArr<double> d_pr_x0, d_pr_J0, d_pr_r0, d_pr_err, d_pr_dx, d_pr_chi, d_pr_H;
     plba::DArr<double> d_Hconst, d_Himu, d_bimu, d_Himu2, d_bimu2, d_sys, d_Lfac, d_bpg, d_x, d_Linv, d_LT32, d_rd32;
-    plba::DArr<int> d_flow_flags;
+    plba::DArr<int> d_flow_flags, d_chol_flags;
     int flow_epoch = 0;
     plba::DArr<double> d_chi_part, d_scale_part, d_maxd_part, d_kfdiag, d_red, d_posediag;
     plba::DArr<plba::Ctrl> d_ctrl;

@@ -38,12 +38,12 @@ def test_backend_is_the_hip_library(hip):
 
 
 @pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 200, 750])
-@pytest.mark.parametrize("mfma,fb", [(1, 32), (0, 32), (1, 64), (0, 64)])
-def test_dense_solver_vs_numpy(pkg, hip, n, mfma, fb):
+@pytest.mark.parametrize("mfma,fb,flow", [(1, 32, 0), (1, 32, 1), (0, 32, 0), (1, 64, 0), (0, 64, 0)])
+def test_dense_solver_vs_numpy(pkg, hip, n, mfma, fb, flow):
     rng = np.random.default_rng(n)
     A = rng.normal(size=(n, n)); A = A @ A.T + n * np.eye(n)
     b = rng.normal(size=n)
-    p = pkg.new_problem(use_mfma=mfma, factor_block=fb)
+    p = pkg.new_problem(use_mfma=mfma, factor_block=fb, factor_flow=flow)
     x, ok = p.debug_dense_solve(A, b)
     assert ok
     _close(x, np.linalg.solve(A, b), 1e-9, "x")
@@ -126,6 +126,16 @@ def _two_stage(pkg, orc, w, tol=POSE_TOL):
 
 def test_two_stage_protocol_small(pkg, orc, hip):
     _two_stage(pkg, orc, pkg.window.make_window(12, 500, 100, imu=True, seed=105))
+
+
+def test_two_stage_protocol_with_the_single_launch_factorisation(pkg, orc, hip):
+    """factor_flow = 1 (k_chol_flow, the experimental dataflow factorisation) gives the same optimisation"""
+    w = pkg.window.make_window(12, 500, 100, imu=True, seed=105)
+    g, o = _pair(pkg, orc, w, factor_flow=1)
+    rg, ro = pkg.protocol.local_ba(g), pkg.protocol.local_ba(o)
+    assert rg["gated"] == ro["gated"] and rg["stage2"].solver_failures == 0
+    assert max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)) < POSE_TOL
+    g.close(); o.close()
 
 
 def test_config1_full_size_no_imu(pkg, orc, hip):
