@@ -35,7 +35,7 @@ struct Ctrl {
 
 struct DevBuf {  // trivially-copyable view of device pointers passed to kernels by value
     // sizes
-    int K, Np, Nl, L, Ep, El, E, M, P, Ppad, ld, npairs, nent;
+    int K, Np, Nl, L, Ep, El, E, M, P, Ppad, ld, npairs, nent, nchunks;
     // camera / gravity
     Cam cam;
     V3 gw;
@@ -62,6 +62,9 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     const int32_t *kf_off_pvr, *kf_off_bias;
     // pairs
     const int32_t *pair_i, *pair_j, *pair_start, *ent_pi, *ent_pj, *ent_slot;   // entries: record positions + landmark slot
+    const int32_t *ch_pair, *ch_start, *ch_end, *pair_ch0, *pair_nch;           // <= 256-entry chunks of the pair lists (k_schur_pairs)
+    double* schur_part;    // nchunks x 48 partial sums
+    int* pair_cnt;         // arrival counters, zero between launches
     // IMU
     const int32_t *imu_i, *imu_j;
     const double *imu_pre, *imu_info_pvr, *imu_info_bias;

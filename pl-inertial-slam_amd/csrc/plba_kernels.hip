@@ -287,11 +287,17 @@ __global__ __launch_bounds__(256) void k_kfdiag(DevBuf d, int state) {
 // streams of a pair are ascending and dense.  Each lane accumulates 6x6 (+2x6 for diagonal pairs) in registers,
 // DPP wave reduction, LDS across the 4 waves; the owning workgroup read-modify-writes its exclusive blocks of `sys`.
 // -------------------------------------------------------------------------------------------------
+// One workgroup per CHUNK of at most 256 entries of a keyframe pair (the heaviest pairs hold ~2500 entries: one
+// workgroup per pair left the launch waiting for ten dependent gather rounds of a handful of workgroups).  A pair's
+// chunks publish their 48 partial sums; the chunk that arrives last adds them up in chunk order (deterministic) and
+// applies the result to the reduced system.
 __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state) {
     __shared__ double s_red[4][48];
     __shared__ double s_in[48], s_tmp[36];
     __shared__ double s_kc[2 * KFCAM_STRIDE];
-    const int p = blockIdx.x;
+    __shared__ int s_last;
+    const int ch = blockIdx.x;
+    const int p = d.ch_pair[ch];
     const int i = d.pair_i[p], j = d.pair_j[p];
     const bool diag = (i == j);
     if (threadIdx.x < 2) kfcam_make(d.cam, d.kf[state] + (size_t)(threadIdx.x == 0 ? i : j) * KF_STRIDE, s_kc + threadIdx.x * KFCAM_STRIDE);
@@ -302,13 +308,12 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state) {
     for (int t = 0; t < 36; ++t) acc[t] = 0.0;
 #pragma unroll
     for (int t = 0; t < 6; ++t) { gb[t] = 0.0; gp[t] = 0.0; }
-    const int s = d.pair_start[p], en = d.pair_start[p + 1];
-    for (int n = s + threadIdx.x; n < en; n += 256) {
+    const int n = d.ch_start[ch] + threadIdx.x;
+    if (n < d.ch_end[ch]) {
         const int pi = d.ent_pi[n], pj = d.ent_pj[n], slot = d.ent_slot[n];
         const double wi = d.erec[(size_t)pi * EREC + 12];
-        if (wi == 0.0) continue;
         const double wj = d.erec[(size_t)pj * EREC + 12];
-        if (wj == 0.0) continue;
+        if (wi != 0.0 && wj != 0.0) {
         const bool is_pt = slot < d.Np;
         const EdgeRows ri = load_rows(d, d.erec + (size_t)pi * EREC, s_kc, is_pt);
         const EdgeRows rj = load_rows(d, d.erec + (size_t)pj * EREC, s_kc + KFCAM_STRIDE, is_pt);
@@ -346,6 +351,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state) {
                 gb[r] -= wi * (ri.ga[r] * f0 + ri.gb[r] * f1);
             }
         }
+        }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -365,6 +371,24 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state) {
     const int t = threadIdx.x;
     const int nred = diag ? 48 : 36;
     if (t < nred) s_in[t] = (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]);
+    const int nch = d.pair_nch[p];
+    if (nch > 1) {
+        // publish this chunk's partial sums (sc1, drained), count arrivals; the last chunk folds them in chunk order
+        double* part = d.schur_part + (size_t)ch * 48;
+        if (t < nred) __hip_atomic_store(&part[t], s_in[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) s_last = (__hip_atomic_fetch_add(&d.pair_cnt[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nch - 1) ? 1 : 0;
+        __syncthreads();
+        if (!s_last) return;
+        if (t == 0) __hip_atomic_store(&d.pair_cnt[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+        if (t < nred) {
+            const double* base = d.schur_part + (size_t)d.pair_ch0[p] * 48 + t;
+            double sum = 0.0;
+            for (int c = 0; c < nch; ++c) sum += __hip_atomic_load(const_cast<double*>(base + (size_t)c * 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_in[t] = sum;
+        }
+    }
     __syncthreads();
     // S = C^T Inner C with C = blkdiag(Rcb, Rcb):  tmp = Inner C, S = C^T tmp
     const double* Rcb = d.cam.Rcb.a;
@@ -831,7 +855,7 @@ void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s) {
     hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, d, add_lambda ? 1 : 0);
 }
 void launch_schur_pairs(const DevBuf& d, int state, hipStream_t s) {
-    if (d.npairs) hipLaunchKernelGGL(k_schur_pairs, dim3(d.npairs), dim3(256), 0, s, d, state);
+    if (d.nchunks) hipLaunchKernelGGL(k_schur_pairs, dim3(d.nchunks), dim3(256), 0, s, d, state);
 }
 void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s) {
     if (d.L) hipLaunchKernelGGL(k_backsub, dim3(lm_blocks(d)), dim3(256), (size_t)d.K * (KFCAM_STRIDE + 6) * sizeof(double), s, d, cur, trial);
