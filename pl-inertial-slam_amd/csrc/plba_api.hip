@@ -427,8 +427,8 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_Linv.alloc((size_t)(p->Ppad / TILE) * TILE * TILE)); HIPCK(p, p->d_flow_flags.alloc(p->Ppad / TILE)); p->flow_epoch = 0;
     HIPCK(p, p->d_chol_flags.alloc((size_t)(p->Ppad / 32 + 2) * (p->Ppad / 32)));
     HIPCK(p, p->d_LT32.alloc((size_t)p->Ppad * 64)); HIPCK(p, p->d_rd32.alloc(p->Ppad));
-    HIPCK(p, p->d_chi_part.alloc((size_t)(E + 255) / 256 + 1)); HIPCK(p, p->d_scale_part.alloc((size_t)(L + 255) / 256 + 1));
-    HIPCK(p, p->d_maxd_part.alloc((size_t)(L + 255) / 256 + 1)); HIPCK(p, p->d_kfdiag.alloc((size_t)K * 6)); HIPCK(p, p->d_posediag.alloc(p->ld));
+    HIPCK(p, p->d_chi_part.alloc((size_t)(E + 255) / 256 + 1)); HIPCK(p, p->d_scale_part.alloc((size_t)(L + 63) / 64 + 33));
+    HIPCK(p, p->d_maxd_part.alloc((size_t)(L + 63) / 64 + 33)); HIPCK(p, p->d_kfdiag.alloc((size_t)K * 6)); HIPCK(p, p->d_posediag.alloc(p->ld));
     HIPCK(p, p->d_red.alloc(8)); HIPCK(p, p->d_ctrl.alloc(1)); HIPCK(p, p->d_trace.alloc(TRACE_CAP)); HIPCK(p, p->d_trace_n.alloc(1));
     // ---- kernel argument block -------------------------------------------------------------------------------------
     DevBuf& d = p->dv;

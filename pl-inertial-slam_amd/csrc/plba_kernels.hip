@@ -52,6 +52,9 @@ DEV double block_max_256(double v, double* s4) {
     __syncthreads();
     return r;
 }
+// Landmark-parallel kernels (one lane per landmark walking its 2-8 observations: dependent gathers) run in one-wave
+// workgroups: four times as many workgroups as 256-thread blocks, so all CUs carry some of the latency.
+constexpr int LMB = 64;
 DEV int pmap(int r) { return r < 3 ? r : r + 3; }   // (dp, dphi) -> position inside the 9-dim PVR block
 
 // -------------------------------------------------------------------------------------------------
@@ -153,13 +156,12 @@ DEV void landmark_dinv_one(const DevBuf& d, int slot, const double* h, const dou
 // FUSE_DINV: lambda of this iteration is already known (every outer iteration but the first), so the damped inverse
 // is formed right here from the registers instead of by a second pass over hll/bl.
 template <bool FUSE_DINV>
-__global__ __launch_bounds__(256) void k_landmark_hll(DevBuf d, int state) {
+__global__ __launch_bounds__(LMB) void k_landmark_hll(DevBuf d, int state) {
     extern __shared__ double s_dyn[];
     double* s_kc = s_dyn;
-    __shared__ double s4[4];
-    for (int k = threadIdx.x; k < d.K; k += 256) kfcam_make(d.cam, d.kf[state] + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
+    for (int k = threadIdx.x; k < d.K; k += LMB) kfcam_make(d.cam, d.kf[state] + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
     __syncthreads();
-    const int slot = blockIdx.x * 256 + threadIdx.x;
+    const int slot = blockIdx.x * LMB + threadIdx.x;
     double md = 0.0;
     if (slot < d.L) {
         const int s = d.lm_start[slot], en = d.lm_start[slot + 1];
@@ -208,12 +210,12 @@ __global__ __launch_bounds__(256) void k_landmark_hll(DevBuf d, int state) {
         }
         if (FUSE_DINV) landmark_dinv_one(d, slot, h, b, active, is_pt);
     }
-    double bm = block_max_256(md, s4);
+    const double bm = wave_max(md);      // one wave per workgroup (LMB == 64)
     if (threadIdx.x == 0) d.maxd_part[blockIdx.x] = bm;
 }
 
-__global__ __launch_bounds__(256) void k_landmark_dinv(DevBuf d) {
-    const int slot = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(LMB) void k_landmark_dinv(DevBuf d) {
+    const int slot = blockIdx.x * LMB + threadIdx.x;
     if (slot >= d.L) return;
     double h[12], b[6];
 #pragma unroll
@@ -461,12 +463,11 @@ DEV void update_kf_one(const DevBuf& d, int cur, int trial, int k) {
 // landmark back-substitution + landmark update (+ landmark part of computeScale)
 //   xl = D (bl - sum_e w Jl^T Jp x_kf)      trial_lm = cur_lm + xl
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_backsub(DevBuf d, int cur, int trial) {
+__global__ __launch_bounds__(LMB) void k_backsub(DevBuf d, int cur, int trial) {
     extern __shared__ double s_dyn[];
     double* s_kc = s_dyn;                       // K x 12 camera blocks of the CURRENT (linearisation) state
     double* s_y = s_dyn + d.K * KFCAM_STRIDE;   // K x 6: blkdiag(Rcb,Rcb) * (dp, dphi) of every keyframe's step
-    __shared__ double s4[4];
-    for (int k = threadIdx.x; k < d.K; k += 256) {
+    for (int k = threadIdx.x; k < d.K; k += LMB) {
         kfcam_make(d.cam, d.kf[cur] + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
         const int o = d.kf_off_pvr[k];
         V3 yp = v3(0, 0, 0), yr = v3(0, 0, 0);
@@ -475,8 +476,8 @@ __global__ __launch_bounds__(256) void k_backsub(DevBuf d, int cur, int trial) {
         y[0] = yp.x; y[1] = yp.y; y[2] = yp.z; y[3] = yr.x; y[4] = yr.y; y[5] = yr.z;
     }
     __syncthreads();
-    if (blockIdx.x == 0) for (int k = threadIdx.x; k < d.K; k += 256) update_kf_one(d, cur, trial, k);   // keyframe part of update()
-    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0) for (int k = threadIdx.x; k < d.K; k += LMB) update_kf_one(d, cur, trial, k);   // keyframe part of update()
+    const int slot = blockIdx.x * LMB + threadIdx.x;
     double sc = 0.0;
     if (slot < d.L) {
         const double* Lc = d.lm[cur] + (size_t)slot * 6;
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(256) void k_backsub(DevBuf d, int cur, int trial) {
 #pragma unroll
         for (int t = 0; t < 6; ++t) { Lt[t] = Lc[t] + xl[t]; d.xl[(size_t)slot * 6 + t] = xl[t]; }
     }
-    double bs = block_sum_256(sc, s4);
+    const double bs = wave_sum(sc);      // one wave per workgroup (LMB == 64)
     if (threadIdx.x == 0) d.scale_part[blockIdx.x] = bs;
 }
 
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(256) void k_gate(DevBuf d, int state, double thresh
 // launchers
 // -------------------------------------------------------------------------------------------------
 int edge_blocks(const DevBuf& d) { return (d.E + 255) / 256; }
-static int lm_blocks(const DevBuf& d) { return (d.L + 255) / 256; }
+static int lm_blocks(const DevBuf& d) { return (d.L + LMB - 1) / LMB; }
 
 // with_pose_edges: this rank owns the IMU / prior edges; they are evaluated by extra blocks of the same launch
 void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s) {
@@ -837,8 +838,8 @@ void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, b
 void launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv, hipStream_t s) {
     if (!d.L) return;
     const size_t sh = (size_t)d.K * KFCAM_STRIDE * sizeof(double);
-    if (fuse_dinv) hipLaunchKernelGGL(k_landmark_hll<true>, dim3(lm_blocks(d)), dim3(256), sh, s, d, state);
-    else hipLaunchKernelGGL(k_landmark_hll<false>, dim3(lm_blocks(d)), dim3(256), sh, s, d, state);
+    if (fuse_dinv) hipLaunchKernelGGL(k_landmark_hll<true>, dim3(lm_blocks(d)), dim3(LMB), sh, s, d, state);
+    else hipLaunchKernelGGL(k_landmark_hll<false>, dim3(lm_blocks(d)), dim3(LMB), sh, s, d, state);
 }
 void launch_kfdiag(const DevBuf& d, int state, hipStream_t s) {
     if (d.npairs) hipLaunchKernelGGL(k_kfdiag, dim3(d.npairs), dim3(256), 0, s, d, state);
@@ -846,7 +847,7 @@ void launch_kfdiag(const DevBuf& d, int state, hipStream_t s) {
     hipLaunchKernelGGL(k_posediag_kf, dim3((d.K * 6 + 255) / 256), dim3(256), 0, s, d);
 }
 void launch_landmark_dinv(const DevBuf& d, hipStream_t s) {
-    if (d.L) hipLaunchKernelGGL(k_landmark_dinv, dim3(lm_blocks(d)), dim3(256), 0, s, d);
+    if (d.L) hipLaunchKernelGGL(k_landmark_dinv, dim3(lm_blocks(d)), dim3(LMB), 0, s, d);
 }
 void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s) {
     const size_t n = (size_t)(d.Ppad + TILE) * d.ld;
@@ -858,7 +859,7 @@ void launch_schur_pairs(const DevBuf& d, int state, hipStream_t s) {
     if (d.nchunks) hipLaunchKernelGGL(k_schur_pairs, dim3(d.nchunks), dim3(256), 0, s, d, state);
 }
 void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s) {
-    if (d.L) hipLaunchKernelGGL(k_backsub, dim3(lm_blocks(d)), dim3(256), (size_t)d.K * (KFCAM_STRIDE + 6) * sizeof(double), s, d, cur, trial);
+    if (d.L) hipLaunchKernelGGL(k_backsub, dim3(lm_blocks(d)), dim3(LMB), (size_t)d.K * (KFCAM_STRIDE + 6) * sizeof(double), s, d, cur, trial);
 }
 void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s) {
     if (d.L) return;   // done by block 0 of k_backsub whenever there are landmarks
