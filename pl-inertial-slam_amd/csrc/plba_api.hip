@@ -79,11 +79,14 @@ int plba_create(const plba_options* opt, plba_problem** out) {
     }
     (void)hipGetDevice(&p->device);
     if ((e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipHostMalloc((void**)&p->h_ctrl, sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess) {
+        (e = hipHostMalloc((void**)&p->h_ctrl, sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&p->h_mail, sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+        (e = hipHostGetDevicePointer((void**)&p->d_mail, p->h_mail, 0)) != hipSuccess) {
         snprintf(g_create_err, sizeof g_create_err, "device initialisation failed: %s", hipGetErrorString(e));
         delete p;
         return PLBA_ERR_DEVICE;
     }
+    memset(p->h_mail, 0, sizeof(Mailbox));
     p->own_stream = true;
     *out = p;
     return PLBA_OK;
@@ -96,6 +99,7 @@ void plba_destroy(plba_problem* p) {
     if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
     if (p->ev_ready) for (auto& e : p->ev) (void)hipEventDestroy(e);
     if (p->h_ctrl) (void)hipHostFree(p->h_ctrl);
+    if (p->h_mail) (void)hipHostFree(p->h_mail);
     delete p;
 }
 
@@ -598,10 +602,23 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
                 launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
                 if ((rc = exchange(p, p->d_red.p, 2, 0))) return rc;
             }
-            launch_decide(d, lp, p->d_red.p, p->world <= 1, s);
+            const unsigned long long seq = ++p->mail_seq;
+            launch_decide(d, lp, p->d_red.p, p->world <= 1, p->d_mail, seq, s);
             MARK(p, 10);
-            HIPCK(p, hipMemcpyAsync(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
-            HIPCK(p, hipStreamSynchronize(s));
+            if (p->opt.profile >= 2) {
+                HIPCK(p, hipStreamSynchronize(s));        // every phase event must have completed before it is read
+            } else {
+                // k_decide is the last kernel of the trial and writes the control block into mapped host memory
+                long spins = 0;
+                while (__atomic_load_n(&p->h_mail->seq, __ATOMIC_ACQUIRE) != seq) {
+                    if (++spins > (1L << 22)) {           // ~ tens of ms: fall back to a real synchronisation (and surface any device error)
+                        HIPCK(p, hipStreamSynchronize(s));
+                        break;
+                    }
+                }
+            }
+            if (__atomic_load_n(&p->h_mail->seq, __ATOMIC_ACQUIRE) != seq) FAIL(p, PLBA_ERR_DEVICE, "LM control block was not delivered by the device");
+            *p->h_ctrl = p->h_mail->c;
             if (p->opt.profile >= 1) st.ms_phase[1] += span(11, 12);
             if (p->opt.profile >= 2) {
                 if (qmax == 0) { st.ms_phase[0] += span(0, 2); st.ms_phase[7] += span(2, 3); }

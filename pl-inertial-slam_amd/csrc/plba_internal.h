@@ -32,6 +32,12 @@ struct Ctrl {
     double lambda, ni, current_chi, temp_chi, scale, rho, maxdiag, pad0;
     int accepted, solver_ok, iteration, trial, n_gate_pt, n_gate_ln, n_fail, pad1;
 };
+// Pinned, device-mapped host memory k_decide writes the control block into at the end of every LM trial: the host
+// polls `seq` instead of paying for a device-to-host copy launch plus a stream synchronisation per trial.
+struct Mailbox {
+    Ctrl c;
+    unsigned long long seq;
+};
 
 struct DevBuf {  // trivially-copyable view of device pointers passed to kernels by value
     // sizes
@@ -113,7 +119,7 @@ void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s);
 // red[0] = activeRobustChi2 (local), red[1] = landmark part of computeScale (local), red[2] = max |Hll_jj| (local)
 void launch_reduce(const DevBuf& d, bool owns_pose_edges, double* red, hipStream_t s);
 void launch_lambda_init2(const DevBuf& d, const LmParams& lp, double* red, bool first_iter, int iteration, bool fused, hipStream_t s);
-void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, hipStream_t s);
+void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, Mailbox* mail, unsigned long long seq, hipStream_t s);
 void launch_gate(const DevBuf& d, int state, double thresh, hipStream_t s);
 void launch_depth(const DevBuf& d, int state, uint8_t* out, hipStream_t s);
 int  edge_blocks(const DevBuf& d);

@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) void k_lambda_init(DevBuf d, LmParams lp, doub
 }
 
 // end of a trial: rho test and lambda schedule of OptimizationAlgorithmLevenberg::solve
-__global__ __launch_bounds__(256) void k_decide(DevBuf d, LmParams lp, double* red, int fused, int nblk_edges, int nblk_lm) {
+__global__ __launch_bounds__(256) void k_decide(DevBuf d, LmParams lp, double* red, int fused, int nblk_edges, int nblk_lm, Mailbox* mail, unsigned long long seq) {
     __shared__ double s4[4];
     if (fused) reduce_inline(d, nblk_edges, nblk_lm, red, s4);
     Ctrl* c = d.ctrl;
@@ -786,6 +786,11 @@ __global__ __launch_bounds__(256) void k_decide(DevBuf d, LmParams lp, double* r
     c->trial += 1;
     if (!c->solver_ok) c->n_fail += 1;
     c->solver_ok = 1;
+    if (mail) {     // hand the decision to the host: payload, system-scope fence, then the sequence number it polls
+        mail->c = *c;
+        __threadfence_system();
+        __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     }
 }
 
@@ -872,8 +877,8 @@ void launch_reduce(const DevBuf& d, bool owns_pose_edges, double* red, hipStream
 void launch_lambda_init2(const DevBuf& d, const LmParams& lp, double* red, bool first_iter, int iteration, bool fused, hipStream_t s) {
     hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(256), 0, s, d, lp, red, first_iter ? 1 : 0, iteration, fused ? 1 : 0, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0);
 }
-void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, hipStream_t s) {
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, s, d, lp, red, fused ? 1 : 0, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0);
+void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, Mailbox* mail, unsigned long long seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, s, d, lp, red, fused ? 1 : 0, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0, mail, seq);
 }
 void launch_gate(const DevBuf& d, int state, double thresh, hipStream_t s) {
     if (d.E == 0) return;

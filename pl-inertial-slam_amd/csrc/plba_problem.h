@@ -97,6 +97,9 @@ struct plba_problem {
     plba::DArr<plba_trace_row> d_trace;
     plba::DArr<int> d_trace_n;
     plba::Ctrl* h_ctrl = nullptr;               // pinned
+    plba::Mailbox* h_mail = nullptr;            // pinned + device-mapped (k_decide -> host), d_mail = its device address
+    plba::Mailbox* d_mail = nullptr;
+    unsigned long long mail_seq = 0;
     plba::DevBuf dv;
     std::vector<plba_trace_row> trace;
     bool saved_valid = false;
