@@ -522,16 +522,18 @@ static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
         HIPCK(p, hipMemsetAsync(d.kfdiag, 0, (size_t)d.K * 6 * 8, s));
         launch_kfdiag(d, p->cur, s);
     }
-    if (p->world > 1) {
+    // Sharded runs: the global chi2 of this state is only exchanged on the first iteration of a call.  On later ones
+    // it is the (already global) chi2 of the trial that was just accepted, evaluated on the very same state, so the
+    // control block keeps it and one collective per iteration is saved.
+    const bool keep_chi = p->world > 1 && !first_iter;
+    if (p->world > 1 && first_iter) {
         int rc;
         launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
         if ((rc = exchange(p, p->d_red.p, 1, 0))) return rc;
-        if (first_iter) {
-            if ((rc = exchange(p, p->d_red.p + 2, 1, 1))) return rc;
-            if ((rc = exchange(p, d.posediag, (size_t)d.P, 0))) return rc;
-        }
+        if ((rc = exchange(p, p->d_red.p + 2, 1, 1))) return rc;
+        if ((rc = exchange(p, d.posediag, (size_t)d.P, 0))) return rc;
     }
-    launch_lambda_init2(d, lm_params(p), p->d_red.p, first_iter, iteration, p->world <= 1, s);
+    launch_lambda_init2(d, lm_params(p), p->d_red.p, first_iter, iteration, p->world <= 1, keep_chi, s);
     MARK(p, 3);
     return PLBA_OK;
 }

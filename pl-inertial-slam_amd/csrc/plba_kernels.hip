@@ -726,7 +726,7 @@ DEV void reduce_inline(const DevBuf& d, int nblk_edges, int nblk_lm, double* red
     if (threadIdx.x == 0) { red[0] = C; red[1] = S; red[2] = Mx; }
     __syncthreads();
 }
-__global__ __launch_bounds__(256) void k_lambda_init(DevBuf d, LmParams lp, double* red, int first_iter, int iteration, int fused, int nblk_edges, int nblk_lm) {
+__global__ __launch_bounds__(256) void k_lambda_init(DevBuf d, LmParams lp, double* red, int first_iter, int iteration, int fused, int keep_chi, int nblk_edges, int nblk_lm) {
     __shared__ double s4[4];
     if (fused) reduce_inline(d, nblk_edges, nblk_lm, red, s4);
     double md = 0.0;
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void k_lambda_init(DevBuf d, LmParams lp, doub
     double mx = block_max_256(md, s4);
     if (threadIdx.x == 0) {
         Ctrl* c = d.ctrl;
-        c->current_chi = red[0];
+        if (!keep_chi) c->current_chi = red[0];
         c->iteration = iteration;
         c->trial = 0;
         if (first_iter) {
@@ -874,8 +874,8 @@ void launch_reduce(const DevBuf& d, bool owns_pose_edges, double* red, hipStream
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, d, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0, owns_pose_edges ? 1 : 0, red);
 }
 // fused: the per-block partials are summed inside the control kernel (single-GPU path, no exchange in between)
-void launch_lambda_init2(const DevBuf& d, const LmParams& lp, double* red, bool first_iter, int iteration, bool fused, hipStream_t s) {
-    hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(256), 0, s, d, lp, red, first_iter ? 1 : 0, iteration, fused ? 1 : 0, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0);
+void launch_lambda_init2(const DevBuf& d, const LmParams& lp, double* red, bool first_iter, int iteration, bool fused, bool keep_chi, hipStream_t s) {
+    hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(256), 0, s, d, lp, red, first_iter ? 1 : 0, iteration, fused ? 1 : 0, keep_chi ? 1 : 0, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0);
 }
 void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, Mailbox* mail, unsigned long long seq, hipStream_t s) {
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, s, d, lp, red, fused ? 1 : 0, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0, mail, seq);
