@@ -547,8 +547,13 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
     launch_schur_pairs(d, p->cur, s);
     MARK(p, 5);
     if (p->world > 1) {   // single GPU: k_assemble / k_schur_pairs wrote bp into bpg directly
-        int rc = exchange(p, d.sys, (size_t)(d.Ppad + 2) * d.ld, 0);
+        // only the lower block-triangle (what the factorisation reads) and the two rhs rows travel
+        const size_t npk = tri_packed_size(d);
+        if (p->d_xbuf.n < npk) HIPCK(p, p->d_xbuf.alloc(npk, false));
+        launch_tri_pack(d, p->d_xbuf.p, false, s);
+        int rc = exchange(p, p->d_xbuf.p, npk, 0);
         if (rc) return rc;
+        launch_tri_pack(d, p->d_xbuf.p, true, s);
         HIPCK(p, hipMemcpyAsync(d.bpg, d.sys + (size_t)(d.Ppad + 1) * d.ld, (size_t)d.ld * 8, hipMemcpyDeviceToDevice, s));
     }
     MARK(p, 6);

@@ -118,6 +118,8 @@ void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s);
 void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s);
 // red[0] = activeRobustChi2 (local), red[1] = landmark part of computeScale (local), red[2] = max |Hll_jj| (local)
 void launch_reduce(const DevBuf& d, bool owns_pose_edges, double* red, hipStream_t s);
+size_t tri_packed_size(const DevBuf& d);   // doubles in the packed lower block-triangle + the two rhs rows
+void launch_tri_pack(const DevBuf& d, double* buf, bool unpack, hipStream_t s);
 void launch_lambda_init2(const DevBuf& d, const LmParams& lp, double* red, bool first_iter, int iteration, bool fused, bool keep_chi, hipStream_t s);
 void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, Mailbox* mail, unsigned long long seq, hipStream_t s);
 void launch_gate(const DevBuf& d, int state, double thresh, hipStream_t s);

@@ -713,6 +713,20 @@ __global__ __launch_bounds__(256) void k_posediag_kf(DevBuf d) {
     if (o >= 0) d.posediag[o + pmap(t % 6)] += d.kfdiag[t];
 }
 // start of an outer iteration: currentChi, and on the first one computeLambdaInit (tau * max |H_jj|)
+// Sharded runs exchange only what the factorisation reads: row r of the reduced system up to the end of its 32-wide
+// diagonal tile, plus the two right-hand-side rows in full.  Packed offset of row r = 32 a + b:
+//   off(r) = 512 a (a + 1) + 32 b (a + 1);  the two rhs rows follow the triangle.
+DEV size_t tri_off(int r) { const size_t a = (size_t)(r >> 5), b = (size_t)(r & 31); return 512 * a * (a + 1) + 32 * b * (a + 1); }
+__global__ __launch_bounds__(256) void k_tri_pack(DevBuf d, double* buf, int unpack) {
+    const int r = blockIdx.x;           // 0 .. Ppad + 1
+    const bool rhs = r >= d.Ppad;
+    const int n = rhs ? d.Ppad : (r | 31) + 1;
+    double* row = d.sys + (size_t)r * d.ld;
+    double* pk = buf + (rhs ? tri_off(d.Ppad) + (size_t)(r - d.Ppad) * d.Ppad : tri_off(r));
+    if (unpack) for (int c = threadIdx.x; c < n; c += 256) row[c] = pk[c];
+    else for (int c = threadIdx.x; c < n; c += 256) pk[c] = row[c];
+}
+
 // k_reduce inlined into the LM control kernels for the single-GPU path (no exchange between reduce and control)
 DEV void reduce_inline(const DevBuf& d, int nblk_edges, int nblk_lm, double* red, double* s4) {
     double c = 0.0, sc = 0.0, md = 0.0;
@@ -869,6 +883,10 @@ void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s) {
 void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s) {
     if (d.L) return;   // done by block 0 of k_backsub whenever there are landmarks
     hipLaunchKernelGGL(k_update_kf, dim3((d.K + 63) / 64), dim3(64), 0, s, d, cur, trial);
+}
+size_t tri_packed_size(const DevBuf& d) { const size_t a = (size_t)(d.Ppad >> 5); return 512 * a * (a + 1) + 2 * (size_t)d.Ppad; }
+void launch_tri_pack(const DevBuf& d, double* buf, bool unpack, hipStream_t s) {
+    hipLaunchKernelGGL(k_tri_pack, dim3(d.Ppad + 2), dim3(256), 0, s, d, buf, unpack ? 1 : 0);
 }
 void launch_reduce(const DevBuf& d, bool owns_pose_edges, double* red, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, d, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0, owns_pose_edges ? 1 : 0, red);

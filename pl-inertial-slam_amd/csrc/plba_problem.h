@@ -92,7 +92,7 @@ struct plba_problem {
     plba::DArr<double> d_Hconst, d_Himu, d_bimu, d_Himu2, d_bimu2, d_sys, d_Lfac, d_bpg, d_x, d_Linv, d_LT32, d_rd32;
     plba::DArr<int> d_flow_flags, d_chol_flags;
     int flow_epoch = 0;
-    plba::DArr<double> d_chi_part, d_scale_part, d_maxd_part, d_kfdiag, d_red, d_posediag;
+    plba::DArr<double> d_chi_part, d_scale_part, d_maxd_part, d_kfdiag, d_red, d_posediag, d_xbuf;
     plba::DArr<plba::Ctrl> d_ctrl;
     plba::DArr<plba_trace_row> d_trace;
     plba::DArr<int> d_trace_n;
