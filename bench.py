@@ -152,10 +152,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # rehearsal on a one-GPU box only (never set by the driver): all ranks share cuda:0 and all-reduce through gloo
+    rehearsal = os.environ.get("PLBA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     ge.build_hip()
     pkg = ge.load_package()
@@ -182,7 +189,7 @@ def main():
     prob.set_stream(stream.cuda_stream)
     prob.upload_window(w)
     if world > 1:
-        prob.set_shard(rank, world, pkg.distributed.make_allreduce(dist, local_rank, stream))
+        prob.set_shard(rank, world, pkg.distributed.make_allreduce(dist, local_rank, stream, via_host=rehearsal))
 
     stage1_and_gate(prob, pkg)
     run_iterations(prob, max(args.warmup, 1))
@@ -199,7 +206,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -218,7 +225,7 @@ def main():
     prob2.set_stream(stream.cuda_stream)
     prob2.upload_window(w)
     if world > 1:
-        prob2.set_shard(rank, world, pkg.distributed.make_allreduce(dist, local_rank, stream))
+        prob2.set_shard(rank, world, pkg.distributed.make_allreduce(dist, local_rank, stream, via_host=rehearsal))
     stage1_and_gate(prob2, pkg)
     done2, trials2, phases2 = run_iterations(prob2, min(args.steps, 50))
     sync()
