@@ -262,14 +262,17 @@ def main():
     if world == 1:
         # end-to-end cost of one reference-shaped BA call incl. PCIe: SoA upload + structure build + 5+10 LM
         # iterations + gating + write-back (reported for DESIGN.md; never `value`)
-        t1 = time.perf_counter()
-        p2 = pkg.new_problem()
-        p2.upload_window(w)
-        r2 = pkg.protocol.local_ba(p2)
-        pkg.protocol.results(p2)
-        torch.cuda.synchronize()
-        e2e = time.perf_counter() - t1
-        p2.close()
+        e2e, r2 = None, None
+        for _ in range(3):                  # best of three: the first call after large frees pays for re-allocation
+            t1 = time.perf_counter()
+            p2 = pkg.new_problem()
+            p2.upload_window(w)
+            r2 = pkg.protocol.local_ba(p2)
+            pkg.protocol.results(p2)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            p2.close()
+            e2e = dt2 if e2e is None else min(e2e, dt2)
         out["config"]["end_to_end_ba_call_ms"] = e2e * 1e3
         out["config"]["end_to_end_iterations_per_s"] = (r2["stage1"].iterations + r2["stage2"].iterations) / e2e
     if rank == 0:
