@@ -57,7 +57,8 @@ typedef struct {
     double user_lambda_init;    /* g2o LM userLambdaInit, 0 = automatic               (0)     */
     double marg_eps;            /* IMU/marginalization.h:99 pseudo-inverse threshold  (1e-8)  */
     int    fix_line_position_jacobian; /* 0 = reproduce IMU/g2otypes.cpp:1347 (SURVEY B-Q1)   */
-    int    whiten_marg_factors; /* 0 = reproduce IMU/marginalization.cpp:67 (SURVEY B-Q4)     */
+    int    whiten_marg_factors; /* 0 = reproduce IMU/marginalization.cpp:67 (SURVEY B-Q4); 1 is rejected
+                                   by plba_marginalize* (PLBA_ERR_INVALID: not implemented)          */
     int    device;              /* HIP device ordinal, -1 = current device            (-1)    */
     int    use_mfma;            /* 1 = fp64 MFMA trailing update in the dense solve    (1)    */
     int    profile;             /* HIP-event timing into plba_stats.ms_phase: 1 = the dense factorisation launches only

@@ -1630,6 +1630,7 @@ static void factor_free(factor_t* f) { free(f->r); for (int i = 0; i < f->nv; ++
 
 int orc_marginalize(plba_problem* p, int first_kf, int max_edges, plba_prior* out) {
     if (!p || !out || first_kf < 0 || first_kf >= p->K) return PLBA_ERR_INVALID;
+    if (p->opt.whiten_marg_factors) FAIL(p, PLBA_ERR_INVALID, "whiten_marg_factors = 1 is not implemented: only the reference's unweighted factors (IMU/marginalization.cpp:67)");
     memset(out, 0, sizeof *out);
     int NUM = max_edges;
     int cap = 2 + 2 * (NUM + 2) + 1;

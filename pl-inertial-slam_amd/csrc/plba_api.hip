@@ -831,6 +831,7 @@ int plba_restore_state(plba_problem* p) {
 
 int plba_marginalize(plba_problem* p, int first_kf, int max_edges, plba_prior* out) {
     if (!p || !out) return PLBA_ERR_INVALID;
+    if (p->opt.whiten_marg_factors) FAIL(p, PLBA_ERR_INVALID, "whiten_marg_factors = 1 is not implemented: only the reference's unweighted factors (IMU/marginalization.cpp:67)");
     int rc = prepare(p);
     if (rc) return rc;
     HIPCK(p, hipSetDevice(p->device));
@@ -839,6 +840,7 @@ int plba_marginalize(plba_problem* p, int first_kf, int max_edges, plba_prior* o
 int plba_marginalize_factors(plba_problem* p, int n_imu, const int32_t* imu_edges, int n_pt, const int32_t* point_edges,
                              int n_ln, const int32_t* line_edges, int use_prior, int n_drop, const int32_t* drop_vid, plba_prior* out) {
     if (!p || !out || n_imu < 0 || n_pt < 0 || n_ln < 0 || n_drop < 0) return PLBA_ERR_INVALID;
+    if (p->opt.whiten_marg_factors) FAIL(p, PLBA_ERR_INVALID, "whiten_marg_factors = 1 is not implemented: only the reference's unweighted factors (IMU/marginalization.cpp:67)");
     int rc = prepare(p);
     if (rc) return rc;
     HIPCK(p, hipSetDevice(p->device));

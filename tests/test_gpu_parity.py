@@ -151,6 +151,18 @@ def test_config3_imu_reduced(pkg, orc, hip):
     _two_stage(pkg, orc, pkg.window.make_config(3, scale=0.1))
 
 
+def test_large_window_many_block_steps(pkg, orc, hip):
+    """100 keyframes: P = 1485 pose dimensions, 47 block steps of the dense factorisation, 24 dataflow hops of the
+    back-substitution — the shape class of BASELINE configs[4], on a landmark count the oracle finishes in seconds"""
+    w = pkg.window.make_window(100, 3000, 600, imu=True, seed=0x5EED0005)
+    g, o = _pair(pkg, orc, w)
+    sg, so = g.optimize(3), o.optimize(3)
+    assert (sg.iterations, sg.trials, sg.solver_failures) == (so.iterations, so.trials, 0)
+    assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-9)
+    assert max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)) < 1e-9
+    g.close(); o.close()
+
+
 def test_levels_and_inactive_landmarks(pkg, orc, hip):
     w = pkg.window.make_window(6, 120, 30, imu=True, seed=106)
     g, o = _pair(pkg, orc, w)

@@ -157,3 +157,13 @@ def test_prior_edge_error_and_chained_marginalization(orc, pkg):
     assert int(kf["vid_pvr"][0]) not in pr2["vid"] and int(kf["vid_bias"][0]) not in pr2["vid"]
     assert set(int(v) for v in pr["vid"]) - {int(kf["vid_pvr"][0]), int(kf["vid_bias"][0])} <= set(int(v) for v in pr2["vid"])
     q.close()
+
+
+def test_whitened_factors_are_rejected_not_ignored(pkg, orc):
+    w = pkg.window.make_window(5, 40, 8, imu=True, seed=5)
+    p = orc.new_problem(whiten_marg_factors=1)
+    p.upload_window(w)
+    p.optimize(1)
+    with pytest.raises(pkg.abi.PlbaError, match="not implemented"):
+        p.marginalize(0, 50)
+    p.close()
