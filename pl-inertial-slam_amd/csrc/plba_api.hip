@@ -517,7 +517,7 @@ static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
     MARK(p, 0);
     launch_linearize(d, p->cur, true, p->rob, owns_pose_edges(p), s);   // observations + IMU / prior edges, one launch
     MARK(p, 2);
-    launch_landmark_hll(d, p->cur, !first_iter, s);
+    p->assembled = launch_landmark_hll(d, p->cur, !first_iter, owns_pose_edges(p), s);
     if (first_iter) {
         HIPCK(p, hipMemsetAsync(d.kfdiag, 0, (size_t)d.K * 6 * 8, s));
         launch_kfdiag(d, p->cur, s);
@@ -543,7 +543,8 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
     hipStream_t s = p->stream;
     MARK(p, 4);
     if (need_dinv) launch_landmark_dinv(d, s);   // otherwise k_landmark_hll<true> already formed (Hll + lambda I)^-1
-    launch_assemble(d, owns_pose_edges(p), s);
+    if (need_dinv || !p->assembled) launch_assemble(d, owns_pose_edges(p), s);   // ... and assembled the pose-side system
+    p->assembled = false;
     launch_schur_pairs(d, p->cur, s);
     MARK(p, 5);
     if (p->world > 1) {   // single GPU: k_assemble / k_schur_pairs wrote bp into bpg directly

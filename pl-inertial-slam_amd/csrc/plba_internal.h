@@ -109,7 +109,7 @@ struct LmParams { double tau, lower, upper, user_lambda; int max_trials; };
 
 void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s);
 void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, bool owns_pose_edges, hipStream_t s);
-void launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv, hipStream_t s);
+bool launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv_assemble, bool add_lambda, hipStream_t s);
 void launch_kfdiag(const DevBuf& d, int state, hipStream_t s);
 void launch_landmark_dinv(const DevBuf& d, hipStream_t s);
 void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s);

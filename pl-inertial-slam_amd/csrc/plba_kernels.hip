@@ -127,6 +127,26 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
 // -------------------------------------------------------------------------------------------------
 // K5: landmark blocks.  Thread per landmark slot, fixed edge order (deterministic).
 // -------------------------------------------------------------------------------------------------
+// sys = Himu + Hconst (+ lambda I on the real diagonal, 1 on the padded diagonal); rows Ppad, Ppad+1 = pose-side
+// gradient; clears the idle IMU accumulator.  Grid-stride over `nblocks` blocks of `nthreads` threads.
+DEV void assemble_part(const DevBuf& d, int add_lambda, int bid, int nblocks, int tid, int nthreads) {
+    const size_t n = (size_t)(d.Ppad + TILE) * d.ld;
+    const double lambda = d.ctrl->lambda;
+    for (size_t idx = (size_t)bid * nthreads + tid; idx < n; idx += (size_t)nblocks * nthreads) {
+        const int r = (int)(idx / d.ld), c = (int)(idx % d.ld);
+        double v = 0.0;
+        if (r < d.Ppad) {
+            v = d.Himu[idx] + d.Hconst[idx];      // IMU edges of this iteration + the constant prior J0^T J0
+            if (r == c && add_lambda) v += (r < d.P) ? lambda : 1.0;
+            d.Himu_alt[idx] = 0.0;                // the accumulator the NEXT outer iteration's pose-side edges add into
+        } else if (r <= d.Ppad + 1) {
+            v = d.bimu[c];
+            if (r == d.Ppad) { d.bpg[c] = v; d.bimu_alt[c] = 0.0; }
+        }
+        d.sys[idx] = v;
+    }
+}
+
 // (Hll + lambda I)^-1 and D*bl of one landmark slot from its undamped blocks
 DEV void landmark_dinv_one(const DevBuf& d, int slot, const double* h, const double* b, bool active, bool is_pt) {
     double dd[12], tt[6];
@@ -155,10 +175,13 @@ DEV void landmark_dinv_one(const DevBuf& d, int slot, const double* h, const dou
 
 // FUSE_DINV: lambda of this iteration is already known (every outer iteration but the first), so the damped inverse
 // is formed right here from the registers instead of by a second pass over hll/bl.
+// Blocks beyond nblk_lm (only launched together with FUSE_DINV, i.e. when lambda is already known) assemble the
+// pose-side part of the reduced system in the shadow of the landmark pass instead of in a launch of their own.
 template <bool FUSE_DINV>
-__global__ __launch_bounds__(LMB) void k_landmark_hll(DevBuf d, int state) {
+__global__ __launch_bounds__(LMB) void k_landmark_hll(DevBuf d, int state, int nblk_lm, int add_lambda) {
     extern __shared__ double s_dyn[];
     double* s_kc = s_dyn;
+    if ((int)blockIdx.x >= nblk_lm) { assemble_part(d, add_lambda, blockIdx.x - nblk_lm, gridDim.x - nblk_lm, threadIdx.x, LMB); return; }
     for (int k = threadIdx.x; k < d.K; k += LMB) kfcam_make(d.cam, d.kf[state] + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
     __syncthreads();
     const int slot = blockIdx.x * LMB + threadIdx.x;
@@ -419,21 +442,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state) {
 
 // sys = Himu + Hconst (+ lambda I on the real diagonal, 1 on the padded diagonal) ; row Ppad = row Ppad+1 = pose-side gradient
 __global__ __launch_bounds__(256) void k_assemble(DevBuf d, int add_lambda) {
-    const size_t n = (size_t)(d.Ppad + TILE) * d.ld;
-    const double lambda = d.ctrl->lambda;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
-        const int r = (int)(idx / d.ld), c = (int)(idx % d.ld);
-        double v = 0.0;
-        if (r < d.Ppad) {
-            v = d.Himu[idx] + d.Hconst[idx];      // IMU edges of this iteration + the constant prior J0^T J0
-            if (r == c && add_lambda) v += (r < d.P) ? lambda : 1.0;
-            d.Himu_alt[idx] = 0.0;                // the accumulator the NEXT outer iteration's pose-side edges add into
-        } else if (r <= d.Ppad + 1) {
-            v = d.bimu[c];
-            if (r == d.Ppad) { d.bpg[c] = v; d.bimu_alt[c] = 0.0; }
-        }
-        d.sys[idx] = v;
-    }
+    assemble_part(d, add_lambda, blockIdx.x, gridDim.x, threadIdx.x, 256);
 }
 
 // SparseOptimizer::update for one keyframe (oplusImpl of VertexNavStatePVR / VertexNavStateBias)
@@ -854,11 +863,21 @@ void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, b
         else hipLaunchKernelGGL(k_prior<false>, dim3(1), dim3(256), 0, s, d, state);
     }
 }
-void launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv, hipStream_t s) {
-    if (!d.L) return;
+// fuse_dinv_assemble: lambda is known (not the first iteration): the damped landmark inverses are formed in the same
+// pass and extra blocks assemble the pose-side system (returns true if it did, so the caller skips k_assemble)
+bool launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv_assemble, bool add_lambda, hipStream_t s) {
+    if (!d.L) return false;
     const size_t sh = (size_t)d.K * KFCAM_STRIDE * sizeof(double);
-    if (fuse_dinv) hipLaunchKernelGGL(k_landmark_hll<true>, dim3(lm_blocks(d)), dim3(LMB), sh, s, d, state);
-    else hipLaunchKernelGGL(k_landmark_hll<false>, dim3(lm_blocks(d)), dim3(LMB), sh, s, d, state);
+    const int nb = lm_blocks(d);
+    if (fuse_dinv_assemble) {
+        const size_t n = (size_t)(d.Ppad + TILE) * d.ld;
+        int ab = (int)((n + 4 * LMB - 1) / (4 * LMB));
+        if (ab > 4096) ab = 4096;
+        hipLaunchKernelGGL(k_landmark_hll<true>, dim3(nb + ab), dim3(LMB), sh, s, d, state, nb, add_lambda ? 1 : 0);
+        return true;
+    }
+    hipLaunchKernelGGL(k_landmark_hll<false>, dim3(nb), dim3(LMB), sh, s, d, state, nb, 0);
+    return false;
 }
 void launch_kfdiag(const DevBuf& d, int state, hipStream_t s) {
     if (d.npairs) hipLaunchKernelGGL(k_kfdiag, dim3(d.npairs), dim3(256), 0, s, d, state);

@@ -100,6 +100,7 @@ struct plba_problem {
     plba::Mailbox* h_mail = nullptr;            // pinned + device-mapped (k_decide -> host), d_mail = its device address
     plba::Mailbox* d_mail = nullptr;
     unsigned long long mail_seq = 0;
+    bool assembled = false;                     // k_landmark_hll already assembled the pose-side system of this iteration
     plba::DevBuf dv;
     std::vector<plba_trace_row> trace;
     bool saved_valid = false;
