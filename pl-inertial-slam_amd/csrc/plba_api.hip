@@ -522,11 +522,13 @@ static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
         HIPCK(p, hipMemsetAsync(d.kfdiag, 0, (size_t)d.K * 6 * 8, s));
         launch_kfdiag(d, p->cur, s);
     }
-    // Sharded runs: the global chi2 of this state is only exchanged on the first iteration of a call.  On later ones
-    // it is the (already global) chi2 of the trial that was just accepted, evaluated on the very same state, so the
-    // control block keeps it and one collective per iteration is saved.
-    const bool keep_chi = p->world > 1 && !first_iter;
-    if (p->world > 1 && first_iter) {
+    // chi2 of the start state (and computeLambdaInit) is only needed on the first iteration of a call.  On later ones it
+    // is the chi2 of the trial that was just accepted, evaluated on the very same state: k_decide left it in the control
+    // block (already global in a sharded run) together with the iteration / trial counters, so neither the control
+    // kernel nor a collective is needed.
+    if (!first_iter) { MARK(p, 3); return PLBA_OK; }
+    const bool keep_chi = false;
+    if (p->world > 1) {
         int rc;
         launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
         if ((rc = exchange(p, p->d_red.p, 1, 0))) return rc;

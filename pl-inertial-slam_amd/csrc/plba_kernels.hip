@@ -801,6 +801,8 @@ __global__ __launch_bounds__(256) void k_decide(DevBuf d, LmParams lp, double* r
         c->ni = 2.0;
         c->current_chi = tempChi;
         c->accepted = 1;
+        c->iteration += 1;      // the next outer iteration starts from this state: its chi2 is tempChi, trial counter 0
+        c->trial = -1;          // (+1 below)
     } else {
         c->lambda = lambda * c->ni;
         c->ni *= 2.0;
