@@ -3,7 +3,8 @@
 // Host side of the hot path: flattens the uploaded graph into device SoA buffers, builds the static
 // structure (landmark CSR, keyframe-pair lists for the Schur complement, pose-side index map), and
 // drives g2o's Levenberg-Marquardt control flow with every arithmetic step on
-// the device; only the control block (a few scalars) crosses PCIe once per damped trial.
+// the device; only the control block (a few scalars) crosses PCIe once per damped trial (k_decide writes it into
+// mapped host memory, the host polls a sequence number).
 // No CPU fallback exists: every entry point that computes needs a HIP device.
 #include <algorithm>
 #include <chrono>

@@ -1,15 +1,18 @@
 // plba_kernels.hip — hand-written gfx950 kernels of the sparse part of one LM iteration.
 //
-//   K1/K2  k_linearize      one lane per observation: residual + Jacobians + Huber weight, keyframe
-//                            camera blocks (Rcb*Rwb^T, Pwb) staged in LDS, coalesced SoA observation loads
-//   K5     k_landmark_hll   per-landmark segmented reduction of Jl^T w Jl / Jl^T w e (landmark-major CSR,
-//                            fixed order, no atomics)
-//          k_landmark_dinv  (Hll + lambda I)^-1 and its product with bl
-//   K6     k_schur_pairs    one workgroup per co-observing keyframe pair: sum of Jp_i^T Q Jp_j over the
-//                            pair's shared landmarks, wavefront + LDS reduction, exclusive block writes
-//          k_backsub        landmark back-substitution fused with the landmark update
-//   K3/K4  k_pose_edges / k_prior   IMU PVR + bias edges (one wave per edge), marginalization prior edge
-//   K8     k_update_kf, k_reduce, k_lambda_init, k_decide   state update, chi2 reductions, LM control
+//   K1-K4  k_linearize      one lane per observation: residual + compact 128-byte linearisation record + Huber weight,
+//                            keyframe camera blocks (Rcb*Rwb^T, Pwb) staged in LDS, coalesced SoA observation loads;
+//                            extra blocks of the same launch evaluate the IMU PVR + bias edges (pose_edge_block) and
+//                            the marginalization prior edge (prior_block).  k_pose_edges / k_prior: stand-alone forms.
+//   K5     k_landmark_hll   per-landmark reduction of Jl^T w Jl / Jl^T w e over its contiguous edge range (fixed
+//                            order, no atomics); when lambda is known it also forms (Hll + lambda I)^-1 and extra
+//                            blocks assemble the pose-side system (assemble_part).  k_landmark_dinv / k_assemble:
+//                            stand-alone forms for the first iteration and for retries.
+//   K6     k_schur_pairs    one workgroup per <= 256-entry chunk of a co-observing keyframe pair: sum of g_i Q g_j^T,
+//                            DPP wave reduction, last-arriver fold in chunk order, exclusive block writes
+//   K8     k_backsub        landmark back-substitution + landmark / keyframe update into the trial buffers
+//          k_lambda_init (first iteration only), k_decide   chi2 reductions, LM control block, mailbox to the host
+//          k_reduce, k_tri_pack, k_posediag*               sharded runs: partial sums / packed exchange buffer
 //
 // g2o semantics reproduced: SURVEY.md Appendix A; reference formulas: see plba_math.h.
 #include "plba_internal.h"
