@@ -53,8 +53,40 @@ def run_case(pkg, c):
     return g
 
 
+def preint_stream(seed, M=4):
+    """EuRoC-shaped IMU stream for the preintegration producer (ns stamps near 1.4e9 s: long double territory), with
+    samples before the first image and past the second one so every branch of src/keyFrame.cpp:147-170 runs."""
+    LD = np.longdouble
+    rng = np.random.default_rng(seed)
+    t_prev = LD("1403636579.763555527") + LD(0.25) * np.arange(M, dtype=LD)
+    t_curr = t_prev + LD(0.25)
+    ts, starts = [], [0]
+    for m in range(M):
+        k = np.arange(-2, 50 + 2, dtype=LD)
+        tt = t_prev[m] + LD(0.0007) + k / LD(200.0) + LD(1e-6) * rng.normal(size=len(k)).astype(LD)
+        ts.append(np.sort(tt)); starts.append(starts[-1] + len(tt))
+    t = np.concatenate(ts)
+    S = len(t)
+    return dict(sample_start=np.array(starts, dtype=np.int32), t=t, gyr=rng.normal(size=(S, 3)) * 0.3,
+                acc=rng.normal(size=(S, 3)) * 2.0 + np.array([0, 0, 9.81]), t_prev=t_prev, t_curr=t_curr,
+                bg=rng.normal(size=(M, 3)) * 1e-3, ba=rng.normal(size=(M, 3)) * 1e-2)
+
+
+def run_preint(pkg):
+    s = preint_stream(0x601D03)
+    p = orc.new_problem()
+    out = p.preintegrate(s["sample_start"], s["t"], s["gyr"], s["acc"], s["t_prev"], s["t_curr"], s["bg"], s["ba"],
+                         pkg.window.GYR_MEAS_COV, pkg.window.ACC_MEAS_COV)
+    p.close()
+    return dict(meta=dict(seed=0x601D03, M=4), dP=out[:, 0:3].tolist(), dV=out[:, 3:6].tolist(), dR=out[:, 6:15].tolist(),
+                JRg=out[:, 51:60].tolist(), cov_diag=[np.diag(o[60:141].reshape(9, 9)).tolist() for o in out], dt=out[:, 141].tolist(),
+                checksum=float(np.abs(out).sum()))
+
+
 def main():
     pkg = ge.load_package()
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "preint_small.json"), "w") as f:
+        json.dump(run_preint(pkg), f, indent=0)
     for name, c in CASES.items():
         g = run_case(pkg, c)
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".json"), "w") as f:

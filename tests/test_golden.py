@@ -58,3 +58,32 @@ def test_oracle_reproduces_golden(pkg, orc, name):
 @pytest.mark.parametrize("name", CASES)
 def test_hip_matches_golden(pkg, hip, name):
     _check(pkg, pkg.new_problem, _load(name), 1e-9)
+
+
+def _check_preint(pkg, new_problem, tol):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    g = _load("preint_small")
+    s = mg.preint_stream(g["meta"]["seed"], g["meta"]["M"])
+    p = new_problem()
+    out = p.preintegrate(s["sample_start"], s["t"], s["gyr"], s["acc"], s["t_prev"], s["t_curr"], s["bg"], s["ba"],
+                         pkg.window.GYR_MEAS_COV, pkg.window.ACC_MEAS_COV)
+    p.close()
+    for key, sl in (("dP", slice(0, 3)), ("dV", slice(3, 6)), ("dR", slice(6, 15)), ("JRg", slice(51, 60))):
+        ref = np.array(g[key])
+        assert np.abs(out[:, sl] - ref).max() <= tol * max(1.0, np.abs(ref).max()), key
+    for m in range(g["meta"]["M"]):
+        ref = np.array(g["cov_diag"][m])
+        assert np.abs(np.diag(out[m, 60:141].reshape(9, 9)) - ref).max() <= tol * np.abs(ref).max()
+    assert np.allclose(out[:, 141], g["dt"], rtol=0, atol=1e-15)
+    assert np.abs(out).sum() == pytest.approx(g["checksum"], rel=tol)
+
+
+def test_oracle_reproduces_the_preintegration_golden(pkg, orc):
+    _check_preint(pkg, orc.new_problem, 1e-13)
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_preintegration_golden(pkg, hip):
+    _check_preint(pkg, pkg.new_problem, 1e-11)
