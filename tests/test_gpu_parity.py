@@ -163,6 +163,29 @@ def test_large_window_many_block_steps(pkg, orc, hip):
     g.close(); o.close()
 
 
+@pytest.mark.parametrize("K,Np,Nl,imu", [
+    (2, 30, 6, True),        # the smallest IMU window: one free keyframe, one block step
+    (6, 80, 0, True),        # points only
+    (6, 0, 40, True),        # lines only
+    (5, 0, 0, True),         # no observations at all: IMU chain + LM damping only
+    (3, 40, 10, False),      # smallest no-IMU window (velocity held by damping alone)
+    (9, 9, 3, True),         # almost every landmark seen by very few keyframes (rank-deficient landmark blocks)
+])
+def test_degenerate_windows(pkg, orc, hip, K, Np, Nl, imu):
+    """ragged / empty inputs: whatever the oracle does with them, the device does the same"""
+    w = pkg.window.make_window(K, Np, Nl, imu=imu, seed=0xDE6E + K + Np)
+    g, o = _pair(pkg, orc, w)
+    sg, so = g.optimize(4), o.optimize(4)
+    assert (sg.iterations, sg.trials, sg.stop_reason, sg.solver_failures) == (so.iterations, so.trials, so.stop_reason, so.solver_failures)
+    if np.isfinite(so.chi2_final):
+        assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-6, abs=1e-9)
+    d = _pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)
+    assert max(d) < (1e-6 if imu else 1e-4), d          # no-IMU windows are gauge-deficient: conditioned by the damping only
+    if Np:
+        assert np.abs(g.get_points() - o.get_points()).max() < 1e-5
+    g.close(); o.close()
+
+
 def test_levels_and_inactive_landmarks(pkg, orc, hip):
     w = pkg.window.make_window(6, 120, 30, imu=True, seed=106)
     g, o = _pair(pkg, orc, w)
