@@ -53,6 +53,7 @@ void plba_default_options(plba_options* o) {
     o->use_mfma = 1;
     o->factor_block = 32;
     o->factor_flow = 0;
+    o->chain_elim = 0;
 }
 const char* plba_backend_name(void) { return "hip-gfx950"; }
 const char* plba_last_error(const plba_problem* p) { return p ? p->err : g_create_err; }
@@ -465,6 +466,45 @@ static int prepare(plba_problem* p) {
     d.Linv = p->d_Linv.p; d.flow_flags = p->d_flow_flags.p; d.LTblk = p->d_LT32.p; d.Linv32 = p->d_LT32.p; d.rdblk = p->d_rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32; d.chol_flags = p->d_chol_flags.p; d.flow = p->opt.factor_flow != 0;
     d.chi_part = p->d_chi_part.p; d.scale_part = p->d_scale_part.p; d.maxd_part = p->d_maxd_part.p; d.kfdiag = p->d_kfdiag.p; d.posediag = p->d_posediag.p;
     d.ctrl = p->d_ctrl.p; d.trace = p->d_trace.p; d.trace_cap = TRACE_CAP; d.trace_n = p->d_trace_n.p;
+    // ---- chain-variable elimination (plba_chain.hip): index maps and the compact dense system ---------------------------------
+    p->chain_ok = false;
+    if (p->opt.chain_elim && p->pr_nv == 0 && p->opt.use_mfma && d.fb == 32 && p->P > 0) {
+        std::vector<int32_t> cidx, pidx, pblk, blk_of_kf(K, -1);
+        for (int k = 0; k < K; ++k) {
+            const int op = p->off_pvr[k], ob = p->off_bias[k];
+            if (op >= 0) for (int c : {0, 1, 2, 6, 7, 8}) { pidx.push_back(op + c); pblk.push_back((int32_t)(cidx.size() / 9)); }
+            if (op >= 0 || ob >= 0) {
+                blk_of_kf[k] = (int)(cidx.size() / 9);
+                for (int c = 0; c < 3; ++c) cidx.push_back(op >= 0 ? op + 3 + c : -1);
+                for (int c = 0; c < 6; ++c) cidx.push_back(ob >= 0 ? ob + c : -1);
+            }
+        }
+        const int nblk = (int)(cidx.size() / 9);
+        bool ok = nblk > 0 && !pidx.empty() && chain_elim_supported((int)pidx.size());
+        // block-tridiagonal only if every IMU edge joins neighbouring chain blocks (or touches a single one)
+        for (int m = 0; m < M && ok; ++m) {
+            const int bi = blk_of_kf[p->imu_i[m]], bj = blk_of_kf[p->imu_j[m]];
+            if (bi >= 0 && bj >= 0 && std::abs(bi - bj) > 1) ok = false;
+        }
+        if (ok) {
+            for (int c = 0; c < 9; ++c) cidx.push_back(-1);        // sentinel row read by the last step
+            ChainView& cv = p->cv;
+            cv.nblk = nblk; cv.Pd = (int)pidx.size(); cv.Pdpad = ((cv.Pd + TILE - 1) / TILE) * TILE; cv.Wld = ((cv.Pd + 1 + 63) / 64) * 64;
+            HIPCK(p, p->d_cidx.upload(cidx)); HIPCK(p, p->d_pidx.upload(pidx)); HIPCK(p, p->d_pblk.upload(pblk));
+            HIPCK(p, p->d_W.alloc((size_t)(nblk * 9 + 4) * cv.Wld)); HIPCK(p, p->d_Ldinv.alloc((size_t)nblk * 81)); HIPCK(p, p->d_Lsub.alloc((size_t)nblk * 81));
+            const size_t sysn_d = (size_t)(cv.Pdpad + TILE) * cv.Pdpad;
+            HIPCK(p, p->d_sysd.alloc(sysn_d)); HIPCK(p, p->d_Lfacd.alloc(sysn_d)); HIPCK(p, p->d_xd.alloc(cv.Pdpad));
+            HIPCK(p, p->d_Linvd.alloc((size_t)(cv.Pdpad / TILE) * TILE * TILE)); HIPCK(p, p->d_LT32d.alloc((size_t)cv.Pdpad * 64)); HIPCK(p, p->d_rd32d.alloc(cv.Pdpad));
+            HIPCK(p, p->d_flow_flagsd.alloc(cv.Pdpad / TILE)); HIPCK(p, p->d_chol_flagsd.alloc((size_t)(cv.Pdpad / 32 + 2) * (cv.Pdpad / 32)));
+            cv.cidx = p->d_cidx.p; cv.pidx = p->d_pidx.p; cv.pblk = p->d_pblk.p; cv.W = p->d_W.p; cv.Ldinv = p->d_Ldinv.p; cv.Lsub = p->d_Lsub.p;
+            DevBuf& dd = p->dd;
+            dd = d;
+            dd.P = cv.Pd; dd.Ppad = cv.Pdpad; dd.ld = cv.Pdpad;
+            dd.sys = p->d_sysd.p; dd.Lfac = p->d_Lfacd.p; dd.x = p->d_xd.p; dd.Linv = p->d_Linvd.p; dd.LTblk = p->d_LT32d.p; dd.Linv32 = p->d_LT32d.p;
+            dd.rdblk = p->d_rd32d.p; dd.flow_flags = p->d_flow_flagsd.p; dd.chol_flags = p->d_chol_flagsd.p;
+            p->chain_ok = true;
+        }
+    }
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
     if (p->pr_nv > 0 && p->rank == 0) {
         const int n = p->pr_n;
@@ -562,11 +602,23 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
     }
     MARK(p, 6);
     if (!do_solve) return PLBA_OK;
-    MARKF(p, 11);
     const int epoch = ++p->flow_epoch;
-    launch_cholesky(d, p->opt.use_mfma != 0, epoch, s);
-    MARKF(p, 12);
-    launch_trsv_back(d, p->opt.use_mfma != 0, epoch, s);
+    if (p->chain_ok) {
+        // velocity / bias variables first (block-tridiagonal, one workgroup), then the dense factorisation on the
+        // 6-per-keyframe pose system, then the chain back-substitution (plba_chain.hip)
+        launch_chain_elim(d, p->cv, s);
+        launch_chain_schur(d, p->cv, p->dd, s);
+        MARKF(p, 11);
+        launch_cholesky(p->dd, true, epoch, s);
+        MARKF(p, 12);
+        launch_trsv_back(p->dd, true, epoch, s);
+        launch_chain_back(d, p->cv, p->dd, s);
+    } else {
+        MARKF(p, 11);
+        launch_cholesky(d, p->opt.use_mfma != 0, epoch, s);
+        MARKF(p, 12);
+        launch_trsv_back(d, p->opt.use_mfma != 0, epoch, s);
+    }
     MARK(p, 7);
     launch_backsub(d, p->cur, p->cur ^ 1, s);
     launch_update_kf(d, p->cur, p->cur ^ 1, s);
@@ -934,8 +986,9 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
         if (w == "err_pt") { v.resize((size_t)p->Ep * 2); for (int e = 0; e < p->Ep; ++e) { const size_t o = (size_t)p->ob_pos[e] * EREC; v[2 * (size_t)e] = h[o + 13]; v[2 * (size_t)e + 1] = h[o + 14]; } }
         else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { const size_t o = (size_t)p->ob_pos[p->Ep + e] * EREC; v[3 * (size_t)e] = h[o + 13]; v[3 * (size_t)e + 1] = h[o + 14]; } }
     } else if (w == "erec") { HIPCK(p, fetch(d.erec, (size_t)p->E * EREC, v)); }
-    else if (w == "stamps") { HIPCK(p, fetch(d.maxd_part, 32, v)); }
+    else if (w == "stamps") { HIPCK(p, fetch(d.maxd_part, 64, v)); }
     else if (w == "pose_dim") v = {(double)p->P};
+    else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};
     else if (w == "chi2") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {p->h_ctrl->current_chi}; }
     else if (w == "maxdiag") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {p->h_ctrl->maxdiag}; }
     else if (w == "solver_ok") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {(double)p->h_ctrl->solver_ok}; }

@@ -127,6 +127,20 @@ void launch_depth(const DevBuf& d, int state, uint8_t* out, hipStream_t s);
 int  edge_blocks(const DevBuf& d);
 
 // dense
+// chain-variable elimination ahead of the dense factorisation (plba_chain.hip)
+struct ChainView {
+    int nblk, Pd, Pdpad, Wld;     // chain blocks (9 padded dims each); dense pose dims, padded to 64; leading dimension of W
+    const int32_t* cidx;          // (nblk + 1) x 9 system indices of the chain dims, -1 = padding (last row all -1)
+    const int32_t* pidx;          // Pd system indices of the pose dims
+    const int32_t* pblk;          // Pd: chain block of the keyframe each pose dim belongs to
+    double* W;                    // (nblk * 9 + 4) x Wld:  L_c^-1 [B | b_c], column Pd = w_b
+    double* Ldinv;                // nblk x 81: L_ii^-1, row-major
+    double* Lsub;                 // nblk x 81: L_{i+1,i}
+};
+bool chain_elim_supported(int Pd);     // the elimination kernel carries at most 1920 coupled columns in one workgroup
+void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s);
+void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);   // writes dd.sys
+void launch_chain_back(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);    // dd.x -> d.x
 void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s);   // sys -> Lfac (lower) incl. the augmented rows
 void launch_trsv_back(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s);      // x = L^-T y; epoch must differ from the previous call's
 void launch_ata(const double* A_colmajor, int rows, int cols, double* out_rowmajor, int ldo, hipStream_t s);  // A^T A

@@ -100,6 +100,13 @@ struct plba_problem {
     plba::Mailbox* h_mail = nullptr;            // pinned + device-mapped (k_decide -> host), d_mail = its device address
     plba::Mailbox* d_mail = nullptr;
     unsigned long long mail_seq = 0;
+    // chain-variable elimination (options.chain_elim; structure permitting): the dense solver then runs on `dd`
+    bool chain_ok = false;
+    plba::ChainView cv{};
+    plba::DevBuf dd{};
+    plba::DArr<int32_t> d_cidx, d_pidx, d_pblk;
+    plba::DArr<double> d_W, d_Ldinv, d_Lsub, d_sysd, d_Lfacd, d_xd, d_Linvd, d_LT32d, d_rd32d;
+    plba::DArr<int> d_flow_flagsd, d_chol_flagsd;
     bool assembled = false;                     // k_landmark_hll already assembled the pose-side system of this iteration
     plba::DevBuf dv;
     std::vector<plba_trace_row> trace;
