@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink landmark counts (debug only; invalidates the number)")
     ap.add_argument("--kf", type=int, default=0, help="override the keyframe count (debug only)")
     ap.add_argument("--fb", type=int, default=0, help="dense factorisation block width (32/64); 0 = library default")
+    ap.add_argument("--chain", action="store_true", help="experimental: chain_elim = 1 (velocity / bias variables eliminated first)")
     args = ap.parse_args()
 
     import torch
@@ -185,7 +186,8 @@ def main():
     stream = torch.cuda.Stream()
     # profile=1: two HIP events per LM trial (on the stream the kernels run on) bracket the dense factorisation launches,
     # the dominant kernel; the full per-phase table comes from a second, untimed problem below
-    prob = pkg.new_problem(profile=1, **({"factor_block": args.fb} if args.fb else {}))
+    extra = dict(**({"factor_block": args.fb} if args.fb else {}), **({"chain_elim": 1} if args.chain else {}))
+    prob = pkg.new_problem(profile=1, **extra)
     prob.set_stream(stream.cuda_stream)
     prob.upload_window(w)
     if world > 1:
@@ -217,11 +219,12 @@ def main():
     b_iter = 2 * (32 * Ep + 40 * El) + 3 * (24 * Npl + 48 * Nll)        # one LM iteration
     P = int(prob.debug_get("pose_dim")[0])
     fb = args.fb if args.fb else 32
-    n_fact_launches = ((P + 63) // 64) * 64 // fb + 1                    # first-block launch + one per block step
-    flops_fact = P ** 3 / 3.0 + P * P                                    # LL^T of the P x P system + the forward solve riding along
+    Pdense = int(prob.debug_get("dense_dim")[0])                          # = P unless chain_elim reduced the dense part
+    n_fact_launches = ((Pdense + 63) // 64) * 64 // fb + 1               # first-block launch + one per block step
+    flops_fact = Pdense ** 3 / 3.0 + Pdense * Pdense                     # LL^T of the dense system + the forward solve riding along
     fact_ms = phases[1] / max(trials, 1) / n_fact_launches               # live: HIP events over the timed region
     # second, untimed pass with every phase bracketed (profile=2): phase table + the HBM-bound kernel's launch time
-    prob2 = pkg.new_problem(profile=2, **({"factor_block": args.fb} if args.fb else {}))
+    prob2 = pkg.new_problem(profile=2, **extra)
     prob2.set_stream(stream.cuda_stream)
     prob2.upload_window(w)
     if world > 1:

@@ -469,12 +469,13 @@ static int prepare(plba_problem* p) {
     // ---- chain-variable elimination (plba_chain.hip): index maps and the compact dense system ---------------------------------
     p->chain_ok = false;
     if (p->opt.chain_elim && p->pr_nv == 0 && p->opt.use_mfma && d.fb == 32 && p->P > 0) {
-        std::vector<int32_t> cidx, pidx, pblk, blk_of_kf(K, -1);
+        std::vector<int32_t> cidx, pidx, pblk, pcol0, blk_of_kf(K, -1);
         for (int k = 0; k < K; ++k) {
             const int op = p->off_pvr[k], ob = p->off_bias[k];
             if (op >= 0) for (int c : {0, 1, 2, 6, 7, 8}) { pidx.push_back(op + c); pblk.push_back((int32_t)(cidx.size() / 9)); }
             if (op >= 0 || ob >= 0) {
                 blk_of_kf[k] = (int)(cidx.size() / 9);
+                pcol0.push_back(op >= 0 ? (int32_t)pidx.size() - 6 : -1);
                 for (int c = 0; c < 3; ++c) cidx.push_back(op >= 0 ? op + 3 + c : -1);
                 for (int c = 0; c < 6; ++c) cidx.push_back(ob >= 0 ? ob + c : -1);
             }
@@ -490,13 +491,13 @@ static int prepare(plba_problem* p) {
             for (int c = 0; c < 9; ++c) cidx.push_back(-1);        // sentinel row read by the last step
             ChainView& cv = p->cv;
             cv.nblk = nblk; cv.Pd = (int)pidx.size(); cv.Pdpad = ((cv.Pd + TILE - 1) / TILE) * TILE; cv.Wld = ((cv.Pd + 1 + 63) / 64) * 64;
-            HIPCK(p, p->d_cidx.upload(cidx)); HIPCK(p, p->d_pidx.upload(pidx)); HIPCK(p, p->d_pblk.upload(pblk));
+            HIPCK(p, p->d_cidx.upload(cidx)); HIPCK(p, p->d_pidx.upload(pidx)); HIPCK(p, p->d_pblk.upload(pblk)); HIPCK(p, p->d_pcol0.upload(pcol0));
             HIPCK(p, p->d_W.alloc((size_t)(nblk * 9 + 4) * cv.Wld)); HIPCK(p, p->d_Ldinv.alloc((size_t)nblk * 81)); HIPCK(p, p->d_Lsub.alloc((size_t)nblk * 81));
             const size_t sysn_d = (size_t)(cv.Pdpad + TILE) * cv.Pdpad;
             HIPCK(p, p->d_sysd.alloc(sysn_d)); HIPCK(p, p->d_Lfacd.alloc(sysn_d)); HIPCK(p, p->d_xd.alloc(cv.Pdpad));
             HIPCK(p, p->d_Linvd.alloc((size_t)(cv.Pdpad / TILE) * TILE * TILE)); HIPCK(p, p->d_LT32d.alloc((size_t)cv.Pdpad * 64)); HIPCK(p, p->d_rd32d.alloc(cv.Pdpad));
             HIPCK(p, p->d_flow_flagsd.alloc(cv.Pdpad / TILE)); HIPCK(p, p->d_chol_flagsd.alloc((size_t)(cv.Pdpad / 32 + 2) * (cv.Pdpad / 32)));
-            cv.cidx = p->d_cidx.p; cv.pidx = p->d_pidx.p; cv.pblk = p->d_pblk.p; cv.W = p->d_W.p; cv.Ldinv = p->d_Ldinv.p; cv.Lsub = p->d_Lsub.p;
+            cv.cidx = p->d_cidx.p; cv.pidx = p->d_pidx.p; cv.pblk = p->d_pblk.p; cv.pcol0 = p->d_pcol0.p; cv.W = p->d_W.p; cv.Ldinv = p->d_Ldinv.p; cv.Lsub = p->d_Lsub.p;
             DevBuf& dd = p->dd;
             dd = d;
             dd.P = cv.Pd; dd.Ppad = cv.Pdpad; dd.ld = cv.Pdpad;
@@ -986,7 +987,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
         if (w == "err_pt") { v.resize((size_t)p->Ep * 2); for (int e = 0; e < p->Ep; ++e) { const size_t o = (size_t)p->ob_pos[e] * EREC; v[2 * (size_t)e] = h[o + 13]; v[2 * (size_t)e + 1] = h[o + 14]; } }
         else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { const size_t o = (size_t)p->ob_pos[p->Ep + e] * EREC; v[3 * (size_t)e] = h[o + 13]; v[3 * (size_t)e + 1] = h[o + 14]; } }
     } else if (w == "erec") { HIPCK(p, fetch(d.erec, (size_t)p->E * EREC, v)); }
-    else if (w == "stamps") { HIPCK(p, fetch(d.maxd_part, 64, v)); }
+    else if (w == "stamps") { HIPCK(p, fetch(d.maxd_part, 80, v)); }
     else if (w == "pose_dim") v = {(double)p->P};
     else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};
     else if (w == "chi2") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {p->h_ctrl->current_chi}; }

@@ -59,8 +59,12 @@ template <int NCS, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_chain_elim(DevBuf d, ChainView cv, int colw) {
     __shared__ double sLsub[4][81], sLinv[4][81];     // ring indexed by block step & 3
     __shared__ double sA[81];
-    __shared__ double sCg[CHUNK][162];                // C_ii (81) and C_{i+1,i} (81) of the current chunk of block steps
     __shared__ int s_step, s_prog[COLW_MAX], s_bad;   // chain steps published; steps completed per column wave
+    // staged per chunk of CHUNK block steps (dynamic LDS, 86 KB): nothing inside a step touches global memory for input
+    extern __shared__ double s_stage[];
+    double (*sCg)[162] = reinterpret_cast<double (*)[162]>(s_stage);                       // C_ii (81) | C_{i+1,i} (81)
+    double (*sBg)[162] = reinterpret_cast<double (*)[162]>(s_stage + CHUNK * 162);         // B_i against the pose dims of blocks i-1, i, i+1: [3][6][9]
+    double* sRhs = s_stage + 2 * CHUNK * 162;                                              // b_c of the chunk: [CHUNK][9]
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ld = d.ld, n = cv.nblk;
     if (threadIdx.x == 0) { s_step = 0; s_bad = 0; }
@@ -73,15 +77,15 @@ __global__ __launch_bounds__(MAXT) void k_chain_elim(DevBuf d, ChainView cv, int
     const int stride = colw * 64;
     const int col0 = (wv - 1) * 64 + lane;
     double wp[NCS][9];
-    int gp[NCS], pb[NCS];      // system index of the column's pose dimension, chain block of its keyframe
+    int pb[NCS], pc[NCS];      // chain block of the column's keyframe, index (0..5) of the column among that keyframe's pose dimensions
     bool act[NCS], rhs[NCS];
 #pragma unroll
     for (int cs = 0; cs < NCS; ++cs) {
         const int col = col0 + cs * stride;
         rhs[cs] = (col == cv.Pd);
         act[cs] = wv > 0 && col <= cv.Pd;
-        gp[cs] = (act[cs] && !rhs[cs]) ? cv.pidx[col] : 0;
         pb[cs] = (act[cs] && !rhs[cs]) ? cv.pblk[col] : 0;
+        pc[cs] = (act[cs] && !rhs[cs]) ? col - cv.pcol0[pb[cs]] : 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) wp[cs][r] = 0.0;
     }
@@ -101,6 +105,15 @@ __global__ __launch_bounds__(MAXT) void k_chain_elim(DevBuf d, ChainView cv, int
                 v = (ga < 0 || gt < 0) ? 0.0 : sym_at(d.sys, ld, ga, gt);
             }
             sCg[idx / 162][e] = v;
+            // coupling of block `blk` with the pose dimensions of the keyframes of blocks blk-1, blk, blk+1
+            const int dl = e / 54, kc = (e % 54) / 9, rr = e % 9;
+            const int nb = blk + dl - 1;
+            const int c0 = (nb >= 0 && nb < n) ? cv.pcol0[nb] : -1;
+            const int gi = ci[rr];
+            double bvv = 0.0;
+            if (gi >= 0 && c0 >= 0) bvv = sym_at(d.sys, ld, gi, cv.pidx[c0 + kc]);
+            sBg[idx / 162][e] = bvv;
+            if (e < 9) sRhs[(idx / 162) * 9 + e] = ci[e] < 0 ? 0.0 : d.sys[(size_t)d.Ppad * ld + ci[e]];
         }
         __syncthreads();
         if (wv == 0) {
@@ -116,6 +129,9 @@ __global__ __launch_bounds__(MAXT) void k_chain_elim(DevBuf d, ChainView cv, int
                     }
                 }
                 ESTAMP(0);
+#ifdef PLBA_STAMPS
+                if (lane == 0 && i >= 20 && i < 24) d.maxd_part[60 + 2 * (i - 20)] = (double)__builtin_readcyclecounter();
+#endif
                 const bool has_next = i + 1 < n;
                 const double* Cg = sCg[i - ch0];
                 double v0 = Cg[e0], v1 = Cg[e1 < 81 ? e1 : 0];
@@ -177,22 +193,35 @@ __global__ __launch_bounds__(MAXT) void k_chain_elim(DevBuf d, ChainView cv, int
                 lds_store(&s_step, i + 1);        // a wave's LDS operations execute in order: the data above is visible first
                 ESTAMP(4);
 #ifdef PLBA_STAMPS
+                if (lane == 0 && i >= 20 && i < 24) d.maxd_part[61 + 2 * (i - 20)] = (double)__builtin_readcyclecounter();
+#endif
+#ifdef PLBA_STAMPS
                 if (lane == 0 && i == 21) d.maxd_part[45] = (double)__builtin_readcyclecounter();
 #endif
             }
         } else {
             for (int i = ch0; i < ch1; ++i) {
-                const int32_t* ci = cv.cidx + i * 9;
+                // W is block lower-trapezoidal: columns of keyframes beyond block i + 1 are still zero.  A wave whose
+                // lanes are all in that state has nothing to do in this step (W keeps its zeros from allocation).
+                bool idle = true;
+#pragma unroll
+                for (int cs = 0; cs < NCS; ++cs) idle = idle && (!act[cs] || (!rhs[cs] && pb[cs] > i + 1));
+                if (__all(idle)) {
+                    int spins0 = 0;
+                    while (lds_load(&s_step) <= i) { __builtin_amdgcn_s_sleep(1); if (++spins0 > SPIN_MAX) { s_bad = 1; break; } }
+                    if (lane == 0) lds_store(&s_prog[wv - 1], i + 1);
+                    continue;
+                }
                 double t[NCS][9];
 #pragma unroll
-                for (int cs = 0; cs < NCS; ++cs)
+                for (int cs = 0; cs < NCS; ++cs) {
+                    // B is sparse: chain block i only couples to the pose dimensions of the neighbouring keyframes
+                    const int dl = pb[cs] - i + 1;                      // 0, 1, 2 where there is coupling
+                    const bool near = act[cs] && !rhs[cs] && dl >= 0 && dl <= 2;
+                    const double* src = rhs[cs] ? sRhs + (i - ch0) * 9 : sBg[i - ch0] + ((near ? dl : 0) * 6 + pc[cs]) * 9;
 #pragma unroll
-                    for (int r = 0; r < 9; ++r) {
-                        const int gi = ci[r];
-                        // B is sparse: chain block i only couples to the pose dimensions of the neighbouring keyframes
-                        const bool near = rhs[cs] || (pb[cs] >= i - 1 && pb[cs] <= i + 1);
-                        t[cs][r] = (!act[cs] || gi < 0 || !near) ? 0.0 : (rhs[cs] ? d.sys[(size_t)d.Ppad * ld + gi] : sym_at(d.sys, ld, gi, gp[cs]));
-                    }
+                    for (int r = 0; r < 9; ++r) { const double v = src[r]; t[cs][r] = (near || (rhs[cs] && act[cs])) ? v : 0.0; }
+                }
                 if (wv == 1) ESTAMP(8);
                 int spins = 0;
                 while (lds_load(&s_step) <= i) { __builtin_amdgcn_s_sleep(1); if (++spins > SPIN_MAX) { s_bad = 1; break; } }
@@ -224,6 +253,9 @@ __global__ __launch_bounds__(MAXT) void k_chain_elim(DevBuf d, ChainView cv, int
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS reads of step i are complete
                 if (lane == 0) lds_store(&s_prog[wv - 1], i + 1);
                 if (wv == 1) ESTAMP(10);
+#ifdef PLBA_STAMPS
+                if (lane == 0 && i == 20) d.maxd_part[70 + wv] = (double)__builtin_readcyclecounter();
+#endif
             }
         }
     }
@@ -353,13 +385,21 @@ bool chain_elim_supported(int Pd) { return Pd + 1 <= 2 * COLW_MAX * 64; }
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s) {
     const int cols = cv.Pd + 1;
     int colw = (cols + 63) / 64;
+    const size_t sh = (size_t)(2 * CHUNK * 162 + CHUNK * 9) * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_elim<1, 384>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_elim<1, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_elim<2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        attr_set = true;
+    }
     if (colw <= 5) {
-        hipLaunchKernelGGL((k_chain_elim<1, 384>), dim3(1), dim3(64 * (1 + colw)), 0, s, d, cv, colw);
+        hipLaunchKernelGGL((k_chain_elim<1, 384>), dim3(1), dim3(64 * (1 + colw)), sh, s, d, cv, colw);
     } else if (colw <= COLW_MAX) {
-        hipLaunchKernelGGL((k_chain_elim<1, 1024>), dim3(1), dim3(64 * (1 + colw)), 0, s, d, cv, colw);
+        hipLaunchKernelGGL((k_chain_elim<1, 1024>), dim3(1), dim3(64 * (1 + colw)), sh, s, d, cv, colw);
     } else {
         colw = (cols + 127) / 128;
-        hipLaunchKernelGGL((k_chain_elim<2, 1024>), dim3(1), dim3(64 * (1 + colw)), 0, s, d, cv, colw);
+        hipLaunchKernelGGL((k_chain_elim<2, 1024>), dim3(1), dim3(64 * (1 + colw)), sh, s, d, cv, colw);
     }
 }
 void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s) {

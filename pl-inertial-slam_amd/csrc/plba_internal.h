@@ -133,6 +133,7 @@ struct ChainView {
     const int32_t* cidx;          // (nblk + 1) x 9 system indices of the chain dims, -1 = padding (last row all -1)
     const int32_t* pidx;          // Pd system indices of the pose dims
     const int32_t* pblk;          // Pd: chain block of the keyframe each pose dim belongs to
+    const int32_t* pcol0;         // nblk: first pose column of the keyframe owning each chain block (-1: its pose is fixed)
     double* W;                    // (nblk * 9 + 4) x Wld:  L_c^-1 [B | b_c], column Pd = w_b
     double* Ldinv;                // nblk x 81: L_ii^-1, row-major
     double* Lsub;                 // nblk x 81: L_{i+1,i}
