@@ -33,6 +33,7 @@ char g_create_err[256] = "";
     } while (0)
 
 static const int TRACE_CAP = 4096;
+static const int SCHUR_CHUNK = 256;   // entries of a keyframe pair per k_schur_pairs workgroup (512: no faster)
 
 static bool all_finite(const double* a, size_t n) {
     for (size_t i = 0; i < n; ++i) if (!std::isfinite(a[i])) return false;
@@ -410,8 +411,8 @@ static int prepare(plba_problem* p) {
     for (size_t q = 0; q < pair_i.size(); ++q) {
         pair_ch0.push_back((int32_t)ch_pair.size());
         int32_t nchq = 0;
-        for (int32_t s0 = pair_start[q]; s0 < pair_start[q + 1]; s0 += 256) {
-            ch_pair.push_back((int32_t)q); ch_start.push_back(s0); ch_end.push_back(std::min(s0 + 256, pair_start[q + 1])); ++nchq;
+        for (int32_t s0 = pair_start[q]; s0 < pair_start[q + 1]; s0 += SCHUR_CHUNK) {
+            ch_pair.push_back((int32_t)q); ch_start.push_back(s0); ch_end.push_back(std::min(s0 + SCHUR_CHUNK, pair_start[q + 1])); ++nchq;
         }
         pair_nch.push_back(nchq);
     }

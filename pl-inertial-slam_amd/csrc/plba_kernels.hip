@@ -336,8 +336,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state) {
     for (int t = 0; t < 36; ++t) acc[t] = 0.0;
 #pragma unroll
     for (int t = 0; t < 6; ++t) { gb[t] = 0.0; gp[t] = 0.0; }
-    const int n = d.ch_start[ch] + threadIdx.x;
-    if (n < d.ch_end[ch]) {
+    for (int n = d.ch_start[ch] + threadIdx.x; n < d.ch_end[ch]; n += 256) {
         const int pi = d.ent_pi[n], pj = d.ent_pj[n], slot = d.ent_slot[n];
         const double wi = d.erec[(size_t)pi * EREC + 12];
         const double wj = d.erec[(size_t)pj * EREC + 12];
