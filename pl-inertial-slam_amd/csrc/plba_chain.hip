@@ -44,6 +44,7 @@ template <typename T> __device__ __forceinline__ void lds_store(T* p, T v) { __h
 template <typename T> __device__ __forceinline__ T lds_load(const T* p) { return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ double sym_at(const double* sys, int ld, int i, int j) { return i >= j ? sys[(size_t)i * ld + j] : sys[(size_t)j * ld + i]; }
 constexpr int SPIN_MAX = 1 << 20;
+constexpr int RING = 8;               // LDS ring of published chain factors; the chain wave checks the column waves' progress every 4th step
 constexpr int CHUNK = 32;             // block steps whose C blocks are staged in LDS at a time (41 KB)
 constexpr int COLW_MAX = 15;          // k_chain_elim: wave 0 = chain, up to 15 waves of column lanes (1024 threads)
 }  // namespace
@@ -57,7 +58,7 @@ constexpr int COLW_MAX = 15;          // k_chain_elim: wave 0 = chain, up to 15 
 #endif
 template <int NCS, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_chain_elim(DevBuf d, ChainView cv, int colw) {
-    __shared__ double sLsub[4][81], sLinv[4][81];     // ring indexed by block step & 3
+    __shared__ __attribute__((aligned(16))) double sLsub[RING][90], sLinv[RING][90];     // ring indexed by block step & (RING - 1); rows of 9 padded to 10: aligned pairs
     __shared__ double sA[81];
     __shared__ int s_step, s_prog[COLW_MAX], s_bad;   // chain steps published; steps completed per column wave
     // staged per chunk of CHUNK block steps (dynamic LDS, 86 KB): nothing inside a step touches global memory for input
@@ -118,12 +119,12 @@ __global__ __launch_bounds__(MAXT) void k_chain_elim(DevBuf d, ChainView cv, int
         __syncthreads();
         if (wv == 0) {
             for (int i = ch0; i < ch1; ++i) {
-                if (i >= 3) {      // the LDS ring holds 4 steps: the column waves must be done with step i - 3
+                if (i >= 4 && (i & 3) == 0) {      // ring of 8: before writing slots i..i+3 the column waves must be done with step i - 4
                     int spins = 0;
                     while (true) {
                         int mn = lds_load(&s_prog[0]);
                         for (int q = 1; q < colw; ++q) mn = min(mn, lds_load(&s_prog[q]));
-                        if (mn >= i - 2) break;
+                        if (mn >= i - 3) break;
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > SPIN_MAX) { bad = true; break; }
                     }
@@ -139,9 +140,9 @@ __global__ __launch_bounds__(MAXT) void k_chain_elim(DevBuf d, ChainView cv, int
 #pragma unroll
                 for (int t = 0; t < 9; ++t) { cs0[t] = Cg[81 + r0 * 9 + t]; cs1[t] = Cg[81 + r1 * 9 + t]; }
                 if (i > 0) {       // (a) C_ii - L_{i,i-1} L_{i,i-1}^T
-                    const double* Lp = sLsub[(i - 1) & 3];
+                    const double* Lp = sLsub[(i - 1) & (RING - 1)];
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) { v0 = fma(-Lp[r0 * 9 + t], Lp[c0 * 9 + t], v0); v1 = fma(-Lp[r1 * 9 + t], Lp[c1 * 9 + t], v1); }
+                    for (int t = 0; t < 9; ++t) { v0 = fma(-Lp[r0 * 10 + t], Lp[c0 * 10 + t], v0); v1 = fma(-Lp[r1 * 10 + t], Lp[c1 * 10 + t], v1); }
                 }
                 sA[e0] = v0;
                 if (e1 < 81) sA[e1] = v1;
@@ -175,19 +176,22 @@ __global__ __launch_bounds__(MAXT) void k_chain_elim(DevBuf d, ChainView cv, int
                     for (int t = j + 1; t < 9; ++t) x[t] = fma(-lane_bcast(a[j], t), x[j], x[t]);     // L[t][j] lives in lane t, register j
                 }
                 ESTAMP(3);
-                double* Li = sLinv[i & 3];
+                double* Li = sLinv[i & (RING - 1)];
                 if (lane < 9) {
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) { Li[t * 9 + lane] = x[t]; cv.Ldinv[(size_t)i * 81 + t * 9 + lane] = x[t]; }
+                    for (int t = 0; t < 9; ++t) { Li[t * 10 + lane] = x[t]; cv.Ldinv[(size_t)i * 81 + t * 9 + lane] = x[t]; }
+                    Li[lane * 10 + 9] = 0.0;
                 }
                 // (d) L_{i+1,i} = C_{i+1,i} L_ii^-T
                 if (has_next) {
                     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) { s0 = fma(cs0[t], Li[c0 * 9 + t], s0); s1 = fma(cs1[t], Li[c1 * 9 + t], s1); }
-                    sLsub[i & 3][e0] = s0;
+                    for (int t = 0; t < 9; ++t) { s0 = fma(cs0[t], Li[c0 * 10 + t], s0); s1 = fma(cs1[t], Li[c1 * 10 + t], s1); }
+                    double* Lo = sLsub[i & (RING - 1)];
+                    Lo[r0 * 10 + c0] = s0;
                     cv.Lsub[(size_t)i * 81 + e0] = s0;
-                    if (e1 < 81) { sLsub[i & 3][e1] = s1; cv.Lsub[(size_t)i * 81 + e1] = s1; }
+                    if (e1 < 81) { Lo[r1 * 10 + c1] = s1; cv.Lsub[(size_t)i * 81 + e1] = s1; }
+                    if (lane < 9) Lo[lane * 10 + 9] = 0.0;
                 }
                 asm volatile("" ::: "memory");
                 lds_store(&s_step, i + 1);        // a wave's LDS operations execute in order: the data above is visible first
@@ -227,23 +231,40 @@ __global__ __launch_bounds__(MAXT) void k_chain_elim(DevBuf d, ChainView cv, int
                 while (lds_load(&s_step) <= i) { __builtin_amdgcn_s_sleep(1); if (++spins > SPIN_MAX) { s_bad = 1; break; } }
                 asm volatile("" ::: "memory");
                 if (wv == 1) ESTAMP(9);
-                const double* Lp = sLsub[(i + 3) & 3];      // (i - 1) & 3
-                const double* Li = sLinv[i & 3];
+                const double2* Lp2 = reinterpret_cast<const double2*>(sLsub[(i + RING - 1) & (RING - 1)]);      // step i - 1; row stride 5 pairs
+                const double2* Li2 = reinterpret_cast<const double2*>(sLinv[i & (RING - 1)]);
+                if (i > 0) {
+#pragma unroll
+                    for (int r = 0; r < 9; ++r)
+#pragma unroll
+                        for (int q2 = 0; q2 < 5; ++q2) {
+                            const double2 l = Lp2[r * 5 + q2];        // the pad column holds 0
+#pragma unroll
+                            for (int cs = 0; cs < NCS; ++cs) {
+                                t[cs][r] = fma(-l.x, wp[cs][2 * q2], t[cs][r]);
+                                if (2 * q2 + 1 < 9) t[cs][r] = fma(-l.y, wp[cs][2 * q2 + 1], t[cs][r]);
+                            }
+                        }
+                }
+                double wn[NCS][9];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+#pragma unroll
+                    for (int cs = 0; cs < NCS; ++cs) wn[cs][r] = 0.0;
+#pragma unroll
+                    for (int q2 = 0; q2 <= r / 2; ++q2) {
+                        const double2 l = Li2[r * 5 + q2];            // L^-1 is lower triangular: entries beyond the diagonal are 0
+#pragma unroll
+                        for (int cs = 0; cs < NCS; ++cs) {
+                            wn[cs][r] = fma(l.x, t[cs][2 * q2], wn[cs][r]);
+                            if (2 * q2 + 1 <= r) wn[cs][r] = fma(l.y, t[cs][2 * q2 + 1], wn[cs][r]);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int cs = 0; cs < NCS; ++cs) {
-                    if (i > 0) {
 #pragma unroll
-                        for (int r = 0; r < 9; ++r)
-#pragma unroll
-                            for (int q = 0; q < 9; ++q) t[cs][r] = fma(-Lp[r * 9 + q], wp[cs][q], t[cs][r]);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 9; ++r) {
-                        double s = 0.0;
-#pragma unroll
-                        for (int q = 0; q <= r; ++q) s = fma(Li[r * 9 + q], t[cs][q], s);
-                        wp[cs][r] = s;
-                    }
+                    for (int r = 0; r < 9; ++r) wp[cs][r] = wn[cs][r];
                     const int col = col0 + cs * stride;
                     if (col < cv.Wld) {
 #pragma unroll
