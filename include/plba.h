@@ -66,9 +66,9 @@ typedef struct {
     int    factor_block;        /* block width of the dense factorisation: 32 or 64                (32)   */
     int    factor_flow;         /* 1 = the whole factorisation as ONE dataflow launch (factor_block 32 with use_mfma;
                                    experimental: measured slower at P = 735), 0 = one launch per block step (0) */
-    int    chain_elim;          /* 1 = eliminate the velocity / bias variables (block-tridiagonal, no landmark coupling)
-                                   ahead of the dense factorisation whenever no prior edge is attached; experimental:
-                                   correct, but not yet faster than the dense path               (0)    */
+    int    chain_elim;          /* 1 = eliminate the velocity / bias variables (block-tridiagonal, no landmark coupling;
+                                   segments between separator keyframes, one workgroup each) ahead of the dense
+                                   factorisation whenever no prior edge is attached; 0 = dense path on the full system (1) */
     int    reserved[2];
 } plba_options;
 

@@ -320,7 +320,7 @@ void orc_default_options(plba_options* o) {
     o->use_mfma = 1;
     o->factor_block = 32;
     o->factor_flow = 0;
-    o->chain_elim = 0;             /* solver-structure options of the HIP library: ignored here */
+    o->chain_elim = 1;             /* solver-structure options of the HIP library: ignored here */
 }
 const char* orc_backend_name(void) { return "cpu-oracle"; }
 

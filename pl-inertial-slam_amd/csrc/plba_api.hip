@@ -7,6 +7,7 @@
 // mapped host memory, the host polls a sequence number).
 // No CPU fallback exists: every entry point that computes needs a HIP device.
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -54,7 +55,7 @@ void plba_default_options(plba_options* o) {
     o->use_mfma = 1;
     o->factor_block = 32;
     o->factor_flow = 0;
-    o->chain_elim = 0;
+    o->chain_elim = 1;
 }
 const char* plba_backend_name(void) { return "hip-gfx950"; }
 const char* plba_last_error(const plba_problem* p) { return p ? p->err : g_create_err; }
@@ -470,41 +471,95 @@ static int prepare(plba_problem* p) {
     // ---- chain-variable elimination (plba_chain.hip): index maps and the compact dense system ---------------------------------
     p->chain_ok = false;
     if (p->opt.chain_elim && p->pr_nv == 0 && p->opt.use_mfma && d.fb == 32 && p->P > 0) {
-        std::vector<int32_t> cidx, pidx, pblk, pcol0, blk_of_kf(K, -1);
+        // chain-block positions in keyframe order: the velocity (3) + bias (6) dims a keyframe contributes, -1 where fixed
+        std::vector<std::array<int32_t, 9>> pos_c;
+        std::vector<int32_t> pos_pose, pos_of_kf(K, -1);       // first system index of the position's pose block (-1: fixed)
         for (int k = 0; k < K; ++k) {
             const int op = p->off_pvr[k], ob = p->off_bias[k];
-            if (op >= 0) for (int c : {0, 1, 2, 6, 7, 8}) { pidx.push_back(op + c); pblk.push_back((int32_t)(cidx.size() / 9)); }
-            if (op >= 0 || ob >= 0) {
-                blk_of_kf[k] = (int)(cidx.size() / 9);
-                pcol0.push_back(op >= 0 ? (int32_t)pidx.size() - 6 : -1);
-                for (int c = 0; c < 3; ++c) cidx.push_back(op >= 0 ? op + 3 + c : -1);
-                for (int c = 0; c < 6; ++c) cidx.push_back(ob >= 0 ? ob + c : -1);
-            }
+            if (op < 0 && ob < 0) continue;
+            std::array<int32_t, 9> c;
+            for (int q = 0; q < 3; ++q) c[q] = op >= 0 ? op + 3 + q : -1;
+            for (int q = 0; q < 6; ++q) c[3 + q] = ob >= 0 ? ob + q : -1;
+            pos_of_kf[k] = (int)pos_c.size();
+            pos_c.push_back(c); pos_pose.push_back(op);
         }
-        const int nblk = (int)(cidx.size() / 9);
-        bool ok = nblk > 0 && !pidx.empty() && chain_elim_supported((int)pidx.size());
-        // block-tridiagonal only if every IMU edge joins neighbouring chain blocks (or touches a single one)
+        const int npos = (int)pos_c.size();
+        bool ok = npos > 0;
+        // block-tridiagonal only if every IMU edge joins neighbouring positions
         for (int m = 0; m < M && ok; ++m) {
-            const int bi = blk_of_kf[p->imu_i[m]], bj = blk_of_kf[p->imu_j[m]];
+            const int bi = pos_of_kf[p->imu_i[m]], bj = pos_of_kf[p->imu_j[m]];
             if (bi >= 0 && bj >= 0 && std::abs(bi - bj) > 1) ok = false;
         }
         if (ok) {
-            for (int c = 0; c < 9; ++c) cidx.push_back(-1);        // sentinel row read by the last step
-            ChainView& cv = p->cv;
-            cv.nblk = nblk; cv.Pd = (int)pidx.size(); cv.Pdpad = ((cv.Pd + TILE - 1) / TILE) * TILE; cv.Wld = ((cv.Pd + 1 + 63) / 64) * 64;
-            HIPCK(p, p->d_cidx.upload(cidx)); HIPCK(p, p->d_pidx.upload(pidx)); HIPCK(p, p->d_pblk.upload(pblk)); HIPCK(p, p->d_pcol0.upload(pcol0));
-            HIPCK(p, p->d_W.alloc((size_t)(nblk * 9 + 4) * cv.Wld)); HIPCK(p, p->d_Ldinv.alloc((size_t)nblk * 81)); HIPCK(p, p->d_Lsub.alloc((size_t)nblk * 81));
-            const size_t sysn_d = (size_t)(cv.Pdpad + TILE) * cv.Pdpad;
-            HIPCK(p, p->d_sysd.alloc(sysn_d)); HIPCK(p, p->d_Lfacd.alloc(sysn_d)); HIPCK(p, p->d_xd.alloc(cv.Pdpad));
-            HIPCK(p, p->d_Linvd.alloc((size_t)(cv.Pdpad / TILE) * TILE * TILE)); HIPCK(p, p->d_LT32d.alloc((size_t)cv.Pdpad * 64)); HIPCK(p, p->d_rd32d.alloc(cv.Pdpad));
-            HIPCK(p, p->d_flow_flagsd.alloc(cv.Pdpad / TILE)); HIPCK(p, p->d_chol_flagsd.alloc((size_t)(cv.Pdpad / 32 + 2) * (cv.Pdpad / 32)));
-            cv.cidx = p->d_cidx.p; cv.pidx = p->d_pidx.p; cv.pblk = p->d_pblk.p; cv.pcol0 = p->d_pcol0.p; cv.W = p->d_W.p; cv.Ldinv = p->d_Ldinv.p; cv.Lsub = p->d_Lsub.p;
-            DevBuf& dd = p->dd;
-            dd = d;
-            dd.P = cv.Pd; dd.Ppad = cv.Pdpad; dd.ld = cv.Pdpad;
-            dd.sys = p->d_sysd.p; dd.Lfac = p->d_Lfacd.p; dd.x = p->d_xd.p; dd.Linv = p->d_Linvd.p; dd.LTblk = p->d_LT32d.p; dd.Linv32 = p->d_LT32d.p;
-            dd.rdblk = p->d_rd32d.p; dd.flow_flags = p->d_flow_flagsd.p; dd.chol_flags = p->d_chol_flagsd.p;
-            p->chain_ok = true;
+            // segment length: the dense factorisation costs ~9 us per 32-wide block step, a chain step ~2 us
+            int best_seg = 1; double best_cost = 1e300;
+            for (int seg = 1; seg <= CHAIN_SEG; ++seg) {
+                int pd = 0;
+                for (int q = 0; q < npos; ++q) {
+                    if (pos_pose[q] >= 0) pd += 6;
+                    if (q % (seg + 1) == seg) for (int c = 0; c < 9; ++c) pd += pos_c[q][c] >= 0;
+                }
+                const int steps = ((pd + TILE - 1) / TILE) * TILE / 32;
+                const double cost = 9.0 * steps + 2.0 * seg;
+                if (cost < best_cost) { best_cost = cost; best_seg = seg; }
+            }
+            const int SEG = best_seg;
+            std::vector<int32_t> cidx, epos, seg_start, seg_col, pidx, ppos, pslot, slotcol((size_t)npos * CHAIN_NSLOT, -1);
+            for (int q = 0; q < npos; ++q) {
+                const bool sep = (q % (SEG + 1) == SEG);
+                if (pos_pose[q] >= 0) {
+                    int sl = 0;
+                    for (int c : {0, 1, 2, 6, 7, 8}) { slotcol[(size_t)q * CHAIN_NSLOT + sl] = (int32_t)pidx.size(); pidx.push_back(pos_pose[q] + c); ppos.push_back(q); pslot.push_back(sl++); }
+                }
+                if (sep) {
+                    for (int c = 0; c < 9; ++c) if (pos_c[q][c] >= 0) { slotcol[(size_t)q * CHAIN_NSLOT + 6 + c] = (int32_t)pidx.size(); pidx.push_back(pos_c[q][c]); ppos.push_back(q); pslot.push_back(6 + c); }
+                    if (seg_start.empty() || seg_start.back() != (int32_t)epos.size()) seg_start.push_back((int32_t)epos.size());
+                } else {
+                    if (seg_start.empty()) seg_start.push_back(0);
+                    for (int c = 0; c < 9; ++c) cidx.push_back(pos_c[q][c]);
+                    epos.push_back(q);
+                }
+            }
+            const int nel = (int)epos.size();
+            if (seg_start.empty() || seg_start.back() != nel) seg_start.push_back(nel);
+            // drop empty segments (two adjacent separators cannot happen for SEG >= 1, but a leading separator can)
+            std::vector<int32_t> ss;
+            for (size_t q = 0; q < seg_start.size(); ++q) if (q == 0 || seg_start[q] != seg_start[q - 1]) ss.push_back(seg_start[q]);
+            seg_start = ss;
+            const int nseg = (int)seg_start.size() - 1;
+            const int Pd = (int)pidx.size();
+            ok = nel > 0 && nseg > 0 && Pd > 0;
+            for (int g = 0; g < nseg && ok; ++g) {
+                const int pf = epos[seg_start[g]], pl = epos[seg_start[g + 1] - 1];
+                int lo = 0, hi = 0;
+                while (lo < Pd && ppos[lo] < pf - 1) ++lo;
+                hi = lo;
+                while (hi < Pd && ppos[hi] <= pl + 1) ++hi;
+                seg_col.push_back(lo); seg_col.push_back(hi);
+                if (seg_start[g + 1] - seg_start[g] > CHAIN_SEG || hi - lo + 1 > 192) ok = false;
+            }
+            if (ok) {
+                for (int c = 0; c < 9; ++c) cidx.push_back(-1);
+                ChainView& cv = p->cv;
+                cv.nel = nel; cv.nseg = nseg; cv.npos = npos; cv.Pd = Pd; cv.Pdpad = ((Pd + TILE - 1) / TILE) * TILE; cv.Wld = ((Pd + 2 + 63) / 64) * 64;
+                HIPCK(p, p->d_cidx.upload(cidx)); HIPCK(p, p->d_epos.upload(epos)); HIPCK(p, p->d_seg_start.upload(seg_start)); HIPCK(p, p->d_seg_col.upload(seg_col));
+                HIPCK(p, p->d_pidx.upload(pidx)); HIPCK(p, p->d_ppos.upload(ppos)); HIPCK(p, p->d_pslot.upload(pslot)); HIPCK(p, p->d_slotcol.upload(slotcol));
+                p->d_W.release();      // must come back zero: the kernels only ever write inside each segment's window
+                HIPCK(p, p->d_W.alloc((size_t)(nel * 9 + 4) * cv.Wld)); HIPCK(p, p->d_Ldinv.alloc((size_t)nel * 81)); HIPCK(p, p->d_Lsub.alloc((size_t)nel * 81));
+                const size_t sysn_d = (size_t)(cv.Pdpad + TILE) * cv.Pdpad;
+                HIPCK(p, p->d_sysd.alloc(sysn_d)); HIPCK(p, p->d_Lfacd.alloc(sysn_d)); HIPCK(p, p->d_xd.alloc(cv.Pdpad));
+                HIPCK(p, p->d_Linvd.alloc((size_t)(cv.Pdpad / TILE) * TILE * TILE)); HIPCK(p, p->d_LT32d.alloc((size_t)cv.Pdpad * 64)); HIPCK(p, p->d_rd32d.alloc(cv.Pdpad));
+                HIPCK(p, p->d_flow_flagsd.alloc(cv.Pdpad / TILE)); HIPCK(p, p->d_chol_flagsd.alloc((size_t)(cv.Pdpad / 32 + 2) * (cv.Pdpad / 32)));
+                cv.cidx = p->d_cidx.p; cv.epos = p->d_epos.p; cv.seg_start = p->d_seg_start.p; cv.seg_col = p->d_seg_col.p;
+                cv.pidx = p->d_pidx.p; cv.ppos = p->d_ppos.p; cv.pslot = p->d_pslot.p; cv.slotcol = p->d_slotcol.p;
+                cv.W = p->d_W.p; cv.Ldinv = p->d_Ldinv.p; cv.Lsub = p->d_Lsub.p;
+                DevBuf& dd = p->dd;
+                dd = d;
+                dd.P = cv.Pd; dd.Ppad = cv.Pdpad; dd.ld = cv.Pdpad;
+                dd.sys = p->d_sysd.p; dd.Lfac = p->d_Lfacd.p; dd.x = p->d_xd.p; dd.Linv = p->d_Linvd.p; dd.LTblk = p->d_LT32d.p; dd.Linv32 = p->d_LT32d.p;
+                dd.rdblk = p->d_rd32d.p; dd.flow_flags = p->d_flow_flagsd.p; dd.chol_flags = p->d_chol_flagsd.p;
+                p->chain_ok = true;
+            }
         }
     }
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------

@@ -128,17 +128,22 @@ int  edge_blocks(const DevBuf& d);
 
 // dense
 // chain-variable elimination ahead of the dense factorisation (plba_chain.hip)
+constexpr int CHAIN_SEG = 8;      // at most this many chain blocks between two separators (one workgroup eliminates a segment)
+constexpr int CHAIN_NSLOT = 15;   // dense columns a keyframe position can own: 6 pose + 9 separator chain dimensions
 struct ChainView {
-    int nblk, Pd, Pdpad, Wld;     // chain blocks (9 padded dims each); dense pose dims, padded to 64; leading dimension of W
-    const int32_t* cidx;          // (nblk + 1) x 9 system indices of the chain dims, -1 = padding (last row all -1)
-    const int32_t* pidx;          // Pd system indices of the pose dims
-    const int32_t* pblk;          // Pd: chain block of the keyframe each pose dim belongs to
-    const int32_t* pcol0;         // nblk: first pose column of the keyframe owning each chain block (-1: its pose is fixed)
-    double* W;                    // (nblk * 9 + 4) x Wld:  L_c^-1 [B | b_c], column Pd = w_b
-    double* Ldinv;                // nblk x 81: L_ii^-1, row-major
-    double* Lsub;                 // nblk x 81: L_{i+1,i}
+    int nel, nseg, npos, Pd, Pdpad, Wld;   // eliminated chain blocks, segments, chain-block positions; dense dims (+ padded); ld of W
+    const int32_t* cidx;          // (nel + 1) x 9 system indices of the eliminated blocks' dims, -1 = padding
+    const int32_t* epos;          // nel: position (keyframe order) of each eliminated block
+    const int32_t* seg_start;     // nseg + 1: eliminated blocks of each segment
+    const int32_t* seg_col;       // 2 x nseg: dense column window [lo, hi) that can couple to the segment
+    const int32_t* pidx;          // Pd system indices of the dense dims (ordered by position: pose dims, then separator chain dims)
+    const int32_t* ppos;          // Pd: position of the keyframe each dense dim belongs to
+    const int32_t* pslot;         // Pd: its slot (0-5 pose, 6-14 separator chain dims)
+    const int32_t* slotcol;       // npos x 15: dense column of each slot, -1 = none
+    double* W;                    // (nel * 9 + 4) x Wld:  L^-1 [B | b_c], column Pd = w_b; zero outside each segment's window
+    double* Ldinv;                // nel x 81: L_ii^-1, row-major
+    double* Lsub;                 // nel x 81: L_{i+1,i}
 };
-bool chain_elim_supported(int Pd);     // the elimination kernel carries at most 1920 coupled columns in one workgroup
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s);
 void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);   // writes dd.sys
 void launch_chain_back(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);    // dd.x -> d.x

@@ -152,13 +152,14 @@ def test_config3_imu_reduced(pkg, orc, hip):
 
 
 @pytest.mark.parametrize("K,Np,Nl,imu", [(12, 500, 100, True), (100, 1500, 300, True), (9, 200, 40, False), (2, 30, 6, True)])
-def test_chain_variable_elimination_option(pkg, orc, hip, K, Np, Nl, imu):
-    """chain_elim = 1 (plba_chain.hip): velocity / bias variables eliminated ahead of the dense factorisation; same
-    optimisation as the oracle's plain dense solve (one workgroup carries up to 1920 coupled columns: K = 100 uses 10 waves)"""
+@pytest.mark.parametrize("chain", [0, 1])
+def test_chain_variable_elimination_option(pkg, orc, hip, K, Np, Nl, imu, chain):
+    """chain_elim = 1 (default, plba_chain.hip): velocity / bias variables eliminated segment-wise ahead of the dense
+    factorisation; chain_elim = 0: the dense path on the full system.  Both give the oracle's optimisation."""
     w = pkg.window.make_window(K, Np, Nl, imu=imu, seed=0xC4A1 + K)
-    g, o = _pair(pkg, orc, w, chain_elim=1)
+    g, o = _pair(pkg, orc, w, chain_elim=chain)
     sg, so = g.optimize(4), o.optimize(4)
-    assert g.debug_get("dense_dim")[0] < g.debug_get("pose_dim")[0]          # the option is really in effect
+    assert (g.debug_get("dense_dim")[0] < g.debug_get("pose_dim")[0]) == bool(chain)          # the option is really in effect
     assert (sg.iterations, sg.trials, sg.solver_failures) == (so.iterations, so.trials, 0)
     assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-7)
     assert max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)) < (1e-7 if imu else 1e-4)
