@@ -242,7 +242,7 @@ def main():
                     traffic=pmc_traffic("k_linearize<true>"), algorithmic_bytes_per_launch=bytes_lin, avg_launch_ms=lin_ms)
     kname = "k_chol32" if fb == 32 else "k_chol_step"
     ach = flops_fact / n_fact_launches / (fact_ms * 1e-3) / 1e12 if fact_ms > 0 else None
-    roof_mfma = dict(bound="mfma", kernel="%s: one block step of the dense fp64 LL^T of the reduced camera system (P=%d, %d launches per solve)" % (kname, P, n_fact_launches),
+    roof_mfma = dict(bound="mfma", kernel="%s: one block step of the dense fp64 LL^T of the reduced camera system (%d of the P=%d pose dims stay dense after the velocity/bias chain elimination, %d launches per solve)" % (kname, Pdense, P, n_fact_launches),
                      achieved=ach, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=(ach / FP64_MFMA_PEAK_TFLOPS) if ach else None,
                      traffic=pmc_traffic(kname), algorithmic_flops_per_launch=flops_fact / n_fact_launches, avg_launch_ms=fact_ms)
     # the factorisation launches are the largest single consumer of an iteration (profiles/r01_*_kernel_stats.csv)

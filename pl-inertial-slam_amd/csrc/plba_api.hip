@@ -470,7 +470,7 @@ static int prepare(plba_problem* p) {
     d.ctrl = p->d_ctrl.p; d.trace = p->d_trace.p; d.trace_cap = TRACE_CAP; d.trace_n = p->d_trace_n.p;
     // ---- chain-variable elimination (plba_chain.hip): index maps and the compact dense system ---------------------------------
     p->chain_ok = false;
-    if (p->opt.chain_elim && p->pr_nv == 0 && p->opt.use_mfma && d.fb == 32 && p->P > 0) {
+    if (p->opt.chain_elim && p->opt.use_mfma && d.fb == 32 && p->P > 0) {
         // chain-block positions in keyframe order: the velocity (3) + bias (6) dims a keyframe contributes, -1 where fixed
         std::vector<std::array<int32_t, 9>> pos_c;
         std::vector<int32_t> pos_pose, pos_of_kf(K, -1);       // first system index of the position's pose block (-1: fixed)
@@ -490,23 +490,38 @@ static int prepare(plba_problem* p) {
             const int bi = pos_of_kf[p->imu_i[m]], bj = pos_of_kf[p->imu_j[m]];
             if (bi >= 0 && bj >= 0 && std::abs(bi - bj) > 1) ok = false;
         }
+        // a marginalization prior couples the chain dims of its kept vertices with each other: those positions stay dense
+        std::vector<char> forced(std::max(npos, 1), 0);
+        for (int a = 0; a < p->pr_nv; ++a)
+            if (pr_kf[a] >= 0 && pr_kf[a] < K && pos_of_kf[pr_kf[a]] >= 0) forced[pos_of_kf[pr_kf[a]]] = 1;
+        // separators: the forced positions, and every position that would make a run of eliminated blocks longer than seg
+        auto separators = [&](int seg) {
+            std::vector<char> sep(npos, 0);
+            int run = 0;
+            for (int q = 0; q < npos; ++q) {
+                if (forced[q] || run == seg) { sep[q] = 1; run = 0; } else ++run;
+            }
+            return sep;
+        };
         if (ok) {
             // segment length: the dense factorisation costs ~9 us per 32-wide block step, a chain step ~2 us
             int best_seg = 1; double best_cost = 1e300;
             for (int seg = 1; seg <= CHAIN_SEG; ++seg) {
+                const std::vector<char> sp = separators(seg);
                 int pd = 0;
                 for (int q = 0; q < npos; ++q) {
                     if (pos_pose[q] >= 0) pd += 6;
-                    if (q % (seg + 1) == seg) for (int c = 0; c < 9; ++c) pd += pos_c[q][c] >= 0;
+                    if (sp[q]) for (int c = 0; c < 9; ++c) pd += pos_c[q][c] >= 0;
                 }
                 const int steps = ((pd + TILE - 1) / TILE) * TILE / 32;
                 const double cost = 9.0 * steps + 2.0 * seg;
                 if (cost < best_cost) { best_cost = cost; best_seg = seg; }
             }
             const int SEG = best_seg;
+            const std::vector<char> is_sep = separators(SEG);
             std::vector<int32_t> cidx, epos, seg_start, seg_col, pidx, ppos, pslot, slotcol((size_t)npos * CHAIN_NSLOT, -1);
             for (int q = 0; q < npos; ++q) {
-                const bool sep = (q % (SEG + 1) == SEG);
+                const bool sep = is_sep[q] != 0;
                 if (pos_pose[q] >= 0) {
                     int sl = 0;
                     for (int c : {0, 1, 2, 6, 7, 8}) { slotcol[(size_t)q * CHAIN_NSLOT + sl] = (int32_t)pidx.size(); pidx.push_back(pos_pose[q] + c); ppos.push_back(q); pslot.push_back(sl++); }
@@ -522,7 +537,7 @@ static int prepare(plba_problem* p) {
             }
             const int nel = (int)epos.size();
             if (seg_start.empty() || seg_start.back() != nel) seg_start.push_back(nel);
-            // drop empty segments (two adjacent separators cannot happen for SEG >= 1, but a leading separator can)
+            // drop empty segments (adjacent or leading separators)
             std::vector<int32_t> ss;
             for (size_t q = 0; q < seg_start.size(); ++q) if (q == 0 || seg_start[q] != seg_start[q - 1]) ss.push_back(seg_start[q]);
             seg_start = ss;

@@ -235,8 +235,10 @@ def test_rejected_trials_follow_the_oracle(pkg, orc, hip):
     g.close(); o.close()
 
 
-def test_prior_edge_parity(pkg, orc, hip):
-    """BA with a marginalization prior: the oracle's prior on both sides (SURVEY B-Q3 decision)."""
+@pytest.mark.parametrize("chain", [1, 0])
+def test_prior_edge_parity(pkg, orc, hip, chain):
+    """BA with a marginalization prior: the oracle's prior on both sides (SURVEY B-Q3 decision).  With chain_elim = 1 the
+    keyframes the prior touches keep their velocity / bias dims in the dense system (forced separators)."""
     w0 = pkg.window.make_window(12, 260, 50, imu=True, seed=22)
     o = orc.new_problem(); o.upload_window(w0)
     pkg.protocol.local_ba(o)
@@ -244,11 +246,13 @@ def test_prior_edge_parity(pkg, orc, hip):
     o.close()
     w0["prior"] = pr        # kept vertices all exist in w0 as well; KF0 itself is not among them
     w0["kf"]["fixed_pvr"] = np.zeros(12, np.uint8); w0["kf"]["fixed_pvr"][0] = 1
-    g, o = _pair(pkg, orc, w0)
+    g, o = _pair(pkg, orc, w0, chain_elim=chain)
     g.debug_build(5.0, False); o.debug_build(5.0, False)
     for name in ("err_prior", "bp", "bschur", "Hschur", "chi2", "maxdiag"):
         _close(g.debug_get(name), o.debug_get(name), 1e-9, name)
     sg, so = g.optimize(4), o.optimize(4)
+    assert (g.debug_get("dense_dim")[0] < g.debug_get("pose_dim")[0]) == bool(chain)
+    assert (sg.iterations, sg.trials, sg.solver_failures) == (so.iterations, so.trials, 0)
     assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-8)
     assert max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)) < 1e-8
     g.close(); o.close()
