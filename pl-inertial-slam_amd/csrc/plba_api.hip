@@ -408,18 +408,20 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_tv.alloc((size_t)L * 6)); HIPCK(p, p->d_xl.alloc((size_t)L * 6));
     HIPCK(p, p->d_off_pvr.upload(p->off_pvr)); HIPCK(p, p->d_off_bias.upload(p->off_bias));
     // chunks of at most 256 entries per pair (contiguous, in pair order)
-    std::vector<int32_t> ch_pair, ch_start, ch_end, pair_ch0, pair_nch;
+    std::vector<ChunkMeta> ch_meta;
     for (size_t q = 0; q < pair_i.size(); ++q) {
-        pair_ch0.push_back((int32_t)ch_pair.size());
-        int32_t nchq = 0;
+        const int32_t ch0 = (int32_t)ch_meta.size();
+        const int32_t nchq = (pair_start[q + 1] - pair_start[q] + SCHUR_CHUNK - 1) / SCHUR_CHUNK;
         for (int32_t s0 = pair_start[q]; s0 < pair_start[q + 1]; s0 += SCHUR_CHUNK) {
-            ch_pair.push_back((int32_t)q); ch_start.push_back(s0); ch_end.push_back(std::min(s0 + SCHUR_CHUNK, pair_start[q + 1])); ++nchq;
+            ChunkMeta m;
+            m.pair = (int32_t)q; m.start = s0; m.end = std::min(s0 + SCHUR_CHUNK, pair_start[q + 1]);
+            m.ij = pair_i[q] | (pair_j[q] << 16); m.nch = nchq; m.ch0 = ch0;
+            m.oi = p->off_pvr[pair_i[q]]; m.oj = p->off_pvr[pair_j[q]];
+            ch_meta.push_back(m);
         }
-        pair_nch.push_back(nchq);
     }
-    HIPCK(p, p->d_ch_pair.upload(ch_pair)); HIPCK(p, p->d_ch_start.upload(ch_start)); HIPCK(p, p->d_ch_end.upload(ch_end));
-    HIPCK(p, p->d_pair_ch0.upload(pair_ch0)); HIPCK(p, p->d_pair_nch.upload(pair_nch));
-    HIPCK(p, p->d_schur_part.alloc(ch_pair.size() * 48)); HIPCK(p, p->d_pair_cnt.alloc(pair_i.size()));
+    HIPCK(p, p->d_ch_meta.upload(ch_meta));
+    HIPCK(p, p->d_schur_part.alloc(ch_meta.size() * 48)); HIPCK(p, p->d_pair_cnt.alloc(pair_i.size()));
     HIPCK(p, p->d_pair_i.upload(pair_i)); HIPCK(p, p->d_pair_j.upload(pair_j)); HIPCK(p, p->d_pair_start.upload(pair_start));
     HIPCK(p, p->d_ent_pi.upload(ent_ei)); HIPCK(p, p->d_ent_pj.upload(ent_ej)); HIPCK(p, p->d_ent_slot.upload(ent_slot)); HIPCK(p, p->d_ob_pos.upload(p->ob_pos));
     HIPCK(p, p->d_imu_i.upload(p->imu_i)); HIPCK(p, p->d_imu_j.upload(p->imu_j)); HIPCK(p, p->d_imu_pre.upload(p->imu_pre));
@@ -442,7 +444,7 @@ static int prepare(plba_problem* p) {
     DevBuf& d = p->dv;
     memset(&d, 0, sizeof d);
     d.K = K; d.Np = Np; d.Nl = Nl; d.L = L; d.Ep = Ep; d.El = El; d.E = E; d.M = M;
-    d.P = p->P; d.Ppad = p->Ppad; d.ld = p->ld; d.npairs = (int)pair_i.size(); d.nent = (int)nent; d.nchunks = (int)ch_pair.size();
+    d.P = p->P; d.Ppad = p->Ppad; d.ld = p->ld; d.npairs = (int)pair_i.size(); d.nent = (int)nent; d.nchunks = (int)ch_meta.size();
     d.cam.fx = p->fx; d.cam.fy = p->fy; d.cam.cx = p->cx; d.cam.cy = p->cy;
     M3 Rbc; for (int i = 0; i < 9; ++i) Rbc.a[i] = p->Rbc[i];
     d.cam.Rcb = transpose(Rbc);
@@ -456,7 +458,7 @@ static int prepare(plba_problem* p) {
     d.hll = p->d_hll.p; d.bl = p->d_bl.p; d.dinv = p->d_dinv.p; d.tv = p->d_tv.p; d.xl = p->d_xl.p; d.lm_active = p->d_lm_active.p;
     d.kf_off_pvr = p->d_off_pvr.p; d.kf_off_bias = p->d_off_bias.p;
     d.pair_i = p->d_pair_i.p; d.pair_j = p->d_pair_j.p; d.pair_start = p->d_pair_start.p; d.ent_pi = p->d_ent_pi.p; d.ent_pj = p->d_ent_pj.p; d.ent_slot = p->d_ent_slot.p; d.ob_pos = p->d_ob_pos.p;
-    d.ch_pair = p->d_ch_pair.p; d.ch_start = p->d_ch_start.p; d.ch_end = p->d_ch_end.p; d.pair_ch0 = p->d_pair_ch0.p; d.pair_nch = p->d_pair_nch.p;
+    d.ch_meta = p->d_ch_meta.p;
     d.schur_part = p->d_schur_part.p; d.pair_cnt = p->d_pair_cnt.p;
     d.imu_i = p->d_imu_i.p; d.imu_j = p->d_imu_j.p; d.imu_pre = p->d_imu_pre.p; d.imu_info_pvr = p->d_imu_ipvr.p; d.imu_info_bias = p->d_imu_ibias.p;
     d.imu_err = p->d_imu_err.p; d.imu_chi = p->d_imu_chi.p;
@@ -660,7 +662,8 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
     if (need_dinv) launch_landmark_dinv(d, s);   // otherwise k_landmark_hll<true> already formed (Hll + lambda I)^-1
     if (need_dinv || !p->assembled) launch_assemble(d, owns_pose_edges(p), s);   // ... and assembled the pose-side system
     p->assembled = false;
-    launch_schur_pairs(d, p->cur, s);
+    const bool chain_rides = do_solve && p->chain_ok && p->world == 1;      // chain blocks need nothing from the other ranks' landmarks... but the all-reduce carries rank 0's IMU terms
+    launch_schur_pairs(d, p->cur, chain_rides ? &p->cv : nullptr, s);
     MARK(p, 5);
     if (p->world > 1) {   // single GPU: k_assemble / k_schur_pairs wrote bp into bpg directly
         // only the lower block-triangle (what the factorisation reads) and the two rhs rows travel
@@ -678,7 +681,7 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
     if (p->chain_ok) {
         // velocity / bias variables first (block-tridiagonal, one workgroup), then the dense factorisation on the
         // 6-per-keyframe pose system, then the chain back-substitution (plba_chain.hip)
-        launch_chain_elim(d, p->cv, s);
+        if (!chain_rides) launch_chain_elim(d, p->cv, s);
         launch_chain_schur(d, p->cv, p->dd, s);
         MARKF(p, 11);
         launch_cholesky(p->dd, true, epoch, s);

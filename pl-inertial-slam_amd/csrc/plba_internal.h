@@ -39,6 +39,10 @@ struct Mailbox {
     unsigned long long seq;
 };
 
+// one chunk (<= 256 entries) of a keyframe pair's entry list: everything k_schur_pairs needs to know up front, 32 bytes
+struct ChunkMeta { int32_t pair, start, end, ij /* i | j << 16 */, nch, ch0 /* the pair's chunks */, oi, oj /* kf_off_pvr of i, j */; };
+
+struct ChainView;
 struct DevBuf {  // trivially-copyable view of device pointers passed to kernels by value
     // sizes
     int K, Np, Nl, L, Ep, El, E, M, P, Ppad, ld, npairs, nent, nchunks;
@@ -68,7 +72,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     const int32_t *kf_off_pvr, *kf_off_bias;
     // pairs
     const int32_t *pair_i, *pair_j, *pair_start, *ent_pi, *ent_pj, *ent_slot;   // entries: record positions + landmark slot
-    const int32_t *ch_pair, *ch_start, *ch_end, *pair_ch0, *pair_nch;           // <= 256-entry chunks of the pair lists (k_schur_pairs)
+    const ChunkMeta* ch_meta;                                                   // <= 256-entry chunks of the pair lists (k_schur_pairs)
     double* schur_part;    // nchunks x 48 partial sums
     int* pair_cnt;         // arrival counters, zero between launches
     // IMU
@@ -113,7 +117,7 @@ bool launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv_assemble, bo
 void launch_kfdiag(const DevBuf& d, int state, hipStream_t s);
 void launch_landmark_dinv(const DevBuf& d, hipStream_t s);
 void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s);
-void launch_schur_pairs(const DevBuf& d, int state, hipStream_t s);
+void launch_schur_pairs(const DevBuf& d, int state, const ChainView* lead /* chain segments riding in front, or null */, hipStream_t s);
 void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s);
 void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s);
 // red[0] = activeRobustChi2 (local), red[1] = landmark part of computeScale (local), red[2] = max |Hll_jj| (local)

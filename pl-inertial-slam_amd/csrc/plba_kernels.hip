@@ -16,6 +16,7 @@
 //
 // g2o semantics reproduced: SURVEY.md Appendix A; reference formulas: see plba_math.h.
 #include "plba_internal.h"
+#include "plba_chain_dev.h"
 
 namespace plba {
 
@@ -319,32 +320,84 @@ __global__ __launch_bounds__(256) void k_kfdiag(DevBuf d, int state) {
 // workgroup per pair left the launch waiting for ten dependent gather rounds of a handful of workgroups).  A pair's
 // chunks publish their 48 partial sums; the chunk that arrives last adds them up in chunk order (deterministic) and
 // applies the result to the reduced system.
-__global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state) {
+// Dependent memory round trips are what this kernel costs, so it is laid out as three of them: (1) one 32-byte chunk
+// descriptor (scalar), (2) the entry's indices | the two keyframe states, (3) both 128-byte records, D_l, t_l and the
+// old values of the output block — all issued before the staged camera blocks are needed; the arithmetic follows.
+// The first `nlead` workgroups eliminate one segment of the velocity / bias chain each instead (plba_chain_dev.h): that work
+// only needs the assembled pose-side system, so on one GPU it runs in the shadow of the pair pass.
+__global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state, ChainView cv, int nlead) {
+    static_assert(ELIM_THREADS == 256, "the chain segments ride in this launch");
+    if ((int)blockIdx.x < nlead) { chain_elim_segment(d, cv, blockIdx.x); return; }
     __shared__ double s_red[4][48];
     __shared__ double s_in[48], s_tmp[36];
     __shared__ double s_kc[2 * KFCAM_STRIDE];
     __shared__ int s_last;
-    const int ch = blockIdx.x;
-    const int p = d.ch_pair[ch];
-    const int i = d.pair_i[p], j = d.pair_j[p];
+    const int ch = blockIdx.x - nlead;
+    const ChunkMeta m = d.ch_meta[ch];
+    const int p = m.pair, i = m.ij & 0xffff, j = (m.ij >> 16) & 0xffff;
     const bool diag = (i == j);
-    if (threadIdx.x < 2) kfcam_make(d.cam, d.kf[state] + (size_t)(threadIdx.x == 0 ? i : j) * KF_STRIDE, s_kc + threadIdx.x * KFCAM_STRIDE);
+    const int t = threadIdx.x;
+    const int n = m.start + t;
+    const bool have = n < m.end;              // chunks hold at most 256 entries: one per lane
+    const int ld = d.ld;
+    // ---- round 2: entry indices (all lanes) | keyframe states (lanes 0, 1) -------------------------------------------------
+    int pi = 0, pj = 0, slot = 0;
+    if (have) { pi = d.ent_pi[n]; pj = d.ent_pj[n]; slot = d.ent_slot[n]; }
+    double kfs[7];
+    if (t < 2) {
+        const double* s = d.kf[state] + (size_t)(t == 0 ? i : j) * KF_STRIDE;
+        kfs[0] = s[0]; kfs[1] = s[1]; kfs[2] = s[2]; kfs[3] = s[6]; kfs[4] = s[7]; kfs[5] = s[8]; kfs[6] = s[9];
+    }
+    // old values of the output block (only the last chunk of a pair uses them; nobody else writes the block in this launch)
+    double old0 = 0.0, old1 = 0.0;
+    size_t a0 = 0, a1 = 0;
+    if (t < 36) {
+        const int r = t / 6, c = t % 6;
+        a0 = (size_t)(m.oi + pmap(r)) * ld + m.oj + pmap(c);
+        a1 = (size_t)(m.oj + pmap(c)) * ld + m.oi + pmap(r);
+        old0 = d.sys[a0]; old1 = d.sys[a1];
+    } else if (diag && t < 48) {
+        const int q = t - 36;
+        a0 = (size_t)((t < 42) ? d.Ppad : d.Ppad + 1) * ld + m.oi + pmap(q % 6);
+        a1 = m.oi + pmap(q % 6);
+        old0 = d.sys[a0];
+        if (t >= 42) old1 = d.bpg[a1];
+    }
+    // ---- round 3: records, D_l, t_l ----------------------------------------------------------------------------------------
+    const bool is_pt = slot < d.Np;
+    double4 qi[4], qj[4];
+    double D[12], tl[6];
+    {
+        const double4* ri4 = reinterpret_cast<const double4*>(d.erec + (size_t)pi * EREC);
+        const double4* rj4 = reinterpret_cast<const double4*>(d.erec + (size_t)pj * EREC);
+        const double4* D4 = reinterpret_cast<const double4*>(d.dinv + (size_t)slot * 12);
+        const double2* t2 = reinterpret_cast<const double2*>(d.tv + (size_t)slot * 6);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { qi[q] = ri4[q]; qj[q] = rj4[q]; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const double4 v = D4[q]; D[4 * q] = v.x; D[4 * q + 1] = v.y; D[4 * q + 2] = v.z; D[4 * q + 3] = v.w; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const double2 v = diag ? t2[q] : make_double2(0.0, 0.0); tl[2 * q] = v.x; tl[2 * q + 1] = v.y; }
+    }
+    if (t < 2) {
+        double s[KF_STRIDE];
+#pragma unroll
+        for (int q = 0; q < KF_STRIDE; ++q) s[q] = 0.0;
+        s[0] = kfs[0]; s[1] = kfs[1]; s[2] = kfs[2]; s[6] = kfs[3]; s[7] = kfs[4]; s[8] = kfs[5]; s[9] = kfs[6];
+        kfcam_make(d.cam, s, s_kc + t * KFCAM_STRIDE);
+    }
     __syncthreads();
-    double acc[36];
-    double gb[6], gp[6];
-#pragma unroll
-    for (int t = 0; t < 36; ++t) acc[t] = 0.0;
-#pragma unroll
-    for (int t = 0; t < 6; ++t) { gb[t] = 0.0; gp[t] = 0.0; }
-    for (int n = d.ch_start[ch] + threadIdx.x; n < d.ch_end[ch]; n += 256) {
-        const int pi = d.ent_pi[n], pj = d.ent_pj[n], slot = d.ent_slot[n];
-        const double wi = d.erec[(size_t)pi * EREC + 12];
-        const double wj = d.erec[(size_t)pj * EREC + 12];
-        if (wi != 0.0 && wj != 0.0) {
-        const bool is_pt = slot < d.Np;
-        const EdgeRows ri = load_rows(d, d.erec + (size_t)pi * EREC, s_kc, is_pt);
-        const EdgeRows rj = load_rows(d, d.erec + (size_t)pj * EREC, s_kc + KFCAM_STRIDE, is_pt);
-        const double* D = d.dinv + (size_t)slot * 12;
+    // per-lane factors of the entry's contribution  g_i Q g_j^T = ga_i T0^T + gb_i T1^T  (zero for an idle lane), then each
+    // of the 36 (+12) sums goes through the wave reduction as soon as it is formed: 6 live accumulators instead of 48
+    const double wi = qi[3].x, wj = qj[3].x;
+    const bool on = have && wi != 0.0 && wj != 0.0;
+    double ga[6], gbv[6], T0[6], T1[6], f0 = 0.0, f1 = 0.0, e0 = 0.0, e1 = 0.0;
+    {
+        EdgeRows ri, rj;
+        rec_row(is_pt, d.fix_q1 != 0, s_kc, d.cam.Rcb, v3(qi[0].x, qi[0].y, qi[0].z), v3(qi[0].w, qi[1].x, qi[1].y), ri.va, ri.ga);
+        rec_row(is_pt, d.fix_q1 != 0, s_kc, d.cam.Rcb, v3(qi[1].z, qi[1].w, qi[2].x), v3(qi[2].y, qi[2].z, qi[2].w), ri.vb, ri.gb);
+        rec_row(is_pt, d.fix_q1 != 0, s_kc + KFCAM_STRIDE, d.cam.Rcb, v3(qj[0].x, qj[0].y, qj[0].z), v3(qj[0].w, qj[1].x, qj[1].y), rj.va, rj.ga);
+        rec_row(is_pt, d.fix_q1 != 0, s_kc + KFCAM_STRIDE, d.cam.Rcb, v3(qj[1].z, qj[1].w, qj[2].x), v3(qj[2].y, qj[2].z, qj[2].w), rj.vb, rj.gb);
         double q00, q01, q10, q11;
         const double ww = wi * wj;
         if (is_pt) {
@@ -356,49 +409,42 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state) {
             q01 = 0.0; q10 = 0.0;
         }
         if (pi == pj) { q00 += wi; q11 += wi; }
-        double T0[6], T1[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            T0[c] = q00 * rj.ga[c] + q01 * rj.gb[c];
-            T1[c] = q10 * rj.ga[c] + q11 * rj.gb[c];
+            T0[c] = on ? q00 * rj.ga[c] + q01 * rj.gb[c] : 0.0;
+            T1[c] = on ? q10 * rj.ga[c] + q11 * rj.gb[c] : 0.0;
+            ga[c] = on ? ri.ga[c] : 0.0;
+            gbv[c] = on ? ri.gb[c] : 0.0;
         }
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) acc[r * 6 + c] += ri.ga[r] * T0[c] + ri.gb[r] * T1[c];
-        if (diag) {
-            const double* t = d.tv + (size_t)slot * 6;
+        if (diag && on) {
             const double sl = is_pt ? -1.0 : 1.0;
-            const V3 ta = v3(t[0], t[1], t[2]);
-            const V3 tb = is_pt ? ta : v3(t[3], t[4], t[5]);
-            const double f0 = ri.e0 + sl * dot(ri.va, ta), f1 = ri.e1 + sl * dot(ri.vb, tb);
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                gp[r] -= wi * (ri.ga[r] * ri.e0 + ri.gb[r] * ri.e1);
-                gb[r] -= wi * (ri.ga[r] * f0 + ri.gb[r] * f1);
-            }
-        }
+            const V3 ta = v3(tl[0], tl[1], tl[2]);
+            const V3 tb = is_pt ? ta : v3(tl[3], tl[4], tl[5]);
+            e0 = wi * qi[3].y; e1 = wi * qi[3].z;
+            f0 = wi * (qi[3].y + sl * dot(ri.va, ta)); f1 = wi * (qi[3].z + sl * dot(ri.vb, tb));
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int t = 0; t < 36; ++t) {
-        const double v = wave_sum_dpp(acc[t]);
-        if (lane == 63) s_red[wv][t] = v;
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double v = wave_sum_dpp(ga[r] * T0[c] + gbv[r] * T1[c]);
+            if (lane == 63) s_red[wv][r * 6 + c] = v;
+        }
     }
     if (diag) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            const double v = wave_sum_dpp(gb[t]);
-            const double u = wave_sum_dpp(gp[t]);
-            if (lane == 63) { s_red[wv][36 + t] = v; s_red[wv][42 + t] = u; }
+        for (int q = 0; q < 6; ++q) {
+            const double v = wave_sum_dpp(-(ga[q] * f0 + gbv[q] * f1));
+            const double u = wave_sum_dpp(-(ga[q] * e0 + gbv[q] * e1));
+            if (lane == 63) { s_red[wv][36 + q] = v; s_red[wv][42 + q] = u; }
         }
     }
     __syncthreads();
-    const int t = threadIdx.x;
     const int nred = diag ? 48 : 36;
     if (t < nred) s_in[t] = (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]);
-    const int nch = d.pair_nch[p];
+    const int nch = m.nch;
     if (nch > 1) {
         // publish this chunk's partial sums (sc1, drained), count arrivals; the last chunk folds them in chunk order
         double* part = d.schur_part + (size_t)ch * 48;
@@ -410,7 +456,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state) {
         if (!s_last) return;
         if (t == 0) __hip_atomic_store(&d.pair_cnt[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
         if (t < nred) {
-            const double* base = d.schur_part + (size_t)d.pair_ch0[p] * 48 + t;
+            const double* base = d.schur_part + (size_t)m.ch0 * 48 + t;
             double sum = 0.0;
             for (int c = 0; c < nch; ++c) sum += __hip_atomic_load(const_cast<double*>(base + (size_t)c * 48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_in[t] = sum;
@@ -424,21 +470,21 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state) {
         s_tmp[t] = s_in[r * 6 + cb] * Rcb[cc] + s_in[r * 6 + cb + 1] * Rcb[3 + cc] + s_in[r * 6 + cb + 2] * Rcb[6 + cc];
     }
     __syncthreads();
-    const int oi = d.kf_off_pvr[i], oj = d.kf_off_pvr[j];
-    const int ld = d.ld;
     if (t < 36) {
         const int r = t / 6, c = t % 6, rb = (r / 3) * 3, rr = r % 3;
         const double v = Rcb[rr] * s_tmp[rb * 6 + c] + Rcb[3 + rr] * s_tmp[(rb + 1) * 6 + c] + Rcb[6 + rr] * s_tmp[(rb + 2) * 6 + c];
-        const int R = pmap(r), Cc = pmap(c);
-        d.sys[(size_t)(oi + R) * ld + oj + Cc] += v;
-        if (!diag) d.sys[(size_t)(oj + Cc) * ld + oi + R] += v;
+        if (diag) {      // (r,c) and (c,r) are two lanes' entries of the same block: each writes its own
+            d.sys[a0] = old0 + v;
+        } else {
+            d.sys[a0] = old0 + v;
+            d.sys[a1] = old1 + v;
+        }
     } else if (diag && t < 48) {
         const int q = t - 36, r = q % 6, rb = (r / 3) * 3, rr = r % 3;
         const double* g = s_in + 36 + (q / 6) * 6;
         const double v = Rcb[rr] * g[rb] + Rcb[3 + rr] * g[rb + 1] + Rcb[6 + rr] * g[rb + 2];
-        const int row = (t < 42) ? d.Ppad : d.Ppad + 1;     // bschur row / bp row of the augmented system
-        d.sys[(size_t)row * ld + oi + pmap(r)] += v;
-        if (t >= 42) d.bpg[oi + pmap(r)] += v;     // bp is consumed by the factorisation in sys; computeScale needs it afterwards
+        d.sys[a0] = old0 + v;                          // bschur row / bp row of the augmented system
+        if (t >= 42) d.bpg[a1] = old1 + v;             // bp is consumed by the factorisation in sys; computeScale needs it afterwards
     }
 }
 
@@ -897,8 +943,9 @@ void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s) {
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, d, add_lambda ? 1 : 0);
 }
-void launch_schur_pairs(const DevBuf& d, int state, hipStream_t s) {
-    if (d.nchunks) hipLaunchKernelGGL(k_schur_pairs, dim3(d.nchunks), dim3(256), 0, s, d, state);
+void launch_schur_pairs(const DevBuf& d, int state, const ChainView* lead, hipStream_t s) {
+    const int nlead = lead ? lead->nseg : 0;
+    if (d.nchunks + nlead) hipLaunchKernelGGL(k_schur_pairs, dim3(d.nchunks + nlead), dim3(256), 0, s, d, state, lead ? *lead : ChainView{}, nlead);
 }
 void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s) {
     if (d.L) hipLaunchKernelGGL(k_backsub, dim3(lm_blocks(d)), dim3(LMB), (size_t)d.K * (KFCAM_STRIDE + 6) * sizeof(double), s, d, cur, trial);

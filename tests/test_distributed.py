@@ -134,6 +134,10 @@ def _nccl_worker(port, out):
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         stream = torch.cuda.Stream()
+        probe = torch.ones(8, device="cuda")
+        dist.all_reduce(probe)                                   # RCCL bring-up itself (communicator, first collective)
+        torch.cuda.synchronize()
+        out.put(("stage", "rccl_ready"))
         fn = pkg.distributed.make_allreduce(dist, 0, stream)
         with torch.cuda.stream(stream):
             buf = torch.arange(4096, dtype=torch.float64, device="cuda") * 0.5
@@ -167,8 +171,16 @@ def test_rccl_allreduce_hook_on_device_pointers(pkg, hip):
     q = ctx.Queue()
     pr = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
     pr.start()
+    import queue
     try:
-        g = q.get(timeout=240)
+        try:
+            g = q.get(timeout=150)
+        except queue.Empty:
+            # the worker never got a plain torch all-reduce through: RCCL did not come up on this box (seen once in ~10
+            # runs on the shared pool); nothing of this repository has run yet at that point
+            pytest.skip("RCCL bring-up (init_process_group / first all_reduce) did not finish within 150 s on this box")
+        if g[0] == "stage":
+            g = q.get(timeout=240)
     finally:
         pr.join(timeout=60)
         if pr.is_alive():
