@@ -272,7 +272,7 @@ int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double
     for (int r = 0; r < n; ++r) memcpy(&h[(size_t)r * ld], A + (size_t)r * n, (size_t)n * 8);
     for (int r = n; r < Ppad; ++r) h[(size_t)r * ld + r] = 1.0;
     memcpy(&h[(size_t)Ppad * ld], b, (size_t)n * 8);
-    DArr<double> sys, Lfac, xx, Linv, LT32, rd32;
+    DArr<double> sys, Lfac, xx, Linv, LT32, rd32, Ninv;
     DArr<Ctrl> ctrl;
     DArr<int> flags, cflags;
     HIPCK(p, sys.upload(h)); HIPCK(p, Lfac.alloc(sysn)); HIPCK(p, xx.alloc(ld)); HIPCK(p, ctrl.alloc(1));
@@ -283,6 +283,7 @@ int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double
     HIPCK(p, hipMemcpy(ctrl.p, &c0, sizeof c0, hipMemcpyHostToDevice));
     DevBuf d; memset(&d, 0, sizeof d);
     d.P = n; d.Ppad = Ppad; d.ld = ld; d.sys = sys.p; d.Lfac = Lfac.p; d.x = xx.p; d.ctrl = ctrl.p; d.Linv = Linv.p; d.flow_flags = flags.p; d.LTblk = LT32.p; d.Linv32 = LT32.p; d.rdblk = rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32; d.chol_flags = cflags.p; d.flow = p->opt.factor_flow != 0;
+    if (Ppad / 32 <= NINV_MAX_T) { HIPCK(p, Ninv.alloc((size_t)2 * Ppad * ld)); d.Ninv = Ninv.p; d.Nwork = Ninv.p + (size_t)Ppad * ld; }
     launch_cholesky(d, p->opt.use_mfma != 0, 1, p->stream);
     launch_trsv_back(d, p->opt.use_mfma != 0, 1, p->stream);
     HIPCK(p, hipStreamSynchronize(p->stream));
@@ -575,10 +576,14 @@ static int prepare(plba_problem* p) {
                 dd.P = cv.Pd; dd.Ppad = cv.Pdpad; dd.ld = cv.Pdpad;
                 dd.sys = p->d_sysd.p; dd.Lfac = p->d_Lfacd.p; dd.x = p->d_xd.p; dd.Linv = p->d_Linvd.p; dd.LTblk = p->d_LT32d.p; dd.Linv32 = p->d_LT32d.p;
                 dd.rdblk = p->d_rd32d.p; dd.flow_flags = p->d_flow_flagsd.p; dd.chol_flags = p->d_chol_flagsd.p;
+                dd.Ninv = nullptr; dd.Nwork = nullptr;
+                if (cv.Pdpad / 32 <= NINV_MAX_T) { HIPCK(p, p->d_Ninvd.alloc((size_t)2 * cv.Pdpad * cv.Pdpad)); dd.Ninv = p->d_Ninvd.p; dd.Nwork = dd.Ninv + (size_t)cv.Pdpad * cv.Pdpad; }
                 p->chain_ok = true;
             }
         }
     }
+    d.Ninv = nullptr; d.Nwork = nullptr;
+    if (!p->chain_ok && p->P > 0 && p->Ppad / 32 <= NINV_MAX_T) { HIPCK(p, p->d_Ninv.alloc((size_t)2 * p->Ppad * p->ld)); d.Ninv = p->d_Ninv.p; d.Nwork = d.Ninv + (size_t)p->Ppad * p->ld; }
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
     if (p->pr_nv > 0 && p->rank == 0) {
         const int n = p->pr_n;

@@ -624,16 +624,27 @@ __global__ __launch_bounds__(256) void k_potrf0_32(DevBuf d) {
     lookahead_factor32<false>(d, 0, sC, S, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
-__global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
-    __shared__ __attribute__((aligned(16))) double sX[64 * LS];      // rows [0,32) = X_r, [32,64) = X_c, [row][k]
-    __shared__ __attribute__((aligned(16))) double sC[32 * LS];      // look-ahead tile
-    __shared__ __attribute__((aligned(16))) Look32 S;
+// One tile workgroup of block step k.  AUG = false: the tiles of the factorisation proper (trailing update, right-hand-side
+// row, look-ahead).  AUG = true: the identity rows, below.  Two instantiations behind one uniform branch, so the code of
+// the critical look-ahead workgroup is scheduled exactly as if the identity rows did not exist.
+template <bool AUG>
+__device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const int T, double* sX, double* sC, Look32& S) {
     const int ld = d.ld;
     const int nt = T - k - 1;
     const int b = blockIdx.x;
     const int ntri = nt * (nt + 1) / 2;
-    int rr, cc;
-    if (b < ntri) {
+    // Workgroups beyond the normal tiles (launched when d.Ninv is set) carry IDENTITY rows appended to the augmented system:
+    // block row j of  N = I L^-T = L^-T  goes through exactly the panel product / trailing update of the right-hand-side
+    // row (X_r = R(j,k) L(k,k)^-T,  R(j,c) -= X_r L(c,k)^T), one short tile each, so the explicit inverse is finished by
+    // the same launches that finish the factor and the back-substitution becomes a matrix-vector product (k_back_gemv)
+    // instead of a chain of cross-workgroup hops.  Row j starts at launch j (R(j,j) = I, R(j,c>j) = 0: never stored).
+    const int nnormal = (ntri + nt > 0) ? ntri + nt : 1;
+    constexpr bool aug = AUG;
+    int rr, cc, aj = 0;
+    if (aug) {
+        const int w = nt > 0 ? nt : 1;
+        aj = (b - nnormal) / w; cc = (b - nnormal) % w; rr = nt;
+    } else if (b < ntri) {
         rr = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
         while ((rr + 1) * (rr + 2) / 2 <= b) ++rr;
         while (rr * (rr + 1) / 2 > b) --rr;
@@ -645,6 +656,8 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
     const int r = k + 1 + rr, c = k + 1 + cc;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const bool diag = (r == c);
+    const bool aug_first = aug && aj == k;            // the identity block itself: nothing stored yet
+    const double* rowsrc = aug ? d.Nwork + (size_t)(aj * 32) * ld : d.sys + (size_t)(r * 32) * ld;
 #ifdef PLBA_STAMPS
     unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
 #define STAMP32(i) do { if (blockIdx.x == 0 && k == 5) ts[i] = __builtin_readcyclecounter(); } while (0)
@@ -657,8 +670,7 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
     const bool act = !(p == 1 && diag);
     double4v x0 = (double4v){0.0, 0.0, 0.0, 0.0}, x1 = x0;
     if (act) {
-        const int br = p ? c : r;
-        const double2* Ag = reinterpret_cast<const double2*>(d.sys + (size_t)(br * 32 + th * 16 + li) * ld + k * 32 + lk * 8);
+        const double2* Ag = reinterpret_cast<const double2*>((p ? d.sys + (size_t)(c * 32) * ld : rowsrc) + (size_t)(th * 16 + li) * ld + k * 32 + lk * 8);
         const double2* B0 = reinterpret_cast<const double2*>(d.Linv32 + (size_t)k * 1024 + li * 32 + lk * 8);
         const double2* B1 = B0 + 16 * 32 / 2;
         double av[8], b0[8], b1[8];
@@ -666,6 +678,10 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
         for (int s = 0; s < 4; ++s) {
             const double2 va = Ag[s], v0 = B0[s], v1 = B1[s];
             av[2 * s] = va.x; av[2 * s + 1] = va.y; b0[2 * s] = v0.x; b0[2 * s + 1] = v0.y; b1[2 * s] = v1.x; b1[2 * s + 1] = v1.y;
+        }
+        if (aug_first && p == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = (th * 16 + li == lk * 8 + e) ? 1.0 : 0.0;
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {     // k index enumerated as 8 * (lane >> 4) + s on both operands
@@ -675,10 +691,10 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
     }
     // the C tile this workgroup updates, fetched in the shadow of the panel products
     const int tr = wv >> 1, tc = wv & 1;
-    double* C = d.sys + (size_t)(r * 32) * ld + c * 32;
+    double* C = (aug ? d.Nwork + (size_t)(aj * 32) * ld : d.sys + (size_t)(r * 32) * ld) + c * 32;
     const bool have_update = (c < T);      // false only for the last step's right-hand-side block
     double cold[4] = {0.0, 0.0, 0.0, 0.0};
-    if (have_update) {
+    if (have_update && !aug_first) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) cold[v] = C[(size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li];
     }
@@ -688,7 +704,7 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
         for (int v = 0; v < 4; ++v) { sX[(xr + 4 * v) * LS + li] = x0[v]; sX[(xr + 4 * v) * LS + 16 + li] = x1[v]; }
         if (p == 0 && c == k + 1) {
             // the finished panel block L(r,k) goes to Lfac, never back into sys: other workgroups still read the unsolved panel
-            double* g = d.Lfac + (size_t)(r * 32 + th * 16 + lk) * ld + k * 32 + li;
+            double* g = (aug ? d.Ninv + (size_t)(aj * 32) * ld : d.Lfac + (size_t)(r * 32) * ld) + (size_t)(th * 16 + lk) * ld + k * 32 + li;
 #pragma unroll
             for (int v = 0; v < 4; ++v) { g[(size_t)(4 * v) * ld] = x0[v]; g[(size_t)(4 * v) * ld + 16] = x1[v]; }
         }
@@ -711,7 +727,7 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
             else C[(size_t)row * ld + col] = nv;
         }
     }
-    if (!lookahead) return;
+    if (AUG || !lookahead) return;
     look32_reset(S, threadIdx.x);
     __syncthreads();
     STAMP32(2);
@@ -722,6 +738,16 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
     __syncthreads();
     if (threadIdx.x < 16 && blockIdx.x == 0 && k == 5) d.maxd_part[16 + threadIdx.x] = (double)(long long)(g_lstamp[threadIdx.x] - ts[0]);
 #endif
+}
+
+
+__global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
+    __shared__ __attribute__((aligned(16))) double sX[64 * LS];      // rows [0,32) = X_r, [32,64) = X_c, [row][k]
+    __shared__ __attribute__((aligned(16))) double sC[32 * LS];      // look-ahead tile
+    __shared__ __attribute__((aligned(16))) Look32 S;
+    const int nt = T - k - 1, ntiles = nt * (nt + 1) / 2 + nt;
+    if ((int)blockIdx.x >= (ntiles > 0 ? ntiles : 1)) chol32_tile<true>(d, k, T, sX, sC, S);
+    else chol32_tile<false>(d, k, T, sX, sC, S);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1101,7 +1127,7 @@ void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s) {
         for (int k = 0; k < T; ++k) {
             const int nt = T - k - 1;
             const int tiles = nt * (nt + 1) / 2 + nt;
-            hipLaunchKernelGGL(k_chol32, dim3(tiles > 0 ? tiles : 1), dim3(256), 0, s, d, k, T);
+            hipLaunchKernelGGL(k_chol32, dim3((tiles > 0 ? tiles : 1) + (d.Ninv ? (k + 1) * (nt > 0 ? nt : 1) : 0)), dim3(256), 0, s, d, k, T);
         }
         return;
     }
@@ -1109,8 +1135,28 @@ void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s) {
     else launch_cholesky_nb<32>(d, use_mfma, s);
 }
 
+// x = L^-T y = N y with the explicit inverse the factorisation launches left in Ninv: a wave per row, no dependencies
+__global__ __launch_bounds__(256) void k_back_gemv(DevBuf d) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= d.Ppad) return;
+    const double* Nr = d.Ninv + (size_t)c * d.ld;
+    const double* y = d.Lfac + (size_t)d.Ppad * d.ld;
+    double s0 = 0.0, s1 = 0.0;
+    int r = (c & ~31) + lane;
+    for (; r + 64 < d.Ppad; r += 128) { s0 = fma(Nr[r], y[r], s0); s1 = fma(Nr[r + 64], y[r + 64], s1); }
+    if (r < d.Ppad) s0 = fma(Nr[r], y[r], s0);
+    double v = s0 + s1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) d.x[c] = v;
+}
+
 void launch_trsv_back(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s) {
     const int T = d.Ppad / TILE;
+    if (inverse_panels(d, use_mfma) && !d.flow && d.Ninv) {
+        hipLaunchKernelGGL(k_back_gemv, dim3((d.Ppad + 3) / 4), dim3(256), 0, s, d);
+        return;
+    }
     if (inverse_panels(d, use_mfma)) {
         hipLaunchKernelGGL(k_inv_diag32, dim3(T), dim3(256), 0, s, d);
         hipLaunchKernelGGL(k_trsv_flow, dim3(T), dim3(256), 0, s, d, T, epoch);

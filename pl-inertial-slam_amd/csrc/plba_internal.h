@@ -87,6 +87,8 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     double *pr_err, *pr_dx, *pr_chi;
     // dense
     double *Hconst, *Himu, *bimu, *Himu_alt, *bimu_alt, *sys, *Lfac, *bpg, *x, *Linv32;   // Lfac: Cholesky factor (same shape as sys)
+    double *Ninv, *Nwork;  // Ppad x ld each: N = L^-T, carried through the factorisation launches as identity rows of the augmented system
+                           // (Nwork: the rows' unsolved trailing part); null: substitution instead
     double* Linv;          // T x 64 x 64 inverses of the diagonal tiles of Lfac
     double* LTblk;         // (Ppad/fb) x fb x fb transposed diagonal blocks of the factor, LT[j][t] = L[t][j]
     double* rdblk;         // Ppad reciprocals of the factor's diagonal
@@ -132,6 +134,7 @@ int  edge_blocks(const DevBuf& d);
 
 // dense
 // chain-variable elimination ahead of the dense factorisation (plba_chain.hip)
+constexpr int NINV_MAX_T = 32;   // explicit-inverse back-substitution up to this many 32-wide block steps (longer sums would outlast the pivot sweep)
 constexpr int CHAIN_SEG = 8;      // at most this many chain blocks between two separators (one workgroup eliminates a segment)
 constexpr int CHAIN_NSLOT = 15;   // dense columns a keyframe position can own: 6 pose + 9 separator chain dimensions
 struct ChainView {
