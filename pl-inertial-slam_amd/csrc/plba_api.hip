@@ -438,8 +438,8 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_Linv.alloc((size_t)(p->Ppad / TILE) * TILE * TILE)); HIPCK(p, p->d_flow_flags.alloc(p->Ppad / TILE)); p->flow_epoch = 0;
     HIPCK(p, p->d_chol_flags.alloc((size_t)(p->Ppad / 32 + 2) * (p->Ppad / 32)));
     HIPCK(p, p->d_LT32.alloc((size_t)p->Ppad * 64)); HIPCK(p, p->d_rd32.alloc(p->Ppad));
-    HIPCK(p, p->d_chi_part.alloc((size_t)(E + 255) / 256 + 1)); HIPCK(p, p->d_scale_part.alloc((size_t)(L + 63) / 64 + 33));
-    HIPCK(p, p->d_maxd_part.alloc((size_t)(L + 63) / 64 + 33)); HIPCK(p, p->d_kfdiag.alloc((size_t)K * 6)); HIPCK(p, p->d_posediag.alloc(p->ld));
+    HIPCK(p, p->d_chi_part.alloc((size_t)(E + 255) / 256 + 1)); HIPCK(p, p->d_scale_part.alloc((size_t)(L + 31) / 32 + 33));      // one partial per landmark workgroup (32 landmarks, plba_kernels.hip LML)
+    HIPCK(p, p->d_maxd_part.alloc((size_t)(L + 31) / 32 + 33)); HIPCK(p, p->d_kfdiag.alloc((size_t)K * 6)); HIPCK(p, p->d_posediag.alloc(p->ld));
     HIPCK(p, p->d_red.alloc(8)); HIPCK(p, p->d_ctrl.alloc(1)); HIPCK(p, p->d_trace.alloc(TRACE_CAP)); HIPCK(p, p->d_trace_n.alloc(1));
     // ---- kernel argument block -------------------------------------------------------------------------------------
     DevBuf& d = p->dv;
@@ -583,6 +583,7 @@ static int prepare(plba_problem* p) {
         }
     }
     d.Ninv = nullptr; d.Nwork = nullptr;
+    HIPCK(p, p->d_dbgbuf.alloc(64)); d.dbgbuf = p->d_dbgbuf.p;
     if (!p->chain_ok && p->P > 0 && p->Ppad / 32 <= NINV_MAX_T) { HIPCK(p, p->d_Ninv.alloc((size_t)2 * p->Ppad * p->ld)); d.Ninv = p->d_Ninv.p; d.Nwork = d.Ninv + (size_t)p->Ppad * p->ld; }
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
     if (p->pr_nv > 0 && p->rank == 0) {
@@ -1067,6 +1068,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
         else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { const size_t o = (size_t)p->ob_pos[p->Ep + e] * EREC; v[3 * (size_t)e] = h[o + 13]; v[3 * (size_t)e + 1] = h[o + 14]; } }
     } else if (w == "erec") { HIPCK(p, fetch(d.erec, (size_t)p->E * EREC, v)); }
     else if (w == "stamps") { HIPCK(p, fetch(d.maxd_part, 80, v)); }
+    else if (w == "dbgbuf") { HIPCK(p, fetch(d.dbgbuf, 64, v)); }
     else if (w == "pose_dim") v = {(double)p->P};
     else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};
     else if (w == "chi2") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {p->h_ctrl->current_chi}; }

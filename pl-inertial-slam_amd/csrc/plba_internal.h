@@ -96,6 +96,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     int fb;                // factorisation block width (32 or 64)
     int* flow_flags;       // T epoch-stamped flags of the back-substitution dataflow
     int* chol_flags;       // (T32 + 1) x T32 tile flags + T32 inverse flags of the single-launch factorisation (epoch-stamped)
+    double* dbgbuf;        // 64 doubles for diagnostic builds (cycle stamps)
     int flow;              // 1: single-launch dataflow factorisation (k_chol_flow), 0: one launch per block step
     // reductions / control
     double *chi_part, *scale_part, *maxd_part, *kfdiag, *posediag;

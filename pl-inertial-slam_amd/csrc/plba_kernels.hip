@@ -58,8 +58,46 @@ DEV double block_max_256(double v, double* s4) {
 }
 // Landmark-parallel kernels (one lane per landmark walking its 2-8 observations: dependent gathers) run in one-wave
 // workgroups: four times as many workgroups as 256-thread blocks, so all CUs carry some of the latency.
-constexpr int LMB = 64;
+constexpr int LMB = 256;           // threads of a landmark-parallel workgroup (workgroup dispatch is not free: 3000 one-wave workgroups
+                                   // arrive spread over ~2 us; the camera-block staging is shared by the four waves)
+constexpr int LMG = 8;             // lanes that share one landmark's edge list (a landmark has ~4, at most a few dozen observations: the
+                                   // kernels cost dependent gather rounds per edge, so a quad walks the list four edges at a time)
+constexpr int LML = LMB / LMG;     // landmarks per workgroup
+constexpr int LMW = LMB / 64;      // waves per workgroup
 DEV int pmap(int r) { return r < 3 ? r : r + 3; }   // (dp, dphi) -> position inside the 9-dim PVR block
+
+template <int CTRL, int ROW_MASK>
+DEV double dpp_get(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+DEV double wave_sum_dpp(double v) {      // row_shr:1,2,4,8 (inclusive scan inside each 16-lane row), row_bcast:15, row_bcast:31
+    v += dpp_get<0x111, 0xf>(v);
+    v += dpp_get<0x112, 0xf>(v);
+    v += dpp_get<0x114, 0xf>(v);
+    v += dpp_get<0x118, 0xf>(v);
+    v += dpp_get<0x142, 0xa>(v);
+    v += dpp_get<0x143, 0xc>(v);
+    return v;
+}
+
+// sum over the LMG lanes that share a landmark, result in all of them: quad_perm [1,0,3,2], [2,3,0,1], then (LMG == 8)
+// row_half_mirror, which pairs every lane with one of the other quad of its 8-lane group
+DEV double quad_sum(double v) {
+    v += dpp_get<0xB1, 0xf>(v);
+    v += dpp_get<0x4E, 0xf>(v);
+    if (LMG == 8) v += dpp_get<0x141, 0xf>(v);
+    return v;
+}
+DEV int quad_sum_i(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    if (LMG == 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    return v;
+}
+
 
 // -------------------------------------------------------------------------------------------------
 // K1/K2: per-observation residual / Jacobian / robust weight
@@ -77,10 +115,20 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
     __shared__ double s4[4];
     if ((int)blockIdx.x >= nblk_edges) {
         const int m = blockIdx.x - nblk_edges;
+#ifdef PLBA_STAMPS_LM
+        const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
         if (m < d.M) pose_edge_block<JAC, 256>(d, state, rb, m, threadIdx.x);
         else prior_block<JAC>(d, state);
+#ifdef PLBA_STAMPS_LM
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (JAC && threadIdx.x == 0 && (m == 0 || m == d.M / 2)) { d.dbgbuf[m == 0 ? 32 : 33] = (double)(__builtin_readcyclecounter() - t0); d.dbgbuf[m == 0 ? 34 : 35] = (double)(long long)__builtin_amdgcn_s_memrealtime(); }
+#endif
         return;
     }
+#ifdef PLBA_STAMPS_LM
+    const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
     const double* kf = d.kf[state];
     for (int k = threadIdx.x; k < d.K; k += 256) kfcam_make(d.cam, kf + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
     __syncthreads();
@@ -126,6 +174,13 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
     }
     double bs = block_sum_256(rho, s4);
     if (threadIdx.x == 0) d.chi_part[blockIdx.x] = bs;
+#ifdef PLBA_STAMPS_LM
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (JAC && threadIdx.x == 0 && ((int)blockIdx.x == 0 || (int)blockIdx.x == nblk_edges / 2 || (int)blockIdx.x == nblk_edges - 1)) {
+        const int o = blockIdx.x == 0 ? 40 : (int)blockIdx.x == nblk_edges / 2 ? 42 : 44;
+        d.dbgbuf[o] = (double)(__builtin_readcyclecounter() - t0); d.dbgbuf[o + 1] = (double)(long long)__builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -152,14 +207,13 @@ DEV void assemble_part(const DevBuf& d, int add_lambda, int bid, int nblocks, in
 }
 
 // (Hll + lambda I)^-1 and D*bl of one landmark slot from its undamped blocks
-DEV void landmark_dinv_one(const DevBuf& d, int slot, const double* h, const double* b, bool active, bool is_pt) {
+DEV void landmark_dinv_one(const DevBuf& d, int slot, const double* h, const double* b, bool active, bool is_pt, double lambda) {
     double dd[12], tt[6];
 #pragma unroll
     for (int i = 0; i < 12; ++i) dd[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) tt[i] = 0.0;
     if (active) {
-        const double lambda = d.ctrl->lambda;
         sym3_inv(h, lambda, dd);
         const V3 t0 = sym3_mul(dd, v3(b[0], b[1], b[2]));
         tt[0] = t0.x; tt[1] = t0.y; tt[2] = t0.z;
@@ -186,12 +240,29 @@ __global__ __launch_bounds__(LMB) void k_landmark_hll(DevBuf d, int state, int n
     extern __shared__ double s_dyn[];
     double* s_kc = s_dyn;
     if ((int)blockIdx.x >= nblk_lm) { assemble_part(d, add_lambda, blockIdx.x - nblk_lm, gridDim.x - nblk_lm, threadIdx.x, LMB); return; }
+    // What this kernel costs is dependent memory round trips, so they are laid out explicitly: (1) the landmark's edge
+    // range, its flags and lambda together with the keyframe states of the camera-block staging, (2) the edge's
+    // indices, (3) its record; the indices of the group's next edge are fetched while the current one is processed.
+#ifdef PLBA_STAMPS_LM
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+#define LMSTAMP(i) do { ts[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LMSTAMP(i) do {} while (0)
+#endif
+    LMSTAMP(0);
+    const int slot = blockIdx.x * LML + (threadIdx.x / LMG), sub = threadIdx.x % LMG;
+    const bool valid = slot < d.L;          // uniform over the lanes of a landmark
+    const int s = valid ? d.lm_start[slot] : 0, en = valid ? d.lm_start[slot + 1] : 0;
+    const bool fixed = valid ? d.lm_fixed[slot] != 0 : true;
+    const double lambda = FUSE_DINV ? d.ctrl->lambda : 0.0;
     for (int k = threadIdx.x; k < d.K; k += LMB) kfcam_make(d.cam, d.kf[state] + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
+    int ed = s + sub;
+    int lvl = 0, pos = 0, kfi = 0;
+    if (ed < en) { lvl = d.ob_level[ed]; pos = d.ob_pos[ed]; kfi = d.ob_kf[ed]; }
     __syncthreads();
-    const int slot = blockIdx.x * LMB + threadIdx.x;
+    LMSTAMP(1);
     double md = 0.0;
-    if (slot < d.L) {
-        const int s = d.lm_start[slot], en = d.lm_start[slot + 1];
+    if (valid) {
         double h[12], b[6];
 #pragma unroll
         for (int i = 0; i < 12; ++i) h[i] = 0.0;
@@ -199,14 +270,16 @@ __global__ __launch_bounds__(LMB) void k_landmark_hll(DevBuf d, int state, int n
         for (int i = 0; i < 6; ++i) b[i] = 0.0;
         int nact = 0;
         const bool is_pt = slot < d.Np;
-        for (int ed = s; ed < en; ++ed) {
-            if (d.ob_level[ed] == 0) ++nact;
-            const double4* r4 = reinterpret_cast<const double4*>(d.erec + (size_t)d.ob_pos[ed] * EREC);
-            const double4 q3 = r4[3];
+        while (ed < en) {      // lane `sub` of the group takes every LMG-th edge
+            const double4* r4 = reinterpret_cast<const double4*>(d.erec + (size_t)pos * EREC);
+            const double4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
+            const int kf_now = kfi;
+            if (lvl == 0) ++nact;
+            ed += LMG;
+            if (ed < en) { lvl = d.ob_level[ed]; pos = d.ob_pos[ed]; kfi = d.ob_kf[ed]; }
             const double w = q3.x;
             if (w == 0.0) continue;
-            const double4 q0 = r4[0], q1 = r4[1], q2 = r4[2];
-            const double* kc = s_kc + d.ob_kf[ed] * KFCAM_STRIDE;
+            const double* kc = s_kc + kf_now * KFCAM_STRIDE;
             M3 M;
 #pragma unroll
             for (int i = 0; i < 9; ++i) M.a[i] = kc[i];
@@ -223,22 +296,51 @@ __global__ __launch_bounds__(LMB) void k_landmark_hll(DevBuf d, int state, int n
                 b[3] -= w * vb.x * e1; b[4] -= w * vb.y * e1; b[5] -= w * vb.z * e1;
             }
         }
-        const bool active = (nact > 0) && !d.lm_fixed[slot];
-        d.lm_active[slot] = active ? 1 : 0;
-        double* ho = d.hll + (size_t)slot * 12;
-        double* bo = d.bl + (size_t)slot * 6;
+        LMSTAMP(2);
+        // the quad's partial blocks, added in a fixed order (deterministic); every lane ends up with the sums
 #pragma unroll
-        for (int i = 0; i < 12; ++i) ho[i] = h[i];
+        for (int i = 0; i < 6; ++i) h[i] = quad_sum(h[i]);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) bo[i] = b[i];
-        if (active) {
-            md = fmax(fmax(fabs(h[0]), fabs(h[3])), fabs(h[5]));
-            if (!is_pt) md = fmax(md, fmax(fmax(fabs(h[6]), fabs(h[9])), fabs(h[11])));
+        for (int i = 0; i < 3; ++i) b[i] = quad_sum(b[i]);
+        if (!is_pt) {       // the second 3 x 3 block exists for lines only (uniform over the group, and over all but one wave)
+#pragma unroll
+            for (int i = 6; i < 12; ++i) h[i] = quad_sum(h[i]);
+#pragma unroll
+            for (int i = 3; i < 6; ++i) b[i] = quad_sum(b[i]);
         }
-        if (FUSE_DINV) landmark_dinv_one(d, slot, h, b, active, is_pt);
+        nact = quad_sum_i(nact);
+        const bool active = (nact > 0) && !fixed;
+        if (sub == 0) {
+            d.lm_active[slot] = active ? 1 : 0;
+            double* ho = d.hll + (size_t)slot * 12;
+            double* bo = d.bl + (size_t)slot * 6;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) ho[i] = h[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) bo[i] = b[i];
+            if (active) {
+                md = fmax(fmax(fabs(h[0]), fabs(h[3])), fabs(h[5]));
+                if (!is_pt) md = fmax(md, fmax(fmax(fabs(h[6]), fabs(h[9])), fabs(h[11])));
+            }
+            if (FUSE_DINV) landmark_dinv_one(d, slot, h, b, active, is_pt, lambda);
+        }
     }
-    const double bm = wave_max(md);      // one wave per workgroup (LMB == 64)
-    if (threadIdx.x == 0) d.maxd_part[blockIdx.x] = bm;
+    LMSTAMP(3);
+    const double bm = wave_max(md);      // one partial per workgroup (the control kernel reads them all in one workgroup)
+    __shared__ double s_w[LMW];
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = bm;
+    __syncthreads();
+    if (threadIdx.x == 0) { double v = s_w[0]; for (int q = 1; q < LMW; ++q) v = fmax(v, s_w[q]); d.maxd_part[blockIdx.x] = v; }
+#ifdef PLBA_STAMPS_LM
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LMSTAMP(4);
+    if (FUSE_DINV && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == nblk_lm / 2 || blockIdx.x == nblk_lm - 1)) {
+        const int o = blockIdx.x == 0 ? 0 : blockIdx.x == nblk_lm / 2 ? 8 : 16;
+        for (int q = 0; q < 5; ++q) d.dbgbuf[o + q] = (double)(ts[q] - ts[0]);
+        d.dbgbuf[o + 5] = (double)(long long)__builtin_amdgcn_s_memrealtime();
+        d.dbgbuf[o + 6] = (double)(en - s);
+    }
+#endif
 }
 
 __global__ __launch_bounds__(LMB) void k_landmark_dinv(DevBuf d) {
@@ -249,24 +351,7 @@ __global__ __launch_bounds__(LMB) void k_landmark_dinv(DevBuf d) {
     for (int i = 0; i < 12; ++i) h[i] = d.hll[(size_t)slot * 12 + i];
 #pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = d.bl[(size_t)slot * 6 + i];
-    landmark_dinv_one(d, slot, h, b, d.lm_active[slot] != 0, slot < d.Np);
-}
-
-template <int CTRL, int ROW_MASK>
-DEV double dpp_get(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-DEV double wave_sum_dpp(double v) {      // row_shr:1,2,4,8 (inclusive scan inside each 16-lane row), row_bcast:15, row_bcast:31
-    v += dpp_get<0x111, 0xf>(v);
-    v += dpp_get<0x112, 0xf>(v);
-    v += dpp_get<0x114, 0xf>(v);
-    v += dpp_get<0x118, 0xf>(v);
-    v += dpp_get<0x142, 0xa>(v);
-    v += dpp_get<0x143, 0xc>(v);
-    return v;
+    landmark_dinv_one(d, slot, h, b, d.lm_active[slot] != 0, slot < d.Np, d.ctrl->lambda);
 }
 
 struct EdgeRows { V3 va, vb; double ga[6], gb[6], w, e0, e1; };
@@ -523,7 +608,19 @@ DEV void update_kf_one(const DevBuf& d, int cur, int trial, int k) {
 __global__ __launch_bounds__(LMB) void k_backsub(DevBuf d, int cur, int trial) {
     extern __shared__ double s_dyn[];
     double* s_kc = s_dyn;                       // K x 12 camera blocks of the CURRENT (linearisation) state
-    double* s_y = s_dyn + d.K * KFCAM_STRIDE;   // K x 6: blkdiag(Rcb,Rcb) * (dp, dphi) of every keyframe's step
+    double* s_y = s_dyn + d.K * KFCAM_STRIDE;   // K x 6: blkdiag(Rcb,Rcb) * (dp, dphi) of every keyframe's step (0 for a fixed one)
+    // round 1: everything that depends on the landmark slot alone, in flight together with the staging's loads
+    const int slot = blockIdx.x * LML + (threadIdx.x / LMG), sub = threadIdx.x % LMG;
+    const bool valid = slot < d.L;          // uniform over the lanes of a landmark
+    const bool lead = valid && sub == 0;
+    const int s = valid ? d.lm_start[slot] : 0, en = valid ? d.lm_start[slot + 1] : 0;
+    const bool on = valid && d.lm_active[slot] && d.ctrl->solver_ok;
+    const double lambda = d.ctrl->lambda;
+    double b[6], Dm[12], Lc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) { b[t] = lead ? d.bl[(size_t)slot * 6 + t] : 0.0; Lc[t] = lead ? d.lm[cur][(size_t)slot * 6 + t] : 0.0; }
+#pragma unroll
+    for (int t = 0; t < 12; ++t) Dm[t] = lead ? d.dinv[(size_t)slot * 12 + t] : 0.0;
     for (int k = threadIdx.x; k < d.K; k += LMB) {
         kfcam_make(d.cam, d.kf[cur] + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
         const int o = d.kf_off_pvr[k];
@@ -532,26 +629,27 @@ __global__ __launch_bounds__(LMB) void k_backsub(DevBuf d, int cur, int trial) {
         double* y = s_y + k * 6;
         y[0] = yp.x; y[1] = yp.y; y[2] = yp.z; y[3] = yr.x; y[4] = yr.y; y[5] = yr.z;
     }
+    // round 2: the first edge's indices
+    int ed = s + sub;
+    int pos = 0, kfi = 0;
+    if (on && ed < en) { pos = d.ob_pos[ed]; kfi = d.ob_kf[ed]; }
     __syncthreads();
     if (blockIdx.x == 0) for (int k = threadIdx.x; k < d.K; k += LMB) update_kf_one(d, cur, trial, k);   // keyframe part of update()
-    const int slot = blockIdx.x * LMB + threadIdx.x;
     double sc = 0.0;
-    if (slot < d.L) {
-        const double* Lc = d.lm[cur] + (size_t)slot * 6;
-        double* Lt = d.lm[trial] + (size_t)slot * 6;
+    if (valid) {
         double xl[6] = {0, 0, 0, 0, 0, 0};
         const bool is_pt = slot < d.Np;
-        if (d.lm_active[slot] && d.ctrl->solver_ok) {
-            const double* b = d.bl + (size_t)slot * 6;
-            double c[6] = {b[0], b[1], b[2], b[3], b[4], b[5]};
+        double c[6] = {0, 0, 0, 0, 0, 0};
+        if (on) {
             const double sl = is_pt ? -1.0 : 1.0;
-            for (int ed = d.lm_start[slot]; ed < d.lm_start[slot + 1]; ++ed) {
-                const double* rec = d.erec + (size_t)d.ob_pos[ed] * EREC;
-                if (rec[12] == 0.0) continue;
-                const int k = d.ob_kf[ed];
-                if (d.kf_off_pvr[k] < 0) continue;
+            while (ed < en) {      // lane `sub` takes every LMG-th edge; the next edge's indices travel while this one is processed
+                const double* rec = d.erec + (size_t)pos * EREC;
+                const int k = kfi;
                 const EdgeRows r = load_rows(d, rec, s_kc + k * KFCAM_STRIDE, is_pt);
-                const double* y = s_y + k * 6;
+                ed += LMG;
+                if (ed < en) { pos = d.ob_pos[ed]; kfi = d.ob_kf[ed]; }
+                if (r.w == 0.0) continue;
+                const double* y = s_y + k * 6;      // zero for a fixed keyframe
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                 for (int q = 0; q < 6; ++q) { s0 += r.ga[q] * y[q]; s1 += r.gb[q] * y[q]; }
@@ -559,19 +657,33 @@ __global__ __launch_bounds__(LMB) void k_backsub(DevBuf d, int cur, int trial) {
                 if (is_pt) { c[0] -= r.va.x * a0 + r.vb.x * a1; c[1] -= r.va.y * a0 + r.vb.y * a1; c[2] -= r.va.z * a0 + r.vb.z * a1; }
                 else { c[0] -= r.va.x * a0; c[1] -= r.va.y * a0; c[2] -= r.va.z * a0; c[3] -= r.vb.x * a1; c[4] -= r.vb.y * a1; c[5] -= r.vb.z * a1; }
             }
-            const double* D = d.dinv + (size_t)slot * 12;
-            V3 a = sym3_mul(D, v3(c[0], c[1], c[2]));
-            xl[0] = a.x; xl[1] = a.y; xl[2] = a.z;
-            if (!is_pt) { V3 e = sym3_mul(D + 6, v3(c[3], c[4], c[5])); xl[3] = e.x; xl[4] = e.y; xl[5] = e.z; }
-            const double lambda = d.ctrl->lambda;
-#pragma unroll
-            for (int t = 0; t < 6; ++t) sc += xl[t] * (lambda * xl[t] + b[t]);
         }
 #pragma unroll
-        for (int t = 0; t < 6; ++t) { Lt[t] = Lc[t] + xl[t]; d.xl[(size_t)slot * 6 + t] = xl[t]; }
+        for (int t = 0; t < 3; ++t) c[t] = quad_sum(c[t]);      // uniform over the group (`on` is)
+        if (!is_pt) {
+#pragma unroll
+            for (int t = 3; t < 6; ++t) c[t] = quad_sum(c[t]);
+        }
+        if (sub == 0) {
+            if (on) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) c[t] += b[t];
+                V3 a = sym3_mul(Dm, v3(c[0], c[1], c[2]));
+                xl[0] = a.x; xl[1] = a.y; xl[2] = a.z;
+                if (!is_pt) { V3 e = sym3_mul(Dm + 6, v3(c[3], c[4], c[5])); xl[3] = e.x; xl[4] = e.y; xl[5] = e.z; }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) sc += xl[t] * (lambda * xl[t] + b[t]);
+            }
+            double* Lt = d.lm[trial] + (size_t)slot * 6;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) { Lt[t] = Lc[t] + xl[t]; d.xl[(size_t)slot * 6 + t] = xl[t]; }
+        }
     }
-    const double bs = wave_sum(sc);      // one wave per workgroup (LMB == 64)
-    if (threadIdx.x == 0) d.scale_part[blockIdx.x] = bs;
+    const double bs = wave_sum(sc);      // one partial per workgroup, waves added in order
+    __shared__ double s_w[LMW];
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = bs;
+    __syncthreads();
+    if (threadIdx.x == 0) { double v = s_w[0]; for (int q = 1; q < LMW; ++q) v += s_w[q]; d.scale_part[blockIdx.x] = v; }
 }
 
 __global__ void k_update_kf(DevBuf d, int cur, int trial) {
@@ -891,7 +1003,7 @@ __global__ __launch_bounds__(256) void k_gate(DevBuf d, int state, double thresh
 // launchers
 // -------------------------------------------------------------------------------------------------
 int edge_blocks(const DevBuf& d) { return (d.E + 255) / 256; }
-static int lm_blocks(const DevBuf& d) { return (d.L + LMB - 1) / LMB; }
+static int lm_blocks(const DevBuf& d) { return (d.L + LML - 1) / LML; }
 
 // with_pose_edges: this rank owns the IMU / prior edges; they are evaluated by extra blocks of the same launch
 void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s) {
@@ -935,7 +1047,7 @@ void launch_kfdiag(const DevBuf& d, int state, hipStream_t s) {
     hipLaunchKernelGGL(k_posediag_kf, dim3((d.K * 6 + 255) / 256), dim3(256), 0, s, d);
 }
 void launch_landmark_dinv(const DevBuf& d, hipStream_t s) {
-    if (d.L) hipLaunchKernelGGL(k_landmark_dinv, dim3(lm_blocks(d)), dim3(LMB), 0, s, d);
+    if (d.L) hipLaunchKernelGGL(k_landmark_dinv, dim3((d.L + LMB - 1) / LMB), dim3(LMB), 0, s, d);
 }
 void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s) {
     const size_t n = (size_t)(d.Ppad + TILE) * d.ld;

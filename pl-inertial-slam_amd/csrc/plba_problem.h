@@ -105,7 +105,7 @@ struct plba_problem {
     plba::ChainView cv{};
     plba::DevBuf dd{};
     plba::DArr<int32_t> d_cidx, d_pidx, d_epos, d_seg_start, d_seg_col, d_ppos, d_pslot, d_slotcol;
-    plba::DArr<double> d_W, d_Ldinv, d_Lsub, d_sysd, d_Lfacd, d_xd, d_Linvd, d_LT32d, d_rd32d, d_Ninv, d_Ninvd;
+    plba::DArr<double> d_W, d_Ldinv, d_Lsub, d_sysd, d_Lfacd, d_xd, d_Linvd, d_LT32d, d_rd32d, d_Ninv, d_Ninvd, d_dbgbuf;
     plba::DArr<int> d_flow_flagsd, d_chol_flagsd;
     bool assembled = false;                     // k_landmark_hll already assembled the pose-side system of this iteration
     plba::DevBuf dv;
