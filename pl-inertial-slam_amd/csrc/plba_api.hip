@@ -562,6 +562,16 @@ static int prepare(plba_problem* p) {
                 cv.nel = nel; cv.nseg = nseg; cv.npos = npos; cv.Pd = Pd; cv.Pdpad = ((Pd + TILE - 1) / TILE) * TILE; cv.Wld = ((Pd + 2 + 63) / 64) * 64;
                 HIPCK(p, p->d_cidx.upload(cidx)); HIPCK(p, p->d_epos.upload(epos)); HIPCK(p, p->d_seg_start.upload(seg_start)); HIPCK(p, p->d_seg_col.upload(seg_col));
                 HIPCK(p, p->d_pidx.upload(pidx)); HIPCK(p, p->d_ppos.upload(ppos)); HIPCK(p, p->d_pslot.upload(pslot)); HIPCK(p, p->d_slotcol.upload(slotcol));
+                {
+                    std::vector<int32_t> kf_at(npos, -1), ekf, ukf;
+                    for (int k = 0; k < K; ++k) if (pos_of_kf[k] >= 0) kf_at[pos_of_kf[k]] = k;
+                    for (int e = 0; e < nel; ++e) ekf.push_back(kf_at[epos[e]]);
+                    for (int k = 0; k < K; ++k) if (pos_of_kf[k] < 0 || is_sep[pos_of_kf[k]]) ukf.push_back(k);
+                    if (ukf.empty()) ukf.push_back(-1);      // keep the array non-empty; nukf stays 0
+                    cv.nukf = (ukf[0] < 0) ? 0 : (int)ukf.size();
+                    HIPCK(p, p->d_kfpos.upload(pos_of_kf)); HIPCK(p, p->d_ekf.upload(ekf)); HIPCK(p, p->d_ukf.upload(ukf));
+                    cv.kfpos = p->d_kfpos.p; cv.ekf = p->d_ekf.p; cv.ukf = p->d_ukf.p;
+                }
                 p->d_W.release();      // must come back zero: the kernels only ever write inside each segment's window
                 HIPCK(p, p->d_W.alloc((size_t)(nel * 9 + 4) * cv.Wld)); HIPCK(p, p->d_Ldinv.alloc((size_t)nel * 81)); HIPCK(p, p->d_Lsub.alloc((size_t)nel * 81));
                 const size_t sysn_d = (size_t)(cv.Pdpad + TILE) * cv.Pdpad;
@@ -693,7 +703,6 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
         launch_cholesky(p->dd, true, epoch, s);
         MARKF(p, 12);
         launch_trsv_back(p->dd, true, epoch, s);
-        launch_chain_back(d, p->cv, p->dd, s);
     } else {
         MARKF(p, 11);
         launch_cholesky(d, p->opt.use_mfma != 0, epoch, s);
@@ -701,8 +710,8 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
         launch_trsv_back(d, p->opt.use_mfma != 0, epoch, s);
     }
     MARK(p, 7);
-    launch_backsub(d, p->cur, p->cur ^ 1, s);
-    launch_update_kf(d, p->cur, p->cur ^ 1, s);
+    launch_backsub(d, p->cur, p->cur ^ 1, p->chain_ok ? &p->cv : nullptr, p->chain_ok ? p->dd.x : nullptr, s);
+    if (!p->chain_ok) launch_update_kf(d, p->cur, p->cur ^ 1, s);
     MARK(p, 8);
     return PLBA_OK;
 }

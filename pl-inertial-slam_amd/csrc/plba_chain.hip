@@ -21,8 +21,9 @@
 //                  was staged in LDS up front.
 //   k_chain_schur  tile (a,b) of  A - W^T W  (v_mfma_f64_16x16x4_f64) over the rows of the segments whose column window
 //                  meets the tile; right-hand side row; identity padding
-//   k_chain_back   one workgroup per segment:  v = w_b - W_B x_d  over its column window, backward block substitution,
-//                  scatter of x into system order
+//   chain_back_segment (plba_kernels.hip, riding in front of the landmark back-substitution launch) one workgroup per
+//                  segment:  v = w_b - W_B x_d  over its column window, backward block substitution, scatter of x into
+//                  system order, and the state update of the segment's keyframes
 //
 // Applicable when no marginalization prior is attached (it couples chain variables of several keyframes) and every IMU
 // edge joins neighbouring chain blocks; otherwise the solver falls back to the dense path on the full system.
@@ -95,63 +96,12 @@ __global__ __launch_bounds__(256) void k_chain_schur(DevBuf d, ChainView cv, Dev
     }
 }
 
-// per segment: x_c = L^-T (w_b - W_B x_d), then x (system order); workgroup 0 also scatters the dense solution dd.x
-constexpr int BACK_THREADS = 256;
-__global__ __launch_bounds__(BACK_THREADS) void k_chain_back(DevBuf d, ChainView cv, DevBuf dd) {
-    __shared__ double sv[SEGMAX * 9];
-    __shared__ double sxw[192];            // dense solution over the segment's column window
-    __shared__ double sM[SEGMAX][162];     // L_ii^-1 | L_{i+1,i}
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = blockIdx.x;
-    const int i0 = cv.seg_start[g], n = cv.seg_start[g + 1] - i0;
-    const int wlo = cv.seg_col[2 * g], wn = cv.seg_col[2 * g + 1] - wlo;
-    if (g == 0) for (int c = threadIdx.x; c < cv.Pd; c += BACK_THREADS) d.x[cv.pidx[c]] = dd.x[c];
-    for (int c = threadIdx.x; c < wn; c += BACK_THREADS) sxw[c] = dd.x[wlo + c];
-    for (int idx = threadIdx.x; idx < n * 81; idx += BACK_THREADS) {
-        sM[idx / 81][idx % 81] = cv.Ldinv[(size_t)i0 * 81 + idx];
-        sM[idx / 81][81 + idx % 81] = cv.Lsub[(size_t)i0 * 81 + idx];
-    }
-    __syncthreads();
-    // v = w_b - W_B x_d over the window: a wave per row
-    for (int r = wv; r < n * 9; r += BACK_THREADS / 64) {
-        const double* Wr = cv.W + (size_t)(i0 * 9 + r) * cv.Wld;
-        double s = 0.0;
-        for (int c = lane; c < wn; c += 64) s = fma(Wr[wlo + c], sxw[c], s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-        if (lane == 0) sv[r] = Wr[cv.Pd] - s;
-    }
-    __syncthreads();
-    if (wv == 0) {
-        const int r = lane < 9 ? lane : 8;     // lanes 0..8 = components; x_{i+1} is kept in lanes 0..8 of `xn`
-        double xn = 0.0;
-        for (int i = n - 1; i >= 0; --i) {
-            const double* Li = sM[i];              // L_ii^-1
-            const double* Ls = Li + 81;            // L_{i+1,i}
-            double t = sv[i * 9 + r];
-            if (i + 1 < n) {
-#pragma unroll
-                for (int q = 0; q < 9; ++q) t = fma(-Ls[q * 9 + r], lane_bcast(xn, q), t);     // (L_{i+1,i}^T x_{i+1})_r
-            }
-            double xi = 0.0;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) xi = fma(Li[q * 9 + r], lane_bcast(t, q), xi);         // (L_ii^-T t)_r ; L^-1 is lower: zeros where q < r
-            xn = xi;
-            const int gi = cv.cidx[(i0 + i) * 9 + r];
-            if (lane < 9 && gi >= 0) d.x[gi] = xi;
-        }
-    }
-}
-
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s) {
     hipLaunchKernelGGL(k_chain_elim, dim3(cv.nseg), dim3(ELIM_THREADS), 0, s, d, cv);
 }
 void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s) {
     const int T = cv.Pdpad / 32;
     hipLaunchKernelGGL(k_chain_schur, dim3(T * (T + 1) / 2 + T), dim3(256), 0, s, d, cv, dd);
-}
-void launch_chain_back(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s) {
-    hipLaunchKernelGGL(k_chain_back, dim3(cv.nseg), dim3(BACK_THREADS), 0, s, d, cv, dd);
 }
 
 }  // namespace plba

@@ -121,7 +121,7 @@ void launch_kfdiag(const DevBuf& d, int state, hipStream_t s);
 void launch_landmark_dinv(const DevBuf& d, hipStream_t s);
 void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s);
 void launch_schur_pairs(const DevBuf& d, int state, const ChainView* lead /* chain segments riding in front, or null */, hipStream_t s);
-void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s);
+void launch_backsub(const DevBuf& d, int cur, int trial, const ChainView* lead /* chain back-substitution riding in front, or null */, const double* xd /* dense solution (dd.x) */, hipStream_t s);
 void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s);
 // red[0] = activeRobustChi2 (local), red[1] = landmark part of computeScale (local), red[2] = max |Hll_jj| (local)
 void launch_reduce(const DevBuf& d, bool owns_pose_edges, double* red, hipStream_t s);
@@ -148,13 +148,16 @@ struct ChainView {
     const int32_t* ppos;          // Pd: position of the keyframe each dense dim belongs to
     const int32_t* pslot;         // Pd: its slot (0-5 pose, 6-14 separator chain dims)
     const int32_t* slotcol;       // npos x 15: dense column of each slot, -1 = none
+    const int32_t* kfpos;         // K: chain-block position of each keyframe, -1 = no free dims
+    const int32_t* ekf;           // nel: keyframe of each eliminated block (its segment's workgroup applies that keyframe's step)
+    const int32_t* ukf;           // nukf keyframes whose whole step sits in the dense solution (separators, fixed): workgroup 0 applies it
+    int nukf;
     double* W;                    // (nel * 9 + 4) x Wld:  L^-1 [B | b_c], column Pd = w_b; zero outside each segment's window
     double* Ldinv;                // nel x 81: L_ii^-1, row-major
     double* Lsub;                 // nel x 81: L_{i+1,i}
 };
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s);
 void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);   // writes dd.sys
-void launch_chain_back(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);    // dd.x -> d.x
 void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s);   // sys -> Lfac (lower) incl. the augmented rows
 void launch_trsv_back(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s);      // x = L^-T y; epoch must differ from the previous call's
 void launch_ata(const double* A_colmajor, int rows, int cols, double* out_rowmajor, int ldo, hipStream_t s);  // A^T A

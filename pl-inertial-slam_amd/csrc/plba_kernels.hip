@@ -602,15 +602,172 @@ DEV void update_kf_one(const DevBuf& d, int cur, int trial, int k) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Chain back-substitution of one segment (plba_chain.hip), riding in front of the landmark back-substitution launch:
+//   x_c = L^-T (w_b - W_B x_d) over the segment's column window, x into system order, then the state update of the
+//   segment's keyframes.  Workgroup 0 also scatters the whole dense solution and updates the keyframes whose step
+//   lies entirely in it (separators, fixed keyframes).  The landmark workgroups of the same launch read the pose
+//   part of the step from the dense solution `xd` itself, never from d.x.
+// -------------------------------------------------------------------------------------------------
+// state update of one keyframe from explicit step values (update_kf_one without the trip through d.x)
+DEV void update_kf_vals(const DevBuf& d, int trial, int k, const double* s /*KF_STRIDE, current state*/, const double* u9, const double* ub6, bool has_pvr, bool has_bias) {
+    double tmp[KF_STRIDE];
+#pragma unroll
+    for (int i = 0; i < KF_STRIDE; ++i) tmp[i] = s[i];
+    const bool ok = d.ctrl->solver_ok != 0;
+    if (ok && has_pvr) kf_oplus_pvr(s, u9, tmp);
+    if (ok && has_bias) {   // IMU/NavState.cpp:100-121
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[16 + i] = s[16 + i] + ub6[i];
+    }
+    double* o = d.kf[trial] + (size_t)k * KF_STRIDE;
+#pragma unroll
+    for (int i = 0; i < KF_STRIDE; ++i) o[i] = tmp[i];
+}
+
+DEV void chain_back_segment(const DevBuf& d, const ChainView& cv, const double* xd, const int g, const int cur, const int trial) {
+    constexpr int BACK_THREADS = LMB;
+    constexpr int UFAST = 5;               // 16 lanes x 5 = 80 window columns on the all-in-flight path (6-slot interior positions)
+    __shared__ double sv[SEGMAX * 9];
+    __shared__ double sxc[SEGMAX * 9];     // the segment's solution, block-major
+    __shared__ double sxw[192];            // dense solution over the segment's column window
+    __shared__ double sM[SEGMAX][162];     // L_ii^-1 | L_{i+1,i}
+#ifdef PLBA_STAMPS_LM
+    unsigned long long cts[6]; cts[0] = __builtin_readcyclecounter();
+#define CSTAMP(i) cts[i] = __builtin_readcyclecounter()
+#else
+#define CSTAMP(i) do {} while (0)
+#endif
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, t = threadIdx.x;
+    const int i0 = cv.seg_start[g], n = cv.seg_start[g + 1] - i0;
+    const int wlo = cv.seg_col[2 * g], wn = cv.seg_col[2 * g + 1] - wlo;
+    // ---- everything that does not depend on the dense solution is requested first ------------------------------------------
+    // (a) W rows: 16 lanes per row, 16 rows per pass
+    const int lg = t >> 4, ll = t & 15;
+    constexpr int NPASS = (SEGMAX * 9 + 15) / 16;
+    double wr[NPASS][UFAST], wbv[NPASS];
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+        const int r = q * 16 + lg;
+        const bool in = r < n * 9;
+        const double* Wr = cv.W + (size_t)(i0 * 9 + (in ? r : 0)) * cv.Wld + wlo;
+#pragma unroll
+        for (int u = 0; u < UFAST; ++u) { const int c = ll + 16 * u; wr[q][u] = Wr[c < wn ? c : 0]; }
+        wbv[q] = Wr[cv.Pd - wlo];
+    }
+    // (b) the keyframe this thread will update (threads [0, n): the segment's; workgroup 0, threads [64, 64 + nukf): the rest)
+    int kf_k = -1, e_blk = -1;
+    if (t < n) { e_blk = t; kf_k = cv.ekf[i0 + t]; }
+    else if (g == 0 && t >= 64 && t - 64 < cv.nukf && t - 64 < BACK_THREADS - 64) kf_k = cv.ukf[t - 64];
+    double ks[KF_STRIDE];
+    int op = -1, ob = -1, pc[6] = {-1, -1, -1, -1, -1, -1}, cc[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+    if (kf_k >= 0) {
+        const double* sp = d.kf[cur] + (size_t)kf_k * KF_STRIDE;
+#pragma unroll
+        for (int i = 0; i < KF_STRIDE; ++i) ks[i] = sp[i];
+        op = d.kf_off_pvr[kf_k]; ob = d.kf_off_bias[kf_k];
+        const int q = cv.kfpos[kf_k];
+        if (q >= 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) pc[i] = cv.slotcol[q * NSLOT + i];
+            if (e_blk < 0) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) cc[i] = cv.slotcol[q * NSLOT + 6 + i];      // a separator's chain dims sit in the dense solution
+            }
+        }
+    }
+    // (c) the factors
+    for (int idx = t; idx < n * 81; idx += BACK_THREADS) {
+        sM[idx / 81][idx % 81] = cv.Ldinv[(size_t)i0 * 81 + idx];
+        sM[idx / 81][81 + idx % 81] = cv.Lsub[(size_t)i0 * 81 + idx];
+    }
+    // ---- the dense solution ---------------------------------------------------------------------------------------------------
+    if (g == 0) for (int c = t; c < cv.Pd; c += BACK_THREADS) d.x[cv.pidx[c]] = xd[c];
+    for (int c = t; c < wn; c += BACK_THREADS) sxw[c] = xd[wlo + c];
+    double u9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ub6[6] = {0, 0, 0, 0, 0, 0};
+    if (kf_k >= 0) {
+        const int ps[6] = {0, 1, 2, 6, 7, 8};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (pc[i] >= 0) u9[ps[i]] = xd[pc[i]];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (cc[i] >= 0) u9[3 + i] = xd[cc[i]];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (cc[3 + i] >= 0) ub6[i] = xd[cc[3 + i]];
+    }
+    __syncthreads();
+    CSTAMP(1);
+    // ---- v = w_b - W_B x_d over the window ------------------------------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+        const int r = q * 16 + lg;
+        double sacc = 0.0;
+#pragma unroll
+        for (int u = 0; u < UFAST; ++u) { const int c = ll + 16 * u; sacc = fma(wr[q][u], c < wn ? sxw[c] : 0.0, sacc); }
+        if (wn > 16 * UFAST && r < n * 9) {      // wide windows (separators next to each other): the rest of the row, not pre-fetched
+            const double* Wr = cv.W + (size_t)(i0 * 9 + r) * cv.Wld + wlo;
+            for (int c = 16 * UFAST + ll; c < wn; c += 16) sacc = fma(Wr[c], sxw[c], sacc);
+        }
+        sacc += dpp_get<0x111, 0xf>(sacc);      // row_shr 1, 2, 4, 8: lane 15 of each 16-lane row holds the row's sum
+        sacc += dpp_get<0x112, 0xf>(sacc);
+        sacc += dpp_get<0x114, 0xf>(sacc);
+        sacc += dpp_get<0x118, 0xf>(sacc);
+        if (ll == 15 && r < n * 9) sv[r] = wbv[q] - sacc;
+    }
+    __syncthreads();
+    CSTAMP(2);
+    if (wv == 0) {
+        const int r = lane < 9 ? lane : 8;     // lanes 0..8 = components; x_{i+1} is kept in lanes 0..8 of `xn`
+        double xn = 0.0;
+        for (int i = n - 1; i >= 0; --i) {
+            const double* Li = sM[i];              // L_ii^-1
+            const double* Ls = Li + 81;            // L_{i+1,i}
+            double tt = sv[i * 9 + r];
+            if (i + 1 < n) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) tt = fma(-Ls[q * 9 + r], lane_bcast(xn, q), tt);     // (L_{i+1,i}^T x_{i+1})_r
+            }
+            double xi = 0.0;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) xi = fma(Li[q * 9 + r], lane_bcast(tt, q), xi);         // (L_ii^-T t)_r ; L^-1 is lower: zeros where q < r
+            xn = xi;
+            const int gi = cv.cidx[(i0 + i) * 9 + r];
+            if (lane < 9) { sxc[i * 9 + r] = gi >= 0 ? xi : 0.0; if (gi >= 0) d.x[gi] = xi; }
+        }
+    }
+    __syncthreads();
+    CSTAMP(3);
+    // ---- keyframe part of update() -----------------------------------------------------------------------------------------
+    if (kf_k >= 0) {
+        if (e_blk >= 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) u9[3 + i] = sxc[e_blk * 9 + i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ub6[i] = sxc[e_blk * 9 + 3 + i];
+            // the pose part of this keyframe's step in system order (the same values workgroup 0 scatters)
+            if (op >= 0) { d.x[op] = u9[0]; d.x[op + 1] = u9[1]; d.x[op + 2] = u9[2]; d.x[op + 6] = u9[6]; d.x[op + 7] = u9[7]; d.x[op + 8] = u9[8]; }
+        }
+        update_kf_vals(d, trial, kf_k, ks, u9, ub6, op >= 0, ob >= 0);
+    }
+    if (g == 0) for (int u = BACK_THREADS - 64 + t; u < cv.nukf; u += BACK_THREADS) update_kf_one(d, cur, trial, cv.ukf[u]);   // more than 192 of them: d.x is complete for these (scattered above, same workgroup)
+#ifdef PLBA_STAMPS_LM
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CSTAMP(4);
+    if (threadIdx.x == 0 && g < 2) { for (int q = 0; q < 5; ++q) d.dbgbuf[48 + 6 * g + q] = (double)(cts[q] - cts[0]); d.dbgbuf[48 + 6 * g + 5] = (double)(long long)__builtin_amdgcn_s_memrealtime(); }
+#endif
+}
+
+// -------------------------------------------------------------------------------------------------
 // landmark back-substitution + landmark update (+ landmark part of computeScale)
 //   xl = D (bl - sum_e w Jl^T Jp x_kf)      trial_lm = cur_lm + xl
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(LMB) void k_backsub(DevBuf d, int cur, int trial) {
+__global__ __launch_bounds__(LMB) void k_backsub(DevBuf d, int cur, int trial, ChainView cv, const double* xd, int nlead) {
+    static_assert(LMB == 256, "the chain segments ride in this launch");
+    if ((int)blockIdx.x < nlead) { chain_back_segment(d, cv, xd, blockIdx.x, cur, trial); return; }
+    const int bid = blockIdx.x - nlead;
     extern __shared__ double s_dyn[];
     double* s_kc = s_dyn;                       // K x 12 camera blocks of the CURRENT (linearisation) state
     double* s_y = s_dyn + d.K * KFCAM_STRIDE;   // K x 6: blkdiag(Rcb,Rcb) * (dp, dphi) of every keyframe's step (0 for a fixed one)
     // round 1: everything that depends on the landmark slot alone, in flight together with the staging's loads
-    const int slot = blockIdx.x * LML + (threadIdx.x / LMG), sub = threadIdx.x % LMG;
+    const int slot = bid * LML + (threadIdx.x / LMG), sub = threadIdx.x % LMG;
     const bool valid = slot < d.L;          // uniform over the lanes of a landmark
     const bool lead = valid && sub == 0;
     const int s = valid ? d.lm_start[slot] : 0, en = valid ? d.lm_start[slot + 1] : 0;
@@ -625,7 +782,10 @@ __global__ __launch_bounds__(LMB) void k_backsub(DevBuf d, int cur, int trial) {
         kfcam_make(d.cam, d.kf[cur] + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
         const int o = d.kf_off_pvr[k];
         V3 yp = v3(0, 0, 0), yr = v3(0, 0, 0);
-        if (o >= 0) { yp = mul(d.cam.Rcb, v3(d.x[o], d.x[o + 1], d.x[o + 2])); yr = mul(d.cam.Rcb, v3(d.x[o + 6], d.x[o + 7], d.x[o + 8])); }
+        if (o >= 0 && nlead) {      // the chain workgroups of this launch are still writing d.x: take the pose step from the dense solution
+            const int32_t* sc = cv.slotcol + cv.kfpos[k] * NSLOT;
+            yp = mul(d.cam.Rcb, v3(xd[sc[0]], xd[sc[1]], xd[sc[2]])); yr = mul(d.cam.Rcb, v3(xd[sc[3]], xd[sc[4]], xd[sc[5]]));
+        } else if (o >= 0) { yp = mul(d.cam.Rcb, v3(d.x[o], d.x[o + 1], d.x[o + 2])); yr = mul(d.cam.Rcb, v3(d.x[o + 6], d.x[o + 7], d.x[o + 8])); }
         double* y = s_y + k * 6;
         y[0] = yp.x; y[1] = yp.y; y[2] = yp.z; y[3] = yr.x; y[4] = yr.y; y[5] = yr.z;
     }
@@ -634,7 +794,7 @@ __global__ __launch_bounds__(LMB) void k_backsub(DevBuf d, int cur, int trial) {
     int pos = 0, kfi = 0;
     if (on && ed < en) { pos = d.ob_pos[ed]; kfi = d.ob_kf[ed]; }
     __syncthreads();
-    if (blockIdx.x == 0) for (int k = threadIdx.x; k < d.K; k += LMB) update_kf_one(d, cur, trial, k);   // keyframe part of update()
+    if (bid == 0 && nlead == 0) for (int k = threadIdx.x; k < d.K; k += LMB) update_kf_one(d, cur, trial, k);   // keyframe part of update()
     double sc = 0.0;
     if (valid) {
         double xl[6] = {0, 0, 0, 0, 0, 0};
@@ -683,7 +843,11 @@ __global__ __launch_bounds__(LMB) void k_backsub(DevBuf d, int cur, int trial) {
     __shared__ double s_w[LMW];
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = bs;
     __syncthreads();
-    if (threadIdx.x == 0) { double v = s_w[0]; for (int q = 1; q < LMW; ++q) v += s_w[q]; d.scale_part[blockIdx.x] = v; }
+    if (threadIdx.x == 0) { double v = s_w[0]; for (int q = 1; q < LMW; ++q) v += s_w[q]; d.scale_part[bid] = v; }
+#ifdef PLBA_STAMPS_LM
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && (bid == 0 || bid == (int)gridDim.x - nlead - 1)) d.dbgbuf[60 + (bid == 0 ? 0 : 1)] = (double)(long long)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 __global__ void k_update_kf(DevBuf d, int cur, int trial) {
@@ -1059,11 +1223,12 @@ void launch_schur_pairs(const DevBuf& d, int state, const ChainView* lead, hipSt
     const int nlead = lead ? lead->nseg : 0;
     if (d.nchunks + nlead) hipLaunchKernelGGL(k_schur_pairs, dim3(d.nchunks + nlead), dim3(256), 0, s, d, state, lead ? *lead : ChainView{}, nlead);
 }
-void launch_backsub(const DevBuf& d, int cur, int trial, hipStream_t s) {
-    if (d.L) hipLaunchKernelGGL(k_backsub, dim3(lm_blocks(d)), dim3(LMB), (size_t)d.K * (KFCAM_STRIDE + 6) * sizeof(double), s, d, cur, trial);
+void launch_backsub(const DevBuf& d, int cur, int trial, const ChainView* lead, const double* xd, hipStream_t s) {
+    const int nlead = lead ? lead->nseg : 0, nb = d.L ? lm_blocks(d) : 0;
+    if (nb + nlead) hipLaunchKernelGGL(k_backsub, dim3(nb + nlead), dim3(LMB), (size_t)d.K * (KFCAM_STRIDE + 6) * sizeof(double), s, d, cur, trial, lead ? *lead : ChainView{}, xd, nlead);
 }
 void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s) {
-    if (d.L) return;   // done by block 0 of k_backsub whenever there are landmarks
+    if (d.L) return;   // done by block 0 of k_backsub whenever there are landmarks (or by the chain workgroups riding in it)
     hipLaunchKernelGGL(k_update_kf, dim3((d.K + 63) / 64), dim3(64), 0, s, d, cur, trial);
 }
 size_t tri_packed_size(const DevBuf& d) { const size_t a = (size_t)(d.Ppad >> 5); return 512 * a * (a + 1) + 2 * (size_t)d.Ppad; }
