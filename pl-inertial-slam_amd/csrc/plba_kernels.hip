@@ -866,43 +866,102 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
     __shared__ double sJ[9 * 24];     // [J0 | J1 | J2] row-major 9 x 24
     __shared__ double sOJ[9 * 24];
     __shared__ double sE[16];
+    __shared__ double sT[16];         // Omega e (9) | Omega_b e_b (6)
     __shared__ double sW[2];
+    __shared__ int sOff[24];          // system index of each of the 24 columns, -1 = fixed
     const int ki = d.imu_i[m], kj = d.imu_j[m];
     const double* si = d.kf[state] + (size_t)ki * KF_STRIDE;
     const double* sj = d.kf[state] + (size_t)kj * KF_STRIDE;
     const double* pre = d.imu_pre + (size_t)m * PRE_STRIDE;
     const double* Om = d.imu_info_pvr + (size_t)m * 81;
     const double* Ob = d.imu_info_bias + (size_t)m * 36;
+#ifdef PLBA_STAMPS_LM
+    unsigned long long pts[8] = {0,0,0,0,0,0,0,0}; pts[0] = __builtin_readcyclecounter();
+#define PSTAMP(i) pts[i] = __builtin_readcyclecounter()
+#else
+#define PSTAMP(i) do {} while (0)
+#endif
+    if (JAC) {
+        for (int t = lane; t < 9 * 24; t += NT) sJ[t] = 0.0;
+        __syncthreads();      // LDS only: nothing global is waited for before the serial parts start
+        if (lane >= 64 && lane < 64 + 24) {      // wave 1, in the shadow of the error evaluation
+            const int c = lane - 64;
+            const int o = c < 9 ? d.kf_off_pvr[ki] : c < 18 ? d.kf_off_pvr[kj] : d.kf_off_bias[ki];
+            sOff[c] = o < 0 ? -1 : o + (c < 9 ? c : c < 18 ? c - 9 : c - 18);
+        }
+    }
+    __shared__ double sS[18];         // Rj^T Ri | Jr(JRg dbg): what the residual-dependent Jacobian blocks need from the static part
+    double e9[9];
+    if (JAC && lane == 128) {         // wave 2: the Jacobian entries that do not depend on the rotation residual, next to the error
+        M3 RjTRi, JrB;
+        pvr_jac_static(si, sj, pre, d.gw, sJ, sJ + 9, sJ + 18, 24, 24, RjTRi, JrB);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { sS[q] = RjTRi.a[q]; sS[9 + q] = JrB.a[q]; }
+    }
     if (lane == 0) {
-        double e9[9], e6[6];
+        double e6[6];
         pvr_error(si, sj, pre, d.gw, e9);
         bias_error(si, sj, e6);
-        double chi = 0.0;
-        for (int r = 0; r < 9; ++r) { double t = 0.0; for (int c = 0; c < 9; ++c) t += Om[r * 9 + c] * e9[c]; chi += e9[r] * t; }
-        double chib = 0.0;
-        for (int r = 0; r < 6; ++r) { double t = 0.0; for (int c = 0; c < 6; ++c) t += Ob[r * 6 + c] * e6[c]; chib += e6[r] * t; }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) sE[r] = e9[r];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) sE[9 + r] = e6[r];
+        PSTAMP(1);
+    }
+    if (!JAC) {
+        // error pass: the serial form (one lane) is all there is to do
+        if (lane == 0) {
+            double chi = 0.0;
+            for (int r = 0; r < 9; ++r) { double t = 0.0; for (int c = 0; c < 9; ++c) t += Om[r * 9 + c] * sE[c]; chi += sE[r] * t; }
+            double chib = 0.0;
+            for (int r = 0; r < 6; ++r) { double t = 0.0; for (int c = 0; c < 6; ++c) t += Ob[r * 6 + c] * sE[9 + c]; chib += sE[9 + r] * t; }
+            double r0 = chi, r1 = 1.0, b0 = chib, b1 = 1.0;
+            if (rb.on[PLBA_EDGE_IMU_PVR]) huber(chi, rb.delta[PLBA_EDGE_IMU_PVR], r0, r1);
+            if (rb.on[PLBA_EDGE_IMU_BIAS]) huber(chib, rb.delta[PLBA_EDGE_IMU_BIAS], b0, b1);
+            double* eo = d.imu_err + (size_t)m * 16;
+            for (int r = 0; r < 15; ++r) eo[r] = sE[r];
+            double* co = d.imu_chi + (size_t)m * 4;
+            co[0] = chi; co[1] = chib; co[2] = r0; co[3] = b0;
+        }
+        return;
+    }
+    __syncthreads();      // e in LDS
+    PSTAMP(2);
+    // wave 0, lane 0 goes on with the Jacobians (written straight into their LDS layout); the other waves form
+    // chi = e^T Omega e, the robust weights and the cached error / chi2 records meanwhile
+    if (lane == 0) {
+        M3 RjTRi, JrB;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { RjTRi.a[q] = sS[q]; JrB.a[q] = sS[9 + q]; }
+        pvr_jac_rphi(pre, e9, RjTRi, JrB, sJ, sJ + 9, sJ + 18, 24, 24);
+        PSTAMP(3);
+    } else if (lane >= 64 && lane < 64 + 9) {          // wave 1: (Omega e)_r, row sums in the serial order of the reference
+        const int r = lane - 64;
+        double t = 0.0;
+        for (int c = 0; c < 9; ++c) t += Om[r * 9 + c] * sE[c];
+        sT[r] = t;
+    } else if (lane >= 128 && lane < 128 + 6) {        // wave 2: (Omega_b e_b)_r
+        const int r = lane - 128;
+        double t = 0.0;
+        for (int c = 0; c < 6; ++c) t += Ob[r * 6 + c] * sE[9 + c];
+        sT[9 + r] = t;
+    } else if (lane >= 192 && lane < 192 + 15) {       // wave 3: cached errors
+        d.imu_err[(size_t)m * 16 + (lane - 192)] = sE[lane - 192];
+    }
+    __syncthreads();
+    if (lane == 64) {
+        double chi = 0.0, chib = 0.0;
+        for (int r = 0; r < 9; ++r) chi += sE[r] * sT[r];
+        for (int r = 0; r < 6; ++r) chib += sE[9 + r] * sT[9 + r];
         double r0 = chi, r1 = 1.0, b0 = chib, b1 = 1.0;
         if (rb.on[PLBA_EDGE_IMU_PVR]) huber(chi, rb.delta[PLBA_EDGE_IMU_PVR], r0, r1);
         if (rb.on[PLBA_EDGE_IMU_BIAS]) huber(chib, rb.delta[PLBA_EDGE_IMU_BIAS], b0, b1);
-        double* eo = d.imu_err + (size_t)m * 16;
-        for (int r = 0; r < 9; ++r) { eo[r] = e9[r]; sE[r] = e9[r]; }
-        for (int r = 0; r < 6; ++r) { eo[9 + r] = e6[r]; sE[9 + r] = e6[r]; }
         double* co = d.imu_chi + (size_t)m * 4;
         co[0] = chi; co[1] = chib; co[2] = r0; co[3] = b0;
         sW[0] = r1; sW[1] = b1;
-        if (JAC) {
-            double J0[81], J1[81], J2[54];
-            for (int t = 0; t < 81; ++t) { J0[t] = 0.0; J1[t] = 0.0; }
-            for (int t = 0; t < 54; ++t) J2[t] = 0.0;
-            pvr_jacobians(si, sj, pre, d.gw, e9, J0, J1, J2);
-            for (int r = 0; r < 9; ++r) {
-                for (int c = 0; c < 9; ++c) { sJ[r * 24 + c] = J0[r * 9 + c]; sJ[r * 24 + 9 + c] = J1[r * 9 + c]; }
-                for (int c = 0; c < 6; ++c) sJ[r * 24 + 18 + c] = J2[r * 6 + c];
-            }
-        }
     }
-    if (!JAC) return;
-    __syncthreads();     // every thread of the NT-thread block reaches both barriers
+    PSTAMP(4);
+    __syncthreads();     // every thread of the NT-thread block reaches every barrier
     const double w = sW[0], wb = sW[1];
     // OJ = w * Omega * J   (9 x 24)
     for (int t = lane; t < 9 * 24; t += NT) {
@@ -913,21 +972,12 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
         sOJ[t] = w * s;
     }
     __syncthreads();
-    int off[24];
-    {
-        const int o0 = d.kf_off_pvr[ki], o1 = d.kf_off_pvr[kj], o2 = d.kf_off_bias[ki];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) { off[c] = o0 < 0 ? -1 : o0 + c; off[9 + c] = o1 < 0 ? -1 : o1 + c; }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) off[18 + c] = o2 < 0 ? -1 : o2 + c;
-    }
+    PSTAMP(5);
     const int ld = d.ld;
     // H += J^T OJ (24 x 24), g += -J^T (w Omega e) = -OJ^T e
     for (int t = lane; t < 24 * 24; t += NT) {
         const int a = t / 24, b = t % 24;
-        int oa = -1, ob = -1;
-#pragma unroll
-        for (int q = 0; q < 24; ++q) { if (q == a) oa = off[q]; if (q == b) ob = off[q]; }
+        const int oa = sOff[a], ob = sOff[b];
         if (oa < 0 || ob < 0) continue;
         double s = 0.0;
 #pragma unroll
@@ -935,9 +985,7 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
         if (s != 0.0) atomicAdd(&d.Himu[(size_t)oa * ld + ob], s);
     }
     if (lane < 24) {
-        int oa = -1;
-#pragma unroll
-        for (int q = 0; q < 24; ++q) if (q == lane) oa = off[q];
+        const int oa = sOff[lane];
         if (oa >= 0) {
             double s = 0.0;
 #pragma unroll
@@ -945,6 +993,9 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
             atomicAdd(&d.bimu[oa], -s);
         }
     }
+#ifdef PLBA_STAMPS_LM
+    if (JAC && lane == 0 && m == 1) { PSTAMP(6); for (int q = 0; q < 7; ++q) d.dbgbuf[24 + q] = (double)(pts[q] - pts[0]); }
+#endif
     // bias edge: J = [-I, +I] on (Bias_i, Bias_j); H_ii += W, H_jj += W, H_ij = H_ji -= W; g_i += W e, g_j -= W e
     {
         const int oi = d.kf_off_bias[ki], oj = d.kf_off_bias[kj];
@@ -971,8 +1022,8 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
     }
 }
 template <bool JAC>
-__global__ __launch_bounds__(64) void k_pose_edges(DevBuf d, int state, Robust rb) {
-    pose_edge_block<JAC, 64>(d, state, rb, blockIdx.x, threadIdx.x);
+__global__ __launch_bounds__(256) void k_pose_edges(DevBuf d, int state, Robust rb) {
+    pose_edge_block<JAC, 256>(d, state, rb, blockIdx.x, threadIdx.x);      // the block's four waves have different jobs
 }
 
 // K4: marginalization prior edge (one workgroup): dx, e = r0 + J0 dx, chi2 = |e|^2, g += -J0^T e.
@@ -1181,8 +1232,8 @@ void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bo
 void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, bool owns, hipStream_t s) {
     if (!owns) return;
     if (d.M > 0) {
-        if (jac) hipLaunchKernelGGL(k_pose_edges<true>, dim3(d.M), dim3(64), 0, s, d, state, rb);
-        else hipLaunchKernelGGL(k_pose_edges<false>, dim3(d.M), dim3(64), 0, s, d, state, rb);
+        if (jac) hipLaunchKernelGGL(k_pose_edges<true>, dim3(d.M), dim3(256), 0, s, d, state, rb);
+        else hipLaunchKernelGGL(k_pose_edges<false>, dim3(d.M), dim3(256), 0, s, d, state, rb);
     }
     if (d.pr_nv > 0) {
         if (jac) hipLaunchKernelGGL(k_prior<true>, dim3(1), dim3(256), 0, s, d, state);

@@ -391,44 +391,68 @@ PLBA_HD void pvr_error(const double* si, const double* sj, const double* pre, V3
     V3 rPhi = so3_log(C);
     e9[0] = rP.x; e9[1] = rP.y; e9[2] = rP.z; e9[3] = rV.x; e9[4] = rV.y; e9[5] = rV.z; e9[6] = rPhi.x; e9[7] = rPhi.y; e9[8] = rPhi.z;
 }
-// EdgeNavStatePVR::linearizeOplus (g2otypes.cpp:94-234).  J0, J1: 9x9 row-major; J2: 9x6.  Caller zero-fills.
-PLBA_HD void pvr_jacobians(const double* si, const double* sj, const double* pre, V3 gw, const double* e9, double* J0, double* J1, double* J2) {
+// lda: row stride of J0 / J1, ldb: row stride of J2 (9 / 6 for separate blocks; 24 / 24 when the three sit side by side).
+// Split in two so that the device can run them on different wavefronts: everything that does not depend on the
+// rotation residual (pvr_jac_static: it runs next to pvr_error) and the three blocks that do (pvr_jac_rphi).
+PLBA_HD void pvr_jac_static(const double* si, const double* sj, const double* pre, V3 gw, double* J0, double* J1, double* J2, int lda, int ldb, M3& RjTRi, M3& JrB) {
     Q4 qi; qi.x = si[6]; qi.y = si[7]; qi.z = si[8]; qi.w = si[9];
     Q4 qj; qj.x = sj[6]; qj.y = sj[7]; qj.z = sj[8]; qj.w = sj[9];
     M3 Ri = q_to_R(qi), Rj = q_to_R(qj), RiT = transpose(Ri);
     double dT = pre[141], dT2 = dT * dT;
     V3 Pi = ld_v3(si), Vi = ld_v3(si + 3), Pj = ld_v3(sj), Vj = ld_v3(sj + 3);
     V3 dbg = ld_v3(si + 16);
-    V3 rPhi = v3(e9[6], e9[7], e9[8]);
-    M3 JrInv = so3_JrInv(rPhi);
     M3 H1 = hat(mul(RiT, Pj - Pi - dT * Vi - (0.5 * dT2) * gw));
     M3 H2 = hat(mul(RiT, Vj - Vi - dT * gw));
-    M3 RjTRi = mulAtB(Rj, Ri);
-    M3 A33 = mul(JrInv, RjTRi);       // J0(6,6) = -JrInv * Rj^T * Ri
+    RjTRi = mulAtB(Rj, Ri);
     M3 RiTRj = mulAtB(Ri, Rj);
-    M3 ET = q_to_R(q_normalized(q_conj(so3_exp(rPhi))));
-    M3 JrB = so3_Jr(mul(ld_m3(pre + 51), dbg));
-    M3 B33 = mul(mul(mul(JrInv, ET), JrB), ld_m3(pre + 51));   // J2(6,0) = -JrInv * Exp(rPhi)^T * Jr * JRg
+    JrB = so3_Jr(mul(ld_m3(pre + 51), dbg));
+#ifdef __HIP_DEVICE_COMPILE__
 #pragma unroll
+#endif
     for (int r = 0; r < 3; ++r) {
-        J0[r * 9 + r] = -1.0;
+        J0[r * lda + r] = -1.0;
+#ifdef __HIP_DEVICE_COMPILE__
 #pragma unroll
+#endif
         for (int c = 0; c < 3; ++c) {
-            J0[r * 9 + 3 + c] = -RiT.a[r * 3 + c] * dT;
-            J0[r * 9 + 6 + c] = H1.a[r * 3 + c];
-            J0[(3 + r) * 9 + 3 + c] = -RiT.a[r * 3 + c];
-            J0[(3 + r) * 9 + 6 + c] = H2.a[r * 3 + c];
-            J0[(6 + r) * 9 + 6 + c] = -A33.a[r * 3 + c];
-            J1[r * 9 + c] = RiTRj.a[r * 3 + c];
-            J1[(3 + r) * 9 + 3 + c] = RiT.a[r * 3 + c];
-            J1[(6 + r) * 9 + 6 + c] = JrInv.a[r * 3 + c];
-            J2[r * 6 + c] = -pre[15 + r * 3 + c];
-            J2[r * 6 + 3 + c] = -pre[24 + r * 3 + c];
-            J2[(3 + r) * 6 + c] = -pre[33 + r * 3 + c];
-            J2[(3 + r) * 6 + 3 + c] = -pre[42 + r * 3 + c];
-            J2[(6 + r) * 6 + c] = -B33.a[r * 3 + c];
+            J0[r * lda + 3 + c] = -RiT.a[r * 3 + c] * dT;
+            J0[r * lda + 6 + c] = H1.a[r * 3 + c];
+            J0[(3 + r) * lda + 3 + c] = -RiT.a[r * 3 + c];
+            J0[(3 + r) * lda + 6 + c] = H2.a[r * 3 + c];
+            J1[r * lda + c] = RiTRj.a[r * 3 + c];
+            J1[(3 + r) * lda + 3 + c] = RiT.a[r * 3 + c];
+            J2[r * ldb + c] = -pre[15 + r * 3 + c];
+            J2[r * ldb + 3 + c] = -pre[24 + r * 3 + c];
+            J2[(3 + r) * ldb + c] = -pre[33 + r * 3 + c];
+            J2[(3 + r) * ldb + 3 + c] = -pre[42 + r * 3 + c];
         }
     }
+}
+PLBA_HD void pvr_jac_rphi(const double* pre, const double* e9, const M3& RjTRi, const M3& JrB, double* J0, double* J1, double* J2, int lda, int ldb) {
+    V3 rPhi = v3(e9[6], e9[7], e9[8]);
+    M3 JrInv = so3_JrInv(rPhi);
+    M3 A33 = mul(JrInv, RjTRi);       // J0(6,6) = -JrInv * Rj^T * Ri
+    M3 ET = q_to_R(q_normalized(q_conj(so3_exp(rPhi))));
+    M3 B33 = mul(mul(mul(JrInv, ET), JrB), ld_m3(pre + 51));   // J2(6,0) = -JrInv * Exp(rPhi)^T * Jr * JRg
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+#endif
+    for (int r = 0; r < 3; ++r) {
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll
+#endif
+        for (int c = 0; c < 3; ++c) {
+            J0[(6 + r) * lda + 6 + c] = -A33.a[r * 3 + c];
+            J1[(6 + r) * lda + 6 + c] = JrInv.a[r * 3 + c];
+            J2[(6 + r) * ldb + c] = -B33.a[r * 3 + c];
+        }
+    }
+}
+// EdgeNavStatePVR::linearizeOplus (g2otypes.cpp:94-234).  J0, J1: 9x9 row-major; J2: 9x6.  Caller zero-fills.
+PLBA_HD void pvr_jacobians(const double* si, const double* sj, const double* pre, V3 gw, const double* e9, double* J0, double* J1, double* J2, int lda = 9, int ldb = 6) {
+    M3 RjTRi, JrB;
+    pvr_jac_static(si, sj, pre, gw, J0, J1, J2, lda, ldb, RjTRi, JrB);
+    pvr_jac_rphi(pre, e9, RjTRi, JrB, J0, J1, J2, lda, ldb);
 }
 // EdgeNavStateBias::computeError (g2otypes.cpp:236-262)
 PLBA_HD void bias_error(const double* si, const double* sj, double* e6) {

@@ -19,3 +19,5 @@ for g in (0, 1):
     o = 48 + 6 * g
     print("chain back segment %d: staged %.0f, W x done %.0f, substitution done %.0f, keyframes updated + drained %.0f cycles" % (g, v[o + 1], v[o + 2], v[o + 3], v[o + 4]))
 print("  end (100 MHz ticks, relative to segment 0): segment 1 %+.0f, first landmark block %+.0f, last landmark block %+.0f" % (v[59] - v[53], v[60] - v[53], v[61] - v[53]))
+
+print("IMU edge block 1, lane 0: error done %.0f, past the barrier %.0f, residual-dependent Jacobian blocks %.0f, chi / weights barrier %.0f, Omega J %.0f, J^T Omega J + atomics issued %.0f cycles" % tuple(v[25:31]))
