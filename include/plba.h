@@ -68,7 +68,9 @@ typedef struct {
                                    experimental: measured slower at P = 735), 0 = one launch per block step (0) */
     int    chain_elim;          /* 1 = eliminate the velocity / bias variables (block-tridiagonal, no landmark coupling;
                                    segments between separator keyframes, one workgroup each) ahead of the dense
-                                   factorisation whenever no prior edge is attached; 0 = dense path on the full system (1) */
+                                   factorisation (keyframes a prior edge touches keep theirs dense; needs use_mfma and
+                                   factor_block 32, and IMU edges between neighbouring keyframes only: otherwise the
+                                   dense path is taken); 0 = dense path on the full system                       (1) */
     int    reserved[2];
 } plba_options;
 
