@@ -304,6 +304,7 @@ static int prepare(plba_problem* p) {
     if (!p->have_cam || !p->K) FAIL(p, PLBA_ERR_STATE, "camera and keyframes must be set before optimize");
     if ((int)p->po_pt.size() != p->Ep) p->Ep = 0;
     HIPCK(p, hipSetDevice(p->device));
+    DArrStreamScope zero_fill_on(p->stream);      // fresh buffers are cleared on the stream their kernels run on
     const int K = p->K, Np = p->Np, Nl = p->Nl, Ep = p->Ep, El = p->El, M = p->M;
     const int L = Np + Nl, E = Ep + El;
     p->L = L; p->E = E;
@@ -311,6 +312,9 @@ static int prepare(plba_problem* p) {
     for (int e = 0; e < Ep; ++e) if (p->po_pt[e] >= Np) FAIL(p, PLBA_ERR_INVALID, "point observation %d refers to point %d of %d", e, p->po_pt[e], Np);
     for (int e = 0; e < El; ++e) if (p->lo_ln[e] >= Nl) FAIL(p, PLBA_ERR_INVALID, "line observation %d refers to line %d of %d", e, p->lo_ln[e], Nl);
     if ((int)p->level.size() != E) p->level.assign(E, 0);
+    const bool ptime = getenv("PLBA_PREP_TIMING") != nullptr;
+    auto pt0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!ptime) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[prepare] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - pt0).count()); pt0 = t; };
     // ---- pose-side index map: non-fixed vertices by ascending id ----------------
     p->off_pvr.assign(K, -1); p->off_bias.assign(K, -1);
     int off = 0;
@@ -344,6 +348,7 @@ static int prepare(plba_problem* p) {
     p->lm_fixed.assign(L, 0);
     for (int i = 0; i < Np; ++i) { memcpy(&p->lm0[(size_t)i * 6], &p->pts[(size_t)i * 3], 24); p->lm_fixed[i] = p->pt_fixed[i]; }
     for (int i = 0; i < Nl; ++i) { memcpy(&p->lm0[(size_t)(Np + i) * 6], &p->lns[(size_t)i * 6], 48); p->lm_fixed[Np + i] = p->ln_fixed[i]; }
+    lap("index maps, slots");
     // ---- keyframe-pair lists for the Schur complement --------------------------------------------------
     std::vector<int64_t> cnt((size_t)K * K + 1, 0);
     for (int s = 0; s < L; ++s)
@@ -381,6 +386,7 @@ static int prepare(plba_problem* p) {
                 ++w;
             }
         }
+    lap("pair lists (host)");
     // ---- prior bookkeeping ----------------------------------------------------------------------------------------
     std::vector<int32_t> pr_kf(p->pr_nv), pr_isb(p->pr_nv), pr_x0off(p->pr_nv), pr_off(p->pr_nv);
     {
@@ -441,6 +447,7 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_chi_part.alloc((size_t)(E + 255) / 256 + 1)); HIPCK(p, p->d_scale_part.alloc((size_t)(L + 31) / 32 + 33));      // one partial per landmark workgroup (32 landmarks, plba_kernels.hip LML)
     HIPCK(p, p->d_maxd_part.alloc((size_t)(L + 31) / 32 + 33)); HIPCK(p, p->d_kfdiag.alloc((size_t)K * 6)); HIPCK(p, p->d_posediag.alloc(p->ld));
     HIPCK(p, p->d_red.alloc(8)); HIPCK(p, p->d_ctrl.alloc(1)); HIPCK(p, p->d_trace.alloc(TRACE_CAP)); HIPCK(p, p->d_trace_n.alloc(1));
+    lap("alloc + upload");
     // ---- kernel argument block -------------------------------------------------------------------------------------
     DevBuf& d = p->dv;
     memset(&d, 0, sizeof d);
@@ -595,6 +602,7 @@ static int prepare(plba_problem* p) {
     d.Ninv = nullptr; d.Nwork = nullptr;
     HIPCK(p, p->d_dbgbuf.alloc(64)); d.dbgbuf = p->d_dbgbuf.p;
     if (!p->chain_ok && p->P > 0 && p->Ppad / 32 <= NINV_MAX_T) { HIPCK(p, p->d_Ninv.alloc((size_t)2 * p->Ppad * p->ld)); d.Ninv = p->d_Ninv.p; d.Nwork = d.Ninv + (size_t)p->Ppad * p->ld; }
+    lap("chain maps + buffers");
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
     if (p->pr_nv > 0 && p->rank == 0) {
         const int n = p->pr_n;

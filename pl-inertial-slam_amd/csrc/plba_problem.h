@@ -1,25 +1,80 @@
 // plba_problem.h — host-side problem object behind the opaque plba_problem* of include/plba.h.
 #pragma once
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "plba_internal.h"
 
 namespace plba {
 
+// Device buffers come from a process-wide pool of power-of-two size classes (per device): a BA call allocates ~100
+// buffers and the window changes with every call, and hipMalloc / hipFree (which synchronises the device) cost more
+// wall time per call than the fifteen LM iterations.  Blocks go back to the pool on release and are only returned to
+// the driver beyond POOL_CAP cached bytes.  The owner synchronises its stream before releasing (plba_destroy does).
+struct DevPool {
+    static constexpr size_t POOL_CAP = (size_t)8 << 30;
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<void*>> free_;     // (device, size class) -> blocks
+    size_t cached = 0;
+    static size_t size_class(size_t bytes) { size_t c = 4096; while (c < bytes) c <<= 1; return c; }
+    hipError_t get(size_t bytes, void** out, size_t* cls) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        *cls = size_class(bytes);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = free_.find({dev, *cls});
+            if (it != free_.end() && !it->second.empty()) { *out = it->second.back(); it->second.pop_back(); cached -= *cls; return hipSuccess; }
+        }
+        hipError_t e = hipMalloc(out, *cls);
+        if (e != hipSuccess) {      // give the cache back to the driver and try once more
+            trim();
+            e = hipMalloc(out, *cls);
+        }
+        return e;
+    }
+    void put(void* ptr, size_t cls) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (cached + cls <= POOL_CAP) { free_[{dev, cls}].push_back(ptr); cached += cls; return; }
+        }
+        (void)hipFree(ptr);
+    }
+    void trim() {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& kv : free_) for (void* q : kv.second) (void)hipFree(q);
+        free_.clear(); cached = 0;
+    }
+};
+inline DevPool& dev_pool() { static DevPool* pool = new DevPool; return *pool; }      // never destroyed: no HIP calls at process exit
+// stream the zero-fill of fresh buffers is ordered on (set by the API entry point for its duration); null: legacy
+// synchronous hipMemset + drain of the null stream
+inline hipStream_t& darr_stream() { static thread_local hipStream_t s = nullptr; return s; }
+struct DArrStreamScope {
+    hipStream_t prev;
+    explicit DArrStreamScope(hipStream_t s) : prev(darr_stream()) { darr_stream() = s; }
+    ~DArrStreamScope() { darr_stream() = prev; }
+};
+
 template <class T>
 struct DArr {
     T* p = nullptr;
     size_t n = 0;
+    size_t cls = 0;          // pool size class of the block behind p
     hipError_t alloc(size_t cnt, bool zero = true) {
         if (cnt == 0) cnt = 1;
-        if (cnt != n || !p) {
-            if (p) (void)hipFree(p);
-            p = nullptr; n = 0;
-            hipError_t e = hipMalloc((void**)&p, cnt * sizeof(T));
-            if (e != hipSuccess) return e;
-            n = cnt;
+        if (!p || cnt * sizeof(T) > cls) {
+            release();
+            hipError_t e = dev_pool().get(cnt * sizeof(T), (void**)&p, &cls);
+            if (e != hipSuccess) { p = nullptr; cls = 0; return e; }
         }
+        n = cnt;
         if (zero) {
+            if (hipStream_t s = darr_stream()) return hipMemsetAsync(p, 0, n * sizeof(T), s);
             // hipMemset runs on the legacy null stream and may return before it completes; the library's
             // kernels run on a NON-blocking stream that does not order against it, so drain it here.
             hipError_t e = hipMemset(p, 0, n * sizeof(T));
@@ -33,7 +88,10 @@ struct DArr {
         if (e != hipSuccess || h.empty()) return e;
         return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p) dev_pool().put(p, cls); p = nullptr; n = 0; cls = 0; }
+    DArr() = default;
+    DArr(const DArr&) = delete;
+    DArr& operator=(const DArr&) = delete;
     ~DArr() { release(); }
 };
 
