@@ -654,7 +654,8 @@ static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
         HIPCK(p, hipMemsetAsync(d.bimu, 0, (size_t)d.ld * 8, s));
     }
     MARK(p, 0);
-    launch_linearize(d, p->cur, true, p->rob, owns_pose_edges(p), s);   // observations + IMU / prior edges, one launch
+    if (!p->spec_lin) launch_linearize(d, p->cur, true, p->rob, owns_pose_edges(p), s);   // observations + IMU / prior edges, one launch
+    p->spec_lin = false;      // else: already enqueued right behind the previous trial's k_decide (plba_optimize)
     MARK(p, 2);
     p->assembled = launch_landmark_hll(d, p->cur, !first_iter, owns_pose_edges(p), s);
     if (first_iter) {
@@ -750,6 +751,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
         p->ev_ready = true;
     }
     auto span = [&](int a, int b) -> double { float ms = 0.f; return hipEventElapsedTime(&ms, p->ev[a], p->ev[b]) == hipSuccess ? (double)ms : 0.0; };
+    p->spec_lin = false;
     for (int it = 0; it < max_iters && !(abort_flag && *abort_flag) && ok; ++it) {
         if ((rc = enqueue_linearize(p, it == 0, it))) return rc;
         double rho = 0.0;
@@ -766,6 +768,17 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             const unsigned long long seq = ++p->mail_seq;
             launch_decide(d, lp, p->d_red.p, p->world <= 1, p->d_mail, seq, s);
             MARK(p, 10);
+            // The next iteration's linearisation goes out NOW, gated on the decision k_decide leaves in the device control
+            // block: if the step was accepted it linearises the trial state (into the accumulators that are swapped in
+            // below), if not it returns at once and the retry goes on with the old records.  The host's reaction time
+            // (mailbox poll + enqueueing the next launches) hides behind it.
+            bool spec = false;
+            if (p->opt.profile < 2 && it + 1 < max_iters) {
+                DevBuf ds = d;
+                std::swap(ds.Himu, ds.Himu_alt); std::swap(ds.bimu, ds.bimu_alt);
+                launch_linearize(ds, trial, true, p->rob, owns_pose_edges(p), s, true);
+                spec = true;
+            }
             if (p->opt.profile >= 2) {
                 HIPCK(p, hipStreamSynchronize(s));        // every phase event must have completed before it is read
             } else {
@@ -790,13 +803,14 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             rho = c.rho;
             lambda = c.lambda;
             st.trials++;
-            if (c.accepted) { p->cur ^= 1; last_chi = c.current_chi; std::swap(p->dv.Himu, p->dv.Himu_alt); std::swap(p->dv.bimu, p->dv.bimu_alt); }
+            if (c.accepted) { p->cur ^= 1; last_chi = c.current_chi; std::swap(p->dv.Himu, p->dv.Himu_alt); std::swap(p->dv.bimu, p->dv.bimu_alt); p->spec_lin = spec; }
             else if (!std::isfinite(lambda)) break;
             qmax++;
         } while (rho < 0 && qmax < lp.max_trials && !(abort_flag && *abort_flag));
         st.iterations++;
         if (qmax == lp.max_trials || rho == 0 || !std::isfinite(lambda)) { ok = false; st.stop_reason = 1; }
     }
+    p->spec_lin = false;      // an unconsumed one (abort / stop right after an accepted step) only refreshed the records of the current state
     if (abort_flag && *abort_flag && st.stop_reason == 0 && st.iterations < max_iters) st.stop_reason = 2;
     // trace + stats
     int ntr = 0;

@@ -114,7 +114,7 @@ struct Robust { int on[5]; double delta[5]; };
 namespace plba {
 struct LmParams { double tau, lower, upper, user_lambda; int max_trials; };
 
-void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s);
+void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s, bool spec = false);   // spec: gated on the device-side LM decision
 void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, bool owns_pose_edges, hipStream_t s);
 bool launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv_assemble, bool add_lambda, hipStream_t s);
 void launch_kfdiag(const DevBuf& d, int state, hipStream_t s);

@@ -109,7 +109,10 @@ template <bool JAC> DEV void prior_block(const DevBuf& d, int state);
 // (one IMU PVR+bias edge pair per block, then one block for the prior), so the serial per-edge IMU math overlaps the
 // observation pass instead of following it.
 template <bool JAC>
-__global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust rb, int nblk_edges) {
+// spec != 0: launched BEFORE the host knows the LM decision of the trial that just ran (so that the host's reaction time
+// hides behind this kernel): linearises the trial state iff the device-side decision was "accepted", else does nothing.
+__global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust rb, int nblk_edges, int spec) {
+    if (spec && !d.ctrl->accepted) return;
     extern __shared__ double s_dyn[];
     double* s_kc = s_dyn;               // K x 12 staged camera blocks
     __shared__ double s4[4];
@@ -1221,13 +1224,13 @@ int edge_blocks(const DevBuf& d) { return (d.E + 255) / 256; }
 static int lm_blocks(const DevBuf& d) { return (d.L + LML - 1) / LML; }
 
 // with_pose_edges: this rank owns the IMU / prior edges; they are evaluated by extra blocks of the same launch
-void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s) {
+void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s, bool spec) {
     const int nb = d.E ? edge_blocks(d) : 0;
     const int pose_blocks = with_pose_edges ? d.M + (d.pr_nv > 0 ? 1 : 0) : 0;
     if (nb + pose_blocks == 0) return;
     const size_t sh = (size_t)d.K * KFCAM_STRIDE * sizeof(double);
-    if (jac) hipLaunchKernelGGL(k_linearize<true>, dim3(nb + pose_blocks), dim3(256), sh, s, d, state, rb, nb);
-    else hipLaunchKernelGGL(k_linearize<false>, dim3(nb + pose_blocks), dim3(256), sh, s, d, state, rb, nb);
+    if (jac) hipLaunchKernelGGL(k_linearize<true>, dim3(nb + pose_blocks), dim3(256), sh, s, d, state, rb, nb, spec ? 1 : 0);
+    else hipLaunchKernelGGL(k_linearize<false>, dim3(nb + pose_blocks), dim3(256), sh, s, d, state, rb, nb, 0);
 }
 void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, bool owns, hipStream_t s) {
     if (!owns) return;

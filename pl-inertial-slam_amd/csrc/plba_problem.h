@@ -103,6 +103,7 @@ struct plba_problem {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool spec_lin = false;     // the next iteration's linearisation is already in the stream (enqueued behind k_decide)
     // ---- host copy of the uploaded graph -------------------------------------------------------
     bool have_cam = false;
     double fx, fy, cx, cy, Rbc[9], Pbc[3], gw[3] = {0, 0, 0};
