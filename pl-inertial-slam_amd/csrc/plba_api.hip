@@ -577,6 +577,14 @@ static int prepare(plba_problem* p) {
                     if (ukf.empty()) ukf.push_back(-1);      // keep the array non-empty; nukf stays 0
                     cv.nukf = (ukf[0] < 0) ? 0 : (int)ukf.size();
                     HIPCK(p, p->d_kfpos.upload(pos_of_kf)); HIPCK(p, p->d_ekf.upload(ekf)); HIPCK(p, p->d_ukf.upload(ukf));
+                    std::vector<int32_t> trow(2 * (size_t)(cv.Pdpad / 32), 0);
+                    for (int tb = 0; tb < cv.Pdpad / 32; ++tb) {
+                        int glo = -1, ghi = -1;
+                        for (int g = 0; g < nseg; ++g)
+                            if (tb * 32 < seg_col[2 * g + 1] && tb * 32 + 32 > seg_col[2 * g]) { if (glo < 0) glo = g; ghi = g; }
+                        if (glo >= 0) { trow[2 * tb] = seg_start[glo] * 9; trow[2 * tb + 1] = seg_start[ghi + 1] * 9; }
+                    }
+                    HIPCK(p, p->d_trow.upload(trow)); cv.trow = p->d_trow.p;
                     cv.kfpos = p->d_kfpos.p; cv.ekf = p->d_ekf.p; cv.ukf = p->d_ukf.p;
                 }
                 p->d_W.release();      // must come back zero: the kernels only ever write inside each segment's window
@@ -709,7 +717,7 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
         if (!chain_rides) launch_chain_elim(d, p->cv, s);
         launch_chain_schur(d, p->cv, p->dd, s);
         MARKF(p, 11);
-        launch_cholesky(p->dd, true, epoch, s);
+        launch_cholesky(p->dd, true, epoch, s, chain_schur_factors_tile0(p->dd));
         MARKF(p, 12);
         launch_trsv_back(p->dd, true, epoch, s);
     } else {

@@ -30,6 +30,7 @@
 // Everything is read from the LOWER triangle of `sys` (in a sharded run only that part is globally summed).
 #include "plba_internal.h"
 #include "plba_chain_dev.h"
+#include "plba_dense_dev.h"
 
 namespace plba {
 
@@ -39,6 +40,8 @@ __global__ __launch_bounds__(ELIM_THREADS) void k_chain_elim(DevBuf d, ChainView
 // ta == Pdpad / 32 carry the right-hand side  b_d - W_B^T w_b  in their first row.  Only the rows of W that belong to
 // segments whose column window meets both tiles are read (everything else in those columns is zero).
 __global__ __launch_bounds__(256) void k_chain_schur(DevBuf d, ChainView cv, DevBuf dd) {
+    __shared__ __attribute__((aligned(16))) double sC0[32 * LS];      // workgroup 0: the first diagonal tile, factored on the spot
+    __shared__ __attribute__((aligned(16))) Look32 S0;
     const int T = cv.Pdpad / 32;
     const int b = blockIdx.x, ntri = T * (T + 1) / 2;
     int ta, tb;
@@ -57,48 +60,71 @@ __global__ __launch_bounds__(256) void k_chain_schur(DevBuf d, ChainView cv, Dev
     const bool a_ok = rhs_row || acol < cv.Pd, b_ok = bcol < cv.Pd;
     const double* Wa = cv.W + (a_ok ? acol : cv.Wld - 1);          // column Wld - 1 is zero padding (Wld >= Pd + 2)
     const double* Wb = cv.W + (b_ok ? bcol : cv.Wld - 1);
+    // The workgroup's cost is dependent memory rounds, so there are two: (1) the tile's row range of W (cv.trow: the
+    // segments whose column window meets a 32-column block are consecutive, and so are their rows) and the index map
+    // of the A entries, (2) the W rows themselves — three 32-row chunks in flight, more only when several segments
+    // meet the tile — together with those entries of A.
+    int rlo = cv.trow[2 * tb], rhi = cv.trow[2 * tb + 1];
+    if (!rhs_row) { rlo = max(rlo, cv.trow[2 * ta]); rhi = min(rhi, cv.trow[2 * ta + 1]); }
+    double aold[4];
+    {
+        const int cb = tb * 32 + tc * 16 + li;
+        const int pb = cb < cv.Pd ? cv.pidx[cb] : 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int lr = tr * 16 + lk + 4 * v;
+            if (rhs_row) aold[v] = (lr == 0 && cb < cv.Pd) ? d.sys[(size_t)d.Ppad * d.ld + pb] : 0.0;
+            else {
+                const int ca = ta * 32 + lr;
+                aold[v] = (ca < cv.Pd && cb < cv.Pd) ? sym_at(d.sys, d.ld, cv.pidx[ca], pb) : ((ca == cb) ? 1.0 : 0.0);
+            }
+        }
+    }
     double4v acc = (double4v){0.0, 0.0, 0.0, 0.0};
-    for (int g = 0; g < cv.nseg; ++g) {
-        const int wlo = cv.seg_col[2 * g], whi = cv.seg_col[2 * g + 1];
-        const bool meets_b = tb * 32 < whi && tb * 32 + 32 > wlo;
-        const bool meets_a = rhs_row || (ta * 32 < whi && ta * 32 + 32 > wlo);
-        if (!(meets_a && meets_b)) continue;
-        const int r0 = cv.seg_start[g] * 9, r1 = cv.seg_start[g + 1] * 9;          // W has 4 zero rows behind the last one
-        for (int s0 = r0; s0 < r1; s0 += 32) {
-            double av[8], bv[8];
+    constexpr int NCH = 3;
+    for (int s0 = rlo; s0 < rhi; s0 += 32 * NCH) {
+        double av[NCH][8], bv[NCH][8];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int r = s0 + 4 * u + lk;
-                const bool in = r < r1;
-                av[u] = in ? Wa[(size_t)r * cv.Wld] : 0.0;
-                bv[u] = in ? Wb[(size_t)r * cv.Wld] : 0.0;
+                const int r = s0 + 32 * ch + 4 * u + lk;
+                const bool in = r < rhi;
+                av[ch][u] = in ? Wa[(size_t)r * cv.Wld] : 0.0;
+                bv[ch][u] = in ? Wb[(size_t)r * cv.Wld] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
-        }
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ch][u], bv[ch][u], acc, 0, 0, 0);
     }
     // C/D layout: col = lane & 15, row = (lane >> 4) + 4 v
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int lr = tr * 16 + lk + 4 * v, lc = tc * 16 + li;
         const int cb = tb * 32 + lc;
-        double out;
+        const double out = (rhs_row && lr != 0) ? 0.0 : ((rhs_row || (ta * 32 + lr < cv.Pd && cb < cv.Pd)) ? aold[v] - acc[v] : aold[v]);
         if (rhs_row) {
-            out = (lr == 0 && cb < cv.Pd) ? d.sys[(size_t)d.Ppad * d.ld + cv.pidx[cb]] - acc[v] : 0.0;
-            dd.sys[(size_t)(cv.Pdpad + lr) * ldd + cb] = out;
+            dd.sys[(size_t)(cv.Pdpad + lr) * ldd + cb] = (cb < cv.Pd) ? out : 0.0;
         } else {
             const int ca = ta * 32 + lr;
-            if (ca < cv.Pd && cb < cv.Pd) out = sym_at(d.sys, d.ld, cv.pidx[ca], cv.pidx[cb]) - acc[v];
-            else out = (ca == cb) ? 1.0 : 0.0;
             dd.sys[(size_t)ca * ldd + cb] = out;
             if (ta != tb) dd.sys[(size_t)cb * ldd + ca] = out;     // keep the matrix symmetric (debug readers)
+            if (b == 0) sC0[lr * LS + lc] = out;
         }
     }
+    if (b != 0 || dd.flow) return;
+    // tile (0,0) is complete in LDS: run the look-ahead pipeline of the factorisation on it right here (L(0,0) -> dd.Lfac,
+    // L(0,0)^-1 -> dd.Linv32[0]) instead of in a launch of its own (k_potrf0_32): the first block step follows directly
+    look32_reset(S0, threadIdx.x);
+    __syncthreads();
+    lookahead_factor32<false>(dd, 0, sC0, S0, wv, lane);
 }
 
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s) {
     hipLaunchKernelGGL(k_chain_elim, dim3(cv.nseg), dim3(ELIM_THREADS), 0, s, d, cv);
 }
+bool chain_schur_factors_tile0(const DevBuf& dd) { return !dd.flow; }
 void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s) {
     const int T = cv.Pdpad / 32;
     hipLaunchKernelGGL(k_chain_schur, dim3(T * (T + 1) / 2 + T), dim3(256), 0, s, d, cv, dd);

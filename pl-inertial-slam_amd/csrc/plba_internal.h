@@ -148,6 +148,7 @@ struct ChainView {
     const int32_t* ppos;          // Pd: position of the keyframe each dense dim belongs to
     const int32_t* pslot;         // Pd: its slot (0-5 pose, 6-14 separator chain dims)
     const int32_t* slotcol;       // npos x 15: dense column of each slot, -1 = none
+    const int32_t* trow;          // 2 x Pdpad/32: rows [lo, hi) of W whose segments' column windows meet each 32-column block of the dense system
     const int32_t* kfpos;         // K: chain-block position of each keyframe, -1 = no free dims
     const int32_t* ekf;           // nel: keyframe of each eliminated block (its segment's workgroup applies that keyframe's step)
     const int32_t* ukf;           // nukf keyframes whose whole step sits in the dense solution (separators, fixed): workgroup 0 applies it
@@ -158,7 +159,9 @@ struct ChainView {
 };
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s);
 void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);   // writes dd.sys
-void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s);   // sys -> Lfac (lower) incl. the augmented rows
+void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s, bool tile0_done = false);   // sys -> Lfac (lower) incl. the augmented rows;
+                                                                                     // tile0_done: the producer of sys already factored tile (0,0) (k_chain_schur)
+bool chain_schur_factors_tile0(const DevBuf& dd);
 void launch_trsv_back(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s);      // x = L^-T y; epoch must differ from the previous call's
 void launch_ata(const double* A_colmajor, int rows, int cols, double* out_rowmajor, int ldo, hipStream_t s);  // A^T A
 
