@@ -421,6 +421,12 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state, ChainV
     __shared__ double s_kc[2 * KFCAM_STRIDE];
     __shared__ int s_last;
     const int ch = blockIdx.x - nlead;
+#ifdef PLBA_STAMPS_LM
+    unsigned long long sts[6] = {0,0,0,0,0,0}; sts[0] = __builtin_readcyclecounter(); const long long rt0 = __builtin_amdgcn_s_memrealtime();
+#define SSTAMP(i) sts[i] = __builtin_readcyclecounter()
+#else
+#define SSTAMP(i) do {} while (0)
+#endif
     const ChunkMeta m = d.ch_meta[ch];
     const int p = m.pair, i = m.ij & 0xffff, j = (m.ij >> 16) & 0xffff;
     const bool diag = (i == j);
@@ -464,8 +470,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state, ChainV
         for (int q = 0; q < 4; ++q) { qi[q] = ri4[q]; qj[q] = rj4[q]; }
 #pragma unroll
         for (int q = 0; q < 3; ++q) { const double4 v = D4[q]; D[4 * q] = v.x; D[4 * q + 1] = v.y; D[4 * q + 2] = v.z; D[4 * q + 3] = v.w; }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { const double2 v = diag ? t2[q] : make_double2(0.0, 0.0); tl[2 * q] = v.x; tl[2 * q + 1] = v.y; }
+        (void)t2;
     }
     if (t < 2) {
         double s[KF_STRIDE];
@@ -475,6 +480,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state, ChainV
         kfcam_make(d.cam, s, s_kc + t * KFCAM_STRIDE);
     }
     __syncthreads();
+    SSTAMP(1);
     // per-lane factors of the entry's contribution  g_i Q g_j^T = ga_i T0^T + gb_i T1^T  (zero for an idle lane), then each
     // of the 36 (+12) sums goes through the wave reduction as soon as it is formed: 6 live accumulators instead of 48
     const double wi = qi[3].x, wj = qj[3].x;
@@ -504,7 +510,11 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state, ChainV
             ga[c] = on ? ri.ga[c] : 0.0;
             gbv[c] = on ? ri.gb[c] : 0.0;
         }
-        if (diag && on) {
+        if (diag && on) {      // diagonal pairs only (one in seven): t_l is fetched here, a round later, to keep the register
+                               // footprint of every other chunk at four workgroups per CU
+            const double2* t2 = reinterpret_cast<const double2*>(d.tv + (size_t)slot * 6);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const double2 v = t2[q]; tl[2 * q] = v.x; tl[2 * q + 1] = v.y; }
             const double sl = is_pt ? -1.0 : 1.0;
             const V3 ta = v3(tl[0], tl[1], tl[2]);
             const V3 tb = is_pt ? ta : v3(tl[3], tl[4], tl[5]);
@@ -530,6 +540,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state, ChainV
         }
     }
     __syncthreads();
+    SSTAMP(2);
     const int nred = diag ? 48 : 36;
     if (t < nred) s_in[t] = (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]);
     const int nch = m.nch;
@@ -541,6 +552,10 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state, ChainV
         __syncthreads();
         if (t == 0) s_last = (__hip_atomic_fetch_add(&d.pair_cnt[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nch - 1) ? 1 : 0;
         __syncthreads();
+        SSTAMP(3);
+#ifdef PLBA_STAMPS_LM
+        if (!s_last && t == 0 && (ch == 0 || ch == d.nchunks / 2 || ch == d.nchunks - 1)) { const int o = ch == 0 ? 0 : ch == d.nchunks / 2 ? 8 : 16; for (int q = 0; q < 4; ++q) d.dbgbuf[o + q] = (double)(sts[q] - sts[0]); d.dbgbuf[o + 4] = -1; d.dbgbuf[o + 5] = (double)rt0; d.dbgbuf[o + 6] = (double)(long long)__builtin_amdgcn_s_memrealtime(); }
+#endif
         if (!s_last) return;
         if (t == 0) __hip_atomic_store(&d.pair_cnt[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
         if (t < nred) {
@@ -574,6 +589,11 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state, ChainV
         d.sys[a0] = old0 + v;                          // bschur row / bp row of the augmented system
         if (t >= 42) d.bpg[a1] = old1 + v;             // bp is consumed by the factorisation in sys; computeScale needs it afterwards
     }
+#ifdef PLBA_STAMPS_LM
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SSTAMP(4);
+    if (t == 0 && (ch == 0 || ch == d.nchunks / 2 || ch == d.nchunks - 1)) { const int o = ch == 0 ? 0 : ch == d.nchunks / 2 ? 8 : 16; for (int q = 0; q < 5; ++q) d.dbgbuf[o + q] = (double)(sts[q] - sts[0]); d.dbgbuf[o + 5] = (double)rt0; d.dbgbuf[o + 6] = (double)(long long)__builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 // sys = Himu + Hconst (+ lambda I on the real diagonal, 1 on the padded diagonal) ; row Ppad = row Ppad+1 = pose-side gradient
