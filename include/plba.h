@@ -71,7 +71,11 @@ typedef struct {
                                    factorisation (keyframes a prior edge touches keep theirs dense; needs use_mfma and
                                    factor_block 32, and IMU edges between neighbouring keyframes only: otherwise the
                                    dense path is taken); 0 = dense path on the full system                       (1) */
-    int    reserved[2];
+    int    wide_steps;          /* 1 = a launch of the dense factorisation retires 64 columns: the look-ahead workgroup factors
+                                   the next 64 x 64 diagonal tile as two pipelined 32-column sweeps (factor_block 32 with
+                                   use_mfma, factor_flow 0; experimental: measured slower);
+                                   0 = one launch per 32 columns                                                    (0) */
+    int    reserved[1];
 } plba_options;
 
 void plba_default_options(plba_options* o);

@@ -321,6 +321,7 @@ void orc_default_options(plba_options* o) {
     o->factor_block = 32;
     o->factor_flow = 0;
     o->chain_elim = 1;             /* solver-structure options of the HIP library: ignored here */
+    o->wide_steps = 0;
 }
 const char* orc_backend_name(void) { return "cpu-oracle"; }
 

@@ -56,6 +56,7 @@ void plba_default_options(plba_options* o) {
     o->factor_block = 32;
     o->factor_flow = 0;
     o->chain_elim = 1;
+    o->wide_steps = 0;
 }
 const char* plba_backend_name(void) { return "hip-gfx950"; }
 const char* plba_last_error(const plba_problem* p) { return p ? p->err : g_create_err; }
@@ -282,7 +283,7 @@ int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double
     Ctrl c0; memset(&c0, 0, sizeof c0); c0.solver_ok = 1;
     HIPCK(p, hipMemcpy(ctrl.p, &c0, sizeof c0, hipMemcpyHostToDevice));
     DevBuf d; memset(&d, 0, sizeof d);
-    d.P = n; d.Ppad = Ppad; d.ld = ld; d.sys = sys.p; d.Lfac = Lfac.p; d.x = xx.p; d.ctrl = ctrl.p; d.Linv = Linv.p; d.flow_flags = flags.p; d.LTblk = LT32.p; d.Linv32 = LT32.p; d.rdblk = rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32; d.chol_flags = cflags.p; d.flow = p->opt.factor_flow != 0;
+    d.P = n; d.Ppad = Ppad; d.ld = ld; d.sys = sys.p; d.Lfac = Lfac.p; d.x = xx.p; d.ctrl = ctrl.p; d.Linv = Linv.p; d.flow_flags = flags.p; d.LTblk = LT32.p; d.Linv32 = LT32.p; d.rdblk = rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32; d.chol_flags = cflags.p; d.flow = p->opt.factor_flow != 0; d.wide = p->opt.wide_steps != 0 && !d.flow;
     if (Ppad / 32 <= NINV_MAX_T) { HIPCK(p, Ninv.alloc((size_t)2 * Ppad * ld)); d.Ninv = Ninv.p; d.Nwork = Ninv.p + (size_t)Ppad * ld; }
     launch_cholesky(d, p->opt.use_mfma != 0, 1, p->stream);
     launch_trsv_back(d, p->opt.use_mfma != 0, 1, p->stream);
@@ -475,7 +476,7 @@ static int prepare(plba_problem* p) {
     d.pr_x0off = p->d_pr_x0off.p; d.pr_off = p->d_pr_off.p; d.pr_x0 = p->d_pr_x0.p; d.pr_J0 = p->d_pr_J0.p; d.pr_r0 = p->d_pr_r0.p;
     d.pr_err = p->d_pr_err.p; d.pr_dx = p->d_pr_dx.p; d.pr_chi = p->d_pr_chi.p;
     d.Hconst = p->d_Hconst.p; d.Himu = p->d_Himu.p; d.bimu = p->d_bimu.p; d.Himu_alt = p->d_Himu2.p; d.bimu_alt = p->d_bimu2.p; d.sys = p->d_sys.p; d.Lfac = p->d_Lfac.p; d.bpg = p->d_bpg.p; d.x = p->d_x.p;
-    d.Linv = p->d_Linv.p; d.flow_flags = p->d_flow_flags.p; d.LTblk = p->d_LT32.p; d.Linv32 = p->d_LT32.p; d.rdblk = p->d_rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32; d.chol_flags = p->d_chol_flags.p; d.flow = p->opt.factor_flow != 0;
+    d.Linv = p->d_Linv.p; d.flow_flags = p->d_flow_flags.p; d.LTblk = p->d_LT32.p; d.Linv32 = p->d_LT32.p; d.rdblk = p->d_rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32; d.chol_flags = p->d_chol_flags.p; d.flow = p->opt.factor_flow != 0; d.wide = p->opt.wide_steps != 0 && !d.flow;
     d.chi_part = p->d_chi_part.p; d.scale_part = p->d_scale_part.p; d.maxd_part = p->d_maxd_part.p; d.kfdiag = p->d_kfdiag.p; d.posediag = p->d_posediag.p;
     d.ctrl = p->d_ctrl.p; d.trace = p->d_trace.p; d.trace_cap = TRACE_CAP; d.trace_n = p->d_trace_n.p;
     // ---- chain-variable elimination (plba_chain.hip): index maps and the compact dense system ---------------------------------

@@ -438,6 +438,190 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// 64-column block steps out of the same 32-wide pieces (wide_steps = 1, the default with factor_block 32 + use_mfma).
+// Of the ~21k cycles a 32-wide step costs only ~10k are the pivot sweep; panel products, trailing update, write-out and
+// the kernel boundary are paid per launch.  Here a launch retires 64 columns:
+//   * panel  X = [A(r,k0) A(r,k1)] M^T  with the 64 x 64 inverse  M = [I11 0; I21 I22]  of the diagonal factor
+//     (three 32 x 32 x 32 products per 32-row block, operands straight from global memory),
+//   * trailing update  A(r,c) -= X_r X_c^T  with inner dimension 64,
+//   * workgroup 0 forms X for the two block rows of the NEXT 64 x 64 diagonal tile, updates its three 32 x 32 tiles into
+//     LDS and factors it there as two pipelined sweeps (factor64_lds).
+// Right-hand-side row and identity rows (N = L^-T) ride along exactly as in k_chol32.
+// -------------------------------------------------------------------------------------------------
+constexpr int LX = 66;      // LDS row stride of the 64-wide panels (132 dwords = 4 mod 64: conflict-free operand reads)
+
+struct Wide64Lds {
+    double sX[64 * LX];                 // rows [0,32) = X_r, [32,64) = X_c; after the updates: I11 | I22 | L21 scratch
+    double sD11[32 * LS], sD21[32 * LS], sD22[32 * LS];
+    Look32 S;
+};
+static_assert(64 * LX >= 3 * 32 * LS, "the inverse / L21 scratch of factor64_lds aliases the panel buffer");
+
+// the panel of one 32-row block: x[0..1] = A0 I11^T (columns 0-31), x[2..3] = A0 I21^T + A1 I22^T (columns 32-63);
+// this wave's 16 rows are rows [16 th, 16 th + 16) of the block that starts at `rows`
+__device__ __forceinline__ void panel64(const DevBuf& d, const int K, const double* rows, const int th, const int li, const int lk, const int ident /*0: stored rows, 1: [I 0], 2: [0 I]*/, double4v* x) {
+    const int ld = d.ld, k0 = 2 * K;
+    double a0[8], a1[8], b11[2][8], b21[2][8], b22[2][8];
+    const double2* A0 = reinterpret_cast<const double2*>(rows + (size_t)(th * 16 + li) * ld + k0 * 32 + lk * 8);
+    const double2* A1 = A0 + 16;
+    const double* I11 = d.Linv32 + (size_t)k0 * 1024;
+    const double* I22 = I11 + 1024;
+    const double* I21 = d.Linv + (size_t)K * TILE * TILE + 32 * TILE;     // rows 32-63, columns 0-31 of the 64 x 64 inverse (row stride 64)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const double2 v0 = A0[s], v1 = A1[s];
+        a0[2 * s] = v0.x; a0[2 * s + 1] = v0.y; a1[2 * s] = v1.x; a1[2 * s + 1] = v1.y;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const double2 u11 = reinterpret_cast<const double2*>(I11 + (hh * 16 + li) * 32 + lk * 8)[s];
+            const double2 u21 = reinterpret_cast<const double2*>(I21 + (hh * 16 + li) * TILE + lk * 8)[s];
+            const double2 u22 = reinterpret_cast<const double2*>(I22 + (hh * 16 + li) * 32 + lk * 8)[s];
+            b11[hh][2 * s] = u11.x; b11[hh][2 * s + 1] = u11.y; b21[hh][2 * s] = u21.x; b21[hh][2 * s + 1] = u21.y; b22[hh][2 * s] = u22.x; b22[hh][2 * s + 1] = u22.y;
+        }
+    }
+    if (ident) {      // an identity row block that is entering the factorisation: nothing of it is stored yet
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const double one = (th * 16 + li == lk * 8 + e) ? 1.0 : 0.0;
+            a0[e] = ident == 1 ? one : 0.0; a1[e] = ident == 2 ? one : 0.0;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {     // k index enumerated as 8 * (lane >> 4) + s on both operands
+        x[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b11[0][s], x[0], 0, 0, 0);
+        x[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b11[1][s], x[1], 0, 0, 0);
+        x[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b21[0][s], x[2], 0, 0, 0);
+        x[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s], b21[1][s], x[3], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        x[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], b22[0][s], x[2], 0, 0, 0);
+        x[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], b22[1][s], x[3], 0, 0, 0);
+    }
+}
+// C/D layout -> LDS rows [xrow0 + lk + 4 v] and, if g != null, the finished panel rows in global memory (row stride ld)
+__device__ __forceinline__ void panel64_store(const double4v* x, double* sX, const int xrow0, double* g, const int ld, const int li, const int lk) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sX[(xrow0 + lk + 4 * v) * LX + 16 * q + li] = x[q][v];
+            if (g) g[(size_t)(lk + 4 * v) * ld + 16 * q + li] = x[q][v];
+        }
+}
+
+template <bool AUG>
+__device__ __forceinline__ void chol64_tile(const DevBuf& d, const int K, const int r, const int c, const int aj, const bool diag, Wide64Lds& W, const int wv, const int lane) {
+    const int ld = d.ld, T32 = d.Ppad / 32, c0 = 2 * K + 2;
+    const int li = lane & 15, lk = lane >> 4, p = wv >> 1, th = wv & 1, tr = wv >> 1, tc = wv & 1;
+    const int ident = AUG ? (aj == 2 * K ? 1 : aj == 2 * K + 1 ? 2 : 0) : 0;
+    const double* rowsrc = AUG ? d.Nwork + (size_t)(aj * 32) * ld : d.sys + (size_t)(r * 32) * ld;
+    const bool act = !(p == 1 && diag);
+    const bool have_update = c < T32;
+    double4v x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] = (double4v){0.0, 0.0, 0.0, 0.0};
+    if (act) panel64(d, K, p ? d.sys + (size_t)(c * 32) * ld : rowsrc, th, li, lk, p ? 0 : ident, x);
+    double* C = (AUG ? d.Nwork + (size_t)(aj * 32) * ld : d.sys + (size_t)(r * 32) * ld) + c * 32;
+    double cold[4] = {0.0, 0.0, 0.0, 0.0};
+    if (have_update && !ident) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) cold[v] = C[(size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li];
+    }
+    if (act) {
+        // the finished panel block goes to Lfac / Ninv (never back into sys: other workgroups still read the unsolved panel)
+        double* g = nullptr;
+        if (p == 0 && c == c0) g = (AUG ? d.Ninv + (size_t)(aj * 32) * ld : d.Lfac + (size_t)(r * 32) * ld) + (size_t)(th * 16) * ld + 2 * K * 32;
+        panel64_store(x, W.sX, p * 32 + th * 16, g, ld, li, lk);
+    }
+    if (!have_update) return;
+    __syncthreads();
+    const int cb = diag ? 0 : 32;
+    double4v acc = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W.sX[(tr * 16 + li) * LX + kk * 4 + lk], W.sX[(cb + tc * 16 + li) * LX + kk * 4 + lk], acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) C[(size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li] = cold[v] - acc[v];
+}
+
+// workgroup 0 of block step K: the next 64 x 64 diagonal tile (32-blocks a = 2K+2, b = a+1)
+__device__ __forceinline__ void chol64_lookahead(const DevBuf& d, const int K, Wide64Lds& W, const int wv, const int lane) {
+    const int ld = d.ld, a = 2 * K + 2, b = a + 1;
+    const int li = lane & 15, lk = lane >> 4, p = wv >> 1, th = wv & 1, tr = wv >> 1, tc = wv & 1;
+    double4v x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] = (double4v){0.0, 0.0, 0.0, 0.0};
+    // rows [0,32) of sX = X_b, rows [32,64) = X_a; both are finished panel blocks of L
+    panel64(d, K, d.sys + (size_t)((p ? a : b) * 32) * ld, th, li, lk, 0, x);
+    double caa[4], cba[4], cbb[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const size_t rr = (size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li;
+        caa[v] = d.sys[(size_t)(a * 32) * ld + a * 32 + rr];
+        cba[v] = d.sys[(size_t)(b * 32) * ld + a * 32 + rr];
+        cbb[v] = d.sys[(size_t)(b * 32) * ld + b * 32 + rr];
+    }
+    panel64_store(x, W.sX, p * 32 + th * 16, d.Lfac + (size_t)((p ? a : b) * 32 + th * 16) * ld + 2 * K * 32, ld, li, lk);
+    __syncthreads();
+    double4v maa = (double4v){0.0, 0.0, 0.0, 0.0}, mba = maa, mbb = maa;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const double xa_r = W.sX[(32 + tr * 16 + li) * LX + kk * 4 + lk], xa_c = W.sX[(32 + tc * 16 + li) * LX + kk * 4 + lk];
+        const double xb_r = W.sX[(tr * 16 + li) * LX + kk * 4 + lk], xb_c = W.sX[(tc * 16 + li) * LX + kk * 4 + lk];
+        maa = __builtin_amdgcn_mfma_f64_16x16x4f64(xa_r, xa_c, maa, 0, 0, 0);
+        mba = __builtin_amdgcn_mfma_f64_16x16x4f64(xb_r, xa_c, mba, 0, 0, 0);
+        mbb = __builtin_amdgcn_mfma_f64_16x16x4f64(xb_r, xb_c, mbb, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int o = (tr * 16 + lk + 4 * v) * LS + tc * 16 + li;
+        W.sD11[o] = caa[v] - maa[v]; W.sD21[o] = cba[v] - mba[v]; W.sD22[o] = cbb[v] - mbb[v];
+    }
+    __syncthreads();      // tiles complete; the panel buffer is free for the factorisation's scratch
+    factor64_lds(d, a, W.sD11, W.sD21, W.sD22, W.S, W.sX, W.sX + 32 * LS, W.sX + 64 * LS, wv, lane);
+}
+
+__global__ __launch_bounds__(256) void k_potrf0_64(DevBuf d) {
+    __shared__ __attribute__((aligned(16))) Wide64Lds W;
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+        const int rw = idx >> 5, cl = idx & 31;
+        W.sD11[rw * LS + cl] = d.sys[(size_t)rw * d.ld + cl];
+        W.sD21[rw * LS + cl] = d.sys[(size_t)(32 + rw) * d.ld + cl];
+        W.sD22[rw * LS + cl] = d.sys[(size_t)(32 + rw) * d.ld + 32 + cl];
+    }
+    __syncthreads();
+    factor64_lds(d, 0, W.sD11, W.sD21, W.sD22, W.S, W.sX, W.sX + 32 * LS, W.sX + 64 * LS, threadIdx.x >> 6, threadIdx.x & 63);
+}
+
+__global__ __launch_bounds__(256) void k_chol64(DevBuf d, int K) {
+    __shared__ __attribute__((aligned(16))) Wide64Lds W;
+    const int T32 = d.Ppad / 32, c0 = 2 * K + 2, nt = T32 - c0, ntri = nt * (nt + 1) / 2;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int bi = blockIdx.x;
+    if (nt > 0) {
+        if (bi == 0) { chol64_lookahead(d, K, W, wv, lane); return; }
+        bi -= 1;
+        if (bi < ntri - 3) {                 // lower-triangular tiles in row-major order; the first three belong to workgroup 0
+            const int b = bi + 3;
+            int rr = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
+            while ((rr + 1) * (rr + 2) / 2 <= b) ++rr;
+            while (rr * (rr + 1) / 2 > b) --rr;
+            const int cc = b - rr * (rr + 1) / 2;
+            chol64_tile<false>(d, K, c0 + rr, c0 + cc, 0, rr == cc, W, wv, lane);
+        } else if (bi < ntri - 3 + nt) {     // right-hand-side row
+            chol64_tile<false>(d, K, T32, c0 + (bi - (ntri - 3)), 0, false, W, wv, lane);
+        } else {                             // identity rows (launched when d.Ninv is set)
+            const int e = bi - (ntri - 3 + nt);
+            chol64_tile<true>(d, K, T32, c0 + e % nt, e / nt, false, W, wv, lane);
+        }
+    } else {                                 // last step: only the panels of the right-hand side and of the identity rows
+        if (bi == 0) chol64_tile<false>(d, K, T32, T32, 0, true, W, wv, lane);
+        else chol64_tile<true>(d, K, T32, T32, bi - 1, true, W, wv, lane);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Single-launch dataflow factorisation (factor_flow = 1; experimental, NOT the default): the whole LL^T in ONE kernel.
 // Measured on MI355X at P = 735: the chain step itself drops to ~16k cycles (from 21.7k with a launch per step), but
 // the two tiles the next step needs arrive through three cross-workgroup hops of ~10k cycles each (sc1 store drain,
@@ -806,6 +990,17 @@ void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s, b
         const int T = d.Ppad / 32;
         const int tiles = (T + 1) * (T + 2) / 2 - 1;        // sum_{c<T} (T - c + 1): rows c..T of every column
         hipLaunchKernelGGL(k_chol_flow, dim3(1 + tiles), dim3(FLOW_THREADS), 0, s, d, T, epoch);
+        return;
+    }
+    if (inverse_panels(d, use_mfma) && d.wide) {
+        const int T32 = d.Ppad / 32, T64 = d.Ppad / TILE;
+        hipLaunchKernelGGL(k_potrf0_64, dim3(1), dim3(256), 0, s, d);
+        for (int K = 0; K < T64; ++K) {
+            const int nt = T32 - (2 * K + 2);
+            const int normal = nt > 0 ? 1 + (nt * (nt + 1) / 2 - 3) + nt : 1;
+            const int aug = d.Ninv ? (2 * K + 2) * (nt > 0 ? nt : 1) : 0;
+            hipLaunchKernelGGL(k_chol64, dim3(normal + aug), dim3(256), 0, s, d, K);
+        }
         return;
     }
     if (inverse_panels(d, use_mfma)) {

@@ -187,7 +187,8 @@ __device__ __forceinline__ void fetch_next_tiles(NextTiles& n, int lane);
 
 // FLOW: called from the single-launch dataflow factorisation: global results go out with sc1 stores, L^-1 is also
 // left in LDS (sLinv, row stride LS) for the same workgroup's next step, and wave 2 prefetches `next`.
-template <bool FLOW>
+// KEEP: L^-1 is also left in LDS (sLinv, row stride LS) for the same workgroup's next stage.
+template <bool FLOW, bool KEEP = FLOW>
 __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, const double* sC, Look32& S, int wv, int lane, double* sLinv = nullptr,
                                                    NextTiles* next = nullptr) {
     const int li = lane & 15, lk = lane >> 4;
@@ -262,7 +263,7 @@ __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, cons
             const int idx = e * 64 + lane, rw = idx >> 5, cl = idx & 31;
             const double v = (cl < 16) ? S.sInv[rw * LS + cl] * S.rs[rw] : 0.0;
             gput<FLOW>(&Ig[idx], v);
-            if (FLOW) sLinv[rw * LS + cl] = v;
+            if (KEEP) sLinv[rw * LS + cl] = v;
         }
         {   // columns 0-15 of L (all rows) and the zero block above the diagonal
             double* Lg = d.Lfac + (size_t)(kb * 32) * d.ld + kb * 32;
@@ -294,14 +295,14 @@ __device__ __forceinline__ void lookahead_factor32(const DevBuf& d, int kb, cons
         for (int v = 0; v < 4; ++v) {
             const double val = -w[v] * S.rs[16 + lk + 4 * v];
             gput<FLOW>(&Ig[(16 + lk + 4 * v) * 32 + li], val);
-            if (FLOW) sLinv[(16 + lk + 4 * v) * LS + li] = val;
+            if (KEEP) sLinv[(16 + lk + 4 * v) * LS + li] = val;
         }
         if (lane < 16) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const double val = x[t] * S.rs[16 + t];
                 gput<FLOW>(&Ig[(16 + t) * 32 + 16 + li], val);
-                if (FLOW) sLinv[(16 + t) * LS + 16 + li] = val;
+                if (KEEP) sLinv[(16 + t) * LS + 16 + li] = val;
             }
         }
         LSTAMP(14);
@@ -322,6 +323,67 @@ __device__ __forceinline__ void fetch_next_tiles(NextTiles& n, int lane) {
 __device__ __forceinline__ void look32_reset(Look32& S, int tid) {
     if (tid < 32) { S.pivd[tid] = piv_empty(); S.rsflag[tid] = 0; }
     if (tid == 32) { S.mflag = 0; S.fail = 0; }
+}
+
+// The 64 x 64 diagonal tile [D11 .; D21 D22] (three 32 x 32 tiles in LDS, row stride LS) factored by one workgroup as two
+// pipelined 32-column sweeps, everything in between staying in LDS:
+//     L11, I11 = L11^-1  (sweep 1)    L21 = D21 I11^T    D22 -= L21 L21^T    L22, I22  (sweep 2)    I21 = -I22 L21 I11
+// L -> d.Lfac tiles (kb,kb), (kb+1,kb), (kb+1,kb+1);  I11, I22 -> d.Linv32[kb], [kb+1];  I21 -> its place in the 64 x 64
+// inverse d.Linv[kb / 2].  sI11 / sI22 / sL21: 32 x LS scratch each; sD21 is overwritten (L21 I11).  All 256 threads
+// enter; the tiles must be complete and visible (barrier) on entry.  This is what lets a block step of the factorisation
+// cover 64 columns: the per-launch costs (panel products, trailing update, write-out, kernel boundary) are paid once
+// per two pivot sweeps.
+__device__ __forceinline__ void factor64_lds(const DevBuf& d, const int kb, double* sD11, double* sD21, double* sD22, Look32& S,
+                                             double* sI11, double* sI22, double* sL21, const int wv, const int lane) {
+    const int li = lane & 15, lk = lane >> 4, tr = wv >> 1, tc = wv & 1;
+    // one copy of the sweep's code for both halves (it is long and fully unrolled: two inlined copies would not share
+    // the instruction cache)
+#pragma nounroll
+    for (int half = 0; half < 2; ++half) {
+        if (half == 1) {
+            {   // L21 = D21 I11^T
+                double4v m = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) m = __builtin_amdgcn_mfma_f64_16x16x4f64(sD21[(tr * 16 + li) * LS + kk * 4 + lk], sI11[(tc * 16 + li) * LS + kk * 4 + lk], m, 0, 0, 0);
+                double* Lg = d.Lfac + (size_t)((kb + 1) * 32) * d.ld + kb * 32;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = tr * 16 + lk + 4 * v, col = tc * 16 + li;
+                    sL21[row * LS + col] = m[v];
+                    Lg[(size_t)row * d.ld + col] = m[v];
+                }
+            }
+            __syncthreads();
+            {   // D22 -= L21 L21^T
+                double4v m = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) m = __builtin_amdgcn_mfma_f64_16x16x4f64(sL21[(tr * 16 + li) * LS + kk * 4 + lk], sL21[(tc * 16 + li) * LS + kk * 4 + lk], m, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sD22[(tr * 16 + lk + 4 * v) * LS + tc * 16 + li] -= m[v];
+            }
+        }
+        look32_reset(S, threadIdx.x);
+        __syncthreads();
+        lookahead_factor32<false, true>(d, kb + half, half ? sD22 : sD11, S, wv, lane, half ? sI22 : sI11);
+        __syncthreads();
+    }
+    double* sT = sD21;
+    {   // T = L21 I11
+        double4v m = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) m = __builtin_amdgcn_mfma_f64_16x16x4f64(sL21[(tr * 16 + li) * LS + kk * 4 + lk], sI11[(kk * 4 + lk) * LS + tc * 16 + li], m, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sT[(tr * 16 + lk + 4 * v) * LS + tc * 16 + li] = m[v];
+    }
+    __syncthreads();
+    {   // I21 = -I22 T
+        double4v m = (double4v){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) m = __builtin_amdgcn_mfma_f64_16x16x4f64(sI22[(tr * 16 + li) * LS + kk * 4 + lk], sT[(kk * 4 + lk) * LS + tc * 16 + li], m, 0, 0, 0);
+        double* Ig = d.Linv + (size_t)(kb >> 1) * TILE * TILE + 32 * TILE;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Ig[(tr * 16 + lk + 4 * v) * TILE + tc * 16 + li] = -m[v];
+    }
 }
 
 }  // namespace plba

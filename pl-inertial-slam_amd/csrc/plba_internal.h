@@ -98,6 +98,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     int* chol_flags;       // (T32 + 1) x T32 tile flags + T32 inverse flags of the single-launch factorisation (epoch-stamped)
     double* dbgbuf;        // 64 doubles for diagnostic builds (cycle stamps)
     int flow;              // 1: single-launch dataflow factorisation (k_chol_flow), 0: one launch per block step
+    int wide;              // 1: a launch retires 64 columns (two pipelined 32-column sweeps in the look-ahead workgroup, k_chol64)
     // reductions / control
     double *chi_part, *scale_part, *maxd_part, *kfdiag, *posediag;
     Ctrl* ctrl;

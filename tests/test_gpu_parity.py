@@ -38,12 +38,14 @@ def test_backend_is_the_hip_library(hip):
 
 
 @pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 200, 750])
-@pytest.mark.parametrize("mfma,fb,flow", [(1, 32, 0), (1, 32, 1), (0, 32, 0), (1, 64, 0), (0, 64, 0)])
-def test_dense_solver_vs_numpy(pkg, hip, n, mfma, fb, flow):
+@pytest.mark.parametrize("mfma,fb,flow,wide", [(1, 32, 0, 1), (1, 32, 0, 0), (1, 32, 1, 0), (0, 32, 0, 0), (1, 64, 0, 0), (0, 64, 0, 0)])
+def test_dense_solver_vs_numpy(pkg, hip, n, mfma, fb, flow, wide):
+    """wide = 0 (default): one launch per 32 columns; wide = 1: 64 columns per launch (two pipelined 32-column sweeps in the
+    look-ahead workgroup); flow = 1: the single-launch dataflow factorisation; mfma = 0 / fb = 64: the VALU check paths"""
     rng = np.random.default_rng(n)
     A = rng.normal(size=(n, n)); A = A @ A.T + n * np.eye(n)
     b = rng.normal(size=n)
-    p = pkg.new_problem(use_mfma=mfma, factor_block=fb, factor_flow=flow)
+    p = pkg.new_problem(use_mfma=mfma, factor_block=fb, factor_flow=flow, wide_steps=wide)
     x, ok = p.debug_dense_solve(A, b)
     assert ok
     _close(x, np.linalg.solve(A, b), 1e-9, "x")
