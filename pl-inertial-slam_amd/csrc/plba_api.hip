@@ -416,20 +416,39 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_tv.alloc((size_t)L * 6)); HIPCK(p, p->d_xl.alloc((size_t)L * 6));
     HIPCK(p, p->d_off_pvr.upload(p->off_pvr)); HIPCK(p, p->d_off_bias.upload(p->off_bias));
     // chunks of at most 256 entries per pair (contiguous, in pair order)
-    std::vector<ChunkMeta> ch_meta;
+    std::vector<ChunkMeta> ch_pm;          // pair-major order (slot = index): the layout of the partial sums
     for (size_t q = 0; q < pair_i.size(); ++q) {
-        const int32_t ch0 = (int32_t)ch_meta.size();
+        const int32_t ch0 = (int32_t)ch_pm.size();
         const int32_t nchq = (pair_start[q + 1] - pair_start[q] + SCHUR_CHUNK - 1) / SCHUR_CHUNK;
         for (int32_t s0 = pair_start[q]; s0 < pair_start[q + 1]; s0 += SCHUR_CHUNK) {
             ChunkMeta m;
-            m.pair = (int32_t)q; m.start = s0; m.end = std::min(s0 + SCHUR_CHUNK, pair_start[q + 1]);
+            m.slot = (int32_t)ch_pm.size(); m.start = s0; m.end = std::min(s0 + SCHUR_CHUNK, pair_start[q + 1]);
             m.ij = pair_i[q] | (pair_j[q] << 16); m.nch = nchq; m.ch0 = ch0;
             m.oi = p->off_pvr[pair_i[q]]; m.oj = p->off_pvr[pair_j[q]];
-            ch_meta.push_back(m);
+            ch_pm.push_back(m);
         }
     }
+    // Launch order: XCD-aware.  Workgroups are dealt round-robin over the XCDs (each with its own 4 MiB L2), and a chunk
+    // gathers the records of its two keyframes: the pairs (sorted by first keyframe) are cut into SCHUR_XCD runs of
+    // equal chunk count, and run x supplies the chunks at launch positions = x (mod SCHUR_XCD), so the records of a
+    // keyframe range are fetched into ONE L2 and re-used by all the pairs that touch them (speed only).
+    std::vector<ChunkMeta> ch_meta;
+    {
+        const size_t n = ch_pm.size();
+        std::vector<size_t> lo(SCHUR_XCD + 1, n);
+        lo[0] = 0;
+        for (int x = 1; x < SCHUR_XCD; ++x) {
+            size_t cut = std::min(n, (n * x + SCHUR_XCD - 1) / SCHUR_XCD);
+            while (cut < n && cut > 0 && ch_pm[cut].ch0 != ch_pm[cut].slot) ++cut;      // cut between pairs
+            lo[x] = std::max(cut, lo[x - 1]);
+        }
+        ch_meta.reserve(n);
+        for (size_t q = 0; ch_meta.size() < n; ++q)
+            for (int x = 0; x < SCHUR_XCD; ++x)
+                if (lo[x] + q < lo[x + 1]) ch_meta.push_back(ch_pm[lo[x] + q]);
+    }
     HIPCK(p, p->d_ch_meta.upload(ch_meta));
-    HIPCK(p, p->d_schur_part.alloc(ch_meta.size() * 48)); HIPCK(p, p->d_pair_cnt.alloc(pair_i.size()));
+    HIPCK(p, p->d_schur_part.alloc(ch_meta.size() * 48)); HIPCK(p, p->d_pair_cnt.alloc(ch_meta.size()));
     HIPCK(p, p->d_pair_i.upload(pair_i)); HIPCK(p, p->d_pair_j.upload(pair_j)); HIPCK(p, p->d_pair_start.upload(pair_start));
     HIPCK(p, p->d_ent_pi.upload(ent_ei)); HIPCK(p, p->d_ent_pj.upload(ent_ej)); HIPCK(p, p->d_ent_slot.upload(ent_slot)); HIPCK(p, p->d_ob_pos.upload(p->ob_pos));
     HIPCK(p, p->d_imu_i.upload(p->imu_i)); HIPCK(p, p->d_imu_j.upload(p->imu_j)); HIPCK(p, p->d_imu_pre.upload(p->imu_pre));

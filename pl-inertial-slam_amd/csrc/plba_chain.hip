@@ -34,7 +34,10 @@
 
 namespace plba {
 
-__global__ __launch_bounds__(ELIM_THREADS) void k_chain_elim(DevBuf d, ChainView cv) { chain_elim_segment(d, cv, blockIdx.x); }
+__global__ __launch_bounds__(ELIM_THREADS) void k_chain_elim(DevBuf d, ChainView cv) {
+    __shared__ __attribute__((aligned(16))) ChainElimLds LDS;
+    chain_elim_segment(d, cv, blockIdx.x, LDS);
+}
 
 // dd.sys tile (ta, tb), ta >= tb, of the dense system  A - W_B^T W_B  (32 x 32, matrix cores); the tiles of block row
 // ta == Pdpad / 32 carry the right-hand side  b_d - W_B^T w_b  in their first row.  Only the rows of W that belong to

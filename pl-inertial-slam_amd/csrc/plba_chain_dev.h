@@ -33,13 +33,17 @@ using namespace chain_detail;
 
 // one segment (workgroup of ELIM_THREADS threads); g = segment index.  Called from k_chain_elim and, on one GPU, from the
 // leading workgroups of the Schur-pair launch (the two are independent: chain blocks carry no landmark coupling).
-__device__ __forceinline__ void chain_elim_segment(const DevBuf& d, const ChainView& cv, const int g) {
-    __shared__ __attribute__((aligned(16))) double sLsub[SEGMAX][90], sLinv[SEGMAX][90];   // published chain factors; rows of 9 padded to 10: aligned pairs
-    __shared__ double sA[81];
-    __shared__ double sCg[SEGMAX][162];                 // C_ii (81) | C_{i+1,i} (81)
-    __shared__ double sBg[SEGMAX][3 * NSLOT * 9];       // B_i against the dense columns of positions p-1, p, p+1
-    __shared__ double sRhs[SEGMAX][9];
-    __shared__ int s_step, s_bad;
+struct ChainElimLds {          // LDS of one segment's elimination (a struct so that a host kernel can overlay it with its own)
+    double sLsub[SEGMAX][90], sLinv[SEGMAX][90];   // published chain factors; rows of 9 padded to 10: aligned pairs
+    double sCg[SEGMAX][162];                       // C_ii (81) | C_{i+1,i} (81)
+    double sBg[SEGMAX][3 * NSLOT * 9];             // B_i against the dense columns of positions p-1, p, p+1
+    double sRhs[SEGMAX][9];
+    double sA[81];
+    int s_step, s_bad;
+};
+__device__ __forceinline__ void chain_elim_segment(const DevBuf& d, const ChainView& cv, const int g, ChainElimLds& LDS) {
+    auto& sLsub = LDS.sLsub; auto& sLinv = LDS.sLinv; auto& sCg = LDS.sCg; auto& sBg = LDS.sBg; auto& sRhs = LDS.sRhs; auto& sA = LDS.sA;
+    int& s_step = LDS.s_step; int& s_bad = LDS.s_bad;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ld = d.ld;
     const int i0 = cv.seg_start[g], i1 = cv.seg_start[g + 1], n = i1 - i0;      // eliminated blocks of this segment

@@ -40,7 +40,7 @@ struct Mailbox {
 };
 
 // one chunk (<= 256 entries) of a keyframe pair's entry list: everything k_schur_pairs needs to know up front, 32 bytes
-struct ChunkMeta { int32_t pair, start, end, ij /* i | j << 16 */, nch, ch0 /* the pair's chunks */, oi, oj /* kf_off_pvr of i, j */; };
+struct ChunkMeta { int32_t slot /* index in pair-major order: where its partial sums go */, start, end, ij /* i | j << 16 */, nch, ch0 /* the pair's chunks: slots [ch0, ch0 + nch) */, oi, oj /* kf_off_pvr of i, j */; };
 
 struct ChainView;
 struct DevBuf {  // trivially-copyable view of device pointers passed to kernels by value
@@ -74,7 +74,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     const int32_t *pair_i, *pair_j, *pair_start, *ent_pi, *ent_pj, *ent_slot;   // entries: record positions + landmark slot
     const ChunkMeta* ch_meta;                                                   // <= 256-entry chunks of the pair lists (k_schur_pairs)
     double* schur_part;    // nchunks x 48 partial sums
-    int* pair_cnt;         // arrival counters, zero between launches
+    int* pair_cnt;         // arrival counters (indexed by a pair's first chunk slot), zero between launches
     // IMU
     const int32_t *imu_i, *imu_j;
     const double *imu_pre, *imu_info_pvr, *imu_info_bias;
@@ -122,6 +122,7 @@ void launch_kfdiag(const DevBuf& d, int state, hipStream_t s);
 void launch_landmark_dinv(const DevBuf& d, hipStream_t s);
 void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s);
 void launch_schur_pairs(const DevBuf& d, int state, const ChainView* lead /* chain segments riding in front, or null */, hipStream_t s);
+constexpr int SCHUR_XCD = 8;     // chunk order and lead padding assume workgroups are dealt round-robin over this many XCDs (speed only)
 void launch_backsub(const DevBuf& d, int cur, int trial, const ChainView* lead /* chain back-substitution riding in front, or null */, const double* xd /* dense solution (dd.x) */, hipStream_t s);
 void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s);
 // red[0] = activeRobustChi2 (local), red[1] = landmark part of computeScale (local), red[2] = max |Hll_jj| (local)

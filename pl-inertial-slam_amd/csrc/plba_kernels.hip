@@ -411,15 +411,21 @@ __global__ __launch_bounds__(256) void k_kfdiag(DevBuf d, int state) {
 // Dependent memory round trips are what this kernel costs, so it is laid out as three of them: (1) one 32-byte chunk
 // descriptor (scalar), (2) the entry's indices | the two keyframe states, (3) both 128-byte records, D_l, t_l and the
 // old values of the output block — all issued before the staged camera blocks are needed; the arithmetic follows.
+struct SchurLds {
+    double s_red[4][48];
+    double s_in[48], s_tmp[36];
+    double s_kc[2 * KFCAM_STRIDE];
+    double stA[4][32 * 12];       // per wave: [entry][ga(6) | gb(6)] of half a wave's entries (operand staging of the reduction)
+    double stB[4][32 * 16];       // per wave: [entry][T0(6), -f0, -e0 | T1(6), -f1, -e1]
+    int s_last;
+};
 // The first `nlead` workgroups eliminate one segment of the velocity / bias chain each instead (plba_chain_dev.h): that work
 // only needs the assembled pose-side system, so on one GPU it runs in the shadow of the pair pass.
-__global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state, ChainView cv, int nlead) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_schur_pairs(DevBuf d, int state, ChainView cv, int nlead) {      // 3 workgroups per CU: what the 49 KB of LDS allow
     static_assert(ELIM_THREADS == 256, "the chain segments ride in this launch");
-    if ((int)blockIdx.x < nlead) { chain_elim_segment(d, cv, blockIdx.x); return; }
-    __shared__ double s_red[4][48];
-    __shared__ double s_in[48], s_tmp[36];
-    __shared__ double s_kc[2 * KFCAM_STRIDE];
-    __shared__ int s_last;
+    __shared__ __attribute__((aligned(16))) union { ChainElimLds ce; SchurLds sp; } lds;      // a workgroup is one or the other
+    if ((int)blockIdx.x < nlead) { if ((int)blockIdx.x < cv.nseg) chain_elim_segment(d, cv, blockIdx.x, lds.ce); return; }     // nlead = nseg rounded up to the XCD count
+    auto& s_red = lds.sp.s_red; auto& s_in = lds.sp.s_in; auto& s_tmp = lds.sp.s_tmp; auto& s_kc = lds.sp.s_kc; int& s_last = lds.sp.s_last;
     const int ch = blockIdx.x - nlead;
 #ifdef PLBA_STAMPS_LM
     unsigned long long sts[6] = {0,0,0,0,0,0}; sts[0] = __builtin_readcyclecounter(); const long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state, ChainV
 #define SSTAMP(i) do {} while (0)
 #endif
     const ChunkMeta m = d.ch_meta[ch];
-    const int p = m.pair, i = m.ij & 0xffff, j = (m.ij >> 16) & 0xffff;
+    const int p = m.ch0, i = m.ij & 0xffff, j = (m.ij >> 16) & 0xffff;      // p: the pair's arrival counter
     const bool diag = (i == j);
     const int t = threadIdx.x;
     const int n = m.start + t;
@@ -523,20 +529,53 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state, ChainV
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // The 36 (+12) sums over the wave's entries are ONE small matrix product,  G (16 x 2n) * B (2n x 16)  with
+    //   G[r][2e + s] = (s ? gb : ga)_e[r]  (r < 6),     B[2e + s][c] = (s ? T1 : T0)_e[c]  (c < 6),  -f_s (c = 6),  -e_s (c = 7),
+    // so the matrix cores add them up (v_mfma_f64_16x16x4_f64, four k-columns = two entries per instruction) instead of
+    // 48 six-step DPP reductions: the factors go through LDS once (half a wave at a time), ~200 instructions in place of
+    // ~900, which is what this kernel was issuing when its gathers were not the bottleneck.  Fixed order: deterministic.
+    typedef double double4v __attribute__((ext_vector_type(4)));
+    double4v accE = (double4v){0.0, 0.0, 0.0, 0.0}, accO = accE;
+    {
+        const int li = lane & 15, lk = lane >> 4;
+        double* stA = lds.sp.stA[wv];
+        double* stB = lds.sp.stB[wv];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
+        for (int hb = 0; hb < 2; ++hb) {
+            if ((lane >> 5) == hb) {
+                double2* pa = reinterpret_cast<double2*>(stA + (lane & 31) * 12);
+                double2* pb = reinterpret_cast<double2*>(stB + (lane & 31) * 16);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const double v = wave_sum_dpp(ga[r] * T0[c] + gbv[r] * T1[c]);
-            if (lane == 63) s_red[wv][r * 6 + c] = v;
+                for (int q = 0; q < 3; ++q) { pa[q] = make_double2(ga[2 * q], ga[2 * q + 1]); pa[3 + q] = make_double2(gbv[2 * q], gbv[2 * q + 1]); }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { pb[q] = make_double2(T0[2 * q], T0[2 * q + 1]); pb[4 + q] = make_double2(T1[2 * q], T1[2 * q + 1]); }
+                pb[3] = make_double2(-f0, -e0); pb[7] = make_double2(-f1, -e1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+            for (int m = 0; m < 16; ++m) {      // k = 4 m + lk: entry 2 m + (lk >> 1) of this half, factor pair s = lk & 1
+                const int eb = 2 * m + (lk >> 1), sp = lk & 1;
+                const double av = stA[eb * 12 + sp * 6 + (li < 6 ? li : 0)];
+                const double bv = stB[eb * 16 + sp * 8 + (li < 8 ? li : 0)];
+                if (m & 1) accO = __builtin_amdgcn_mfma_f64_16x16x4f64(li < 6 ? av : 0.0, li < 8 ? bv : 0.0, accO, 0, 0, 0);
+                else accE = __builtin_amdgcn_mfma_f64_16x16x4f64(li < 6 ? av : 0.0, li < 8 ? bv : 0.0, accE, 0, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-    }
-    if (diag) {
+        // C/D layout: column = lane & 15, row = (lane >> 4) + 4 v.  Rows 0-5 x columns 0-5: the block; column 6: bschur part; 7: bp part
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const double v = wave_sum_dpp(-(ga[q] * f0 + gbv[q] * f1));
-            const double u = wave_sum_dpp(-(ga[q] * e0 + gbv[q] * e1));
-            if (lane == 63) { s_red[wv][36 + q] = v; s_red[wv][42 + q] = u; }
+        for (int v = 0; v < 2; ++v) {
+            const int r = lk + 4 * v;
+            const double val = accE[v] + accO[v];
+            if (r < 6) {
+                if (li < 6) s_red[wv][r * 6 + li] = val;
+                else if (li == 6) s_red[wv][36 + r] = val;
+                else if (li == 7) s_red[wv][42 + r] = val;
+            }
         }
     }
     __syncthreads();
@@ -546,7 +585,7 @@ __global__ __launch_bounds__(256) void k_schur_pairs(DevBuf d, int state, ChainV
     const int nch = m.nch;
     if (nch > 1) {
         // publish this chunk's partial sums (sc1, drained), count arrivals; the last chunk folds them in chunk order
-        double* part = d.schur_part + (size_t)ch * 48;
+        double* part = d.schur_part + (size_t)m.slot * 48;
         if (t < nred) __hip_atomic_store(&part[t], s_in[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1294,7 +1333,7 @@ void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s) {
     hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(256), 0, s, d, add_lambda ? 1 : 0);
 }
 void launch_schur_pairs(const DevBuf& d, int state, const ChainView* lead, hipStream_t s) {
-    const int nlead = lead ? lead->nseg : 0;
+    const int nlead = lead ? (lead->nseg + SCHUR_XCD - 1) / SCHUR_XCD * SCHUR_XCD : 0;      // keeps chunk index = block index (mod XCD count)
     if (d.nchunks + nlead) hipLaunchKernelGGL(k_schur_pairs, dim3(d.nchunks + nlead), dim3(256), 0, s, d, state, lead ? *lead : ChainView{}, nlead);
 }
 void launch_backsub(const DevBuf& d, int cur, int trial, const ChainView* lead, const double* xd, hipStream_t s) {
