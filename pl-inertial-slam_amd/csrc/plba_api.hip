@@ -488,6 +488,7 @@ static int prepare(plba_problem* p) {
     d.pair_i = p->d_pair_i.p; d.pair_j = p->d_pair_j.p; d.pair_start = p->d_pair_start.p; d.ent_pi = p->d_ent_pi.p; d.ent_pj = p->d_ent_pj.p; d.ent_slot = p->d_ent_slot.p; d.ob_pos = p->d_ob_pos.p;
     d.ch_meta = p->d_ch_meta.p;
     d.schur_part = p->d_schur_part.p; d.pair_cnt = p->d_pair_cnt.p;
+    HIPCK(p, p->d_trial_cnt.alloc(1)); d.trial_cnt = p->d_trial_cnt.p;
     d.imu_i = p->d_imu_i.p; d.imu_j = p->d_imu_j.p; d.imu_pre = p->d_imu_pre.p; d.imu_info_pvr = p->d_imu_ipvr.p; d.imu_info_bias = p->d_imu_ibias.p;
     d.imu_err = p->d_imu_err.p; d.imu_chi = p->d_imu_chi.p;
     d.pr_n = p->pr_n; d.pr_nv = p->pr_nv;
@@ -787,14 +788,17 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
         do {
             if ((rc = enqueue_solve(p, true, it == 0 || qmax > 0))) return rc;
             const int trial = p->cur ^ 1;
-            launch_linearize(d, trial, false, p->rob, owns_pose_edges(p), s);
+            const unsigned long long seq = ++p->mail_seq;
+            // one GPU: the workgroup of the trial-error launch that finishes last takes the LM decision (no k_decide launch)
+            const bool decide_rides = p->world <= 1 && p->opt.profile < 2;
+            DecideFusion df{lp, p->d_red.p, p->d_mail, seq};
+            launch_linearize(d, trial, false, p->rob, owns_pose_edges(p), s, false, decide_rides ? &df : nullptr);
             MARK(p, 9);
             if (p->world > 1) {
                 launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
                 if ((rc = exchange(p, p->d_red.p, 2, 0))) return rc;
             }
-            const unsigned long long seq = ++p->mail_seq;
-            launch_decide(d, lp, p->d_red.p, p->world <= 1, p->d_mail, seq, s);
+            if (!decide_rides) launch_decide(d, lp, p->d_red.p, p->world <= 1, p->d_mail, seq, s);
             MARK(p, 10);
             // The next iteration's linearisation goes out NOW, gated on the decision k_decide leaves in the device control
             // block: if the step was accepted it linearises the trial state (into the accumulators that are swapped in

@@ -75,6 +75,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     const ChunkMeta* ch_meta;                                                   // <= 256-entry chunks of the pair lists (k_schur_pairs)
     double* schur_part;    // nchunks x 48 partial sums
     int* pair_cnt;         // arrival counters (indexed by a pair's first chunk slot), zero between launches
+    int* trial_cnt;        // arrival counter of the trial-error launch's workgroups (the last one decides), zero between launches
     // IMU
     const int32_t *imu_i, *imu_j;
     const double *imu_pre, *imu_info_pvr, *imu_info_bias;
@@ -115,7 +116,10 @@ struct Robust { int on[5]; double delta[5]; };
 namespace plba {
 struct LmParams { double tau, lower, upper, user_lambda; int max_trials; };
 
-void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s, bool spec = false);   // spec: gated on the device-side LM decision
+struct Mailbox;
+struct DecideFusion { LmParams lp; double* red; Mailbox* mail; unsigned long long seq; };     // the LM decision taken by the last workgroup of the trial-error launch
+void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s, bool spec = false, const DecideFusion* df = nullptr);
+                                                                        // spec: gated on the device-side LM decision; df: errors-only pass that also decides
 void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, bool owns_pose_edges, hipStream_t s);
 bool launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv_assemble, bool add_lambda, hipStream_t s);
 void launch_kfdiag(const DevBuf& d, int state, hipStream_t s);

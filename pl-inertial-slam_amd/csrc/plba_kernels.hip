@@ -104,6 +104,27 @@ DEV int quad_sum_i(int v) {
 // -------------------------------------------------------------------------------------------------
 template <bool JAC, int NT> DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane);
 template <bool JAC> DEV void prior_block(const DevBuf& d, int state);
+// End of a trial folded into the trial-error launch (one GPU): the workgroup that finishes last takes the LM decision
+// (decide_body = what k_decide does), so the decision is out one launch earlier.
+struct DecideArgs { LmParams lp; double* red; Mailbox* mail; unsigned long long seq; int nblk_lm; int fuse; };
+DEV void decide_body(const DevBuf& d, const LmParams& lp, double* red, int fused, int nblk_edges, int nblk_lm, Mailbox* mail, unsigned long long seq, double* s4, bool coherent);
+DEV void publish(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }     // sc1: visible to a same-launch reader on another XCD
+
+// Every workgroup of the trial-error launch ends here: its results have gone out with sc1 stores; once they are drained it
+// counts itself, and the last one to arrive reads everybody's (sc1 loads) and decides.
+DEV void trial_arrive(const DevBuf& d, const DecideArgs& da, int nblk_edges, double* s4) {
+    __shared__ int s_lastblk;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int prev = __hip_atomic_fetch_add(d.trial_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_lastblk = (prev == (int)gridDim.x - 1) ? 1 : 0;
+        if (s_lastblk) __hip_atomic_store(d.trial_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_lastblk) return;
+    decide_body(d, da.lp, da.red, 1, nblk_edges, da.nblk_lm, da.mail, da.seq, s4, true);
+}
 
 // Blocks [0, nblk_edges) handle observations.  Blocks beyond evaluate the pose-side edges inside the SAME launch
 // (one IMU PVR+bias edge pair per block, then one block for the prior), so the serial per-edge IMU math overlaps the
@@ -111,7 +132,7 @@ template <bool JAC> DEV void prior_block(const DevBuf& d, int state);
 template <bool JAC>
 // spec != 0: launched BEFORE the host knows the LM decision of the trial that just ran (so that the host's reaction time
 // hides behind this kernel): linearises the trial state iff the device-side decision was "accepted", else does nothing.
-__global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust rb, int nblk_edges, int spec) {
+__global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust rb, int nblk_edges, int spec, DecideArgs da) {
     if (spec && !d.ctrl->accepted) return;
     extern __shared__ double s_dyn[];
     double* s_kc = s_dyn;               // K x 12 staged camera blocks
@@ -127,6 +148,7 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (JAC && threadIdx.x == 0 && (m == 0 || m == d.M / 2)) { d.dbgbuf[m == 0 ? 32 : 33] = (double)(__builtin_readcyclecounter() - t0); d.dbgbuf[m == 0 ? 34 : 35] = (double)(long long)__builtin_amdgcn_s_memrealtime(); }
 #endif
+        if (!JAC && da.fuse) trial_arrive(d, da, nblk_edges, s4);
         return;
     }
 #ifdef PLBA_STAMPS_LM
@@ -176,7 +198,8 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
         }
     }
     double bs = block_sum_256(rho, s4);
-    if (threadIdx.x == 0) d.chi_part[blockIdx.x] = bs;
+    if (threadIdx.x == 0) { if (!JAC && da.fuse) publish(&d.chi_part[blockIdx.x], bs); else d.chi_part[blockIdx.x] = bs; }
+    if (!JAC && da.fuse) { trial_arrive(d, da, nblk_edges, s4); return; }
 #ifdef PLBA_STAMPS_LM
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (JAC && threadIdx.x == 0 && ((int)blockIdx.x == 0 || (int)blockIdx.x == nblk_edges / 2 || (int)blockIdx.x == nblk_edges - 1)) {
@@ -983,7 +1006,7 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
             double* eo = d.imu_err + (size_t)m * 16;
             for (int r = 0; r < 15; ++r) eo[r] = sE[r];
             double* co = d.imu_chi + (size_t)m * 4;
-            co[0] = chi; co[1] = chib; co[2] = r0; co[3] = b0;
+            publish(co, chi); publish(co + 1, chib); publish(co + 2, r0); publish(co + 3, b0);      // read by the last-arriving workgroup of this launch
         }
         return;
     }
@@ -1110,7 +1133,7 @@ DEV void prior_block(const DevBuf& d, int state) {
         chi += sacc * sacc;
     }
     double tot = block_sum_256(chi, s4);
-    if (threadIdx.x == 0) d.pr_chi[0] = tot;
+    if (threadIdx.x == 0) publish(&d.pr_chi[0], tot);
     if (!JAC) return;
     __syncthreads();
     for (int v = 0; v < d.pr_nv; ++v) {
@@ -1174,11 +1197,13 @@ __global__ __launch_bounds__(256) void k_tri_pack(DevBuf d, double* buf, int unp
 }
 
 // k_reduce inlined into the LM control kernels for the single-GPU path (no exchange between reduce and control)
-DEV void reduce_inline(const DevBuf& d, int nblk_edges, int nblk_lm, double* red, double* s4) {
+DEV double fetch(const double* p, bool coherent) { return coherent ? __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; }
+// coherent: the partial sums come from other workgroups of the SAME launch (sc1 loads), not from an earlier kernel
+DEV void reduce_inline(const DevBuf& d, int nblk_edges, int nblk_lm, double* red, double* s4, bool coherent = false) {
     double c = 0.0, sc = 0.0, md = 0.0;
-    for (int i = threadIdx.x; i < nblk_edges; i += 256) c += d.chi_part[i];
-    for (int i = threadIdx.x; i < d.M; i += 256) c += d.imu_chi[(size_t)i * 4 + 2] + d.imu_chi[(size_t)i * 4 + 3];
-    if (threadIdx.x == 0 && d.pr_nv > 0) c += d.pr_chi[0];
+    for (int i = threadIdx.x; i < nblk_edges; i += 256) c += fetch(&d.chi_part[i], coherent);
+    for (int i = threadIdx.x; i < d.M; i += 256) c += fetch(&d.imu_chi[(size_t)i * 4 + 2], coherent) + fetch(&d.imu_chi[(size_t)i * 4 + 3], coherent);
+    if (threadIdx.x == 0 && d.pr_nv > 0) c += fetch(&d.pr_chi[0], coherent);
     for (int i = threadIdx.x; i < nblk_lm; i += 256) { sc += d.scale_part[i]; md = fmax(md, d.maxd_part[i]); }
     const double C = block_sum_256(c, s4);
     const double S = block_sum_256(sc, s4);
@@ -1207,14 +1232,34 @@ __global__ __launch_bounds__(256) void k_lambda_init(DevBuf d, LmParams lp, doub
 }
 
 // end of a trial: rho test and lambda schedule of OptimizationAlgorithmLevenberg::solve
-__global__ __launch_bounds__(256) void k_decide(DevBuf d, LmParams lp, double* red, int fused, int nblk_edges, int nblk_lm, Mailbox* mail, unsigned long long seq) {
-    __shared__ double s4[4];
-    if (fused) reduce_inline(d, nblk_edges, nblk_lm, red, s4);
+DEV void decide_body(const DevBuf& d, const LmParams& lp, double* red, int fused, int nblk_edges, int nblk_lm, Mailbox* mail, unsigned long long seq, double* s4, bool coherent) {
+    // two memory rounds (the control block; then every partial sum and the pose step together) and ONE barrier: what is
+    // left of a trial after its last error is known sits on the critical path of every LM iteration
+    __shared__ double s_r[4][4];
     Ctrl* c = d.ctrl;
     const double lambda = c->lambda;
-    double sp = 0.0;
-    if (c->solver_ok) for (int j = threadIdx.x; j < d.P; j += 256) { const double xj = d.x[j]; sp += xj * (lambda * xj + d.bpg[j]); }
-    double SP = block_sum_256(sp, s4);
+    const int sok = c->solver_ok;
+    double cs = 0.0, sc = 0.0, md = 0.0, sp = 0.0;
+    if (fused) {
+        for (int i = threadIdx.x; i < nblk_edges; i += 256) cs += fetch(&d.chi_part[i], coherent);
+        for (int i = threadIdx.x; i < d.M; i += 256) cs += fetch(&d.imu_chi[(size_t)i * 4 + 2], coherent) + fetch(&d.imu_chi[(size_t)i * 4 + 3], coherent);
+        if (threadIdx.x == 0 && d.pr_nv > 0) cs += fetch(&d.pr_chi[0], coherent);
+        for (int i = threadIdx.x; i < nblk_lm; i += 256) { sc += d.scale_part[i]; md = fmax(md, d.maxd_part[i]); }
+    }
+    if (sok) for (int j = threadIdx.x; j < d.P; j += 256) { const double xj = d.x[j]; sp += xj * (lambda * xj + d.bpg[j]); }
+    cs = wave_sum(cs); sc = wave_sum(sc); md = wave_max(md); sp = wave_sum(sp);
+    if ((threadIdx.x & 63) == 0) { double* r = s_r[threadIdx.x >> 6]; r[0] = cs; r[1] = sc; r[2] = md; r[3] = sp; }
+    __syncthreads();
+    double SP = 0.0;
+    if (threadIdx.x == 0) {
+        if (fused) {
+            red[0] = (s_r[0][0] + s_r[1][0]) + (s_r[2][0] + s_r[3][0]);
+            red[1] = (s_r[0][1] + s_r[1][1]) + (s_r[2][1] + s_r[3][1]);
+            red[2] = fmax(fmax(s_r[0][2], s_r[1][2]), fmax(s_r[2][2], s_r[3][2]));
+        }
+        SP = (s_r[0][3] + s_r[1][3]) + (s_r[2][3] + s_r[3][3]);
+    }
+    (void)s4;
     if (threadIdx.x == 0) {
     double tempChi = red[0];
     if (!c->solver_ok) tempChi = 1.7976931348623157e308;
@@ -1255,6 +1300,10 @@ __global__ __launch_bounds__(256) void k_decide(DevBuf d, LmParams lp, double* r
     }
     }
 }
+__global__ __launch_bounds__(256) void k_decide(DevBuf d, LmParams lp, double* red, int fused, int nblk_edges, int nblk_lm, Mailbox* mail, unsigned long long seq) {
+    __shared__ double s4[4];
+    decide_body(d, lp, red, fused, nblk_edges, nblk_lm, mail, seq, s4, false);
+}
 
 // chi2() > thresh || !isDepthPositive()  =>  setLevel(1)   (mapHandler.cpp:6047-6066)
 __global__ __launch_bounds__(256) void k_gate(DevBuf d, int state, double thresh, uint8_t* depth_out, int do_gate) {
@@ -1283,13 +1332,15 @@ int edge_blocks(const DevBuf& d) { return (d.E + 255) / 256; }
 static int lm_blocks(const DevBuf& d) { return (d.L + LML - 1) / LML; }
 
 // with_pose_edges: this rank owns the IMU / prior edges; they are evaluated by extra blocks of the same launch
-void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s, bool spec) {
+void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s, bool spec, const DecideFusion* df) {
     const int nb = d.E ? edge_blocks(d) : 0;
     const int pose_blocks = with_pose_edges ? d.M + (d.pr_nv > 0 ? 1 : 0) : 0;
     if (nb + pose_blocks == 0) return;
     const size_t sh = (size_t)d.K * KFCAM_STRIDE * sizeof(double);
-    if (jac) hipLaunchKernelGGL(k_linearize<true>, dim3(nb + pose_blocks), dim3(256), sh, s, d, state, rb, nb, spec ? 1 : 0);
-    else hipLaunchKernelGGL(k_linearize<false>, dim3(nb + pose_blocks), dim3(256), sh, s, d, state, rb, nb, 0);
+    DecideArgs da{};
+    if (df && !jac) { da.lp = df->lp; da.red = df->red; da.mail = df->mail; da.seq = df->seq; da.nblk_lm = d.L ? lm_blocks(d) : 0; da.fuse = 1; }
+    if (jac) hipLaunchKernelGGL(k_linearize<true>, dim3(nb + pose_blocks), dim3(256), sh, s, d, state, rb, nb, spec ? 1 : 0, da);
+    else hipLaunchKernelGGL(k_linearize<false>, dim3(nb + pose_blocks), dim3(256), sh, s, d, state, rb, nb, 0, da);
 }
 void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, bool owns, hipStream_t s) {
     if (!owns) return;
