@@ -171,6 +171,13 @@ int plba_recompute_errors(plba_problem* p);                       /* computeActi
  * and isDepthPositive on the current estimates; either pointer may be NULL. */
 int plba_get_edge_chi2(plba_problem* p, plba_edge_kind kind, double* chi2, uint8_t* depth_positive);
 int plba_get_trace(plba_problem* p, plba_trace_row* rows, int cap, int* n);
+/* Observation culling decision of the call site after the final optimize() (mapHandler.cpp:5541-5556 points, :5611-5620
+ * lines): an edge is bad iff  chi2() > thresh || !isDepthPositive()  on the final estimates, where a
+ * level-1 (gated-out) edge first gets computeError() — its cached error is refreshed, as in the reference — and a
+ * level-0 edge uses the error cached by the last evaluation pass.  bad_point[Ep] / bad_line[El] receive 0 / 1 (either
+ * may be NULL); the counts are optional.  What the reference then does with a bad observation (erasing it from the map,
+ * covisibility bookkeeping) is host map surgery and stays with the caller.  Returns the number of bad observations. */
+int plba_cull_observations(plba_problem* p, double chi2_thresh, uint8_t* bad_point, uint8_t* bad_line, int* n_point_out, int* n_line_out);
 
 /* ---- results (write-back of mapHandler.cpp:6202-6239) --------------------------------------- */
 int plba_get_keyframes(plba_problem* p, double* P3, double* V3, double* q_xyzw4, double* dbg3, double* dba3);

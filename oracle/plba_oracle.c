@@ -1469,6 +1469,35 @@ int orc_gate_outliers(plba_problem* p, double thresh, int* np_out, int* nl_out) 
     if (nl_out) *nl_out = nl;
     return np + nl;
 }
+/* mapHandler.cpp:5541-5556 (points), :5611-5620 (lines): level-1 edges get computeError() first, then
+ * chi2() > thresh || !isDepthPositive() marks the observation for removal */
+int orc_cull_observations(plba_problem* p, double thresh, uint8_t* bad_point, uint8_t* bad_line, int* np_out, int* nl_out) {
+    if (!p) return PLBA_ERR_INVALID;
+    int np = 0, nl = 0;
+    for (int e = 0; e < p->Ep; ++e) {
+        double t[2]; int d;
+        point_error(p, &p->ns[p->po_kf[e]], p->pt + 3 * p->po_pt[e], p->po_uv + 2 * e, t, &d);
+        if (p->po_level[e]) { p->po_err[2 * e] = t[0]; p->po_err[2 * e + 1] = t[1]; }      /* e->computeError() */
+        const double* er = p->po_err + 2 * e;
+        const double c = p->po_w[e] * (er[0] * er[0] + er[1] * er[1]);
+        const int bad = (c > thresh || !d);
+        if (bad_point) bad_point[e] = (uint8_t)bad;
+        np += bad;
+    }
+    for (int e = 0; e < p->El; ++e) {
+        double t[3]; int d;
+        line_error(p, &p->ns[p->lo_kf[e]], p->ln + 6 * p->lo_ln[e], p->lo_l + 3 * e, t, &d);
+        if (p->lo_level[e]) { p->lo_err[3 * e] = t[0]; p->lo_err[3 * e + 1] = t[1]; p->lo_err[3 * e + 2] = t[2]; }
+        const double* er = p->lo_err + 3 * e;
+        const double c = p->lo_w[e] * (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]);
+        const int bad = (c > thresh || !d);
+        if (bad_line) bad_line[e] = (uint8_t)bad;
+        nl += bad;
+    }
+    if (np_out) *np_out = np;
+    if (nl_out) *nl_out = nl;
+    return np + nl;
+}
 int orc_get_trace(plba_problem* p, plba_trace_row* rows, int cap, int* n) {
     if (!p) return PLBA_ERR_INVALID;
     int c = p->trace_n < cap ? p->trace_n : cap;

@@ -73,6 +73,7 @@ SIGNATURES = {
     "optimize": (C.c_int, [_P, C.c_int, c_uint8_p, C.POINTER(Stats)]),
     "gate_outliers": (C.c_int, [_P, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "recompute_errors": (C.c_int, [_P]),
+    "cull_observations": (C.c_int, [_P, C.c_double, c_uint8_p, c_uint8_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "get_edge_chi2": (C.c_int, [_P, C.c_int, c_double_p, c_uint8_p]),
     "get_trace": (C.c_int, [_P, C.POINTER(TraceRow), C.c_int, C.POINTER(C.c_int)]),
     "get_keyframes": (C.c_int, [_P] + [c_double_p] * 5),
@@ -295,6 +296,15 @@ class Problem:
 
     def recompute_errors(self):
         self.call("recompute_errors")
+
+    def cull_observations(self, thresh=5.991):
+        """Culling decision of the call site after the final optimize (mapHandler.cpp:5541-5620): per-observation
+        bad flags for points and lines (level-1 edges are re-evaluated on the final estimates first)."""
+        Ep, El = self.dims.get("Ep", 0), self.dims.get("El", 0)
+        bp, bl = np.zeros(max(Ep, 1), np.uint8), np.zeros(max(El, 1), np.uint8)
+        a, b = C.c_int(0), C.c_int(0)
+        self.call("cull_observations", float(thresh), _up(bp), _up(bl), C.byref(a), C.byref(b), allow_positive=True)
+        return {"bad_points": bp[:Ep].astype(bool), "bad_lines": bl[:El].astype(bool), "n_points": a.value, "n_lines": b.value}
 
     def edge_chi2(self, kind):
         n = {EDGE_POINT: self.dims.get("Ep", 0), EDGE_LINE: self.dims.get("El", 0),

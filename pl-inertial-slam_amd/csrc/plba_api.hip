@@ -931,6 +931,29 @@ int plba_gate_outliers(plba_problem* p, double thresh, int* np_out, int* nl_out)
     return p->h_ctrl->n_gate_pt + p->h_ctrl->n_gate_ln;
 }
 
+int plba_cull_observations(plba_problem* p, double thresh, uint8_t* bad_point, uint8_t* bad_line, int* np_out, int* nl_out) {
+    if (!p) return PLBA_ERR_INVALID;
+    int rc = prepare(p);
+    if (rc) return rc;
+    HIPCK(p, hipSetDevice(p->device));
+    const DevBuf& d = p->dv;
+    const int E = p->Ep + p->El;
+    std::vector<uint8_t> bad((size_t)std::max(E, 1), 0);
+    if (E) {
+        launch_cull(d, p->cur, thresh, p->d_depth.p, p->stream);
+        HIPCK(p, hipStreamSynchronize(p->stream));
+        HIPCK(p, hipMemcpy(bad.data(), p->d_depth.p, (size_t)E, hipMemcpyDeviceToHost));
+    }
+    int np = 0, nl = 0;
+    for (int e = 0; e < p->Ep; ++e) np += bad[e];
+    for (int e = 0; e < p->El; ++e) nl += bad[p->Ep + e];
+    if (bad_point && p->Ep) memcpy(bad_point, bad.data(), (size_t)p->Ep);
+    if (bad_line && p->El) memcpy(bad_line, bad.data() + p->Ep, (size_t)p->El);
+    if (np_out) *np_out = np;
+    if (nl_out) *nl_out = nl;
+    return np + nl;
+}
+
 int plba_get_edge_chi2(plba_problem* p, plba_edge_kind kind, double* chi2, uint8_t* dpos) {
     if (!p) return PLBA_ERR_INVALID;
     int rc = prepare(p);

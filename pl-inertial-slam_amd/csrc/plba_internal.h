@@ -136,6 +136,7 @@ void launch_tri_pack(const DevBuf& d, double* buf, bool unpack, hipStream_t s);
 void launch_lambda_init2(const DevBuf& d, const LmParams& lp, double* red, bool first_iter, int iteration, bool fused, bool keep_chi, hipStream_t s);
 void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, Mailbox* mail, unsigned long long seq, hipStream_t s);
 void launch_gate(const DevBuf& d, int state, double thresh, hipStream_t s);
+void launch_cull(const DevBuf& d, int state, double thresh, uint8_t* bad, hipStream_t s);   // per-observation culling flags
 void launch_depth(const DevBuf& d, int state, uint8_t* out, hipStream_t s);
 int  edge_blocks(const DevBuf& d);
 

@@ -1325,6 +1325,32 @@ __global__ __launch_bounds__(256) void k_gate(DevBuf d, int state, double thresh
     }
 }
 
+// Culling decision after the final optimize (mapHandler.cpp:5541-5556, :5611-5620): level-1 edges get computeError() on the
+// current estimates (cached chi2 refreshed), then  chi2 > thresh || !isDepthPositive  =>  bad.  Lane per observation.
+__global__ __launch_bounds__(256) void k_cull(DevBuf d, int state, double thresh, uint8_t* bad) {
+    extern __shared__ double s_dyn[];
+    double* s_kc = s_dyn;
+    const double* kf = d.kf[state];
+    for (int k = threadIdx.x; k < d.K; k += 256) kfcam_make(d.cam, kf + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.E) return;
+    const double* L = d.lm[state] + (size_t)d.ob_slot[e] * 6;
+    const double* kc = s_kc + d.ob_kf[e] * KFCAM_STRIDE;
+    double e2[2], rec[12];
+    bool dpos;
+    if (e < d.Ep) {
+        const double2 uv = reinterpret_cast<const double2*>(d.po_uv)[e];
+        point_edge_rec(d.cam, kc, v3(L[0], L[1], L[2]), uv.x, uv.y, e2, rec, dpos, false);
+    } else {
+        const double* l = d.lo_l + (size_t)(e - d.Ep) * 3;
+        line_edge_rec(d.cam, kc, v3(L[0], L[1], L[2]), v3(L[3], L[4], L[5]), l[0], l[1], l[2], e2, rec, dpos, false);
+    }
+    double chi = d.ob_chi2[e];
+    if (d.ob_level[e] != 0) { chi = d.ob_w[e] * (e2[0] * e2[0] + e2[1] * e2[1]); d.ob_chi2[e] = chi; }
+    bad[e] = (chi > thresh || !dpos) ? 1 : 0;
+}
+
 // -------------------------------------------------------------------------------------------------
 // launchers
 // -------------------------------------------------------------------------------------------------
@@ -1413,6 +1439,10 @@ void launch_gate(const DevBuf& d, int state, double thresh, hipStream_t s) {
     if (d.E == 0) return;
     const size_t sh = (size_t)d.K * KFCAM_STRIDE * sizeof(double);
     hipLaunchKernelGGL(k_gate, dim3(edge_blocks(d)), dim3(256), sh, s, d, state, thresh, (uint8_t*)nullptr, 1);
+}
+void launch_cull(const DevBuf& d, int state, double thresh, uint8_t* bad, hipStream_t s) {
+    if (d.E == 0) return;
+    hipLaunchKernelGGL(k_cull, dim3(edge_blocks(d)), dim3(256), (size_t)d.K * KFCAM_STRIDE * sizeof(double), s, d, state, thresh, bad);
 }
 void launch_depth(const DevBuf& d, int state, uint8_t* out, hipStream_t s) {
     if (d.E == 0) return;

@@ -237,6 +237,28 @@ def test_rejected_trials_follow_the_oracle(pkg, orc, hip):
     g.close(); o.close()
 
 
+def test_observation_culling_flags_match_the_oracle(pkg, orc, hip):
+    """the culling decision the call site takes after the final optimize (mapHandler.cpp:5541-5620):
+    level-1 edges re-evaluated on the final estimates, chi2 > 5.991 || !isDepthPositive => bad.  Bit-exact flags."""
+    w = pkg.window.make_window(10, 400, 80, imu=True, seed=0xC011)
+    rng = np.random.default_rng(5)
+    w["po_uv"] = w["po_uv"].copy()
+    bad = rng.choice(len(w["po_uv"]), 40, replace=False)
+    w["po_uv"][bad] += rng.normal(size=(40, 2)) * 6.0            # gross outliers: gated after stage 1, then culled
+    g, o = _pair(pkg, orc, w)
+    pkg.protocol.local_ba(g); pkg.protocol.local_ba(o)
+    assert np.array_equal(g.get_levels(pkg.abi.EDGE_POINT), o.get_levels(pkg.abi.EDGE_POINT))
+    assert g.get_levels(pkg.abi.EDGE_POINT).sum() > 0
+    cg, co = g.cull_observations(), o.cull_observations()
+    assert np.array_equal(cg["bad_points"], co["bad_points"]) and np.array_equal(cg["bad_lines"], co["bad_lines"])
+    assert (cg["n_points"], cg["n_lines"]) == (co["n_points"], co["n_lines"]) == (cg["bad_points"].sum(), cg["bad_lines"].sum())
+    assert cg["n_points"] >= 30                                  # the planted outliers are among them
+    # level-1 edges had their cached chi2 refreshed on the final estimates (computeError), like the reference's
+    chg, _ = g.edge_chi2(pkg.abi.EDGE_POINT); cho, _ = o.edge_chi2(pkg.abi.EDGE_POINT)
+    _close(chg, cho, 1e-9, "chi2 after culling")
+    g.close(); o.close()
+
+
 @pytest.mark.parametrize("chain", [1, 0])
 def test_prior_edge_parity(pkg, orc, hip, chain):
     """BA with a marginalization prior: the oracle's prior on both sides (SURVEY B-Q3 decision).  With chain_elim = 1 the

@@ -154,6 +154,30 @@ def test_two_stage_protocol_and_gating(orc, pkg):
     p.close()
 
 
+def test_culling_decision_after_the_final_optimize(orc, pkg):
+    """mapHandler.cpp:5541-5620: level-1 edges are re-evaluated on the final estimates, then
+    chi2 > 5.991 || !isDepthPositive marks an observation for removal."""
+    w = pkg.window.make_window(8, 150, 30, imu=True, seed=14)
+    p = orc.new_problem()
+    p.upload_window(w)
+    pkg.protocol.local_ba(p)
+    lv_p, lv_l = p.get_levels(pkg.abi.EDGE_POINT), p.get_levels(pkg.abi.EDGE_LINE)
+    chi_p0, _ = p.edge_chi2(pkg.abi.EDGE_POINT)
+    cull = p.cull_observations()
+    chi_p, dp_p = p.edge_chi2(pkg.abi.EDGE_POINT)
+    chi_l, dp_l = p.edge_chi2(pkg.abi.EDGE_LINE)
+    assert np.array_equal(cull["bad_points"], (chi_p > 5.991) | (dp_p == 0))
+    assert np.array_equal(cull["bad_lines"], (chi_l > 5.991) | (dp_l == 0))
+    assert (cull["n_points"], cull["n_lines"]) == (cull["bad_points"].sum(), cull["bad_lines"].sum())
+    # only the gated-out edges had their cached error refreshed (their estimates moved during stage 2)
+    assert np.array_equal(chi_p[lv_p == 0], chi_p0[lv_p == 0])
+    assert lv_p.sum() > 0 and not np.array_equal(chi_p[lv_p == 1], chi_p0[lv_p == 1])
+    # every synthetic gross outlier is culled; the level-0 inliers of a converged window are not
+    assert cull["bad_points"][w["truth"]["point_outlier"]].all()
+    assert cull["bad_points"][lv_p == 0].mean() < 0.05
+    p.close()
+
+
 def test_abort_flag_stops_between_iterations(orc, pkg):
     w = pkg.window.make_window(5, 40, 8, imu=True, seed=15)
     p = orc.new_problem(); p.upload_window(w)
