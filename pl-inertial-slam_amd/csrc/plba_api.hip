@@ -20,6 +20,9 @@ using namespace plba;
 
 namespace {
 char g_create_err[256] = "";
+static std::mutex g_ctx_mu;
+static std::vector<HostCtx> g_ctx_free;
+static std::map<int, hipStream_t> g_lib_stream;
 }  // namespace
 
 #define FAIL(p, code, ...)                                  \
@@ -83,15 +86,46 @@ int plba_create(const plba_options* opt, plba_problem** out) {
         }
     }
     (void)hipGetDevice(&p->device);
-    if ((e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipHostMalloc((void**)&p->h_ctrl, sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess ||
-        (e = hipHostMalloc((void**)&p->h_mail, sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
-        (e = hipHostGetDevicePointer((void**)&p->d_mail, p->h_mail, 0)) != hipSuccess) {
-        snprintf(g_create_err, sizeof g_create_err, "device initialisation failed: %s", hipGetErrorString(e));
-        delete p;
-        return PLBA_ERR_DEVICE;
+    // stream, pinned control block and mapped mailbox come from a process-wide cache: creating and freeing them per BA
+    // call (hipHostMalloc / hipHostFree / stream create / destroy synchronise the device and remap memory) costs
+    // milliseconds as soon as another problem is alive
+    {
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        for (size_t i = 0; i < g_ctx_free.size(); ++i)
+            if (g_ctx_free[i].device == p->device) { p->ctx = g_ctx_free[i]; g_ctx_free.erase(g_ctx_free.begin() + (long)i); p->have_ctx = true; break; }
     }
+    if (!p->have_ctx) {
+        HostCtx c;
+        c.device = p->device;
+        // ONE library stream per device, shared by every problem that does not bring its own (plba_set_stream): each
+        // stream is a hardware queue, and with a few of them alive in the process the first operation on one that has
+        // been idle was measured to wait ~20 ms for its queue to be scheduled again
+        {
+            std::lock_guard<std::mutex> g(g_ctx_mu);
+            auto it = g_lib_stream.find(p->device);
+            if (it == g_lib_stream.end()) {
+                hipStream_t st = nullptr;
+                if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) == hipSuccess) it = g_lib_stream.emplace(p->device, st).first;
+            }
+            if (it != g_lib_stream.end()) { c.stream = it->second; e = hipSuccess; }
+        }
+        if (e != hipSuccess ||
+            (e = hipHostMalloc((void**)&c.h_ctrl, sizeof(Ctrl), hipHostMallocDefault)) != hipSuccess ||
+            (e = hipHostMalloc((void**)&c.h_mail, sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+            (e = hipHostGetDevicePointer((void**)&c.d_mail, c.h_mail, 0)) != hipSuccess) {
+            snprintf(g_create_err, sizeof g_create_err, "device initialisation failed: %s", hipGetErrorString(e));
+            delete p;
+            return PLBA_ERR_DEVICE;
+        }
+        c.stage = new StageArea;
+        const size_t cap = (size_t)64 << 20;
+        if (hipHostMalloc((void**)&c.stage->base, cap, hipHostMallocDefault) == hipSuccess) c.stage->cap = cap;      // optional: uploads fall back to pageable copies
+        else c.stage->base = nullptr;
+        p->ctx = c; p->have_ctx = true;
+    }
+    p->stream = p->ctx.stream; p->h_ctrl = (Ctrl*)p->ctx.h_ctrl; p->h_mail = (Mailbox*)p->ctx.h_mail; p->d_mail = (Mailbox*)p->ctx.d_mail;
     memset(p->h_mail, 0, sizeof(Mailbox));
+    p->mail_seq = 0;
     p->own_stream = true;
     *out = p;
     return PLBA_OK;
@@ -101,16 +135,18 @@ void plba_destroy(plba_problem* p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    if (p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
+    if (p->have_ctx) {
+        (void)hipStreamSynchronize(p->ctx.stream);
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        g_ctx_free.push_back(p->ctx);          // kept for the next problem (never freed: a handful of bytes and one stream per concurrent problem)
+    }
     if (p->ev_ready) for (auto& e : p->ev) (void)hipEventDestroy(e);
-    if (p->h_ctrl) (void)hipHostFree(p->h_ctrl);
-    if (p->h_mail) (void)hipHostFree(p->h_mail);
     delete p;
 }
 
 int plba_set_stream(plba_problem* p, void* s) {
     if (!p) return PLBA_ERR_INVALID;
-    if (p->own_stream && p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+    if (p->own_stream && p->stream) (void)hipStreamSynchronize(p->stream);      // the problem's own stream stays with its cached context
     p->stream = (hipStream_t)s;
     p->own_stream = false;
     return PLBA_OK;
@@ -305,7 +341,7 @@ static int prepare(plba_problem* p) {
     if (!p->have_cam || !p->K) FAIL(p, PLBA_ERR_STATE, "camera and keyframes must be set before optimize");
     if ((int)p->po_pt.size() != p->Ep) p->Ep = 0;
     HIPCK(p, hipSetDevice(p->device));
-    DArrStreamScope zero_fill_on(p->stream);      // fresh buffers are cleared on the stream their kernels run on
+    DArrStreamScope zero_fill_on(p->stream, p->have_ctx ? p->ctx.stage : nullptr);      // fresh buffers are cleared, and uploads queued, on the stream their kernels run on
     const int K = p->K, Np = p->Np, Nl = p->Nl, Ep = p->Ep, El = p->El, M = p->M;
     const int L = Np + Nl, E = Ep + El;
     p->L = L; p->E = E;
@@ -468,6 +504,7 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_maxd_part.alloc((size_t)(L + 31) / 32 + 33)); HIPCK(p, p->d_kfdiag.alloc((size_t)K * 6)); HIPCK(p, p->d_posediag.alloc(p->ld));
     HIPCK(p, p->d_red.alloc(8)); HIPCK(p, p->d_ctrl.alloc(1)); HIPCK(p, p->d_trace.alloc(TRACE_CAP)); HIPCK(p, p->d_trace_n.alloc(1));
     lap("alloc + upload");
+    if (ptime) fprintf(stderr, "[prepare] pool: %zu hipMalloc, %zu reused so far, %.1f MB cached\n", dev_pool().n_malloc, dev_pool().n_reuse, dev_pool().cached / 1048576.0);
     // ---- kernel argument block -------------------------------------------------------------------------------------
     DevBuf& d = p->dv;
     memset(&d, 0, sizeof d);
@@ -651,6 +688,8 @@ static int prepare(plba_problem* p) {
         }
         HIPCK(p, hipMemcpy(p->d_Hconst.p, Hc.data(), Hc.size() * 8, hipMemcpyHostToDevice));
     }
+    HIPCK(p, hipStreamSynchronize(p->stream));      // the uploads above were queued on the stream from host vectors that end here
+    lap("final stream sync");
     p->cur = 0;
     p->saved_valid = true;
     p->dirty = false;

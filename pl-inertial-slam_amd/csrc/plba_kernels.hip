@@ -1313,15 +1313,24 @@ __global__ __launch_bounds__(256) void k_gate(DevBuf d, int state, double thresh
     for (int k = threadIdx.x; k < d.K; k += 256) kfcam_make(d.cam, kf + (size_t)k * KF_STRIDE, s_kc + k * KFCAM_STRIDE);
     __syncthreads();
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= d.E) return;
-    const double* L = d.lm[state] + (size_t)d.ob_slot[e] * 6;
-    const double* kc = s_kc + d.ob_kf[e] * KFCAM_STRIDE;
-    bool dpos = cam_Pc(d.cam, kc, v3(L[0], L[1], L[2])).z > 0.0;
-    if (e >= d.Ep) dpos = dpos && (cam_Pc(d.cam, kc, v3(L[3], L[4], L[5])).z > 0.0);
-    if (depth_out) depth_out[e] = dpos ? 1 : 0;
-    if (do_gate && (d.ob_chi2[e] > thresh || !dpos)) {
-        if (d.ob_level[e] == 0) atomicAdd(e < d.Ep ? &d.ctrl->n_gate_pt : &d.ctrl->n_gate_ln, 1);
-        d.ob_level[e] = 1;
+    bool newly_pt = false, newly_ln = false;
+    if (e < d.E) {
+        const double* L = d.lm[state] + (size_t)d.ob_slot[e] * 6;
+        const double* kc = s_kc + d.ob_kf[e] * KFCAM_STRIDE;
+        bool dpos = cam_Pc(d.cam, kc, v3(L[0], L[1], L[2])).z > 0.0;
+        if (e >= d.Ep) dpos = dpos && (cam_Pc(d.cam, kc, v3(L[3], L[4], L[5])).z > 0.0);
+        if (depth_out) depth_out[e] = dpos ? 1 : 0;
+        if (do_gate && (d.ob_chi2[e] > thresh || !dpos)) {
+            if (d.ob_level[e] == 0) { newly_pt = e < d.Ep; newly_ln = !newly_pt; }
+            d.ob_level[e] = 1;
+        }
+    }
+    if (do_gate) {      // one counter update per wave, not one per gated observation (they all hit the same two words)
+        const int cp = __popcll(__ballot(newly_pt)), cl = __popcll(__ballot(newly_ln));
+        if ((threadIdx.x & 63) == 0) {
+            if (cp) atomicAdd(&d.ctrl->n_gate_pt, cp);
+            if (cl) atomicAdd(&d.ctrl->n_gate_ln, cl);
+        }
     }
 }
 

@@ -1,5 +1,6 @@
 // plba_problem.h — host-side problem object behind the opaque plba_problem* of include/plba.h.
 #pragma once
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -18,6 +19,7 @@ struct DevPool {
     std::mutex mu;
     std::map<std::pair<int, size_t>, std::vector<void*>> free_;     // (device, size class) -> blocks
     size_t cached = 0;
+    size_t n_malloc = 0, n_reuse = 0;      // statistics (PLBA_PREP_TIMING prints them)
     static size_t size_class(size_t bytes) { size_t c = 4096; while (c < bytes) c <<= 1; return c; }
     hipError_t get(size_t bytes, void** out, size_t* cls) {
         int dev = 0;
@@ -26,7 +28,8 @@ struct DevPool {
         {
             std::lock_guard<std::mutex> g(mu);
             auto it = free_.find({dev, *cls});
-            if (it != free_.end() && !it->second.empty()) { *out = it->second.back(); it->second.pop_back(); cached -= *cls; return hipSuccess; }
+            if (it != free_.end() && !it->second.empty()) { *out = it->second.back(); it->second.pop_back(); cached -= *cls; ++n_reuse; return hipSuccess; }
+            ++n_malloc;
         }
         hipError_t e = hipMalloc(out, *cls);
         if (e != hipSuccess) {      // give the cache back to the driver and try once more
@@ -54,10 +57,16 @@ inline DevPool& dev_pool() { static DevPool* pool = new DevPool; return *pool; }
 // stream the zero-fill of fresh buffers is ordered on (set by the API entry point for its duration); null: legacy
 // synchronous hipMemset + drain of the null stream
 inline hipStream_t& darr_stream() { static thread_local hipStream_t s = nullptr; return s; }
+// pinned staging area the queued uploads go through (host vector -> staging by memcpy, staging -> device by an async
+// copy): pageable sources make the runtime pin / stage on its own, which was measured at ~20 ms per BA call as soon as a
+// second problem is alive in the process.  Bump-allocated; valid until the owner has synchronised the stream.
+struct StageArea { char* base = nullptr; size_t cap = 0, used = 0; };
+inline StageArea*& darr_stage() { static thread_local StageArea* a = nullptr; return a; }
 struct DArrStreamScope {
     hipStream_t prev;
-    explicit DArrStreamScope(hipStream_t s) : prev(darr_stream()) { darr_stream() = s; }
-    ~DArrStreamScope() { darr_stream() = prev; }
+    StageArea* prev_stage;
+    explicit DArrStreamScope(hipStream_t s, StageArea* st = nullptr) : prev(darr_stream()), prev_stage(darr_stage()) { darr_stream() = s; darr_stage() = st; if (st) st->used = 0; }
+    ~DArrStreamScope() { darr_stream() = prev; darr_stage() = prev_stage; }
 };
 
 template <class T>
@@ -83,10 +92,24 @@ struct DArr {
         }
         return hipSuccess;
     }
+    // With a stream set (DArrStreamScope) the copy is queued on it: the CALLER keeps `h` alive and unchanged until it
+    // has synchronised that stream (prepare() does, once, at its end) instead of paying a synchronisation per buffer.
     hipError_t upload(const std::vector<T>& h) {
         hipError_t e = alloc(h.size(), h.empty());
         if (e != hipSuccess || h.empty()) return e;
-        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+        const size_t bytes = h.size() * sizeof(T);
+        if (hipStream_t s = darr_stream()) {
+            StageArea* st = darr_stage();
+            const size_t need = (bytes + 255) & ~(size_t)255;
+            if (st && st->base && st->used + need <= st->cap) {
+                char* src = st->base + st->used;
+                st->used += need;
+                memcpy(src, h.data(), bytes);
+                return hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, s);
+            }
+            return hipMemcpyAsync(p, h.data(), bytes, hipMemcpyHostToDevice, s);
+        }
+        return hipMemcpy(p, h.data(), bytes, hipMemcpyHostToDevice);
     }
     void release() { if (p) dev_pool().put(p, cls); p = nullptr; n = 0; cls = 0; }
     DArr() = default;
@@ -97,7 +120,18 @@ struct DArr {
 
 }  // namespace plba
 
+struct HostCtx {           // per-problem runtime objects, cached across problems (plba_create / plba_destroy)
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void* h_ctrl = nullptr;      // pinned copy of the control block
+    void* h_mail = nullptr;      // mapped, coherent mailbox the decision kernel writes and the host polls
+    void* d_mail = nullptr;      // its device address
+    plba::StageArea* stage = nullptr;   // pinned upload staging (heap object: HostCtx is copied around by value)
+};
+
 struct plba_problem {
+    HostCtx ctx;
+    bool have_ctx = false;
     plba_options opt;
     char err[512];
     int device = 0;
