@@ -668,6 +668,42 @@ static int prepare(plba_problem* p) {
     d.Ninv = nullptr; d.Nwork = nullptr;
     HIPCK(p, p->d_dbgbuf.alloc(64)); d.dbgbuf = p->d_dbgbuf.p;
     if (!p->chain_ok && p->P > 0 && p->Ppad / 32 <= NINV_MAX_T) { HIPCK(p, p->d_Ninv.alloc((size_t)2 * p->Ppad * p->ld)); d.Ninv = p->d_Ninv.p; d.Nwork = d.Ninv + (size_t)p->Ppad * p->ld; }
+    // ---- structural exchange list of a sharded run (k_list_pack): every lower-triangle entry of the reduced system that can be
+    // non-zero before the factorisation.  Everything else is zero on every rank and need not travel.
+    d.xlist = nullptr; d.nxlist = 0;
+    if (p->world > 1) {
+        std::vector<int32_t> xl;
+        const int ld = p->ld;
+        auto add_block = [&](const std::vector<int>& dims) {
+            for (size_t a = 0; a < dims.size(); ++a)
+                for (size_t b = 0; b < dims.size(); ++b)
+                    if (dims[a] >= 0 && dims[b] >= 0 && dims[a] >= dims[b]) xl.push_back(dims[a] * ld + dims[b]);
+        };
+        {   // pose x pose: the landmarks' Schur terms can couple any two keyframes
+            std::vector<int> pd;
+            for (int k = 0; k < K; ++k) if (p->off_pvr[k] >= 0) for (int c : {0, 1, 2, 6, 7, 8}) pd.push_back(p->off_pvr[k] + c);
+            add_block(pd);
+        }
+        for (int m = 0; m < M; ++m) {   // IMU PVR edge over [PVR_i | PVR_j | Bias_i], bias edge over [Bias_i | Bias_j]
+            const int ki = p->imu_i[m], kj = p->imu_j[m];
+            std::vector<int> e1, e2;
+            for (int c = 0; c < 9; ++c) { e1.push_back(p->off_pvr[ki] >= 0 ? p->off_pvr[ki] + c : -1); }
+            for (int c = 0; c < 9; ++c) { e1.push_back(p->off_pvr[kj] >= 0 ? p->off_pvr[kj] + c : -1); }
+            for (int c = 0; c < 6; ++c) { e1.push_back(p->off_bias[ki] >= 0 ? p->off_bias[ki] + c : -1); e2.push_back(p->off_bias[ki] >= 0 ? p->off_bias[ki] + c : -1); }
+            for (int c = 0; c < 6; ++c) e2.push_back(p->off_bias[kj] >= 0 ? p->off_bias[kj] + c : -1);
+            add_block(e1); add_block(e2);
+        }
+        {   // the prior couples all of its kept dims
+            std::vector<int> pd;
+            for (int a = 0; a < p->pr_nv; ++a) if (pr_off[a] >= 0) for (int c = 0; c < p->pr_size[a]; ++c) pd.push_back(pr_off[a] + c);
+            add_block(pd);
+        }
+        for (int r = 0; r < p->Ppad; ++r) xl.push_back(r * ld + r);      // lambda / the padding's ones
+        std::sort(xl.begin(), xl.end());
+        xl.erase(std::unique(xl.begin(), xl.end()), xl.end());
+        HIPCK(p, p->d_xlist.upload(xl));
+        d.xlist = p->d_xlist.p; d.nxlist = (int)xl.size();
+    }
     lap("chain maps + buffers");
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
     if (p->pr_nv > 0 && p->rank == 0) {
@@ -759,13 +795,13 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
     launch_schur_pairs(d, p->cur, chain_rides ? &p->cv : nullptr, s);
     MARK(p, 5);
     if (p->world > 1) {   // single GPU: k_assemble / k_schur_pairs wrote bp into bpg directly
-        // only the lower block-triangle (what the factorisation reads) and the two rhs rows travel
-        const size_t npk = tri_packed_size(d);
+        // only the entries that can be non-zero before the factorisation (pose x pose, IMU / prior blocks, diagonal) and the two rhs rows travel
+        const size_t npk = list_packed_size(d);
         if (p->d_xbuf.n < npk) HIPCK(p, p->d_xbuf.alloc(npk, false));
-        launch_tri_pack(d, p->d_xbuf.p, false, s);
+        launch_list_pack(d, p->d_xbuf.p, false, s);
         int rc = exchange(p, p->d_xbuf.p, npk, 0);
         if (rc) return rc;
-        launch_tri_pack(d, p->d_xbuf.p, true, s);
+        launch_list_pack(d, p->d_xbuf.p, true, s);
         HIPCK(p, hipMemcpyAsync(d.bpg, d.sys + (size_t)(d.Ppad + 1) * d.ld, (size_t)d.ld * 8, hipMemcpyDeviceToDevice, s));
     }
     MARK(p, 6);

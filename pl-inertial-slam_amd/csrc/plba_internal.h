@@ -74,6 +74,8 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     const int32_t *pair_i, *pair_j, *pair_start, *ent_pi, *ent_pj, *ent_slot;   // entries: record positions + landmark slot
     const ChunkMeta* ch_meta;                                                   // <= 256-entry chunks of the pair lists (k_schur_pairs)
     double* schur_part;    // nchunks x 48 partial sums
+    const int32_t* xlist;  // sharded runs: linear indices (r * ld + c, r >= c) of the lower-triangle entries that can be non-zero before the factorisation
+    int nxlist;
     int* pair_cnt;         // arrival counters (indexed by a pair's first chunk slot), zero between launches
     int* trial_cnt;        // arrival counter of the trial-error launch's workgroups (the last one decides), zero between launches
     // IMU
@@ -132,6 +134,8 @@ void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s);
 // red[0] = activeRobustChi2 (local), red[1] = landmark part of computeScale (local), red[2] = max |Hll_jj| (local)
 void launch_reduce(const DevBuf& d, bool owns_pose_edges, double* red, hipStream_t s);
 size_t tri_packed_size(const DevBuf& d);   // doubles in the packed lower block-triangle + the two rhs rows
+size_t list_packed_size(const DevBuf& d);  // doubles in the structural exchange buffer (d.xlist entries + the two rhs rows)
+void launch_list_pack(const DevBuf& d, double* buf, bool unpack, hipStream_t s);
 void launch_tri_pack(const DevBuf& d, double* buf, bool unpack, hipStream_t s);
 void launch_lambda_init2(const DevBuf& d, const LmParams& lp, double* red, bool first_iter, int iteration, bool fused, bool keep_chi, hipStream_t s);
 void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, Mailbox* mail, unsigned long long seq, hipStream_t s);

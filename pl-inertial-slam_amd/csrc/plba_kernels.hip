@@ -1431,6 +1431,31 @@ void launch_update_kf(const DevBuf& d, int cur, int trial, hipStream_t s) {
     hipLaunchKernelGGL(k_update_kf, dim3((d.K + 63) / 64), dim3(64), 0, s, d, cur, trial);
 }
 size_t tri_packed_size(const DevBuf& d) { const size_t a = (size_t)(d.Ppad >> 5); return 512 * a * (a + 1) + 2 * (size_t)d.Ppad; }
+// Sharded runs, structural version of the exchange: only the entries of the lower triangle that CAN be non-zero before the
+// factorisation travel (pose x pose for the landmarks' Schur terms, the IMU / prior blocks, the diagonal: d.xlist, built at
+// upload), plus the two right-hand-side rows.  buf = [entries | row Ppad | row Ppad + 1].  Unpacking mirrors every entry
+// (the diagonal tiles are read whole by the factorisation).
+__global__ __launch_bounds__(256) void k_list_pack(DevBuf d, double* buf, int unpack) {
+    const int n = d.nxlist;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n + 2 * d.Ppad; k += gridDim.x * 256) {
+        if (k < n) {
+            const int idx = d.xlist[k];
+            if (unpack) { const double v = buf[k]; d.sys[idx] = v; const int r = idx / d.ld, c = idx % d.ld; d.sys[(size_t)c * d.ld + r] = v; }
+            else buf[k] = d.sys[idx];
+        } else {
+            const int q = k - n, row = d.Ppad + q / d.Ppad, c = q % d.Ppad;
+            if (unpack) d.sys[(size_t)row * d.ld + c] = buf[k];
+            else buf[k] = d.sys[(size_t)row * d.ld + c];
+        }
+    }
+}
+size_t list_packed_size(const DevBuf& d) { return (size_t)d.nxlist + 2 * (size_t)d.Ppad; }
+void launch_list_pack(const DevBuf& d, double* buf, bool unpack, hipStream_t s) {
+    const size_t n = list_packed_size(d);
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_list_pack, dim3(blocks), dim3(256), 0, s, d, buf, unpack ? 1 : 0);
+}
 void launch_tri_pack(const DevBuf& d, double* buf, bool unpack, hipStream_t s) {
     hipLaunchKernelGGL(k_tri_pack, dim3(d.Ppad + 2), dim3(256), 0, s, d, buf, unpack ? 1 : 0);
 }
