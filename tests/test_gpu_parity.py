@@ -168,6 +168,42 @@ def test_chain_variable_elimination_option(pkg, orc, hip, K, Np, Nl, imu, chain)
     g.close(); o.close()
 
 
+def _variant(pkg, w, kind):
+    """structural edge cases for the chain elimination / index maps, applied to a generated window"""
+    K = len(w["kf"]["P"])
+    kf = w["kf"]
+    if kind == "fixed_middle":           # a fixed keyframe inside the window: its chain block is missing, two chains
+        kf["fixed_pvr"] = kf["fixed_pvr"].copy(); kf["fixed_bias"] = kf["fixed_bias"].copy()
+        kf["fixed_pvr"][K // 2] = 1; kf["fixed_bias"][K // 2] = 1
+    elif kind == "fixed_bias_only":      # pose free, bias fixed: chain block with 3 live dims
+        kf["fixed_bias"] = kf["fixed_bias"].copy(); kf["fixed_bias"][[2, K - 2]] = 1
+    elif kind == "fixed_pose_only":      # bias free, pose/velocity fixed: chain block with 6 live dims, no pose block
+        kf["fixed_pvr"] = kf["fixed_pvr"].copy(); kf["fixed_pvr"][3] = 1
+    elif kind == "dropped_imu_edge":     # no IMU edge between two neighbours: the chain falls apart there
+        im = dict(w["imu"]); keep = np.ones(K - 1, bool); keep[K // 3] = False
+        for k in ("kf_i", "kf_j", "preint", "info_pvr", "info_bias"): im[k] = im[k][keep]
+        w["imu"] = im
+    elif kind == "nothing_fixed":        # gauge left to the damping
+        kf["fixed_pvr"] = np.zeros(K, np.uint8); kf["fixed_bias"] = np.zeros(K, np.uint8)
+    return w
+
+
+@pytest.mark.parametrize("K", [9, 10, 17, 18, 19, 28])
+@pytest.mark.parametrize("kind", ["plain", "fixed_middle", "fixed_bias_only", "fixed_pose_only", "dropped_imu_edge", "nothing_fixed"])
+def test_window_structure_variants(pkg, orc, hip, K, kind):
+    """segment-boundary window sizes x structural variants: whatever the index maps (positions, separators, segments, column
+    windows, keyframe owners) come out as, the device takes the oracle's steps"""
+    if kind != "plain" and K in (10, 18):
+        pytest.skip("variant covered at the neighbouring sizes")
+    w = _variant(pkg, pkg.window.make_window(K, 40 * K, 8 * K, imu=True, seed=0x57A0 + K), kind)
+    g, o = _pair(pkg, orc, w)
+    sg, so = g.optimize(4), o.optimize(4)
+    assert (sg.iterations, sg.trials, sg.solver_failures) == (so.iterations, so.trials, so.solver_failures)
+    assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-7)
+    assert max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)) < 1e-7
+    g.close(); o.close()
+
+
 def test_large_window_many_block_steps(pkg, orc, hip):
     """100 keyframes: P = 1485 pose dimensions, 47 block steps of the dense factorisation, 24 dataflow hops of the
     back-substitution — the shape class of BASELINE configs[4], on a landmark count the oracle finishes in seconds"""
