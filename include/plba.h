@@ -62,7 +62,7 @@ typedef struct {
     int    device;              /* HIP device ordinal, -1 = current device            (-1)    */
     int    use_mfma;            /* 1 = fp64 MFMA trailing update in the dense solve    (1)    */
     int    profile;             /* HIP-event timing into plba_stats.ms_phase: 1 = the dense factorisation launches only
-                                   (two events per trial), 2 = every phase (0 = off)            */
+                                   (two events on every 8th trial, scaled to all trials), 2 = every phase (0 = off) */
     int    factor_block;        /* block width of the dense factorisation: 32 or 64                (32)   */
     int    factor_flow;         /* 1 = the whole factorisation as ONE dataflow launch (factor_block 32 with use_mfma;
                                    experimental: measured slower at P = 735), 0 = one launch per block step (0) */

@@ -137,6 +137,8 @@ struct plba_problem {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool ev_sample = false;    // profile = 1: this trial's factorisation span is being timed
+    unsigned trial_counter = 0;
     bool spec_lin = false;     // the next iteration's linearisation is already in the stream (enqueued behind k_decide)
     // ---- host copy of the uploaded graph -------------------------------------------------------
     bool have_cam = false;
