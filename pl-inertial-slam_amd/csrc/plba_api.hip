@@ -7,6 +7,7 @@
 // mapped host memory, the host polls a sequence number).
 // No CPU fallback exists: every entry point that computes needs a HIP device.
 #include <algorithm>
+#include <thread>
 #include <array>
 #include <chrono>
 #include <cmath>
@@ -387,42 +388,79 @@ static int prepare(plba_problem* p) {
     for (int i = 0; i < Nl; ++i) { memcpy(&p->lm0[(size_t)(Np + i) * 6], &p->lns[(size_t)i * 6], 48); p->lm_fixed[Np + i] = p->ln_fixed[i]; }
     lap("index maps, slots");
     // ---- keyframe-pair lists for the Schur complement --------------------------------------------------
-    std::vector<int64_t> cnt((size_t)K * K + 1, 0);
-    for (int s = 0; s < L; ++s)
-        for (int a = lm_start[s]; a < lm_start[s + 1]; ++a) {
-            if (p->off_pvr[ob_kf[a]] < 0) continue;
-            for (int b = a; b < lm_start[s + 1]; ++b) {
-                if (p->off_pvr[ob_kf[b]] < 0) continue;
-                const int i = std::min(ob_kf[a], ob_kf[b]), j = std::max(ob_kf[a], ob_kf[b]);
-                cnt[(size_t)i * K + j + 1]++;
+    // Counting sort of the (landmark, observation a, observation b >= a) triples by keyframe pair, on a few host threads:
+    // thread t owns a contiguous range of landmarks with about 1/T of the triples; per-thread pair counts give every thread
+    // its own slice of every pair's entry range, in thread (= landmark) order, so the result is the serial one bit for bit.
+    const int NT = (E > 20000) ? 4 : 1;
+    std::vector<int> lm_cut(NT + 1, L);
+    {
+        std::vector<int64_t> tri(L + 1, 0);
+        for (int s = 0; s < L; ++s) { const int64_t k = lm_start[s + 1] - lm_start[s]; tri[s + 1] = tri[s] + k * (k + 1) / 2; }
+        lm_cut[0] = 0;
+        for (int t = 1; t < NT; ++t) lm_cut[t] = (int)(std::lower_bound(tri.begin(), tri.end(), tri[L] * t / NT) - tri.begin());
+        for (int t = 1; t <= NT; ++t) lm_cut[t] = std::max(lm_cut[t], lm_cut[t - 1]);
+        lm_cut[NT] = L;
+    }
+    std::vector<int32_t> kfree(E);        // keyframe of an observation, -1 if that keyframe's pose is fixed
+    for (int e = 0; e < E; ++e) kfree[e] = p->off_pvr[ob_kf[e]] >= 0 ? ob_kf[e] : -1;
+    std::vector<std::vector<int32_t>> tcnt(NT, std::vector<int32_t>((size_t)K * K, 0));
+    auto count_range = [&](int t) {
+        int32_t* c = tcnt[t].data();
+        for (int s = lm_cut[t]; s < lm_cut[t + 1]; ++s)
+            for (int a = lm_start[s]; a < lm_start[s + 1]; ++a) {
+                const int ka = kfree[a];
+                if (ka < 0) continue;
+                for (int b = a; b < lm_start[s + 1]; ++b) {
+                    const int kb = kfree[b];
+                    if (kb < 0) continue;
+                    c[ka <= kb ? (size_t)ka * K + kb : (size_t)kb * K + ka]++;
+                }
             }
-        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < NT; ++t) th.emplace_back(count_range, t);
+        count_range(0);
+        for (auto& x : th) x.join();
+    }
     std::vector<int32_t> pair_i, pair_j, pair_start;
-    std::vector<int64_t> pos((size_t)K * K, -1);
+    std::vector<std::vector<int64_t>> tpos(NT, std::vector<int64_t>((size_t)K * K, -1));
     int64_t nent = 0;
     for (int i = 0; i < K; ++i)
         for (int j = i; j < K; ++j) {
-            const int64_t c = cnt[(size_t)i * K + j + 1];
+            int64_t c = 0;
+            for (int t = 0; t < NT; ++t) c += tcnt[t][(size_t)i * K + j];
             if (c == 0) continue;
-            pos[(size_t)i * K + j] = nent;
             pair_i.push_back(i); pair_j.push_back(j); pair_start.push_back((int32_t)nent);
+            int64_t o = nent;
+            for (int t = 0; t < NT; ++t) { tpos[t][(size_t)i * K + j] = o; o += tcnt[t][(size_t)i * K + j]; }
             nent += c;
         }
     if (nent > 0x7fffffff) FAIL(p, PLBA_ERR_INVALID, "too many Schur pair entries");
     pair_start.push_back((int32_t)nent);
     std::vector<int32_t> ent_ei((size_t)nent), ent_ej((size_t)nent), ent_slot((size_t)nent);
-    for (int s = 0; s < L; ++s)
-        for (int a = lm_start[s]; a < lm_start[s + 1]; ++a) {
-            if (p->off_pvr[ob_kf[a]] < 0) continue;
-            for (int b = a; b < lm_start[s + 1]; ++b) {
-                if (p->off_pvr[ob_kf[b]] < 0) continue;
-                int ea = a, eb = b;
-                if (ob_kf[ea] > ob_kf[eb]) std::swap(ea, eb);
-                int64_t& w = pos[(size_t)ob_kf[ea] * K + ob_kf[eb]];
-                ent_ei[(size_t)w] = p->ob_pos[ea]; ent_ej[(size_t)w] = p->ob_pos[eb]; ent_slot[(size_t)w] = s;
-                ++w;
+    auto fill_range = [&](int t) {
+        int64_t* pos = tpos[t].data();
+        for (int s = lm_cut[t]; s < lm_cut[t + 1]; ++s)
+            for (int a = lm_start[s]; a < lm_start[s + 1]; ++a) {
+                const int ka = kfree[a];
+                if (ka < 0) continue;
+                for (int b = a; b < lm_start[s + 1]; ++b) {
+                    const int kb = kfree[b];
+                    if (kb < 0) continue;
+                    const bool sw = ka > kb;
+                    int64_t& w = pos[sw ? (size_t)kb * K + ka : (size_t)ka * K + kb];
+                    ent_ei[(size_t)w] = p->ob_pos[sw ? b : a]; ent_ej[(size_t)w] = p->ob_pos[sw ? a : b]; ent_slot[(size_t)w] = s;
+                    ++w;
+                }
             }
-        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < NT; ++t) th.emplace_back(fill_range, t);
+        fill_range(0);
+        for (auto& x : th) x.join();
+    }
     lap("pair lists (host)");
     // ---- prior bookkeeping ----------------------------------------------------------------------------------------
     std::vector<int32_t> pr_kf(p->pr_nv), pr_isb(p->pr_nv), pr_x0off(p->pr_nv), pr_off(p->pr_nv);
