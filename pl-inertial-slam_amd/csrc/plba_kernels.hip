@@ -994,17 +994,29 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
         PSTAMP(1);
     }
     if (!JAC) {
-        // error pass: the serial form (one lane) is all there is to do
+        // error pass: chi = e^T Omega e with a lane per row of Omega (same row sums, same order as the serial form), so the
+        // 117 dependent multiply-adds and their loads do not sit behind the serial error evaluation
+        __syncthreads();
+        if (lane < 9) {
+            double t = 0.0;
+            for (int c = 0; c < 9; ++c) t += Om[lane * 9 + c] * sE[c];
+            sT[lane] = t;
+        } else if (lane >= 64 && lane < 64 + 6) {
+            const int r = lane - 64;
+            double t = 0.0;
+            for (int c = 0; c < 6; ++c) t += Ob[r * 6 + c] * sE[9 + c];
+            sT[9 + r] = t;
+        } else if (lane >= 128 && lane < 128 + 15) {
+            d.imu_err[(size_t)m * 16 + (lane - 128)] = sE[lane - 128];
+        }
+        __syncthreads();
         if (lane == 0) {
-            double chi = 0.0;
-            for (int r = 0; r < 9; ++r) { double t = 0.0; for (int c = 0; c < 9; ++c) t += Om[r * 9 + c] * sE[c]; chi += sE[r] * t; }
-            double chib = 0.0;
-            for (int r = 0; r < 6; ++r) { double t = 0.0; for (int c = 0; c < 6; ++c) t += Ob[r * 6 + c] * sE[9 + c]; chib += sE[9 + r] * t; }
+            double chi = 0.0, chib = 0.0;
+            for (int r = 0; r < 9; ++r) chi += sE[r] * sT[r];
+            for (int r = 0; r < 6; ++r) chib += sE[9 + r] * sT[9 + r];
             double r0 = chi, r1 = 1.0, b0 = chib, b1 = 1.0;
             if (rb.on[PLBA_EDGE_IMU_PVR]) huber(chi, rb.delta[PLBA_EDGE_IMU_PVR], r0, r1);
             if (rb.on[PLBA_EDGE_IMU_BIAS]) huber(chib, rb.delta[PLBA_EDGE_IMU_BIAS], b0, b1);
-            double* eo = d.imu_err + (size_t)m * 16;
-            for (int r = 0; r < 15; ++r) eo[r] = sE[r];
             double* co = d.imu_chi + (size_t)m * 4;
             publish(co, chi); publish(co + 1, chib); publish(co + 2, r0); publish(co + 3, b0);      // read by the last-arriving workgroup of this launch
         }
