@@ -295,6 +295,39 @@ def test_observation_culling_flags_match_the_oracle(pkg, orc, hip):
     g.close(); o.close()
 
 
+def test_rejected_trials_with_imu_edges(pkg, orc, hip):
+    """retries on the default path (chain elimination, queued-ahead linearisation gated on the device-side decision, double
+    buffered IMU accumulators): a rejected step must leave records and accumulators of the current state untouched"""
+    w = pkg.window.make_window(10, 150, 30, imu=True, seed=77)
+    w["points"] = w["points"] + np.random.default_rng(1).normal(size=w["points"].shape) * 1.0
+    g, o = _pair(pkg, orc, w, user_lambda_init=1e-6)
+    sg, so = g.optimize(6), o.optimize(6)
+    tg, to = g.trace(), o.trace()
+    assert any(not r["accepted"] for r in to), "the scenario is meant to produce rejected trials"
+    assert [r["accepted"] for r in tg] == [r["accepted"] for r in to]
+    assert [(r["iteration"], r["trial"]) for r in tg] == [(r["iteration"], r["trial"]) for r in to]
+    # lambda = 1e-6 on landmarks perturbed by a metre: the damped systems are conditioned ~1e10, so the two solvers agree to
+    # a few digits only (the first trial already: 588734 vs 588843); what must agree exactly is the control flow
+    assert tg[0]["chi2_current"] == pytest.approx(to[0]["chi2_current"], rel=1e-10)      # same start
+    for a, b in zip(tg, to):
+        assert a["lam"] == pytest.approx(b["lam"], rel=3e-2)
+        assert a["chi2_current"] == pytest.approx(b["chi2_current"], rel=3e-2)
+    # rejected steps restore the state (chi2_current unchanged) and raise lambda
+    for a, b in zip(tg[:-1], tg[1:]):
+        if not a["accepted"] and b["iteration"] == a["iteration"]:
+            assert b["lam"] > a["lam"] and b["chi2_current"] == a["chi2_current"]
+    assert sg.chi2_final <= sg.chi2_initial
+    g.close(); o.close()
+    # the chain path and the dense path solve the same first (identical) system to many more digits than either agrees with
+    # the CPU solver; later trials start from states that already differ in the fourth digit
+    g1 = pkg.new_problem(user_lambda_init=1e-6); g1.upload_window(w)
+    g0 = pkg.new_problem(user_lambda_init=1e-6, chain_elim=0); g0.upload_window(w)
+    g1.optimize(6); g0.optimize(6)
+    assert g1.trace()[0]["chi2_trial"] == pytest.approx(g0.trace()[0]["chi2_trial"], rel=1e-7)
+    assert [r["accepted"] for r in g1.trace()] == [r["accepted"] for r in g0.trace()]
+    g1.close(); g0.close()
+
+
 @pytest.mark.parametrize("chain", [1, 0])
 def test_prior_edge_parity(pkg, orc, hip, chain):
     """BA with a marginalization prior: the oracle's prior on both sides (SURVEY B-Q3 decision).  With chain_elim = 1 the
