@@ -139,7 +139,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink landmark counts (debug only; invalidates the number)")
     ap.add_argument("--kf", type=int, default=0, help="override the keyframe count (debug only)")
     ap.add_argument("--fb", type=int, default=0, help="dense factorisation block width (32/64); 0 = library default")
-    ap.add_argument("--chain", action="store_true", help="experimental: chain_elim = 1 (velocity / bias variables eliminated first)")
+    ap.add_argument("--no-chain", action="store_true", help="debug: chain_elim = 0 (dense path on the full 15-dims-per-keyframe system)")
+    ap.add_argument("--wide", action="store_true", help="debug: wide_steps = 1 (64 columns per launch; measured slower)")
     args = ap.parse_args()
 
     import torch
@@ -186,7 +187,7 @@ def main():
     stream = torch.cuda.Stream()
     # profile=1: two HIP events per LM trial (on the stream the kernels run on) bracket the dense factorisation launches,
     # the dominant kernel; the full per-phase table comes from a second, untimed problem below
-    extra = dict(**({"factor_block": args.fb} if args.fb else {}), **({"chain_elim": 1} if args.chain else {}))
+    extra = dict(**({"factor_block": args.fb} if args.fb else {}), **({"chain_elim": 0} if args.no_chain else {}), **({"wide_steps": 1} if args.wide else {}))
     prob = pkg.new_problem(profile=1, **extra)
     prob.set_stream(stream.cuda_stream)
     prob.upload_window(w)
@@ -223,6 +224,8 @@ def main():
     n_fact_launches = ((Pdense + 63) // 64) * 64 // fb + 1               # first-block launch + one per block step
     if Pdense < P and fb == 32:
         n_fact_launches -= 1          # chain elimination: the first diagonal tile is factored inside k_chain_schur, ahead of the events
+    if fb == 32 and ((Pdense + 63) // 64) * 64 // 32 <= 32 and not args.wide:
+        n_fact_launches -= 1          # explicit-inverse back-substitution: the last block step (panels only) is folded into k_back_gemv
     flops_fact = Pdense ** 3 / 3.0 + Pdense * Pdense                     # LL^T of the dense system + the forward solve riding along
     fact_ms = phases[1] / max(trials, 1) / n_fact_launches               # live: HIP events over the timed region
     # second, untimed pass with every phase bracketed (profile=2): phase table + the HBM-bound kernel's launch time

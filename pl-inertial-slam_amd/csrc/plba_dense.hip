@@ -1006,7 +1006,8 @@ void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s, b
     if (inverse_panels(d, use_mfma)) {
         const int T = d.Ppad / 32;
         if (!tile0_done) hipLaunchKernelGGL(k_potrf0_32, dim3(1), dim3(256), 0, s, d);
-        for (int k = 0; k < T; ++k) {
+        const int kend = (d.Ninv && !d.wide) ? T - 1 : T;      // with the explicit inverse the last step (panels only) is folded into k_back_gemv
+        for (int k = 0; k < kend; ++k) {
             const int nt = T - k - 1;
             const int tiles = nt * (nt + 1) / 2 + nt;
             hipLaunchKernelGGL(k_chol32, dim3((tiles > 0 ? tiles : 1) + (d.Ninv ? (k + 1) * (nt > 0 ? nt : 1) : 0)), dim3(256), 0, s, d, k, T);
@@ -1017,26 +1018,50 @@ void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s, b
     else launch_cholesky_nb<32>(d, use_mfma, s);
 }
 
-// x = L^-T y = N y with the explicit inverse the factorisation launches left in Ninv: a wave per row, no dependencies
-__global__ __launch_bounds__(256) void k_back_gemv(DevBuf d) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (c >= d.Ppad) return;
+// x = L^-T y = N y with the explicit inverse the factorisation launches left in Ninv: a wave per row, no dependencies.
+// The LAST block step of the factorisation (no trailing matrix left: only the panels  y_T = b_T M^T  and  N(:,T) = R(:,T) M^T,
+// M = L(T,T)^-1) is not launched when this kernel follows; it is folded in here: with  z = M^T (M b_T)  (32 values, formed
+// once per workgroup from the published inverse) row c of the product ends with  R(c,T) . z,  and the last 32 rows ARE z.
+__global__ __launch_bounds__(256) void k_back_gemv(DevBuf d, int fold_last) {
+    __shared__ double sM[32 * 33], sr[32], sy[32], sz[32];
+    const int c0 = fold_last ? d.Ppad - 32 : d.Ppad;             // first column of the last block (fold_last = 0: every step was launched)
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // the grid covers Ppad rows exactly
     const double* Nr = d.Ninv + (size_t)c * d.ld;
     const double* y = d.Lfac + (size_t)d.Ppad * d.ld;
     double s0 = 0.0, s1 = 0.0;
     int r = (c & ~31) + lane;
-    for (; r + 64 < d.Ppad; r += 128) { s0 = fma(Nr[r], y[r], s0); s1 = fma(Nr[r + 64], y[r + 64], s1); }
-    if (r < d.Ppad) s0 = fma(Nr[r], y[r], s0);
-    double v = s0 + s1;
+    for (; r + 64 < c0; r += 128) { s0 = fma(Nr[r], y[r], s0); s1 = fma(Nr[r + 64], y[r + 64], s1); }
+    if (r < c0) s0 = fma(Nr[r], y[r], s0);
+    const double tw = (fold_last && c < c0 && lane < 32) ? d.Nwork[(size_t)c * d.ld + c0 + lane] : 0.0;      // R(c, T): the row's unsolved last block
+    if (fold_last) {
+        for (int idx = threadIdx.x; idx < 1024; idx += 256) sM[(idx >> 5) * 33 + (idx & 31)] = d.Linv32[(size_t)(c0 >> 5) * 1024 + idx];
+        if (threadIdx.x < 32) sr[threadIdx.x] = d.sys[(size_t)d.Ppad * d.ld + c0 + threadIdx.x];
+    } else if (threadIdx.x < 32) sz[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (fold_last && threadIdx.x < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) t = fma(sM[threadIdx.x * 33 + q], sr[q], t);
+        sy[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (fold_last && threadIdx.x < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t = fma(sM[i * 33 + threadIdx.x], sy[i], t);
+        sz[threadIdx.x] = t;
+    }
+    __syncthreads();
+    double v = s0 + s1 + (lane < 32 ? tw * sz[lane] : 0.0);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (lane == 0) d.x[c] = v;
+    if (lane == 0) d.x[c] = c < c0 ? v : sz[c - c0];
 }
 
 void launch_trsv_back(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s) {
     const int T = d.Ppad / TILE;
     if (inverse_panels(d, use_mfma) && !d.flow && d.Ninv) {
-        hipLaunchKernelGGL(k_back_gemv, dim3((d.Ppad + 3) / 4), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_back_gemv, dim3((d.Ppad + 3) / 4), dim3(256), 0, s, d, d.wide ? 0 : 1);
         return;
     }
     if (inverse_panels(d, use_mfma)) {
