@@ -806,7 +806,7 @@ static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
     p->assembled = launch_landmark_hll(d, p->cur, !first_iter, owns_pose_edges(p), s);
     if (first_iter) {
         HIPCK(p, hipMemsetAsync(d.kfdiag, 0, (size_t)d.K * 6 * 8, s));
-        launch_kfdiag(d, p->cur, s);
+        launch_kfdiag(d, p->cur, p->world > 1, s);
     }
     // chi2 of the start state (and computeLambdaInit) is only needed on the first iteration of a call.  On later ones it
     // is the chi2 of the trial that was just accepted, evaluated on the very same state: k_decide left it in the control

@@ -124,7 +124,7 @@ void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bo
                                                                         // spec: gated on the device-side LM decision; df: errors-only pass that also decides
 void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, bool owns_pose_edges, hipStream_t s);
 bool launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv_assemble, bool add_lambda, hipStream_t s);
-void launch_kfdiag(const DevBuf& d, int state, hipStream_t s);
+void launch_kfdiag(const DevBuf& d, int state, bool with_posediag, hipStream_t s);
 void launch_landmark_dinv(const DevBuf& d, hipStream_t s);
 void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s);
 void launch_schur_pairs(const DevBuf& d, int state, const ChainView* lead /* chain segments riding in front, or null */, hipStream_t s);

@@ -392,29 +392,52 @@ DEV EdgeRows load_rows(const DevBuf& d, const double* rec, const double* kc, boo
 }
 
 // per-keyframe diagonal of sum Jp^T w Jp (only needed for lambda_init at iteration 0)
+// One workgroup per <= 256-entry chunk of a DIAGONAL pair (the other chunks leave at once), partial sums combined by the
+// pair's last chunk in chunk order: the same descriptors, partial-sum slots and arrival counters as k_schur_pairs, which
+// never runs at the same time.  (One workgroup per keyframe walked up to 2500 entries in ten dependent rounds: 21 us.)
 __global__ __launch_bounds__(256) void k_kfdiag(DevBuf d, int state) {
     __shared__ double s4[4];
     __shared__ double s_kc[KFCAM_STRIDE];
-    const int p = blockIdx.x;
-    const int i = d.pair_i[p];
-    if (i != d.pair_j[p]) return;
+    __shared__ double s_v[6];
+    __shared__ int s_lastc;
+    const ChunkMeta m = d.ch_meta[blockIdx.x];
+    const int i = m.ij & 0xffff, j = (m.ij >> 16) & 0xffff;
+    if (i != j) return;
     if (threadIdx.x == 0) kfcam_make(d.cam, d.kf[state] + (size_t)i * KF_STRIDE, s_kc);
     __syncthreads();
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int n = d.pair_start[p] + threadIdx.x; n < d.pair_start[p + 1]; n += 256) {
+    const int n = m.start + threadIdx.x;
+    if (n < m.end) {
         const bool is_pt = d.ent_slot[n] < d.Np;
         const EdgeRows r = load_rows(d, d.erec + (size_t)d.ent_pi[n] * EREC, s_kc, is_pt);
         double ja[6], jb[6];
         basis_apply(d.cam.Rcb, r.ga, ja);
         basis_apply(d.cam.Rcb, r.gb, jb);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) acc[c] += r.w * (ja[c] * ja[c] + jb[c] * jb[c]);
+        for (int c = 0; c < 6; ++c) acc[c] = r.w * (ja[c] * ja[c] + jb[c] * jb[c]);
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        double v = block_sum_256(acc[c], s4);
-        if (threadIdx.x == 0) d.kfdiag[i * 6 + c] = v;
+        const double v = block_sum_256(acc[c], s4);
+        if (threadIdx.x == 0) s_v[c] = v;
     }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (m.nch > 1) {
+        if (t < 6) __hip_atomic_store(&d.schur_part[(size_t)m.slot * 48 + t], s_v[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) s_lastc = (__hip_atomic_fetch_add(&d.pair_cnt[m.ch0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == m.nch - 1) ? 1 : 0;
+        __syncthreads();
+        if (!s_lastc) return;
+        if (t == 0) __hip_atomic_store(&d.pair_cnt[m.ch0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < 6) {
+            double sum = 0.0;
+            for (int c = 0; c < m.nch; ++c) sum += __hip_atomic_load(&d.schur_part[(size_t)(m.ch0 + c) * 48 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_v[t] = sum;
+        }
+    }
+    if (t < 6) d.kfdiag[i * 6 + t] = s_v[t];
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1227,6 +1250,12 @@ __global__ __launch_bounds__(256) void k_lambda_init(DevBuf d, LmParams lp, doub
     __shared__ double s4[4];
     if (fused) reduce_inline(d, nblk_edges, nblk_lm, red, s4);
     double md = 0.0;
+    if (first_iter && fused) {      // one GPU: the pose diagonal is formed here (k_posediag + k_posediag_kf as two passes of this workgroup)
+        for (int r = threadIdx.x; r < d.ld; r += 256) d.posediag[r] = (r < d.P) ? d.Himu[(size_t)r * d.ld + r] + d.Hconst[(size_t)r * d.ld + r] : 0.0;
+        __syncthreads();
+        for (int t = threadIdx.x; t < d.K * 6; t += 256) { const int o = d.kf_off_pvr[t / 6]; if (o >= 0) d.posediag[o + pmap(t % 6)] += d.kfdiag[t]; }
+        __syncthreads();
+    }
     if (first_iter) for (int r = threadIdx.x; r < d.P; r += 256) md = fmax(md, fabs(d.posediag[r]));
     double mx = block_max_256(md, s4);
     if (threadIdx.x == 0) {
@@ -1416,8 +1445,9 @@ bool launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv_assemble, bo
     hipLaunchKernelGGL(k_landmark_hll<false>, dim3(nb), dim3(LMB), sh, s, d, state, nb, 0);
     return false;
 }
-void launch_kfdiag(const DevBuf& d, int state, hipStream_t s) {
-    if (d.npairs) hipLaunchKernelGGL(k_kfdiag, dim3(d.npairs), dim3(256), 0, s, d, state);
+void launch_kfdiag(const DevBuf& d, int state, bool with_posediag, hipStream_t s) {
+    if (d.nchunks) hipLaunchKernelGGL(k_kfdiag, dim3(d.nchunks), dim3(256), 0, s, d, state);
+    if (!with_posediag) return;      // one GPU: k_lambda_init forms the pose diagonal itself
     hipLaunchKernelGGL(k_posediag, dim3((d.ld + 255) / 256), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_posediag_kf, dim3((d.K * 6 + 255) / 256), dim3(256), 0, s, d);
 }
