@@ -1272,7 +1272,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     } else if (w == "err_prior") { HIPCK(p, fetch(d.pr_err, p->pr_nv ? p->pr_n : 0, v)); }
     else if (w == "err_pt" || w == "err_ln") {
         std::vector<double> h; HIPCK(p, fetch(d.erec, (size_t)p->E * EREC, h));
-        if (w == "err_pt") { v.resize((size_t)p->Ep * 2); for (int e = 0; e < p->Ep; ++e) { const size_t o = (size_t)p->ob_pos[e] * EREC; v[2 * (size_t)e] = h[o + 13]; v[2 * (size_t)e + 1] = h[o + 14]; } }
+        if (w == "err_pt") { v.resize((size_t)p->Ep * 2); for (int e = 0; e < p->Ep; ++e) { const size_t o = (size_t)p->ob_pos[e] * EREC; v[2 * (size_t)e] = h[o + EREC_PT_E0]; v[2 * (size_t)e + 1] = h[o + EREC_PT_E0 + 1]; } }      // 64-byte point record
         else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { const size_t o = (size_t)p->ob_pos[p->Ep + e] * EREC; v[3 * (size_t)e] = h[o + 13]; v[3 * (size_t)e + 1] = h[o + 14]; } }
     } else if (w == "erec") { HIPCK(p, fetch(d.erec, (size_t)p->E * EREC, v)); }
     else if (w == "stamps") { HIPCK(p, fetch(d.maxd_part, 80, v)); }

@@ -169,10 +169,11 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
             double e2[2], rec[12];
             bool dpos;
             int kind;
+            V3 Pc = v3(0, 0, 0);
             if (e < d.Ep) {
                 kind = PLBA_EDGE_POINT;
                 const double2 uv = reinterpret_cast<const double2*>(d.po_uv)[e];
-                point_edge_rec(d.cam, kc, v3(L[0], L[1], L[2]), uv.x, uv.y, e2, rec, dpos, JAC);
+                point_edge_rec(d.cam, kc, v3(L[0], L[1], L[2]), uv.x, uv.y, e2, rec, dpos, false, &Pc);      // the record is Pc itself
             } else {
                 kind = PLBA_EDGE_LINE;
                 const double* l = d.lo_l + (size_t)(e - d.Ep) * 3;
@@ -183,18 +184,23 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
             if (rb.on[kind]) huber(chi, rb.delta[kind], r0, r1);
             rho = r0;
             d.ob_chi2[e] = chi;
-            if (JAC) {   // one full 128-byte line per observation, at its keyframe-major position
+            if (JAC) {   // at the observation's keyframe-major position: half a 128-byte line for a point, a full one for a line
                 double4* out = reinterpret_cast<double4*>(d.erec + (size_t)d.ob_pos[e] * EREC);
-                out[0] = make_double4(rec[0], rec[1], rec[2], rec[3]);
-                out[1] = make_double4(rec[4], rec[5], rec[6], rec[7]);
-                out[2] = make_double4(rec[8], rec[9], rec[10], rec[11]);
-                out[3] = make_double4(w0 * r1, e2[0], e2[1], chi);
+                if (e < d.Ep) {
+                    out[0] = make_double4(Pc.x, Pc.y, Pc.z, w0 * r1);
+                    out[1] = make_double4(e2[0], e2[1], chi, 0.0);
+                } else {
+                    out[0] = make_double4(rec[0], rec[1], rec[2], rec[3]);
+                    out[1] = make_double4(rec[4], rec[5], rec[6], rec[7]);
+                    out[2] = make_double4(rec[8], rec[9], rec[10], rec[11]);
+                    out[3] = make_double4(w0 * r1, e2[0], e2[1], chi);
+                }
             }
         } else if (JAC) {
             double4* out = reinterpret_cast<double4*>(d.erec + (size_t)d.ob_pos[e] * EREC);
             const double4 z = make_double4(0, 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) out[i] = z;
+            out[0] = z; out[1] = z;
+            if (e >= d.Ep) { out[2] = z; out[3] = z; }
         }
     }
     double bs = block_sum_256(rho, s4);
@@ -298,19 +304,23 @@ __global__ __launch_bounds__(LMB) void k_landmark_hll(DevBuf d, int state, int n
         const bool is_pt = slot < d.Np;
         while (ed < en) {      // lane `sub` of the group takes every LMG-th edge
             const double4* r4 = reinterpret_cast<const double4*>(d.erec + (size_t)pos * EREC);
-            const double4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
+            const double4 q0 = r4[0], q1 = r4[1];
+            double4 q2 = make_double4(0, 0, 0, 0), q3 = q2;
+            if (!is_pt) { q2 = r4[2]; q3 = r4[3]; }
             const int kf_now = kfi;
             if (lvl == 0) ++nact;
             ed += LMG;
             if (ed < en) { lvl = d.ob_level[ed]; pos = d.ob_pos[ed]; kfi = d.ob_kf[ed]; }
-            const double w = q3.x;
+            const double w = is_pt ? q0.w : q3.x;
             if (w == 0.0) continue;
             const double* kc = s_kc + kf_now * KFCAM_STRIDE;
             M3 M;
 #pragma unroll
             for (int i = 0; i < 9; ++i) M.a[i] = kc[i];
-            const V3 va = mulT(M, v3(q0.x, q0.y, q0.z)), vb = mulT(M, v3(q1.z, q1.w, q2.x));   // M^T uA, M^T uB
-            const double e0 = q3.y, e1 = q3.z;
+            V3 ua = v3(q0.x, q0.y, q0.z), ub = v3(q1.z, q1.w, q2.x);
+            if (is_pt) { V3 Pp; point_rows_from_Pc(d.cam, v3(q0.x, q0.y, q0.z), ua, ub, Pp); }
+            const V3 va = mulT(M, ua), vb = mulT(M, ub);   // M^T uA, M^T uB
+            const double e0 = is_pt ? q1.x : q3.y, e1 = is_pt ? q1.y : q3.z;
             if (is_pt) {   // Jl rows = -va^T, -vb^T on the same 3 coordinates
                 h[0] += w * (va.x * va.x + vb.x * vb.x); h[1] += w * (va.x * va.y + vb.x * vb.y); h[2] += w * (va.x * va.z + vb.x * vb.z);
                 h[3] += w * (va.y * va.y + vb.y * vb.y); h[4] += w * (va.y * va.z + vb.y * vb.z); h[5] += w * (va.z * va.z + vb.z * vb.z);
@@ -383,10 +393,19 @@ __global__ __launch_bounds__(LMB) void k_landmark_dinv(DevBuf d) {
 struct EdgeRows { V3 va, vb; double ga[6], gb[6], w, e0, e1; };
 DEV EdgeRows load_rows(const DevBuf& d, const double* rec, const double* kc, bool is_pt) {
     const double4* r4 = reinterpret_cast<const double4*>(rec);
-    const double4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
+    const double4 q0 = r4[0], q1 = r4[1];
     EdgeRows o;
-    rec_row(is_pt, d.fix_q1 != 0, kc, d.cam.Rcb, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o.va, o.ga);
-    rec_row(is_pt, d.fix_q1 != 0, kc, d.cam.Rcb, v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), o.vb, o.gb);
+    if (is_pt) {      // 64-byte point record: camera-frame point, weight, errors
+        V3 ua, ub, P;
+        point_rows_from_Pc(d.cam, v3(q0.x, q0.y, q0.z), ua, ub, P);
+        rec_row(true, d.fix_q1 != 0, kc, d.cam.Rcb, ua, P, o.va, o.ga);
+        rec_row(true, d.fix_q1 != 0, kc, d.cam.Rcb, ub, P, o.vb, o.gb);
+        o.w = q0.w; o.e0 = q1.x; o.e1 = q1.y;
+        return o;
+    }
+    const double4 q2 = r4[2], q3 = r4[3];
+    rec_row(false, d.fix_q1 != 0, kc, d.cam.Rcb, v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o.va, o.ga);
+    rec_row(false, d.fix_q1 != 0, kc, d.cam.Rcb, v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), o.vb, o.gb);
     o.w = q3.x; o.e0 = q3.y; o.e1 = q3.z;
     return o;
 }
@@ -414,7 +433,7 @@ __global__ __launch_bounds__(256) void k_kfdiag(DevBuf d, int state) {
         basis_apply(d.cam.Rcb, r.ga, ja);
         basis_apply(d.cam.Rcb, r.gb, jb);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) acc[c] = r.w * (ja[c] * ja[c] + jb[c] * jb[c]);
+        for (int c = 0; c < 6; ++c) acc[c] = (r.w != 0.0) ? r.w * (ja[c] * ja[c] + jb[c] * jb[c]) : 0.0;      // an inactive point's record is all zeros: its rows are not finite
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
@@ -518,8 +537,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const double4* rj4 = reinterpret_cast<const double4*>(d.erec + (size_t)pj * EREC);
         const double4* D4 = reinterpret_cast<const double4*>(d.dinv + (size_t)slot * 12);
         const double2* t2 = reinterpret_cast<const double2*>(d.tv + (size_t)slot * 6);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { qi[q] = ri4[q]; qj[q] = rj4[q]; }
+        qi[0] = ri4[0]; qi[1] = ri4[1]; qj[0] = rj4[0]; qj[1] = rj4[1];
+        const double4 z4 = make_double4(0.0, 0.0, 0.0, 0.0);
+        qi[2] = z4; qi[3] = z4; qj[2] = z4; qj[3] = z4;
+        if (!is_pt) { qi[2] = ri4[2]; qi[3] = ri4[3]; qj[2] = rj4[2]; qj[3] = rj4[3]; }      // point records are 64 bytes (plba_math.h)
 #pragma unroll
         for (int q = 0; q < 3; ++q) { const double4 v = D4[q]; D[4 * q] = v.x; D[4 * q + 1] = v.y; D[4 * q + 2] = v.z; D[4 * q + 3] = v.w; }
         (void)t2;
@@ -535,15 +556,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     SSTAMP(1);
     // per-lane factors of the entry's contribution  g_i Q g_j^T = ga_i T0^T + gb_i T1^T  (zero for an idle lane), then each
     // of the 36 (+12) sums goes through the wave reduction as soon as it is formed: 6 live accumulators instead of 48
-    const double wi = qi[3].x, wj = qj[3].x;
+    const double wi = is_pt ? qi[0].w : qi[3].x, wj = is_pt ? qj[0].w : qj[3].x;
+    const double ei0 = is_pt ? qi[1].x : qi[3].y, ei1 = is_pt ? qi[1].y : qi[3].z;
     const bool on = have && wi != 0.0 && wj != 0.0;
     double ga[6], gbv[6], T0[6], T1[6], f0 = 0.0, f1 = 0.0, e0 = 0.0, e1 = 0.0;
     {
         EdgeRows ri, rj;
-        rec_row(is_pt, d.fix_q1 != 0, s_kc, d.cam.Rcb, v3(qi[0].x, qi[0].y, qi[0].z), v3(qi[0].w, qi[1].x, qi[1].y), ri.va, ri.ga);
-        rec_row(is_pt, d.fix_q1 != 0, s_kc, d.cam.Rcb, v3(qi[1].z, qi[1].w, qi[2].x), v3(qi[2].y, qi[2].z, qi[2].w), ri.vb, ri.gb);
-        rec_row(is_pt, d.fix_q1 != 0, s_kc + KFCAM_STRIDE, d.cam.Rcb, v3(qj[0].x, qj[0].y, qj[0].z), v3(qj[0].w, qj[1].x, qj[1].y), rj.va, rj.ga);
-        rec_row(is_pt, d.fix_q1 != 0, s_kc + KFCAM_STRIDE, d.cam.Rcb, v3(qj[1].z, qj[1].w, qj[2].x), v3(qj[2].y, qj[2].z, qj[2].w), rj.vb, rj.gb);
+        V3 uia = v3(qi[0].x, qi[0].y, qi[0].z), Pia = v3(qi[0].w, qi[1].x, qi[1].y), uib = v3(qi[1].z, qi[1].w, qi[2].x), Pib = v3(qi[2].y, qi[2].z, qi[2].w);
+        V3 uja = v3(qj[0].x, qj[0].y, qj[0].z), Pja = v3(qj[0].w, qj[1].x, qj[1].y), ujb = v3(qj[1].z, qj[1].w, qj[2].x), Pjb = v3(qj[2].y, qj[2].z, qj[2].w);
+        if (is_pt) {
+            point_rows_from_Pc(d.cam, v3(qi[0].x, qi[0].y, qi[0].z), uia, uib, Pia); Pib = Pia;
+            point_rows_from_Pc(d.cam, v3(qj[0].x, qj[0].y, qj[0].z), uja, ujb, Pja); Pjb = Pja;
+        }
+        rec_row(is_pt, d.fix_q1 != 0, s_kc, d.cam.Rcb, uia, Pia, ri.va, ri.ga);
+        rec_row(is_pt, d.fix_q1 != 0, s_kc, d.cam.Rcb, uib, Pib, ri.vb, ri.gb);
+        rec_row(is_pt, d.fix_q1 != 0, s_kc + KFCAM_STRIDE, d.cam.Rcb, uja, Pja, rj.va, rj.ga);
+        rec_row(is_pt, d.fix_q1 != 0, s_kc + KFCAM_STRIDE, d.cam.Rcb, ujb, Pjb, rj.vb, rj.gb);
         double q00, q01, q10, q11;
         const double ww = wi * wj;
         if (is_pt) {
@@ -570,8 +598,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const double sl = is_pt ? -1.0 : 1.0;
             const V3 ta = v3(tl[0], tl[1], tl[2]);
             const V3 tb = is_pt ? ta : v3(tl[3], tl[4], tl[5]);
-            e0 = wi * qi[3].y; e1 = wi * qi[3].z;
-            f0 = wi * (qi[3].y + sl * dot(ri.va, ta)); f1 = wi * (qi[3].z + sl * dot(ri.vb, tb));
+            e0 = wi * ei0; e1 = wi * ei1;
+            f0 = wi * (ei0 + sl * dot(ri.va, ta)); f1 = wi * (ei1 + sl * dot(ri.vb, tb));
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

@@ -262,9 +262,22 @@ PLBA_HD ProjJac proj_jac(const Cam& cam, const double* kc, V3 Pc) {
 //                            world-frame position block, SURVEY B-Q1;  [ -u_a ; ... ] with fix_line_position_jacobian)
 // (derivation: -u^T hat(P) = (P x u)^T, and -u^T M = -(Rcb M^T u)^T Rcb.)
 constexpr int EREC = 16;
+// A POINT observation's record is its camera-frame point alone: both rows of the projection Jacobian (u_A, u_B) and
+// P_A = P_B follow from it and the intrinsics, with exactly the expressions of point_edge_rec.  Point records therefore
+// occupy only the first 64 bytes of their 128-byte slot,
+//   [0..2] Pc  [3] w  [4] e0  [5] e1  [6] chi2  [7] 0
+// which is what k_linearize writes and the landmark / Schur / back-substitution passes read for 5 observations in 6.
+constexpr int EREC_PT_W = 3, EREC_PT_E0 = 4;
+PLBA_HD void point_rows_from_Pc(const Cam& cam, V3 Pc, V3& ua, V3& ub, V3& P) {
+    const double iz = 1.0 / Pc.z;
+    ua = v3(cam.fx * iz, 0.0, -cam.fx * Pc.x * iz * iz);
+    ub = v3(0.0, cam.fy * iz, -cam.fy * Pc.y * iz * iz);
+    P = Pc + cam.c0;
+}
 
-PLBA_HD void point_edge_rec(const Cam& cam, const double* kc, V3 Pw, double u, double v, double* e2, double* rec12, bool& depth_pos, bool jac) {
+PLBA_HD void point_edge_rec(const Cam& cam, const double* kc, V3 Pw, double u, double v, double* e2, double* rec12, bool& depth_pos, bool jac, V3* Pc_out = nullptr) {
     V3 Pc = cam_Pc(cam, kc, Pw);
+    if (Pc_out) *Pc_out = Pc;
     const double iz = 1.0 / Pc.z;
     e2[0] = u - (Pc.x * iz * cam.fx + cam.cx);
     e2[1] = v - (Pc.y * iz * cam.fy + cam.cy);
