@@ -374,13 +374,14 @@ static int prepare(plba_problem* p) {
     for (int e = 0; e < Ep; ++e) { ob_kf[e] = p->po_kf[e]; ob_slot[e] = p->po_pt[e]; ob_w[e] = p->po_w[e]; lm_start[p->po_pt[e] + 1]++; }
     for (int e = 0; e < El; ++e) { ob_kf[Ep + e] = p->lo_kf[e]; ob_slot[Ep + e] = Np + p->lo_ln[e]; ob_w[Ep + e] = p->lo_w[e]; lm_start[Np + p->lo_ln[e] + 1]++; }
     for (int s = 0; s < L; ++s) lm_start[s + 1] += lm_start[s];
-    // keyframe-major record positions (stable: landmark order inside a keyframe)
+    // keyframe-major record positions (stable: landmark order inside a keyframe), in EREC_UNIT = 64-byte units: a point
+    // record takes one unit, a line record two, packed back to back (plba_math.h)
     p->ob_pos.assign(E, 0);
     {
         std::vector<int32_t> cntk(K + 1, 0);
-        for (int e = 0; e < E; ++e) cntk[ob_kf[e] + 1]++;
+        for (int e = 0; e < E; ++e) cntk[ob_kf[e] + 1] += (e < Ep) ? 1 : 2;
         for (int k = 0; k < K; ++k) cntk[k + 1] += cntk[k];
-        for (int e = 0; e < E; ++e) p->ob_pos[e] = cntk[ob_kf[e]]++;
+        for (int e = 0; e < E; ++e) { p->ob_pos[e] = cntk[ob_kf[e]]; cntk[ob_kf[e]] += (e < Ep) ? 1 : 2; }
     }
     p->lm0.assign((size_t)L * 6, 0.0);
     p->lm_fixed.assign(L, 0);
@@ -484,7 +485,7 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_po_uv.upload(p->po_uv)); HIPCK(p, p->d_lo_l.upload(p->lo_l)); HIPCK(p, p->d_ob_w.upload(ob_w));
     HIPCK(p, p->d_ob_kf.upload(ob_kf)); HIPCK(p, p->d_ob_slot.upload(ob_slot)); HIPCK(p, p->d_lm_start.upload(lm_start));
     HIPCK(p, p->d_level.upload(p->level)); HIPCK(p, p->d_lm_fixed.upload(p->lm_fixed));
-    HIPCK(p, p->d_ob_chi2.alloc(E)); HIPCK(p, p->d_erec.alloc((size_t)E * EREC)); HIPCK(p, p->d_depth.alloc(E));
+    HIPCK(p, p->d_ob_chi2.alloc(E)); HIPCK(p, p->d_erec.alloc(((size_t)Ep + 2 * (size_t)El) * EREC_UNIT + EREC)); HIPCK(p, p->d_depth.alloc(E));
     HIPCK(p, p->d_lm_active.alloc(L));
     HIPCK(p, p->d_hll.alloc((size_t)L * 12)); HIPCK(p, p->d_bl.alloc((size_t)L * 6)); HIPCK(p, p->d_dinv.alloc((size_t)L * 12));
     HIPCK(p, p->d_tv.alloc((size_t)L * 6)); HIPCK(p, p->d_xl.alloc((size_t)L * 6));
@@ -1271,10 +1272,10 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
         for (int m = 0; m < p->M; ++m) memcpy(&v[(size_t)m * nn], &h[(size_t)m * 16 + o], nn * 8);
     } else if (w == "err_prior") { HIPCK(p, fetch(d.pr_err, p->pr_nv ? p->pr_n : 0, v)); }
     else if (w == "err_pt" || w == "err_ln") {
-        std::vector<double> h; HIPCK(p, fetch(d.erec, (size_t)p->E * EREC, h));
-        if (w == "err_pt") { v.resize((size_t)p->Ep * 2); for (int e = 0; e < p->Ep; ++e) { const size_t o = (size_t)p->ob_pos[e] * EREC; v[2 * (size_t)e] = h[o + EREC_PT_E0]; v[2 * (size_t)e + 1] = h[o + EREC_PT_E0 + 1]; } }      // 64-byte point record
-        else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { const size_t o = (size_t)p->ob_pos[p->Ep + e] * EREC; v[3 * (size_t)e] = h[o + 13]; v[3 * (size_t)e + 1] = h[o + 14]; } }
-    } else if (w == "erec") { HIPCK(p, fetch(d.erec, (size_t)p->E * EREC, v)); }
+        std::vector<double> h; HIPCK(p, fetch(d.erec, ((size_t)p->Ep + 2 * (size_t)p->El) * EREC_UNIT, h));
+        if (w == "err_pt") { v.resize((size_t)p->Ep * 2); for (int e = 0; e < p->Ep; ++e) { const size_t o = (size_t)p->ob_pos[e] * EREC_UNIT; v[2 * (size_t)e] = h[o + EREC_PT_E0]; v[2 * (size_t)e + 1] = h[o + EREC_PT_E0 + 1]; } }      // 64-byte point record
+        else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { const size_t o = (size_t)p->ob_pos[p->Ep + e] * EREC_UNIT; v[3 * (size_t)e] = h[o + 13]; v[3 * (size_t)e + 1] = h[o + 14]; } }
+    } else if (w == "erec") { HIPCK(p, fetch(d.erec, ((size_t)p->Ep + 2 * (size_t)p->El) * EREC_UNIT, v)); }
     else if (w == "stamps") { HIPCK(p, fetch(d.maxd_part, 80, v)); }
     else if (w == "dbgbuf") { HIPCK(p, fetch(d.dbgbuf, 64, v)); }
     else if (w == "pose_dim") v = {(double)p->P};

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
             rho = r0;
             d.ob_chi2[e] = chi;
             if (JAC) {   // at the observation's keyframe-major position: half a 128-byte line for a point, a full one for a line
-                double4* out = reinterpret_cast<double4*>(d.erec + (size_t)d.ob_pos[e] * EREC);
+                double4* out = reinterpret_cast<double4*>(d.erec + (size_t)d.ob_pos[e] * EREC_UNIT);
                 if (e < d.Ep) {
                     out[0] = make_double4(Pc.x, Pc.y, Pc.z, w0 * r1);
                     out[1] = make_double4(e2[0], e2[1], chi, 0.0);
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
                 }
             }
         } else if (JAC) {
-            double4* out = reinterpret_cast<double4*>(d.erec + (size_t)d.ob_pos[e] * EREC);
+            double4* out = reinterpret_cast<double4*>(d.erec + (size_t)d.ob_pos[e] * EREC_UNIT);
             const double4 z = make_double4(0, 0, 0, 0);
             out[0] = z; out[1] = z;
             if (e >= d.Ep) { out[2] = z; out[3] = z; }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(LMB) void k_landmark_hll(DevBuf d, int state, int n
         int nact = 0;
         const bool is_pt = slot < d.Np;
         while (ed < en) {      // lane `sub` of the group takes every LMG-th edge
-            const double4* r4 = reinterpret_cast<const double4*>(d.erec + (size_t)pos * EREC);
+            const double4* r4 = reinterpret_cast<const double4*>(d.erec + (size_t)pos * EREC_UNIT);
             const double4 q0 = r4[0], q1 = r4[1];
             double4 q2 = make_double4(0, 0, 0, 0), q3 = q2;
             if (!is_pt) { q2 = r4[2]; q3 = r4[3]; }
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void k_kfdiag(DevBuf d, int state) {
     const int n = m.start + threadIdx.x;
     if (n < m.end) {
         const bool is_pt = d.ent_slot[n] < d.Np;
-        const EdgeRows r = load_rows(d, d.erec + (size_t)d.ent_pi[n] * EREC, s_kc, is_pt);
+        const EdgeRows r = load_rows(d, d.erec + (size_t)d.ent_pi[n] * EREC_UNIT, s_kc, is_pt);
         double ja[6], jb[6];
         basis_apply(d.cam.Rcb, r.ga, ja);
         basis_apply(d.cam.Rcb, r.gb, jb);
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     double4 qi[4], qj[4];
     double D[12], tl[6];
     {
-        const double4* ri4 = reinterpret_cast<const double4*>(d.erec + (size_t)pi * EREC);
-        const double4* rj4 = reinterpret_cast<const double4*>(d.erec + (size_t)pj * EREC);
+        const double4* ri4 = reinterpret_cast<const double4*>(d.erec + (size_t)pi * EREC_UNIT);
+        const double4* rj4 = reinterpret_cast<const double4*>(d.erec + (size_t)pj * EREC_UNIT);
         const double4* D4 = reinterpret_cast<const double4*>(d.dinv + (size_t)slot * 12);
         const double2* t2 = reinterpret_cast<const double2*>(d.tv + (size_t)slot * 6);
         qi[0] = ri4[0]; qi[1] = ri4[1]; qj[0] = rj4[0]; qj[1] = rj4[1];
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(LMB) void k_backsub(DevBuf d, int cur, int trial, C
         if (on) {
             const double sl = is_pt ? -1.0 : 1.0;
             while (ed < en) {      // lane `sub` takes every LMG-th edge; the next edge's indices travel while this one is processed
-                const double* rec = d.erec + (size_t)pos * EREC;
+                const double* rec = d.erec + (size_t)pos * EREC_UNIT;
                 const int k = kfi;
                 const EdgeRows r = load_rows(d, rec, s_kc + k * KFCAM_STRIDE, is_pt);
                 ed += LMG;

@@ -264,10 +264,11 @@ PLBA_HD ProjJac proj_jac(const Cam& cam, const double* kc, V3 Pc) {
 constexpr int EREC = 16;
 // A POINT observation's record is its camera-frame point alone: both rows of the projection Jacobian (u_A, u_B) and
 // P_A = P_B follow from it and the intrinsics, with exactly the expressions of point_edge_rec.  Point records therefore
-// occupy only the first 64 bytes of their 128-byte slot,
+// take 64 bytes (line records keep 128; both kinds are packed back to back in keyframe-major order),
 //   [0..2] Pc  [3] w  [4] e0  [5] e1  [6] chi2  [7] 0
 // which is what k_linearize writes and the landmark / Schur / back-substitution passes read for 5 observations in 6.
 constexpr int EREC_PT_W = 3, EREC_PT_E0 = 4;
+constexpr int EREC_UNIT = 8;        // record positions (ob_pos, ent_pi / ent_pj) count 64-byte units: 1 per point record, 2 per line record
 PLBA_HD void point_rows_from_Pc(const Cam& cam, V3 Pc, V3& ua, V3& ub, V3& P) {
     const double iz = 1.0 / Pc.z;
     ua = v3(cam.fx * iz, 0.0, -cam.fx * Pc.x * iz * iz);
