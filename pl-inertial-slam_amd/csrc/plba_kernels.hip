@@ -541,8 +541,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const double4 z4 = make_double4(0.0, 0.0, 0.0, 0.0);
         qi[2] = z4; qi[3] = z4; qj[2] = z4; qj[3] = z4;
         if (!is_pt) { qi[2] = ri4[2]; qi[3] = ri4[3]; qj[2] = rj4[2]; qj[3] = rj4[3]; }      // point records are 64 bytes (plba_math.h)
+        {   // a point's (Hll + lambda I)^-1 is one symmetric 3 x 3 (48 bytes); a line's two of them
+            const double4 v0 = D4[0];
+            const double2 v1 = reinterpret_cast<const double2*>(D4)[2];
+            D[0] = v0.x; D[1] = v0.y; D[2] = v0.z; D[3] = v0.w; D[4] = v1.x; D[5] = v1.y;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { const double4 v = D4[q]; D[4 * q] = v.x; D[4 * q + 1] = v.y; D[4 * q + 2] = v.z; D[4 * q + 3] = v.w; }
+            for (int q = 6; q < 12; ++q) D[q] = 0.0;
+            if (!is_pt) {
+                const double2 v2 = reinterpret_cast<const double2*>(D4)[3];
+                const double4 v3 = D4[2];
+                D[6] = v2.x; D[7] = v2.y; D[8] = v3.x; D[9] = v3.y; D[10] = v3.z; D[11] = v3.w;
+            }
+        }
         (void)t2;
     }
     if (t < 2) {
