@@ -707,6 +707,44 @@ static int prepare(plba_problem* p) {
     d.Ninv = nullptr; d.Nwork = nullptr;
     HIPCK(p, p->d_dbgbuf.alloc(64)); d.dbgbuf = p->d_dbgbuf.p;
     if (!p->chain_ok && p->P > 0 && p->Ppad / 32 <= NINV_MAX_T) { HIPCK(p, p->d_Ninv.alloc((size_t)2 * p->Ppad * p->ld)); d.Ninv = p->d_Ninv.p; d.Nwork = d.Ninv + (size_t)p->Ppad * p->ld; }
+    // ---- structural assembly list (assemble_part): with the chain elimination on, sys is written by the assembly pass and
+    // by k_schur_pairs only, so the entries neither of them can make non-zero never need touching again
+    d.alist = nullptr; d.nalist = 0;
+    if (p->chain_ok) {
+        std::vector<int32_t> al;
+        const int ld = p->ld;
+        auto add_full = [&](const std::vector<int>& dims) {
+            for (int a : dims) for (int b : dims) if (a >= 0 && b >= 0) al.push_back(a * ld + b);
+        };
+        for (int m = 0; m < M; ++m) {   // IMU PVR edge over [PVR_i | PVR_j | Bias_i], bias edge over [Bias_i | Bias_j]
+            const int ki = p->imu_i[m], kj = p->imu_j[m];
+            std::vector<int> e1, e2;
+            for (int c = 0; c < 9; ++c) e1.push_back(p->off_pvr[ki] >= 0 ? p->off_pvr[ki] + c : -1);
+            for (int c = 0; c < 9; ++c) e1.push_back(p->off_pvr[kj] >= 0 ? p->off_pvr[kj] + c : -1);
+            for (int c = 0; c < 6; ++c) { e1.push_back(p->off_bias[ki] >= 0 ? p->off_bias[ki] + c : -1); e2.push_back(p->off_bias[ki] >= 0 ? p->off_bias[ki] + c : -1); }
+            for (int c = 0; c < 6; ++c) e2.push_back(p->off_bias[kj] >= 0 ? p->off_bias[kj] + c : -1);
+            add_full(e1); add_full(e2);
+        }
+        {
+            std::vector<int> pd;
+            for (int a = 0; a < p->pr_nv; ++a) if (pr_off[a] >= 0) for (int c = 0; c < p->pr_size[a]; ++c) pd.push_back(pr_off[a] + c);
+            add_full(pd);
+        }
+        for (size_t q = 0; q < pair_i.size(); ++q) {      // the 6 x 6 blocks k_schur_pairs adds into, both mirror images
+            const int oi = p->off_pvr[pair_i[q]], oj = p->off_pvr[pair_j[q]];
+            for (int r : {0, 1, 2, 6, 7, 8}) for (int c : {0, 1, 2, 6, 7, 8}) { al.push_back((oi + r) * ld + oj + c); al.push_back((oj + c) * ld + oi + r); }
+        }
+        if (p->world > 1) {      // a sharded run's all-reduce brings in the OTHER ranks' pair blocks: every pose x pose entry is live
+            std::vector<int> pd;
+            for (int k = 0; k < K; ++k) if (p->off_pvr[k] >= 0) for (int c : {0, 1, 2, 6, 7, 8}) pd.push_back(p->off_pvr[k] + c);
+            add_full(pd);
+        }
+        for (int r = 0; r < p->Ppad; ++r) al.push_back(r * ld + r);
+        std::sort(al.begin(), al.end());
+        al.erase(std::unique(al.begin(), al.end()), al.end());
+        HIPCK(p, p->d_alist.upload(al));
+        d.alist = p->d_alist.p; d.nalist = (int)al.size();
+    }
     // ---- structural exchange list of a sharded run (k_list_pack): every lower-triangle entry of the reduced system that can be
     // non-zero before the factorisation.  Everything else is zero on every rank and need not travel.
     d.xlist = nullptr; d.nxlist = 0;

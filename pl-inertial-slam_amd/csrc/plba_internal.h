@@ -74,6 +74,8 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     const int32_t *pair_i, *pair_j, *pair_start, *ent_pi, *ent_pj, *ent_slot;   // entries: record positions + landmark slot
     const ChunkMeta* ch_meta;                                                   // <= 256-entry chunks of the pair lists (k_schur_pairs)
     double* schur_part;    // nchunks x 48 partial sums
+    const int32_t* alist;  // chain path: linear indices of the entries of sys the pose-side assembly has to rebuild (null: all of them)
+    int nalist;
     const int32_t* xlist;  // sharded runs: linear indices (r * ld + c, r >= c) of the lower-triangle entries that can be non-zero before the factorisation
     int nxlist;
     int* pair_cnt;         // arrival counters (indexed by a pair's first chunk slot), zero between launches
