@@ -8,11 +8,12 @@ stage 1 optimize(5) with Huber + chi2/depth gating run once untimed; the timed r
 stage 2 (optimize(10), no Huber on point/line edges) from the saved post-gating state until exactly
 K iterations have run.
 
-N = 1  : BASELINE configs[2] — 50 KF / 20k points / 4k lines + IMU (the metric's configuration).
-N > 1  : landmarks sharded over ranks, one RCCL all-reduce of the reduced camera system
-         per trial; weak scaling: every rank holds a 20k-point / 4k-line shard of a window whose
-         landmark count grows with N (N = 8, K = 200 is BASELINE configs[4]); `value` counts
-         shard-iterations (N per global LM iteration) so that it aggregates like a throughput.
+N = 1  : BASELINE configs[2] — 50 KF / 20k points / 4k lines + IMU (the metric's configuration); `--config 5` runs
+         BASELINE configs[4] (200 KF / 200k points / 40k lines + IMU) on the one GPU instead, and the default run carries
+         a short configs[4] leg as `config.configs4_single_gpu` (the N = 1 denominator of the scaling runs).
+N > 1  : BASELINE configs[4], ONE problem whose landmarks are sharded over the N ranks, one all-reduce
+         (RCCL over xGMI) of the structurally non-zero part of the reduced camera system per trial: strong scaling,
+         `value` = GLOBAL LM iterations per second of that one window.
 
 Prints ONE JSON line on rank 0.
 """
@@ -38,13 +39,28 @@ def stage1_and_gate(prob, pkg):
     prob.save_state()
 
 
+def csrc_sha16():
+    """hash of the kernel sources: a PMC summary is only quoted for the build it was measured on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "pl-inertial-slam_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_prefix):
-    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r01_pmc_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied); None if absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r02_pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied, tools/rocpd_extract.py).
+    PMC counters cannot be collected from inside this process, so the file is tied to the build it came from by a hash of
+    csrc/: None when the file is absent or was measured on different kernel sources (never a stale number)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
-        ks = json.load(open(path))["kernels"]
+        js = json.load(open(path))
+        ks = js["kernels"]
     except (OSError, ValueError, KeyError):
+        return None
+    if js.get("csrc_sha16") != csrc_sha16():
         return None
     for name, v in ks.items():
         if kernel_prefix in name and "traffic_bytes_per_launch" in v:
@@ -109,6 +125,28 @@ def parity_and_config4(w, pkg):
     return d, c4
 
 
+def config5_leg(pkg, stream, iters=30):
+    """BASELINE configs[4] (200 KF / 200k points / 40k lines + IMU) on ONE GPU: the N = 1 denominator of the N > 1 runs,
+    which strong-scale exactly this window.  Same protocol as the main leg, fewer iterations."""
+    import torch
+    w = pkg.window.make_config(5)
+    prob = pkg.new_problem()
+    prob.set_stream(stream.cuda_stream)
+    prob.upload_window(w)
+    stage1_and_gate(prob, pkg)
+    run_iterations(prob, 5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done, trials, _ = run_iterations(prob, iters)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = dict(workload="configs[4]: 200 KF / 200k points / 40k lines + IMU, one GPU", iterations_per_s=done / dt, ms_per_iteration=dt / done * 1e3,
+               steps=done, trials_per_iteration=trials / max(done, 1), point_obs=int(w["meta"]["Ep"]), line_obs=int(w["meta"]["El"]),
+               pose_dim=int(prob.debug_get("pose_dim")[0]), dense_dim=int(prob.debug_get("dense_dim")[0]))
+    prob.close()
+    return out
+
+
 def cpu_baseline(w, pkg, budget_s=20.0):
     """The CPU oracle (restatement of the reference's g2o path) timed on this box's host cores on a
     bounded sample of the same window: stage-2 LM iterations until ~budget_s of CPU work."""
@@ -136,6 +174,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5-leg", action="store_true", help="skip the short configs[4] single-GPU leg of the default run")
+    ap.add_argument("--config", type=int, default=0, help="BASELINE config (1-based): 3 = configs[2] (default at N = 1), 5 = configs[4] (always at N > 1)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink landmark counts (debug only; invalidates the number)")
     ap.add_argument("--kf", type=int, default=0, help="override the keyframe count (debug only)")
     ap.add_argument("--fb", type=int, default=0, help="dense factorisation block width (32/64); 0 = library default")
@@ -171,17 +211,19 @@ def main():
     win = pkg.window
 
     # ---- workload -------------------------------------------------------------------------------
-    if world == 1:
-        cfg = dict(win.CONFIGS[3])
+    cfg_idx = args.config if args.config else (3 if world == 1 else 5)
+    if cfg_idx not in (3, 5) or (world > 1 and cfg_idx != 5):
+        raise SystemExit("--config must be 3 (N = 1) or 5")
+    cfg = dict(win.CONFIGS[cfg_idx])
+    if cfg_idx == 3:
         name = "configs[2]: 50 KF / 20k points / 4k lines + IMU preintegration edges (9-DoF PVR + 6-DoF bias vertices)"
     else:
-        # weak scaling: the configs[2] keyframe window with configs[2]'s landmark count PER RANK (landmarks are what shards)
-        cfg = dict(K=50, Np=20000 * world, Nl=4000 * world, imu=True)
-        name = "%d KF / %d points / %d lines + IMU, landmarks sharded over %d ranks" % (cfg["K"], cfg["Np"], cfg["Nl"], world)
+        name = "configs[4]: 200 KF / 200k points / 40k lines + IMU preintegration edges" + (
+            ", landmarks sharded over %d ranks, one all-reduce of the reduced pose normal equations per LM trial" % world if world > 1 else ", one GPU")
     if args.kf:
         cfg["K"] = args.kf
     cfg["Np"] = max(1, int(cfg["Np"] * args.scale)); cfg["Nl"] = max(1, int(cfg["Nl"] * args.scale))
-    w_full = win.make_window(cfg["K"], cfg["Np"], cfg["Nl"], imu=cfg["imu"], seed=0x5EED0003 if world == 1 else 0x5EED0005)
+    w_full = win.make_window(cfg["K"], cfg["Np"], cfg["Nl"], imu=cfg["imu"], seed=0x5EED0000 + cfg_idx)
     w = win.shard_window(w_full, rank, world) if world > 1 else w_full
 
     stream = torch.cuda.Stream()
@@ -191,8 +233,32 @@ def main():
     prob = pkg.new_problem(profile=1, **extra)
     prob.set_stream(stream.cuda_stream)
     prob.upload_window(w)
+    # N > 1: the exchange hook is C++ on RCCL (include/plba_rccl.h: ncclAllReduce on the library's stream, a communicator of its
+    # own, no Python inside the LM loop); torch.distributed only carries rank 0's ncclUniqueId.  Fallback (recorded in the
+    # JSON line): the same collective through torch.distributed.all_reduce from a ctypes callback.
+    xch, xch_kind = None, None
     if world > 1:
-        prob.set_shard(rank, world, pkg.distributed.make_allreduce(dist, local_rank, stream, via_host=rehearsal))
+        if not rehearsal and os.environ.get("PLBA_BENCH_TORCH_EXCHANGE") != "1":
+            try:
+                ge.build_rccl()
+                xch = pkg.distributed.RcclExchange(dist, rank, world)
+                xch_kind = "libplba_rccl.so: ncclAllReduce (C++)"
+            except Exception as e:      # noqa: BLE001 — any failure to bring the native hook up must not lose the run
+                print("rank %d: native RCCL hook unavailable (%s); using torch.distributed" % (rank, e), file=sys.stderr)
+                xch = None
+        ok = torch.tensor([1 if xch is not None else 0], device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks or none
+        if int(ok.item()) == 0:
+            xch, xch_kind = None, "torch.distributed.all_reduce (%s) from a ctypes callback" % ("gloo, host-staged rehearsal" if rehearsal else "nccl = RCCL")
+
+    def attach(pb):
+        if world == 1:
+            return
+        if xch is not None:
+            xch.attach(pb)
+        else:
+            pb.set_shard(rank, world, pkg.distributed.make_allreduce(dist, local_rank, stream, via_host=rehearsal))
+    attach(prob)
 
     stage1_and_gate(prob, pkg)
     run_iterations(prob, max(args.warmup, 1))
@@ -213,11 +279,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    m = w["meta"] if world == 1 else dict(Ep=len(w["po_pt"]), El=len(w["lo_ln"]), Np=len(w["points"]), Nl=len(w["lines"]))
-    Ep, El, Npl, Nll = (m["Ep"], m["El"], m["Np"], m["Nl"])
     # algorithmic bytes: 32 B per point observation, 40 B per line observation, landmarks 24 / 48 B
-    bytes_lin = 32 * Ep + 40 * El + 24 * Npl + 48 * Nll                 # one k_linearize launch
-    b_iter = 2 * (32 * Ep + 40 * El) + 3 * (24 * Npl + 48 * Nll)        # one LM iteration
+    mg = w_full["meta"]
+    Ep, El = mg["Ep"], mg["El"]
+    b_iter = 2 * (32 * Ep + 40 * El) + 3 * (24 * mg["Np"] + 48 * mg["Nl"])        # one LM iteration of the whole window (all ranks)
+    bytes_lin = 32 * len(w["po_pt"]) + 40 * len(w["lo_ln"]) + 24 * len(w["points"]) + 48 * len(w["lines"])      # one k_linearize launch on THIS rank's shard
     P = int(prob.debug_get("pose_dim")[0])
     fb = args.fb if args.fb else 32
     Pdense = int(prob.debug_get("dense_dim")[0])                          # = P unless chain_elim reduced the dense part
@@ -232,8 +298,7 @@ def main():
     prob2 = pkg.new_problem(profile=2, **extra)
     prob2.set_stream(stream.cuda_stream)
     prob2.upload_window(w)
-    if world > 1:
-        prob2.set_shard(rank, world, pkg.distributed.make_allreduce(dist, local_rank, stream, via_host=rehearsal))
+    attach(prob2)
     stage1_and_gate(prob2, pkg)
     done2, trials2, phases2 = run_iterations(prob2, min(args.steps, 50))
     sync()
@@ -254,17 +319,17 @@ def main():
     roofline = roof_mfma
 
     out = {
-        "metric": "local-BA iterations/sec (50 KF, 20k pts, 4k lines, IMU)",
-        "value": world * done / dt,
+        "metric": "local-BA iterations/sec (50 KF, 20k pts, 4k lines, IMU)" if cfg_idx == 3 else "local-BA iterations/sec (200 KF, 200k pts, 40k lines, IMU)",
+        "value": done / dt,
         "unit": "iterations/s",
         "n_gpus": world, "steps": done, "warmup": args.warmup, "ms_per_step": dt / done * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": name, "K": cfg["K"], "points": cfg["Np"], "lines": cfg["Nl"], "point_obs": int(Ep), "line_obs": int(El),
                    "pose_dim": P, "trials_per_iteration": trials / max(done, 1), "protocol": "stage-2 LM iterations (no Huber on point/line edges) replayed from the post-gating state",
-                   "global_iterations_per_s": done / dt,
-                   "value_definition": "N x global LM iterations/s: every rank iterates a full-size landmark shard (per-GPU work fixed as N grows)",
+                   "global_iterations_per_s": done / dt, "dense_dim": Pdense, "exchange": xch_kind,
+                   "value_definition": "global LM iterations/s of ONE window (total work fixed as N grows: its landmarks are sharded over the N ranks)",
                    "algorithmic_bytes_per_iteration": b_iter,
-                   "hbm_frac_whole_iteration": b_iter / (dt / done) / 1e9 / HBM_PEAK_GBS},
+                   "hbm_frac_whole_iteration": b_iter / (dt / done) / 1e9 / (HBM_PEAK_GBS * world)},
         "roofline": roofline,
         "roofline_hbm_kernel": roof_hbm,
         "phase_ms_per_iteration": per_iter,
@@ -288,11 +353,15 @@ def main():
             e2e = dt2 if e2e is None else min(e2e, dt2)
         out["config"]["end_to_end_ba_call_ms"] = e2e * 1e3
         out["config"]["end_to_end_iterations_per_s"] = (r2["stage1"].iterations + r2["stage2"].iterations) / e2e
+    if world == 1 and cfg_idx == 3 and not args.no_config5_leg:
+        out["config"]["configs4_single_gpu"] = config5_leg(pkg, stream)
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and cfg_idx == 3:
             out["max_pose_delta_vs_cpu"], out["config4_sliding_window"] = parity_and_config4(w_full, pkg)
             out["cpu_baseline"] = cpu_baseline(w_full, pkg)
         else:
+            # N > 1: the CPU leg belongs to the N = 1 line (contract); configs[4]: one oracle iteration takes longer than the
+            # whole bench budget (P = 2985 dense Cholesky + 1 M observations on one thread), its parity is tests/test_large_configs.py
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if prob is not None:

@@ -279,6 +279,12 @@ class Problem:
         self._cb = ALLREDUCE_FN(_tramp)
         self.call("set_shard", rank, world, self._cb, None)
 
+    def set_shard_native(self, rank, world, fn_addr, user_ptr):
+        """plba_set_shard with a NATIVE plba_allreduce_fn (e.g. plba_rccl_allreduce of include/plba_rccl.h) and its user
+        pointer: no Python frame runs inside the LM loop."""
+        self._cb = C.cast(C.c_void_p(fn_addr), ALLREDUCE_FN)
+        self.call("set_shard", rank, world, self._cb, C.c_void_p(user_ptr))
+
     def set_stream(self, stream_handle):
         self.call("set_stream", C.c_void_p(stream_handle))
 

@@ -534,6 +534,7 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_pr_x0.upload(p->pr_x0)); HIPCK(p, p->d_pr_J0.upload(p->pr_J0)); HIPCK(p, p->d_pr_r0.upload(p->pr_r0));
     HIPCK(p, p->d_pr_err.alloc(p->pr_n)); HIPCK(p, p->d_pr_dx.alloc(p->pr_n)); HIPCK(p, p->d_pr_chi.alloc(1));
     HIPCK(p, p->d_Hconst.alloc((size_t)p->Ppad * p->ld)); HIPCK(p, p->d_Himu.alloc((size_t)p->Ppad * p->ld)); HIPCK(p, p->d_Himu2.alloc((size_t)p->Ppad * p->ld)); HIPCK(p, p->d_bimu2.alloc(p->ld));
+    HIPCK(p, p->d_bprior.alloc(p->ld)); HIPCK(p, p->d_bprior2.alloc(p->ld));
     HIPCK(p, p->d_bimu.alloc(p->ld)); HIPCK(p, p->d_sys.alloc(sysn)); HIPCK(p, p->d_Lfac.alloc(sysn));
     HIPCK(p, p->d_bpg.alloc(p->ld)); HIPCK(p, p->d_x.alloc(p->ld));
     HIPCK(p, p->d_Linv.alloc((size_t)(p->Ppad / TILE) * TILE * TILE)); HIPCK(p, p->d_flow_flags.alloc(p->Ppad / TILE)); p->flow_epoch = 0;
@@ -571,7 +572,7 @@ static int prepare(plba_problem* p) {
     d.pr_kf = p->d_pr_kf.p; d.pr_isbias = p->d_pr_isbias.p; d.pr_size = p->d_pr_size.p; d.pr_idx = p->d_pr_idx.p;
     d.pr_x0off = p->d_pr_x0off.p; d.pr_off = p->d_pr_off.p; d.pr_x0 = p->d_pr_x0.p; d.pr_J0 = p->d_pr_J0.p; d.pr_r0 = p->d_pr_r0.p;
     d.pr_err = p->d_pr_err.p; d.pr_dx = p->d_pr_dx.p; d.pr_chi = p->d_pr_chi.p;
-    d.Hconst = p->d_Hconst.p; d.Himu = p->d_Himu.p; d.bimu = p->d_bimu.p; d.Himu_alt = p->d_Himu2.p; d.bimu_alt = p->d_bimu2.p; d.sys = p->d_sys.p; d.Lfac = p->d_Lfac.p; d.bpg = p->d_bpg.p; d.x = p->d_x.p;
+    d.Hconst = p->d_Hconst.p; d.Himu = p->d_Himu.p; d.bimu = p->d_bimu.p; d.Himu_alt = p->d_Himu2.p; d.bimu_alt = p->d_bimu2.p; d.bprior = p->d_bprior.p; d.bprior_alt = p->d_bprior2.p; d.sys = p->d_sys.p; d.Lfac = p->d_Lfac.p; d.bpg = p->d_bpg.p; d.x = p->d_x.p;
     d.Linv = p->d_Linv.p; d.flow_flags = p->d_flow_flags.p; d.LTblk = p->d_LT32.p; d.Linv32 = p->d_LT32.p; d.rdblk = p->d_rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32; d.chol_flags = p->d_chol_flags.p; d.flow = p->opt.factor_flow != 0; d.wide = p->opt.wide_steps != 0 && !d.flow;
     d.chi_part = p->d_chi_part.p; d.scale_part = p->d_scale_part.p; d.maxd_part = p->d_maxd_part.p; d.kfdiag = p->d_kfdiag.p; d.posediag = p->d_posediag.p;
     d.ctrl = p->d_ctrl.p; d.trace = p->d_trace.p; d.trace_cap = TRACE_CAP; d.trace_n = p->d_trace_n.p;
@@ -966,7 +967,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             bool spec = false;
             if (p->opt.profile < 2 && it + 1 < max_iters) {
                 DevBuf ds = d;
-                std::swap(ds.Himu, ds.Himu_alt); std::swap(ds.bimu, ds.bimu_alt);
+                std::swap(ds.Himu, ds.Himu_alt); std::swap(ds.bimu, ds.bimu_alt); std::swap(ds.bprior, ds.bprior_alt);
                 launch_linearize(ds, trial, true, p->rob, owns_pose_edges(p), s, true);
                 spec = true;
             }
@@ -995,7 +996,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             rho = c.rho;
             lambda = c.lambda;
             st.trials++;
-            if (c.accepted) { p->cur ^= 1; last_chi = c.current_chi; std::swap(p->dv.Himu, p->dv.Himu_alt); std::swap(p->dv.bimu, p->dv.bimu_alt); p->spec_lin = spec; }
+            if (c.accepted) { p->cur ^= 1; last_chi = c.current_chi; std::swap(p->dv.Himu, p->dv.Himu_alt); std::swap(p->dv.bimu, p->dv.bimu_alt); std::swap(p->dv.bprior, p->dv.bprior_alt); p->spec_lin = spec; }
             else if (!std::isfinite(lambda)) break;
             qmax++;
         } while (rho < 0 && qmax < lp.max_trials && !(abort_flag && *abort_flag));

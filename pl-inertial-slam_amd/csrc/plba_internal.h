@@ -91,6 +91,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     const double *pr_x0, *pr_J0, *pr_r0;
     double *pr_err, *pr_dx, *pr_chi;
     // dense
+    double *bprior, *bprior_alt;   // gradient of the prior edge (plain stores, swapped with the IMU accumulators)
     double *Hconst, *Himu, *bimu, *Himu_alt, *bimu_alt, *sys, *Lfac, *bpg, *x, *Linv32;   // Lfac: Cholesky factor (same shape as sys)
     double *Ninv, *Nwork;  // Ppad x ld each: N = L^-T, carried through the factorisation launches as identity rows of the augmented system
                            // (Nwork: the rows' unsolved trailing part); null: substitution instead

@@ -239,7 +239,7 @@ DEV void assemble_part(const DevBuf& d, int add_lambda, int bid, int nblocks, in
                 d.sys[idx] = v;
             } else {
                 const int q = (int)(k - n), row = q / d.ld, c = q - row * d.ld;
-                const double v = d.bimu[c];
+                const double v = d.bimu[c] + d.bprior[c];
                 if (row == 0) { d.bpg[c] = v; d.bimu_alt[c] = 0.0; }
                 d.sys[(size_t)(d.Ppad + row) * d.ld + c] = v;
             }
@@ -255,7 +255,7 @@ DEV void assemble_part(const DevBuf& d, int add_lambda, int bid, int nblocks, in
             if (r == c && add_lambda) v += (r < d.P) ? lambda : 1.0;
             d.Himu_alt[idx] = 0.0;                // the accumulator the NEXT outer iteration's pose-side edges add into
         } else if (r <= d.Ppad + 1) {
-            v = d.bimu[c];
+            v = d.bimu[c] + d.bprior[c];
             if (r == d.Ppad) { d.bpg[c] = v; d.bimu_alt[c] = 0.0; }
         }
         d.sys[idx] = v;
@@ -1164,6 +1164,10 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) s += sJ[k * 24 + a] * sOJ[k * 24 + b];
+        // the bias edge's own (Bias_i, Bias_i) term joins here, so that every destination receives ONE add per workgroup: with
+        // the neighbouring edge's workgroup that makes two adders per address, and a two-term sum does not depend on the
+        // order of the atomics (bit-reproducible pose-side system)
+        if (a >= 18 && b >= 18) s += wb * Ob[(a - 18) * 6 + (b - 18)];
         if (s != 0.0) atomicAdd(&d.Himu[(size_t)oa * ld + ob], s);
     }
     if (lane < 24) {
@@ -1172,6 +1176,12 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < 9; ++k) s += sOJ[k * 24 + lane] * sE[k];
+            if (lane >= 18) {      // + the bias edge's gradient on Bias_i
+                double sb = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) sb += Ob[(lane - 18) * 6 + c] * sE[9 + c];
+                s -= wb * sb;
+            }
             atomicAdd(&d.bimu[oa], -s);
         }
     }
@@ -1185,8 +1195,7 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
             const int r = lane / 6, c = lane % 6;
             const double v = wb * Ob[r * 6 + c];
             if (v != 0.0) {
-                if (oi >= 0) atomicAdd(&d.Himu[(size_t)(oi + r) * ld + oi + c], v);
-                if (oj >= 0) atomicAdd(&d.Himu[(size_t)(oj + r) * ld + oj + c], v);
+                if (oj >= 0) atomicAdd(&d.Himu[(size_t)(oj + r) * ld + oj + c], v);      // (Bias_i, Bias_i): added with the PVR edge's block above
                 if (oi >= 0 && oj >= 0) {
                     atomicAdd(&d.Himu[(size_t)(oi + r) * ld + oj + c], -v);
                     atomicAdd(&d.Himu[(size_t)(oj + r) * ld + oi + c], -v);
@@ -1198,8 +1207,7 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
 #pragma unroll
             for (int c = 0; c < 6; ++c) s += Ob[r * 6 + c] * sE[9 + c];
             s *= wb;
-            if (oi >= 0) atomicAdd(&d.bimu[oi + r], s);
-            if (oj >= 0) atomicAdd(&d.bimu[oj + r], -s);
+            if (oj >= 0) atomicAdd(&d.bimu[oj + r], -s);      // Bias_i's share went out with the PVR edge's gradient above
         }
     }
 }
@@ -1241,7 +1249,7 @@ DEV void prior_block(const DevBuf& d, int state) {
             const double* col = d.pr_J0 + (size_t)(ix + c) * n;
             double sacc = 0.0;
             for (int r = 0; r < n; ++r) sacc += col[r] * d.pr_err[r];
-            atomicAdd(&d.bimu[o + c], -sacc);
+            d.bprior[o + c] = -sacc;      // a vector of its own (added by the assembly pass): the IMU edges' atomics stay two per address
         }
     }
 }

@@ -14,8 +14,12 @@
 //                then the keyframe block of the reduced system) — identical to the dense pseudo-inverse
 //                whenever the discarded eigen-directions are block-local null spaces (rank-deficient landmark
 //                blocks), which is the case the threshold exists for.
-//            (4) A' = V S V^T by one-sided Jacobi (one workgroup per column pair, one launch per round),
-//                J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b'              (cpp:364-372)
+//            (4) A' = V S V^T by one-sided Jacobi, J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b'   (cpp:364-372).
+//                n <= 100 (the reference's 12-keyframe window keeps <= 7 x 9 + 6 + the old prior's vertices): ONE
+//                workgroup holds G = A'V and V in LDS (2 n^2 doubles <= 160 KB) and runs every round of every sweep
+//                without leaving the CU; larger n: one launch per round (k_jacobi_round).
+//   One stream synchronisation per call: index lists go up through the pinned staging area before the first launch,
+//   results come back through it in two asynchronous copies.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -37,7 +41,7 @@ constexpr int MAXB = 15;   // largest block eliminated at once (PVR 9 + bias 6)
 // ---- (1) factor evaluation -------------------------------------------------------------------------------------
 struct MargObs { int edge; int row; int col_lm; int col_kf; };
 
-__global__ void k_marg_obs(DevBuf d, int state, const MargObs* f, int nf, double* J, double* r, int R) {
+MDEV void marg_obs(const DevBuf& d, int state, const MargObs* f, int nf, double* J, double* r, int R) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nf) return;
     const MargObs o = f[i];
@@ -66,8 +70,8 @@ __global__ void k_marg_obs(DevBuf d, int state, const MargObs* f, int nf, double
     }
 }
 
-__global__ void k_marg_imu(DevBuf d, int state, int m, int row, int c_pi, int c_pj, int c_bi, int c_bj, double* J, double* r, int R) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+MDEV void marg_imu(const DevBuf& d, int state, int m, int row, int c_pi, int c_pj, int c_bi, int c_bj, double* J, double* r, int R) {
+    if (threadIdx.x != 0) return;
     const double* si = d.kf[state] + (size_t)d.imu_i[m] * KF_STRIDE;
     const double* sj = d.kf[state] + (size_t)d.imu_j[m] * KF_STRIDE;
     const double* pre = d.imu_pre + (size_t)m * PRE_STRIDE;
@@ -90,16 +94,25 @@ __global__ void k_marg_imu(DevBuf d, int state, int m, int row, int c_pi, int c_
 }
 
 // old prior as a factor: residual = EdgeMarginalization error at the final estimate, Jacobian = J0 columns
-__global__ void k_marg_prior(DevBuf d, int row, const int* vcol, double* J, double* r, int R) {
-    const int n = d.pr_n;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) r[row + t] = d.pr_err[t];
+MDEV void marg_prior(const DevBuf& d, int blk, int nblk, int row, const int* vcol, double* J, double* r, int R) {
+    const int n = d.pr_n, stride = nblk * blockDim.x, first = blk * blockDim.x + threadIdx.x;
+    for (int t = first; t < n; t += stride) r[row + t] = d.pr_err[t];
     for (int v = 0; v < d.pr_nv; ++v) {
         const int sz = d.pr_size[v], ix = d.pr_idx[v], col = vcol[v];
-        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < sz * n; t += gridDim.x * blockDim.x) {
+        for (int t = first; t < sz * n; t += stride) {
             const int c = t / n, rr = t % n;
             J[(size_t)(col + c) * R + row + rr] = d.pr_J0[(size_t)(ix + c) * n + rr];
         }
     }
+}
+// one launch for every selected factor: blocks [0, ob) observation edges (a lane each), [ob, ob + nimu) one IMU edge pair each,
+// the rest copy the old prior's rows
+__global__ __launch_bounds__(64) void k_marg_factors(DevBuf d, int state, const MargObs* f, int nf, int ob, const int* imu, int nimu, int prior_row,
+                                                    const int* vcol, double* J, double* r, int R) {
+    const int b = blockIdx.x;
+    if (b < ob) { marg_obs(d, state, f, nf, J, r, R); return; }
+    if (b < ob + nimu) { const int* q = imu + 6 * (b - ob); marg_imu(d, state, q[0], q[1], q[2], q[3], q[4], q[5], J, r, R); return; }
+    marg_prior(d, b - ob - nimu, gridDim.x - ob - nimu, prior_row, vcol, J, r, R);
 }
 
 __global__ void k_jt_r(const double* J, const double* r, int R, int pos, double* b) {
@@ -159,6 +172,15 @@ __global__ void k_block_Z(const double* A, int pos, const int* boff, const int* 
         Z[(size_t)row * pos + o + c] = acc;
     }
 }
+__global__ void k_block_Z1(const double* A, int pos, int o, int s, const double* P, double* Z) {      // one block at offset o
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= pos) return;
+    for (int c = 0; c < s; ++c) {
+        double acc = 0.0;
+        for (int t = 0; t < s; ++t) acc += A[(size_t)row * pos + o + t] * P[t * MAXB + c];
+        Z[(size_t)row * pos + o + c] = acc;
+    }
+}
 // A[r][c] -= sum_{k in elim} Z[r][k] A[k][c],  b[r] -= sum Z[r][k] b[k]   for r, c in `rest`
 __global__ void k_schur_apply(double* A, double* b, int pos, const double* Z, const int* elim, int nelim, const uint8_t* is_rest) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y * blockDim.y + threadIdx.y;
@@ -167,6 +189,157 @@ __global__ void k_schur_apply(double* A, double* b, int pos, const double* Z, co
     double acc = 0.0;
     if (c == pos) { for (int t = 0; t < nelim; ++t) { const int k = elim[t]; acc += Z[(size_t)r * pos + k] * b[k]; } b[r] -= acc; }
     else { for (int t = 0; t < nelim; ++t) { const int k = elim[t]; acc += Z[(size_t)r * pos + k] * A[(size_t)k * pos + c]; } A[(size_t)r * pos + c] -= acc; }
+}
+
+
+// landmark blocks in registers: S = 3 (point) / 6 (line), everything unrolled so that M and V never touch scratch memory
+template <int S>
+MDEV void pinv_small(const double* A, int pos, int o, double eps, double* out) {
+    double M[S][S], V[S][S];
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            M[i][j] = 0.5 * (A[(size_t)(o + i) * pos + o + j] + A[(size_t)(o + j) * pos + o + i]);   // cpp:351
+            V[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0.0, dg = 0.0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            dg += M[i][i] * M[i][i];
+#pragma unroll
+            for (int j = i + 1; j < S; ++j) off += M[i][j] * M[i][j];
+        }
+        if (off <= 1e-32 * (dg + off) || off == 0.0) break;
+#pragma unroll
+        for (int p = 0; p < S - 1; ++p)
+#pragma unroll
+            for (int q = p + 1; q < S; ++q) {
+                const double apq = M[p][q];
+                if (apq != 0.0) {
+                    const double th = (M[q][q] - M[p][p]) / (2.0 * apq);
+                    const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+                    for (int k = 0; k < S; ++k) { const double a = M[k][p], b = M[k][q]; M[k][p] = c * a - sn * b; M[k][q] = sn * a + c * b; }
+#pragma unroll
+                    for (int k = 0; k < S; ++k) { const double a = M[p][k], b = M[q][k]; M[p][k] = c * a - sn * b; M[q][k] = sn * a + c * b; }
+#pragma unroll
+                    for (int k = 0; k < S; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - sn * b; V[k][q] = sn * a + c * b; }
+                }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < S; ++k) { const double w = M[k][k]; if (w > eps) acc += V[i][k] * V[j][k] / w; }
+            out[i * MAXB + j] = acc;
+        }
+}
+__global__ void k_block_pinv_small(const double* A, int pos, const int* boff, const int* bsize, int nblk, double eps, double* Pinv) {
+    const int bi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bi >= nblk) return;
+    double* out = Pinv + (size_t)bi * MAXB * MAXB;
+    if (bsize[bi] == 3) pinv_small<3>(A, pos, boff[bi], eps, out);
+    else pinv_small<6>(A, pos, boff[bi], eps, out);
+}
+
+// ---- one-sided Jacobi (Hestenes) of a symmetric positive semi-definite n x n matrix held in LDS by ONE workgroup ------------
+// G (column-major, leading dimension n, starts as the matrix) and V (starts as I) stay in LDS through every round of
+// every sweep; a round rotates the npad / 2 disjoint column pairs of the round-robin schedule, one wave per pair
+// (each lane owns rows lane, lane + 64: n <= 128), and ends in one workgroup barrier.  On return the columns of G are
+// orthogonal: g_j = lambda_j v_j.
+MDEV double wave_sum(double x) {
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+MDEV void jacobi_lds(double* G, double* V, int n, double tol, int max_sweeps, int* s_rot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int npad = (n & 1) ? n + 1 : n, mm = npad - 1;
+    if (n < 2) return;
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (threadIdx.x == 0) *s_rot = 0;
+        __syncthreads();
+        for (int round = 0; round < mm; ++round) {
+            for (int i = wave; i < npad / 2; i += nw) {
+                int p, q;
+                if (i == 0) { p = mm; q = round % mm; }
+                else { p = (round + i) % mm; q = (round - i + mm) % mm; }
+                if (p > q) { const int t = p; p = q; q = t; }
+                if (q >= n) continue;                           // padding column: bye
+                double* gp = G + (size_t)p * n; double* gq = G + (size_t)q * n;
+                const int t0 = lane, t1 = lane + 64;
+                const double x0 = t0 < n ? gp[t0] : 0.0, y0 = t0 < n ? gq[t0] : 0.0;
+                const double x1 = t1 < n ? gp[t1] : 0.0, y1 = t1 < n ? gq[t1] : 0.0;
+                const double a = wave_sum(x0 * x0 + x1 * x1), b = wave_sum(y0 * y0 + y1 * y1), g = wave_sum(x0 * y0 + x1 * y1);
+                if (!(fabs(g) > tol * sqrt(a * b)) || g == 0.0) continue;
+                if (lane == 0) atomicAdd(s_rot, 1);
+                const double zeta = (b - a) / (2.0 * g);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                double* vp = V + (size_t)p * n; double* vq = V + (size_t)q * n;
+                if (t0 < n) { gp[t0] = c * x0 - s * y0; gq[t0] = s * x0 + c * y0; const double u = vp[t0], w = vq[t0]; vp[t0] = c * u - s * w; vq[t0] = s * u + c * w; }
+                if (t1 < n) { gp[t1] = c * x1 - s * y1; gq[t1] = s * x1 + c * y1; const double u = vp[t1], w = vq[t1]; vp[t1] = c * u - s * w; vq[t1] = s * u + c * w; }
+            }
+            __syncthreads();
+        }
+        if (*s_rot == 0) break;
+        __syncthreads();
+    }
+}
+constexpr int JLDS_MAX_N = 100;       // 2 * 100 * 100 doubles = 160,000 of the CU's 163,840 bytes of LDS
+// eigen pseudo-inverse of the dropped keyframe block (<= 15 dims) of the system the landmarks have been eliminated from
+__global__ __launch_bounds__(256) void k_pose_pinv(const double* A, int pos, int o, int sz, double eps, double* Pinv) {
+    __shared__ double G[MAXB * MAXB], V[MAXB * MAXB], lam[MAXB];
+    __shared__ int rot;
+    for (int t = threadIdx.x; t < sz * sz; t += blockDim.x) {
+        const int c = t / sz, r = t % sz;
+        G[t] = 0.5 * (A[(size_t)(o + r) * pos + o + c] + A[(size_t)(o + c) * pos + o + r]);   // cpp:351
+        V[t] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    jacobi_lds(G, V, sz, 1e-15, 40, &rot);
+    __syncthreads();
+    if ((int)threadIdx.x < sz) { double l = 0.0; for (int t = 0; t < sz; ++t) l += V[threadIdx.x * sz + t] * G[threadIdx.x * sz + t]; lam[threadIdx.x] = l; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < sz * sz; t += blockDim.x) {
+        const int i = t / sz, j = t % sz;
+        double acc = 0.0;
+        for (int k = 0; k < sz; ++k) if (lam[k] > eps) acc += V[k * sz + i] * V[k * sz + j] / lam[k];
+        Pinv[i * MAXB + j] = acc;
+    }
+}
+// the kept block: A' out, eigen square root J0 = sqrt(S) V^T (column-major), r0 = sqrt(S^-1) V^T b'   (cpp:364-372)
+// outp = [Ar n*n | br n | J0 n*n | r0 n]
+__global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const double* b, int pos, int m, int n, double eps, double* outp) {
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    double* G = s_dyn; double* V = s_dyn + (size_t)n * n;
+    __shared__ int rot;
+    double* Ar = outp; double* br = outp + (size_t)n * n; double* J0 = br + n; double* r0 = J0 + (size_t)n * n;
+    for (int t = threadIdx.x; t < n * n; t += blockDim.x) {
+        const int c = t / n, r = t % n;
+        const double v = 0.5 * (A[(size_t)(m + r) * pos + m + c] + A[(size_t)(m + c) * pos + m + r]);
+        G[t] = v; Ar[t] = v; V[t] = (r == c) ? 1.0 : 0.0;
+    }
+    for (int t = threadIdx.x; t < n; t += blockDim.x) br[t] = b[m + t];
+    __syncthreads();
+    jacobi_lds(G, V, n, 1e-15, 30, &rot);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int j = wave; j < n; j += nw) {
+        const double* g = G + (size_t)j * n; const double* v = V + (size_t)j * n;
+        double l = 0.0, vb = 0.0;
+        for (int t = lane; t < n; t += 64) { l += v[t] * g[t]; vb += v[t] * b[m + t]; }
+        l = wave_sum(l); vb = wave_sum(vb);
+        const double S = l > eps ? l : 0.0, Si = l > eps ? 1.0 / l : 0.0;
+        const double ss = sqrt(S);
+        for (int c = lane; c < n; c += 64) J0[(size_t)c * n + j] = ss * v[c];
+        if (lane == 0) r0[j] = sqrt(Si) * vb;
+    }
 }
 
 // ---- (4) one-sided Jacobi (Hestenes) on the symmetric positive semi-definite A' ---------------------------------------
@@ -309,67 +482,73 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
     }
     const int n = pos - m;
     for (auto& o : obs) { o.col_lm = col[o.col_lm]; o.col_kf = col[o.col_kf]; }
-    // ---- device work -------------------------------------------------------------------------------------------------------
-    DArr<double> dJ, dr, dA, db, dZ, dPinv, dG, dV, dJ0, dr0;
+    // ---- device work: every index list goes up before the first launch, one stream synchronisation at the end ----------------
+    DArr<double> dJ, dr, dA, db, dZ, dPinvL, dPinvP, dOut, dG, dV;
     DArr<MargObs> dobs;
-    DArr<int> dboff, dbsize, delim, dvcol, drot;
-    DArr<uint8_t> drest;
-    PLBA_HIPCK(p, dJ.alloc((size_t)R * pos)); PLBA_HIPCK(p, dr.alloc(R)); PLBA_HIPCK(p, dA.alloc((size_t)pos * pos)); PLBA_HIPCK(p, db.alloc(pos));
-    PLBA_HIPCK(p, dZ.alloc((size_t)pos * pos)); PLBA_HIPCK(p, dobs.upload(obs));
-    PLBA_HIPCK(p, hipStreamSynchronize(s));
+    DArr<int> dboff, dbsize, delimL, delimP, dvcol, dimu, drot;
+    DArr<uint8_t> drestL, drestP;
+    struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{s};   // declared after the buffers: runs before they go back to the pool
+    DArrStreamScope staged(s, p->have_ctx ? p->ctx.stage : nullptr);      // prepare() has synchronised: the staging area is free again
     const int state = p->cur;
-    if (!obs.empty()) hipLaunchKernelGGL(k_marg_obs, dim3(((int)obs.size() + 63) / 64), dim3(64), 0, s, d, state, dobs.p, (int)obs.size(), dJ.p, dr.p, R);
-    for (size_t t = 0; t < imu_edges.size(); ++t) {
-        const int m = imu_edges[t], ki = p->imu_i[m], kj = p->imu_j[m];
-        hipLaunchKernelGGL(k_marg_imu, dim3(1), dim3(64), 0, s, d, state, m, imu_rows[t], col[p->vid_pvr[ki]], col[p->vid_pvr[kj]], col[p->vid_bias[ki]], col[p->vid_bias[kj]], dJ.p, dr.p, R);
-    }
-    if (prior_row >= 0) {
-        Robust rb = p->rob;
-        launch_pose_edges(d, state, false, rb, true, s);       // refreshes pr_err = EdgeMarginalization::computeError at the final estimate
-        std::vector<int> vcol(p->pr_nv);
-        for (int i = 0; i < p->pr_nv; ++i) vcol[i] = col[p->pr_vid[i]];
-        PLBA_HIPCK(p, dvcol.upload(vcol));
-        hipLaunchKernelGGL(k_marg_prior, dim3(64), dim3(256), 0, s, d, prior_row, dvcol.p, dJ.p, dr.p, R);
-    }
-    launch_ata(dJ.p, R, pos, dA.p, pos, s);   // A = J^T J
-    hipLaunchKernelGGL(k_jt_r, dim3((pos + 63) / 64), dim3(64), 0, s, dJ.p, dr.p, R, pos, db.p);
     const double eps = p->opt.marg_eps;
-    auto eliminate = [&](const std::vector<int>& boff, const std::vector<int>& bsize, const std::vector<uint8_t>& rest) -> int {
-        const int nb = (int)boff.size();
-        if (nb == 0) return PLBA_OK;
-        std::vector<int> elim;
-        for (int b = 0; b < nb; ++b) for (int t = 0; t < bsize[b]; ++t) elim.push_back(boff[b] + t);
-        PLBA_HIPCK(p, dboff.upload(boff)); PLBA_HIPCK(p, dbsize.upload(bsize)); PLBA_HIPCK(p, delim.upload(elim)); PLBA_HIPCK(p, drest.upload(rest));
-        PLBA_HIPCK(p, dPinv.alloc((size_t)nb * MAXB * MAXB));
-        hipLaunchKernelGGL(k_block_pinv, dim3((nb + 63) / 64), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, nb, eps, dPinv.p);
-        hipLaunchKernelGGL(k_block_Z, dim3((pos + 63) / 64, nb), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, nb, dPinv.p, dZ.p);
-        hipLaunchKernelGGL(k_schur_apply, dim3((pos + 1 + 15) / 16, (pos + 15) / 16), dim3(16, 16), 0, s, dA.p, db.p, pos, dZ.p, delim.p, (int)elim.size(), drest.p);
-        PLBA_HIPCK(p, hipStreamSynchronize(s));   // the uploaded index vectors are reused by the next call
-        return PLBA_OK;
-    };
-    {
-        std::vector<uint8_t> rest(pos, 1);
-        for (size_t b = 0; b < blk_off.size(); ++b) for (int t = 0; t < blk_size[b]; ++t) rest[blk_off[b] + t] = 0;
-        int rc = eliminate(blk_off, blk_size, rest);
-        if (rc) return rc;
-        if (pose_size > 0) {
-            for (int t = 0; t < pose_size; ++t) rest[pose_off + t] = 0;
-            rc = eliminate(std::vector<int>{pose_off}, std::vector<int>{pose_size}, rest);
-            if (rc) return rc;
-        }
+    // host-side index vectors (alive until the final synchronisation: without a staging area the copies read them directly)
+    std::vector<int> imu_desc, vcol, elimL, elimP;
+    std::vector<uint8_t> restL(pos, 1), restP;
+    for (size_t t = 0; t < imu_edges.size(); ++t) {
+        const int mI = imu_edges[t], ki = p->imu_i[mI], kj = p->imu_j[mI];
+        for (int v : {mI, imu_rows[t], col[p->vid_pvr[ki]], col[p->vid_pvr[kj]], col[p->vid_bias[ki]], col[p->vid_bias[kj]]}) imu_desc.push_back(v);
     }
-    // ---- eigen square root of the reduced system ------------------------------------------------------------------------------
-    PLBA_HIPCK(p, dG.alloc((size_t)n * n)); PLBA_HIPCK(p, dV.alloc((size_t)n * n)); PLBA_HIPCK(p, dJ0.alloc((size_t)n * n)); PLBA_HIPCK(p, dr0.alloc(n));
-    PLBA_HIPCK(p, drot.alloc(1));
-    const int nn_blocks = (int)(((size_t)n * n + 255) / 256);
-    hipLaunchKernelGGL(k_extract_cm, dim3(nn_blocks), dim3(256), 0, s, dA.p, pos, m, n, dG.p);
-    std::vector<double> Ar((size_t)n * n), br(n), Afull;
-    PLBA_HIPCK(p, hipStreamSynchronize(s));
-    PLBA_HIPCK(p, hipMemcpy(Ar.data(), dG.p, Ar.size() * 8, hipMemcpyDeviceToHost));      // symmetric: col-major == row-major
-    PLBA_HIPCK(p, hipMemcpy(br.data(), db.p + m, (size_t)n * 8, hipMemcpyDeviceToHost));
-    hipLaunchKernelGGL(k_set_identity, dim3(nn_blocks), dim3(256), 0, s, dV.p, n);
-    const int npad = (n % 2) ? n + 1 : n;
-    if (n > 1) {
+    if (prior_row >= 0) { vcol.resize(p->pr_nv); for (int i = 0; i < p->pr_nv; ++i) vcol[i] = col[p->pr_vid[i]]; }
+    for (size_t bq = 0; bq < blk_off.size(); ++bq) for (int t = 0; t < blk_size[bq]; ++t) { elimL.push_back(blk_off[bq] + t); restL[blk_off[bq] + t] = 0; }
+    restP = restL;
+    for (int t = 0; t < pose_size; ++t) { elimP.push_back(pose_off + t); restP[pose_off + t] = 0; }
+    for (size_t bq = 0; bq < blk_size.size(); ++bq) if (blk_size[bq] != 3 && blk_size[bq] != 6) PLBA_FAIL(p, PLBA_ERR_INVALID, "marginalize: landmark block of %d dims", blk_size[bq]);
+    PLBA_HIPCK(p, dJ.alloc((size_t)R * pos)); PLBA_HIPCK(p, dr.alloc(R)); PLBA_HIPCK(p, dA.alloc((size_t)pos * pos, false)); PLBA_HIPCK(p, db.alloc(pos, false));
+    PLBA_HIPCK(p, dZ.alloc((size_t)pos * pos)); PLBA_HIPCK(p, dobs.upload(obs)); PLBA_HIPCK(p, dimu.upload(imu_desc)); PLBA_HIPCK(p, dvcol.upload(vcol));
+    PLBA_HIPCK(p, dboff.upload(blk_off)); PLBA_HIPCK(p, dbsize.upload(blk_size)); PLBA_HIPCK(p, delimL.upload(elimL)); PLBA_HIPCK(p, delimP.upload(elimP));
+    PLBA_HIPCK(p, drestL.upload(restL)); PLBA_HIPCK(p, drestP.upload(restP));
+    PLBA_HIPCK(p, dPinvL.alloc(std::max<size_t>(blk_off.size(), 1) * MAXB * MAXB, false)); PLBA_HIPCK(p, dPinvP.alloc(MAXB * MAXB, false));
+    const size_t nout = 2 * (size_t)n * n + 2 * (size_t)n;
+    PLBA_HIPCK(p, dOut.alloc(nout, false));
+    // (1) factors -> stacked Jacobian
+    if (prior_row >= 0) launch_pose_edges(d, state, false, p->rob, true, s);       // refreshes pr_err = EdgeMarginalization::computeError at the final estimate
+    {
+        const int nobs = (int)obs.size(), nimu = (int)imu_edges.size();
+        const int ob = (nobs + 63) / 64, pb = prior_row >= 0 ? 16 : 0;
+        if (ob + nimu + pb > 0)
+            hipLaunchKernelGGL(k_marg_factors, dim3(ob + nimu + pb), dim3(64), 0, s, d, state, dobs.p, nobs, ob, dimu.p, nimu, prior_row, dvcol.p, dJ.p, dr.p, R);
+    }
+    // (2) A = J^T J, b = J^T r
+    launch_ata(dJ.p, R, pos, dA.p, pos, s);
+    hipLaunchKernelGGL(k_jt_r, dim3((pos + 63) / 64), dim3(64), 0, s, dJ.p, dr.p, R, pos, db.p);
+    // (3) landmark blocks, then the keyframe block of the reduced system
+    if (!blk_off.empty()) {
+        const int nb = (int)blk_off.size();
+        hipLaunchKernelGGL(k_block_pinv_small, dim3((nb + 63) / 64), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, nb, eps, dPinvL.p);
+        hipLaunchKernelGGL(k_block_Z, dim3((pos + 63) / 64, nb), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, nb, dPinvL.p, dZ.p);
+        hipLaunchKernelGGL(k_schur_apply, dim3((pos + 1 + 15) / 16, (pos + 15) / 16), dim3(16, 16), 0, s, dA.p, db.p, pos, dZ.p, delimL.p, (int)elimL.size(), drestL.p);
+    }
+    if (pose_size > 0) {
+        hipLaunchKernelGGL(k_pose_pinv, dim3(1), dim3(256), 0, s, dA.p, pos, pose_off, pose_size, eps, dPinvP.p);
+        hipLaunchKernelGGL(k_block_Z1, dim3((pos + 63) / 64), dim3(64), 0, s, dA.p, pos, pose_off, pose_size, dPinvP.p, dZ.p);
+        hipLaunchKernelGGL(k_schur_apply, dim3((pos + 1 + 15) / 16, (pos + 15) / 16), dim3(16, 16), 0, s, dA.p, db.p, pos, dZ.p, delimP.p, (int)elimP.size(), drestP.p);
+    }
+    // (4) eigen square root of the kept block
+    double* oAr = dOut.p; double* obr = oAr + (size_t)n * n; double* oJ0 = obr + n; double* or0 = oJ0 + (size_t)n * n;
+    if (n <= JLDS_MAX_N) {
+        const size_t sh = 2 * (size_t)n * n * sizeof(double);
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_marg_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * JLDS_MAX_N * JLDS_MAX_N * sizeof(double))); attr_set = true; }
+        hipLaunchKernelGGL(k_marg_finish, dim3(1), dim3(1024), sh, s, dA.p, db.p, pos, m, n, eps, dOut.p);
+    } else {
+        // larger kept blocks: G and V in HBM, one launch per round, convergence checked on the host once per sweep
+        PLBA_HIPCK(p, dG.alloc((size_t)n * n, false)); PLBA_HIPCK(p, dV.alloc((size_t)n * n, false)); PLBA_HIPCK(p, drot.alloc(1));
+        const int nn_blocks = (int)(((size_t)n * n + 255) / 256);
+        hipLaunchKernelGGL(k_extract_cm, dim3(nn_blocks), dim3(256), 0, s, dA.p, pos, m, n, dG.p);
+        PLBA_HIPCK(p, hipMemcpyAsync(oAr, dG.p, (size_t)n * n * 8, hipMemcpyDeviceToDevice, s));      // symmetric: col-major == row-major
+        PLBA_HIPCK(p, hipMemcpyAsync(obr, db.p + m, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_set_identity, dim3(nn_blocks), dim3(256), 0, s, dV.p, n);
+        const int npad = (n % 2) ? n + 1 : n;
         for (int sweep = 0; sweep < 30; ++sweep) {
             PLBA_HIPCK(p, hipMemsetAsync(drot.p, 0, sizeof(int), s));
             for (int round = 0; round < npad - 1; ++round)
@@ -379,20 +558,30 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
             PLBA_HIPCK(p, hipStreamSynchronize(s));
             if (rotated == 0) break;
         }
+        hipLaunchKernelGGL(k_eigen_sqrt, dim3((n + 63) / 64), dim3(64), 0, s, dG.p, dV.p, db.p + m, n, eps, oJ0, or0);
     }
-    hipLaunchKernelGGL(k_eigen_sqrt, dim3((n + 63) / 64), dim3(64), 0, s, dG.p, dV.p, db.p + m, n, eps, dJ0.p, dr0.p);
+    // ---- results: two asynchronous copies into pinned memory (the staging area's free tail), ONE synchronisation -------------
+    const size_t nkf = (size_t)p->K * KF_STRIDE;
+    std::vector<double> pageable;
+    double* hres = nullptr;
+    {
+        StageArea* st = darr_stage();
+        const size_t need = (nout + nkf) * sizeof(double), at = st ? ((st->used + 255) & ~(size_t)255) : 0;
+        if (st && st->base && at + need <= st->cap) hres = (double*)(st->base + at);
+        else { pageable.resize(nout + nkf); hres = pageable.data(); }
+    }
+    PLBA_HIPCK(p, hipMemcpyAsync(hres, dOut.p, nout * 8, hipMemcpyDeviceToHost, s));
+    PLBA_HIPCK(p, hipMemcpyAsync(hres + nout, d.kf[state], nkf * 8, hipMemcpyDeviceToHost, s));
     PLBA_HIPCK(p, hipStreamSynchronize(s));
     PLBA_HIPCK(p, hipGetLastError());
     // ---- output (host buffers owned by the caller until plba_prior_free) ----------------------------------------------------------
     out->n = n; out->m = m; out->nv = (int)kept.size();
     out->vid = (int32_t*)calloc(kept.size() + 1, 4); out->size = (int32_t*)calloc(kept.size() + 1, 4); out->idx = (int32_t*)calloc(kept.size() + 1, 4);
-    out->J0 = (double*)calloc((size_t)n * n + 1, 8); out->r0 = (double*)calloc(n + 1, 8);
-    out->Ar = (double*)calloc((size_t)n * n + 1, 8); out->br = (double*)calloc(n + 1, 8);
-    memcpy(out->Ar, Ar.data(), Ar.size() * 8); memcpy(out->br, br.data(), (size_t)n * 8);
-    PLBA_HIPCK(p, hipMemcpy(out->J0, dJ0.p, (size_t)n * n * 8, hipMemcpyDeviceToHost));
-    PLBA_HIPCK(p, hipMemcpy(out->r0, dr0.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-    std::vector<double> kfh((size_t)p->K * KF_STRIDE);
-    PLBA_HIPCK(p, hipMemcpy(kfh.data(), d.kf[state], kfh.size() * 8, hipMemcpyDeviceToHost));
+    out->J0 = (double*)malloc(((size_t)n * n + 1) * 8); out->r0 = (double*)malloc((size_t)(n + 1) * 8);
+    out->Ar = (double*)malloc(((size_t)n * n + 1) * 8); out->br = (double*)malloc((size_t)(n + 1) * 8);
+    memcpy(out->Ar, hres, (size_t)n * n * 8); memcpy(out->br, hres + (size_t)n * n, (size_t)n * 8);
+    memcpy(out->J0, hres + (size_t)n * n + n, (size_t)n * n * 8); memcpy(out->r0, hres + 2 * (size_t)n * n + n, (size_t)n * 8);
+    const double* kfh = hres + nout;
     size_t nx = 0;
     for (auto* k : kept) nx += k->size == 9 ? 10 : 6;
     out->x0 = (double*)calloc(nx + 1, 8);

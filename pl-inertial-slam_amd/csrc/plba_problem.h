@@ -186,6 +186,7 @@ struct plba_problem {
     plba::DArr<double> d_imu_pre, d_imu_ipvr, d_imu_ibias, d_imu_err, d_imu_chi;
     plba::DArr<int32_t> d_pr_kf, d_pr_isbias, d_pr_size, d_pr_idx, d_pr_x0off, d_pr_off;
     plba::DArr<double> d_pr_x0, d_pr_J0, d_pr_r0, d_pr_err, d_pr_dx, d_pr_chi, d_pr_H;
+    plba::DArr<double> d_bprior, d_bprior2;
     plba::DArr<double> d_Hconst, d_Himu, d_bimu, d_Himu2, d_bimu2, d_sys, d_Lfac, d_bpg, d_x, d_Linv, d_LT32, d_rd32;
     plba::DArr<int> d_flow_flags, d_chol_flags;
     int flow_epoch = 0;

@@ -59,3 +59,50 @@ def make_allreduce(dist, device_index=None, stream=None, via_host=False):
         else:
             dist.all_reduce(t, op=_op(op))
     return fn
+
+
+class RcclExchange:
+    """The exchange hook in C++ (include/plba_rccl.h, libplba_rccl.so): ncclAllReduce on the library's stream, bound to a
+    communicator of its own.  torch.distributed is used ONCE, to hand rank 0's ncclUniqueId to the other ranks; after that
+    no Python runs inside the LM loop (Problem.set_shard_native)."""
+
+    def __init__(self, dist, rank, world, lib_path=None):
+        import os
+        import torch
+        path = lib_path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libplba_rccl.so")
+        self.lib = C.CDLL(path)
+        self.lib.plba_rccl_last_error.restype = C.c_char_p
+        self.lib.plba_rccl_unique_id.argtypes = [C.c_char_p]
+        self.lib.plba_rccl_init.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_char_p]
+        self.lib.plba_rccl_destroy.argtypes = [C.c_void_p]
+        idb = C.create_string_buffer(128)
+        if rank == 0 and self.lib.plba_rccl_unique_id(idb) != 0:
+            raise RuntimeError("plba_rccl_unique_id: %s" % self.lib.plba_rccl_last_error().decode())
+        if world > 1:
+            on_gpu = dist.get_backend() == "nccl"
+            t = torch.tensor(list(idb.raw), dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+            dist.broadcast(t, src=0)
+            idb = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        self.comm = C.c_void_p()
+        if self.lib.plba_rccl_init(C.byref(self.comm), rank, world, idb) != 0:
+            raise RuntimeError("plba_rccl_init: %s" % self.lib.plba_rccl_last_error().decode())
+        self.rank, self.world = rank, world
+
+    @property
+    def fn_addr(self):
+        return C.cast(self.lib.plba_rccl_allreduce, C.c_void_p).value
+
+    def attach(self, problem):
+        problem.set_shard_native(self.rank, self.world, self.fn_addr, self.comm.value)
+
+    def allreduce(self, ptr, n, op, stream):
+        """direct call of the native hook (tests)"""
+        f = self.lib.plba_rccl_allreduce
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        if f(self.comm, C.c_void_p(ptr), n, op, C.c_void_p(stream)) != 0:
+            raise RuntimeError("plba_rccl_allreduce: %s" % self.lib.plba_rccl_last_error().decode())
+
+    def close(self):
+        if self.comm:
+            self.lib.plba_rccl_destroy(self.comm)
+            self.comm = C.c_void_p()

@@ -65,3 +65,21 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle", txt, flags=re.M), f
                 assert not re.search(r"(CDLL|dlopen)\([^)]*oracle", txt), f
+
+
+def test_rccl_hook_library_exports_its_header(pkg):
+    """include/plba_rccl.h: the multi-GPU exchange hook in C++ (libplba_rccl.so).  It binds RCCL by dlopen at first use, so
+    loading it needs neither a GPU nor librccl; the hook has exactly the plba_allreduce_fn signature plba_set_shard takes."""
+    import __graft_entry__ as g
+    g.build_rccl()
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "plba_rccl.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(plba_rccl_[a-z0-9_]+)\s*\(", txt))
+    assert declared == {"plba_rccl_unique_id", "plba_rccl_init", "plba_rccl_allreduce", "plba_rccl_destroy", "plba_rccl_last_error"}
+    lib = C.CDLL(g.RCCL_LIB)
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    # bad arguments are refused before RCCL is touched
+    lib.plba_rccl_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    assert lib.plba_rccl_allreduce(None, None, 4, 0, None) != 0
+    lib.plba_rccl_last_error.restype = C.c_char_p
+    assert b"bad argument" in lib.plba_rccl_last_error()

@@ -20,7 +20,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, use_hip, out):
+WIN_SMALL = (8, 240, 50, 0xD157, 5, 10)          # K, points, lines, seed, stage-1 / stage-2 iterations
+WIN_K200 = (200, 6000, 1200, 0x5EED0005, 2, 2)    # the BASELINE configs[4] window shape (P = 2985) at a landmark count the oracle finishes
+
+
+def _worker(rank, world, port, use_hip, out, win=WIN_SMALL):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -31,7 +35,7 @@ def _worker(rank, world, port, use_hip, out):
     pkg = ge.load_package()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        w = pkg.window.make_window(8, 240, 50, imu=True, seed=0xD157)
+        w = pkg.window.make_window(win[0], win[1], win[2], imu=True, seed=win[3])
         ws = pkg.window.shard_window(w, rank, world)
         if use_hip:
             torch.cuda.set_device(0)
@@ -42,7 +46,7 @@ def _worker(rank, world, port, use_hip, out):
             p = orc.new_problem()
             p.upload_window(ws)
             p.set_shard(rank, world, pkg.distributed.make_allreduce(dist))
-        r = pkg.protocol.local_ba(p)
+        r = pkg.protocol.local_ba(p, stage1=win[4], stage2=win[5])
         res = pkg.protocol.results(p)
         tr = p.trace()
         lo, hi = ws["shard"]["pt_range"]
@@ -58,12 +62,12 @@ def _worker(rank, world, port, use_hip, out):
         os._exit(1)
 
 
-def _run(world, use_hip):
+def _run(world, use_hip, win=WIN_SMALL):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, use_hip, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, use_hip, q, win)) for r in range(world)]
     for p in procs:
         p.start()
     got = []
@@ -82,10 +86,10 @@ def _run(world, use_hip):
     return sorted(got, key=lambda g: g[0])
 
 
-def _check(got, pkg, orc):
-    w = pkg.window.make_window(8, 240, 50, imu=True, seed=0xD157)
+def _check(got, pkg, orc, win=WIN_SMALL):
+    w = pkg.window.make_window(win[0], win[1], win[2], imu=True, seed=win[3])
     ref = orc.new_problem(); ref.upload_window(w)
-    rr = pkg.protocol.local_ba(ref)
+    rr = pkg.protocol.local_ba(ref, stage1=win[4], stage2=win[5])
     res = pkg.protocol.results(ref)
     # every rank holds the same keyframe estimates, equal to the unsharded solve
     for g in got:
@@ -107,6 +111,13 @@ def test_sharded_oracle_world2_gloo(pkg, orc):
 @pytest.mark.gpu
 def test_sharded_hip_world2_gloo_host_staged(pkg, orc, hip):
     _check(_run(2, True), pkg, orc)
+
+
+@pytest.mark.gpu
+def test_sharded_hip_world2_k200(pkg, orc, hip):
+    """the configs[4] window shape (200 keyframes, P = 2985: structural exchange list of ~0.8 M doubles, chain elimination
+    after the all-reduce) on two landmark shards == the unsharded oracle"""
+    _check(_run(2, True, WIN_K200), pkg, orc, WIN_K200)
 
 
 def test_shard_window_partitions_landmarks(pkg):
@@ -179,6 +190,65 @@ def test_rccl_allreduce_hook_on_device_pointers(pkg, hip):
             # the worker never got a plain torch all-reduce through: RCCL did not come up on this box (seen once in ~10
             # runs on the shared pool); nothing of this repository has run yet at that point
             pytest.skip("RCCL bring-up (init_process_group / first all_reduce) did not finish within 150 s on this box")
+        if g[0] == "stage":
+            g = q.get(timeout=240)
+    finally:
+        pr.join(timeout=60)
+        if pr.is_alive():
+            pr.kill()
+    assert g[0] == "ok", g[-1]
+    assert g[1] is True and g[2] >= 1
+
+
+def _native_rccl_worker(out):
+    """libplba_rccl.so on a world-size-1 communicator of its own (no torch.distributed at all): unique id, ncclCommInitRank,
+    the hook called the way plba_api.hip calls it (device pointer, element count, op, stream), and a problem that carries it."""
+    sys.path.insert(0, ROOT)
+    try:
+        import torch
+        import __graft_entry__ as ge
+        pkg = ge.load_package()
+        ge.build_rccl()
+        torch.cuda.set_device(0)
+        x = pkg.distributed.RcclExchange(None, 0, 1)
+        out.put(("stage", "rccl_ready"))
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            buf = torch.arange(1 << 16, dtype=torch.float64, device="cuda") * 0.25
+            ref = buf.clone()
+        x.allreduce(buf.data_ptr(), buf.numel(), 0, stream.cuda_stream)            # sum over one rank: identity
+        x.allreduce(buf.data_ptr() + 8 * 100, 1000, 1, stream.cuda_stream)         # max on an interior slice
+        stream.synchronize()
+        ok = bool(torch.equal(buf, ref))
+        w = pkg.window.make_window(6, 150, 30, imu=True, seed=0xD158)
+        p = pkg.new_problem()
+        p.set_stream(stream.cuda_stream)
+        p.upload_window(pkg.window.shard_window(w, 0, 1))
+        x.attach(p)
+        st = p.optimize(3)
+        p.close()
+        x.close()
+        out.put(("ok", ok, st.iterations))
+    except BaseException as e:
+        import traceback
+        out.put(("error", "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+        out.close(); out.join_thread()
+        os._exit(1)
+
+
+@pytest.mark.gpu
+def test_native_rccl_hook(pkg, hip):
+    import queue
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_native_rccl_worker, args=(q,))
+    pr.start()
+    try:
+        try:
+            g = q.get(timeout=150)
+        except queue.Empty:
+            pytest.skip("RCCL bring-up (ncclCommInitRank) did not finish within 150 s on this box")
         if g[0] == "stage":
             g = q.get(timeout=240)
     finally:

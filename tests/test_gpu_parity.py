@@ -328,6 +328,53 @@ def test_rejected_trials_with_imu_edges(pkg, orc, hip):
     g1.close(); g0.close()
 
 
+def _overshoot_window(pkg, seed, rot=1.2, vel=10.0, pts=4.0, K=10, Np=150, Nl=30):
+    """a window started so far from the optimum that damped Gauss-Newton steps overshoot: rotations off by `rot` rad, velocities
+    by `vel` m/s, points by `pts` m.  Run with user_lambda_init = 1e4 it stays WELL CONDITIONED through the rejections: the
+    IMU information puts 2e10 on the diagonal, so lambda >= 1e3 keeps cond(H + lambda I) <= 2e7 (with lambda = 1 the very
+    first damped solve already differs in the 5th digit between two fp64 solvers)"""
+    W = pkg.window
+    w = W.make_window(K, Np, Nl, imu=True, seed=seed)
+    rng = np.random.default_rng(seed)
+    kf = w["kf"]
+    q = kf["q"].copy()
+    for k in range(1, K):
+        q[k] = W.quat_from_R(W.R_from_quat(q[k]) @ W.exp_so3(rng.normal(size=3) * rot))
+    kf["q"] = q
+    kf["V"] = kf["V"] + np.vstack([np.zeros((1, 3)), rng.normal(size=(K - 1, 3)) * vel])
+    w["points"] = w["points"] + rng.normal(size=w["points"].shape) * pts
+    return w
+
+
+@pytest.mark.parametrize("chain", [1, 0])
+@pytest.mark.parametrize("seed", [77, 80])
+def test_rejected_trials_pin_values_on_a_well_conditioned_window(pkg, orc, hip, seed, chain):
+    """the rejected-trial machinery of the default path (speculative linearisation gated on the device-side
+    decision, double-buffered IMU accumulators, records of the current state surviving a rejected step) verified on VALUES,
+    not only control flow: genuine overshoots (chi2 8.5e6 -> 1.1e7) at lambda ~ 1e3..5e4, seed 80 also with trials whose
+    reduced-camera Cholesky fails (chi2 = DBL_MAX) and rejections in a row; every lambda / chi2 of the trace and the final
+    states to 1e-7."""
+    w = _overshoot_window(pkg, seed)
+    g, o = _pair(pkg, orc, w, user_lambda_init=1e4, chain_elim=chain)
+    sg, so = g.optimize(8), o.optimize(8)
+    tg, to = g.trace(), o.trace()
+    rej = [not r["accepted"] for r in to]
+    assert sum(rej) >= 2, "the scenario is meant to reject trials"
+    if seed == 80:
+        assert so.solver_failures >= 2 and any(a and b for a, b in zip(rej[:-1], rej[1:]))
+    assert [(r["iteration"], r["trial"], r["accepted"], r["solver_ok"]) for r in tg] == [(r["iteration"], r["trial"], r["accepted"], r["solver_ok"]) for r in to]
+    for a, b in zip(tg, to):
+        for k in ("lam", "chi2_current", "scale"):
+            assert a[k] == pytest.approx(b[k], rel=1e-7), (k, a, b)
+        if b["chi2_trial"] < 1e300:
+            assert a["chi2_trial"] == pytest.approx(b["chi2_trial"], rel=1e-7), (a, b)
+    assert (sg.iterations, sg.trials, sg.solver_failures) == (so.iterations, so.trials, so.solver_failures)
+    assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-7)
+    assert max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)) < 1e-7
+    _close(g.get_points(), o.get_points(), 1e-7, "points")
+    g.close(); o.close()
+
+
 @pytest.mark.parametrize("chain", [1, 0])
 def test_prior_edge_parity(pkg, orc, hip, chain):
     """BA with a marginalization prior: the oracle's prior on both sides (SURVEY B-Q3 decision).  With chain_elim = 1 the
