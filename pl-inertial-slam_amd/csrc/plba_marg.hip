@@ -115,13 +115,14 @@ __global__ __launch_bounds__(64) void k_marg_factors(DevBuf d, int state, const 
     marg_prior(d, b - ob - nimu, gridDim.x - ob - nimu, prior_row, vcol, J, r, R);
 }
 
-__global__ void k_jt_r(const double* J, const double* r, int R, int pos, double* b) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_jt_r(const double* J, const double* r, int R, int pos, double* b) {      // one wave per column
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= pos) return;
     const double* col = J + (size_t)c * R;
     double s = 0.0;
-    for (int t = 0; t < R; ++t) s += col[t] * r[t];
-    b[c] = s;
+    for (int t = lane; t < R; t += 64) s += col[t] * r[t];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) b[c] = s;
 }
 
 // ---- (3) block pseudo-inverse + Schur update --------------------------------------------------------------------
@@ -172,14 +173,13 @@ __global__ void k_block_Z(const double* A, int pos, const int* boff, const int* 
         Z[(size_t)row * pos + o + c] = acc;
     }
 }
-__global__ void k_block_Z1(const double* A, int pos, int o, int s, const double* P, double* Z) {      // one block at offset o
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= pos) return;
-    for (int c = 0; c < s; ++c) {
-        double acc = 0.0;
-        for (int t = 0; t < s; ++t) acc += A[(size_t)row * pos + o + t] * P[t * MAXB + c];
-        Z[(size_t)row * pos + o + c] = acc;
-    }
+__global__ void k_block_Z1(const double* A, int pos, int o, int s, const double* P, double* Z) {      // one block at offset o; a thread per (row, column)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pos * s) return;
+    const int row = i / s, c = i - row * s;
+    double acc = 0.0;
+    for (int t = 0; t < s; ++t) acc += A[(size_t)row * pos + o + t] * P[t * MAXB + c];
+    Z[(size_t)row * pos + o + c] = acc;
 }
 // A[r][c] -= sum_{k in elim} Z[r][k] A[k][c],  b[r] -= sum Z[r][k] b[k]   for r, c in `rest`
 __global__ void k_schur_apply(double* A, double* b, int pos, const double* Z, const int* elim, int nelim, const uint8_t* is_rest) {
@@ -211,7 +211,7 @@ MDEV void pinv_small(const double* A, int pos, int o, double eps, double* out) {
 #pragma unroll
             for (int j = i + 1; j < S; ++j) off += M[i][j] * M[i][j];
         }
-        if (off <= 1e-32 * (dg + off) || off == 0.0) break;
+        if (off <= 1e-28 * (dg + off) || off == 0.0) break;
 #pragma unroll
         for (int p = 0; p < S - 1; ++p)
 #pragma unroll
@@ -257,39 +257,120 @@ MDEV double wave_sum(double x) {
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
     return x;
 }
-MDEV void jacobi_lds(double* G, double* V, int n, double tol, int max_sweeps, int* s_rot) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int npad = (n & 1) ? n + 1 : n, mm = npad - 1;
+template <int CTRL, int ROW_MASK>
+MDEV double dpp_get(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over each 32-lane half of the wave, returned to every lane of that half (row_shr 1, 2, 4, 8, row_bcast:15, readlane)
+MDEV double half_sum(double v, bool upper) {
+    v += dpp_get<0x111, 0xf>(v);
+    v += dpp_get<0x112, 0xf>(v);
+    v += dpp_get<0x114, 0xf>(v);
+    v += dpp_get<0x118, 0xf>(v);
+    v += dpp_get<0x142, 0xa>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double s0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+    const double s1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+    return upper ? s1 : s0;
+}
+// A round rotates the npad / 2 disjoint column pairs of the round-robin schedule, one HALF-wave per pair (lane l of the half
+// owns rows l, l + 32, l + 64, l + 96: n <= 128), and ends in one workgroup barrier.  A pair is left alone when
+//   |g_p . g_q| <= tol |g_p| |g_q|                      (orthogonal to the rounding of the dot product), or
+//   |g_p . g_q| <= delta (|g_p| + |g_q|),  delta = 4 n macheps |A|_F    (noise2 = 2 delta^2 against (|g_p|^2 + |g_q|^2)):
+// every entry of G carries ~ delta of absolute rounding from the rotations, so a column that has sunk to that level (a
+// numerically null direction: the gauge freedom of the first prior) can never pass the RELATIVE test and would keep every
+// sweep rotating — round 1's criterion never terminated before its sweep limit.
+MDEV void jacobi_lds(double* G, double* V, int n, double tol, double noise2, int max_sweeps, int* s_rot, double* dbg = nullptr) {
+    __shared__ double s_norm[128];
+    __shared__ int s_perm[128], s_live;
+    const int lane = threadIdx.x & 63, hl = lane & 31, nh = (blockDim.x >> 6) * 2, half = (threadIdx.x >> 6) * 2 + (lane >> 5);
+    const bool upper = lane >= 32;
     if (n < 2) return;
+    const double tol2 = tol * tol;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-        if (threadIdx.x == 0) *s_rot = 0;
+        // columns at the noise floor (|g_j|^2 <= noise2: never rotated, see above — e.g. the exactly zero velocity columns of
+        // keyframes no selected factor constrains) leave the schedule; the others are visited in order of decreasing norm
+        for (int j = threadIdx.x; j < n; j += blockDim.x) { double a = 0.0; const double* g = G + (size_t)j * n; for (int t = 0; t < n; ++t) a += g[t] * g[t]; s_norm[j] = a; }
+        if (threadIdx.x == 0) { *s_rot = 0; s_live = 0; }
         __syncthreads();
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            const double a = s_norm[j];
+            if (a > noise2) {
+                int rank = 0;
+                for (int k = 0; k < n; ++k) { const double b = s_norm[k]; rank += (b > noise2) && (b > a || (b == a && k < j)); }
+                s_perm[rank] = j;
+                atomicAdd(&s_live, 1);
+            }
+        }
+        __syncthreads();
+        const int nl = s_live;
+        if (nl < 2) break;
+        const int npad = (nl & 1) ? nl + 1 : nl, mm = npad - 1, npairs = npad / 2;
         for (int round = 0; round < mm; ++round) {
-            for (int i = wave; i < npad / 2; i += nw) {
-                int p, q;
-                if (i == 0) { p = mm; q = round % mm; }
-                else { p = (round + i) % mm; q = (round - i + mm) % mm; }
-                if (p > q) { const int t = p; p = q; q = t; }
-                if (q >= n) continue;                           // padding column: bye
+            for (int i0 = 0; i0 < npairs; i0 += nh) {      // both halves of a wave run the loop the same number of times (DPP / readlane need the whole wave)
+                const int i = i0 + half;
+                int p = 0, q = 0;
+                bool live = i < npairs;
+                if (live) {
+                    if (i == 0) { p = mm; q = round % mm; }
+                    else { p = (round + i) % mm; q = (round - i + mm) % mm; }
+                    if (p > q) { const int t = p; p = q; q = t; }
+                    live = q < nl;                               // padding column: bye
+                    if (live) { p = s_perm[p]; q = s_perm[q]; }
+                }
                 double* gp = G + (size_t)p * n; double* gq = G + (size_t)q * n;
-                const int t0 = lane, t1 = lane + 64;
-                const double x0 = t0 < n ? gp[t0] : 0.0, y0 = t0 < n ? gq[t0] : 0.0;
-                const double x1 = t1 < n ? gp[t1] : 0.0, y1 = t1 < n ? gq[t1] : 0.0;
-                const double a = wave_sum(x0 * x0 + x1 * x1), b = wave_sum(y0 * y0 + y1 * y1), g = wave_sum(x0 * y0 + x1 * y1);
-                if (!(fabs(g) > tol * sqrt(a * b)) || g == 0.0) continue;
-                if (lane == 0) atomicAdd(s_rot, 1);
-                const double zeta = (b - a) / (2.0 * g);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                double x[4], y[4];
+                double pa = 0.0, pb = 0.0, pg = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int t = hl + 32 * k;
+                    const bool in = live && t < n;
+                    x[k] = in ? gp[t] : 0.0; y[k] = in ? gq[t] : 0.0;
+                    pa += x[k] * x[k]; pb += y[k] * y[k]; pg += x[k] * y[k];
+                }
+                const double a = half_sum(pa, upper), b = half_sum(pb, upper), g = half_sum(pg, upper);
+                if (!live || !(g * g > tol2 * a * b) || !(g * g > noise2 * (a + b)) || g == 0.0) continue;
+                if (hl == 0) atomicAdd(s_rot, 1);
+                // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (b - a) / (2 g), written with one square root and one division
+                const double dd = b - a;
+                const double t = ((dd * g >= 0.0) ? 2.0 : -2.0) * fabs(g) / (fabs(dd) + sqrt(dd * dd + 4.0 * g * g));
+                const double c = rsqrt(1.0 + t * t), s = c * t;
                 double* vp = V + (size_t)p * n; double* vq = V + (size_t)q * n;
-                if (t0 < n) { gp[t0] = c * x0 - s * y0; gq[t0] = s * x0 + c * y0; const double u = vp[t0], w = vq[t0]; vp[t0] = c * u - s * w; vq[t0] = s * u + c * w; }
-                if (t1 < n) { gp[t1] = c * x1 - s * y1; gq[t1] = s * x1 + c * y1; const double u = vp[t1], w = vq[t1]; vp[t1] = c * u - s * w; vq[t1] = s * u + c * w; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = hl + 32 * k;
+                    if (r < n) {
+                        gp[r] = c * x[k] - s * y[k]; gq[r] = s * x[k] + c * y[k];
+                        const double u = vp[r], w = vq[r];
+                        vp[r] = c * u - s * w; vq[r] = s * u + c * w;
+                    }
+                }
             }
             __syncthreads();
         }
+        if (dbg && threadIdx.x == 0 && sweep < 40) dbg[sweep] = (double)*s_rot + 1e-3 * nl;
         if (*s_rot == 0) break;
         __syncthreads();
     }
+}
+// |g_p . g_q| <= JACOBI_TOL |g_p| |g_q| counts as orthogonal: an n-term fp64 dot product carries ~ n * 1.1e-16 of relative
+// rounding, so 1e-15 (round 1) was never reached and every call ran all its sweeps; 1e-13 leaves eigenvalues good to ~1e-13
+constexpr double JACOBI_TOL = 1e-13;
+// 2 delta^2 of the comment above, from the Frobenius norm of the n x n matrix held in G (call with the whole workgroup)
+MDEV double jacobi_noise2(const double* G, int n, double* s_part) {
+    double f = 0.0;
+    for (int t = threadIdx.x; t < n * n; t += blockDim.x) f += G[t] * G[t];
+    f = wave_sum(f);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = f;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_part[w];
+    __syncthreads();
+    const double delta = 4.0 * n * 1.1102230246251565e-16;
+    return 2.0 * delta * delta * tot;
 }
 constexpr int JLDS_MAX_N = 100;       // 2 * 100 * 100 doubles = 160,000 of the CU's 163,840 bytes of LDS
 // eigen pseudo-inverse of the dropped keyframe block (<= 15 dims) of the system the landmarks have been eliminated from
@@ -301,8 +382,10 @@ __global__ __launch_bounds__(256) void k_pose_pinv(const double* A, int pos, int
         G[t] = 0.5 * (A[(size_t)(o + r) * pos + o + c] + A[(size_t)(o + c) * pos + o + r]);   // cpp:351
         V[t] = (r == c) ? 1.0 : 0.0;
     }
+    __shared__ double s_part[16];
     __syncthreads();
-    jacobi_lds(G, V, sz, 1e-15, 40, &rot);
+    const double noise2 = jacobi_noise2(G, sz, s_part);
+    jacobi_lds(G, V, sz, JACOBI_TOL, noise2, 40, &rot);
     __syncthreads();
     if ((int)threadIdx.x < sz) { double l = 0.0; for (int t = 0; t < sz; ++t) l += V[threadIdx.x * sz + t] * G[threadIdx.x * sz + t]; lam[threadIdx.x] = l; }
     __syncthreads();
@@ -315,7 +398,7 @@ __global__ __launch_bounds__(256) void k_pose_pinv(const double* A, int pos, int
 }
 // the kept block: A' out, eigen square root J0 = sqrt(S) V^T (column-major), r0 = sqrt(S^-1) V^T b'   (cpp:364-372)
 // outp = [Ar n*n | br n | J0 n*n | r0 n]
-__global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const double* b, int pos, int m, int n, double eps, double* outp) {
+__global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const double* b, int pos, int m, int n, double eps, double* outp, double* dbg) {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     double* G = s_dyn; double* V = s_dyn + (size_t)n * n;
     __shared__ int rot;
@@ -326,8 +409,11 @@ __global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const dou
         G[t] = v; Ar[t] = v; V[t] = (r == c) ? 1.0 : 0.0;
     }
     for (int t = threadIdx.x; t < n; t += blockDim.x) br[t] = b[m + t];
+    __shared__ double s_part[16];
     __syncthreads();
-    jacobi_lds(G, V, n, 1e-15, 30, &rot);
+    const double noise2 = jacobi_noise2(G, n, s_part);
+    if (dbg && threadIdx.x == 0) { for (int q = 0; q < 48; ++q) dbg[q] = -1.0; dbg[40] = noise2; }
+    jacobi_lds(G, V, n, JACOBI_TOL, noise2, 30, &rot, dbg);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int j = wave; j < n; j += nw) {
@@ -520,7 +606,7 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
     }
     // (2) A = J^T J, b = J^T r
     launch_ata(dJ.p, R, pos, dA.p, pos, s);
-    hipLaunchKernelGGL(k_jt_r, dim3((pos + 63) / 64), dim3(64), 0, s, dJ.p, dr.p, R, pos, db.p);
+    hipLaunchKernelGGL(k_jt_r, dim3((pos + 3) / 4), dim3(256), 0, s, dJ.p, dr.p, R, pos, db.p);
     // (3) landmark blocks, then the keyframe block of the reduced system
     if (!blk_off.empty()) {
         const int nb = (int)blk_off.size();
@@ -530,7 +616,7 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
     }
     if (pose_size > 0) {
         hipLaunchKernelGGL(k_pose_pinv, dim3(1), dim3(256), 0, s, dA.p, pos, pose_off, pose_size, eps, dPinvP.p);
-        hipLaunchKernelGGL(k_block_Z1, dim3((pos + 63) / 64), dim3(64), 0, s, dA.p, pos, pose_off, pose_size, dPinvP.p, dZ.p);
+        hipLaunchKernelGGL(k_block_Z1, dim3((pos * pose_size + 255) / 256), dim3(256), 0, s, dA.p, pos, pose_off, pose_size, dPinvP.p, dZ.p);
         hipLaunchKernelGGL(k_schur_apply, dim3((pos + 1 + 15) / 16, (pos + 15) / 16), dim3(16, 16), 0, s, dA.p, db.p, pos, dZ.p, delimP.p, (int)elimP.size(), drestP.p);
     }
     // (4) eigen square root of the kept block
@@ -539,7 +625,7 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
         const size_t sh = 2 * (size_t)n * n * sizeof(double);
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_marg_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * JLDS_MAX_N * JLDS_MAX_N * sizeof(double))); attr_set = true; }
-        hipLaunchKernelGGL(k_marg_finish, dim3(1), dim3(1024), sh, s, dA.p, db.p, pos, m, n, eps, dOut.p);
+        hipLaunchKernelGGL(k_marg_finish, dim3(1), dim3(1024), sh, s, dA.p, db.p, pos, m, n, eps, dOut.p, d.dbgbuf);
     } else {
         // larger kept blocks: G and V in HBM, one launch per round, convergence checked on the host once per sweep
         PLBA_HIPCK(p, dG.alloc((size_t)n * n, false)); PLBA_HIPCK(p, dV.alloc((size_t)n * n, false)); PLBA_HIPCK(p, drot.alloc(1));
@@ -552,7 +638,7 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
         for (int sweep = 0; sweep < 30; ++sweep) {
             PLBA_HIPCK(p, hipMemsetAsync(drot.p, 0, sizeof(int), s));
             for (int round = 0; round < npad - 1; ++round)
-                hipLaunchKernelGGL(k_jacobi_round, dim3(npad / 2), dim3(256), 0, s, dG.p, dV.p, n, npad, round, 1e-15, drot.p);
+                hipLaunchKernelGGL(k_jacobi_round, dim3(npad / 2), dim3(256), 0, s, dG.p, dV.p, n, npad, round, JACOBI_TOL, drot.p);
             int rotated = 0;
             PLBA_HIPCK(p, hipMemcpyAsync(&rotated, drot.p, sizeof(int), hipMemcpyDeviceToHost, s));
             PLBA_HIPCK(p, hipStreamSynchronize(s));
