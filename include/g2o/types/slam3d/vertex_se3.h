@@ -1,0 +1,3 @@
+// forwards to the MI355X-native facade: see include/plba_g2o/types_slam3d.h (replaces g2o/types/slam3d/vertex_se3.h of the third-party g2o)
+#pragma once
+#include "plba_g2o/types_slam3d.h"

@@ -11,9 +11,13 @@
 //   NavState (IMU/NavState.h), IMUPreintegrator (IMU/IMUPreintegrator.h), Sophus::SO3 (IMU/so3.h)
 //   MarginalizationInfo, ResidualBlockInfo                                    (IMU/marginalization.h:29-100)
 //
-// optimize() does not walk virtual computeError()/linearizeOplus() per edge: it recognises the edge/vertex types of
-// the hot path, flattens the graph into the SoA arrays of include/plba.h in the reference's insertion order and
-// runs the HIP kernels.  Graphs containing other vertex/edge types are rejected (there is no CPU fallback).
+// optimize() does not walk virtual computeError()/linearizeOplus() per edge on the hot path: it recognises the edge/vertex
+// types of the local BA, flattens the graph into the SoA arrays of include/plba.h in the reference's insertion order and
+// runs the HIP kernels.  The OTHER g2o users of the same translation unit (src/mapHandler.cpp: IMUInitEstBg :4989-5036, a
+// 1-vertex EdgeGyrBias problem; the pose-graph optimisers :4068-4297, :4299-4528, VertexSE3 / EdgeSE3) are tiny problems
+// over host-evaluated edge types: those graphs run g2o's Levenberg / Gauss-Newton loop on the host, over
+// the edges' own computeError() / linearizeOplus(), with a dense Cholesky (on the device through plba_debug_dense_solve
+// once the system is large).  A graph mixing the two families is rejected.
 #pragma once
 
 #if defined(__has_include)
@@ -33,6 +37,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <limits>
 #include <map>
 #include <memory>
 #include <string>
@@ -148,10 +153,18 @@ public:
     virtual ~RobustKernel() {}
     virtual void setDelta(double d) { _delta = d; }
     double delta() const { return _delta; }
+    virtual void robustify(double e2, double* rho) const { rho[0] = e2; rho[1] = 1.0; rho[2] = 0.0; }      // host path only
 protected:
     double _delta = 1.0;
 };
-class RobustKernelHuber : public RobustKernel {};
+class RobustKernelHuber : public RobustKernel {
+public:
+    void robustify(double e, double* rho) const override {      // g2o RobustKernelHuber::robustify
+        const double dsqr = _delta * _delta;
+        if (e <= dsqr) { rho[0] = e; rho[1] = 1.0; rho[2] = 0.0; }
+        else { const double sqrte = std::sqrt(e); rho[0] = 2 * sqrte * _delta - dsqr; rho[1] = _delta / sqrte; rho[2] = -0.5 * rho[1] / e; }
+    }
+};
 
 // ---- graph elements -----------------------------------------------------------------------------------------------
 class OptimizableGraph {
@@ -172,8 +185,13 @@ public:
         virtual void setToOriginImpl() = 0;
         virtual bool read(std::istream&) { return true; }
         virtual bool write(std::ostream&) const { return true; }
+        virtual void push() {}             // g2o's estimate stack (LM trials of the host path)
+        virtual void pop() {}
+        virtual void discardTop() {}
+        int hessianIndex() const { return _hidx; }
         SparseOptimizer* graph() const { return _graph; }
         int _plba_index = -1;       // keyframe / point / line index in the flattened arrays
+        int _hidx = -1;             // first row of the vertex in the host path's normal equations, -1 = fixed / inactive
     protected:
         friend class SparseOptimizer;
         int _id = -1;
@@ -197,6 +215,14 @@ public:
         virtual void linearizeOplus() {}
         virtual bool read(std::istream&) { return true; }
         virtual bool write(std::ostream&) const { return true; }
+        // host path: an edge type that evaluates itself (computeError / linearizeOplus fill _error and the Jacobian blocks)
+        virtual bool plbaHostEvaluable() const { return false; }
+        virtual const double* plbaError() const { return nullptr; }            // dimension() doubles
+        virtual const double* plbaInformation() const { return nullptr; }      // dimension()^2, row-major
+        virtual const double* plbaJacobian(size_t) const { return nullptr; }   // dimension() x vertex(k)->dimension(), row-major
+        // EstimatePropagator support (computeInitialGuess): can `to` be initialised from the other vertices, and do it
+        virtual double initialEstimatePossible(const Vertex*, const Vertex*) { return -1.0; }
+        virtual void initialEstimate(const Vertex*, Vertex*) {}
         SparseOptimizer* graph() const { return _graph; }
         int _plba_kind = -1, _plba_index = -1;                  // plba_edge_kind and index after flattening
         double _chi2_cache = 0.0;
@@ -219,8 +245,12 @@ public:
     void setEstimate(const T& e) { _estimate = e; }
     int dimension() const override { return D; }
     void setToOriginImpl() override {}
+    void push() override { _backup.push_back(_estimate); }
+    void pop() override { if (!_backup.empty()) { _estimate = _backup.back(); _backup.pop_back(); } }
+    void discardTop() override { if (!_backup.empty()) _backup.pop_back(); }
 protected:
     T _estimate;
+    std::vector<T> _backup;
 };
 
 template <int D, typename E>
@@ -250,6 +280,17 @@ public:
     const std::vector<double>& jacobianOplus(size_t k) const { return _jac[k]; }
     const std::vector<double>& jacobianOplusXi() const { return _jac[0]; }
     const std::vector<double>& jacobianOplusXj() const { return _jac[1]; }
+    // `e->information() = Matrix6d::Identity();` (src/mapHandler.cpp:4175,4406): assignable view of the information matrix
+    struct InformationRef {
+        BaseEdgeT* e;
+        template <typename M> InformationRef& operator=(const M& m) { e->setInformation(m); return *this; }
+        double operator()(int i, int j) const { return e->_info[(size_t)i * e->_dimension + j]; }
+    };
+    InformationRef information() { return InformationRef{this}; }
+    bool plbaHostEvaluable() const override { return !_jac.empty() && _jac.size() == this->_vertices.size(); }
+    const double* plbaError() const override { return _error.data(); }
+    const double* plbaInformation() const override { return _info.data(); }
+    const double* plbaJacobian(size_t k) const override { return k < _jac.size() ? _jac[k].data() : nullptr; }
 protected:
     double& J(size_t k, int cols, int r, int c) { return _jac[k][(size_t)r * cols + c]; }
     void allocJacobians(std::initializer_list<int> dims) {
@@ -264,31 +305,45 @@ template <int D, typename E, typename VXi> class BaseUnaryEdge : public BaseEdge
 template <int D, typename E, typename VXi, typename VXj> class BaseBinaryEdge : public BaseEdgeT<D, E> { public: BaseBinaryEdge() { this->resize(2); } };
 template <int D, typename E> class BaseMultiEdge : public BaseEdgeT<D, E> {};
 
-// ---- solver chain (configuration objects only; the arithmetic lives in the HIP library) --------------------------------
+// ---- solver chain (configuration objects only; the arithmetic lives in the HIP library / the host loop below) -----------
 struct PoseMatrixTypeTag {};
 template <typename M> class LinearSolverEigen { public: void setBlockOrdering(bool) {} };
+template <typename M> class LinearSolverCholmod { public: void setBlockOrdering(bool) {} };      // g2o/solvers/cholmod (mapHandler.cpp:4071,4302)
+template <typename M> class LinearSolverDense { public: void setBlockOrdering(bool) {} };        // g2o/solvers/dense
+template <typename M> class LinearSolverCSparse { public: void setBlockOrdering(bool) {} };
 class Solver { public: virtual ~Solver() {} };
+template <int P, int L> struct BlockSolverTraits { static const int PoseDim = P, LandmarkDim = L; typedef PoseMatrixTypeTag PoseMatrixType; };
+template <typename Traits>
+class BlockSolver : public Solver {
+public:
+    typedef PoseMatrixTypeTag PoseMatrixType;
+    template <typename LS> explicit BlockSolver(std::unique_ptr<LS> ls) { (void)ls; }
+};
 class BlockSolverX : public Solver {
 public:
     typedef PoseMatrixTypeTag PoseMatrixType;
     template <typename LS> explicit BlockSolverX(std::unique_ptr<LS> ls) { (void)ls; }
 };
+typedef BlockSolver<BlockSolverTraits<6, 3>> BlockSolver_6_3;
+typedef BlockSolver<BlockSolverTraits<7, 3>> BlockSolver_7_3;
+typedef BlockSolver<BlockSolverTraits<3, 2>> BlockSolver_3_2;
+template <int PointDoF> class StructureOnlySolver { public: void calc(...) {} };                 // g2o/solvers/structure_only (included, never used by src/)
 class OptimizationAlgorithm { public: virtual ~OptimizationAlgorithm() {} };
 class OptimizationAlgorithmLevenberg : public OptimizationAlgorithm {
 public:
-    explicit OptimizationAlgorithmLevenberg(std::unique_ptr<BlockSolverX> s) : _solver(std::move(s)) {}
+    template <typename S> explicit OptimizationAlgorithmLevenberg(std::unique_ptr<S> s) : _solver(std::move(s)) {}
     void setUserLambdaInit(double l) { userLambdaInit = l; }
     void setMaxTrialsAfterFailure(int n) { maxTrials = n; }
     double userLambdaInit = 0.0;
     int maxTrials = 10;
 private:
-    std::unique_ptr<BlockSolverX> _solver;
+    std::unique_ptr<Solver> _solver;
 };
 class OptimizationAlgorithmGaussNewton : public OptimizationAlgorithm {
 public:
-    explicit OptimizationAlgorithmGaussNewton(std::unique_ptr<BlockSolverX> s) : _solver(std::move(s)) {}
+    template <typename S> explicit OptimizationAlgorithmGaussNewton(std::unique_ptr<S> s) : _solver(std::move(s)) {}
 private:
-    std::unique_ptr<BlockSolverX> _solver;
+    std::unique_ptr<Solver> _solver;
 };
 
 }  // namespace g2o
@@ -413,6 +468,9 @@ public:
         for (int i = 0; i < 3; ++i) { cam.Pbc[i] = Pbc_(i); for (int j = 0; j < 3; ++j) cam.Rbc[i * 3 + j] = Rbc_(i, j); }
     }
     bool isDepthPositive() { return _depth_cache_fresh(); }
+    // `if (e->level() == 1) e->computeError();` of the culling loop (src/mapHandler.cpp:5541-5556): the cached error of a
+    // gated-out edge is refreshed on the written-back estimates (same arithmetic as the device kernels, plba_math.h)
+    inline void computeError() override;
     void GetJacAddr(std::vector<double*>& addr) { addr.assign(2, nullptr); }
     void GetEstData(std::vector<VectorXd>& data) {
         VectorXd a(3), b;
@@ -432,6 +490,7 @@ public:
         for (int i = 0; i < 3; ++i) { cam.Pbc[i] = Pbc_(i); for (int j = 0; j < 3; ++j) cam.Rbc[i * 3 + j] = Rbc_(i, j); }
     }
     bool isDepthPositive() { return _depth_cache_fresh(); }
+    inline void computeError() override;      // culling loop, src/mapHandler.cpp:5611-5620
     void GetJacAddr(std::vector<double*>& addr) { addr.assign(2, nullptr); }
     void GetEstData(std::vector<VectorXd>& data) {
         VectorXd a(6), b;
@@ -774,6 +833,7 @@ public:
 
     // = g2o SparseOptimizer::optimize: returns the number of iterations, -1/0 on failure
     int optimize(int iterations) {
+        if (!onDevicePath()) return optimizeHost(iterations);
         if (!flatten()) { std::cerr << "[plba g2o facade] " << _err << std::endl; return -1; }
         static_assert(sizeof(bool) == 1, "force-stop flag is polled as a byte");
         const int rc = plba_optimize(_prob, iterations, reinterpret_cast<const volatile uint8_t*>(_forceStop), &_stats);
@@ -783,6 +843,207 @@ public:
         return _stats.iterations;
     }
 
+
+    // ================================================================================================================
+    // host path: graphs of host-evaluated edge types (IMUInitEstBg, pose-graph optimisation: SURVEY §8f row 4)
+    // ================================================================================================================
+    // true when every edge belongs to the local-BA family the HIP kernels implement
+    bool onDevicePath() const {
+        for (auto* e : _edges)
+            if (!(dynamic_cast<EdgeNavStatePVRPointXYZ*>(e) || dynamic_cast<EdgeNavStateLine*>(e) || dynamic_cast<EdgeNavStatePVR*>(e) ||
+                  dynamic_cast<EdgeNavStateBias*>(e) || dynamic_cast<EdgeMarginalization*>(e))) return false;
+        return true;
+    }
+    // g2o SparseOptimizer::computeActiveErrors / activeChi2 / activeRobustChi2 on the host-evaluated edges of the active level
+    void computeActiveErrors() { if (onDevicePath()) return; collectActive(); for (auto* e : _active) e->computeError(); }
+    double activeChi2() { double c = 0.0; for (auto* e : _active) c += edgeChi2(e); return c; }
+    double activeRobustChi2() {
+        double c = 0.0;
+        for (auto* e : _active) { const double e2 = edgeChi2(e); if (e->robustKernel()) { double rho[3]; e->robustKernel()->robustify(e2, rho); c += rho[0]; } else c += e2; }
+        return c;
+    }
+    // g2o SparseOptimizer::computeInitialGuess: estimates propagate from the fixed vertices through the active edges
+    // (EstimatePropagator with unit edge costs: breadth first, edges in insertion order; g2o is third-party and unpinned,
+    // its priority-queue tie breaking is not reproduced — SURVEY App. A provenance warning)
+    void computeInitialGuess() {
+        if (onDevicePath()) return;
+        collectActive();
+        std::map<OptimizableGraph::Vertex*, bool> done;
+        std::vector<OptimizableGraph::Vertex*> frontier;
+        for (auto* e : _active) for (auto* v : e->vertices()) if (v && v->fixed() && !done[v]) { done[v] = true; frontier.push_back(v); }
+        while (!frontier.empty()) {
+            std::vector<OptimizableGraph::Vertex*> next;
+            for (auto* from : frontier)
+                for (auto* e : _active) {
+                    if (e->vertices().size() != 2) continue;
+                    OptimizableGraph::Vertex* to = e->vertex(0) == from ? e->vertex(1) : e->vertex(1) == from ? e->vertex(0) : nullptr;
+                    if (!to || done[to] || to->fixed() || e->initialEstimatePossible(from, to) <= 0.0) continue;
+                    e->initialEstimate(from, to);
+                    done[to] = true; next.push_back(to);
+                }
+            frontier.swap(next);
+        }
+    }
+
+private:
+    static double edgeChi2(const OptimizableGraph::Edge* e) {
+        const int d = e->dimension();
+        const double* er = e->plbaError(); const double* om = e->plbaInformation();
+        double c = 0.0;
+        for (int i = 0; i < d; ++i) { double t = 0.0; for (int j = 0; j < d; ++j) t += om[(size_t)i * d + j] * er[j]; c += er[i] * t; }
+        return c;
+    }
+    void collectActive() {
+        _active.clear();
+        for (auto* e : _edges) if (e->level() == _level) _active.push_back(e);
+    }
+    // Hessian indices: non-fixed vertices of the active edges, non-marginalized first, each group by ascending id (App. A.1)
+    bool indexHost() {
+        collectActive();
+        for (auto& kv : _vertices) kv.second->_hidx = -1;
+        std::map<int, OptimizableGraph::Vertex*> used;
+        for (auto* e : _active) {
+            if (!e->plbaHostEvaluable()) return fail("edge type is neither on the device path nor host-evaluable");
+            for (auto* v : e->vertices()) { if (!v) return fail("edge with an unset vertex"); used[v->id()] = v; }
+        }
+        _hverts.clear(); _hN = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (auto& kv : used) {
+                OptimizableGraph::Vertex* v = kv.second;
+                if (v->fixed() || (int)v->marginalized() != pass) continue;
+                v->_hidx = _hN; _hN += v->dimension(); _hverts.push_back(v);
+            }
+        return true;
+    }
+    // buildSystem (App. A.4): H = sum J^T (rho1 Omega) J, b = -sum J^T (rho1 Omega e), dense, both triangles
+    void buildHost(std::vector<double>& H, std::vector<double>& b) {
+        const int N = _hN;
+        H.assign((size_t)N * N, 0.0); b.assign(N, 0.0);
+        std::vector<double> OJ, we;
+        for (auto* e : _active) {
+            e->linearizeOplus();
+            const int d = e->dimension();
+            const double* er = e->plbaError(); const double* om = e->plbaInformation();
+            double w = 1.0;
+            if (e->robustKernel()) { double rho[3]; e->robustKernel()->robustify(edgeChi2(e), rho); w = rho[1]; }
+            we.assign(d, 0.0);
+            for (int i = 0; i < d; ++i) { double t = 0.0; for (int j = 0; j < d; ++j) t += om[(size_t)i * d + j] * er[j]; we[i] = w * t; }
+            const size_t nv = e->vertices().size();
+            for (size_t a = 0; a < nv; ++a) {
+                OptimizableGraph::Vertex* va = e->vertex(a);
+                if (va->_hidx < 0) continue;
+                const int da = va->dimension(); const double* Ja = e->plbaJacobian(a);
+                for (int c = 0; c < da; ++c) { double t = 0.0; for (int r = 0; r < d; ++r) t += Ja[(size_t)r * da + c] * we[r]; b[va->_hidx + c] -= t; }
+                OJ.assign((size_t)d * da, 0.0);                   // (rho1 Omega) J_a
+                for (int r = 0; r < d; ++r) for (int c = 0; c < da; ++c) { double t = 0.0; for (int k = 0; k < d; ++k) t += om[(size_t)r * d + k] * Ja[(size_t)k * da + c]; OJ[(size_t)r * da + c] = w * t; }
+                for (size_t bq = 0; bq < nv; ++bq) {
+                    OptimizableGraph::Vertex* vb = e->vertex(bq);
+                    if (vb->_hidx < 0) continue;
+                    const int dbb = vb->dimension(); const double* Jb = e->plbaJacobian(bq);
+                    for (int r = 0; r < dbb; ++r) for (int c = 0; c < da; ++c) { double t = 0.0; for (int k = 0; k < d; ++k) t += Jb[(size_t)k * dbb + r] * OJ[(size_t)k * da + c]; H[(size_t)(vb->_hidx + r) * N + va->_hidx + c] += t; }
+                }
+            }
+        }
+    }
+    // (H + lambda I) x = b: dense LL^T; on the device (K7, the same kernels the local BA uses) once the system is large
+    bool solveHost(const std::vector<double>& H, const std::vector<double>& b, double lambda, std::vector<double>& x) {
+        const int N = _hN;
+        std::vector<double> A(H);
+        for (int i = 0; i < N; ++i) A[(size_t)i * N + i] += lambda;
+        x.assign(N, 0.0);
+        if (N > 384) {
+            if (!_prob) { plba_options o; plba_default_options(&o); if (plba_create(&o, &_prob) != PLBA_OK) _prob = nullptr; }
+            if (_prob) { int ok = 0; if (plba_debug_dense_solve(_prob, N, A.data(), b.data(), x.data(), &ok) == PLBA_OK) return ok != 0; }
+        }
+        for (int j = 0; j < N; ++j) {
+            double dj = A[(size_t)j * N + j];
+            for (int k = 0; k < j; ++k) dj -= A[(size_t)j * N + k] * A[(size_t)j * N + k];
+            if (!(dj > 0.0)) return false;
+            dj = std::sqrt(dj);
+            A[(size_t)j * N + j] = dj;
+            for (int i = j + 1; i < N; ++i) {
+                double sacc = A[(size_t)i * N + j];
+                for (int k = 0; k < j; ++k) sacc -= A[(size_t)i * N + k] * A[(size_t)j * N + k];
+                A[(size_t)i * N + j] = sacc / dj;
+            }
+        }
+        for (int i = 0; i < N; ++i) { double sacc = b[i]; for (int k = 0; k < i; ++k) sacc -= A[(size_t)i * N + k] * x[k]; x[i] = sacc / A[(size_t)i * N + i]; }
+        for (int i = N - 1; i >= 0; --i) { double sacc = x[i]; for (int k = i + 1; k < N; ++k) sacc -= A[(size_t)k * N + i] * x[k]; x[i] = sacc / A[(size_t)i * N + i]; }
+        return true;
+    }
+    // g2o SparseOptimizer::optimize with OptimizationAlgorithmLevenberg::solve or
+    // OptimizationAlgorithmGaussNewton::solve on the host-evaluated edges
+    int optimizeHost(int iterations) {
+        auto* lm = dynamic_cast<OptimizationAlgorithmLevenberg*>(_algorithm);
+        auto* gn = dynamic_cast<OptimizationAlgorithmGaussNewton*>(_algorithm);
+        if (!lm && !gn) { fail("no optimisation algorithm set"); std::cerr << "[plba g2o facade] " << _err << std::endl; return -1; }
+        if (!indexHost()) { std::cerr << "[plba g2o facade] " << _err << std::endl; return -1; }
+        std::memset(&_stats, 0, sizeof _stats);
+        if (_hN == 0) return 0;
+        const int N = _hN;
+        std::vector<double> H, b, x;
+        double lambda = 0.0, ni = 2.0;
+        int done = 0;
+        bool ok = true;
+        for (int it = 0; it < iterations && !terminate() && ok; ++it) {
+            for (auto* e : _active) e->computeError();
+            double currentChi = activeRobustChi2();
+            if (it == 0) _stats.chi2_initial = currentChi;
+            buildHost(H, b);
+            if (gn) {                                                           // one undamped step
+                const bool sok = solveHost(H, b, 0.0, x);
+                if (sok) for (auto* v : _hverts) v->oplusImpl(&x[v->_hidx]);
+                else { ok = false; ++_stats.solver_failures; }
+                ++_stats.trials; ++done;
+                continue;
+            }
+            if (it == 0) {                                                      // computeLambdaInit
+                if (lm->userLambdaInit > 0) lambda = lm->userLambdaInit;
+                else { double md = 0.0; for (int i = 0; i < N; ++i) md = std::max(md, std::fabs(H[(size_t)i * N + i])); lambda = 1e-5 * md; }
+                ni = 2.0;
+            }
+            double rho = 0.0;
+            int qmax = 0;
+            do {
+                for (auto* v : _hverts) v->push();
+                const bool sok = solveHost(H, b, lambda, x);
+                if (!sok) ++_stats.solver_failures;
+                for (auto* v : _hverts) v->oplusImpl(&x[v->_hidx]);
+                for (auto* e : _active) e->computeError();
+                double tempChi = activeRobustChi2();
+                if (!sok) tempChi = std::numeric_limits<double>::max();
+                double scale = 1e-3;
+                for (int i = 0; i < N; ++i) scale += x[i] * (lambda * x[i] + b[i]);
+                rho = (currentChi - tempChi) / scale;
+                ++_stats.trials;
+                if (rho > 0 && std::isfinite(tempChi)) {
+                    double alpha = 1.0 - std::pow(2 * rho - 1, 3);
+                    alpha = std::min(alpha, 2.0 / 3.0);
+                    lambda *= std::max(1.0 / 3.0, alpha);
+                    ni = 2.0;
+                    currentChi = tempChi;
+                    for (auto* v : _hverts) v->discardTop();
+                } else {
+                    lambda *= ni; ni *= 2.0;
+                    for (auto* v : _hverts) v->pop();
+                    if (!std::isfinite(lambda)) break;
+                }
+                ++qmax;
+            } while (rho < 0 && qmax < lm->maxTrials && !terminate());
+            ++done;
+            _stats.chi2_final = currentChi; _stats.lambda_final = lambda;
+            if (qmax == lm->maxTrials || rho == 0 || !std::isfinite(lambda)) { ok = false; _stats.stop_reason = 1; }
+        }
+        if (gn) { for (auto* e : _active) e->computeError(); _stats.chi2_final = activeRobustChi2(); }
+        _stats.iterations = done;
+        if (_verbose) std::cerr << "iterations= " << done << "\t chi2= " << _stats.chi2_final << "\t lambda= " << lambda << std::endl;
+        return done;
+    }
+    std::vector<OptimizableGraph::Edge*> _active;
+    std::vector<OptimizableGraph::Vertex*> _hverts;
+    int _hN = 0;
+
+public:
     // used by MarginalizationInfo::marginalizeWithoutThread
     bool marginalizeFactors(const std::vector<ResidualBlockInfo*>& factors, MarginalizationInfo* out) {
         if (!_prob) { _err = "marginalize before optimize"; return false; }
@@ -1015,6 +1276,28 @@ private:
     std::string _err;
 };
 
+inline void EdgeNavStatePVRPointXYZ::computeError() {
+    const plba::Cam c = plba_make_cam(cam);
+    double kc[12], e2[2], Jp[12], Jl[6];
+    plba::kfcam_make(c, static_cast<const VertexNavStatePVR*>(_vertices[1])->estimate().raw(), kc);
+    const Vector3d& P = static_cast<const VertexLMPointXYZ*>(_vertices[0])->estimate();
+    bool dpos = true;
+    plba::point_edge(c, kc, plba::v3(P[0], P[1], P[2]), _measurement[0], _measurement[1], e2, Jp, Jl, dpos, false);
+    _error[0] = e2[0]; _error[1] = e2[1];
+    _chi2_cache = _info[0] * (e2[0] * e2[0] + e2[1] * e2[1]);
+    _depth_cache = dpos;
+}
+inline void EdgeNavStateLine::computeError() {
+    const plba::Cam c = plba_make_cam(cam);
+    double kc[12], e2[2], Jp[12], Jl[6];
+    plba::kfcam_make(c, static_cast<const VertexNavStatePVR*>(_vertices[1])->estimate().raw(), kc);
+    const Vector6d& L = static_cast<const VertexLine*>(_vertices[0])->estimate();
+    bool dpos = true;
+    plba::line_edge(c, kc, plba::v3(L[0], L[1], L[2]), plba::v3(L[3], L[4], L[5]), _measurement[0], _measurement[1], _measurement[2], false, e2, Jp, Jl, dpos, false);
+    _error[0] = e2[0]; _error[1] = e2[1]; _error[2] = 0.0;
+    _chi2_cache = _info[0] * (e2[0] * e2[0] + e2[1] * e2[1]);
+    _depth_cache = dpos;
+}
 inline bool EdgeNavStatePVRPointXYZ::_depth_cache_fresh() { return _depth_cache; }
 inline bool EdgeNavStateLine::_depth_cache_fresh() { return _depth_cache; }
 

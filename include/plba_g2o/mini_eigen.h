@@ -80,6 +80,30 @@ public:
     const double* coeffs() const { return c_; }
 };
 
+// rigid transform (Eigen::Isometry3d): rotation matrix + translation, the estimate type of g2o's VertexSE3
+class Isometry3d {
+    Matrix3d R_;
+    Vector3d t_;
+public:
+    Isometry3d() { R_.setIdentity(); }
+    static Isometry3d Identity() { return Isometry3d(); }
+    Matrix3d& linear() { return R_; }
+    const Matrix3d& linear() const { return R_; }
+    Matrix3d rotation() const { return R_; }
+    Vector3d& translation() { return t_; }
+    const Vector3d& translation() const { return t_; }
+    Isometry3d inverse() const {
+        Isometry3d r;
+        r.R_ = R_.transpose();
+        const Vector3d rt = r.R_ * t_;
+        for (int i = 0; i < 3; ++i) r.t_[i] = -rt[i];
+        return r;
+    }
+    Isometry3d operator*(const Isometry3d& o) const { Isometry3d r; r.R_ = R_ * o.R_; r.t_ = R_ * o.t_ + t_; return r; }
+    Vector3d operator*(const Vector3d& v) const { return R_ * v + t_; }
+    Matrix4d matrix() const { Matrix4d m; m.setIdentity(); for (int i = 0; i < 3; ++i) { m(i, 3) = t_[i]; for (int j = 0; j < 3; ++j) m(i, j) = R_(i, j); } return m; }
+};
+
 }  // namespace Eigen
 
 #define EIGEN_MAKE_ALIGNED_OPERATOR_NEW

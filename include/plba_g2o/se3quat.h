@@ -103,6 +103,16 @@ public:
         r[0] = omega.x; r[1] = omega.y; r[2] = omega.z; r[3] = ups.x; r[4] = ups.y; r[5] = ups.z;
         return r;
     }
+    // g2o's slam3d types take rigid transforms as Eigen::Isometry3d: `v_se3->setEstimate(g2o::SE3Quat::exp(x))` and
+    // `e_se3->setMeasurement(g2o::SE3Quat::exp(x))` (src/mapHandler.cpp:4122,4152,4173) rely on this conversion
+    operator Eigen::Isometry3d() const {
+        Eigen::Isometry3d T = Eigen::Isometry3d::Identity();
+        const plba::M3 m = plba::q_to_R(q_);
+        Matrix3d R; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i, j) = m.a[i * 3 + j];
+        T.linear() = R;
+        T.translation() = Vector3d(t_.x, t_.y, t_.z);
+        return T;
+    }
     void normalizeRotation() {                                 // :283-288
         if (q_.w < 0) { q_.x = -q_.x; q_.y = -q_.y; q_.z = -q_.z; q_.w = -q_.w; }
         q_ = plba::q_normalized(q_);

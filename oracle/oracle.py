@@ -54,6 +54,9 @@ def lib():
             "orc_se3_exp": [dp, dp, dp], "orc_se3_mul": [dp] * 6, "orc_se3_map": [dp] * 4, "orc_se3_log": [dp, dp, dp],
             "orc_se3_oplus": [dp] * 5,
             "orc_eval_gyrbias_edge": [dp] * 7,
+            "orc_gyrbias_estimate": [C.c_int, dp, dp, dp, dp, dp, C.c_int, C.c_int, dp, dp],
+            "orc_pgo": [C.c_int, C.POINTER(C.c_int32), dp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp, dp, C.c_int, C.c_double, C.c_int, C.c_int, dp],
+            "orc_se3_edge_error": [dp, dp, dp, dp], "orc_se3_vertex_oplus": [dp, dp, dp],
             "orc_eval_se3_edge": [C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip],
         }
         for name, args in sigs.items():

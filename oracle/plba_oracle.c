@@ -2194,3 +2194,253 @@ void orc_eval_gyrbias_edge(const double* dRbij, const double* JdRbg, const doubl
         for (int i = 0; i < 9; ++i) J9[i] = -Jx[i];
     }
 }
+
+/* =================================================================================================================
+ * SURVEY §8f row 4 — the OTHER g2o users of src/mapHandler.cpp, restated for the checker:
+ *   MapHandler::IMUInitEstBg (src/mapHandler.cpp:4989-5036): one VertexGyrBias, M EdgeGyrBias, Levenberg, optimize(1)
+ *   the pose-graph optimisers (src/mapHandler.cpp:4068-4297, 4299-4528): g2o VertexSE3 / EdgeSE3, Levenberg with
+ *   userLambdaInit 1e-10.
+ * g2o is third-party and un-vendored: the slam3d parametrisation is restated from its published form
+ * (update X <- X * fromVectorMQT(u); error toVectorMQT(Z^-1 Xi^-1 Xj)).  The EdgeSE3 Jacobians are taken here by
+ * CENTRAL DIFFERENCES of the error through the vertex update, so that this checker does not share the analytic derivation
+ * of include/plba_g2o/types_slam3d.h.  The LM loop is SURVEY App. A.3 on dense normal equations.
+ * ================================================================================================================= */
+typedef struct {
+    int N;
+    void* ctx;
+    double (*errors)(void* ctx);                          /* computeActiveErrors + activeRobustChi2 */
+    void (*build)(void* ctx, double* H, double* b);       /* buildSystem: H = sum J^T W J, b = -sum J^T W e */
+    void (*push)(void* ctx);
+    void (*pop)(void* ctx);
+    void (*update)(void* ctx, const double* x);
+} graph_ops;
+
+/* stats: chi2 before, chi2 after, iterations done, trials */
+static void lm_dense(graph_ops* g, int iters, double user_lambda, int gauss_newton, double* stats) {
+    const int N = g->N;
+    double* H = (double*)xcalloc((size_t)N * N, 8); double* A = (double*)xcalloc((size_t)N * N, 8);
+    double* b = (double*)xcalloc(N, 8); double* x = (double*)xcalloc(N, 8);
+    double lambda = 0.0, ni = 2.0;
+    int done = 0, trials = 0, ok = 1;
+    stats[0] = stats[1] = g->errors(g->ctx);
+    for (int it = 0; it < iters && ok; ++it) {
+        double currentChi = g->errors(g->ctx);
+        g->build(g->ctx, H, b);
+        if (gauss_newton) {
+            memcpy(A, H, (size_t)N * N * 8);
+            if (chol_factor(A, N)) { chol_solve(A, N, b, x); g->update(g->ctx, x); } else ok = 0;
+            ++trials; ++done;
+            stats[1] = g->errors(g->ctx);
+            continue;
+        }
+        if (it == 0) {
+            if (user_lambda > 0) lambda = user_lambda;
+            else { double md = 0.0; for (int i = 0; i < N; ++i) if (fabs(H[(size_t)i * N + i]) > md) md = fabs(H[(size_t)i * N + i]); lambda = 1e-5 * md; }
+            ni = 2.0;
+        }
+        double rho = 0.0;
+        int qmax = 0;
+        do {
+            g->push(g->ctx);
+            memcpy(A, H, (size_t)N * N * 8);
+            for (int i = 0; i < N; ++i) A[(size_t)i * N + i] += lambda;
+            const int sok = chol_factor(A, N);
+            if (sok) chol_solve(A, N, b, x); else memset(x, 0, (size_t)N * 8);
+            g->update(g->ctx, x);
+            double tempChi = g->errors(g->ctx);
+            if (!sok) tempChi = DBL_MAX;
+            double scale = 1e-3;
+            for (int i = 0; i < N; ++i) scale += x[i] * (lambda * x[i] + b[i]);
+            rho = (currentChi - tempChi) / scale;
+            ++trials;
+            if (rho > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow(2 * rho - 1, 3);
+                if (alpha > 2. / 3.) alpha = 2. / 3.;
+                lambda *= (alpha > 1. / 3.) ? alpha : 1. / 3.;
+                ni = 2; currentChi = tempChi;
+            } else {
+                lambda *= ni; ni *= 2;
+                g->pop(g->ctx);
+                if (!isfinite(lambda)) break;
+            }
+            ++qmax;
+        } while (rho < 0 && qmax < 10);
+        ++done;
+        stats[1] = currentChi;
+        if (qmax == 10 || rho == 0 || !isfinite(lambda)) ok = 0;
+    }
+    stats[2] = done; stats[3] = trials;
+    free(H); free(A); free(b); free(x);
+}
+
+/* ---- IMUInitEstBg ------------------------------------------------------------------------------------------------ */
+typedef struct { int M; const double *dR, *J, *Ri, *Rj, *info; double bg[3], saved[3]; } gyr_ctx;
+static double gyr_errors(void* c) {
+    gyr_ctx* g = (gyr_ctx*)c;
+    double chi = 0.0;
+    for (int m = 0; m < g->M; ++m) {
+        double e[3];
+        orc_eval_gyrbias_edge(g->dR + 9 * m, g->J + 9 * m, g->Ri + 9 * m, g->Rj + 9 * m, g->bg, e, NULL);
+        chi += quad_form(e, g->info + 9 * m, 3);
+    }
+    return chi;
+}
+static void gyr_build(void* c, double* H, double* b) {
+    gyr_ctx* g = (gyr_ctx*)c;
+    memset(H, 0, 72); memset(b, 0, 24);
+    for (int m = 0; m < g->M; ++m) {
+        double e[3], J[9], OJ[9], Oe[3];
+        orc_eval_gyrbias_edge(g->dR + 9 * m, g->J + 9 * m, g->Ri + 9 * m, g->Rj + 9 * m, g->bg, e, J);
+        const double* Om = g->info + 9 * m;
+        mat_mul(Om, J, OJ, 3, 3, 3); m3_v(Om, e, Oe);
+        for (int r = 0; r < 3; ++r) {
+            for (int cc = 0; cc < 3; ++cc) { double s = 0; for (int k = 0; k < 3; ++k) s += J[k * 3 + r] * OJ[k * 3 + cc]; H[r * 3 + cc] += s; }
+            double s = 0; for (int k = 0; k < 3; ++k) s += J[k * 3 + r] * Oe[k];
+            b[r] -= s;
+        }
+    }
+}
+static void gyr_push(void* c) { gyr_ctx* g = (gyr_ctx*)c; memcpy(g->saved, g->bg, 24); }
+static void gyr_pop(void* c) { gyr_ctx* g = (gyr_ctx*)c; memcpy(g->bg, g->saved, 24); }
+static void gyr_update(void* c, const double* x) { gyr_ctx* g = (gyr_ctx*)c; for (int i = 0; i < 3; ++i) g->bg[i] += x[i]; }
+/* bg3: in = start (the reference starts at zero), out = estimate; stats4: chi2 before / after, iterations, trials */
+void orc_gyrbias_estimate(int M, const double* dR9, const double* JRg9, const double* Rwbi9, const double* Rwbj9, const double* info9,
+                          int iters, int gauss_newton, double* bg3, double* stats4) {
+    gyr_ctx c; c.M = M; c.dR = dR9; c.J = JRg9; c.Ri = Rwbi9; c.Rj = Rwbj9; c.info = info9;
+    memcpy(c.bg, bg3, 24);
+    graph_ops g = {3, &c, gyr_errors, gyr_build, gyr_push, gyr_pop, gyr_update};
+    lm_dense(&g, iters, 0.0, gauss_newton, stats4);
+    memcpy(bg3, c.bg, 24);
+}
+
+/* ---- pose graph: g2o VertexSE3 / EdgeSE3 ------------------------------------------------------------------------------ */
+typedef struct { double R[9], t[3]; } iso_t;
+static void iso_mul(const iso_t* a, const iso_t* b, iso_t* o) { iso_t r; m3_mul(a->R, b->R, r.R); m3_v(a->R, b->t, r.t); for (int i = 0; i < 3; ++i) r.t[i] += a->t[i]; *o = r; }
+static void iso_inv(const iso_t* a, iso_t* o) { iso_t r; m3_T(a->R, r.R); m3_v(r.R, a->t, r.t); for (int i = 0; i < 3; ++i) r.t[i] = -r.t[i]; *o = r; }
+static void iso_from_mqt(const double* u, iso_t* o) { /* internal::fromVectorMQT */
+    memcpy(o->t, u, 24);
+    const double w2 = 1.0 - (u[3] * u[3] + u[4] * u[4] + u[5] * u[5]);
+    if (w2 < 0) { memset(o->R, 0, 72); o->R[0] = o->R[4] = o->R[8] = 1.0; }
+    else { double q[4] = {u[3], u[4], u[5], sqrt(w2)}; q_to_R(q, o->R); }
+}
+static void iso_to_mqt(const iso_t* a, double* e) { /* internal::toVectorMQT: q normalised, w >= 0 */
+    double q[4];
+    R_to_q(a->R, q); q_normalize(q);
+    if (q[3] < 0) for (int i = 0; i < 4; ++i) q[i] = -q[i];
+    memcpy(e, a->t, 24); e[3] = q[0]; e[4] = q[1]; e[5] = q[2];
+}
+typedef struct {
+    int nv, ne;
+    iso_t *X, *saved;
+    const int32_t *fixed, *ei, *ej;
+    int* hidx;
+    iso_t *Z, *Zi;
+    const double* info;
+} pgo_ctx;
+static void pgo_edge_error(const pgo_ctx* g, int k, const iso_t* Xi, const iso_t* Xj, double* e) {
+    iso_t a, b;
+    iso_inv(Xi, &a); iso_mul(&g->Zi[k], &a, &b); iso_mul(&b, Xj, &a);
+    iso_to_mqt(&a, e);
+}
+static double pgo_errors(void* c) {
+    pgo_ctx* g = (pgo_ctx*)c;
+    double chi = 0.0;
+    for (int k = 0; k < g->ne; ++k) { double e[6]; pgo_edge_error(g, k, &g->X[g->ei[k]], &g->X[g->ej[k]], e); chi += quad_form(e, g->info + 36 * k, 6); }
+    return chi;
+}
+static void pgo_numjac(const pgo_ctx* g, int k, int which, double* J /*6x6 row-major*/) {
+    const double h = 1e-6;
+    for (int c = 0; c < 6; ++c) {
+        double u[6] = {0, 0, 0, 0, 0, 0}, ep[6], em[6];
+        iso_t d, Xp, Xm;
+        const iso_t* Xi = &g->X[g->ei[k]]; const iso_t* Xj = &g->X[g->ej[k]];
+        u[c] = h; iso_from_mqt(u, &d); iso_mul(which ? Xj : Xi, &d, &Xp);
+        u[c] = -h; iso_from_mqt(u, &d); iso_mul(which ? Xj : Xi, &d, &Xm);
+        pgo_edge_error(g, k, which ? Xi : &Xp, which ? &Xp : Xj, ep);
+        pgo_edge_error(g, k, which ? Xi : &Xm, which ? &Xm : Xj, em);
+        for (int r = 0; r < 6; ++r) J[r * 6 + c] = (ep[r] - em[r]) / (2 * h);
+    }
+}
+static void pgo_build(void* c, double* H, double* b) {
+    pgo_ctx* g = (pgo_ctx*)c;
+    int N = 0;
+    for (int v = 0; v < g->nv; ++v) if (g->hidx[v] >= 0) N += 6;
+    memset(H, 0, (size_t)N * N * 8); memset(b, 0, (size_t)N * 8);
+    for (int k = 0; k < g->ne; ++k) {
+        double e[6], J[2][36], Oe[6];
+        const int vv[2] = {g->ei[k], g->ej[k]};
+        pgo_edge_error(g, k, &g->X[vv[0]], &g->X[vv[1]], e);
+        pgo_numjac(g, k, 0, J[0]); pgo_numjac(g, k, 1, J[1]);
+        const double* Om = g->info + 36 * k;
+        for (int r = 0; r < 6; ++r) { double s = 0; for (int q = 0; q < 6; ++q) s += Om[r * 6 + q] * e[q]; Oe[r] = s; }
+        for (int a = 0; a < 2; ++a) {
+            const int oa = g->hidx[vv[a]];
+            if (oa < 0) continue;
+            for (int cc = 0; cc < 6; ++cc) { double s = 0; for (int r = 0; r < 6; ++r) s += J[a][r * 6 + cc] * Oe[r]; b[oa + cc] -= s; }
+            for (int bb = 0; bb < 2; ++bb) {
+                const int ob = g->hidx[vv[bb]];
+                if (ob < 0) continue;
+                for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 6; ++cc) {
+                    double s = 0;
+                    for (int p = 0; p < 6; ++p) for (int q = 0; q < 6; ++q) s += J[a][p * 6 + r] * Om[p * 6 + q] * J[bb][q * 6 + cc];
+                    H[(size_t)(oa + r) * N + ob + cc] += s;
+                }
+            }
+        }
+    }
+}
+static void pgo_push(void* c) { pgo_ctx* g = (pgo_ctx*)c; memcpy(g->saved, g->X, sizeof(iso_t) * (size_t)g->nv); }
+static void pgo_pop(void* c) { pgo_ctx* g = (pgo_ctx*)c; memcpy(g->X, g->saved, sizeof(iso_t) * (size_t)g->nv); }
+static void pgo_update(void* c, const double* x) {
+    pgo_ctx* g = (pgo_ctx*)c;
+    for (int v = 0; v < g->nv; ++v) if (g->hidx[v] >= 0) { iso_t d; iso_from_mqt(x + g->hidx[v], &d); iso_mul(&g->X[v], &d, &g->X[v]); }
+}
+/* pose12: nv x (R row-major 9, t 3), in = initial estimates, out = optimised; vertices are addressed by their INDEX in these arrays
+ * and must be given in ascending vertex-id order (Hessian order, App. A.1); meas12 likewise per edge; info36 row-major.
+ * initial_guess: breadth-first propagation from the fixed vertices through the edges in insertion order (the facade's reading of
+ * g2o's computeInitialGuess).  stats4: chi2 before (after the initial guess) / after, iterations, trials. */
+void orc_pgo(int nv, const int32_t* fixed, double* pose12, int ne, const int32_t* ei, const int32_t* ej, const double* meas12,
+             const double* info36, int iters, double user_lambda, int gauss_newton, int initial_guess, double* stats4) {
+    pgo_ctx g;
+    g.nv = nv; g.ne = ne; g.fixed = fixed; g.ei = ei; g.ej = ej; g.info = info36;
+    g.X = (iso_t*)xcalloc(nv, sizeof(iso_t)); g.saved = (iso_t*)xcalloc(nv, sizeof(iso_t));
+    g.Z = (iso_t*)xcalloc(ne > 0 ? ne : 1, sizeof(iso_t)); g.Zi = (iso_t*)xcalloc(ne > 0 ? ne : 1, sizeof(iso_t));
+    g.hidx = (int*)xcalloc(nv, sizeof(int));
+    int N = 0;
+    for (int v = 0; v < nv; ++v) { memcpy(g.X[v].R, pose12 + 12 * v, 72); memcpy(g.X[v].t, pose12 + 12 * v + 9, 24); if (fixed[v]) g.hidx[v] = -1; else { g.hidx[v] = N; N += 6; } }
+    for (int k = 0; k < ne; ++k) { memcpy(g.Z[k].R, meas12 + 12 * k, 72); memcpy(g.Z[k].t, meas12 + 12 * k + 9, 24); iso_inv(&g.Z[k], &g.Zi[k]); }
+    if (initial_guess) {
+        char* done = (char*)xcalloc(nv, 1); int* front = (int*)xcalloc(nv, sizeof(int)); int* next = (int*)xcalloc(nv, sizeof(int));
+        int nf = 0;
+        for (int k = 0; k < ne; ++k) { const int vv[2] = {ei[k], ej[k]}; for (int a = 0; a < 2; ++a) if (fixed[vv[a]] && !done[vv[a]]) { done[vv[a]] = 1; front[nf++] = vv[a]; } }
+        while (nf > 0) {
+            int nn = 0;
+            for (int f = 0; f < nf; ++f) for (int k = 0; k < ne; ++k) {
+                const int from = front[f];
+                const int to = ei[k] == from ? ej[k] : ej[k] == from ? ei[k] : -1;
+                if (to < 0 || done[to] || fixed[to]) continue;
+                if (ei[k] == from) iso_mul(&g.X[from], &g.Z[k], &g.X[to]); else iso_mul(&g.X[from], &g.Zi[k], &g.X[to]);
+                done[to] = 1; next[nn++] = to;
+            }
+            memcpy(front, next, sizeof(int) * (size_t)nn); nf = nn;
+        }
+        free(done); free(front); free(next);
+    }
+    graph_ops ops = {N, &g, pgo_errors, pgo_build, pgo_push, pgo_pop, pgo_update};
+    if (N > 0) lm_dense(&ops, iters, user_lambda, gauss_newton, stats4);
+    else { stats4[0] = stats4[1] = pgo_errors(&g); stats4[2] = stats4[3] = 0; }
+    for (int v = 0; v < nv; ++v) { memcpy(pose12 + 12 * v, g.X[v].R, 72); memcpy(pose12 + 12 * v + 9, g.X[v].t, 24); }
+    free(g.X); free(g.saved); free(g.Z); free(g.Zi); free(g.hidx);
+}
+/* the EdgeSE3 pieces on their own, for Jacobian checks of include/plba_g2o/types_slam3d.h: error of one edge and the vertex update */
+void orc_se3_edge_error(const double* Xi12, const double* Xj12, const double* Z12, double* e6) {
+    pgo_ctx g; iso_t Xi, Xj, Z, Zi;
+    memcpy(Xi.R, Xi12, 72); memcpy(Xi.t, Xi12 + 9, 24); memcpy(Xj.R, Xj12, 72); memcpy(Xj.t, Xj12 + 9, 24); memcpy(Z.R, Z12, 72); memcpy(Z.t, Z12 + 9, 24);
+    iso_inv(&Z, &Zi); g.Zi = &Zi;
+    pgo_edge_error(&g, 0, &Xi, &Xj, e6);
+}
+void orc_se3_vertex_oplus(const double* X12, const double* u6, double* out12) {
+    iso_t X, d; memcpy(X.R, X12, 72); memcpy(X.t, X12 + 9, 24);
+    iso_from_mqt(u6, &d); iso_mul(&X, &d, &X);
+    memcpy(out12, X.R, 72); memcpy(out12 + 9, X.t, 24);
+}

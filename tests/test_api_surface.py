@@ -27,7 +27,7 @@ def shim(pkg, hip_lib_path):
            "-I", os.path.join(pkgdir, "csrc"), src, "-o", so, "-L", pkgdir, "-lplba_hip", "-Wl,-rpath," + pkgdir]
     subprocess.run(cmd, check=True, capture_output=True)
     lib = C.CDLL(so)
-    for f in ("shim_se3_exp", "shim_se3_log", "shim_se3_oplus", "shim_se3_inverse_mul", "shim_se3_vertex_io", "shim_eval_se3_edge"):
+    for f in ("shim_se3_exp", "shim_se3_log", "shim_se3_oplus", "shim_se3_inverse_mul", "shim_se3_vertex_io", "shim_eval_se3_edge", "shim_eval_edge_se3"):
         getattr(lib, f).restype = None
     return lib
 
@@ -328,3 +328,35 @@ def test_navstate_point_edges(shim, orc, pkg):
             assert np.allclose(Jj[:, :9], Jjo, rtol=1e-11, atol=1e-11) and np.all(Jj[:, 9:] == 0)
             if not only_pose:
                 assert np.allclose(Ji, Jio, rtol=1e-11, atol=1e-11)
+
+
+def test_edge_se3_jacobians_are_the_derivatives_of_its_error(pkg, orc, shim):
+    """include/plba_g2o/types_slam3d.h: analytic _jacobianOplusXi / Xj of EdgeSE3 against central differences of the oracle's
+    error through the oracle's vertex update (tools/api_surface_shim.cpp evaluates the facade's edge)"""
+    rng = np.random.default_rng(3)
+    W = pkg.window
+    lib = orc.lib().cdll
+    for _ in range(5):
+        X = []
+        for _k in range(3):
+            R = W.exp_so3(rng.normal(size=3) * 0.8); t = rng.normal(size=3) * 2
+            X.append(np.ascontiguousarray(np.concatenate([R.ravel(), t])))
+        Xi, Xj, Z = X
+        e, Ji, Jj = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 6))
+        shim.shim_eval_edge_se3(_d(Xi), _d(Xj), _d(Z), _d(e), _d(Ji), _d(Jj))
+        e0 = np.zeros(6)
+        lib.orc_se3_edge_error(_d(Xi), _d(Xj), _d(Z), _d(e0))
+        assert np.abs(e - e0).max() < 1e-12
+        h = 1e-6
+        for which, Jan in ((0, Ji), (1, Jj)):
+            Jn = np.zeros((6, 6))
+            for c in range(6):
+                ep, em, Xp, Xm = np.zeros(6), np.zeros(6), np.zeros(12), np.zeros(12)
+                u = np.zeros(6); u[c] = h
+                lib.orc_se3_vertex_oplus(_d(Xj if which else Xi), _d(u), _d(Xp))
+                u[c] = -h
+                lib.orc_se3_vertex_oplus(_d(Xj if which else Xi), _d(u), _d(Xm))
+                lib.orc_se3_edge_error(_d(Xi if which else Xp), _d(Xp if which else Xj), _d(Z), _d(ep))
+                lib.orc_se3_edge_error(_d(Xi if which else Xm), _d(Xm if which else Xj), _d(Z), _d(em))
+                Jn[:, c] = (ep - em) / (2 * h)
+            assert np.abs(Jan - Jn).max() < 1e-7, which

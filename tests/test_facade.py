@@ -100,3 +100,92 @@ def test_call_site_protocol_through_the_facade(pkg, orc, hip, tmp_path):
     ro = pkg.protocol.results(o)
     assert np.abs(r["P"] - ro["P"]).max() < 1e-5 and np.abs(r["q"] - ro["q"]).max() < 1e-5
     o.close()
+
+
+def make_nomarg_window(pkg, seed=41, K=12, n_fixed=3):
+    """The graph MapHandler::localBundleAdjustmentWithImu (USE_MARG off, src/mapHandler.cpp:5086-5739) builds: keyframes
+    [0, n_fixed) are covisible keyframes OUTSIDE the sliding window (fixed PVR vertex, NO bias vertex, :5220-5231), keyframe
+    n_fixed is the window's RefKeyframe predecessor (fixed PVR + bias, :5233-5240, source of the first IMU edge), the rest is
+    the window (nothing fixed: firstFix is false when a predecessor exists, :5157-5166).  Landmarks are the `local` ones —
+    observed by at least one window keyframe — with ALL their observations, also those in the fixed keyframes."""
+    w = pkg.window.make_window(K, 300, 60, imu=True, seed=seed)
+    role = np.zeros(K, np.int32); role[:n_fixed] = 1; role[n_fixed] = 2
+    kf = w["kf"]
+    kf["vid_bias"] = kf["vid_bias"].copy(); kf["vid_bias"][:n_fixed] = -1
+    kf["fixed_pvr"] = (role != 0).astype(np.uint8); kf["fixed_bias"] = (role == 2).astype(np.uint8)
+
+    def local(lm, kfs, N):
+        keep = np.zeros(N, bool)
+        np.logical_or.at(keep, lm, role[kfs] == 0)
+        new = np.cumsum(keep) - 1
+        sel = keep[lm]
+        return keep, sel, new
+    keep, sel, new = local(w["po_pt"], w["po_kf"], len(w["points"]))
+    w["points"] = w["points"][keep]
+    w["po_pt"], w["po_kf"], w["po_uv"], w["po_w"] = new[w["po_pt"][sel]].astype(np.int32), w["po_kf"][sel], w["po_uv"][sel], w["po_w"][sel]
+    keep, sel, new = local(w["lo_ln"], w["lo_kf"], len(w["lines"]))
+    w["lines"] = w["lines"][keep]
+    w["lo_ln"], w["lo_kf"], w["lo_l"], w["lo_w"] = new[w["lo_ln"][sel]].astype(np.int32), w["lo_kf"][sel], w["lo_l"][sel], w["lo_w"][sel]
+    im = dict(w["imu"]); m = im["kf_i"] >= n_fixed
+    for k in ("kf_i", "kf_j", "preint", "info_pvr", "info_bias"):
+        im[k] = im[k][m]
+    w["imu"] = im
+    w["role"] = role
+    return w
+
+
+@pytest.mark.gpu
+def test_use_marg_off_shape_against_the_oracle(pkg, orc, hip):
+    """VERDICT r01 missing #3 / next #8: fixed covisible keyframes WITHOUT bias vertex mixed with the IMU-chained window, a fixed
+    RefKeyframe carrying PVR + bias and an IMU edge into the window, two-stage solve, then the culling decision — through the
+    C ABI against the oracle"""
+    w = make_nomarg_window(pkg)
+    assert (w["kf"]["vid_bias"] < 0).sum() == 3 and w["role"][w["po_kf"]].max() >= 1      # observations in fixed keyframes exist
+    g = pkg.new_problem(); g.upload_window(w)
+    o = orc.new_problem(); o.upload_window(w)
+    g.debug_build(7.0, False); o.debug_build(7.0, False)
+    assert g.debug_get("pose_dim")[0] == o.debug_get("pose_dim")[0] == 8 * 15
+    for name in ("err_pt", "err_ln", "err_pvr", "err_bias", "bp", "bschur", "Hschur", "chi2", "maxdiag"):
+        a, b = g.debug_get(name), o.debug_get(name)
+        assert np.abs(a - b).max() <= 1e-9 * max(np.abs(b).max(), 1e-300), name
+    rg, ro = pkg.protocol.local_ba(g), pkg.protocol.local_ba(o)
+    assert rg["gated"] == ro["gated"]
+    assert (rg["stage2"].iterations, rg["stage2"].trials, rg["stage2"].solver_failures) == (ro["stage2"].iterations, ro["stage2"].trials, 0)
+    kg, ko = g.get_keyframes(), o.get_keyframes()
+    for k in ("P", "V", "q", "dbg", "dba"):
+        assert np.abs(kg[k] - ko[k]).max() < 1e-8, k
+    assert np.array_equal(kg["P"][:4], w["kf"]["P"][:4]) and np.array_equal(kg["q"][:4], w["kf"]["q"][:4])      # fixed keyframes stay put
+    assert np.abs(g.get_points() - o.get_points()).max() < 1e-7
+    cg, co = g.cull_observations(), o.cull_observations()
+    assert np.array_equal(cg["bad_points"], co["bad_points"]) and np.array_equal(cg["bad_lines"], co["bad_lines"])
+    g.close(); o.close()
+
+
+@pytest.mark.gpu
+def test_use_marg_off_call_site_through_the_facade(pkg, hip, tmp_path):
+    """the same graph built by the call-site-shaped code of tools/localba_harness.cpp (`nomarg`): vertices in the reference's
+    insertion order (window keyframes first, then the fixed ones), culling loop with computeError() on the gated edges"""
+    w = make_nomarg_window(pkg)
+    K = len(w["kf"]["P"])
+    exe = build_harness()
+    win, res = str(tmp_path / "w.bin"), str(tmp_path / "r.bin")
+    write_window(w, win, do_marg=0)
+    with open(win, "ab") as f:
+        w["role"].astype(np.int32).tofile(f); w["imu"]["kf_i"].astype(np.int32).tofile(f); w["imu"]["kf_j"].astype(np.int32).tofile(f)
+    subprocess.check_call([exe, "nomarg", win, res], timeout=120)
+    Np, Nl, Ep, El = len(w["points"]), len(w["lines"]), len(w["po_pt"]), len(w["lo_ln"])
+    r = read_result(res, K, Np, Nl)
+    with open(res, "rb") as f:
+        f.seek(-(Ep + El), 2)
+        bad = np.fromfile(f, np.uint8, Ep + El)
+    g = pkg.new_problem(); g.upload_window(w)
+    out = pkg.protocol.local_ba(g)
+    ref = pkg.protocol.results(g)
+    assert r["gated"] == out["gated"]
+    for k in ("P", "V", "q", "points", "lines"):
+        assert np.abs(r[k] - ref[k]).max() < 1e-9, k
+    win_kf = w["role"] == 0
+    assert np.abs(r["dbg"][win_kf] - ref["dbg"][win_kf]).max() < 1e-9
+    c = g.cull_observations()
+    assert np.array_equal(bad[:Ep].astype(bool), c["bad_points"]) and np.array_equal(bad[Ep:].astype(bool), c["bad_lines"])
+    g.close()

@@ -5,6 +5,7 @@
 
 #include "plba_g2o/types_six_dof_expmap.h"
 #include "plba_g2o/g2otypes.h"
+#include "plba_g2o/types_slam3d.h"
 
 using namespace g2o;
 
@@ -174,6 +175,21 @@ void shim_navstate_point(const double* camv, const double* nav22, const double* 
         e.computeError(); e.linearizeOplus();
         cp(e.error(), err2); cp(e.jacobianOplusXi(), Ji6); cp(e.jacobianOplusXj(), Jj30); *dpos = e.isDepthPositive();
     }
+}
+
+// g2o slam3d EdgeSE3 between two VertexSE3 (include/plba_g2o/types_slam3d.h); poses as (R row-major 9, t 3)
+void shim_eval_edge_se3(const double* Xi12, const double* Xj12, const double* Z12, double* err6, double* Ji36, double* Jj36) {
+    auto iso = [](const double* p) {
+        Eigen::Isometry3d T = Eigen::Isometry3d::Identity();
+        Matrix3d R; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i, j) = p[i * 3 + j];
+        T.linear() = R; T.translation() = Vector3d(p[9], p[10], p[11]);
+        return T;
+    };
+    VertexSE3 a, b; a.setEstimate(iso(Xi12)); b.setEstimate(iso(Xj12)); a.setId(0); b.setId(1);
+    EdgeSE3 e; e.setVertex(0, &a); e.setVertex(1, &b); e.setMeasurement(iso(Z12));
+    e.computeError(); e.linearizeOplus();
+    for (int i = 0; i < 6; ++i) err6[i] = e.error()[i];
+    for (int i = 0; i < 36; ++i) { Ji36[i] = e.jacobianOplusXi()[i]; Jj36[i] = e.jacobianOplusXj()[i]; }
 }
 
 }  // extern "C"

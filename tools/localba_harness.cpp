@@ -5,6 +5,13 @@
 // on a window read from a flat binary file (written by tests/test_facade.py) instead of KeyFrame/MapPoint objects.
 // It proves that code written against the reference's g2o API (IMU/g2otypes.h, IMU/marginalization.h) runs on the HIP
 // path unchanged in shape.  Usage: localba_harness <window.bin> <result.bin>
+//
+// The same translation unit also holds the OTHER g2o users of src/mapHandler.cpp, in the shape of their call sites and
+// compiled against the header set include/mapHandler.h:35-45 pulls (slam3d, cholmod / dense / structure_only solvers,
+// types_six_dof_expmap), so that "mapHandler.cpp compiles against include/" is checked on everything it uses from g2o:
+//   localba_harness nomarg  <window.bin> <result.bin>   MapHandler::localBundleAdjustmentWithImu (USE_MARG off, :5086-5739)
+//   localba_harness gyrbias <in.bin> <out.bin>          MapHandler::IMUInitEstBg (:4989-5036)
+//   localba_harness pgo     <in.bin> <out.bin>          MapHandler::loopClosureOptimizationCovGraphG2O (:4299-4528), g2o part
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -15,13 +22,132 @@
 #include <g2o/core/robust_kernel_impl.h>
 #include <g2o/core/sparse_optimizer.h>
 #include <g2o/solvers/eigen/linear_solver_eigen.h>
+// the rest of what include/mapHandler.h:35-45 includes from g2o
+#include <g2o/types/slam3d/vertex_se3.h>
+#include <g2o/types/slam3d/edge_se3.h>
+#include <g2o/core/solver.h>
+#include <g2o/core/robust_kernel.h>
+#include <g2o/solvers/cholmod/linear_solver_cholmod.h>
+#include <g2o/solvers/dense/linear_solver_dense.h>
+#include <g2o/solvers/structure_only/structure_only_solver.h>
+#include <g2o/types/sba/types_six_dof_expmap.h>
 #include "plba_g2o/g2otypes.h"
+
+#include <cstring>
+#include <map>
+#include <string>
+typedef Eigen::Matrix<double, 6, 6> Matrix6d;
 
 template <typename T> static std::vector<T> rd(FILE* f, size_t n) { std::vector<T> v(n); if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } return v; }
 template <typename T> static void wr(FILE* f, const std::vector<T>& v) { if (!v.empty()) fwrite(v.data(), sizeof(T), v.size(), f); }
 
+// ---- MapHandler::IMUInitEstBg (src/mapHandler.cpp:4989-5036): one VertexGyrBias, one EdgeGyrBias per keyframe pair ------------
+static int imu_init_est_bg(const char* in, const char* out) {
+    FILE* f = fopen(in, "rb");
+    if (!f) { perror("in"); return 2; }
+    auto hdr = rd<int32_t>(f, 2);
+    const int M = hdr[0], iters = hdr[1];
+    auto dR = rd<double>(f, 9 * (size_t)M), JRg = rd<double>(f, 9 * (size_t)M), Ri = rd<double>(f, 9 * (size_t)M), Rj = rd<double>(f, 9 * (size_t)M), info = rd<double>(f, 9 * (size_t)M);
+    fclose(f);
+    auto m3 = [](const double* p) { Matrix3d m; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m(i, j) = p[i * 3 + j]; return m; };
+
+    g2o::SparseOptimizer optimizer;
+    auto linearSolver = g2o::make_unique<SlamLinearSolver>();
+    linearSolver->setBlockOrdering(false);
+    auto blockSolver = g2o::make_unique<g2o::BlockSolverX>(std::move(linearSolver));
+    g2o::OptimizationAlgorithm* algorithm = new g2o::OptimizationAlgorithmLevenberg(std::move(blockSolver));
+    optimizer.setAlgorithm(algorithm);
+    g2o::VertexGyrBias* vBiasg = new g2o::VertexGyrBias();
+    vBiasg->setEstimate(Eigen::Vector3d::Zero());
+    vBiasg->setId(0);
+    optimizer.addVertex(vBiasg);
+    for (int m = 0; m < M; ++m) {
+        g2o::EdgeGyrBias* eBiasg = new g2o::EdgeGyrBias();
+        eBiasg->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(0)));
+        eBiasg->dRbij = m3(&dR[9 * (size_t)m]);
+        eBiasg->J_dR_bg = m3(&JRg[9 * (size_t)m]);
+        eBiasg->Rwbi = m3(&Ri[9 * (size_t)m]);
+        eBiasg->Rwbj = m3(&Rj[9 * (size_t)m]);
+        eBiasg->setInformation(m3(&info[9 * (size_t)m]));          // getCovPVPhi().bottomRightCorner(3,3).inverse(), formed by the caller
+        optimizer.addEdge(eBiasg);
+    }
+    optimizer.initializeOptimization();
+    const int done = optimizer.optimize(iters);                    // the reference: 1 ("actually a linear estimator")
+    g2o::VertexGyrBias* vBgEst = static_cast<g2o::VertexGyrBias*>(optimizer.vertex(0));
+    const Vector3d bg = vBgEst->estimate();
+    FILE* o = fopen(out, "wb");
+    if (!o) { perror("out"); return 2; }
+    wr(o, std::vector<double>{bg[0], bg[1], bg[2], optimizer.lastStats().chi2_initial, optimizer.lastStats().chi2_final, (double)done});
+    fclose(o);
+    printf("imu_init_est_bg: %d edges, bg = (%.6e, %.6e, %.6e)\n", M, bg[0], bg[1], bg[2]);
+    return 0;
+}
+
+// ---- g2o part of MapHandler::loopClosureOptimizationCovGraphG2O (src/mapHandler.cpp:4299-4528) -------------------------------------
+// vertices: id, fixed flag, se3 6-vector x with estimate SE3Quat::exp(x); kf2kf edges with setInformation, loop-closure edges
+// with `information() = ...`; computeInitialGuess / computeActiveErrors / optimize(maxItersPGO); poses back as SE3Quat::log().
+static int pose_graph(const char* in, const char* out) {
+    FILE* f = fopen(in, "rb");
+    if (!f) { perror("in"); return 2; }
+    auto hdr = rd<int32_t>(f, 5);
+    const int nv = hdr[0], ne = hdr[1], nlc = hdr[2], iters = hdr[3], init_guess = hdr[4];
+    auto vid = rd<int32_t>(f, nv), vfix = rd<int32_t>(f, nv); auto vx = rd<double>(f, 6 * (size_t)nv);
+    auto ei = rd<int32_t>(f, ne + nlc), ej = rd<int32_t>(f, ne + nlc); auto ex = rd<double>(f, 6 * (size_t)(ne + nlc));
+    fclose(f);
+    auto v6 = [](const double* p) { Vector6d x; for (int i = 0; i < 6; ++i) x[i] = p[i]; return x; };
+
+    typedef g2o::BlockSolver<g2o::BlockSolverTraits<6, 3>> BlockSolverType;
+    typedef g2o::LinearSolverCholmod<BlockSolverType::PoseMatrixType> LinearSolverType;
+    auto solver = new g2o::OptimizationAlgorithmLevenberg(g2o::make_unique<BlockSolverType>(g2o::make_unique<LinearSolverType>()));
+    g2o::SparseOptimizer optimizer;
+    optimizer.setVerbose(false);
+    solver->setUserLambdaInit(1e-10);
+    optimizer.setAlgorithm(solver);
+    for (int i = 0; i < nv; ++i) {
+        g2o::VertexSE3* v_se3 = new g2o::VertexSE3();
+        v_se3->setId(vid[i]);
+        v_se3->setMarginalized(false);
+        v_se3->setEstimate(g2o::SE3Quat::exp(v6(&vx[6 * (size_t)i])));
+        if (vfix[i]) v_se3->setFixed(true);
+        optimizer.addVertex(v_se3);
+    }
+    for (int k = 0; k < ne + nlc; ++k) {
+        g2o::EdgeSE3* e_se3 = new g2o::EdgeSE3();
+        e_se3->setVertex(0, optimizer.vertex(ei[k]));
+        e_se3->setVertex(1, optimizer.vertex(ej[k]));
+        e_se3->setMeasurement(g2o::SE3Quat::exp(v6(&ex[6 * (size_t)k])));
+        if (k < ne) e_se3->setInformation(Matrix6d::Identity());
+        else e_se3->information() = Matrix6d::Identity();           // the loop-closure edges' spelling (:4406)
+        optimizer.addEdge(e_se3);
+    }
+    optimizer.initializeOptimization();
+    if (init_guess) optimizer.computeInitialGuess();
+    optimizer.computeActiveErrors();
+    const double chi0 = optimizer.activeChi2();
+    const int done = optimizer.optimize(iters);
+    std::vector<double> res;
+    for (int i = 0; i < nv; ++i) {
+        g2o::VertexSE3* v_se3 = static_cast<g2o::VertexSE3*>(optimizer.vertex(vid[i]));
+        g2o::SE3Quat Tiw_corr = v_se3->estimateAsSE3Quat();
+        const Vector6d x = Tiw_corr.log();
+        for (int c = 0; c < 6; ++c) res.push_back(x[c]);
+    }
+    res.push_back(chi0); res.push_back(optimizer.lastStats().chi2_final); res.push_back((double)done); res.push_back((double)optimizer.lastStats().trials);
+    FILE* o = fopen(out, "wb");
+    if (!o) { perror("out"); return 2; }
+    wr(o, res);
+    fclose(o);
+    printf("pose_graph: %d vertices, %d + %d edges, chi2 %.6e -> %.6e in %d iterations\n", nv, ne, nlc, chi0, optimizer.lastStats().chi2_final, done);
+    return 0;
+}
+
+static int local_ba_with_imu(const char* in, const char* out);
+
 int main(int argc, char** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s window.bin result.bin\n", argv[0]); return 2; }
+    if (argc >= 4 && !strcmp(argv[1], "gyrbias")) return imu_init_est_bg(argv[2], argv[3]);
+    if (argc >= 4 && !strcmp(argv[1], "pgo")) return pose_graph(argv[2], argv[3]);
+    if (argc >= 4 && !strcmp(argv[1], "nomarg")) return local_ba_with_imu(argv[2], argv[3]);
+    if (argc < 3) { fprintf(stderr, "usage: %s [nomarg|gyrbias|pgo] window.bin result.bin\n", argv[0]); return 2; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror("window"); return 2; }
     auto hdr = rd<int32_t>(f, 8);
@@ -214,5 +340,197 @@ int main(int argc, char** argv) {
     wr(o, J0); wr(o, r0);
     fclose(o);
     printf("localba_harness: gated %d+%d, chi2 %.6f, prior n=%d\n", gated_pt, gated_ln, chi2_final, n);
+    return 0;
+}
+
+
+// ---- MapHandler::localBundleAdjustmentWithImu (USE_MARG off, src/mapHandler.cpp:5086-5739) --------------------------------------------
+// Window file as above plus per-keyframe roles: 0 = sliding-window keyframe, 1 = fixed covisible keyframe outside the window (PVR
+// vertex only, :5220-5231), 2 = RefKeyframe, the window's predecessor (fixed PVR + bias vertices, :5233-5240, source of the first
+// IMU edge).  IMU edge m joins keyframes imu_i[m] -> imu_j[m].  After the two-stage solve the culling decision of :5541-5620.
+static int local_ba_with_imu(const char* in, const char* out) {
+    FILE* f = fopen(in, "rb");
+    if (!f) { perror("window"); return 2; }
+    auto hdr = rd<int32_t>(f, 8);
+    const int K = hdr[0], Np = hdr[1], Nl = hdr[2], Ep = hdr[3], El = hdr[4], M = hdr[5];
+    auto cam = rd<double>(f, 4); auto Rbcv = rd<double>(f, 9); auto Pbcv = rd<double>(f, 3); auto gwv = rd<double>(f, 3); auto hub = rd<double>(f, 4);
+    auto kf_idx = rd<int32_t>(f, K);
+    auto P = rd<double>(f, 3 * K), V = rd<double>(f, 3 * K), q = rd<double>(f, 4 * K), bg = rd<double>(f, 3 * K), ba = rd<double>(f, 3 * K);
+    auto pts = rd<double>(f, 3 * (size_t)Np), lns = rd<double>(f, 6 * (size_t)Nl);
+    auto po_pt = rd<int32_t>(f, Ep), po_kf = rd<int32_t>(f, Ep); auto po_uv = rd<double>(f, 2 * (size_t)Ep), po_sig = rd<double>(f, Ep);
+    auto lo_ln = rd<int32_t>(f, El), lo_kf = rd<int32_t>(f, El); auto lo_l = rd<double>(f, 3 * (size_t)El), lo_sig = rd<double>(f, El);
+    auto pre = rd<double>(f, 142 * (size_t)M), ipvr = rd<double>(f, 81 * (size_t)M), ibias = rd<double>(f, 36 * (size_t)M);
+    auto role = rd<int32_t>(f, K); auto imu_i = rd<int32_t>(f, M), imu_j = rd<int32_t>(f, M);
+    fclose(f);
+    Matrix3d Rbc; Vector3d tbc, gw(gwv[0], gwv[1], gwv[2]);
+    for (int i = 0; i < 3; ++i) { tbc(i) = Pbcv[i]; for (int j = 0; j < 3; ++j) Rbc(i, j) = Rbcv[i * 3 + j]; }
+    const double fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    bool abortFlag = false;
+    bool* mbaAbort = &abortFlag;
+    auto nav = [&](int k) {
+        NavState ns;
+        ns.Set_Pos(Vector3d(P[3 * k], P[3 * k + 1], P[3 * k + 2])); ns.Set_Vel(Vector3d(V[3 * k], V[3 * k + 1], V[3 * k + 2]));
+        ns.Set_Rot(Sophus::SO3(Quaterniond(q[4 * k + 3], q[4 * k], q[4 * k + 1], q[4 * k + 2])));
+        ns.Set_BiasGyr(Vector3d(bg[3 * k], bg[3 * k + 1], bg[3 * k + 2])); ns.Set_BiasAcc(Vector3d(ba[3 * k], ba[3 * k + 1], ba[3 * k + 2]));
+        return ns;
+    };
+    int first_window = -1, ref_kf = -1;
+    for (int k = 0; k < K; ++k) { if (role[k] == 0 && first_window < 0) first_window = k; if (role[k] == 2) ref_kf = k; }
+    const bool firstFix = ref_kf < 0;                                // :5157-5166
+
+    g2o::SparseOptimizer optimizer;
+    auto linearSolver = g2o::make_unique<SlamLinearSolver>();
+    auto blockSolver = g2o::make_unique<g2o::BlockSolverX>(std::move(linearSolver));
+    g2o::OptimizationAlgorithm* algorithm = new g2o::OptimizationAlgorithmLevenberg(std::move(blockSolver));
+    optimizer.setAlgorithm(algorithm);
+    if (mbaAbort) optimizer.setForceStopFlag(mbaAbort);
+    int maxKFid = 0;
+    for (int k = 0; k < K; ++k) {                                    // sliding-window keyframe vertices (:5190-5218)
+        if (role[k] != 0) continue;
+        const int idKF = kf_idx[k] * 2;
+        g2o::VertexNavStatePVR* vNSPVR = new g2o::VertexNavStatePVR();
+        vNSPVR->setEstimate(nav(k)); vNSPVR->setId(idKF); vNSPVR->setFixed(false);
+        if (k == first_window && firstFix) vNSPVR->setFixed(true);
+        optimizer.addVertex(vNSPVR);
+        g2o::VertexNavStateBias* vNSBias = new g2o::VertexNavStateBias();
+        vNSBias->setEstimate(nav(k)); vNSBias->setId(idKF + 1); vNSBias->setFixed(false);
+        if (k == first_window && firstFix) vNSBias->setFixed(true);
+        optimizer.addVertex(vNSBias);
+        if (idKF + 1 > maxKFid) maxKFid = idKF + 1;
+    }
+    for (int k = 0; k < K; ++k) {                                    // fixed keyframes (:5220-5243)
+        if (role[k] == 0) continue;
+        const int idKF = kf_idx[k] * 2;
+        g2o::VertexNavStatePVR* vNSPVR = new g2o::VertexNavStatePVR();
+        vNSPVR->setEstimate(nav(k)); vNSPVR->setId(idKF); vNSPVR->setFixed(true);
+        optimizer.addVertex(vNSPVR);
+        if (role[k] == 2) {
+            g2o::VertexNavStateBias* vNSBias = new g2o::VertexNavStateBias();
+            vNSBias->setEstimate(nav(k)); vNSBias->setId(idKF + 1); vNSBias->setFixed(true);
+            optimizer.addVertex(vNSBias);
+        }
+        if (idKF + 1 > maxKFid) maxKFid = idKF + 1;
+    }
+    for (int m = 0; m < M; ++m) {                                    // :5253-5293
+        IMUPreintegrator imupre; imupre.setPayload(&pre[(size_t)m * 142]);
+        const int k0 = imu_i[m], k1 = imu_j[m];
+        g2o::EdgeNavStatePVR* epvr = new g2o::EdgeNavStatePVR();
+        epvr->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[k0])));
+        epvr->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[k1])));
+        epvr->setVertex(2, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[k0] + 1)));
+        epvr->setMeasurement(imupre);
+        Matrix9d InvCovPVR; for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) InvCovPVR(i, j) = ipvr[(size_t)m * 81 + i * 9 + j];
+        epvr->setInformation(InvCovPVR);
+        epvr->SetParams(gw);
+        g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber; epvr->setRobustKernel(rk); rk->setDelta(hub[2]);
+        optimizer.addEdge(epvr);
+        g2o::EdgeNavStateBias* ebias = new g2o::EdgeNavStateBias();
+        ebias->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[k0] + 1)));
+        ebias->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[k1] + 1)));
+        ebias->setMeasurement(imupre);
+        Matrix6d InvCovB; for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) InvCovB(i, j) = ibias[(size_t)m * 36 + i * 6 + j];
+        ebias->setInformation(InvCovB);
+        g2o::RobustKernelHuber* rkb = new g2o::RobustKernelHuber; ebias->setRobustKernel(rkb); rkb->setDelta(hub[3]);
+        optimizer.addEdge(ebias);
+    }
+    std::vector<g2o::EdgeNavStatePVRPointXYZ*> vpEdgesMono;
+    int maxPointId = maxKFid, e = 0;
+    for (int l = 0; l < Np; ++l) {                                  // :5309-5358
+        g2o::VertexLMPointXYZ* vPoint = new g2o::VertexLMPointXYZ();
+        vPoint->setEstimate(Vector3d(pts[3 * l], pts[3 * l + 1], pts[3 * l + 2]));
+        const int id = l + maxKFid + 1;
+        vPoint->setId(id); vPoint->setFixed(false); vPoint->setMarginalized(true);
+        optimizer.addVertex(vPoint);
+        for (; e < Ep && po_pt[e] == l; ++e) {
+            g2o::EdgeNavStatePVRPointXYZ* ed = new g2o::EdgeNavStatePVRPointXYZ();
+            ed->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(id)));
+            ed->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[po_kf[e]])));
+            ed->setMeasurement(Vector2d(po_uv[2 * e], po_uv[2 * e + 1]));
+            const float invSigma2 = 1.0 / po_sig[e];
+            ed->setInformation(Eigen::Matrix2d::Identity() * invSigma2);
+            g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber; ed->setRobustKernel(rk); rk->setDelta(hub[0]);
+            ed->SetParams(fx, fy, cx, cy, Rbc, tbc);
+            optimizer.addEdge(ed); vpEdgesMono.push_back(ed);
+        }
+        maxPointId = id + 1;
+    }
+    std::vector<g2o::EdgeNavStateLine*> vlEdgesMono;
+    e = 0;
+    for (int l = 0; l < Nl; ++l) {                                  // :5366-5412
+        g2o::VertexLine* vLine = new g2o::VertexLine();
+        Vector6d l6; for (int c = 0; c < 6; ++c) l6(c) = lns[6 * l + c];
+        vLine->setEstimate(l6);
+        const int id = l + maxPointId + 1;
+        vLine->setId(id); vLine->setMarginalized(true);
+        optimizer.addVertex(vLine);
+        for (; e < El && lo_ln[e] == l; ++e) {
+            g2o::EdgeNavStateLine* ed = new g2o::EdgeNavStateLine();
+            ed->setVertex(0, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(id)));
+            ed->setVertex(1, dynamic_cast<g2o::OptimizableGraph::Vertex*>(optimizer.vertex(2 * kf_idx[lo_kf[e]])));
+            ed->setMeasurement(Vector3d(lo_l[3 * e], lo_l[3 * e + 1], lo_l[3 * e + 2]));
+            const float invSigma2 = 1.0 / lo_sig[e];
+            ed->setInformation(Eigen::Matrix3d::Identity() * invSigma2);
+            g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber; ed->setRobustKernel(rk); rk->setDelta(hub[1]);
+            ed->SetParams(fx, fy, cx, cy, Rbc, tbc);
+            optimizer.addEdge(ed); vlEdgesMono.push_back(ed);
+        }
+    }
+    if (mbaAbort) if (*mbaAbort) return 1;                          // :5487-5489
+    optimizer.initializeOptimization();
+    optimizer.optimize(5);
+    bool bDoMore = true;
+    if (mbaAbort) if (*mbaAbort) bDoMore = false;
+    int gated_pt = 0, gated_ln = 0;
+    if (bDoMore) {
+        for (size_t i = 0, iend = vpEdgesMono.size(); i < iend; i++) {
+            g2o::EdgeNavStatePVRPointXYZ* ed = vpEdgesMono[i];
+            if (ed->chi2() > 5.991 || !ed->isDepthPositive()) { ed->setLevel(1); ++gated_pt; }
+            ed->setRobustKernel(0);
+        }
+        for (size_t i = 0; i < vlEdgesMono.size(); i++) {
+            g2o::EdgeNavStateLine* ed = vlEdgesMono[i];
+            if (ed->chi2() > 5.991 || !ed->isDepthPositive()) { ed->setLevel(1); ++gated_ln; }
+            ed->setRobustKernel(0);
+        }
+        optimizer.initializeOptimization(0);
+        optimizer.optimize(10);
+    }
+    const double chi2_final = optimizer.lastStats().chi2_final;
+    // culling decision (:5541-5556 points, :5611-5620 lines); erasing the observation from the map is map surgery (out of scope)
+    std::vector<uint8_t> bad_pt(vpEdgesMono.size(), 0), bad_ln(vlEdgesMono.size(), 0);
+    for (int i = (int)vpEdgesMono.size() - 1; i >= 0; i--) {
+        g2o::EdgeNavStatePVRPointXYZ* ed = vpEdgesMono[i];
+        if (ed->level() == 1) ed->computeError();
+        if (ed->chi2() > 5.991 || !ed->isDepthPositive()) bad_pt[i] = 1;
+    }
+    for (int i = (int)vlEdgesMono.size() - 1; i >= 0; i--) {
+        g2o::EdgeNavStateLine* ed = vlEdgesMono[i];
+        if (ed->level() == 1) ed->computeError();
+        if (ed->chi2() > 5.991 || !ed->isDepthPositive()) bad_ln[i] = 1;
+    }
+    std::vector<double> oP(3 * K), oV(3 * K), oq(4 * K), odbg(3 * K, 0.0), odba(3 * K, 0.0), opts(3 * (size_t)Np), olns(6 * (size_t)Nl);
+    for (int k = 0; k < K; ++k) {
+        g2o::VertexNavStatePVR* vNSPVR = static_cast<g2o::VertexNavStatePVR*>(optimizer.vertex(2 * kf_idx[k]));
+        const NavState& a = vNSPVR->estimate();
+        Vector3d p = a.Get_P(), v = a.Get_V();
+        Quaterniond qq = a.Get_R().unit_quaternion();
+        for (int i = 0; i < 3; ++i) { oP[3 * k + i] = p(i); oV[3 * k + i] = v(i); }
+        oq[4 * k] = qq.x(); oq[4 * k + 1] = qq.y(); oq[4 * k + 2] = qq.z(); oq[4 * k + 3] = qq.w();
+        if (role[k] != 1) {
+            g2o::VertexNavStateBias* vNSBias = static_cast<g2o::VertexNavStateBias*>(optimizer.vertex(2 * kf_idx[k] + 1));
+            Vector3d g = vNSBias->estimate().Get_dBias_Gyr(), c = vNSBias->estimate().Get_dBias_Acc();
+            for (int i = 0; i < 3; ++i) { odbg[3 * k + i] = g(i); odba[3 * k + i] = c(i); }
+        }
+    }
+    for (int l = 0; l < Np; ++l) { const Vector3d& p = static_cast<g2o::VertexLMPointXYZ*>(optimizer.vertex(l + maxKFid + 1))->estimate(); for (int i = 0; i < 3; ++i) opts[3 * l + i] = p(i); }
+    for (int l = 0; l < Nl; ++l) { const Vector6d& p = static_cast<g2o::VertexLine*>(optimizer.vertex(l + maxPointId + 1))->estimate(); for (int i = 0; i < 6; ++i) olns[6 * l + i] = p(i); }
+    FILE* o = fopen(out, "wb");
+    if (!o) { perror("result"); return 2; }
+    std::vector<int32_t> oh{gated_pt, gated_ln, 0, 0, 0};
+    wr(o, oh); wr(o, std::vector<double>{chi2_final});
+    wr(o, oP); wr(o, oV); wr(o, oq); wr(o, odbg); wr(o, odba); wr(o, opts); wr(o, olns);
+    wr(o, bad_pt); wr(o, bad_ln);
+    fclose(o);
+    printf("local_ba_with_imu: gated %d+%d, chi2 %.6f\n", gated_pt, gated_ln, chi2_final);
     return 0;
 }
