@@ -98,9 +98,8 @@ int plba_create(const plba_options* opt, plba_problem** out) {
     if (!p->have_ctx) {
         HostCtx c;
         c.device = p->device;
-        // ONE library stream per device, shared by every problem that does not bring its own (plba_set_stream): each
-        // stream is a hardware queue, and with a few of them alive in the process the first operation on one that has
-        // been idle was measured to wait ~20 ms for its queue to be scheduled again
+        // ONE library stream per device, shared by every problem that does not bring its own (plba_set_stream).  (The ~20 ms
+        // stalls once blamed on idle queues came from pageable host memory handed to hipMemcpy: plba_problem.h, plba_d2h.)
         {
             std::lock_guard<std::mutex> g(g_ctx_mu);
             auto it = g_lib_stream.find(p->device);
@@ -313,21 +312,22 @@ int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double
     DArr<double> sys, Lfac, xx, Linv, LT32, rd32, Ninv;
     DArr<Ctrl> ctrl;
     DArr<int> flags, cflags;
+    DArrStreamScope staged(p->stream, p->have_ctx ? p->ctx.stage : nullptr);      // `h` stays alive until the final wait below
     HIPCK(p, sys.upload(h)); HIPCK(p, Lfac.alloc(sysn)); HIPCK(p, xx.alloc(ld)); HIPCK(p, ctrl.alloc(1));
     HIPCK(p, Linv.alloc((size_t)(Ppad / TILE) * TILE * TILE)); HIPCK(p, flags.alloc(Ppad / TILE));
     HIPCK(p, LT32.alloc((size_t)Ppad * 64)); HIPCK(p, rd32.alloc(Ppad));
     HIPCK(p, cflags.alloc((size_t)(Ppad / 32 + 2) * (Ppad / 32)));
     Ctrl c0; memset(&c0, 0, sizeof c0); c0.solver_ok = 1;
-    HIPCK(p, hipMemcpy(ctrl.p, &c0, sizeof c0, hipMemcpyHostToDevice));
+    HIPCK(p, plba_h2d(p, ctrl.p, &c0, sizeof c0));
     DevBuf d; memset(&d, 0, sizeof d);
     d.P = n; d.Ppad = Ppad; d.ld = ld; d.sys = sys.p; d.Lfac = Lfac.p; d.x = xx.p; d.ctrl = ctrl.p; d.Linv = Linv.p; d.flow_flags = flags.p; d.LTblk = LT32.p; d.Linv32 = LT32.p; d.rdblk = rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32; d.chol_flags = cflags.p; d.flow = p->opt.factor_flow != 0; d.wide = p->opt.wide_steps != 0 && !d.flow;
     if (Ppad / 32 <= NINV_MAX_T) { HIPCK(p, Ninv.alloc((size_t)2 * Ppad * ld)); d.Ninv = Ninv.p; d.Nwork = Ninv.p + (size_t)Ppad * ld; }
     launch_cholesky(d, p->opt.use_mfma != 0, 1, p->stream);
     launch_trsv_back(d, p->opt.use_mfma != 0, 1, p->stream);
-    HIPCK(p, hipStreamSynchronize(p->stream));
+    HIPCK(p, plba_stream_wait(p->stream));
     HIPCK(p, hipGetLastError());
-    HIPCK(p, hipMemcpy(x, xx.p, (size_t)n * 8, hipMemcpyDeviceToHost));
-    HIPCK(p, hipMemcpy(&c0, ctrl.p, sizeof c0, hipMemcpyDeviceToHost));
+    HIPCK(p, plba_d2h(p, x, xx.p, (size_t)n * 8));
+    HIPCK(p, plba_d2h(p, &c0, ctrl.p, sizeof c0));
     if (ok) *ok = c0.solver_ok;
     return PLBA_OK;
 }
@@ -789,8 +789,8 @@ static int prepare(plba_problem* p) {
         HIPCK(p, p->d_pr_H.alloc((size_t)n * n));
         launch_ata(p->d_pr_J0.p, n, n, p->d_pr_H.p, n, p->stream);
         std::vector<double> H((size_t)n * n), Hc((size_t)p->Ppad * p->ld, 0.0);
-        HIPCK(p, hipStreamSynchronize(p->stream));
-        HIPCK(p, hipMemcpy(H.data(), p->d_pr_H.p, H.size() * 8, hipMemcpyDeviceToHost));
+        HIPCK(p, plba_stream_wait(p->stream));
+        HIPCK(p, plba_d2h(p, H.data(), p->d_pr_H.p, H.size() * 8));
         for (int a = 0; a < p->pr_nv; ++a) {
             if (pr_off[a] < 0) continue;
             for (int b = 0; b < p->pr_nv; ++b) {
@@ -800,9 +800,9 @@ static int prepare(plba_problem* p) {
                         Hc[(size_t)(pr_off[a] + c) * p->ld + pr_off[b] + e] = H[(size_t)(p->pr_idx[a] + c) * n + p->pr_idx[b] + e];
             }
         }
-        HIPCK(p, hipMemcpy(p->d_Hconst.p, Hc.data(), Hc.size() * 8, hipMemcpyHostToDevice));
+        HIPCK(p, plba_h2d(p, p->d_Hconst.p, Hc.data(), Hc.size() * 8));
     }
-    HIPCK(p, hipStreamSynchronize(p->stream));      // the uploads above were queued on the stream from host vectors that end here
+    HIPCK(p, plba_stream_wait(p->stream));      // the uploads above were queued on the stream from host vectors that end here
     lap("final stream sync");
     p->cur = 0;
     p->saved_valid = true;
@@ -926,9 +926,9 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
     Ctrl c0;
     memset(&c0, 0, sizeof c0);
     c0.solver_ok = 1; c0.ni = 2.0;
-    HIPCK(p, hipMemcpyAsync(d.ctrl, &c0, sizeof c0, hipMemcpyHostToDevice, s));
+    HIPCK(p, plba_h2d(p, d.ctrl, &c0, sizeof c0));
     HIPCK(p, hipMemsetAsync(d.trace_n, 0, sizeof(int), s));
-    HIPCK(p, hipStreamSynchronize(s));   // c0 lives on the stack
+    HIPCK(p, plba_stream_wait(s));   // c0 lives on the stack
     const LmParams lp = lm_params(p);
     bool ok = true;
     double last_chi = 0.0, lambda = 0.0;
@@ -972,13 +972,13 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
                 spec = true;
             }
             if (p->opt.profile >= 2) {
-                HIPCK(p, hipStreamSynchronize(s));        // every phase event must have completed before it is read
+                HIPCK(p, plba_stream_wait(s));        // every phase event must have completed before it is read
             } else {
                 // k_decide is the last kernel of the trial and writes the control block into mapped host memory
                 long spins = 0;
                 while (__atomic_load_n(&p->h_mail->seq, __ATOMIC_ACQUIRE) != seq) {
                     if (++spins > (1L << 22)) {           // ~ tens of ms: fall back to a real synchronisation (and surface any device error)
-                        HIPCK(p, hipStreamSynchronize(s));
+                        HIPCK(p, plba_stream_wait(s));
                         break;
                     }
                 }
@@ -1008,15 +1008,15 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
     if (abort_flag && *abort_flag && st.stop_reason == 0 && st.iterations < max_iters) st.stop_reason = 2;
     // trace + stats
     int ntr = 0;
-    HIPCK(p, hipMemcpy(&ntr, d.trace_n, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCK(p, plba_d2h(p, &ntr, d.trace_n, sizeof(int)));
     ntr = std::min(ntr, TRACE_CAP);
     p->trace.resize(ntr);
-    if (ntr) HIPCK(p, hipMemcpy(p->trace.data(), d.trace, sizeof(plba_trace_row) * ntr, hipMemcpyDeviceToHost));
+    if (ntr) HIPCK(p, plba_d2h(p, p->trace.data(), d.trace, sizeof(plba_trace_row) * ntr));
     if (ntr) {
         st.chi2_initial = p->trace[0].chi2_current;
         st.chi2_final = p->trace[0].chi2_current;
         for (const auto& r : p->trace) if (r.accepted) st.chi2_final = r.chi2_trial;
-        HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+        HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl)));
         st.solver_failures = p->h_ctrl->n_fail;
         st.lambda_final = p->h_ctrl->lambda;
     } else {
@@ -1025,8 +1025,8 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
         launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
         if (p->world > 1 && (rc = exchange(p, p->d_red.p, 1, 0))) return rc;
         double chi = 0.0;
-        HIPCK(p, hipMemcpyAsync(&chi, p->d_red.p, 8, hipMemcpyDeviceToHost, s));
-        HIPCK(p, hipStreamSynchronize(s));
+        HIPCK(p, plba_d2h(p, &chi, p->d_red.p, 8));
+        HIPCK(p, plba_stream_wait(s));
         st.chi2_initial = st.chi2_final = chi;
     }
     (void)last_chi;
@@ -1041,7 +1041,7 @@ int plba_recompute_errors(plba_problem* p) {
     if (rc) return rc;
     HIPCK(p, hipSetDevice(p->device));
     launch_linearize(p->dv, p->cur, false, p->rob, owns_pose_edges(p), p->stream);
-    HIPCK(p, hipStreamSynchronize(p->stream));
+    HIPCK(p, plba_stream_wait(p->stream));
     return PLBA_OK;
 }
 
@@ -1052,12 +1052,12 @@ int plba_set_levels(plba_problem* p, plba_edge_kind kind, const uint8_t* level) 
     if ((int)p->level.size() != E) p->level.assign(E, 0);
     if (!p->dirty) {   // device copy may have been changed by gate_outliers: refresh the host mirror first
         HIPCK(p, hipSetDevice(p->device));
-        HIPCK(p, hipStreamSynchronize(p->stream));
-        if (E) HIPCK(p, hipMemcpy(p->level.data(), p->d_level.p, E, hipMemcpyDeviceToHost));
+        HIPCK(p, plba_stream_wait(p->stream));
+        if (E) HIPCK(p, plba_d2h(p, p->level.data(), p->d_level.p, E));
     }
     if (kind == PLBA_EDGE_POINT) memcpy(p->level.data(), level, p->Ep);
     else memcpy(p->level.data() + p->Ep, level, p->El);
-    if (!p->dirty && E) HIPCK(p, hipMemcpy(p->d_level.p, p->level.data(), E, hipMemcpyHostToDevice));
+    if (!p->dirty && E) HIPCK(p, plba_h2d(p, p->d_level.p, p->level.data(), E));
     return PLBA_OK;
 }
 int plba_get_levels(plba_problem* p, plba_edge_kind kind, uint8_t* level) {
@@ -1067,8 +1067,8 @@ int plba_get_levels(plba_problem* p, plba_edge_kind kind, uint8_t* level) {
     if ((int)p->level.size() != E) p->level.assign(E, 0);
     if (!p->dirty && E) {
         HIPCK(p, hipSetDevice(p->device));
-        HIPCK(p, hipStreamSynchronize(p->stream));
-        HIPCK(p, hipMemcpy(p->level.data(), p->d_level.p, E, hipMemcpyDeviceToHost));
+        HIPCK(p, plba_stream_wait(p->stream));
+        HIPCK(p, plba_d2h(p, p->level.data(), p->d_level.p, E));
     }
     if (kind == PLBA_EDGE_POINT) memcpy(level, p->level.data(), p->Ep);
     else memcpy(level, p->level.data() + p->Ep, p->El);
@@ -1085,7 +1085,7 @@ int plba_gate_outliers(plba_problem* p, double thresh, int* np_out, int* nl_out)
     HIPCK(p, hipMemsetAsync(&c->n_gate_pt, 0, 2 * sizeof(int), p->stream));
     launch_gate(d, p->cur, thresh, p->stream);
     HIPCK(p, hipMemcpyAsync(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, p->stream));
-    HIPCK(p, hipStreamSynchronize(p->stream));
+    HIPCK(p, plba_stream_wait(p->stream));
     p->rob.on[PLBA_EDGE_POINT] = 0;    // setRobustKernel(0) on every point / line edge (mapHandler.cpp:6055,6065)
     p->rob.on[PLBA_EDGE_LINE] = 0;
     if (np_out) *np_out = p->h_ctrl->n_gate_pt;
@@ -1103,8 +1103,8 @@ int plba_cull_observations(plba_problem* p, double thresh, uint8_t* bad_point, u
     std::vector<uint8_t> bad((size_t)std::max(E, 1), 0);
     if (E) {
         launch_cull(d, p->cur, thresh, p->d_depth.p, p->stream);
-        HIPCK(p, hipStreamSynchronize(p->stream));
-        HIPCK(p, hipMemcpy(bad.data(), p->d_depth.p, (size_t)E, hipMemcpyDeviceToHost));
+        HIPCK(p, plba_stream_wait(p->stream));
+        HIPCK(p, plba_d2h(p, bad.data(), p->d_depth.p, (size_t)E));
     }
     int np = 0, nl = 0;
     for (int e = 0; e < p->Ep; ++e) np += bad[e];
@@ -1122,22 +1122,22 @@ int plba_get_edge_chi2(plba_problem* p, plba_edge_kind kind, double* chi2, uint8
     if (rc) return rc;
     HIPCK(p, hipSetDevice(p->device));
     const DevBuf& d = p->dv;
-    HIPCK(p, hipStreamSynchronize(p->stream));
+    HIPCK(p, plba_stream_wait(p->stream));
     if (kind == PLBA_EDGE_POINT || kind == PLBA_EDGE_LINE) {
         const int o = kind == PLBA_EDGE_POINT ? 0 : p->Ep, n = kind == PLBA_EDGE_POINT ? p->Ep : p->El;
-        if (chi2 && n) HIPCK(p, hipMemcpy(chi2, d.ob_chi2 + o, (size_t)n * 8, hipMemcpyDeviceToHost));
+        if (chi2 && n) HIPCK(p, plba_d2h(p, chi2, d.ob_chi2 + o, (size_t)n * 8));
         if (dpos && n) {
             launch_depth(d, p->cur, p->d_depth.p, p->stream);
-            HIPCK(p, hipStreamSynchronize(p->stream));
-            HIPCK(p, hipMemcpy(dpos, p->d_depth.p + o, n, hipMemcpyDeviceToHost));
+            HIPCK(p, plba_stream_wait(p->stream));
+            HIPCK(p, plba_d2h(p, dpos, p->d_depth.p + o, n));
         }
     } else if (kind == PLBA_EDGE_IMU_PVR || kind == PLBA_EDGE_IMU_BIAS) {
         std::vector<double> c((size_t)p->M * 4);
-        if (p->M) HIPCK(p, hipMemcpy(c.data(), d.imu_chi, c.size() * 8, hipMemcpyDeviceToHost));
+        if (p->M) HIPCK(p, plba_d2h(p, c.data(), d.imu_chi, c.size() * 8));
         for (int m = 0; m < p->M; ++m) { if (chi2) chi2[m] = c[(size_t)m * 4 + (kind == PLBA_EDGE_IMU_PVR ? 0 : 1)]; if (dpos) dpos[m] = 1; }
     } else if (kind == PLBA_EDGE_PRIOR) {
         double c = 0.0;
-        if (p->pr_nv) HIPCK(p, hipMemcpy(&c, d.pr_chi, 8, hipMemcpyDeviceToHost));
+        if (p->pr_nv) HIPCK(p, plba_d2h(p, &c, d.pr_chi, 8));
         if (chi2) chi2[0] = c;
         if (dpos) dpos[0] = 1;
     } else return PLBA_ERR_INVALID;
@@ -1157,9 +1157,9 @@ int plba_get_keyframes(plba_problem* p, double* P3, double* V3, double* q4, doub
     int rc = prepare(p);
     if (rc) return rc;
     HIPCK(p, hipSetDevice(p->device));
-    HIPCK(p, hipStreamSynchronize(p->stream));
+    HIPCK(p, plba_stream_wait(p->stream));
     std::vector<double> h((size_t)p->K * KF_STRIDE);
-    HIPCK(p, hipMemcpy(h.data(), p->dv.kf[p->cur], h.size() * 8, hipMemcpyDeviceToHost));
+    HIPCK(p, plba_d2h(p, h.data(), p->dv.kf[p->cur], h.size() * 8));
     for (int k = 0; k < p->K; ++k) {
         const double* s = &h[(size_t)k * KF_STRIDE];
         if (P3) memcpy(P3 + 3 * k, s, 24);
@@ -1174,9 +1174,9 @@ static int get_lm(plba_problem* p, std::vector<double>& h) {
     int rc = prepare(p);
     if (rc) return rc;
     HIPCK(p, hipSetDevice(p->device));
-    HIPCK(p, hipStreamSynchronize(p->stream));
+    HIPCK(p, plba_stream_wait(p->stream));
     h.resize((size_t)p->L * 6);
-    if (p->L) HIPCK(p, hipMemcpy(h.data(), p->dv.lm[p->cur], h.size() * 8, hipMemcpyDeviceToHost));
+    if (p->L) HIPCK(p, plba_d2h(p, h.data(), p->dv.lm[p->cur], h.size() * 8));
     return PLBA_OK;
 }
 int plba_get_points(plba_problem* p, double* xyz) {
@@ -1248,15 +1248,15 @@ int plba_debug_build(plba_problem* p, double lambda, int do_solve) {
     Ctrl c0;
     memset(&c0, 0, sizeof c0);
     c0.solver_ok = 1; c0.ni = 2.0;
-    HIPCK(p, hipMemcpy(d.ctrl, &c0, sizeof c0, hipMemcpyHostToDevice));
+    HIPCK(p, plba_h2d(p, d.ctrl, &c0, sizeof c0));
     if ((rc = enqueue_linearize(p, true, 0))) return rc;
-    HIPCK(p, hipStreamSynchronize(p->stream));
-    HIPCK(p, hipMemcpy(&c0, d.ctrl, sizeof c0, hipMemcpyDeviceToHost));
+    HIPCK(p, plba_stream_wait(p->stream));
+    HIPCK(p, plba_d2h(p, &c0, d.ctrl, sizeof c0));
     c0.lambda = lambda;
-    HIPCK(p, hipMemcpy(d.ctrl, &c0, sizeof c0, hipMemcpyHostToDevice));
+    HIPCK(p, plba_h2d(p, d.ctrl, &c0, sizeof c0));
     if ((rc = enqueue_solve(p, do_solve != 0, true))) return rc;
-    HIPCK(p, hipStreamSynchronize(p->stream));
-    HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost));
+    HIPCK(p, plba_stream_wait(p->stream));
+    HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl)));
     return PLBA_OK;
 }
 
@@ -1264,13 +1264,13 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     if (!p || !what) return PLBA_ERR_INVALID;
     if (p->dirty) FAIL(p, PLBA_ERR_STATE, "debug_get before debug_build/optimize");
     HIPCK(p, hipSetDevice(p->device));
-    HIPCK(p, hipStreamSynchronize(p->stream));
+    HIPCK(p, plba_stream_wait(p->stream));
     const DevBuf& d = p->dv;
     std::vector<double> v;
     const std::string w(what);
     auto fetch = [&](const double* dev, size_t cnt, std::vector<double>& h) -> hipError_t {
         h.resize(cnt);
-        return cnt ? hipMemcpy(h.data(), dev, cnt * 8, hipMemcpyDeviceToHost) : hipSuccess;
+        return cnt ? plba_d2h(p, h.data(), dev, cnt * 8) : hipSuccess;
     };
     const size_t P = p->P, ld = p->ld;
     if (w == "Hschur") {
@@ -1283,7 +1283,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     else if (w == "x") {
         std::vector<double> hx, hl; std::vector<uint8_t> act(p->L);
         HIPCK(p, fetch(d.x, ld, hx)); HIPCK(p, fetch(d.xl, (size_t)p->L * 6, hl));
-        if (p->L) HIPCK(p, hipMemcpy(act.data(), d.lm_active, p->L, hipMemcpyDeviceToHost));
+        if (p->L) HIPCK(p, plba_d2h(p, act.data(), d.lm_active, p->L));
         v.assign(hx.begin(), hx.begin() + P);
         for (int s = 0; s < p->L; ++s) if (act[s]) for (int t = 0; t < (s < p->Np ? 3 : 6); ++t) v.push_back(hl[(size_t)s * 6 + t]);
     } else if (w == "hll_pt" || w == "hll_ln") {
@@ -1319,9 +1319,9 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     else if (w == "dbgbuf") { HIPCK(p, fetch(d.dbgbuf, 64, v)); }
     else if (w == "pose_dim") v = {(double)p->P};
     else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};
-    else if (w == "chi2") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {p->h_ctrl->current_chi}; }
-    else if (w == "maxdiag") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {p->h_ctrl->maxdiag}; }
-    else if (w == "solver_ok") { HIPCK(p, hipMemcpy(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost)); v = {(double)p->h_ctrl->solver_ok}; }
+    else if (w == "chi2") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {p->h_ctrl->current_chi}; }
+    else if (w == "maxdiag") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {p->h_ctrl->maxdiag}; }
+    else if (w == "solver_ok") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {(double)p->h_ctrl->solver_ok}; }
     else FAIL(p, PLBA_ERR_INVALID, "debug_get: unknown buffer '%s'", what);
     if (n) *n = v.size();
     if (out) { const size_t c = std::min(v.size(), cap); if (c) memcpy(out, v.data(), c * 8); }

@@ -640,8 +640,8 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
             for (int round = 0; round < npad - 1; ++round)
                 hipLaunchKernelGGL(k_jacobi_round, dim3(npad / 2), dim3(256), 0, s, dG.p, dV.p, n, npad, round, JACOBI_TOL, drot.p);
             int rotated = 0;
-            PLBA_HIPCK(p, hipMemcpyAsync(&rotated, drot.p, sizeof(int), hipMemcpyDeviceToHost, s));
-            PLBA_HIPCK(p, hipStreamSynchronize(s));
+            PLBA_HIPCK(p, plba_d2h(p, &rotated, drot.p, sizeof(int)));
+            PLBA_HIPCK(p, plba_stream_wait(s));
             if (rotated == 0) break;
         }
         hipLaunchKernelGGL(k_eigen_sqrt, dim3((n + 63) / 64), dim3(64), 0, s, dG.p, dV.p, db.p + m, n, eps, oJ0, or0);
@@ -658,7 +658,7 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
     }
     PLBA_HIPCK(p, hipMemcpyAsync(hres, dOut.p, nout * 8, hipMemcpyDeviceToHost, s));
     PLBA_HIPCK(p, hipMemcpyAsync(hres + nout, d.kf[state], nkf * 8, hipMemcpyDeviceToHost, s));
-    PLBA_HIPCK(p, hipStreamSynchronize(s));
+    PLBA_HIPCK(p, plba_stream_wait(s));
     PLBA_HIPCK(p, hipGetLastError());
     // ---- output (host buffers owned by the caller until plba_prior_free) ----------------------------------------------------------
     out->n = n; out->m = m; out->nv = (int)kept.size();

@@ -62,20 +62,19 @@ extern "C" int plba_preintegrate(plba_problem* p, int M, const int32_t* sample_s
     }
     PLBA_HIPCK(p, hipSetDevice(p->device));
     hipStream_t s = p->stream;
+    DArrStreamScope staged(s, p->have_ctx ? p->ctx.stage : nullptr);      // uploads queued on the stream through the pinned staging area
     DArr<int> d_start, d_idx;
     DArr<double> d_dt, d_g, d_a, d_bg, d_ba, d_out;
     PLBA_HIPCK(p, d_start.upload(sstart));
     if (sidx.empty()) { sidx.push_back(0); sdt.push_back(0.0); }
     PLBA_HIPCK(p, d_idx.upload(sidx)); PLBA_HIPCK(p, d_dt.upload(sdt));
-    PLBA_HIPCK(p, d_g.upload(std::vector<double>(gyr3, gyr3 + 3 * (size_t)(S > 0 ? S : 1))));
-    PLBA_HIPCK(p, d_a.upload(std::vector<double>(acc3, acc3 + 3 * (size_t)(S > 0 ? S : 1))));
-    PLBA_HIPCK(p, d_bg.upload(std::vector<double>(bg3, bg3 + 3 * (size_t)M)));
-    PLBA_HIPCK(p, d_ba.upload(std::vector<double>(ba3, ba3 + 3 * (size_t)M)));
+    const std::vector<double> hg(gyr3, gyr3 + 3 * (size_t)(S > 0 ? S : 1)), ha(acc3, acc3 + 3 * (size_t)(S > 0 ? S : 1)), hbg(bg3, bg3 + 3 * (size_t)M), hba(ba3, ba3 + 3 * (size_t)M);
+    PLBA_HIPCK(p, d_g.upload(hg)); PLBA_HIPCK(p, d_a.upload(ha)); PLBA_HIPCK(p, d_bg.upload(hbg)); PLBA_HIPCK(p, d_ba.upload(hba));      // alive until the final wait
     PLBA_HIPCK(p, d_out.alloc((size_t)M * PREINT_DOUBLES));
     hipLaunchKernelGGL(k_preintegrate, dim3((M + 63) / 64), dim3(64), 0, s, M, d_start.p, d_idx.p, d_dt.p, d_g.p, d_a.p, d_bg.p, d_ba.p,
                        gyr_meas_cov, acc_meas_cov, d_out.p);
     PLBA_HIPCK(p, hipGetLastError());
-    PLBA_HIPCK(p, hipMemcpyAsync(out142, d_out.p, (size_t)M * PREINT_DOUBLES * 8, hipMemcpyDeviceToHost, s));
-    PLBA_HIPCK(p, hipStreamSynchronize(s));
+    PLBA_HIPCK(p, plba_d2h(p, out142, d_out.p, (size_t)M * PREINT_DOUBLES * 8));
+    PLBA_HIPCK(p, plba_stream_wait(s));
     return PLBA_OK;
 }

@@ -1,5 +1,7 @@
 // plba_problem.h — host-side problem object behind the opaque plba_problem* of include/plba.h.
 #pragma once
+#include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -213,6 +215,54 @@ struct plba_problem {
     bool ev_ready = false;
 };
 
+
+// Wait for a stream WITHOUT parking the host thread on an interrupt: hipStreamSynchronize blocks on a completion signal once
+// its short spin is over, and on this platform the wake-up was measured at 7-20 ms when other HIP users are alive in the
+// process (tools/debug_e2e.py: the 0.5 ms of queued uploads of prepare() then "took" 20 ms).  Polling hipStreamQuery keeps
+// the wait in user space; after `spin_ms` it falls back to the blocking call (which also surfaces device errors).
+inline hipError_t plba_stream_wait(hipStream_t s, double spin_ms = 50.0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return hipSuccess;
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > spin_ms) break;
+    }
+    return hipStreamSynchronize(s);
+}
+
+// Copies between device memory and CALLER-OWNED (pageable) host memory go through the context's pinned staging area.
+// Handing a pageable pointer to hipMemcpy makes the runtime pin (register) those pages with the GPU for transfers above its
+// staging threshold; when the host allocator later gives such pages back to the OS (free of an mmap'ed std::vector / numpy
+// buffer, heap trim), the driver's MMU notifier has to invalidate the registration and evicts the process's GPU queues: the
+// next stream operations then sat 10-25 ms in the queue (tools/debug_e2e3.py; which call paid depended on the allocator's
+// state, e.g. on whether another problem's host vectors were alive).  Pinned memory the library owns never goes back.
+inline hipError_t plba_d2h(plba_problem* p, void* dst, const void* src_dev, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    plba::StageArea* st = p->have_ctx ? p->ctx.stage : nullptr;
+    if (!st || !st->base || !st->cap) { hipError_t e = hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, p->stream); return e != hipSuccess ? e : plba_stream_wait(p->stream); }
+    for (size_t off = 0; off < bytes; off += st->cap) {
+        const size_t n = std::min(st->cap, bytes - off);
+        hipError_t e = hipMemcpyAsync(st->base, (const char*)src_dev + off, n, hipMemcpyDeviceToHost, p->stream);
+        if (e == hipSuccess) e = plba_stream_wait(p->stream);
+        if (e != hipSuccess) return e;
+        memcpy((char*)dst + off, st->base, n);
+    }
+    return hipSuccess;
+}
+inline hipError_t plba_h2d(plba_problem* p, void* dst_dev, const void* src, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    plba::StageArea* st = p->have_ctx ? p->ctx.stage : nullptr;
+    if (!st || !st->base || !st->cap) { hipError_t e = hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, p->stream); return e != hipSuccess ? e : plba_stream_wait(p->stream); }
+    for (size_t off = 0; off < bytes; off += st->cap) {
+        const size_t n = std::min(st->cap, bytes - off);
+        memcpy(st->base, (const char*)src + off, n);
+        hipError_t e = hipMemcpyAsync((char*)dst_dev + off, st->base, n, hipMemcpyHostToDevice, p->stream);
+        if (e == hipSuccess) e = plba_stream_wait(p->stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 #define PLBA_FAIL(p, code, ...)                             \
     do {                                                    \
