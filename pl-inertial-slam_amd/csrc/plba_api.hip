@@ -61,6 +61,7 @@ void plba_default_options(plba_options* o) {
     o->factor_flow = 0;
     o->chain_elim = 1;
     o->wide_steps = 0;
+    o->band_solve = 1;
 }
 const char* plba_backend_name(void) { return "hip-gfx950"; }
 const char* plba_last_error(const plba_problem* p) { return p ? p->err : g_create_err; }
@@ -666,6 +667,7 @@ static int prepare(plba_problem* p) {
                 ChainView& cv = p->cv;
                 cv.nel = nel; cv.nseg = nseg; cv.npos = npos; cv.Pd = Pd; cv.Pdpad = ((Pd + TILE - 1) / TILE) * TILE; cv.Wld = ((Pd + 2 + 63) / 64) * 64;
                 HIPCK(p, p->d_cidx.upload(cidx)); HIPCK(p, p->d_epos.upload(epos)); HIPCK(p, p->d_seg_start.upload(seg_start)); HIPCK(p, p->d_seg_col.upload(seg_col));
+                p->h_pidx = pidx; p->h_seg_col = seg_col;
                 HIPCK(p, p->d_pidx.upload(pidx)); HIPCK(p, p->d_ppos.upload(ppos)); HIPCK(p, p->d_pslot.upload(pslot)); HIPCK(p, p->d_slotcol.upload(slotcol));
                 {
                     std::vector<int32_t> kf_at(npos, -1), ekf, ukf;
@@ -706,7 +708,7 @@ static int prepare(plba_problem* p) {
         }
     }
     d.Ninv = nullptr; d.Nwork = nullptr;
-    HIPCK(p, p->d_dbgbuf.alloc(64)); d.dbgbuf = p->d_dbgbuf.p;
+    HIPCK(p, p->d_dbgbuf.alloc(64)); d.dbgbuf = p->d_dbgbuf.p; p->dd.dbgbuf = d.dbgbuf;
     if (!p->chain_ok && p->P > 0 && p->Ppad / 32 <= NINV_MAX_T) { HIPCK(p, p->d_Ninv.alloc((size_t)2 * p->Ppad * p->ld)); d.Ninv = p->d_Ninv.p; d.Nwork = d.Ninv + (size_t)p->Ppad * p->ld; }
     // ---- structural assembly list (assemble_part): with the chain elimination on, sys is written by the assembly pass and
     // by k_schur_pairs only, so the entries neither of them can make non-zero never need touching again
@@ -745,6 +747,7 @@ static int prepare(plba_problem* p) {
         al.erase(std::unique(al.begin(), al.end()), al.end());
         HIPCK(p, p->d_alist.upload(al));
         d.alist = p->d_alist.p; d.nalist = (int)al.size();
+        p->h_alist.swap(al);      // kept on the host: the staged upload reads it until the final wait, and the band measurement below
     }
     // ---- structural exchange list of a sharded run (k_list_pack): every lower-triangle entry of the reduced system that can be
     // non-zero before the factorisation.  Everything else is zero on every rank and need not travel.
@@ -781,6 +784,36 @@ static int prepare(plba_problem* p) {
         xl.erase(std::unique(xl.begin(), xl.end()), xl.end());
         HIPCK(p, p->d_xlist.upload(xl));
         d.xlist = p->d_xlist.p; d.nxlist = (int)xl.size();
+    }
+    // ---- banded twisted solve (plba_band.hip): measure the band of the compact dense system from the structure ----------------
+    p->band_ok = false;
+    p->dd.band = 0;
+    if (p->chain_ok && p->opt.band_solve && p->world == 1 && !p->dv.flow && !p->dv.wide) {
+        const ChainView& cv = p->cv;
+        const int T = cv.Pdpad / 32;
+        int hbt = 0;
+        if (T >= (p->opt.band_solve >= 2 ? 8 : BAND_MIN_TILES) && band_lds_bytes(cv.Pdpad) <= 160 * 1024) {      // band_solve = 2 (tests): any system of >= 8 tiles
+            const std::vector<int32_t>& hpidx = p->h_pidx; const std::vector<int32_t>& hsegcol = p->h_seg_col;
+            std::vector<int32_t> dense_of(p->ld, -1);
+            for (int c = 0; c < cv.Pd; ++c) dense_of[hpidx[c]] = c;
+            // (1) entries the pose-side assembly / the Schur pairs can make non-zero (d.alist), (2) the chain elimination's fill:
+            // all dense columns of a segment's window couple with each other
+            for (int32_t idx : p->h_alist) {
+                const int r = dense_of[idx / p->ld], c = dense_of[idx % p->ld];
+                if (r >= 0 && c >= 0) hbt = std::max(hbt, std::abs(r / 32 - c / 32));
+            }
+            for (int g = 0; g < cv.nseg; ++g) if (hsegcol[2 * g + 1] > hsegcol[2 * g]) hbt = std::max(hbt, (hsegcol[2 * g + 1] - 1) / 32 - hsegcol[2 * g] / 32);
+            if (hbt <= BAND_HB) {
+                BandView& bv = p->bandv;
+                bv.T = T; bv.nA = (T - BAND_HB) / 2; bv.nB = T - BAND_HB - bv.nA;
+                HIPCK(p, p->d_band_L.alloc((size_t)2 * T * 4 * 1024, false)); HIPCK(p, p->d_band_y.alloc((size_t)2 * cv.Pdpad, false));
+                HIPCK(p, p->d_band_mid.alloc((size_t)2 * (9 * 1024 + 96), false));
+                bv.Lband = p->d_band_L.p; bv.y = p->d_band_y.p; bv.mid = p->d_band_mid.p;
+                p->band_ok = true;
+                p->dd.band = 1;
+            }
+        }
+        if (ptime) fprintf(stderr, "[prepare] dense system: %d dims, %d tiles, band %d sub-diagonal tiles -> %s\n", cv.Pd, T, hbt, p->band_ok ? "banded twisted solve" : "dense path");
     }
     lap("chain maps + buffers");
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
@@ -895,9 +928,14 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
         if (!chain_rides) launch_chain_elim(d, p->cv, s);
         launch_chain_schur(d, p->cv, p->dd, s);
         MARKF(p, 11);
-        launch_cholesky(p->dd, true, epoch, s, chain_schur_factors_tile0(p->dd));
-        MARKF(p, 12);
-        launch_trsv_back(p->dd, true, epoch, s);
+        if (p->band_ok) {
+            launch_band_solve(p->dd, p->bandv, s);      // factorisation, forward and backward substitution: two launches
+            MARKF(p, 12);
+        } else {
+            launch_cholesky(p->dd, true, epoch, s, chain_schur_factors_tile0(p->dd));
+            MARKF(p, 12);
+            launch_trsv_back(p->dd, true, epoch, s);
+        }
     } else {
         MARKF(p, 11);
         launch_cholesky(d, p->opt.use_mfma != 0, epoch, s);
@@ -1319,6 +1357,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     else if (w == "dbgbuf") { HIPCK(p, fetch(d.dbgbuf, 64, v)); }
     else if (w == "pose_dim") v = {(double)p->P};
     else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};
+    else if (w == "band") v = {(double)(p->band_ok ? 1 : 0)};
     else if (w == "chi2") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {p->h_ctrl->current_chi}; }
     else if (w == "maxdiag") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {p->h_ctrl->maxdiag}; }
     else if (w == "solver_ok") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {(double)p->h_ctrl->solver_ok}; }

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_chain_schur(DevBuf d, ChainView cv, Dev
             if (b == 0) sC0[lr * LS + lc] = out;
         }
     }
-    if (b != 0 || dd.flow || dd.wide) return;
+    if (b != 0 || dd.flow || dd.wide || dd.band) return;
     // tile (0,0) is complete in LDS: run the look-ahead pipeline of the factorisation on it right here (L(0,0) -> dd.Lfac,
     // L(0,0)^-1 -> dd.Linv32[0]) instead of in a launch of its own (k_potrf0_32): the first block step follows directly
     look32_reset(S0, threadIdx.x);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_chain_schur(DevBuf d, ChainView cv, Dev
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s) {
     hipLaunchKernelGGL(k_chain_elim, dim3(cv.nseg), dim3(ELIM_THREADS), 0, s, d, cv);
 }
-bool chain_schur_factors_tile0(const DevBuf& dd) { return !dd.flow && !dd.wide; }
+bool chain_schur_factors_tile0(const DevBuf& dd) { return !dd.flow && !dd.wide && !dd.band; }
 void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s) {
     const int T = cv.Pdpad / 32;
     hipLaunchKernelGGL(k_chain_schur, dim3(T * (T + 1) / 2 + T), dim3(256), 0, s, d, cv, dd);

@@ -103,6 +103,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     int* flow_flags;       // T epoch-stamped flags of the back-substitution dataflow
     int* chol_flags;       // (T32 + 1) x T32 tile flags + T32 inverse flags of the single-launch factorisation (epoch-stamped)
     double* dbgbuf;        // 64 doubles for diagnostic builds (cycle stamps)
+    int band;              // 1: the banded twisted solver handles this system (plba_band.hip): k_chain_schur leaves tile (0,0) unfactored
     int flow;              // 1: single-launch dataflow factorisation (k_chol_flow), 0: one launch per block step
     int wide;              // 1: a launch retires 64 columns (two pipelined 32-column sweeps in the look-ahead workgroup, k_chol64)
     // reductions / control
@@ -171,6 +172,17 @@ struct ChainView {
     double* Ldinv;                // nel x 81: L_ii^-1, row-major
     double* Lsub;                 // nel x 81: L_{i+1,i}
 };
+// banded twisted solve of the compact dense system (plba_band.hip)
+constexpr int BAND_HB = 3;        // sub-diagonal 32 x 32 tiles of the band it supports
+constexpr int BAND_MIN_TILES = 24;   // shortest system (in 32-column tiles) the two-ended sweep is used for: below, one launch per tile is faster
+struct BandView {
+    int T, nA, nB;                // tiles; tiles eliminated by the top-down / bottom-up sweep (the middle block has BAND_HB tiles)
+    double* Lband;                // 2 x T x 4 x 1024: per direction and column block: L(k,k)^-1 and the three panels below it
+    double* y;                    // 2 x Pdpad: forward-substituted right-hand sides
+    double* mid;                  // 2 x (9 x 1024 + 96): the two sweeps' middle windows and right-hand sides
+};
+size_t band_lds_bytes(int Pdpad);
+void launch_band_solve(const DevBuf& dd, const BandView& bv, hipStream_t s);      // dd.sys (+ rhs row) -> dd.x
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s);
 void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);   // writes dd.sys
 void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s, bool tile0_done = false);   // sys -> Lfac (lower) incl. the augmented rows;

@@ -207,6 +207,10 @@ struct plba_problem {
     plba::DArr<int32_t> d_cidx, d_pidx, d_epos, d_seg_start, d_seg_col, d_ppos, d_pslot, d_slotcol;
     plba::DArr<double> d_W, d_Ldinv, d_Lsub, d_sysd, d_Lfacd, d_xd, d_Linvd, d_LT32d, d_rd32d, d_Ninv, d_Ninvd, d_dbgbuf;
     plba::DArr<int> d_flow_flagsd, d_chol_flagsd;
+    bool band_ok = false;                       // the compact dense system is banded: twisted in-LDS solver (plba_band.hip)
+    plba::BandView bandv{};
+    plba::DArr<double> d_band_L, d_band_y, d_band_mid;
+    std::vector<int32_t> h_pidx, h_seg_col, h_alist;      // host copies of the chain maps / assembly list (band measurement)
     bool assembled = false;                     // k_landmark_hll already assembled the pose-side system of this iteration
     plba::DevBuf dv;
     std::vector<plba_trace_row> trace;

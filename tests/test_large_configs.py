@@ -35,6 +35,7 @@ def test_config5_full_size_properties(pkg, hip, w5):
     assert r["stage1"].iterations == 5 and r["stage2"].iterations == 10
     assert r["stage1"].solver_failures == 0 and r["stage2"].solver_failures == 0
     assert g.debug_get("pose_dim")[0] == 199 * 15 and g.debug_get("dense_dim")[0] < 199 * 15      # chain path in effect
+    assert g.debug_get("band")[0] == 1                                  # 44 tiles, band of 3: the two-ended in-LDS sweep solves it
     tr = g.trace()
     chi = [t["chi2_current"] for t in tr] + [tr[-1]["chi2_trial"] if tr[-1]["accepted"] else tr[-1]["chi2_current"]]
     assert all(b <= a * (1 + 1e-12) for a, b in zip(chi[:-1], chi[1:])), "chi2 must not increase over accepted LM steps"
@@ -135,4 +136,45 @@ def test_config4_full_size_sliding_window(pkg, hip):
     assert r["stage2"].solver_failures == 0 and r["stage2"].iterations == 10
     assert r["stage2"].chi2_final < r["stage1"].chi2_initial
     assert np.abs(g.get_keyframes()["P"] - w["truth"]["P"]).max() < 0.05
+    g.close()
+
+
+@pytest.mark.parametrize("K,Np,Nl", [(50, 2000, 400), (33, 900, 200), (100, 3000, 600)])
+def test_banded_twisted_solver_matches_the_dense_path_and_the_oracle(pkg, orc, hip, K, Np, Nl):
+    """plba_band.hip: when the compact dense system is block-banded (<= 3 sub-diagonal tiles: tracks over <= 8 consecutive
+    keyframes) two workgroups factor it from both ends inside LDS.  Same optimisation as the dense multi-launch path
+    (band_solve = 0) and as the oracle."""
+    w = pkg.window.make_window(K, Np, Nl, imu=True, seed=0xBA4D + K)
+    res = {}
+    for band in (1, 0):
+        g = pkg.new_problem(band_solve=2 * band); g.upload_window(w)      # 2: also below the 24-tile threshold of the default
+        g.debug_build(3.0, True)
+        x = g.debug_get("x").copy()
+        assert g.debug_get("band")[0] == band and g.debug_get("solver_ok")[0] == 1
+        st = g.optimize(4)
+        res[band] = (x, st, g.get_keyframes(), [t["accepted"] for t in g.trace()])
+        g.close()
+    o = orc.new_problem(); o.upload_window(w)
+    o.debug_build(3.0, True)
+    xo = o.debug_get("x").copy()
+    so = o.optimize(4)
+    ko = o.get_keyframes()
+    o.close()
+    sc = np.abs(xo).max()
+    assert np.abs(res[1][0] - xo).max() < 1e-7 * sc and np.abs(res[0][0] - xo).max() < 1e-7 * sc
+    assert np.abs(res[1][0] - res[0][0]).max() < 1e-9 * sc
+    for band in (1, 0):
+        st = res[band][1]
+        assert (st.iterations, st.trials, st.solver_failures) == (so.iterations, so.trials, 0)
+        assert st.chi2_final == pytest.approx(so.chi2_final, rel=1e-8)
+        assert max(_pose_delta(res[band][2], ko, pkg)) < 1e-8
+    assert res[1][3] == res[0][3]
+
+
+def test_banded_solver_reports_a_non_positive_pivot(pkg, hip):
+    """a window whose damped system is not positive definite must come back as a failed solve from the band path too"""
+    w = pkg.window.make_window(50, 1500, 300, imu=True, seed=0xBA4D)
+    g = pkg.new_problem(band_solve=2); g.upload_window(w)
+    g.debug_build(-1e13, True)               # lambda far below zero: indefinite on purpose
+    assert g.debug_get("band")[0] == 1 and g.debug_get("solver_ok")[0] == 0
     g.close()
