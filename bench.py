@@ -326,7 +326,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": name, "K": cfg["K"], "points": cfg["Np"], "lines": cfg["Nl"], "point_obs": int(Ep), "line_obs": int(El),
                    "pose_dim": P, "trials_per_iteration": trials / max(done, 1), "protocol": "stage-2 LM iterations (no Huber on point/line edges) replayed from the post-gating state",
-                   "global_iterations_per_s": done / dt, "dense_dim": Pdense, "exchange": xch_kind,
+                   "global_iterations_per_s": done / dt, "dense_dim": Pdense, "exchange": xch_kind, "banded_twisted_solve": bool(prob.debug_get("band")[0]),
                    "value_definition": "global LM iterations/s of ONE window (total work fixed as N grows: its landmarks are sharded over the N ranks)",
                    "algorithmic_bytes_per_iteration": b_iter,
                    "hbm_frac_whole_iteration": b_iter / (dt / done) / 1e9 / (HBM_PEAK_GBS * world)},

@@ -79,8 +79,8 @@ typedef struct {
                                    sub-diagonal 32 x 32 tiles — tracks spanning a few consecutive keyframes, as in a sliding window —
                                    it is factored and solved by two workgroups walking the band from both ends with the window
                                    resident in LDS (plba_band.hip) instead of one launch per 32 columns, from 24 tiles (768 dense
-                                   dims) on, where it was measured faster; 2 = from 8 tiles on (tests); wider bands, smaller
-                                   systems and sharded runs take the dense path regardless                               (1) */
+                                   dims) on, where it was measured faster; 2 = from 8 tiles on (tests); wider bands and smaller
+                                   systems take the dense path regardless                                                 (1) */
 } plba_options;
 
 void plba_default_options(plba_options* o);

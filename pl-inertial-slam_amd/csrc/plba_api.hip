@@ -463,6 +463,21 @@ static int prepare(plba_problem* p) {
         fill_range(0);
         for (auto& x : th) x.join();
     }
+    // Co-observation structure of the keyframes: which pose x pose blocks of the reduced system the landmarks' Schur terms can
+    // touch.  A sharded run needs the UNION over the ranks (each holds the pairs of its own landmarks only): one all-reduce
+    // (max) of a K x K map per upload, after which every rank derives the same assembly / exchange lists and band.
+    std::vector<uint8_t> cov((size_t)K * K, 0);
+    for (size_t q = 0; q < pair_i.size(); ++q) { cov[(size_t)pair_i[q] * K + pair_j[q]] = 1; cov[(size_t)pair_j[q] * K + pair_i[q]] = 1; }
+    if (p->world > 1) {
+        std::vector<double> cd((size_t)K * K);
+        for (size_t t = 0; t < cd.size(); ++t) cd[t] = cov[t];
+        DArr<double> dcov;
+        HIPCK(p, dcov.upload(cd));
+        if (int xrc = p->xfn(p->xuser, dcov.p, cd.size(), 1, (void*)p->stream)) FAIL(p, PLBA_ERR_EXCHANGE, "all-reduce callback failed (%d)", xrc);
+        HIPCK(p, plba_stream_wait(p->stream));
+        HIPCK(p, plba_d2h(p, cd.data(), dcov.p, cd.size() * 8));
+        for (size_t t = 0; t < cd.size(); ++t) cov[t] = cd[t] != 0.0;
+    }
     lap("pair lists (host)");
     // ---- prior bookkeeping ----------------------------------------------------------------------------------------
     std::vector<int32_t> pr_kf(p->pr_nv), pr_isb(p->pr_nv), pr_x0off(p->pr_nv), pr_off(p->pr_nv);
@@ -737,10 +752,11 @@ static int prepare(plba_problem* p) {
             const int oi = p->off_pvr[pair_i[q]], oj = p->off_pvr[pair_j[q]];
             for (int r : {0, 1, 2, 6, 7, 8}) for (int c : {0, 1, 2, 6, 7, 8}) { al.push_back((oi + r) * ld + oj + c); al.push_back((oj + c) * ld + oi + r); }
         }
-        if (p->world > 1) {      // a sharded run's all-reduce brings in the OTHER ranks' pair blocks: every pose x pose entry is live
-            std::vector<int> pd;
-            for (int k = 0; k < K; ++k) if (p->off_pvr[k] >= 0) for (int c : {0, 1, 2, 6, 7, 8}) pd.push_back(p->off_pvr[k] + c);
-            add_full(pd);
+        if (p->world > 1) {      // a sharded run's all-reduce brings in the OTHER ranks' pair blocks: the global co-observation map
+            for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
+                if (!cov[(size_t)i * K + j] || p->off_pvr[i] < 0 || p->off_pvr[j] < 0) continue;
+                for (int r : {0, 1, 2, 6, 7, 8}) for (int c : {0, 1, 2, 6, 7, 8}) al.push_back((p->off_pvr[i] + r) * ld + p->off_pvr[j] + c);
+            }
         }
         for (int r = 0; r < p->Ppad; ++r) al.push_back(r * ld + r);
         std::sort(al.begin(), al.end());
@@ -760,10 +776,13 @@ static int prepare(plba_problem* p) {
                 for (size_t b = 0; b < dims.size(); ++b)
                     if (dims[a] >= 0 && dims[b] >= 0 && dims[a] >= dims[b]) xl.push_back(dims[a] * ld + dims[b]);
         };
-        {   // pose x pose: the landmarks' Schur terms can couple any two keyframes
-            std::vector<int> pd;
-            for (int k = 0; k < K; ++k) if (p->off_pvr[k] >= 0) for (int c : {0, 1, 2, 6, 7, 8}) pd.push_back(p->off_pvr[k] + c);
-            add_block(pd);
+        // pose x pose: the keyframe pairs some rank's landmarks couple (global co-observation map, identical on every rank)
+        for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
+            if (!cov[(size_t)i * K + j] || p->off_pvr[i] < 0 || p->off_pvr[j] < 0) continue;
+            for (int r : {0, 1, 2, 6, 7, 8}) for (int c : {0, 1, 2, 6, 7, 8}) {
+                const int a = p->off_pvr[i] + r, b2 = p->off_pvr[j] + c;
+                if (a >= b2) xl.push_back(a * ld + b2);
+            }
         }
         for (int m = 0; m < M; ++m) {   // IMU PVR edge over [PVR_i | PVR_j | Bias_i], bias edge over [Bias_i | Bias_j]
             const int ki = p->imu_i[m], kj = p->imu_j[m];
@@ -788,7 +807,7 @@ static int prepare(plba_problem* p) {
     // ---- banded twisted solve (plba_band.hip): measure the band of the compact dense system from the structure ----------------
     p->band_ok = false;
     p->dd.band = 0;
-    if (p->chain_ok && p->opt.band_solve && p->world == 1 && !p->dv.flow && !p->dv.wide) {
+    if (p->chain_ok && p->opt.band_solve && !p->dv.flow && !p->dv.wide) {      // (sharded runs: the lists above hold the GLOBAL structure)
         const ChainView& cv = p->cv;
         const int T = cv.Pdpad / 32;
         int hbt = 0;
