@@ -31,8 +31,14 @@ def pmc(db_fetch, db_write, out):
         f, w = v.get("FETCH_SIZE_KB_avg"), v.get("WRITE_SIZE_KB_avg")
         if f is not None and w is not None:
             v["traffic_bytes_per_launch"] = (2.0 * f + w) * 1024.0
+    import glob, hashlib, os
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "pl-inertial-slam_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
     json.dump({"note": "per-launch averages; traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction of MI355X_MICROARCH.md; "
-                       "command: rocprofv3 --pmc <counter> -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline (one pass per counter)",
+                       "command: rocprofv3 --pmc <counter> -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-config5-leg (one pass per counter)",
+               "csrc_sha16": h.hexdigest()[:16],      # bench.py quotes these numbers only for the kernel sources they were measured on
                "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
 
 
