@@ -219,6 +219,47 @@ int plba_preintegrate(plba_problem* p, int M, const int32_t* sample_start, const
                       const double* acc3, const long double* t_prev, const long double* t_curr, const double* bg3,
                       const double* ba3, double gyr_meas_cov, double acc_meas_cov, double* out142);
 
+/* ---- pre-VIO-init visual-only local BA -------------------------------------------------------
+ * MapHandler::levMarquardtOptimizationLBA (src/mapHandler.cpp:1441-2098), the optimiser localBundleAdjustment
+ * (:1329-1439) runs while the IMU is not initialised: hand-rolled LM over [6 per local keyframe | 3 per point | 6 per
+ * line], scalar residual = norm of the reprojection error, Cauchy weights (stvo-pl/src/auxiliar.cpp:556-559),
+ * multiplicative damping, lambda schedule and termination tests exactly as coded there.  Deviations from the source text
+ * (DESIGN.md §9): a line's end points are read from its own 6 entries (:1787-1788 read both from one, 3-strided, offset); a non-positive
+ * pivot ends the run with stats->solver_failed = 1 (SimplicialLDLT has no such exit).  The stale map pose of the line
+ * pass (:1790) IS reproduced unless use_iterate_poses != 0. */
+typedef struct plba_lba_options {
+    double lambda_lm;           /* SlamConfig::lambdaLbaLM      initial lambda, scaled by max |H_ii| (:1653-1659) */
+    double lambda_k;            /* SlamConfig::lambdaLbaK       lambda /= k when the error grew, *= k otherwise (:1894-1900) */
+    int    max_iters;           /* SlamConfig::maxItersLba */
+    double homog_th;            /* SlamConfig::homogTh          floor of gz^2 and of the error norm in the Jacobians */
+    double min_error;           /* Config::minError             (:1884) */
+    double min_error_change;    /* Config::minErrorChange       (:1884, :1911) */
+    int    use_iterate_poses;   /* 0 = the line pass linearises at the map poses, as the reference does (:1790) */
+    int    reserved;
+} plba_lba_options;
+typedef struct plba_lba_stats {
+    int    iterations;          /* linear solves performed */
+    int    updates;             /* of which applied to X */
+    double err_first, err_last; /* robust error of the first pass / observations (the reference's own first value is x / 0 = inf, :1650,
+                                   reproduced internally); of the last pass / landmarks (:1882) */
+    double lambda;              /* lambda when the loop ended */
+    int    solver_failed;
+    int    reserved;
+} plba_lba_stats;
+void plba_lba_default_options(plba_lba_options* o);
+/* K keyframes appear in the observations; kf_loc[k] = index 0..Nkf-1 of keyframe k among the optimised ones (kf_list
+ * order) or -1 when it only anchors landmarks (:1516-1521).  T_kf_w16: K row-major 4x4 map poses (KeyFrame::T_kf_w;
+ * x_kf_w is taken as logmap_se3 of it).  xyz3 (Np x 3) / pq6 (Nl x 6): in = map estimates, out = optimised.
+ * Observations are landmark-major as localBundleAdjustment builds its lists.  T_out16: K x 16, the optimised poses
+ * (unchanged for kf_loc = -1).  pt_moved / ln_moved (optional): 1 where the landmark moved more than 1 cm, for which the
+ * reference clears `inlier` (:1944-1970).  `p` supplies the device, the stream and the error text. */
+int plba_lba_visual(plba_problem* p, const plba_lba_options* opt, int K, const double* T_kf_w16, const int32_t* kf_loc,
+                    int Np, double* xyz3, int Nl, double* pq6,
+                    int Ep, const int32_t* po_pt, const int32_t* po_kf, const double* uv2,
+                    int El, const int32_t* lo_ln, const int32_t* lo_kf, const double* l3,
+                    double fx, double fy, double cx, double cy, double* T_out16, uint8_t* pt_moved, uint8_t* ln_moved,
+                    plba_lba_stats* stats);
+
 /* ---- diagnostics used by the parity tests (not needed by a drop-in caller) ------------------- */
 /* Runs computeActiveErrors + buildSystem + setLambda(lambda) + Schur on the current state without
  * updating it, then exposes named internal buffers: "Hschur" (P*P row-major), "bschur" (P),

@@ -2444,3 +2444,232 @@ void orc_se3_vertex_oplus(const double* X12, const double* u6, double* out12) {
     iso_from_mqt(u6, &d); iso_mul(&X, &d, &X);
     memcpy(out12, X.R, 72); memcpy(out12 + 9, X.t, 24);
 }
+
+/* =================================================================================================================
+ * SURVEY §8f row 2 — the pre-VIO-init visual-only local BA: MapHandler::levMarquardtOptimizationLBA
+ * (src/mapHandler.cpp:1441-2098), restated.  Hand-rolled LM on X = [6 per local keyframe | 3 per point | 6 per line]:
+ * scalar residual = NORM of the reprojection error, Jacobian row e^T J / max(homogTh, |e|), Cauchy weights
+ * (stvo-pl/src/auxiliar.cpp:556-559), multiplicative damping H_ii += lambda H_ii (:1662-1663, :1887-1888), SimplicialLDLT of
+ * the full system, pose update T <- T * inverse(expmap(dx)) (:1672-1676), lambda schedule as coded (:1895-1900: divided by
+ * lambda_k when the error grew, MULTIPLIED when it shrank).  SE(3) helpers: stvo-pl/src/auxiliar.cpp:113-173.
+ * Decisions on the defects of SURVEY App. B-Q9:
+ *   :1650  err /= (Npt_obs + Nls_obs) with both counters 0: reproduced (IEEE: +inf), it makes the first comparison of :1894 a "success";
+ *   :1787-1788  P and Q of a line read from the same, 3-strided offset -> NOT reproduced (P = X[.. + 6 l], Q = X[.. + 6 l + 3]);
+ *   :1790  the line pass inside the loop takes keyframe poses from the MAP, not from X -> reproduced unless use_iterate_poses.
+ * ================================================================================================================= */
+typedef struct { double lambda_lm, lambda_k; int max_iters; double homog_th, min_error, min_error_change; int use_iterate_poses; int pad; } lba_opt_t;
+typedef struct { int iterations; int updates; double err_first, err_last, lambda; int solver_failed; int reserved; } lba_stats_t;
+
+static void se3_inverse(const double* T, double* Ti) { /* inverse_se3, auxiliar.cpp:113-122 */
+    memset(Ti, 0, 128); Ti[15] = 1.0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Ti[i * 4 + j] = T[j * 4 + i];
+    for (int i = 0; i < 3; ++i) Ti[i * 4 + 3] = -(Ti[i * 4] * T[3] + Ti[i * 4 + 1] * T[7] + Ti[i * 4 + 2] * T[11]);
+}
+static void se3_mul(const double* A, const double* B, double* C) { double t[16]; mat_mul(A, B, t, 4, 4, 4); memcpy(C, t, 128); }
+static void se3_expmap(const double* x, double* T) { /* expmap_se3, auxiliar.cpp:124-141: x = (t, w) */
+    const double* w = x + 3;
+    double th = v3_norm(w), R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {x[0], x[1], x[2]};
+    if (!(th < 0.000001)) {
+        double s[9], wn[3] = {w[0] / th, w[1] / th, w[2] / th}, ss[9], V[9], tv[3];
+        so3_hat(wn, s); m3_mul(s, s, ss);
+        const double sn = sin(th), cs = cos(th);
+        for (int i = 0; i < 9; ++i) {
+            const double I = (i % 4 == 0) ? 1.0 : 0.0;
+            R[i] = I + s[i] * sn + ss[i] * (1.0 - cs);
+            V[i] = I + s[i] * (1.0 - cs) / th + ss[i] * (th - sn) / th;
+        }
+        m3_v(V, t, tv); memcpy(t, tv, 24);
+    }
+    memset(T, 0, 128); T[15] = 1.0;
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j]; T[i * 4 + 3] = t[i]; }
+}
+static void se3_logmap(const double* T, double* x) { /* logmap_se3, auxiliar.cpp:143-173 */
+    double R[9], Vt[3] = {T[3], T[7], T[11]}, w[3] = {0, 0, 0}, V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[i * 3 + j] = T[i * 4 + j];
+    double cosine = (R[0] + R[4] + R[8] - 1.0) / 2.0;
+    if (cosine > 1.0) cosine = 1.0; else if (cosine < -1.0) cosine = -1.0;
+    double sine = sqrt(1.0 - cosine * cosine);
+    if (sine > 1.0) sine = 1.0;
+    const double theta = acos(cosine);
+    if (theta > 0.000001) {
+        const double f = theta / (2.0 * sine);
+        w[0] = f * (R[7] - R[5]); w[1] = f * (R[2] - R[6]); w[2] = f * (R[3] - R[1]);     /* skewcoords(theta (R - R^T) / (2 sine)) */
+        double s[9], ss[9], wn[3] = {w[0] / theta, w[1] / theta, w[2] / theta};
+        so3_hat(wn, s); m3_mul(s, s, ss);
+        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + s[i] * (1.0 - cosine) / theta + ss[i] * (theta - sine) / theta;
+    }
+    double Vi[9];
+    lu_inverse(V, Vi, 3);
+    m3_v(Vi, Vt, x);
+    x[3] = w[0]; x[4] = w[1]; x[5] = w[2];
+}
+/* pose / landmark Jacobian pieces shared by the point and the line-end-point terms (:1490-1512): g = point in the camera
+ * frame, (a, b) = (fx dx, fy dy) resp. (fx lx, fy ly); Jp6 unscaled, Jl3 = (.,.,.) unscaled (before * R^T and the norm) */
+static void lba_jac_pieces(const double* g, double a, double b, double homog_th, double* Jp6, double* Jl3) {
+    double gz2 = g[2] * g[2];
+    gz2 = 1.0 / (homog_th > gz2 ? homog_th : gz2);
+    Jp6[0] = gz2 * a * g[2];
+    Jp6[1] = gz2 * b * g[2];
+    Jp6[2] = -gz2 * (a * g[0] + b * g[1]);
+    Jp6[3] = -gz2 * (a * g[0] * g[1] + b * g[1] * g[1] + b * g[2] * g[2]);
+    Jp6[4] = gz2 * (a * g[0] * g[0] + a * g[2] * g[2] + b * g[0] * g[1]);
+    Jp6[5] = gz2 * (b * g[0] * g[2] - a * g[1] * g[2]);
+    Jl3[0] = Jp6[0]; Jl3[1] = Jp6[1]; Jl3[2] = Jp6[2];
+}
+static void rowvec_R(const double* v3, const double* Tiw, double* o) { /* v^T * Tiw.block(0,0,3,3) */
+    for (int c = 0; c < 3; ++c) o[c] = v3[0] * Tiw[0 * 4 + c] + v3[1] * Tiw[1 * 4 + c] + v3[2] * Tiw[2 * 4 + c];
+}
+/* one observation: residual norm, weight, pose Jacobian (6), landmark Jacobian (3 or 6); Tiw = inverse(T_kf_w) */
+static void lba_point_obs(const double* cam4, double homog_th, const double* Tiw, const double* Xw, const double* uv, double* rn, double* w, double* Jp, double* Jl) {
+    double g[3], e[2], Jl3[3];
+    for (int i = 0; i < 3; ++i) g[i] = Tiw[i * 4] * Xw[0] + Tiw[i * 4 + 1] * Xw[1] + Tiw[i * 4 + 2] * Xw[2] + Tiw[i * 4 + 3];
+    e[0] = uv[0] - (cam4[2] + cam4[0] * g[0] / g[2]); e[1] = uv[1] - (cam4[3] + cam4[1] * g[1] / g[2]);
+    const double n = sqrt(e[0] * e[0] + e[1] * e[1]), dn = homog_th > n ? homog_th : n;
+    lba_jac_pieces(g, cam4[0] * e[0], cam4[1] * e[1], homog_th, Jp, Jl3);
+    for (int i = 0; i < 6; ++i) Jp[i] /= dn;
+    rowvec_R(Jl3, Tiw, Jl);
+    for (int i = 0; i < 3; ++i) Jl[i] /= dn;
+    *rn = n; *w = 1.0 / (1.0 + n * n);
+}
+static void lba_line_obs(const double* cam4, double homog_th, const double* Tiw, const double* PQ, const double* l3, double* rn, double* w, double* Jp, double* Jl) {
+    double gp[3], gq[3], e[2], JP[6], JQ[6], a3[3], b3[3];
+    for (int i = 0; i < 3; ++i) {
+        gp[i] = Tiw[i * 4] * PQ[0] + Tiw[i * 4 + 1] * PQ[1] + Tiw[i * 4 + 2] * PQ[2] + Tiw[i * 4 + 3];
+        gq[i] = Tiw[i * 4] * PQ[3] + Tiw[i * 4 + 1] * PQ[4] + Tiw[i * 4 + 2] * PQ[5] + Tiw[i * 4 + 3];
+    }
+    e[0] = l3[0] * (cam4[2] + cam4[0] * gp[0] / gp[2]) + l3[1] * (cam4[3] + cam4[1] * gp[1] / gp[2]) + l3[2];
+    e[1] = l3[0] * (cam4[2] + cam4[0] * gq[0] / gq[2]) + l3[1] * (cam4[3] + cam4[1] * gq[1] / gq[2]) + l3[2];
+    const double n = sqrt(e[0] * e[0] + e[1] * e[1]), dn = homog_th > n ? homog_th : n;
+    /* NB the reference forms BOTH end points' pieces with (fx lx, fy ly) = (fx e0, fy e1)  (:1580-1583, reused at :1612) */
+    lba_jac_pieces(gp, cam4[0] * e[0], cam4[1] * e[1], homog_th, JP, a3);
+    lba_jac_pieces(gq, cam4[0] * e[0], cam4[1] * e[1], homog_th, JQ, b3);
+    rowvec_R(a3, Tiw, Jl); rowvec_R(b3, Tiw, Jl + 3);
+    for (int i = 0; i < 3; ++i) { Jl[i] *= e[0] / dn; Jl[3 + i] *= e[1] / dn; }
+    for (int i = 0; i < 6; ++i) Jp[i] = (JP[i] * e[0] + JQ[i] * e[1]) / dn;
+    *rn = n; *w = 1.0 / (1.0 + n * n);
+}
+/* dense LDL^T without pivoting (Eigen SimplicialLDLT on an SPD-by-construction matrix), solves A x = b in place of x */
+static int ldlt_solve(double* A, int n, const double* b, double* x) {
+    for (int j = 0; j < n; ++j) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k] * A[(size_t)k * n + k];
+        if (d == 0.0 || !isfinite(d)) return 0;
+        A[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k] * A[(size_t)k * n + k];
+            A[(size_t)i * n + j] = s / d;
+        }
+    }
+    for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= A[(size_t)i * n + k] * x[k]; x[i] = s; }
+    for (int i = 0; i < n; ++i) x[i] /= A[(size_t)i * n + i];
+    for (int i = n - 1; i >= 0; --i) { double s = x[i]; for (int k = i + 1; k < n; ++k) s -= A[(size_t)k * n + i] * x[k]; x[i] = s; }
+    return 1;
+}
+/* kf_loc[k]: local index of keyframe k (0 .. Nkf-1, ascending with k) or -1 = not optimised; T_kf_w16: K x 4x4 row-major map poses;
+ * xyz3 / pq6 in = map estimates, out = optimised; T_out16: K x 16.  Returns 0, or -1 when there is no observation. */
+void orc_lba_default_options(void* o_) {
+    lba_opt_t* o = (lba_opt_t*)o_;
+    o->lambda_lm = 1e-5; o->lambda_k = 10.0; o->max_iters = 15; o->homog_th = 1e-7; o->min_error = 1e-7; o->min_error_change = 1e-7; o->use_iterate_poses = 0; o->pad = 0;
+}
+/* same argument list as plba_lba_visual (include/plba.h); the problem handle is not used */
+int orc_lba_visual(void* problem, const void* opt_, int K, const double* T_kf_w16, const int32_t* kf_loc, int Np, double* xyz3, int Nl, double* pq6,
+                   int Ep, const int32_t* po_pt, const int32_t* po_kf, const double* uv2, int El, const int32_t* lo_ln, const int32_t* lo_kf, const double* l3,
+                   double fx, double fy, double cx, double cy, double* T_out16, uint8_t* pt_moved, uint8_t* ln_moved, void* stats_) {
+    (void)problem;
+    const lba_opt_t* o = (const lba_opt_t*)opt_;
+    lba_stats_t* st = (lba_stats_t*)stats_;
+    memset(st, 0, sizeof *st);
+    if (Ep + El == 0) return -1;
+    int Nkf = 0;
+    for (int k = 0; k < K; ++k) if (kf_loc[k] >= 0) ++Nkf;
+    const int N = 6 * Nkf + 3 * Np + 6 * Nl;
+    const double cam4[4] = {fx, fy, cx, cy};
+    double* X = (double*)xcalloc(N, 8); double* DX = (double*)xcalloc(N, 8); double* g = (double*)xcalloc(N, 8);
+    double* H = (double*)xcalloc((size_t)N * N, 8);
+    for (int k = 0; k < K; ++k) if (kf_loc[k] >= 0) se3_logmap(T_kf_w16 + 16 * k, X + 6 * kf_loc[k]);      /* x_kf_w */
+    memcpy(X + 6 * Nkf, xyz3, (size_t)3 * Np * 8); memcpy(X + 6 * Nkf + 3 * Np, pq6, (size_t)6 * Nl * 8);
+    double err = 0.0, err_prev = 999999999.9, lambda = o->lambda_lm;
+    int iters, updates = 0;
+    for (iters = 0; iters < o->max_iters; ++iters) {
+        memset(H, 0, (size_t)N * N * 8); memset(g, 0, (size_t)N * 8); memset(DX, 0, (size_t)N * 8);
+        err = 0.0;
+        for (int e = 0; e < Ep; ++e) {
+            const int k = po_kf[e], loc = kf_loc[k], l = po_pt[e];
+            double T[16], Tiw[16], rn, w, Jp[6], Jl[3];
+            if (iters > 0 && loc >= 0) se3_expmap(X + 6 * loc, T); else memcpy(T, T_kf_w16 + 16 * k, 128);      /* :1726-1730 */
+            se3_inverse(T, Tiw);
+            lba_point_obs(cam4, o->homog_th, Tiw, X + 6 * Nkf + 3 * l, uv2 + 2 * e, &rn, &w, Jp, Jl);
+            const int idx = 6 * loc, jdx = 6 * Nkf + 3 * l;
+            err += rn * rn * w;
+            for (int a = 0; a < 3; ++a) { g[jdx + a] += Jl[a] * rn * w; for (int b = 0; b < 3; ++b) H[(size_t)(jdx + a) * N + jdx + b] += Jl[a] * Jl[b] * w; }
+            if (loc >= 0) {
+                for (int a = 0; a < 6; ++a) {
+                    g[idx + a] += Jp[a] * rn * w;
+                    for (int b = 0; b < 6; ++b) H[(size_t)(idx + a) * N + idx + b] += Jp[a] * Jp[b] * w;
+                    for (int b = 0; b < 3; ++b) { H[(size_t)(jdx + b) * N + idx + a] += Jl[b] * Jp[a] * w; H[(size_t)(idx + a) * N + jdx + b] += Jl[b] * Jp[a] * w; }
+                }
+            }
+        }
+        for (int e = 0; e < El; ++e) {
+            const int k = lo_kf[e], loc = kf_loc[k], l = lo_ln[e];
+            double T[16], Tiw[16], rn, w, Jp[6], Jl[6];
+            if (iters > 0 && loc >= 0 && o->use_iterate_poses) se3_expmap(X + 6 * loc, T); else memcpy(T, T_kf_w16 + 16 * k, 128);   /* :1790: the map pose */
+            se3_inverse(T, Tiw);
+            lba_line_obs(cam4, o->homog_th, Tiw, X + 6 * Nkf + 3 * Np + 6 * l, l3 + 3 * e, &rn, &w, Jp, Jl);
+            const int idx = 6 * loc, jdx = 6 * Nkf + 3 * Np + 6 * l;
+            err += rn * rn * w;
+            for (int a = 0; a < 6; ++a) { g[jdx + a] += Jl[a] * rn * w; for (int b = 0; b < 6; ++b) H[(size_t)(jdx + a) * N + jdx + b] += Jl[a] * Jl[b] * w; }
+            if (loc >= 0) {
+                for (int a = 0; a < 6; ++a) {
+                    g[idx + a] += Jp[a] * rn * w;
+                    for (int b = 0; b < 6; ++b) H[(size_t)(idx + a) * N + idx + b] += Jp[a] * Jp[b] * w;
+                    for (int b = 0; b < 6; ++b) { H[(size_t)(jdx + b) * N + idx + a] += Jl[b] * Jp[a] * w; H[(size_t)(idx + a) * N + jdx + b] += Jl[b] * Jp[a] * w; }
+                }
+            }
+        }
+        if (iters == 0) {
+            st->err_first = err / (double)(Ep + El);                       /* reported only */
+            err /= 0.0;                                                    /* :1650 as coded: both counters are still 0 -> +inf (NaN for a zero sum), IEEE 754 */
+            double Hmax = 0.0;
+            for (int i = 0; i < N; ++i) { const double d = H[(size_t)i * N + i]; if (d > Hmax || d < -Hmax) Hmax = fabs(d); }
+            lambda *= Hmax;                                                /* :1653-1659 */
+        } else {
+            err /= (double)(Np + Nl);                                      /* :1882, as coded: the LANDMARK counts */
+            if (fabs(err - err_prev) < o->min_error_change || err < o->min_error) break;      /* :1884-1885 */
+        }
+        for (int i = 0; i < N; ++i) H[(size_t)i * N + i] += lambda * H[(size_t)i * N + i];
+        if (!ldlt_solve(H, N, g, DX)) { st->solver_failed = 1; break; }
+        int do_update = 1;
+        if (iters > 0) {
+            if (err > err_prev) { lambda /= o->lambda_k; do_update = 0; }   /* :1894-1897 */
+            else lambda *= o->lambda_k;
+        }
+        if (do_update) {
+            ++updates;
+            for (int i = 0; i < Nkf; ++i) {                                /* :1670-1675, :1901-1906 */
+                double Tp[16], Td[16], Tdi[16], Tc[16];
+                se3_expmap(X + 6 * i, Tp); se3_expmap(DX + 6 * i, Td); se3_inverse(Td, Tdi); se3_mul(Tp, Tdi, Tc);
+                se3_logmap(Tc, X + 6 * i);
+            }
+            for (int i = 6 * Nkf; i < N; ++i) X[i] += DX[i];
+        }
+        if (iters > 0) { double nn = 0.0; for (int i = 0; i < N; ++i) nn += DX[i] * DX[i]; if (sqrt(nn) < o->min_error_change) { err_prev = err; ++iters; break; } }
+        err_prev = err;
+    }
+    for (int k = 0; k < K; ++k) { if (kf_loc[k] >= 0) se3_expmap(X + 6 * kf_loc[k], T_out16 + 16 * k); else memcpy(T_out16 + 16 * k, T_kf_w16 + 16 * k, 128); }
+    for (int i = 0; i < Np; ++i) {          /* :1944-1970: moved more than 1 cm -> the reference clears `inlier` */
+        double n2 = 0.0;
+        for (int c = 0; c < 3; ++c) { const double dl = X[6 * Nkf + 3 * i + c] - xyz3[3 * i + c]; n2 += dl * dl; }
+        if (pt_moved) pt_moved[i] = sqrt(n2) > 0.01;
+    }
+    for (int i = 0; i < Nl; ++i) {
+        double n2 = 0.0;
+        for (int c = 0; c < 6; ++c) { const double dl = X[6 * Nkf + 3 * Np + 6 * i + c] - pq6[6 * i + c]; n2 += dl * dl; }
+        if (ln_moved) ln_moved[i] = sqrt(n2) > 0.01;
+    }
+    memcpy(xyz3, X + 6 * Nkf, (size_t)3 * Np * 8); memcpy(pq6, X + 6 * Nkf + 3 * Np, (size_t)6 * Nl * 8);
+    st->iterations = iters; st->updates = updates; st->err_last = err; st->lambda = lambda;
+    free(X); free(DX); free(g); free(H);
+    return 0;
+}

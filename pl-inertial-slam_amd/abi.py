@@ -45,6 +45,16 @@ class Prior(C.Structure):
                 ("Ar", c_double_p), ("br", c_double_p)]
 
 
+class LbaOptions(C.Structure):
+    _fields_ = [("lambda_lm", C.c_double), ("lambda_k", C.c_double), ("max_iters", C.c_int), ("homog_th", C.c_double),
+                ("min_error", C.c_double), ("min_error_change", C.c_double), ("use_iterate_poses", C.c_int), ("reserved", C.c_int)]
+
+
+class LbaStats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("updates", C.c_int), ("err_first", C.c_double), ("err_last", C.c_double),
+                ("lam", C.c_double), ("solver_failed", C.c_int), ("reserved", C.c_int)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 _P = C.c_void_p  # plba_problem*
@@ -85,6 +95,10 @@ SIGNATURES = {
     "marginalize_factors": (C.c_int, [_P, C.c_int, c_int32_p, C.c_int, c_int32_p, C.c_int, c_int32_p, C.c_int, C.c_int, c_int32_p, C.POINTER(Prior)]),
     "preintegrate": (C.c_int, [_P, C.c_int, c_int32_p, C.POINTER(C.c_longdouble), c_double_p, c_double_p, C.POINTER(C.c_longdouble), C.POINTER(C.c_longdouble), c_double_p, c_double_p, C.c_double, C.c_double, c_double_p]),
     "prior_free": (None, [C.POINTER(Prior)]),
+    "lba_default_options": (None, [C.POINTER(LbaOptions)]),
+    "lba_visual": (C.c_int, [_P, C.POINTER(LbaOptions), C.c_int, c_double_p, c_int32_p, C.c_int, c_double_p, C.c_int, c_double_p,
+                             C.c_int, c_int32_p, c_int32_p, c_double_p, C.c_int, c_int32_p, c_int32_p, c_double_p,
+                             C.c_double, C.c_double, C.c_double, C.c_double, c_double_p, c_uint8_p, c_uint8_p, C.POINTER(LbaStats)]),
     "debug_build": (C.c_int, [_P, C.c_double, C.c_int]),
     "debug_get": (C.c_int, [_P, C.c_char_p, c_double_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "debug_dense_solve": (C.c_int, [_P, C.c_int, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
@@ -369,6 +383,28 @@ class Problem:
                    Ar=arr(pr.Ar, n * n, np.float64).reshape(n, n), br=arr(pr.br, n, np.float64))
         self.lib.fn["prior_free"](C.byref(pr))
         return out
+
+    def lba_visual(self, T_kf_w, kf_loc, xyz, pq, po_pt, po_kf, uv, lo_ln, lo_kf, l3, cam, **opts):
+        """MapHandler::levMarquardtOptimizationLBA (src/mapHandler.cpp:1441-2098) on the arrays of include/plba.h;
+        returns the optimised poses / landmarks, the moved flags and the run's statistics."""
+        o = LbaOptions()
+        self.lib.fn["lba_default_options"](C.byref(o))
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError("unknown LBA option %r" % k)
+            setattr(o, k, v)
+        T = _f64(T_kf_w).reshape(-1, 16).copy(); K = T.shape[0]
+        xyz = _f64(xyz).reshape(-1, 3).copy(); pq = _f64(pq).reshape(-1, 6).copy()
+        po_pt, po_kf, lo_ln, lo_kf, loc = _i32(po_pt), _i32(po_kf), _i32(lo_ln), _i32(lo_kf), _i32(kf_loc)
+        uv, l3 = _f64(uv).reshape(-1, 2), _f64(l3).reshape(-1, 3)
+        Tout = np.zeros((K, 16)); pm = np.zeros(max(len(xyz), 1), np.uint8); lm = np.zeros(max(len(pq), 1), np.uint8)
+        st = LbaStats()
+        self.call("lba_visual", C.byref(o), K, _dp(T), _ip(loc), len(xyz), _dp(xyz), len(pq), _dp(pq),
+                  len(po_pt), _ip(po_pt), _ip(po_kf), _dp(uv), len(lo_ln), _ip(lo_ln), _ip(lo_kf), _dp(l3),
+                  float(cam[0]), float(cam[1]), float(cam[2]), float(cam[3]), _dp(Tout), _up(pm), _up(lm), C.byref(st))
+        return dict(T=Tout.reshape(K, 4, 4), xyz=xyz, pq=pq, pt_moved=pm[:len(xyz)].astype(bool), ln_moved=lm[:len(pq)].astype(bool),
+                    iterations=st.iterations, updates=st.updates, err_first=st.err_first, err_last=st.err_last, lam=st.lam,
+                    solver_failed=st.solver_failed)
 
     # -- diagnostics -------------------------------------------------------------------------
     def debug_build(self, lam, do_solve=False):

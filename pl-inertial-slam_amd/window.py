@@ -416,3 +416,61 @@ def shard_window(w, rank, world):
     out["lo_kf"] = w["lo_kf"][lsel]; out["lo_l"] = w["lo_l"][lsel]; out["lo_w"] = w["lo_w"][lsel]
     out["shard"] = dict(rank=rank, world=world, pt_range=(lo, hi), ln_range=(llo, lhi))
     return out
+
+
+def make_visual_window(K=8, Np=300, Nl=60, n_fixed=2, seed=0x1BA, noise_px=0.5, pose_noise=(0.02, 0.01), lm_noise=0.03, track=6):
+    """Synthetic input of the pre-init visual-only local BA (MapHandler::localBundleAdjustment, src/mapHandler.cpp:1329-1439,
+    feeding levMarquardtOptimizationLBA): K stereo-rig keyframes T_kf_w (camera-to-world 4x4) moving sideways in front of a
+    landmark cloud, the first `n_fixed` of them only anchoring landmarks (kf_loc = -1), landmark-major observation lists
+    (points: pixel (u, v); lines: normalised image-line coefficients), estimates perturbed away from the truth."""
+    rng = np.random.default_rng(seed)
+    cam = (FX, FY, CX, CY)
+    fx, fy, cx, cy = cam
+    T_true = np.zeros((K, 4, 4))
+    for k in range(K):
+        R = exp_so3(np.array([0.02 * np.sin(0.7 * k), 0.05 * np.sin(0.4 * k + 0.3), 0.01 * k]))
+        T_true[k, :3, :3] = R
+        T_true[k, :3, 3] = [0.25 * k, 0.03 * np.sin(k), 0.05 * k]
+        T_true[k, 3, 3] = 1.0
+
+    def proj(T, X):
+        Xc = T[:3, :3].T @ (X - T[:3, 3])
+        return np.array([cx + fx * Xc[0] / Xc[2], cy + fy * Xc[1] / Xc[2]]), Xc[2]
+
+    def tracks(n):
+        out = []
+        for _ in range(n):
+            k0 = int(rng.integers(0, max(K - 1, 1)))
+            ln = int(rng.integers(2, track + 1))
+            out.append(list(range(k0, min(K, k0 + ln))))
+        return out
+
+    xyz_true = np.zeros((Np, 3)); po_pt, po_kf, uv = [], [], []
+    for i, ks in enumerate(tracks(Np)):
+        c = T_true[ks[len(ks) // 2]]
+        xyz_true[i] = c[:3, 3] + c[:3, :3] @ np.array([rng.uniform(-2.5, 2.5), rng.uniform(-1.5, 1.5), rng.uniform(4.0, 10.0)])
+        for k in ks:
+            z, _ = proj(T_true[k], xyz_true[i])
+            po_pt.append(i); po_kf.append(k); uv.append(z + rng.normal(0.0, noise_px, 2))
+    pq_true = np.zeros((Nl, 6)); lo_ln, lo_kf, l3 = [], [], []
+    for i, ks in enumerate(tracks(Nl)):
+        c = T_true[ks[len(ks) // 2]]
+        P = c[:3, 3] + c[:3, :3] @ np.array([rng.uniform(-2.5, 2.5), rng.uniform(-1.5, 1.5), rng.uniform(4.0, 10.0)])
+        Q = P + c[:3, :3] @ np.array([rng.uniform(-1.0, 1.0), rng.uniform(-1.0, 1.0), rng.uniform(-0.5, 0.5)])
+        pq_true[i] = np.concatenate([P, Q])
+        for k in ks:
+            a, _ = proj(T_true[k], P); b, _ = proj(T_true[k], Q)
+            a = a + rng.normal(0.0, noise_px, 2); b = b + rng.normal(0.0, noise_px, 2)
+            l = np.cross(np.append(a, 1.0), np.append(b, 1.0))
+            lo_ln.append(i); lo_kf.append(k); l3.append(l / np.hypot(l[0], l[1]))
+    kf_loc = np.array([-1 if k < n_fixed else k - n_fixed for k in range(K)], np.int32)
+    T = T_true.copy()
+    for k in range(n_fixed, K):
+        dR = exp_so3(rng.normal(0.0, pose_noise[1], 3))
+        T[k, :3, :3] = T[k, :3, :3] @ dR
+        T[k, :3, 3] += rng.normal(0.0, pose_noise[0], 3)
+    return dict(cam=cam, T_kf_w=T, kf_loc=kf_loc, xyz=xyz_true + rng.normal(0.0, lm_noise, xyz_true.shape),
+                pq=pq_true + rng.normal(0.0, lm_noise, pq_true.shape),
+                po_pt=np.array(po_pt, np.int32), po_kf=np.array(po_kf, np.int32), uv=np.array(uv).reshape(-1, 2),
+                lo_ln=np.array(lo_ln, np.int32), lo_kf=np.array(lo_kf, np.int32), l3=np.array(l3).reshape(-1, 3),
+                truth=dict(T=T_true, xyz=xyz_true, pq=pq_true))
