@@ -235,7 +235,10 @@ typedef struct plba_lba_options {
     double min_error;           /* Config::minError             (:1884) */
     double min_error_change;    /* Config::minErrorChange       (:1884, :1911) */
     int    use_iterate_poses;   /* 0 = the line pass linearises at the map poses, as the reference does (:1790) */
-    int    reserved;
+    int    variant;             /* 0 = levMarquardtOptimizationLBA; 1 = levMarquardtOptimizationGBA (:2210-2812): the same text
+                                   with `int Hmax` (:2468: lambda scales with the truncated maximum), the error divided by the zero
+                                   counters in EVERY pass (:2744: every step is taken) — and machine epsilon for both thresholds
+                                   (:2746, :2776), which the caller passes as min_error / min_error_change */
 } plba_lba_options;
 typedef struct plba_lba_stats {
     int    iterations;          /* linear solves performed */

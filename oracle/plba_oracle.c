@@ -2456,8 +2456,11 @@ void orc_se3_vertex_oplus(const double* X12, const double* u6, double* out12) {
  *   :1650  err /= (Npt_obs + Nls_obs) with both counters 0: reproduced (IEEE: +inf), it makes the first comparison of :1894 a "success";
  *   :1787-1788  P and Q of a line read from the same, 3-strided offset -> NOT reproduced (P = X[.. + 6 l], Q = X[.. + 6 l + 3]);
  *   :1790  the line pass inside the loop takes keyframe poses from the MAP, not from X -> reproduced unless use_iterate_poses.
+ * variant = 1 is levMarquardtOptimizationGBA (:2210-2812), the same text over all keyframes with three differences that matter:
+ * `int Hmax` (:2468), err divided by the zero counters in EVERY pass (:2744; every step is taken, lambda only grows) and
+ * machine epsilon as both thresholds (:2746, :2776; the caller passes them as min_error / min_error_change).
  * ================================================================================================================= */
-typedef struct { double lambda_lm, lambda_k; int max_iters; double homog_th, min_error, min_error_change; int use_iterate_poses; int pad; } lba_opt_t;
+typedef struct { double lambda_lm, lambda_k; int max_iters; double homog_th, min_error, min_error_change; int use_iterate_poses; int variant; } lba_opt_t;
 typedef struct { int iterations; int updates; double err_first, err_last, lambda; int solver_failed; int reserved; } lba_stats_t;
 
 static void se3_inverse(const double* T, double* Ti) { /* inverse_se3, auxiliar.cpp:113-122 */
@@ -2570,7 +2573,7 @@ static int ldlt_solve(double* A, int n, const double* b, double* x) {
  * xyz3 / pq6 in = map estimates, out = optimised; T_out16: K x 16.  Returns 0, or -1 when there is no observation. */
 void orc_lba_default_options(void* o_) {
     lba_opt_t* o = (lba_opt_t*)o_;
-    o->lambda_lm = 1e-5; o->lambda_k = 10.0; o->max_iters = 15; o->homog_th = 1e-7; o->min_error = 1e-7; o->min_error_change = 1e-7; o->use_iterate_poses = 0; o->pad = 0;
+    o->lambda_lm = 1e-5; o->lambda_k = 10.0; o->max_iters = 15; o->homog_th = 1e-7; o->min_error = 1e-7; o->min_error_change = 1e-7; o->use_iterate_poses = 0; o->variant = 0;
 }
 /* same argument list as plba_lba_visual (include/plba.h); the problem handle is not used */
 int orc_lba_visual(void* problem, const void* opt_, int K, const double* T_kf_w16, const int32_t* kf_loc, int Np, double* xyz3, int Nl, double* pq6,
@@ -2633,9 +2636,11 @@ int orc_lba_visual(void* problem, const void* opt_, int K, const double* T_kf_w1
             err /= 0.0;                                                    /* :1650 as coded: both counters are still 0 -> +inf (NaN for a zero sum), IEEE 754 */
             double Hmax = 0.0;
             for (int i = 0; i < N; ++i) { const double d = H[(size_t)i * N + i]; if (d > Hmax || d < -Hmax) Hmax = fabs(d); }
+            if (o->variant == 1) Hmax = (double)(int)Hmax;                 /* GBA: `int Hmax` (:2468) truncates */
             lambda *= Hmax;                                                /* :1653-1659 */
         } else {
-            err /= (double)(Np + Nl);                                      /* :1882, as coded: the LANDMARK counts */
+            if (o->variant == 1) err /= 0.0;                               /* GBA :2744: the zero counters again -> every pass is a "success" */
+            else err /= (double)(Np + Nl);                                 /* :1882, as coded: the LANDMARK counts */
             if (fabs(err - err_prev) < o->min_error_change || err < o->min_error) break;      /* :1884-1885 */
         }
         for (int i = 0; i < N; ++i) H[(size_t)i * N + i] += lambda * H[(size_t)i * N + i];

@@ -47,7 +47,7 @@ class Prior(C.Structure):
 
 class LbaOptions(C.Structure):
     _fields_ = [("lambda_lm", C.c_double), ("lambda_k", C.c_double), ("max_iters", C.c_int), ("homog_th", C.c_double),
-                ("min_error", C.c_double), ("min_error_change", C.c_double), ("use_iterate_poses", C.c_int), ("reserved", C.c_int)]
+                ("min_error", C.c_double), ("min_error_change", C.c_double), ("use_iterate_poses", C.c_int), ("variant", C.c_int)]
 
 
 class LbaStats(C.Structure):

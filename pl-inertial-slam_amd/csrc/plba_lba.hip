@@ -6,14 +6,14 @@
 // whole system.  A scalar residual makes every observation's Hessian contribution rank one: H_pl = w Jp Jl^T, so the
 // landmark-block Schur complement of a landmark l seen from keyframes a, b is the rank-one update
 //     S[a, b] -= (w_a w_b Jl_a^T D_l Jl_b) Jp_a Jp_b^T,        D_l = (Hll_l + lambda diag Hll_l)^-1,
-// which is what k_lba_schur forms; the 6 Nkf pose system then goes through the dense fp64 Cholesky of plba_dense.hip and
+// which is what k_lba_pairs forms (a wave per keyframe pair chunk over host-built pair entries); the 6 Nkf pose system then goes through the dense fp64 Cholesky of plba_dense.hip and
 // landmarks are back-substituted.  The LM control (lambda schedule as coded, termination tests, the map-pose quirk of the
 // line pass) stays on the host, two small read-backs per iteration: this path runs a handful of iterations on a small
 // window before the IMU is initialised; it is not the north-star kernel and is not tuned like it.
 //
 // Kernel map (one iteration): k_lba_poses -> k_lba_landmarks (thread per landmark, observations landmark-major as
-// the reference's lists are) -> k_lba_posesys (wave per local keyframe over its observations) -> k_lba_reduce
-// -> [host: err, lambda] -> k_lba_sysinit -> k_lba_schur -> Cholesky / back-substitution (plba_dense.hip)
+// the reference's lists are) -> k_lba_posesys (workgroup per local keyframe over its observations) -> k_lba_reduce
+// -> [host: err, lambda] -> k_lba_sysinit -> k_lba_dinv -> k_lba_pairs -> k_lba_rhs -> Cholesky / back-substitution (plba_dense.hip)
 // -> k_lba_backsub -> k_lba_update (gated on solver_ok) -> k_lba_dxnorm -> [host: |DX|].
 #include "plba_internal.h"
 #include "plba_problem.h"
@@ -44,9 +44,13 @@ struct LbaDev {
     double* Hll;               // (Np + Nl) x 21 (upper, row-major packed; points use the first 6)
     double* gl;                // (Np + Nl) x 6
     double* Dl;                // (Np + Nl) x 21: (Hll + lambda diag)^-1
+    double* urec;              // (Ep + El) x 8: u = w D Jl (6), s = w Jl . (D gl), pad
+    const int32_t* pair_ent;   // 2 x nent: the two observations (of keyframes la <= lb, one landmark) of each Schur pair entry, pair-major
+    const int32_t* chunk;      // nchunk x 4: la, lb, first entry, end entry (<= PAIR_CHUNK entries of one keyframe pair)
+    int nchunk;
     double* Hpp;               // Nkf x 21
     double* gp;                // Nkf x 6
-    double* part;              // per-block partial sums (err), then 4 scalars: err, Hmax, |DX|^2
+    double* part;              // 2 x nblk per-block partials: error sums (later the landmark part of |DX|^2), max |Hll_ii|
     double* scal;
     double* DXl;               // 3 Np + 6 Nl
     double* sys;               // (Ppad + 64) x ld
@@ -199,10 +203,11 @@ __device__ __forceinline__ void row_R(const double* v, const double* Tiw, double
 }
 
 constexpr int LM_NT = 128;
+__device__ __forceinline__ int diag_q(int a) { return a * 6 - a * (a - 1) / 2; }      // packed index of (a, a)
 // thread per landmark: its observations' records, Hll (packed upper), gl, and the error sum
 __global__ void __launch_bounds__(LM_NT) k_lba_landmarks(LbaDev d) {
     const int l = blockIdx.x * LM_NT + threadIdx.x, L = d.Np + d.Nl;
-    double err = 0.0;
+    double err = 0.0, hm = 0.0;
     if (l < L) {
         const bool is_pt = l < d.Np;
         const int dim = is_pt ? 3 : 6;
@@ -258,25 +263,43 @@ __global__ void __launch_bounds__(LM_NT) k_lba_landmarks(LbaDev d) {
                 for (int b = a; b < 6; ++b, ++q) H[q] += Jl[a] * Jl[b] * w;
             }
         }
-        (void)dim;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) if (a < dim) hm = fmax(hm, fabs(H[diag_q(a)]));
 #pragma unroll
         for (int i = 0; i < 21; ++i) d.Hll[(size_t)21 * l + i] = H[i];
 #pragma unroll
         for (int i = 0; i < 6; ++i) d.gl[(size_t)6 * l + i] = gv[i];
     }
-    __shared__ double sh[LM_NT];
-    sh[threadIdx.x] = err;
+    __shared__ double sh[LM_NT], shm[LM_NT];
+    sh[threadIdx.x] = err; shm[threadIdx.x] = hm;
     __syncthreads();
-    for (int s = LM_NT / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
-    if (threadIdx.x == 0) d.part[blockIdx.x] = sh[0];
+    for (int s = LM_NT / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sh[threadIdx.x] += sh[threadIdx.x + s]; shm[threadIdx.x] = fmax(shm[threadIdx.x], shm[threadIdx.x + s]); }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { d.part[blockIdx.x] = sh[0]; d.part[gridDim.x + blockIdx.x] = shm[0]; }
 }
-// one wave per local keyframe: Hpp (packed upper 21) and gp over the keyframe's observations, in a fixed order
-__global__ void __launch_bounds__(64) k_lba_posesys(LbaDev d) {
-    const int i = blockIdx.x, lane = threadIdx.x;
+// one workgroup per local keyframe: Hpp (packed upper 21) and gp over the keyframe's observations, in a fixed order
+constexpr int KF_NT = 256;
+template <int NV>
+__device__ __forceinline__ void block_sum(double* acc, double* sh /* KF_NT / 64 x NV */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double v = acc[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) sh[wv * NV + q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) { double v = 0.0; for (int w = 0; w < KF_NT / 64; ++w) v += sh[w * NV + threadIdx.x]; acc[0] = v; }
+}
+__global__ void __launch_bounds__(KF_NT) k_lba_posesys(LbaDev d) {
+    const int i = blockIdx.x;
+    __shared__ double sh[(KF_NT / 64) * 27];
     double acc[27];
 #pragma unroll
     for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-    for (int t = d.kf_start[i] + lane; t < d.kf_start[i + 1]; t += 64) {
+    for (int t = d.kf_start[i] + threadIdx.x; t < d.kf_start[i + 1]; t += KF_NT) {
         const double* r = d.rec + (size_t)REC * d.kf_obs[t];
         const double w = r[12], n = r[13];
         double Jp[6];
@@ -290,41 +313,25 @@ __global__ void __launch_bounds__(64) k_lba_posesys(LbaDev d) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) acc[21 + a] += Jp[a] * n * w;
     }
-#pragma unroll
-    for (int q = 0; q < 27; ++q) {
-        double v = acc[q];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        acc[q] = v;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < 21; ++q) d.Hpp[21 * i + q] = acc[q];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) d.gp[6 * i + q] = acc[21 + q];
-    }
+    block_sum<27>(acc, sh);
+    if (threadIdx.x < 21) d.Hpp[21 * i + threadIdx.x] = acc[0];
+    else if (threadIdx.x < 27) d.gp[6 * i + threadIdx.x - 21] = acc[0];
 }
-__device__ __forceinline__ int diag_q(int a) { return a * 6 - a * (a - 1) / 2; }      // packed index of (a, a)
 // scal[0] = sum of the error partials (fixed order), scal[1] = max |H_ii| over the whole diagonal (:1653-1658)
 __global__ void __launch_bounds__(256) k_lba_reduce(LbaDev d, int nblk) {
-    __shared__ double sh[256];
-    double hm = 0.0;
-    const int L = d.Np + d.Nl;
-    for (int l = threadIdx.x; l < L; l += 256) {
-        const int dim = l < d.Np ? 3 : 6;
-        for (int a = 0; a < dim; ++a) hm = fmax(hm, fabs(d.Hll[(size_t)21 * l + diag_q(a)]));
-    }
-    for (int i = threadIdx.x; i < d.Nkf; i += 256)
-        for (int a = 0; a < 6; ++a) hm = fmax(hm, fabs(d.Hpp[21 * i + diag_q(a)]));
-    sh[threadIdx.x] = hm;
+    __shared__ double sh[256], shm[256];
+    double hm = 0.0, e = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) { e += d.part[b]; hm = fmax(hm, d.part[nblk + b]); }
+    for (int i = threadIdx.x; i < d.Nkf * 6; i += 256) hm = fmax(hm, fabs(d.Hpp[21 * (i / 6) + diag_q(i % 6)]));
+    sh[threadIdx.x] = e; shm[threadIdx.x] = hm;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]); __syncthreads(); }
-    if (threadIdx.x == 0) {
-        double e = 0.0;
-        for (int b = 0; b < nblk; ++b) e += d.part[b];
-        d.scal[0] = e; d.scal[1] = sh[0];
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sh[threadIdx.x] += sh[threadIdx.x + s]; shm[threadIdx.x] = fmax(shm[threadIdx.x], shm[threadIdx.x + s]); }
+        __syncthreads();
     }
+    if (threadIdx.x == 0) { d.scal[0] = sh[0]; d.scal[1] = shm[0]; }
 }
-// pose system before the Schur complement: damped diagonal blocks, rhs row, unit padding, solver flag
+// pose system before the Schur complement: damped diagonal blocks, unit padding, solver flag
 __global__ void k_lba_sysinit(LbaDev d, double lambda) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) { d.ctrl->solver_ok = 1; }
@@ -335,7 +342,6 @@ __global__ void k_lba_sysinit(LbaDev d, double lambda) {
         if (a == b) v += lambda * v;
         d.sys[(size_t)(6 * i + a) * d.ld + 6 * i + b] = v;
     }
-    if (t < d.P) d.sys[(size_t)d.Ppad * d.ld + t] = d.gp[t];
     if (t >= d.P && t < d.Ppad) d.sys[(size_t)t * d.ld + t] = 1.0;
 }
 // 3 x 3 / 6 x 6 SPD inverse from the packed upper triangle (Cholesky, then L^-1, then L^-T L^-1); false if not positive
@@ -415,9 +421,10 @@ __device__ __forceinline__ void load_packed(const double* H21, double lambda, do
 #pragma unroll
         for (int b = a; b < N; ++b, ++q) { const double v = H21[diag_q(a) + (b - a)]; Hp[q] = (a == b) ? v + lambda * v : v; }
 }
-// thread per landmark: D = (Hll + lambda diag Hll)^-1, then the rank-one Schur updates of every keyframe pair that sees it
+// thread per landmark: D = (Hll + lambda diag Hll)^-1 and, per observation, u = w D Jl and s = w Jl . (D gl): everything the
+// pair kernel and the right-hand side need from the landmark block
 template <int N>
-__device__ void schur_landmark(const LbaDev& d, int l, double lambda) {
+__device__ void dinv_landmark(const LbaDev& d, int l, double lambda) {
     double Hp[N * (N + 1) / 2], Dp[N * (N + 1) / 2];
     load_packed<N>(d.Hll + (size_t)21 * l, lambda, Hp);
     if (!spd_inv_packed<N>(Hp, Dp)) d.ctrl->solver_ok = 0;
@@ -427,45 +434,83 @@ __device__ void schur_landmark(const LbaDev& d, int l, double lambda) {
 #pragma unroll
     for (int i = 0; i < N; ++i) gv[i] = d.gl[(size_t)6 * l + i];
     sym_mul_packed<N>(Dp, gv, tv);
-    const int e0 = d.lm_start[l], e1 = d.lm_start[l + 1];
-    for (int ea = e0; ea < e1; ++ea) {
-        const int la = d.kf_loc[d.obs_kf[ea]];
-        if (la < 0) continue;
-        const double* ra = d.rec + (size_t)REC * ea;
-        double Ja[N], ua[N], Jpa[6];
+    for (int e = d.lm_start[l]; e < d.lm_start[l + 1]; ++e) {
+        const double* r = d.rec + (size_t)REC * e;
+        double Ja[N], ua[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) Ja[i] = ra[6 + i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Jpa[i] = ra[i];
-        const double wa = ra[12];
+        for (int i = 0; i < N; ++i) Ja[i] = r[6 + i];
+        const double wa = r[12];
         sym_mul_packed<N>(Dp, Ja, ua);
         double sg = 0.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) sg += Ja[i] * tv[i];
-        sg *= wa;
+        double* u = d.urec + (size_t)8 * e;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) atomicAdd(d.sys + (size_t)d.Ppad * d.ld + 6 * la + i, -Jpa[i] * sg);
-        for (int eb = e0; eb < e1; ++eb) {
-            const int lb = d.kf_loc[d.obs_kf[eb]];
-            if (lb < 0) continue;
-            const double* rb = d.rec + (size_t)REC * eb;
-            double c = 0.0;
-#pragma unroll
-            for (int i = 0; i < N; ++i) c += ua[i] * rb[6 + i];
-            c *= wa * rb[12];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const double ci = c * Jpa[i];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) atomicAdd(d.sys + (size_t)(6 * la + i) * d.ld + 6 * lb + j, -ci * rb[j]);
-            }
-        }
+        for (int i = 0; i < 6; ++i) u[i] = i < N ? wa * ua[i] : 0.0;
+        u[6] = wa * sg; u[7] = 0.0;
     }
 }
-__global__ void __launch_bounds__(LM_NT) k_lba_schur(LbaDev d, double lambda) {
+__global__ void __launch_bounds__(LM_NT) k_lba_dinv(LbaDev d, double lambda) {
     const int l = blockIdx.x * LM_NT + threadIdx.x;
     if (l >= d.Np + d.Nl) return;
-    if (l < d.Np) schur_landmark<3>(d, l, lambda); else schur_landmark<6>(d, l, lambda);
+    if (l < d.Np) dinv_landmark<3>(d, l, lambda); else dinv_landmark<6>(d, l, lambda);
+}
+// One wave per chunk of a keyframe pair's entries.  A scalar residual makes H_pl rank one, so an entry (observations a, b of
+// one landmark) contributes  -(u_a . Jl_b) w_b  Jp_a Jp_b^T  to S[la, lb]: 36 sums per lane, a wave reduction, then one
+// add per element and chunk (the only atomics of the iteration; a pair has few chunks).
+constexpr int PAIR_CHUNK = 256;
+__global__ void __launch_bounds__(64) k_lba_pairs(LbaDev d) {
+    const int32_t* ck = d.chunk + 4 * (size_t)blockIdx.x;
+    const int la = ck[0], lb = ck[1], lane = threadIdx.x;
+    double acc[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) acc[q] = 0.0;
+    for (int t = ck[2] + lane; t < ck[3]; t += 64) {
+        const int ea = d.pair_ent[2 * (size_t)t], eb = d.pair_ent[2 * (size_t)t + 1];
+        const double* ra = d.rec + (size_t)REC * ea;
+        const double* rb = d.rec + (size_t)REC * eb;
+        const double* ua = d.urec + (size_t)8 * ea;
+        double c = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c += ua[i] * rb[6 + i];      // points carry zeros in the upper three
+        c *= rb[12];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double ci = c * ra[i];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i * 6 + j] += ci * rb[j];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 36; ++q) {
+        double v = acc[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        acc[q] = v;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                atomicAdd(d.sys + (size_t)(6 * la + i) * d.ld + 6 * lb + j, -acc[i * 6 + j]);
+                if (la != lb) atomicAdd(d.sys + (size_t)(6 * lb + j) * d.ld + 6 * la + i, -acc[i * 6 + j]);
+            }
+    }
+}
+// right-hand side of the reduced system: gp - sum over the keyframe's observations of Jp s  (workgroup per local keyframe, fixed order)
+__global__ void __launch_bounds__(KF_NT) k_lba_rhs(LbaDev d) {
+    const int i = blockIdx.x;
+    __shared__ double sh[(KF_NT / 64) * 6];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int t = d.kf_start[i] + threadIdx.x; t < d.kf_start[i + 1]; t += KF_NT) {
+        const int e = d.kf_obs[t];
+        const double* r = d.rec + (size_t)REC * e;
+        const double sg = d.urec[(size_t)8 * e + 6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[a] += r[a] * sg;
+    }
+    block_sum<6>(acc, sh);
+    if (threadIdx.x < 6) d.sys[(size_t)d.Ppad * d.ld + 6 * i + threadIdx.x] = d.gp[6 * i + threadIdx.x] - acc[0];
 }
 // dx_l = D (gl - sum_a w_a Jl_a (Jp_a . dx_pose(a)))
 template <int N>
@@ -508,11 +553,15 @@ __global__ void __launch_bounds__(LM_NT) k_lba_backsub(LbaDev d) {
 // |DX|^2 (:1911) and, when the step is taken and the solve succeeded, the update of :1901-1910
 __global__ void __launch_bounds__(256) k_lba_update(LbaDev d, int nblk, int do_update) {
     const bool ok = d.ctrl->solver_ok != 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0) {
+        __shared__ double sh[256];
         double nn = 0.0;
-        for (int b = 0; b < nblk; ++b) nn += d.part[b];
-        for (int i = 0; i < d.P; ++i) nn += d.x[i] * d.x[i];
-        d.scal[2] = nn;
+        for (int b = threadIdx.x; b < nblk; b += 256) nn += d.part[b];
+        for (int i = threadIdx.x; i < d.P; i += 256) nn += d.x[i] * d.x[i];
+        sh[threadIdx.x] = nn;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
+        if (threadIdx.x == 0) d.scal[2] = sh[0];
     }
     if (!ok || !do_update) return;
     const int t = blockIdx.x * 256 + threadIdx.x, nl = 3 * d.Np + 6 * d.Nl;
@@ -550,7 +599,7 @@ void plba_lba_default_options(plba_lba_options* o) {
     o->min_error = 1e-7;      // Config::minError
     o->min_error_change = 1e-7;      // Config::minErrorChange
     o->use_iterate_poses = 0;
-    o->reserved = 0;
+    o->variant = 0;
 }
 
 int plba_lba_visual(plba_problem* p, const plba_lba_options* opt, int K, const double* T_kf_w16, const int32_t* kf_loc,
@@ -593,13 +642,47 @@ int plba_lba_visual(plba_problem* p, const plba_lba_options* opt, int K, const d
     kf_obs.assign(std::max(kf_start[Nkf], 1), 0);
     { std::vector<int32_t> cur(kf_start.begin(), kf_start.end() - 1); for (int e = 0; e < E; ++e) { const int lc = kf_loc[obs_kf[e]]; if (lc >= 0) kf_obs[cur[lc]++] = e; } }
 
+    // Schur pair entries: for every landmark, every pair of its observations in local keyframes la <= lb (an observation with
+    // itself included), grouped by keyframe pair and cut into chunks of <= PAIR_CHUNK entries; constant over the iterations
+    std::vector<int32_t> pair_ent, chunk;
+    {
+        std::vector<int64_t> cnt((size_t)Nkf * Nkf + 1, 0);
+        auto for_pairs = [&](auto&& fn) {
+            for (int l = 0; l < L; ++l)
+                for (int ea = lm_start[l]; ea < lm_start[l + 1]; ++ea) {
+                    const int la = kf_loc[obs_kf[ea]];
+                    if (la < 0) continue;
+                    for (int eb = lm_start[l]; eb < lm_start[l + 1]; ++eb) {
+                        const int lb = kf_loc[obs_kf[eb]];
+                        if (lb < la) continue;      // the (lb, la) block is the transpose; la == lb keeps every ordered pair (normally just the observation with itself)
+                        fn(la, lb, ea, eb);
+                    }
+                }
+        };
+        for_pairs([&](int la, int lb, int, int) { ++cnt[(size_t)la * Nkf + lb + 1]; });
+        for (size_t i = 0; i < (size_t)Nkf * Nkf; ++i) cnt[i + 1] += cnt[i];
+        const int64_t nent = cnt[(size_t)Nkf * Nkf];
+        if (nent > INT32_MAX / 2) FAIL(p, PLBA_ERR_INVALID, "plba_lba_visual: too many co-observation pairs");
+        pair_ent.assign((size_t)2 * std::max<int64_t>(nent, 1), 0);
+        std::vector<int64_t> cur(cnt.begin(), cnt.end() - 1);
+        for_pairs([&](int la, int lb, int ea, int eb) { const int64_t t = cur[(size_t)la * Nkf + lb]++; pair_ent[2 * t] = ea; pair_ent[2 * t + 1] = eb; });
+        for (int la = 0; la < Nkf; ++la)
+            for (int lb = la; lb < Nkf; ++lb)
+                for (int64_t t0 = cnt[(size_t)la * Nkf + lb], t1 = cnt[(size_t)la * Nkf + lb + 1]; t0 < t1; t0 += PAIR_CHUNK) {
+                    chunk.push_back(la); chunk.push_back(lb); chunk.push_back((int32_t)t0); chunk.push_back((int32_t)std::min<int64_t>(t1, t0 + PAIR_CHUNK));
+                }
+    }
+    const int nchunk = (int)(chunk.size() / 4);
+    if (chunk.empty()) chunk.assign(4, 0);
+
     HIPCK(p, hipSetDevice(p->device));
     hipStream_t s = p->stream;
     const int P = 6 * Nkf, Ppad = std::max(TILE, (P + TILE - 1) / TILE * TILE), ld = Ppad;
     const size_t sysn = (size_t)(Ppad + TILE) * ld, nl = (size_t)3 * Np + (size_t)6 * Nl;
     const int nblk = (L + LM_NT - 1) / LM_NT;
     DArr<double> dT, dZ, dXp, dXl, dTiw, dRec, dHll, dgl, dDl, dHpp, dgp, dpart, dscal, dDXl, sys, Lfac, xx, Linv, LT32, rd32, Ninv, dTout;
-    DArr<int32_t> dloc, dlockf, dlms, dokf, dkfs, dkfo;
+    DArr<int32_t> dloc, dlockf, dlms, dokf, dkfs, dkfo, dpent, dchunk;
+    DArr<double> dUrec;
     DArr<int> flags, cflags;
     DArr<Ctrl> ctrl;
     std::vector<double> hT(T_kf_w16, T_kf_w16 + (size_t)16 * K), hXl(std::max<size_t>(nl, 1), 0.0);
@@ -610,8 +693,9 @@ int plba_lba_visual(plba_problem* p, const plba_lba_options* opt, int K, const d
         DArrStreamScope staged(s, p->have_ctx ? p->ctx.stage : nullptr);      // host vectors above stay alive until the wait below
         HIPCK(p, dT.upload(hT)); HIPCK(p, dZ.upload(obs_z)); HIPCK(p, dXl.upload(hXl)); HIPCK(p, dloc.upload(hloc)); HIPCK(p, dlockf.upload(loc_kf));
         HIPCK(p, dlms.upload(lm_start)); HIPCK(p, dokf.upload(obs_kf)); HIPCK(p, dkfs.upload(kf_start)); HIPCK(p, dkfo.upload(kf_obs));
+        HIPCK(p, dpent.upload(pair_ent)); HIPCK(p, dchunk.upload(chunk)); HIPCK(p, dUrec.alloc((size_t)8 * E));
         HIPCK(p, dXp.alloc(P)); HIPCK(p, dTiw.alloc((size_t)24 * K)); HIPCK(p, dRec.alloc((size_t)REC * E)); HIPCK(p, dHll.alloc((size_t)21 * L)); HIPCK(p, dgl.alloc((size_t)6 * L));
-        HIPCK(p, dDl.alloc((size_t)21 * L)); HIPCK(p, dHpp.alloc((size_t)21 * Nkf)); HIPCK(p, dgp.alloc(P)); HIPCK(p, dpart.alloc(nblk)); HIPCK(p, dscal.alloc(4)); HIPCK(p, dDXl.alloc(nl));
+        HIPCK(p, dDl.alloc((size_t)21 * L)); HIPCK(p, dHpp.alloc((size_t)21 * Nkf)); HIPCK(p, dgp.alloc(P)); HIPCK(p, dpart.alloc((size_t)2 * nblk)); HIPCK(p, dscal.alloc(4)); HIPCK(p, dDXl.alloc(nl));
         HIPCK(p, sys.alloc(sysn)); HIPCK(p, Lfac.alloc(sysn)); HIPCK(p, xx.alloc(ld)); HIPCK(p, ctrl.alloc(1)); HIPCK(p, dTout.alloc((size_t)16 * K));
         HIPCK(p, Linv.alloc((size_t)(Ppad / TILE) * TILE * TILE)); HIPCK(p, flags.alloc(Ppad / TILE)); HIPCK(p, LT32.alloc((size_t)Ppad * 64)); HIPCK(p, rd32.alloc(Ppad));
         HIPCK(p, cflags.alloc((size_t)(Ppad / 32 + 2) * (Ppad / 32)));
@@ -623,6 +707,7 @@ int plba_lba_visual(plba_problem* p, const plba_lba_options* opt, int K, const d
     d.fx = fx; d.fy = fy; d.cx = cx; d.cy = cy; d.homog_th = opt->homog_th;
     d.Tmap = dT.p; d.kf_loc = dloc.p; d.loc_kf = dlockf.p; d.lm_start = dlms.p; d.obs_kf = dokf.p; d.obs_z = dZ.p; d.kf_start = dkfs.p; d.kf_obs = dkfo.p;
     d.Xp = dXp.p; d.Xl = dXl.p; d.Tiw = dTiw.p; d.rec = dRec.p; d.Hll = dHll.p; d.gl = dgl.p; d.Dl = dDl.p; d.Hpp = dHpp.p; d.gp = dgp.p;
+    d.urec = dUrec.p; d.pair_ent = dpent.p; d.chunk = dchunk.p; d.nchunk = nchunk;
     d.part = dpart.p; d.scal = dscal.p; d.DXl = dDXl.p; d.sys = sys.p; d.x = xx.p; d.ctrl = ctrl.p; d.Tout = dTout.p;
     DevBuf dd; memset(&dd, 0, sizeof dd);
     dd.P = P; dd.Ppad = Ppad; dd.ld = ld; dd.sys = sys.p; dd.Lfac = Lfac.p; dd.x = xx.p; dd.ctrl = ctrl.p; dd.Linv = Linv.p; dd.flow_flags = flags.p; dd.LTblk = LT32.p; dd.Linv32 = LT32.p; dd.rdblk = rd32.p;
@@ -638,16 +723,17 @@ int plba_lba_visual(plba_problem* p, const plba_lba_options* opt, int K, const d
     for (iters = 0; iters < opt->max_iters; ++iters) {
         hipLaunchKernelGGL(k_lba_poses, grid(K, 64), dim3(64), 0, s, d, iters > 0 ? 1 : 0, opt->use_iterate_poses);
         hipLaunchKernelGGL(k_lba_landmarks, dim3(nblk), dim3(LM_NT), 0, s, d);
-        hipLaunchKernelGGL(k_lba_posesys, dim3(Nkf), dim3(64), 0, s, d);
+        hipLaunchKernelGGL(k_lba_posesys, dim3(Nkf), dim3(KF_NT), 0, s, d);
         hipLaunchKernelGGL(k_lba_reduce, dim3(1), dim3(256), 0, s, d, nblk);
         HIPCK(p, plba_d2h(p, scal, dscal.p, 16));
         err = scal[0];
         if (iters == 0) {
             st->err_first = err / (double)(Ep + El);      // reported only
             err /= 0.0;                    // :1650 as coded (both counters are still 0): +inf, which makes the first comparison of :1894 a "success" 
-            lambda *= scal[1];             // :1653-1659
+            lambda *= opt->variant == 1 ? (double)(int)scal[1] : scal[1];      // :1653-1659; GBA declares `int Hmax` (:2468)
         } else {
-            err /= (double)(Np + Nl);      // :1882 as coded
+            if (opt->variant == 1) err /= 0.0;      // GBA :2744 divides by the zero counters in every pass
+            else err /= (double)(Np + Nl);          // :1882 as coded
             if (fabs(err - err_prev) < opt->min_error_change || err < opt->min_error) break;
         }
         int do_update = 1;
@@ -655,7 +741,9 @@ int plba_lba_visual(plba_problem* p, const plba_lba_options* opt, int K, const d
         if (iters > 0) { if (err > err_prev) { lambda_next = lambda / opt->lambda_k; do_update = 0; } else lambda_next = lambda * opt->lambda_k; }
         HIPCK(p, hipMemsetAsync(sys.p, 0, sysn * 8, s));
         hipLaunchKernelGGL(k_lba_sysinit, grid(std::max(Nkf * 36, Ppad), 256), dim3(256), 0, s, d, lambda);
-        hipLaunchKernelGGL(k_lba_schur, dim3(nblk), dim3(LM_NT), 0, s, d, lambda);
+        hipLaunchKernelGGL(k_lba_dinv, dim3(nblk), dim3(LM_NT), 0, s, d, lambda);
+        if (nchunk) hipLaunchKernelGGL(k_lba_pairs, dim3(nchunk), dim3(64), 0, s, d);
+        hipLaunchKernelGGL(k_lba_rhs, dim3(Nkf), dim3(KF_NT), 0, s, d);
         launch_cholesky(dd, p->opt.use_mfma != 0, iters + 1, s);
         launch_trsv_back(dd, p->opt.use_mfma != 0, iters + 1, s);
         hipLaunchKernelGGL(k_lba_backsub, dim3(nblk), dim3(LM_NT), 0, s, d);

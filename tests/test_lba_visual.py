@@ -97,6 +97,33 @@ def test_oracle_run_follows_the_coded_schedule(pkg, orc):
     o.close()
 
 
+def test_oracle_gba_variant_takes_every_step(pkg, orc):
+    """levMarquardtOptimizationGBA (:2210-2812): err is x / 0 in every pass (:2744), so no step is ever refused, lambda
+    only grows, and lambda starts from the TRUNCATED max |H_ii| (`int Hmax`, :2468)"""
+    w = pkg.window.make_visual_window(K=6, Np=100, Nl=20, n_fixed=1, seed=8)
+    o = orc.new_problem()
+    eps = float(np.finfo(float).eps)
+    r = _run(o, w, variant=1, min_error=eps, min_error_change=eps, max_iters=6)
+    assert r["iterations"] == 6 and r["updates"] == 6 and np.isinf(r["err_last"])
+    l0 = _run(o, w, variant=0, max_iters=1)["lam"]
+    l1 = _run(o, w, variant=1, max_iters=1)["lam"]
+    assert l1 == pytest.approx(1e-5 * np.floor(l0 / 1e-5), rel=1e-12) and l1 < l0
+    assert r["lam"] == pytest.approx(l1 * 10.0 ** 5, rel=1e-12)
+    o.close()
+
+
+@pytest.mark.gpu
+def test_device_gba_variant_matches_the_oracle(pkg, orc, hip):
+    w = pkg.window.make_visual_window(K=7, Np=200, Nl=40, n_fixed=1, seed=13)
+    eps = float(np.finfo(float).eps)
+    g = pkg.new_problem(); o = orc.new_problem()
+    a, b = (_run(x, w, variant=1, min_error=eps, min_error_change=eps, max_iters=8) for x in (g, o))
+    assert (a["iterations"], a["updates"]) == (b["iterations"], b["updates"]) == (8, 8)
+    assert a["lam"] == pytest.approx(b["lam"], rel=1e-12)
+    assert np.abs(a["T"] - b["T"]).max() < 1e-9 and np.abs(a["xyz"] - b["xyz"]).max() < 1e-8 and np.abs(a["pq"] - b["pq"]).max() < 1e-8
+    g.close(); o.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("K,Np,Nl,nfix,seed,iterate", [(6, 150, 30, 2, 1, 0), (8, 300, 0, 1, 2, 0), (5, 0, 60, 2, 3, 0), (10, 400, 80, 3, 4, 1), (3, 60, 12, 1, 5, 0)])
 def test_device_lba_matches_the_oracle(pkg, orc, hip, K, Np, Nl, nfix, seed, iterate):
