@@ -511,6 +511,38 @@ def test_marginalization_parity(pkg, orc, hip):
     g.close(); o.close()
 
 
+def _far_window(pkg, far):
+    """the landmarks the oldest keyframe sees, pushed out along their rays: Jacobians ~ fx / depth, so the information a view
+    gives on a landmark falls like 1 / depth^2 and its depth direction like 1 / depth^4 — through the 1e-8 threshold"""
+    w = pkg.window.make_window(6, 120, 20, imu=True, seed=31, outlier_frac=0.0)
+    P0 = w["kf"]["P"][0]
+    sp = sorted(set(w["po_pt"][w["po_kf"] == 0].tolist())); sl = sorted(set(w["lo_ln"][w["lo_kf"] == 0].tolist()))
+    w["points"][sp] = P0 + far * (w["points"][sp] - P0)
+    w["lines"][sl] = np.tile(P0, 2) + far * (w["lines"][sl] - np.tile(P0, 2))
+    return w
+
+
+def test_marginalization_structured_pinv_against_the_dense_pinv(pkg, orc, hip):
+    """VERDICT r01 item 2.  The reference thresholds the eigenvalues of the WHOLE dropped block Amm at 1e-8
+    (IMU/marginalization.cpp:351-362, the oracle does the same on the dense matrix); the device eliminates landmark blocks
+    first and thresholds block by block (plba_marg.hip).  The two agree when every discarded direction is a block-local null
+    space — any scene whose landmark depths keep the depth information above 1e-8 (with this camera and a 0.5 m baseline:
+    below ~1.4 km) — and do NOT agree when a discarded direction carries a little information and mixes the keyframe with its
+    landmarks.  This test pins both statements and records the size of the deviation."""
+    dev = {}
+    for far in (1.0, 10.0, 1e3, 1e6, 1e7):
+        w = _far_window(pkg, far)
+        g, o = _pair(pkg, orc, w)
+        pg, po = g.marginalize(0, 50), o.marginalize(0, 50)
+        g.close(); o.close()
+        assert (pg["n"], list(pg["vid"])) == (po["n"], list(po["vid"]))
+        dev[far] = np.abs(pg["Ar"] - po["Ar"]).max() / np.abs(po["Ar"]).max()
+    # realistic depths (7 m, 70 m) and the all-null case (7e7 m: every far direction is below the threshold in both): parity
+    assert dev[1.0] < 1e-9 and dev[10.0] < 1e-7 and dev[1e7] < 1e-9, dev
+    # 7 km and 7000 km: thresholded directions that are not block-local; measured 2.8e-2 and 3.4e-2 of max |A'| on MI355X
+    assert 1e-4 < dev[1e3] < 0.2 and 1e-4 < dev[1e6] < 0.2, dev
+
+
 def test_sliding_window_with_device_prior(pkg, orc, hip):
     """config 4 shape: BA -> device marginalization -> next BA carries the device-built prior;
     the same prior fed to the oracle must give the same poses."""
