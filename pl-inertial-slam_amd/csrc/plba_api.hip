@@ -393,7 +393,7 @@ static int prepare(plba_problem* p) {
     // Counting sort of the (landmark, observation a, observation b >= a) triples by keyframe pair, on a few host threads:
     // thread t owns a contiguous range of landmarks with about 1/T of the triples; per-thread pair counts give every thread
     // its own slice of every pair's entry range, in thread (= landmark) order, so the result is the serial one bit for bit.
-    const int NT = (E > 20000) ? 4 : 1;
+    const int NT = (E > 60000) ? 8 : (E > 20000) ? 4 : 1;
     std::vector<int> lm_cut(NT + 1, L);
     {
         std::vector<int64_t> tri(L + 1, 0);
@@ -722,6 +722,7 @@ static int prepare(plba_problem* p) {
             }
         }
     }
+    lap("chain maps + buffers");
     d.Ninv = nullptr; d.Nwork = nullptr;
     HIPCK(p, p->d_dbgbuf.alloc(64)); d.dbgbuf = p->d_dbgbuf.p; p->dd.dbgbuf = d.dbgbuf;
     if (!p->chain_ok && p->P > 0 && p->Ppad / 32 <= NINV_MAX_T) { HIPCK(p, p->d_Ninv.alloc((size_t)2 * p->Ppad * p->ld)); d.Ninv = p->d_Ninv.p; d.Nwork = d.Ninv + (size_t)p->Ppad * p->ld; }
@@ -729,42 +730,50 @@ static int prepare(plba_problem* p) {
     // by k_schur_pairs only, so the entries neither of them can make non-zero never need touching again
     d.alist = nullptr; d.nalist = 0;
     if (p->chain_ok) {
-        std::vector<int32_t> al;
+        // a bitmap over the Ppad x ld entries, read back in ascending order (was: push + sort + unique, 1.5 ms at configs[2])
         const int ld = p->ld;
-        auto add_full = [&](const std::vector<int>& dims) {
-            for (int a : dims) for (int b : dims) if (a >= 0 && b >= 0) al.push_back(a * ld + b);
+        std::vector<uint64_t> bits(((size_t)p->Ppad * ld + 63) / 64, 0);
+        auto mark = [&](int idx) { bits[(size_t)idx >> 6] |= 1ull << (idx & 63); };
+        auto add_full = [&](const int* dims, int n) {
+            for (int a = 0; a < n; ++a) { if (dims[a] < 0) continue; for (int b = 0; b < n; ++b) if (dims[b] >= 0) mark(dims[a] * ld + dims[b]); }
         };
         for (int m = 0; m < M; ++m) {   // IMU PVR edge over [PVR_i | PVR_j | Bias_i], bias edge over [Bias_i | Bias_j]
             const int ki = p->imu_i[m], kj = p->imu_j[m];
-            std::vector<int> e1, e2;
-            for (int c = 0; c < 9; ++c) e1.push_back(p->off_pvr[ki] >= 0 ? p->off_pvr[ki] + c : -1);
-            for (int c = 0; c < 9; ++c) e1.push_back(p->off_pvr[kj] >= 0 ? p->off_pvr[kj] + c : -1);
-            for (int c = 0; c < 6; ++c) { e1.push_back(p->off_bias[ki] >= 0 ? p->off_bias[ki] + c : -1); e2.push_back(p->off_bias[ki] >= 0 ? p->off_bias[ki] + c : -1); }
-            for (int c = 0; c < 6; ++c) e2.push_back(p->off_bias[kj] >= 0 ? p->off_bias[kj] + c : -1);
-            add_full(e1); add_full(e2);
+            int e1[24], e2[12];
+            for (int c = 0; c < 9; ++c) e1[c] = p->off_pvr[ki] >= 0 ? p->off_pvr[ki] + c : -1;
+            for (int c = 0; c < 9; ++c) e1[9 + c] = p->off_pvr[kj] >= 0 ? p->off_pvr[kj] + c : -1;
+            for (int c = 0; c < 6; ++c) { e1[18 + c] = e2[c] = p->off_bias[ki] >= 0 ? p->off_bias[ki] + c : -1; }
+            for (int c = 0; c < 6; ++c) e2[6 + c] = p->off_bias[kj] >= 0 ? p->off_bias[kj] + c : -1;
+            add_full(e1, 24); add_full(e2, 12);
         }
         {
             std::vector<int> pd;
             for (int a = 0; a < p->pr_nv; ++a) if (pr_off[a] >= 0) for (int c = 0; c < p->pr_size[a]; ++c) pd.push_back(pr_off[a] + c);
-            add_full(pd);
+            add_full(pd.data(), (int)pd.size());
         }
+        static const int pose6[6] = {0, 1, 2, 6, 7, 8};
         for (size_t q = 0; q < pair_i.size(); ++q) {      // the 6 x 6 blocks k_schur_pairs adds into, both mirror images
             const int oi = p->off_pvr[pair_i[q]], oj = p->off_pvr[pair_j[q]];
-            for (int r : {0, 1, 2, 6, 7, 8}) for (int c : {0, 1, 2, 6, 7, 8}) { al.push_back((oi + r) * ld + oj + c); al.push_back((oj + c) * ld + oi + r); }
+            for (int r : pose6) for (int c : pose6) { mark((oi + r) * ld + oj + c); mark((oj + c) * ld + oi + r); }
         }
         if (p->world > 1) {      // a sharded run's all-reduce brings in the OTHER ranks' pair blocks: the global co-observation map
             for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
                 if (!cov[(size_t)i * K + j] || p->off_pvr[i] < 0 || p->off_pvr[j] < 0) continue;
-                for (int r : {0, 1, 2, 6, 7, 8}) for (int c : {0, 1, 2, 6, 7, 8}) al.push_back((p->off_pvr[i] + r) * ld + p->off_pvr[j] + c);
+                for (int r : pose6) for (int c : pose6) mark((p->off_pvr[i] + r) * ld + p->off_pvr[j] + c);
             }
         }
-        for (int r = 0; r < p->Ppad; ++r) al.push_back(r * ld + r);
-        std::sort(al.begin(), al.end());
-        al.erase(std::unique(al.begin(), al.end()), al.end());
+        for (int r = 0; r < p->Ppad; ++r) mark(r * ld + r);
+        std::vector<int32_t> al;
+        al.reserve(65536);
+        for (size_t wd = 0; wd < bits.size(); ++wd) {
+            uint64_t v = bits[wd];
+            while (v) { al.push_back((int32_t)(wd * 64 + __builtin_ctzll(v))); v &= v - 1; }
+        }
         HIPCK(p, p->d_alist.upload(al));
         d.alist = p->d_alist.p; d.nalist = (int)al.size();
         p->h_alist.swap(al);      // kept on the host: the staged upload reads it until the final wait, and the band measurement below
     }
+    lap("assembly list");
     // ---- structural exchange list of a sharded run (k_list_pack): every lower-triangle entry of the reduced system that can be
     // non-zero before the factorisation.  Everything else is zero on every rank and need not travel.
     d.xlist = nullptr; d.nxlist = 0;
@@ -834,7 +843,7 @@ static int prepare(plba_problem* p) {
         }
         if (ptime) fprintf(stderr, "[prepare] dense system: %d dims, %d tiles, band %d sub-diagonal tiles -> %s\n", cv.Pd, T, hbt, p->band_ok ? "banded twisted solve" : "dense path");
     }
-    lap("chain maps + buffers");
+    lap("exchange list, band");
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
     if (p->pr_nv > 0 && p->rank == 0) {
         const int n = p->pr_n;
