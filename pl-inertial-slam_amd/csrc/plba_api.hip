@@ -501,7 +501,7 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_po_uv.upload(p->po_uv)); HIPCK(p, p->d_lo_l.upload(p->lo_l)); HIPCK(p, p->d_ob_w.upload(ob_w));
     HIPCK(p, p->d_ob_kf.upload(ob_kf)); HIPCK(p, p->d_ob_slot.upload(ob_slot)); HIPCK(p, p->d_lm_start.upload(lm_start));
     HIPCK(p, p->d_level.upload(p->level)); HIPCK(p, p->d_lm_fixed.upload(p->lm_fixed));
-    HIPCK(p, p->d_ob_chi2.alloc(E)); HIPCK(p, p->d_erec.alloc(((size_t)Ep + 2 * (size_t)El) * EREC_UNIT + EREC)); HIPCK(p, p->d_depth.alloc(E));
+    HIPCK(p, p->d_ob_chi2.alloc(E)); HIPCK(p, p->d_erec.alloc(((size_t)Ep + 2 * (size_t)El) * EREC_UNIT + EREC)); HIPCK(p, p->d_erec2.alloc(((size_t)Ep + 2 * (size_t)El) * EREC_UNIT + EREC)); HIPCK(p, p->d_depth.alloc(E));
     HIPCK(p, p->d_lm_active.alloc(L));
     HIPCK(p, p->d_hll.alloc((size_t)L * 12)); HIPCK(p, p->d_bl.alloc((size_t)L * 6)); HIPCK(p, p->d_dinv.alloc((size_t)L * 12));
     HIPCK(p, p->d_tv.alloc((size_t)L * 6)); HIPCK(p, p->d_xl.alloc((size_t)L * 6));
@@ -574,7 +574,7 @@ static int prepare(plba_problem* p) {
     d.fix_q1 = p->opt.fix_line_position_jacobian;
     d.kf[0] = p->d_kf[0].p; d.kf[1] = p->d_kf[1].p; d.lm[0] = p->d_lm[0].p; d.lm[1] = p->d_lm[1].p;
     d.po_uv = p->d_po_uv.p; d.lo_l = p->d_lo_l.p; d.ob_w = p->d_ob_w.p; d.ob_kf = p->d_ob_kf.p; d.ob_slot = p->d_ob_slot.p;
-    d.ob_level = p->d_level.p; d.ob_chi2 = p->d_ob_chi2.p; d.erec = p->d_erec.p;
+    d.ob_level = p->d_level.p; d.ob_chi2 = p->d_ob_chi2.p; d.erec = p->d_erec.p; d.erec_alt = p->d_erec2.p;
     d.lm_start = p->d_lm_start.p; d.lm_fixed = p->d_lm_fixed.p;
     d.hll = p->d_hll.p; d.bl = p->d_bl.p; d.dinv = p->d_dinv.p; d.tv = p->d_tv.p; d.xl = p->d_xl.p; d.lm_active = p->d_lm_active.p;
     d.kf_off_pvr = p->d_off_pvr.p; d.kf_off_bias = p->d_off_bias.p;
@@ -904,7 +904,9 @@ static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
     if (!p->spec_lin) launch_linearize(d, p->cur, true, p->rob, owns_pose_edges(p), s);   // observations + IMU / prior edges, one launch
     p->spec_lin = false;      // else: already enqueued right behind the previous trial's k_decide (plba_optimize)
     MARK(p, 2);
-    p->assembled = launch_landmark_hll(d, p->cur, !first_iter, owns_pose_edges(p), s);
+    if (p->spec_hll) p->assembled = true;      // the accepted trial's landmark blocks + assembly ran behind its deciding launch
+    else p->assembled = launch_landmark_hll(d, p->cur, !first_iter, owns_pose_edges(p), s);
+    p->spec_hll = false;
     if (first_iter) {
         HIPCK(p, hipMemsetAsync(d.kfdiag, 0, (size_t)d.K * 6 * 8, s));
         launch_kfdiag(d, p->cur, p->world > 1, s);
@@ -1003,7 +1005,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
         p->ev_ready = true;
     }
     auto span = [&](int a, int b) -> double { float ms = 0.f; return hipEventElapsedTime(&ms, p->ev[a], p->ev[b]) == hipSuccess ? (double)ms : 0.0; };
-    p->spec_lin = false;
+    p->spec_lin = false; p->spec_hll = false;
     double fact_sampled_ms = 0.0;
     int fact_samples = 0;
     for (int it = 0; it < max_iters && !(abort_flag && *abort_flag) && ok; ++it) {
@@ -1018,24 +1020,48 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             // one GPU: the workgroup of the trial-error launch that finishes last takes the LM decision (no k_decide launch)
             const bool decide_rides = p->world <= 1 && p->opt.profile < 2;
             DecideFusion df{lp, p->d_red.p, p->d_mail, seq};
-            launch_linearize(d, trial, false, p->rob, owns_pose_edges(p), s, false, decide_rides ? &df : nullptr);
-            MARK(p, 9);
-            if (p->world > 1) {
-                launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
-                if ((rc = exchange(p, p->d_red.p, 2, 0))) return rc;
-            }
-            if (!decide_rides) launch_decide(d, lp, p->d_red.p, p->world <= 1, p->d_mail, seq, s);
-            MARK(p, 10);
-            // The next iteration's linearisation goes out NOW, gated on the decision k_decide leaves in the device control
-            // block: if the step was accepted it linearises the trial state (into the accumulators that are swapped in
-            // below), if not it returns at once and the retry goes on with the old records.  The host's reaction time
-            // (mailbox poll + enqueueing the next launches) hides behind it.
-            bool spec = false;
-            if (p->opt.profile < 2 && it + 1 < max_iters) {
+            // One GPU, not the call's last iteration: the trial is LINEARISED while it is measured (k_linearize<true> with the
+            // decision riding in its last workgroup) into the idle record table / accumulators, and its landmark blocks +
+            // assembly follow gated on that decision; acceptance swaps the tables in, rejection leaves them to be overwritten.
+            const bool jac_trial = decide_rides && it + 1 < max_iters;
+            bool spec = false, spec_hll = false, jac_sync = false;
+            if (jac_trial) {
                 DevBuf ds = d;
-                std::swap(ds.Himu, ds.Himu_alt); std::swap(ds.bimu, ds.bimu_alt); std::swap(ds.bprior, ds.bprior_alt);
-                launch_linearize(ds, trial, true, p->rob, owns_pose_edges(p), s, true);
+                std::swap(ds.Himu, ds.Himu_alt); std::swap(ds.bimu, ds.bimu_alt); std::swap(ds.bprior, ds.bprior_alt); std::swap(ds.erec, ds.erec_alt);
+                launch_linearize(ds, trial, true, p->rob, owns_pose_edges(p), s, false, &df);
+                MARK(p, 9);
+                MARK(p, 10);
+                spec_hll = launch_landmark_hll(ds, trial, true, owns_pose_edges(p), s, true);      // false: no landmarks, nothing rode
                 spec = true;
+            } else if (p->world <= 1 && it + 1 < max_iters) {
+                // the synchronous form of the same thing (profile >= 2: an event after every phase): the trial is measured by the
+                // SAME kernel instance — the two instances round chi2 differently in the last bit — then k_decide, no speculation
+                DevBuf ds = d;
+                std::swap(ds.Himu, ds.Himu_alt); std::swap(ds.bimu, ds.bimu_alt); std::swap(ds.bprior, ds.bprior_alt); std::swap(ds.erec, ds.erec_alt);
+                launch_linearize(ds, trial, true, p->rob, owns_pose_edges(p), s);
+                MARK(p, 9);
+                launch_decide(d, lp, p->d_red.p, true, p->d_mail, seq, s);
+                MARK(p, 10);
+                jac_sync = true;
+            } else {
+                launch_linearize(d, trial, false, p->rob, owns_pose_edges(p), s, false, decide_rides ? &df : nullptr);
+                MARK(p, 9);
+                if (p->world > 1) {
+                    launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
+                    if ((rc = exchange(p, p->d_red.p, 2, 0))) return rc;
+                }
+                if (!decide_rides) launch_decide(d, lp, p->d_red.p, p->world <= 1, p->d_mail, seq, s);
+                MARK(p, 10);
+                // The next iteration's linearisation goes out NOW, gated on the decision k_decide leaves in the device control
+                // block: if the step was accepted it linearises the trial state (into the accumulators that are swapped in
+                // below), if not it returns at once and the retry goes on with the old records.  The host's reaction time
+                // (mailbox poll + enqueueing the next launches) hides behind it.  (Sharded runs only: one GPU takes the paths above.)
+                if (p->opt.profile < 2 && it + 1 < max_iters) {
+                    DevBuf ds = d;
+                    std::swap(ds.Himu, ds.Himu_alt); std::swap(ds.bimu, ds.bimu_alt); std::swap(ds.bprior, ds.bprior_alt);
+                    launch_linearize(ds, trial, true, p->rob, owns_pose_edges(p), s, true);
+                    spec = true;
+                }
             }
             if (p->opt.profile >= 2) {
                 HIPCK(p, plba_stream_wait(s));        // every phase event must have completed before it is read
@@ -1062,14 +1088,19 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             rho = c.rho;
             lambda = c.lambda;
             st.trials++;
-            if (c.accepted) { p->cur ^= 1; last_chi = c.current_chi; std::swap(p->dv.Himu, p->dv.Himu_alt); std::swap(p->dv.bimu, p->dv.bimu_alt); std::swap(p->dv.bprior, p->dv.bprior_alt); p->spec_lin = spec; }
+            if (c.accepted) {
+                p->cur ^= 1; last_chi = c.current_chi;
+                std::swap(p->dv.Himu, p->dv.Himu_alt); std::swap(p->dv.bimu, p->dv.bimu_alt); std::swap(p->dv.bprior, p->dv.bprior_alt);
+                if (jac_trial || jac_sync) std::swap(p->dv.erec, p->dv.erec_alt);
+                p->spec_lin = spec || jac_sync; p->spec_hll = spec_hll;
+            }
             else if (!std::isfinite(lambda)) break;
             qmax++;
         } while (rho < 0 && qmax < lp.max_trials && !(abort_flag && *abort_flag));
         st.iterations++;
         if (qmax == lp.max_trials || rho == 0 || !std::isfinite(lambda)) { ok = false; st.stop_reason = 1; }
     }
-    p->spec_lin = false;      // an unconsumed one (abort / stop right after an accepted step) only refreshed the records of the current state
+    p->spec_lin = false; p->spec_hll = false;      // an unconsumed one (abort / stop right after an accepted step) only refreshed the records of the current state
     if (p->opt.profile == 1 && fact_samples > 0) st.ms_phase[1] = fact_sampled_ms / fact_samples * st.trials;      // sampled trials scaled to all
     if (abort_flag && *abort_flag && st.stop_reason == 0 && st.iterations < max_iters) st.stop_reason = 2;
     // trace + stats

@@ -62,6 +62,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     uint8_t* ob_level;     // E
     double* ob_chi2;       // E   cached e^T Omega e of the last evaluation pass
     double* erec;          // E x 16, indexed by ob_pos[e]
+    double* erec_alt;      // the idle record table: a trial that is linearised while it is measured writes here (swapped in on acceptance)
     const int32_t* ob_pos; // E  keyframe-major position of observation e's record
     // landmarks
     const int32_t* lm_start;  // L + 1 (unified edge index)
@@ -127,7 +128,7 @@ struct DecideFusion { LmParams lp; double* red; Mailbox* mail; unsigned long lon
 void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, hipStream_t s, bool spec = false, const DecideFusion* df = nullptr);
                                                                         // spec: gated on the device-side LM decision; df: errors-only pass that also decides
 void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, bool owns_pose_edges, hipStream_t s);
-bool launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv_assemble, bool add_lambda, hipStream_t s);
+bool launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv_assemble, bool add_lambda, hipStream_t s, bool spec = false);   // spec: gated on the device-side LM decision
 void launch_kfdiag(const DevBuf& d, int state, bool with_posediag, hipStream_t s);
 void launch_landmark_dinv(const DevBuf& d, hipStream_t s);
 void launch_assemble(const DevBuf& d, bool add_lambda, hipStream_t s);

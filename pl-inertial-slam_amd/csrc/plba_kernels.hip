@@ -102,10 +102,15 @@ DEV int quad_sum_i(int v) {
 // -------------------------------------------------------------------------------------------------
 // K1/K2: per-observation residual / Jacobian / robust weight
 // -------------------------------------------------------------------------------------------------
-template <bool JAC, int NT> DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane);
-template <bool JAC> DEV void prior_block(const DevBuf& d, int state);
+struct DecideArgs;
+// arrive != null (the trial pass with Jacobians): the block counts itself in for the LM decision as soon as its chi2 is out, and goes on
+template <bool JAC, int NT> DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane, const DecideArgs* arrive = nullptr, int nblk_edges = 0, double* s4 = nullptr);
+template <bool JAC> DEV void prior_block(const DevBuf& d, int state, const DecideArgs* arrive = nullptr, int nblk_edges = 0, double* s4a = nullptr);
 // End of a trial folded into the trial-error launch (one GPU): the workgroup that finishes last takes the LM decision
-// (decide_body = what k_decide does), so the decision is out one launch earlier.
+// (decide_body = what k_decide does), so the decision is out one launch earlier.  The trial-error launch is normally the
+// JAC = true instance: steps are accepted far more often than not, so the trial state is linearised in the same pass that
+// measures it — into the idle record table and accumulators, swapped in on acceptance — and the errors-only pass (13 us at
+// configs[2]) leaves the iteration; a rejected trial costs nothing extra, its records are simply never swapped in.
 struct DecideArgs { LmParams lp; double* red; Mailbox* mail; unsigned long long seq; int nblk_lm; int fuse; };
 DEV void decide_body(const DevBuf& d, const LmParams& lp, double* red, int fused, int nblk_edges, int nblk_lm, Mailbox* mail, unsigned long long seq, double* s4, bool coherent);
 DEV void publish(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }     // sc1: visible to a same-launch reader on another XCD
@@ -142,13 +147,14 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
 #ifdef PLBA_STAMPS_LM
         const unsigned long long t0 = __builtin_readcyclecounter();
 #endif
-        if (m < d.M) pose_edge_block<JAC, 256>(d, state, rb, m, threadIdx.x);
-        else prior_block<JAC>(d, state);
+        const DecideArgs* early = nullptr;      // (arriving right after chi2 was measured slower: the deciding block is then an IMU block whose Jacobians wait for its own decision)
+        if (m < d.M) pose_edge_block<JAC, 256>(d, state, rb, m, threadIdx.x, early, nblk_edges, s4);
+        else prior_block<JAC>(d, state, early, nblk_edges, s4);
 #ifdef PLBA_STAMPS_LM
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (JAC && threadIdx.x == 0 && (m == 0 || m == d.M / 2)) { d.dbgbuf[m == 0 ? 32 : 33] = (double)(__builtin_readcyclecounter() - t0); d.dbgbuf[m == 0 ? 34 : 35] = (double)(long long)__builtin_amdgcn_s_memrealtime(); }
 #endif
-        if (!JAC && da.fuse) trial_arrive(d, da, nblk_edges, s4);
+        if (da.fuse) trial_arrive(d, da, nblk_edges, s4);
         return;
     }
 #ifdef PLBA_STAMPS_LM
@@ -204,8 +210,8 @@ __global__ __launch_bounds__(256) void k_linearize(DevBuf d, int state, Robust r
         }
     }
     double bs = block_sum_256(rho, s4);
-    if (threadIdx.x == 0) { if (!JAC && da.fuse) publish(&d.chi_part[blockIdx.x], bs); else d.chi_part[blockIdx.x] = bs; }
-    if (!JAC && da.fuse) { trial_arrive(d, da, nblk_edges, s4); return; }
+    if (threadIdx.x == 0) { if (da.fuse) publish(&d.chi_part[blockIdx.x], bs); else d.chi_part[blockIdx.x] = bs; }
+    if (da.fuse) { trial_arrive(d, da, nblk_edges, s4); return; }
 #ifdef PLBA_STAMPS_LM
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (JAC && threadIdx.x == 0 && ((int)blockIdx.x == 0 || (int)blockIdx.x == nblk_edges / 2 || (int)blockIdx.x == nblk_edges - 1)) {
@@ -292,7 +298,8 @@ DEV void landmark_dinv_one(const DevBuf& d, int slot, const double* h, const dou
 // Blocks beyond nblk_lm (only launched together with FUSE_DINV, i.e. when lambda is already known) assemble the
 // pose-side part of the reduced system in the shadow of the landmark pass instead of in a launch of their own.
 template <bool FUSE_DINV>
-__global__ __launch_bounds__(LMB) void k_landmark_hll(DevBuf d, int state, int nblk_lm, int add_lambda) {
+__global__ __launch_bounds__(LMB) void k_landmark_hll(DevBuf d, int state, int nblk_lm, int add_lambda, int spec) {
+    if (spec && !d.ctrl->accepted) return;      // enqueued behind the deciding launch: runs only for the state that was accepted
     extern __shared__ double s_dyn[];
     double* s_kc = s_dyn;
     if ((int)blockIdx.x >= nblk_lm) { assemble_part(d, add_lambda, blockIdx.x - nblk_lm, gridDim.x - nblk_lm, threadIdx.x, LMB); return; }
@@ -1032,7 +1039,7 @@ __global__ void k_update_kf(DevBuf d, int cur, int trial) {
 // pose-side system with fp64 atomics (a handful of edges share a destination block).
 // -------------------------------------------------------------------------------------------------
 template <bool JAC, int NT>
-DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane) {
+DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane, const DecideArgs* arrive, int nblk_edges, double* s4) {
     __shared__ double sJ[9 * 24];     // [J0 | J1 | J2] row-major 9 x 24
     __shared__ double sOJ[9 * 24];
     __shared__ double sE[16];
@@ -1139,11 +1146,12 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
         if (rb.on[PLBA_EDGE_IMU_PVR]) huber(chi, rb.delta[PLBA_EDGE_IMU_PVR], r0, r1);
         if (rb.on[PLBA_EDGE_IMU_BIAS]) huber(chib, rb.delta[PLBA_EDGE_IMU_BIAS], b0, b1);
         double* co = d.imu_chi + (size_t)m * 4;
-        co[0] = chi; co[1] = chib; co[2] = r0; co[3] = b0;
+        publish(co, chi); publish(co + 1, chib); publish(co + 2, r0); publish(co + 3, b0);      // the trial pass with Jacobians: read by the last-arriving workgroup of this launch
         sW[0] = r1; sW[1] = b1;
     }
     PSTAMP(4);
     __syncthreads();     // every thread of the NT-thread block reaches every barrier
+    if (arrive) trial_arrive(d, *arrive, nblk_edges, s4);      // chi2 is out: the decision need not wait for this block's Jacobians
     const double w = sW[0], wb = sW[1];
     // OJ = w * Omega * J   (9 x 24)
     for (int t = lane; t < 9 * 24; t += NT) {
@@ -1219,7 +1227,7 @@ __global__ __launch_bounds__(256) void k_pose_edges(DevBuf d, int state, Robust 
 // K4: marginalization prior edge (one workgroup): dx, e = r0 + J0 dx, chi2 = |e|^2, g += -J0^T e.
 // Its Hessian J0^T J0 is constant and pre-scattered into Hconst at upload.
 template <bool JAC>
-DEV void prior_block(const DevBuf& d, int state) {
+DEV void prior_block(const DevBuf& d, int state, const DecideArgs* arrive, int nblk_edges, double* s4a) {
     __shared__ double s4[4];
     const int n = d.pr_n;
     for (int v = threadIdx.x; v < d.pr_nv; v += 256) {
@@ -1241,6 +1249,7 @@ DEV void prior_block(const DevBuf& d, int state) {
     if (threadIdx.x == 0) publish(&d.pr_chi[0], tot);
     if (!JAC) return;
     __syncthreads();
+    if (arrive) trial_arrive(d, *arrive, nblk_edges, s4a);
     for (int v = 0; v < d.pr_nv; ++v) {
         const int o = d.pr_off[v];
         if (o < 0) continue;
@@ -1484,7 +1493,7 @@ void launch_linearize(const DevBuf& d, int state, bool jac, const Robust& rb, bo
     if (nb + pose_blocks == 0) return;
     const size_t sh = (size_t)d.K * KFCAM_STRIDE * sizeof(double);
     DecideArgs da{};
-    if (df && !jac) { da.lp = df->lp; da.red = df->red; da.mail = df->mail; da.seq = df->seq; da.nblk_lm = d.L ? lm_blocks(d) : 0; da.fuse = 1; }
+    if (df) { da.lp = df->lp; da.red = df->red; da.mail = df->mail; da.seq = df->seq; da.nblk_lm = d.L ? lm_blocks(d) : 0; da.fuse = 1; }
     if (jac) hipLaunchKernelGGL(k_linearize<true>, dim3(nb + pose_blocks), dim3(256), sh, s, d, state, rb, nb, spec ? 1 : 0, da);
     else hipLaunchKernelGGL(k_linearize<false>, dim3(nb + pose_blocks), dim3(256), sh, s, d, state, rb, nb, 0, da);
 }
@@ -1501,7 +1510,7 @@ void launch_pose_edges(const DevBuf& d, int state, bool jac, const Robust& rb, b
 }
 // fuse_dinv_assemble: lambda is known (not the first iteration): the damped landmark inverses are formed in the same
 // pass and extra blocks assemble the pose-side system (returns true if it did, so the caller skips k_assemble)
-bool launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv_assemble, bool add_lambda, hipStream_t s) {
+bool launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv_assemble, bool add_lambda, hipStream_t s, bool spec) {
     if (!d.L) return false;
     const size_t sh = (size_t)d.K * KFCAM_STRIDE * sizeof(double);
     const int nb = lm_blocks(d);
@@ -1509,10 +1518,10 @@ bool launch_landmark_hll(const DevBuf& d, int state, bool fuse_dinv_assemble, bo
         const size_t n = (size_t)(d.Ppad + TILE) * d.ld;
         int ab = (int)((n + 4 * LMB - 1) / (4 * LMB));
         if (ab > 4096) ab = 4096;
-        hipLaunchKernelGGL(k_landmark_hll<true>, dim3(nb + ab), dim3(LMB), sh, s, d, state, nb, add_lambda ? 1 : 0);
+        hipLaunchKernelGGL(k_landmark_hll<true>, dim3(nb + ab), dim3(LMB), sh, s, d, state, nb, add_lambda ? 1 : 0, spec ? 1 : 0);
         return true;
     }
-    hipLaunchKernelGGL(k_landmark_hll<false>, dim3(nb), dim3(LMB), sh, s, d, state, nb, 0);
+    hipLaunchKernelGGL(k_landmark_hll<false>, dim3(nb), dim3(LMB), sh, s, d, state, nb, 0, 0);
     return false;
 }
 void launch_kfdiag(const DevBuf& d, int state, bool with_posediag, hipStream_t s) {

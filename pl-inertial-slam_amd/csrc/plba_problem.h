@@ -141,7 +141,8 @@ struct plba_problem {
     bool own_stream = false;
     bool ev_sample = false;    // profile = 1: this trial's factorisation span is being timed
     unsigned trial_counter = 0;
-    bool spec_lin = false;     // the next iteration's linearisation is already in the stream (enqueued behind k_decide)
+    bool spec_lin = false;
+    bool spec_hll = false;     // ... and so are its landmark blocks and the pose-side assembly     // the next iteration's linearisation is already in the stream (enqueued behind k_decide)
     // ---- host copy of the uploaded graph -------------------------------------------------------
     bool have_cam = false;
     double fx, fy, cx, cy, Rbc[9], Pbc[3], gw[3] = {0, 0, 0};
@@ -173,7 +174,7 @@ struct plba_problem {
     int cur = 0;                          // index of the current estimate buffers
     // ---- device ----------------------------------------------------------------------------------
     plba::DArr<double> d_kf[2], d_kf_saved, d_lm[2], d_lm_saved;
-    plba::DArr<double> d_po_uv, d_lo_l, d_ob_w, d_ob_chi2, d_erec;
+    plba::DArr<double> d_po_uv, d_lo_l, d_ob_w, d_ob_chi2, d_erec, d_erec2;
     plba::DArr<int32_t> d_ob_kf, d_ob_slot, d_lm_start, d_off_pvr, d_off_bias;
     plba::DArr<uint8_t> d_level, d_lm_fixed, d_lm_active, d_depth;
     plba::DArr<double> d_hll, d_bl, d_dinv, d_tv, d_xl;
