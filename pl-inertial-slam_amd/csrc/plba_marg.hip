@@ -356,9 +356,136 @@ MDEV void jacobi_lds(double* G, double* V, int n, double tol, double noise2, int
         __syncthreads();
     }
 }
+// ---- two-sided (classical) Jacobi, all rotations of a round at once -----------------------------------------------------------
+// A (n x n symmetric, leading dimension lda — odd, so that the row phase walks distinct LDS banks) and V (n x n, starts as I)
+// live in LDS.  A round of the round-robin schedule holds n/2 disjoint pairs, one HALF-wave each: (0) c, s from a_pp, a_qq, a_pq —
+// three scalars, no dot products, which is what the one-sided method spends its time on; (1) its column pair of A and V;
+// barrier; (2) its row pair of A; barrier.  A pair is left alone
+// when |a_pq| <= tol sqrt(|a_pp a_qq|) or |a_pq| <= delta = 8 macheps |A|_F (the absolute rounding every entry carries after a few
+// hundred rotations).  On exit the eigenvalues are the diagonal of A, the eigenvectors the columns of V.
+// The reference's SelfAdjointEigenSolver (tridiagonal QR) has the same absolute accuracy, macheps |A|.
+// 1 / sqrt(x) for a normal positive x: v_rsq_f64 (~ single precision) + two Newton steps; the library routine's range handling
+// is not needed here and costs a third of a round
+MDEV double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    y = y * fma(-hx * y, y, 1.5);
+    return y;
+}
+MDEV void jacobi2_lds(double* A, int lda, double* V, int n, double tol, double delta, int max_sweeps, int* s_rot, double* dbg = nullptr) {
+    if (n < 2) return;
+    const int lane = threadIdx.x & 63, hl = lane & 31, nh = (blockDim.x >> 6) * 2, half = (threadIdx.x >> 6) * 2 + (lane >> 5);
+    const double tol2 = tol * tol;
+    constexpr int MAXIT = 2;      // pairs a half-wave owns per round: 64 pairs / 32 halves (1024 threads), 8 / 8 (256 threads, n <= 16)
+    __shared__ int s_perm[128], s_live;
+    __shared__ unsigned char s_lf[128];
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        // Columns that are already decoupled — every off-diagonal entry at the floor: the exactly zero velocity columns of keyframes
+        // no selected factor constrains, and, sweep after sweep, whatever has converged — leave the schedule; a round costs two
+        // workgroup barriers however few of its pairs rotate, so the sweeps shrink with the live set (60 -> 39 -> ... at configs[3])
+        if (threadIdx.x == 0) s_live = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            const double ajj = fabs(A[(size_t)j * lda + j]);
+            bool live = false;
+            for (int k = 0; k < n; ++k) {
+                const double v = A[(size_t)k * lda + j];
+                if (k != j && v != 0.0 && fabs(v) > delta && v * v > tol2 * ajj * fabs(A[(size_t)k * lda + k])) { live = true; break; }
+            }
+            s_lf[j] = live ? 1 : 0;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {      // live columns in index order (deterministic)
+            if (!s_lf[j]) continue;
+            int rank = 0;
+            for (int k = 0; k < j; ++k) rank += s_lf[k];
+            s_perm[rank] = j;
+            atomicAdd(&s_live, 1);
+        }
+        __syncthreads();
+        const int nl = s_live;
+        if (dbg && threadIdx.x == 0 && sweep < 40) dbg[sweep] = (double)nl;
+        if (threadIdx.x == 0) *s_rot = nl;
+        if (nl < 2) break;
+        const int npad = (nl & 1) ? nl + 1 : nl, mm = npad - 1, npairs = npad / 2;
+        // this half-wave's pairs follow a recurrence over the rounds: p and q of pair i advance by one modulo mm (pair 0 keeps index mm)
+        int pr[MAXIT], qr[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) { const int i = it * nh + half; pr[it] = (i == 0) ? mm : i % mm; qr[it] = (i == 0) ? 0 : (mm - i % mm) % mm; }
+        for (int round = 0; round < mm; ++round) {
+            int pp[MAXIT], qq[MAXIT];
+            double cc[MAXIT], ss[MAXIT];
+            // (0) + (1): a half-wave per pair takes c, s from a_pp, a_qq, a_pq (every lane the same three reads) and rotates its two
+            // columns of A and of V at once: no other pair's rotation touches these columns or those three entries in this phase
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int i = it * nh + half;
+                int p = pr[it], q = qr[it];
+                if (p > q) { const int t = p; p = q; q = t; }
+                if (i >= npairs || q >= nl) q = -1;      // no such pair / padding index: bye
+                else { p = s_perm[p]; q = s_perm[q]; }
+                double c = 1.0, sn = 0.0;
+                if (q >= 0) {
+                    const double app = A[(size_t)p * lda + p], aqq = A[(size_t)q * lda + q], apq = A[(size_t)q * lda + p];
+                    if (apq != 0.0 && apq * apq > tol2 * fabs(app * aqq) && fabs(apq) > delta) {
+                        // tan(theta) = sign(a b) |b| / (|a| + h), a = a_qq - a_pp, b = 2 a_pq, h = hypot(a, b)
+                        //   =>  c = (|a| + h) r,  s = sign(a b) |b| r,  r = 1 / sqrt(2 h (h + |a|)):  two reciprocal square roots, no division
+                        const double a = aqq - app, bb = 2.0 * apq, fa = fabs(a);
+                        const double h2 = fma(a, a, bb * bb);
+                        const double h = h2 * rsqrt_nr(h2);
+                        const double r = rsqrt_nr(2.0 * h * (h + fa));
+                        c = (fa + h) * r;
+                        sn = ((a * bb >= 0.0) ? fabs(bb) : -fabs(bb)) * r;
+                    }
+                }
+                pp[it] = p; qq[it] = q; cc[it] = c; ss[it] = sn;
+                if (q >= 0 && sn != 0.0) {
+                    double* ap = A + (size_t)p * lda; double* aq = A + (size_t)q * lda;
+                    double* vp = V + (size_t)p * n; double* vq = V + (size_t)q * n;
+                    for (int r = hl; r < n; r += 32) {
+                        const double x = ap[r], y = aq[r], u = vp[r], w = vq[r];
+                        ap[r] = c * x - sn * y; aq[r] = sn * x + c * y;
+                        vp[r] = c * u - sn * w; vq[r] = sn * u + c * w;
+                    }
+                }
+                // next round's pair: both members advance by one modulo mm (pair 0: only its second member)
+                if (i == 0) { qr[it] = (qr[it] + 1 == mm) ? 0 : qr[it] + 1; }
+                else { pr[it] = (pr[it] + 1 == mm) ? 0 : pr[it] + 1; qr[it] = (qr[it] + 1 == mm) ? 0 : qr[it] + 1; }
+            }
+            __syncthreads();
+            // (2) the same half-waves rotate their two ROWS of A (every column was touched by some pair in (1): hence the barrier)
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int p = pp[it], q = qq[it];
+                const double c = cc[it], sn = ss[it];
+                if (q >= 0 && sn != 0.0) {
+                    for (int k = hl; k < n; k += 32) {
+                        double* col = A + (size_t)k * lda;
+                        const double x = col[p], y = col[q];
+                        col[p] = c * x - sn * y; col[q] = sn * x + c * y;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+MDEV double jacobi2_delta(const double* A, int lda, int n, double* s_part) {      // 8 macheps |A|_F  (call with the whole workgroup)
+    double f = 0.0;
+    for (int t = threadIdx.x; t < n * n; t += blockDim.x) { const double v = A[(size_t)(t / n) * lda + t % n]; f += v * v; }
+    f = wave_sum(f);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = f;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_part[w];
+    __syncthreads();
+    return 8.0 * 1.1102230246251565e-16 * sqrt(tot);
+}
 // |g_p . g_q| <= JACOBI_TOL |g_p| |g_q| counts as orthogonal: an n-term fp64 dot product carries ~ n * 1.1e-16 of relative
 // rounding, so 1e-15 (round 1) was never reached and every call ran all its sweeps; 1e-13 leaves eigenvalues good to ~1e-13
 constexpr double JACOBI_TOL = 1e-13;
+constexpr double JACOBI2_TOL = 1e-15;     // two-sided: |a_pq| against sqrt(|a_pp a_qq|), three exact scalars — no dot-product rounding to stay above
 // 2 delta^2 of the comment above, from the Frobenius norm of the n x n matrix held in G (call with the whole workgroup)
 MDEV double jacobi_noise2(const double* G, int n, double* s_part) {
     double f = 0.0;
@@ -384,10 +511,10 @@ __global__ __launch_bounds__(256) void k_pose_pinv(const double* A, int pos, int
     }
     __shared__ double s_part[16];
     __syncthreads();
-    const double noise2 = jacobi_noise2(G, sz, s_part);
-    jacobi_lds(G, V, sz, JACOBI_TOL, noise2, 40, &rot);
+    const double delta = jacobi2_delta(G, sz, sz, s_part);
+    jacobi2_lds(G, sz, V, sz, JACOBI2_TOL, delta, 40, &rot);
     __syncthreads();
-    if ((int)threadIdx.x < sz) { double l = 0.0; for (int t = 0; t < sz; ++t) l += V[threadIdx.x * sz + t] * G[threadIdx.x * sz + t]; lam[threadIdx.x] = l; }
+    if ((int)threadIdx.x < sz) lam[threadIdx.x] = G[threadIdx.x * sz + threadIdx.x];
     __syncthreads();
     for (int t = threadIdx.x; t < sz * sz; t += blockDim.x) {
         const int i = t / sz, j = t % sz;
@@ -400,27 +527,29 @@ __global__ __launch_bounds__(256) void k_pose_pinv(const double* A, int pos, int
 // outp = [Ar n*n | br n | J0 n*n | r0 n]
 __global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const double* b, int pos, int m, int n, double eps, double* outp, double* dbg) {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    double* G = s_dyn; double* V = s_dyn + (size_t)n * n;
+    const int lda = n | 1;
+    double* G = s_dyn; double* V = s_dyn + (size_t)n * lda;
     __shared__ int rot;
     double* Ar = outp; double* br = outp + (size_t)n * n; double* J0 = br + n; double* r0 = J0 + (size_t)n * n;
     for (int t = threadIdx.x; t < n * n; t += blockDim.x) {
         const int c = t / n, r = t % n;
         const double v = 0.5 * (A[(size_t)(m + r) * pos + m + c] + A[(size_t)(m + c) * pos + m + r]);
-        G[t] = v; Ar[t] = v; V[t] = (r == c) ? 1.0 : 0.0;
+        G[(size_t)c * lda + r] = v; Ar[t] = v; V[t] = (r == c) ? 1.0 : 0.0;
     }
     for (int t = threadIdx.x; t < n; t += blockDim.x) br[t] = b[m + t];
     __shared__ double s_part[16];
     __syncthreads();
-    const double noise2 = jacobi_noise2(G, n, s_part);
-    if (dbg && threadIdx.x == 0) { for (int q = 0; q < 48; ++q) dbg[q] = -1.0; dbg[40] = noise2; }
-    jacobi_lds(G, V, n, JACOBI_TOL, noise2, 30, &rot, dbg);
+    const double delta = jacobi2_delta(G, lda, n, s_part);
+    if (dbg && threadIdx.x == 0) { for (int q = 0; q < 48; ++q) dbg[q] = -1.0; dbg[40] = delta; }
+    jacobi2_lds(G, lda, V, n, JACOBI2_TOL, delta, 40, &rot, dbg);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int j = wave; j < n; j += nw) {
-        const double* g = G + (size_t)j * n; const double* v = V + (size_t)j * n;
-        double l = 0.0, vb = 0.0;
-        for (int t = lane; t < n; t += 64) { l += v[t] * g[t]; vb += v[t] * b[m + t]; }
-        l = wave_sum(l); vb = wave_sum(vb);
+        const double* v = V + (size_t)j * n;
+        const double l = G[(size_t)j * lda + j];
+        double vb = 0.0;
+        for (int t = lane; t < n; t += 64) vb += v[t] * b[m + t];
+        vb = wave_sum(vb);
         const double S = l > eps ? l : 0.0, Si = l > eps ? 1.0 / l : 0.0;
         const double ss = sqrt(S);
         for (int c = lane; c < n; c += 64) J0[(size_t)c * n + j] = ss * v[c];
@@ -622,9 +751,9 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
     // (4) eigen square root of the kept block
     double* oAr = dOut.p; double* obr = oAr + (size_t)n * n; double* oJ0 = obr + n; double* or0 = oJ0 + (size_t)n * n;
     if (n <= JLDS_MAX_N) {
-        const size_t sh = 2 * (size_t)n * n * sizeof(double);
+        const size_t sh = ((size_t)n * (n | 1) + (size_t)n * n) * sizeof(double);
         static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_marg_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * JLDS_MAX_N * JLDS_MAX_N * sizeof(double))); attr_set = true; }
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_marg_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * JLDS_MAX_N * JLDS_MAX_N + JLDS_MAX_N) * sizeof(double))); attr_set = true; }
         hipLaunchKernelGGL(k_marg_finish, dim3(1), dim3(1024), sh, s, dA.p, db.p, pos, m, n, eps, dOut.p, d.dbgbuf);
     } else {
         // larger kept blocks: G and V in HBM, one launch per round, convergence checked on the host once per sweep
