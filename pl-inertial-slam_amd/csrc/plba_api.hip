@@ -13,7 +13,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 
 #include "plba_problem.h"
 
@@ -338,6 +341,63 @@ int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double
 // =================================================================================================
 // structure + device image
 // =================================================================================================
+// A few persistent host threads for the structure build: spawning std::threads per call cost more than the work they
+// did (8 threads were no faster than 4).  Workers sleep on a condition variable between jobs; run(n, f) executes f(0..n-1)
+// with the caller taking index 0.
+namespace {
+class HostPool {
+public:
+    static HostPool& get() { static HostPool p; return p; }
+    void run(int n, const std::function<void(int)>& f) {
+        if (n <= 1) { f(0); return; }
+        std::lock_guard<std::mutex> serial(run_m_);      // one job at a time (problems on different host threads)
+        ensure(n - 1);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &f; njobs_ = n; next_ = 1; pending_ = n - 1; ++gen_;
+        }
+        cv_.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+private:
+    void ensure(int workers) {
+        while ((int)th_.size() < workers) th_.emplace_back([this] { loop(); });
+    }
+    void loop() {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return stop_ || (gen_ != seen && next_ < njobs_); });
+            if (stop_) return;
+            seen = gen_;
+            while (next_ < njobs_) {
+                const int i = next_++;
+                const std::function<void(int)>* f = job_;
+                lk.unlock();
+                (*f)(i);
+                lk.lock();
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_, run_m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* job_ = nullptr;
+    int njobs_ = 0, next_ = 0, pending_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
+}  // namespace
+
 static int prepare(plba_problem* p) {
     if (!p->dirty) return PLBA_OK;
     if (!p->have_cam || !p->K) FAIL(p, PLBA_ERR_STATE, "camera and keyframes must be set before optimize");
@@ -419,12 +479,7 @@ static int prepare(plba_problem* p) {
                 }
             }
     };
-    {
-        std::vector<std::thread> th;
-        for (int t = 1; t < NT; ++t) th.emplace_back(count_range, t);
-        count_range(0);
-        for (auto& x : th) x.join();
-    }
+    HostPool::get().run(NT, count_range);
     std::vector<int32_t> pair_i, pair_j, pair_start;
     std::vector<std::vector<int64_t>> tpos(NT, std::vector<int64_t>((size_t)K * K, -1));
     int64_t nent = 0;
@@ -440,7 +495,13 @@ static int prepare(plba_problem* p) {
         }
     if (nent > 0x7fffffff) FAIL(p, PLBA_ERR_INVALID, "too many Schur pair entries");
     pair_start.push_back((int32_t)nent);
-    std::vector<int32_t> ent_ei((size_t)nent), ent_ej((size_t)nent), ent_slot((size_t)nent);
+    // the three entry arrays are built straight in the pinned staging area when it has room (3 x 4 bytes x 317 k entries at
+    // configs[2]: no pageable copy, no second pass over them)
+    std::vector<int32_t> ent_ei_v, ent_ej_v, ent_slot_v;
+    int32_t* ent_ei = (int32_t*)stage_take((size_t)nent * 4); int32_t* ent_ej = ent_ei ? (int32_t*)stage_take((size_t)nent * 4) : nullptr;
+    int32_t* ent_slot = ent_ej ? (int32_t*)stage_take((size_t)nent * 4) : nullptr;
+    const bool ent_staged = ent_slot != nullptr;
+    if (!ent_staged) { ent_ei_v.resize((size_t)nent); ent_ej_v.resize((size_t)nent); ent_slot_v.resize((size_t)nent); ent_ei = ent_ei_v.data(); ent_ej = ent_ej_v.data(); ent_slot = ent_slot_v.data(); }
     auto fill_range = [&](int t) {
         int64_t* pos = tpos[t].data();
         for (int s = lm_cut[t]; s < lm_cut[t + 1]; ++s)
@@ -457,12 +518,7 @@ static int prepare(plba_problem* p) {
                 }
             }
     };
-    {
-        std::vector<std::thread> th;
-        for (int t = 1; t < NT; ++t) th.emplace_back(fill_range, t);
-        fill_range(0);
-        for (auto& x : th) x.join();
-    }
+    HostPool::get().run(NT, fill_range);
     // Co-observation structure of the keyframes: which pose x pose blocks of the reduced system the landmarks' Schur terms can
     // touch.  A sharded run needs the UNION over the ranks (each holds the pairs of its own landmarks only): one all-reduce
     // (max) of a K x K map per upload, after which every rank derives the same assembly / exchange lists and band.
@@ -541,7 +597,8 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_ch_meta.upload(ch_meta));
     HIPCK(p, p->d_schur_part.alloc(ch_meta.size() * 48)); HIPCK(p, p->d_pair_cnt.alloc(ch_meta.size()));
     HIPCK(p, p->d_pair_i.upload(pair_i)); HIPCK(p, p->d_pair_j.upload(pair_j)); HIPCK(p, p->d_pair_start.upload(pair_start));
-    HIPCK(p, p->d_ent_pi.upload(ent_ei)); HIPCK(p, p->d_ent_pj.upload(ent_ej)); HIPCK(p, p->d_ent_slot.upload(ent_slot)); HIPCK(p, p->d_ob_pos.upload(p->ob_pos));
+    if (ent_staged) { HIPCK(p, p->d_ent_pi.upload_staged(ent_ei, (size_t)nent)); HIPCK(p, p->d_ent_pj.upload_staged(ent_ej, (size_t)nent)); HIPCK(p, p->d_ent_slot.upload_staged(ent_slot, (size_t)nent)); }
+    else { HIPCK(p, p->d_ent_pi.upload(ent_ei_v)); HIPCK(p, p->d_ent_pj.upload(ent_ej_v)); HIPCK(p, p->d_ent_slot.upload(ent_slot_v)); } HIPCK(p, p->d_ob_pos.upload(p->ob_pos));
     HIPCK(p, p->d_imu_i.upload(p->imu_i)); HIPCK(p, p->d_imu_j.upload(p->imu_j)); HIPCK(p, p->d_imu_pre.upload(p->imu_pre));
     HIPCK(p, p->d_imu_ipvr.upload(p->imu_ipvr)); HIPCK(p, p->d_imu_ibias.upload(p->imu_ibias));
     HIPCK(p, p->d_imu_err.alloc((size_t)M * 16)); HIPCK(p, p->d_imu_chi.alloc((size_t)M * 4));

@@ -782,7 +782,7 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
     {
         StageArea* st = darr_stage();
         const size_t need = (nout + nkf) * sizeof(double), at = st ? ((st->used + 255) & ~(size_t)255) : 0;
-        if (st && st->base && at + need <= st->cap) hres = (double*)(st->base + at);
+        if (st && st->base && at + need <= st->upload_cap()) hres = (double*)(st->base + at);
         else { pageable.resize(nout + nkf); hres = pageable.data(); }
     }
     PLBA_HIPCK(p, hipMemcpyAsync(hres, dOut.p, nout * 8, hipMemcpyDeviceToHost, s));

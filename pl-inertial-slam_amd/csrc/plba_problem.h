@@ -62,7 +62,15 @@ inline hipStream_t& darr_stream() { static thread_local hipStream_t s = nullptr;
 // pinned staging area the queued uploads go through (host vector -> staging by memcpy, staging -> device by an async
 // copy): pageable sources make the runtime pin / stage on its own, which was measured at ~20 ms per BA call as soon as a
 // second problem is alive in the process.  Bump-allocated; valid until the owner has synchronised the stream.
-struct StageArea { char* base = nullptr; size_t cap = 0, used = 0; };
+// [0, cap - XFER): bump-allocated by the queued uploads of one DArrStreamScope; [cap - XFER, cap): bounce buffer of the blocking
+// plba_d2h / plba_h2d copies, which may run while queued uploads are still waiting for their turn on the stream
+struct StageArea {
+    char* base = nullptr; size_t cap = 0, used = 0;
+    static constexpr size_t XFER = (size_t)4 << 20;
+    size_t upload_cap() const { return cap > XFER ? cap - XFER : 0; }
+    char* xfer() const { return base + upload_cap(); }
+    size_t xfer_cap() const { return cap - upload_cap(); }
+};
 inline StageArea*& darr_stage() { static thread_local StageArea* a = nullptr; return a; }
 struct DArrStreamScope {
     hipStream_t prev;
@@ -70,6 +78,16 @@ struct DArrStreamScope {
     explicit DArrStreamScope(hipStream_t s, StageArea* st = nullptr) : prev(darr_stream()), prev_stage(darr_stage()) { darr_stream() = s; darr_stage() = st; if (st) st->used = 0; }
     ~DArrStreamScope() { darr_stream() = prev; darr_stage() = prev_stage; }
 };
+
+// a block of the current staging area to build an upload in place (null: no staging area, or full)
+inline void* stage_take(size_t bytes) {
+    StageArea* st = darr_stage();
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (!darr_stream() || !st || !st->base || st->used + need > st->upload_cap()) return nullptr;
+    void* r = st->base + st->used;
+    st->used += need;
+    return r;
+}
 
 template <class T>
 struct DArr {
@@ -103,7 +121,7 @@ struct DArr {
         if (hipStream_t s = darr_stream()) {
             StageArea* st = darr_stage();
             const size_t need = (bytes + 255) & ~(size_t)255;
-            if (st && st->base && st->used + need <= st->cap) {
+            if (st && st->base && st->used + need <= st->upload_cap()) {
                 char* src = st->base + st->used;
                 st->used += need;
                 memcpy(src, h.data(), bytes);
@@ -112,6 +130,12 @@ struct DArr {
             return hipMemcpyAsync(p, h.data(), bytes, hipMemcpyHostToDevice, s);
         }
         return hipMemcpy(p, h.data(), bytes, hipMemcpyHostToDevice);
+    }
+    // `src` already lives in the pinned staging area (stage_take below): one asynchronous copy, no host-side memcpy
+    hipError_t upload_staged(const T* src, size_t cnt) {
+        hipError_t e = alloc(cnt, cnt == 0);
+        if (e != hipSuccess || cnt == 0) return e;
+        return hipMemcpyAsync(p, src, cnt * sizeof(T), hipMemcpyHostToDevice, darr_stream());
     }
     void release() { if (p) dev_pool().put(p, cls); p = nullptr; n = 0; cls = 0; }
     DArr() = default;
@@ -245,24 +269,24 @@ inline hipError_t plba_stream_wait(hipStream_t s, double spin_ms = 50.0) {
 inline hipError_t plba_d2h(plba_problem* p, void* dst, const void* src_dev, size_t bytes) {
     if (!bytes) return hipSuccess;
     plba::StageArea* st = p->have_ctx ? p->ctx.stage : nullptr;
-    if (!st || !st->base || !st->cap) { hipError_t e = hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, p->stream); return e != hipSuccess ? e : plba_stream_wait(p->stream); }
-    for (size_t off = 0; off < bytes; off += st->cap) {
-        const size_t n = std::min(st->cap, bytes - off);
-        hipError_t e = hipMemcpyAsync(st->base, (const char*)src_dev + off, n, hipMemcpyDeviceToHost, p->stream);
+    if (!st || !st->base || !st->xfer_cap()) { hipError_t e = hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, p->stream); return e != hipSuccess ? e : plba_stream_wait(p->stream); }
+    for (size_t off = 0; off < bytes; off += st->xfer_cap()) {
+        const size_t n = std::min(st->xfer_cap(), bytes - off);
+        hipError_t e = hipMemcpyAsync(st->xfer(), (const char*)src_dev + off, n, hipMemcpyDeviceToHost, p->stream);
         if (e == hipSuccess) e = plba_stream_wait(p->stream);
         if (e != hipSuccess) return e;
-        memcpy((char*)dst + off, st->base, n);
+        memcpy((char*)dst + off, st->xfer(), n);
     }
     return hipSuccess;
 }
 inline hipError_t plba_h2d(plba_problem* p, void* dst_dev, const void* src, size_t bytes) {
     if (!bytes) return hipSuccess;
     plba::StageArea* st = p->have_ctx ? p->ctx.stage : nullptr;
-    if (!st || !st->base || !st->cap) { hipError_t e = hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, p->stream); return e != hipSuccess ? e : plba_stream_wait(p->stream); }
-    for (size_t off = 0; off < bytes; off += st->cap) {
-        const size_t n = std::min(st->cap, bytes - off);
-        memcpy(st->base, (const char*)src + off, n);
-        hipError_t e = hipMemcpyAsync((char*)dst_dev + off, st->base, n, hipMemcpyHostToDevice, p->stream);
+    if (!st || !st->base || !st->xfer_cap()) { hipError_t e = hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, p->stream); return e != hipSuccess ? e : plba_stream_wait(p->stream); }
+    for (size_t off = 0; off < bytes; off += st->xfer_cap()) {
+        const size_t n = std::min(st->xfer_cap(), bytes - off);
+        memcpy(st->xfer(), (const char*)src + off, n);
+        hipError_t e = hipMemcpyAsync((char*)dst_dev + off, st->xfer(), n, hipMemcpyHostToDevice, p->stream);
         if (e == hipSuccess) e = plba_stream_wait(p->stream);
         if (e != hipSuccess) return e;
     }
