@@ -870,14 +870,17 @@ static int prepare(plba_problem* p) {
         HIPCK(p, p->d_xlist.upload(xl));
         d.xlist = p->d_xlist.p; d.nxlist = (int)xl.size();
     }
-    // ---- banded twisted solve (plba_band.hip): measure the band of the compact dense system from the structure ----------------
-    p->band_ok = false;
-    p->dd.band = 0;
+    // ---- band of the compact dense system, measured from the structure; two ways to use it -------------------------------------
+    //   T >= 24 tiles: the two-ended sweep inside LDS (plba_band.hip, two workgroups, two launches)
+    //   8 <= T < 24  : the two-ended ("twin") form of the multi-launch factorisation (plba_dense.hip): same kernels, the two ends
+    //                  of the band eliminated side by side in each launch
+    p->band_ok = false; p->twin_ok = false;
+    p->dd.band = 0; p->dd.twin_nA = 0; p->dd.twin_nB = 0; p->dd.perm = nullptr; p->dd.xmap = nullptr; p->dd.alt = nullptr;
     if (p->chain_ok && p->opt.band_solve && !p->dv.flow && !p->dv.wide) {      // (sharded runs: the lists above hold the GLOBAL structure)
         const ChainView& cv = p->cv;
         const int T = cv.Pdpad / 32;
         int hbt = 0;
-        if (T >= (p->opt.band_solve >= 2 ? 8 : BAND_MIN_TILES) && band_lds_bytes(cv.Pdpad) <= 160 * 1024) {      // band_solve = 2 (tests): any system of >= 8 tiles
+        if (T >= 8) {
             const std::vector<int32_t>& hpidx = p->h_pidx; const std::vector<int32_t>& hsegcol = p->h_seg_col;
             std::vector<int32_t> dense_of(p->ld, -1);
             for (int c = 0; c < cv.Pd; ++c) dense_of[hpidx[c]] = c;
@@ -888,7 +891,7 @@ static int prepare(plba_problem* p) {
                 if (r >= 0 && c >= 0) hbt = std::max(hbt, std::abs(r / 32 - c / 32));
             }
             for (int g = 0; g < cv.nseg; ++g) if (hsegcol[2 * g + 1] > hsegcol[2 * g]) hbt = std::max(hbt, (hsegcol[2 * g + 1] - 1) / 32 - hsegcol[2 * g] / 32);
-            if (hbt <= BAND_HB) {
+            if (T >= (p->opt.band_solve >= 2 ? 8 : BAND_MIN_TILES) && band_lds_bytes(cv.Pdpad) <= 160 * 1024 && hbt <= BAND_HB) {      // band_solve = 2 (tests): in LDS from 8 tiles on
                 BandView& bv = p->bandv;
                 bv.T = T; bv.nA = (T - BAND_HB) / 2; bv.nB = T - BAND_HB - bv.nA;
                 HIPCK(p, p->d_band_L.alloc((size_t)2 * T * 4 * 1024, false)); HIPCK(p, p->d_band_y.alloc((size_t)2 * cv.Pdpad, false));
@@ -896,9 +899,52 @@ static int prepare(plba_problem* p) {
                 bv.Lband = p->d_band_L.p; bv.y = p->d_band_y.p; bv.mid = p->d_band_mid.p;
                 p->band_ok = true;
                 p->dd.band = 1;
+            } else if (p->opt.band_solve == 1 && p->dd.Ninv && hbt >= 1) {
+                // chains of nC tiles each; the middle keeps >= hbt tiles so that the last top tile and the first bottom tile do not couple
+                const int nC = (T - hbt) / 2;
+                if (nC >= 2) {
+                    TwinView& tv = p->twinv;
+                    tv.T = T; tv.nA = nC; tv.nB = nC;
+                    const int m0 = tv.nA + tv.nB, n32 = cv.Pdpad;
+                    std::vector<int32_t> perm(n32), xmap(n32);
+                    for (int i = 0; i < n32; ++i) {
+                        int pi;
+                        if (i < tv.nA * 32) pi = i;
+                        else if (i >= (T - tv.nB) * 32) pi = tv.nA * 32 + (T * 32 - 1 - i);
+                        else pi = m0 * 32 + (i - tv.nA * 32);
+                        perm[i] = pi; xmap[pi] = i;
+                    }
+                    std::vector<TwinTile> list;
+                    tv.off.assign(1, 0);
+                    auto add_chain = [&](int k, int c_lo, int c_hi, int aj_lo, bool is_b, bool last) {      // chain tiles (c_lo, c_hi) after pivot k, then the middle
+                        std::vector<int> S;
+                        for (int c = c_lo; c < c_hi; ++c) S.push_back(c);
+                        for (int c = m0; c < T; ++c) S.push_back(c);
+                        for (size_t a = 0; a < S.size(); ++a)
+                            for (size_t b2 = 0; b2 <= a; ++b2) {
+                                const int r = S[a], c = S[b2];
+                                TwinTile e; e.r = (int16_t)r; e.c = (int16_t)c; e.aj = -1;
+                                e.flags = (int16_t)((is_b && r >= m0 && c >= m0 ? 1 : 0) | ((last && r == k + 1) ? 2 : 0) | (c == S[0] ? 4 : 0));
+                                list.push_back(e);
+                            }
+                        for (int c : S) { TwinTile e; e.r = (int16_t)T; e.c = (int16_t)c; e.aj = -1; e.flags = (int16_t)((is_b && c >= m0 ? 1 : 0) | (c == S[0] ? 4 : 0)); list.push_back(e); }
+                        for (int aj = aj_lo; aj <= k; ++aj) for (int c : S) { TwinTile e; e.r = (int16_t)T; e.c = (int16_t)c; e.aj = (int16_t)aj; e.flags = (int16_t)(c == S[0] ? 4 : 0); list.push_back(e); }
+                    };
+                    for (int t = 0; t < std::max(tv.nA, tv.nB); ++t) {
+                        if (t < tv.nA) add_chain(t, t + 1, tv.nA, 0, false, t == tv.nA - 1);
+                        tv.off.push_back((int)list.size());
+                        if (t < tv.nB) add_chain(tv.nA + t, tv.nA + t + 1, m0, tv.nA, true, t == tv.nB - 1);
+                        tv.off.push_back((int)list.size());
+                    }
+                    HIPCK(p, p->d_twin_list.upload(list)); HIPCK(p, p->d_twin_perm.upload(perm)); HIPCK(p, p->d_twin_xmap.upload(xmap));
+                    HIPCK(p, p->d_twin_alt.alloc((size_t)(cv.Pdpad + TILE) * cv.Pdpad));
+                    tv.list = p->d_twin_list.p;
+                    p->dd.twin_nA = tv.nA; p->dd.twin_nB = tv.nB; p->dd.perm = p->d_twin_perm.p; p->dd.xmap = p->d_twin_xmap.p; p->dd.alt = p->d_twin_alt.p;
+                    p->twin_ok = true;
+                }
             }
         }
-        if (ptime) fprintf(stderr, "[prepare] dense system: %d dims, %d tiles, band %d sub-diagonal tiles -> %s\n", cv.Pd, T, hbt, p->band_ok ? "banded twisted solve" : "dense path");
+        if (ptime) fprintf(stderr, "[prepare] dense system: %d dims, %d tiles, band %d sub-diagonal tiles -> %s\n", cv.Pd, T, hbt, p->band_ok ? "banded twisted solve in LDS" : p->twin_ok ? "twin multi-launch factorisation" : "dense path");
     }
     lap("exchange list, band");
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
@@ -1018,6 +1064,10 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
         if (p->band_ok) {
             launch_band_solve(p->dd, p->bandv, s);      // factorisation, forward and backward substitution: two launches
             MARKF(p, 12);
+        } else if (p->twin_ok) {
+            launch_twin_cholesky(p->dd, p->twinv, s);   // the band's two ends side by side: nA + 1 + (middle - 1) launches instead of T - 1
+            MARKF(p, 12);
+            launch_trsv_back(p->dd, true, epoch, s);
         } else {
             launch_cholesky(p->dd, true, epoch, s, chain_schur_factors_tile0(p->dd));
             MARKF(p, 12);
@@ -1474,6 +1524,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     else if (w == "pose_dim") v = {(double)p->P};
     else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};
     else if (w == "band") v = {(double)(p->band_ok ? 1 : 0)};
+    else if (w == "twin") v = {(double)(p->twin_ok ? 1 : 0)};
     else if (w == "chi2") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {p->h_ctrl->current_chi}; }
     else if (w == "maxdiag") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {p->h_ctrl->maxdiag}; }
     else if (w == "solver_ok") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {(double)p->h_ctrl->solver_ok}; }

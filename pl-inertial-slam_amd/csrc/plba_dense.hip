@@ -315,32 +315,15 @@ __global__ __launch_bounds__(256) void k_potrf0_32(DevBuf d) {
 // row, look-ahead).  AUG = true: the identity rows, below.  Two instantiations behind one uniform branch, so the code of
 // the critical look-ahead workgroup is scheduled exactly as if the identity rows did not exist.
 template <bool AUG>
-__device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const int T, double* sX, double* sC, Look32& S) {
+__device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const int T, const int r, const int c, const int aj, const bool to_alt, const bool nolook, const bool first_col,
+                                            double* sX, double* sC, Look32& S) {
     const int ld = d.ld;
-    const int nt = T - k - 1;
-    const int b = blockIdx.x;
-    const int ntri = nt * (nt + 1) / 2;
-    // Workgroups beyond the normal tiles (launched when d.Ninv is set) carry IDENTITY rows appended to the augmented system:
+    // AUG workgroups (launched when d.Ninv is set) carry IDENTITY rows appended to the augmented system:
     // block row j of  N = I L^-T = L^-T  goes through exactly the panel product / trailing update of the right-hand-side
     // row (X_r = R(j,k) L(k,k)^-T,  R(j,c) -= X_r L(c,k)^T), one short tile each, so the explicit inverse is finished by
     // the same launches that finish the factor and the back-substitution becomes a matrix-vector product (k_back_gemv)
     // instead of a chain of cross-workgroup hops.  Row j starts at launch j (R(j,j) = I, R(j,c>j) = 0: never stored).
-    const int nnormal = (ntri + nt > 0) ? ntri + nt : 1;
     constexpr bool aug = AUG;
-    int rr, cc, aj = 0;
-    if (aug) {
-        const int w = nt > 0 ? nt : 1;
-        aj = (b - nnormal) / w; cc = (b - nnormal) % w; rr = nt;
-    } else if (b < ntri) {
-        rr = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
-        while ((rr + 1) * (rr + 2) / 2 <= b) ++rr;
-        while (rr * (rr + 1) / 2 > b) --rr;
-        cc = b - rr * (rr + 1) / 2;
-    } else {
-        rr = nt;
-        cc = b - ntri;
-    }
-    const int r = k + 1 + rr, c = k + 1 + cc;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const bool diag = (r == c);
     const bool aug_first = aug && aj == k;            // the identity block itself: nothing stored yet
@@ -378,7 +361,7 @@ __device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const 
     }
     // the C tile this workgroup updates, fetched in the shadow of the panel products
     const int tr = wv >> 1, tc = wv & 1;
-    double* C = (aug ? d.Nwork + (size_t)(aj * 32) * ld : d.sys + (size_t)(r * 32) * ld) + c * 32;
+    double* C = (aug ? d.Nwork + (size_t)(aj * 32) * ld : (to_alt ? d.alt : d.sys) + (size_t)(r * 32) * ld) + c * 32;
     const bool have_update = (c < T);      // false only for the last step's right-hand-side block
     double cold[4] = {0.0, 0.0, 0.0, 0.0};
     if (have_update && !aug_first) {
@@ -389,7 +372,7 @@ __device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const 
         const int xr = p * 32 + th * 16 + lk;
 #pragma unroll
         for (int v = 0; v < 4; ++v) { sX[(xr + 4 * v) * LS + li] = x0[v]; sX[(xr + 4 * v) * LS + 16 + li] = x1[v]; }
-        if (p == 0 && c == k + 1) {
+        if (p == 0 && first_col) {      // first_col: c is the step's first trailing column (k + 1 in the ordinary enumeration)
             // the finished panel block L(r,k) goes to Lfac, never back into sys: other workgroups still read the unsolved panel
             double* g = (aug ? d.Ninv + (size_t)(aj * 32) * ld : d.Lfac + (size_t)(r * 32) * ld) + (size_t)(th * 16 + lk) * ld + k * 32 + li;
 #pragma unroll
@@ -399,7 +382,7 @@ __device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const 
     if (!have_update) return;
     __syncthreads();
     STAMP32(1);
-    const bool lookahead = (r == k + 1 && diag);
+    const bool lookahead = (r == k + 1 && diag && !nolook);
     {
         const int cb = diag ? 0 : 32;
         double4v acc = (double4v){0.0, 0.0, 0.0, 0.0};
@@ -432,9 +415,74 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
     __shared__ __attribute__((aligned(16))) double sX[64 * LS];      // rows [0,32) = X_r, [32,64) = X_c, [row][k]
     __shared__ __attribute__((aligned(16))) double sC[32 * LS];      // look-ahead tile
     __shared__ __attribute__((aligned(16))) Look32 S;
-    const int nt = T - k - 1, ntiles = nt * (nt + 1) / 2 + nt;
-    if ((int)blockIdx.x >= (ntiles > 0 ? ntiles : 1)) chol32_tile<true>(d, k, T, sX, sC, S);
-    else chol32_tile<false>(d, k, T, sX, sC, S);
+    // the workgroup's tile: (rr, cc) over the trailing lower triangle, then the right-hand-side block row, then the identity rows
+    const int nt = T - k - 1, ntri = nt * (nt + 1) / 2, ntiles = ntri + nt;
+    const int nnormal = ntiles > 0 ? ntiles : 1;
+    const int b = blockIdx.x;
+    int rr, cc, aj = 0;
+    const bool aug = b >= nnormal;
+    if (aug) {
+        const int w = nt > 0 ? nt : 1;
+        aj = (b - nnormal) / w; cc = (b - nnormal) % w; rr = nt;
+    } else if (b < ntri) {
+        rr = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
+        while ((rr + 1) * (rr + 2) / 2 <= b) ++rr;
+        while (rr * (rr + 1) / 2 > b) --rr;
+        cc = b - rr * (rr + 1) / 2;
+    } else {
+        rr = nt;
+        cc = b - ntri;
+    }
+    if (aug) chol32_tile<true>(d, k, T, k + 1 + rr, k + 1 + cc, aj, false, false, cc == 0, sX, sC, S);
+    else chol32_tile<false>(d, k, T, k + 1 + rr, k + 1 + cc, 0, false, false, cc == 0, sX, sC, S);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Two-ended ("twin") factorisation of a block-banded system.  g2o's solver is a SPARSE Cholesky; the reduced camera system is
+// banded in keyframe order (tracks span a few keyframes), so its two ends can be eliminated independently.  Stored permuted
+// as [top nA tiles | bottom nB tiles reversed | middle] (k_chain_schur writes through d.perm) the two ends are two chains of
+// ONE right-looking Cholesky whose steps do not read each other's data: launch t runs step t (chain A) and step nA + t
+// (chain B) side by side, each over its own tile list (its remaining chain tiles, the middle tiles, the right-hand-side row,
+// its identity rows).  Both chains update the middle block: chain B adds its part into d.alt (zeroed by the producer) and
+// k_twin_combine folds it in and factors the first middle tile; the ordinary steps finish the middle.  T - 1 dependent
+// launches become  max(nA, nB) + 1 + (T - nA - nB - 1).
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chol32_list(DevBuf d, int kA, int kB, int T, const TwinTile* list, int nAent) {
+    __shared__ __attribute__((aligned(16))) double sX[64 * LS];
+    __shared__ __attribute__((aligned(16))) double sC[32 * LS];
+    __shared__ __attribute__((aligned(16))) Look32 S;
+    const TwinTile e = list[blockIdx.x];
+    const int k = (int)blockIdx.x < nAent ? kA : kB;
+    if (e.aj >= 0) chol32_tile<true>(d, k, T, e.r, e.c, e.aj, false, false, (e.flags & 4) != 0, sX, sC, S);
+    else chol32_tile<false>(d, k, T, e.r, e.c, 0, (e.flags & 1) != 0, (e.flags & 2) != 0, (e.flags & 4) != 0, sX, sC, S);
+}
+// middle block += chain B's part (lower tiles and the right-hand-side block row); the workgroup of the first middle tile
+// factors it on the spot (the look-ahead pipeline: L -> Lfac, L^-1 -> Linv32), so the ordinary step m0 follows directly
+__global__ __launch_bounds__(256) void k_twin_combine(DevBuf d, int m0, int T) {
+    __shared__ __attribute__((aligned(16))) double sC[32 * LS];
+    __shared__ __attribute__((aligned(16))) Look32 S;
+    const int nM = T - m0, ntri = nM * (nM + 1) / 2;
+    const int b = blockIdx.x;
+    int rr, cc;
+    if (b < ntri) {
+        rr = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
+        while ((rr + 1) * (rr + 2) / 2 <= b) ++rr;
+        while (rr * (rr + 1) / 2 > b) --rr;
+        cc = b - rr * (rr + 1) / 2;
+    } else { rr = nM; cc = b - ntri; }
+    const int r = m0 + rr, c = m0 + cc;
+    const size_t base = (size_t)(r * 32) * d.ld + c * 32;
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
+        const int row = idx >> 5, col = idx & 31;
+        const size_t a = base + (size_t)row * d.ld + col;
+        const double v = d.sys[a] + d.alt[a];
+        d.sys[a] = v;
+        if (b == 0) sC[row * LS + col] = v;
+    }
+    if (b != 0) return;
+    look32_reset(S, threadIdx.x);
+    __syncthreads();
+    lookahead_factor32<false>(d, m0, sC, S, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -985,6 +1033,20 @@ static void launch_cholesky_nb(const DevBuf& d, bool use_mfma, hipStream_t s) {
     }
 }
 static bool inverse_panels(const DevBuf& d, bool use_mfma) { return d.fb == 32 && use_mfma; }
+void launch_twin_cholesky(const DevBuf& d, const TwinView& tv, hipStream_t s) {
+    const int T = tv.T, m0 = tv.nA + tv.nB, nl = std::max(tv.nA, tv.nB);
+    for (int t = 0; t < nl; ++t) {
+        const int a0 = tv.off[2 * t], b0 = tv.off[2 * t + 1], e1 = tv.off[2 * t + 2];
+        if (e1 > a0) hipLaunchKernelGGL(k_chol32_list, dim3(e1 - a0), dim3(256), 0, s, d, t, tv.nA + t, T, tv.list + a0, b0 - a0);
+    }
+    const int nM = T - m0;
+    hipLaunchKernelGGL(k_twin_combine, dim3(nM * (nM + 1) / 2 + nM), dim3(256), 0, s, d, m0, T);
+    for (int k = m0; k < T - 1; ++k) {      // the last step (panels only) is folded into k_back_gemv, as in launch_cholesky
+        const int nt = T - k - 1;
+        const int tiles = nt * (nt + 1) / 2 + nt;
+        hipLaunchKernelGGL(k_chol32, dim3((tiles > 0 ? tiles : 1) + (k + 1) * (nt > 0 ? nt : 1)), dim3(256), 0, s, d, k, T);
+    }
+}
 void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s, bool tile0_done) {
     if (inverse_panels(d, use_mfma) && d.flow) {
         const int T = d.Ppad / 32;
@@ -1055,7 +1117,7 @@ __global__ __launch_bounds__(256) void k_back_gemv(DevBuf d, int fold_last) {
     double v = s0 + s1 + (lane < 32 ? tw * sz[lane] : 0.0);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (lane == 0) d.x[c] = c < c0 ? v : sz[c - c0];
+    if (lane == 0) d.x[d.xmap ? d.xmap[c] : c] = c < c0 ? v : sz[c - c0];      // xmap: the system is stored permuted (twin factorisation)
 }
 
 void launch_trsv_back(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s) {

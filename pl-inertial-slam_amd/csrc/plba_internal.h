@@ -105,6 +105,12 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     int* chol_flags;       // (T32 + 1) x T32 tile flags + T32 inverse flags of the single-launch factorisation (epoch-stamped)
     double* dbgbuf;        // 64 doubles for diagnostic builds (cycle stamps)
     int band;              // 1: the banded twisted solver handles this system (plba_band.hip): k_chain_schur leaves tile (0,0) unfactored
+    // two-ended multi-launch factorisation of a banded system ("twin", plba_dense.hip): the system is stored PERMUTED
+    // [top nA tiles | bottom nB tiles, reversed | middle], so that the two ends are two independent chains of one Cholesky
+    int twin_nA, twin_nB;  // 0: off
+    const int32_t* perm;   // Ppad: natural dense index -> permuted (k_chain_schur writes through it)
+    const int32_t* xmap;   // Ppad: permuted -> natural (k_back_gemv writes x through it)
+    double* alt;           // same shape as sys: the bottom chain's updates of the middle block (added in by k_twin_combine)
     int flow;              // 1: single-launch dataflow factorisation (k_chol_flow), 0: one launch per block step
     int wide;              // 1: a launch retires 64 columns (two pipelined 32-column sweeps in the look-ahead workgroup, k_chol64)
     // reductions / control
@@ -186,6 +192,14 @@ size_t band_lds_bytes(int Pdpad);
 void launch_band_solve(const DevBuf& dd, const BandView& bv, hipStream_t s);      // dd.sys (+ rhs row) -> dd.x
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s);
 void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);   // writes dd.sys
+// one workgroup of a list-driven block step: block row / column, identity row (-1: a tile of the factorisation proper), flags
+struct TwinTile { int16_t r, c, aj, flags; };      // flags: 1 = writes d.alt instead of d.sys, 2 = no look-ahead on this tile, 4 = c is the step's first trailing column (stores the finished panel block)
+struct TwinView {
+    int T, nA, nB;                 // tiles; length of the top / bottom chain (middle = T - nA - nB >= band width)
+    const TwinTile* list;          // all launches' tiles, launch t = [off[2 t], off[2 t + 1]) chain A, [off[2 t + 1], off[2 t + 2]) chain B
+    std::vector<int> off;          // host side
+};
+void launch_twin_cholesky(const DevBuf& d, const TwinView& tv, hipStream_t s);      // sys (permuted; tiles 0 and nA factored by the producer) -> Lfac, Ninv
 void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s, bool tile0_done = false);   // sys -> Lfac (lower) incl. the augmented rows;
                                                                                      // tile0_done: the producer of sys already factored tile (0,0) (k_chain_schur)
 bool chain_schur_factors_tile0(const DevBuf& dd);

@@ -166,7 +166,12 @@ struct plba_problem {
     bool ev_sample = false;    // profile = 1: this trial's factorisation span is being timed
     unsigned trial_counter = 0;
     bool spec_lin = false;
-    bool spec_hll = false;     // ... and so are its landmark blocks and the pose-side assembly     // the next iteration's linearisation is already in the stream (enqueued behind k_decide)
+    bool spec_hll = false;
+    bool twin_ok = false;      // two-ended multi-launch factorisation of the compact dense system (plba_dense.hip: launch_twin_cholesky)
+    plba::TwinView twinv;
+    plba::DArr<plba::TwinTile> d_twin_list;
+    plba::DArr<int32_t> d_twin_perm, d_twin_xmap;
+    plba::DArr<double> d_twin_alt;     // ... and so are its landmark blocks and the pose-side assembly     // the next iteration's linearisation is already in the stream (enqueued behind k_decide)
     // ---- host copy of the uploaded graph -------------------------------------------------------
     bool have_cam = false;
     double fx, fy, cx, cy, Rbc[9], Pbc[3], gw[3] = {0, 0, 0};

@@ -178,3 +178,43 @@ def test_banded_solver_reports_a_non_positive_pivot(pkg, hip):
     g.debug_build(-1e13, True)               # lambda far below zero: indefinite on purpose
     assert g.debug_get("band")[0] == 1 and g.debug_get("solver_ok")[0] == 0
     g.close()
+
+
+@pytest.mark.parametrize("K,Np,Nl", [(50, 2000, 400), (36, 900, 200), (80, 2500, 500)])
+def test_twin_factorisation_matches_the_dense_path_and_the_oracle(pkg, orc, hip, K, Np, Nl):
+    """plba_dense.hip launch_twin_cholesky (the default for 8 <= tiles < 24): the banded compact system stored permuted
+    [top chain | bottom chain reversed | middle], both ends eliminated side by side in each launch.  Same optimisation as the
+    plain dense path (band_solve = 0) and as the oracle."""
+    w = pkg.window.make_window(K, Np, Nl, imu=True, seed=0x7B1A + K)
+    res = {}
+    for twin in (1, 0):
+        g = pkg.new_problem(band_solve=twin); g.upload_window(w)
+        g.debug_build(3.0, True)
+        x = g.debug_get("x").copy()
+        assert g.debug_get("twin")[0] == twin and g.debug_get("band")[0] == 0 and g.debug_get("solver_ok")[0] == 1
+        st = g.optimize(4)
+        res[twin] = (x, st, g.get_keyframes(), [t["accepted"] for t in g.trace()])
+        g.close()
+    o = orc.new_problem(); o.upload_window(w)
+    o.debug_build(3.0, True)
+    xo = o.debug_get("x").copy()
+    so = o.optimize(4)
+    ko = o.get_keyframes()
+    o.close()
+    sc = np.abs(xo).max()
+    assert np.abs(res[1][0] - xo).max() < 1e-7 * sc and np.abs(res[0][0] - xo).max() < 1e-7 * sc
+    assert np.abs(res[1][0] - res[0][0]).max() < 1e-9 * sc
+    for twin in (1, 0):
+        st = res[twin][1]
+        assert (st.iterations, st.trials, st.solver_failures) == (so.iterations, so.trials, 0)
+        assert st.chi2_final == pytest.approx(so.chi2_final, rel=1e-8)
+        assert max(_pose_delta(res[twin][2], ko, pkg)) < 1e-8
+    assert res[1][3] == res[0][3]
+
+
+def test_twin_factorisation_reports_a_non_positive_pivot(pkg, hip):
+    w = pkg.window.make_window(50, 1500, 300, imu=True, seed=0xBA4D)
+    g = pkg.new_problem(); g.upload_window(w)
+    g.debug_build(-1e13, True)               # lambda far below zero: indefinite on purpose
+    assert g.debug_get("twin")[0] == 1 and g.debug_get("solver_ok")[0] == 0
+    g.close()
