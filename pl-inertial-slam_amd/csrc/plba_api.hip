@@ -900,11 +900,12 @@ static int prepare(plba_problem* p) {
                 p->band_ok = true;
                 p->dd.band = 1;
             } else if (p->opt.band_solve == 1 && p->dd.Ninv && hbt >= 1) {
-                // chains of nC tiles each; the middle keeps >= hbt tiles so that the last top tile and the first bottom tile do not couple
-                const int nC = (T - hbt) / 2;
-                if (nC >= 2) {
+                // the bottom chain one tile shorter than the top one (its part of the middle is complete when the top chain takes its last
+                // step, which folds it in and factors the first middle tile); the middle keeps >= hbt tiles so that the chains do not couple
+                const int nC = (T - hbt - 1) / 2;
+                if (nC >= 1) {
                     TwinView& tv = p->twinv;
-                    tv.T = T; tv.nA = nC; tv.nB = nC;
+                    tv.T = T; tv.nA = nC + 1; tv.nB = nC;
                     const int m0 = tv.nA + tv.nB, n32 = cv.Pdpad;
                     std::vector<int32_t> perm(n32), xmap(n32);
                     for (int i = 0; i < n32; ++i) {
@@ -924,10 +925,11 @@ static int prepare(plba_problem* p) {
                             for (size_t b2 = 0; b2 <= a; ++b2) {
                                 const int r = S[a], c = S[b2];
                                 TwinTile e; e.r = (int16_t)r; e.c = (int16_t)c; e.aj = -1;
-                                e.flags = (int16_t)((is_b && r >= m0 && c >= m0 ? 1 : 0) | ((last && r == k + 1) ? 2 : 0) | (c == S[0] ? 4 : 0));
+                                e.flags = (int16_t)((is_b && r >= m0 && c >= m0 ? 1 : 0) | ((is_b && last && r == k + 1) ? 2 : 0) | (c == S[0] ? 4 : 0) |
+                                                    ((!is_b && last) ? 8 : 0) | ((!is_b && last && r == m0 && c == m0) ? 16 : 0));      // (top chain's last step: S = the middle)
                                 list.push_back(e);
                             }
-                        for (int c : S) { TwinTile e; e.r = (int16_t)T; e.c = (int16_t)c; e.aj = -1; e.flags = (int16_t)((is_b && c >= m0 ? 1 : 0) | (c == S[0] ? 4 : 0)); list.push_back(e); }
+                        for (int c : S) { TwinTile e; e.r = (int16_t)T; e.c = (int16_t)c; e.aj = -1; e.flags = (int16_t)((is_b && c >= m0 ? 1 : 0) | (c == S[0] ? 4 : 0) | ((!is_b && last) ? 8 : 0)); list.push_back(e); }
                         for (int aj = aj_lo; aj <= k; ++aj) for (int c : S) { TwinTile e; e.r = (int16_t)T; e.c = (int16_t)c; e.aj = (int16_t)aj; e.flags = (int16_t)(c == S[0] ? 4 : 0); list.push_back(e); }
                     };
                     for (int t = 0; t < std::max(tv.nA, tv.nB); ++t) {

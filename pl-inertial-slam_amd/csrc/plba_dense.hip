@@ -315,8 +315,9 @@ __global__ __launch_bounds__(256) void k_potrf0_32(DevBuf d) {
 // row, look-ahead).  AUG = true: the identity rows, below.  Two instantiations behind one uniform branch, so the code of
 // the critical look-ahead workgroup is scheduled exactly as if the identity rows did not exist.
 template <bool AUG>
-__device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const int T, const int r, const int c, const int aj, const bool to_alt, const bool nolook, const bool first_col,
+__device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const int T, const int r, const int c, const int aj, const int tflags, const bool first_col,
                                             double* sX, double* sC, Look32& S) {
+    const bool to_alt = (tflags & 1) != 0, nolook = (tflags & 2) != 0, add_alt = (tflags & 8) != 0, look_here = (tflags & 16) != 0;
     const int ld = d.ld;
     // AUG workgroups (launched when d.Ninv is set) carry IDENTITY rows appended to the augmented system:
     // block row j of  N = I L^-T = L^-T  goes through exactly the panel product / trailing update of the right-hand-side
@@ -367,6 +368,11 @@ __device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const 
     if (have_update && !aug_first) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) cold[v] = C[(size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li];
+        if (!aug && add_alt) {      // the other chain's finished part of this middle tile (twin factorisation)
+            const double* Ca = d.alt + (size_t)(r * 32) * ld + c * 32;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cold[v] += Ca[(size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li];
+        }
     }
     if (act) {
         const int xr = p * 32 + th * 16 + lk;
@@ -382,7 +388,7 @@ __device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const 
     if (!have_update) return;
     __syncthreads();
     STAMP32(1);
-    const bool lookahead = (r == k + 1 && diag && !nolook);
+    const bool lookahead = diag && ((r == k + 1 && !nolook) || look_here);
     {
         const int cb = diag ? 0 : 32;
         double4v acc = (double4v){0.0, 0.0, 0.0, 0.0};
@@ -401,7 +407,7 @@ __device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const 
     look32_reset(S, threadIdx.x);
     __syncthreads();
     STAMP32(2);
-    lookahead_factor32<false>(d, k + 1, sC, S, wv, lane);
+    lookahead_factor32<false>(d, r, sC, S, wv, lane);
     STAMP32(3);
 #ifdef PLBA_STAMPS
     if (lane == 0 && blockIdx.x == 0 && k == 5) for (int q = 0; q < 4; ++q) d.maxd_part[4 * wv + q] = (double)(ts[q] - ts[0]);
@@ -433,8 +439,8 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
         rr = nt;
         cc = b - ntri;
     }
-    if (aug) chol32_tile<true>(d, k, T, k + 1 + rr, k + 1 + cc, aj, false, false, cc == 0, sX, sC, S);
-    else chol32_tile<false>(d, k, T, k + 1 + rr, k + 1 + cc, 0, false, false, cc == 0, sX, sC, S);
+    if (aug) chol32_tile<true>(d, k, T, k + 1 + rr, k + 1 + cc, aj, 0, cc == 0, sX, sC, S);
+    else chol32_tile<false>(d, k, T, k + 1 + rr, k + 1 + cc, 0, 0, cc == 0, sX, sC, S);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -443,9 +449,10 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
 // as [top nA tiles | bottom nB tiles reversed | middle] (k_chain_schur writes through d.perm) the two ends are two chains of
 // ONE right-looking Cholesky whose steps do not read each other's data: launch t runs step t (chain A) and step nA + t
 // (chain B) side by side, each over its own tile list (its remaining chain tiles, the middle tiles, the right-hand-side row,
-// its identity rows).  Both chains update the middle block: chain B adds its part into d.alt (zeroed by the producer) and
-// k_twin_combine folds it in and factors the first middle tile; the ordinary steps finish the middle.  T - 1 dependent
-// launches become  max(nA, nB) + 1 + (T - nA - nB - 1).
+// its identity rows).  Both chains update the middle block: chain B (one tile shorter than chain A) adds its part into
+// d.alt (zeroed by the producer); chain A's LAST step, alone in its launch, folds that in (cold += alt) and factors the first
+// middle tile by look-ahead as any other step does; the ordinary steps finish the middle.  T - 1 dependent launches become
+// nA + (T - nA - nB - 1).
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chol32_list(DevBuf d, int kA, int kB, int T, const TwinTile* list, int nAent) {
     __shared__ __attribute__((aligned(16))) double sX[64 * LS];
@@ -453,37 +460,10 @@ __global__ __launch_bounds__(256) void k_chol32_list(DevBuf d, int kA, int kB, i
     __shared__ __attribute__((aligned(16))) Look32 S;
     const TwinTile e = list[blockIdx.x];
     const int k = (int)blockIdx.x < nAent ? kA : kB;
-    if (e.aj >= 0) chol32_tile<true>(d, k, T, e.r, e.c, e.aj, false, false, (e.flags & 4) != 0, sX, sC, S);
-    else chol32_tile<false>(d, k, T, e.r, e.c, 0, (e.flags & 1) != 0, (e.flags & 2) != 0, (e.flags & 4) != 0, sX, sC, S);
+    if (e.aj >= 0) chol32_tile<true>(d, k, T, e.r, e.c, e.aj, 0, (e.flags & 4) != 0, sX, sC, S);
+    else chol32_tile<false>(d, k, T, e.r, e.c, 0, e.flags, (e.flags & 4) != 0, sX, sC, S);
 }
-// middle block += chain B's part (lower tiles and the right-hand-side block row); the workgroup of the first middle tile
-// factors it on the spot (the look-ahead pipeline: L -> Lfac, L^-1 -> Linv32), so the ordinary step m0 follows directly
-__global__ __launch_bounds__(256) void k_twin_combine(DevBuf d, int m0, int T) {
-    __shared__ __attribute__((aligned(16))) double sC[32 * LS];
-    __shared__ __attribute__((aligned(16))) Look32 S;
-    const int nM = T - m0, ntri = nM * (nM + 1) / 2;
-    const int b = blockIdx.x;
-    int rr, cc;
-    if (b < ntri) {
-        rr = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
-        while ((rr + 1) * (rr + 2) / 2 <= b) ++rr;
-        while (rr * (rr + 1) / 2 > b) --rr;
-        cc = b - rr * (rr + 1) / 2;
-    } else { rr = nM; cc = b - ntri; }
-    const int r = m0 + rr, c = m0 + cc;
-    const size_t base = (size_t)(r * 32) * d.ld + c * 32;
-    for (int idx = threadIdx.x; idx < 1024; idx += 256) {
-        const int row = idx >> 5, col = idx & 31;
-        const size_t a = base + (size_t)row * d.ld + col;
-        const double v = d.sys[a] + d.alt[a];
-        d.sys[a] = v;
-        if (b == 0) sC[row * LS + col] = v;
-    }
-    if (b != 0) return;
-    look32_reset(S, threadIdx.x);
-    __syncthreads();
-    lookahead_factor32<false>(d, m0, sC, S, threadIdx.x >> 6, threadIdx.x & 63);
-}
+
 
 // -------------------------------------------------------------------------------------------------
 // 64-column block steps out of the same 32-wide pieces (wide_steps = 1, the default with factor_block 32 + use_mfma).
@@ -1039,8 +1019,6 @@ void launch_twin_cholesky(const DevBuf& d, const TwinView& tv, hipStream_t s) {
         const int a0 = tv.off[2 * t], b0 = tv.off[2 * t + 1], e1 = tv.off[2 * t + 2];
         if (e1 > a0) hipLaunchKernelGGL(k_chol32_list, dim3(e1 - a0), dim3(256), 0, s, d, t, tv.nA + t, T, tv.list + a0, b0 - a0);
     }
-    const int nM = T - m0;
-    hipLaunchKernelGGL(k_twin_combine, dim3(nM * (nM + 1) / 2 + nM), dim3(256), 0, s, d, m0, T);
     for (int k = m0; k < T - 1; ++k) {      // the last step (panels only) is folded into k_back_gemv, as in launch_cholesky
         const int nt = T - k - 1;
         const int tiles = nt * (nt + 1) / 2 + nt;

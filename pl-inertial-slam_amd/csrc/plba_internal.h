@@ -110,7 +110,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     int twin_nA, twin_nB;  // 0: off
     const int32_t* perm;   // Ppad: natural dense index -> permuted (k_chain_schur writes through it)
     const int32_t* xmap;   // Ppad: permuted -> natural (k_back_gemv writes x through it)
-    double* alt;           // same shape as sys: the bottom chain's updates of the middle block (added in by k_twin_combine)
+    double* alt;           // same shape as sys: the bottom chain's updates of the middle block (folded in by the top chain's last step)
     int flow;              // 1: single-launch dataflow factorisation (k_chol_flow), 0: one launch per block step
     int wide;              // 1: a launch retires 64 columns (two pipelined 32-column sweeps in the look-ahead workgroup, k_chol64)
     // reductions / control
@@ -193,7 +193,8 @@ void launch_band_solve(const DevBuf& dd, const BandView& bv, hipStream_t s);    
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s);
 void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);   // writes dd.sys
 // one workgroup of a list-driven block step: block row / column, identity row (-1: a tile of the factorisation proper), flags
-struct TwinTile { int16_t r, c, aj, flags; };      // flags: 1 = writes d.alt instead of d.sys, 2 = no look-ahead on this tile, 4 = c is the step's first trailing column (stores the finished panel block)
+struct TwinTile { int16_t r, c, aj, flags; };      // flags: 1 = writes d.alt instead of d.sys, 2 = no look-ahead on this tile, 4 = c is the step's first trailing column (stores the finished panel block),
+                                                   // 8 = add d.alt's tile to the old value first, 16 = this (diagonal) tile is the next pivot: factor it here
 struct TwinView {
     int T, nA, nB;                 // tiles; length of the top / bottom chain (middle = T - nA - nB >= band width)
     const TwinTile* list;          // all launches' tiles, launch t = [off[2 t], off[2 t + 1]) chain A, [off[2 t + 1], off[2 t + 2]) chain B
