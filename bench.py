@@ -312,6 +312,16 @@ def main():
                     traffic=pmc_traffic("k_linearize<true>"), algorithmic_bytes_per_launch=bytes_lin, avg_launch_ms=lin_ms)
     kname = "k_chol32" if fb == 32 else "k_chol_step"
     banded = bool(prob.debug_get("band")[0])
+    twin = bool(prob.debug_get("twin")[0])
+    if twin:
+        # plba_dense.hip launch_twin_cholesky: the same block steps (k_chol32_list: both ends of the band per launch, then k_chol32 on the
+        # middle), fewer of them; flops counted as the DENSE factorisation's would overstate what the banded system needs, so the banded count
+        T = ((Pdense + 63) // 64) * 64 // 32
+        n_fact_launches = int(prob.debug_get("fact_launches")[0])
+        flops_fact = T * (1.0 / 3.0 + 3.0 + 12.0) * 32 ** 3
+        fact_ms = phases[1] / max(trials, 1) / n_fact_launches
+        kname = "k_chol32_list"
+
     if banded:
         # plba_band.hip: the two launches (k_band_fwd: factorisation + forward substitution from both ends, k_band_back) of the banded
         # twisted solve; banded LL^T with 3 sub-diagonal tiles: (1/3 + 3 + 12) * 32^3 flops per 32-column tile
@@ -321,7 +331,7 @@ def main():
         fact_ms = phases[1] / max(trials, 1) / n_fact_launches
         kname = "k_band_fwd"
     ach = flops_fact / n_fact_launches / (fact_ms * 1e-3) / 1e12 if fact_ms > 0 else None
-    roof_mfma = dict(bound="mfma", kernel=("k_band_fwd + k_band_back: banded twisted fp64 LL^T of the reduced camera system from both ends in LDS (%d of the P=%d pose dims stay dense after the velocity/bias chain elimination, band of 3 tiles, %d launches per solve)" % (Pdense, P, n_fact_launches)) if banded else "%s: one block step of the dense fp64 LL^T of the reduced camera system (%d of the P=%d pose dims stay dense after the velocity/bias chain elimination, %d launches per solve)" % (kname, Pdense, P, n_fact_launches),
+    roof_mfma = dict(bound="mfma", kernel=("k_band_fwd + k_band_back: banded twisted fp64 LL^T of the reduced camera system from both ends in LDS (%d of the P=%d pose dims stay dense after the velocity/bias chain elimination, band of 3 tiles, %d launches per solve)" % (Pdense, P, n_fact_launches)) if banded else ("k_chol32_list / k_chol32: one block step of the two-ended fp64 LL^T of the banded reduced camera system (%d of the P=%d pose dims stay dense after the velocity/bias chain elimination; both ends of the band per launch, %d dependent launches per solve; flops = the banded factorisation's)" % (Pdense, P, n_fact_launches)) if twin else "%s: one block step of the dense fp64 LL^T of the reduced camera system (%d of the P=%d pose dims stay dense after the velocity/bias chain elimination, %d launches per solve)" % (kname, Pdense, P, n_fact_launches),
                      achieved=ach, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=(ach / FP64_MFMA_PEAK_TFLOPS) if ach else None,
                      traffic=pmc_traffic(kname), algorithmic_flops_per_launch=flops_fact / n_fact_launches, avg_launch_ms=fact_ms)
     # the factorisation launches are the largest single consumer of an iteration (profiles/r01_*_kernel_stats.csv)
@@ -335,7 +345,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": name, "K": cfg["K"], "points": cfg["Np"], "lines": cfg["Nl"], "point_obs": int(Ep), "line_obs": int(El),
                    "pose_dim": P, "trials_per_iteration": trials / max(done, 1), "protocol": "stage-2 LM iterations (no Huber on point/line edges) replayed from the post-gating state",
-                   "global_iterations_per_s": done / dt, "dense_dim": Pdense, "exchange": xch_kind, "banded_twisted_solve": banded,
+                   "global_iterations_per_s": done / dt, "dense_dim": Pdense, "exchange": xch_kind, "banded_twisted_solve": banded, "twin_factorisation": twin,
                    "value_definition": "global LM iterations/s of ONE window (total work fixed as N grows: its landmarks are sharded over the N ranks)",
                    "algorithmic_bytes_per_iteration": b_iter,
                    "hbm_frac_whole_iteration": b_iter / (dt / done) / 1e9 / (HBM_PEAK_GBS * world)},

@@ -75,12 +75,13 @@ typedef struct {
                                    the next 64 x 64 diagonal tile as two pipelined 32-column sweeps (factor_block 32 with
                                    use_mfma, factor_flow 0; experimental: measured slower);
                                    0 = one launch per 32 columns                                                    (0) */
-    int    band_solve;          /* 1 = when the compact dense system (after the chain elimination) is block-banded with at most three
-                                   sub-diagonal 32 x 32 tiles — tracks spanning a few consecutive keyframes, as in a sliding window —
-                                   it is factored and solved by two workgroups walking the band from both ends with the window
-                                   resident in LDS (plba_band.hip) instead of one launch per 32 columns, from 24 tiles (768 dense
-                                   dims) on, where it was measured faster; 2 = from 8 tiles on (tests); wider bands and smaller
-                                   systems take the dense path regardless                                                 (1) */
+    int    band_solve;          /* how the band of the compact dense system (after the chain elimination) is used when it has at most
+                                   three sub-diagonal 32 x 32 tiles — tracks spanning a few consecutive keyframes, as in a sliding
+                                   window.  1 = from 8 to 48 tiles the two ends of the band are eliminated side by side in every
+                                   launch of the dense factorisation ("twin" form, plba_dense.hip: T - 1 dependent launches become
+                                   about T / 2); longer systems are factored and solved by two workgroups walking the band from
+                                   both ends with the window resident in LDS (plba_band.hip).  2 = the in-LDS form from 8 tiles on
+                                   (tests).  0 = neither.  Wider bands and smaller systems take the plain dense path      (1) */
 } plba_options;
 
 void plba_default_options(plba_options* o);

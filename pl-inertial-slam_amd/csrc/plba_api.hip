@@ -891,7 +891,10 @@ static int prepare(plba_problem* p) {
                 if (r >= 0 && c >= 0) hbt = std::max(hbt, std::abs(r / 32 - c / 32));
             }
             for (int g = 0; g < cv.nseg; ++g) if (hsegcol[2 * g + 1] > hsegcol[2 * g]) hbt = std::max(hbt, (hsegcol[2 * g + 1] - 1) / 32 - hsegcol[2 * g] / 32);
-            if (T >= (p->opt.band_solve >= 2 ? 8 : BAND_MIN_TILES) && band_lds_bytes(cv.Pdpad) <= 160 * 1024 && hbt <= BAND_HB) {      // band_solve = 2 (tests): in LDS from 8 tiles on
+            const char* twin_env = getenv("PLBA_TWIN_MAX_T");      // experiments: the longest system the twin form takes (default: below the in-LDS threshold)
+            const int twin_max_t = twin_env ? atoi(twin_env) : TWIN_MAX_TILES;
+            const bool twin_pref = p->opt.band_solve == 1 && T <= twin_max_t;
+            if (!twin_pref && T >= (p->opt.band_solve >= 2 ? 8 : BAND_MIN_TILES) && band_lds_bytes(cv.Pdpad) <= 160 * 1024 && hbt <= BAND_HB) {      // band_solve = 2 (tests): in LDS from 8 tiles on
                 BandView& bv = p->bandv;
                 bv.T = T; bv.nA = (T - BAND_HB) / 2; bv.nB = T - BAND_HB - bv.nA;
                 HIPCK(p, p->d_band_L.alloc((size_t)2 * T * 4 * 1024, false)); HIPCK(p, p->d_band_y.alloc((size_t)2 * cv.Pdpad, false));
@@ -899,7 +902,8 @@ static int prepare(plba_problem* p) {
                 bv.Lband = p->d_band_L.p; bv.y = p->d_band_y.p; bv.mid = p->d_band_mid.p;
                 p->band_ok = true;
                 p->dd.band = 1;
-            } else if (p->opt.band_solve == 1 && p->dd.Ninv && hbt >= 1) {
+            } else if (twin_pref && hbt >= 1) {
+                if (!p->dd.Ninv) { HIPCK(p, p->d_Ninvd.alloc((size_t)2 * cv.Pdpad * cv.Pdpad)); p->dd.Ninv = p->d_Ninvd.p; p->dd.Nwork = p->dd.Ninv + (size_t)cv.Pdpad * cv.Pdpad; }
                 // the bottom chain one tile shorter than the top one (its part of the middle is complete when the top chain takes its last
                 // step, which folds it in and factors the first middle tile); the middle keeps >= hbt tiles so that the chains do not couple
                 const int nC = (T - hbt - 1) / 2;
@@ -1527,6 +1531,11 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};
     else if (w == "band") v = {(double)(p->band_ok ? 1 : 0)};
     else if (w == "twin") v = {(double)(p->twin_ok ? 1 : 0)};
+    else if (w == "fact_launches") {      // dependent launches of one factorisation between the profile events 11 and 12 (bench.py's roofline)
+        if (p->band_ok) v = {2.0};
+        else if (p->twin_ok) v = {(double)(p->twinv.nA + (p->twinv.T - p->twinv.nA - p->twinv.nB - 1))};
+        else v = {-1.0};
+    }
     else if (w == "chi2") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {p->h_ctrl->current_chi}; }
     else if (w == "maxdiag") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {p->h_ctrl->maxdiag}; }
     else if (w == "solver_ok") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {(double)p->h_ctrl->solver_ok}; }

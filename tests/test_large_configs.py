@@ -35,7 +35,7 @@ def test_config5_full_size_properties(pkg, hip, w5):
     assert r["stage1"].iterations == 5 and r["stage2"].iterations == 10
     assert r["stage1"].solver_failures == 0 and r["stage2"].solver_failures == 0
     assert g.debug_get("pose_dim")[0] == 199 * 15 and g.debug_get("dense_dim")[0] < 199 * 15      # chain path in effect
-    assert g.debug_get("band")[0] == 1                                  # 44 tiles, band of 3: the two-ended in-LDS sweep solves it
+    assert g.debug_get("twin")[0] == 1 and g.debug_get("band")[0] == 0      # 44 tiles, band of 3: the two-ended multi-launch factorisation solves it
     tr = g.trace()
     chi = [t["chi2_current"] for t in tr] + [tr[-1]["chi2_trial"] if tr[-1]["accepted"] else tr[-1]["chi2_current"]]
     assert all(b <= a * (1 + 1e-12) for a, b in zip(chi[:-1], chi[1:])), "chi2 must not increase over accepted LM steps"
@@ -180,7 +180,7 @@ def test_banded_solver_reports_a_non_positive_pivot(pkg, hip):
     g.close()
 
 
-@pytest.mark.parametrize("K,Np,Nl", [(50, 2000, 400), (36, 900, 200), (80, 2500, 500)])
+@pytest.mark.parametrize("K,Np,Nl", [(50, 2000, 400), (36, 900, 200), (80, 2500, 500), (200, 6000, 1200)])
 def test_twin_factorisation_matches_the_dense_path_and_the_oracle(pkg, orc, hip, K, Np, Nl):
     """plba_dense.hip launch_twin_cholesky (the default for 8 <= tiles < 24): the banded compact system stored permuted
     [top chain | bottom chain reversed | middle], both ends eliminated side by side in each launch.  Same optimisation as the
