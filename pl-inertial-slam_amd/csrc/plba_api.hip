@@ -875,7 +875,7 @@ static int prepare(plba_problem* p) {
     //   8 <= T < 24  : the two-ended ("twin") form of the multi-launch factorisation (plba_dense.hip): same kernels, the two ends
     //                  of the band eliminated side by side in each launch
     p->band_ok = false; p->twin_ok = false;
-    p->dd.band = 0; p->dd.twin_nA = 0; p->dd.twin_nB = 0; p->dd.perm = nullptr; p->dd.xmap = nullptr; p->dd.alt = nullptr;
+    p->dd.band = 0; p->dd.twin_m0 = 0; p->dd.twin_fac = nullptr; p->dd.perm = nullptr; p->dd.xmap = nullptr; p->dd.alt = nullptr;
     if (p->chain_ok && p->opt.band_solve && !p->dv.flow && !p->dv.wide) {      // (sharded runs: the lists above hold the GLOBAL structure)
         const ChainView& cv = p->cv;
         const int T = cv.Pdpad / 32;
@@ -904,53 +904,106 @@ static int prepare(plba_problem* p) {
                 p->dd.band = 1;
             } else if (twin_pref && hbt >= 1) {
                 if (!p->dd.Ninv) { HIPCK(p, p->d_Ninvd.alloc((size_t)2 * cv.Pdpad * cv.Pdpad)); p->dd.Ninv = p->d_Ninvd.p; p->dd.Nwork = p->dd.Ninv + (size_t)cv.Pdpad * cv.Pdpad; }
-                // the bottom chain one tile shorter than the top one (its part of the middle is complete when the top chain takes its last
-                // step, which folds it in and factors the first middle tile); the middle keeps >= hbt tiles so that the chains do not couple
-                const int nC = (T - hbt - 1) / 2;
-                if (nC >= 1) {
-                    TwinView& tv = p->twinv;
-                    tv.T = T; tv.nA = nC + 1; tv.nB = nC;
-                    const int m0 = tv.nA + tv.nB, n32 = cv.Pdpad;
-                    std::vector<int32_t> perm(n32), xmap(n32);
-                    for (int i = 0; i < n32; ++i) {
-                        int pi;
-                        if (i < tv.nA * 32) pi = i;
-                        else if (i >= (T - tv.nB) * 32) pi = tv.nA * 32 + (T * 32 - 1 - i);
-                        else pi = m0 * 32 + (i - tv.nA * 32);
-                        perm[i] = pi; xmap[pi] = i;
+                // Chains and separators (plba_dense.hip, "Multi-chain factorisation").  Natural layout of the band:
+                //   two chains :  C0 (n + 1 tiles) | S1 | C1 (n tiles, eliminated bottom-up)
+                //   four chains:  C0 (n + 1) | S1 | C1 (n) | S2 | C2 (n + 1) | S3 | C3 (n, bottom-up)
+                // separators >= hbt tiles wide (chains must not couple); C1 / C3 accumulate their separator updates in `alt` and are one tile
+                // shorter, so that the last step of C0 / C2 folds those in.  The variant with fewer dependent launches is taken.
+                struct Chain { int nat0, len; bool rev, alt; int sep[2]; int p0; };
+                struct Plan { std::vector<Chain> ch; std::vector<int> sep_nat0, sep_w; int launches; };
+                auto plan_for = [&](int nch) {
+                    Plan pl; pl.launches = 1 << 30;
+                    const int nsep = nch - 1;
+                    const int nC = (T - nsep * hbt - nch / 2) / nch;      // nch/2 chains carry the extra tile
+                    if (nC < 1) return pl;
+                    int left = T - nsep * hbt - nch / 2 - nch * nC;      // tiles that do not divide: widen the first separators
+                    int at = 0;
+                    for (int c = 0; c < nch; ++c) {
+                        Chain ch; ch.nat0 = at; ch.len = nC + ((c & 1) ? 0 : 1); ch.alt = (c & 1) != 0; ch.rev = (c == nch - 1);
+                        ch.sep[0] = c == 0 ? 0 : (c == nch - 1 ? nsep - 1 : c - 1); ch.sep[1] = (c == 0 || c == nch - 1) ? -1 : c; ch.p0 = 0;
+                        at += ch.len;
+                        pl.ch.push_back(ch);
+                        if (c < nsep) { const int w = hbt + (left > 0 ? 1 : 0); if (left > 0) --left; pl.sep_nat0.push_back(at); pl.sep_w.push_back(w); at += w; }
                     }
+                    int sw = 0; for (int w : pl.sep_w) sw += w;
+                    pl.launches = (nC + 1) + (sw - 1);
+                    return pl;
+                };
+                Plan pl = plan_for(2);
+                { Plan p4 = plan_for(4); if (p4.launches < pl.launches) pl = p4; }
+                if (pl.launches < T - 1) {
+                    TwinView& tv = p->twinv;
+                    const int nch = (int)pl.ch.size(), nsep = nch - 1, n32 = cv.Pdpad;
+                    int pt = 0;
+                    for (auto& ch : pl.ch) { ch.p0 = pt; pt += ch.len; }
+                    const int m0 = pt;
+                    std::vector<int> sep_p0(nsep);
+                    for (int q = 0; q < nsep; ++q) { sep_p0[q] = pt; pt += pl.sep_w[q]; }
+                    tv.T = T; tv.m0 = m0; tv.nchains = nch;
+                    std::vector<int32_t> perm(n32), xmap(n32), fac(T, -1);
+                    for (const auto& ch : pl.ch)
+                        for (int j = 0; j < ch.len; ++j)
+                            for (int e = 0; e < 32; ++e) {
+                                const int nat = (ch.nat0 + j) * 32 + e;
+                                perm[nat] = ch.rev ? (ch.p0 + (ch.len - 1 - j)) * 32 + (31 - e) : (ch.p0 + j) * 32 + e;
+                            }
+                    for (int q = 0; q < nsep; ++q)
+                        for (int j = 0; j < pl.sep_w[q] * 32; ++j) perm[pl.sep_nat0[q] * 32 + j] = sep_p0[q] * 32 + j;
+                    for (int i = 0; i < n32; ++i) xmap[perm[i]] = i;
+                    for (const auto& ch : pl.ch) fac[ch.rev ? ch.nat0 + ch.len - 1 : ch.nat0] = ch.p0 | (ch.rev ? 1 << 16 : 0);
                     std::vector<TwinTile> list;
                     tv.off.assign(1, 0);
-                    auto add_chain = [&](int k, int c_lo, int c_hi, int aj_lo, bool is_b, bool last) {      // chain tiles (c_lo, c_hi) after pivot k, then the middle
-                        std::vector<int> S;
-                        for (int c = c_lo; c < c_hi; ++c) S.push_back(c);
-                        for (int c = m0; c < T; ++c) S.push_back(c);
-                        for (size_t a = 0; a < S.size(); ++a)
-                            for (size_t b2 = 0; b2 <= a; ++b2) {
-                                const int r = S[a], c = S[b2];
-                                TwinTile e; e.r = (int16_t)r; e.c = (int16_t)c; e.aj = -1;
-                                e.flags = (int16_t)((is_b && r >= m0 && c >= m0 ? 1 : 0) | ((is_b && last && r == k + 1) ? 2 : 0) | (c == S[0] ? 4 : 0) |
-                                                    ((!is_b && last) ? 8 : 0) | ((!is_b && last && r == m0 && c == m0) ? 16 : 0));      // (top chain's last step: S = the middle)
-                                list.push_back(e);
+                    int nl = 0;
+                    for (const auto& ch : pl.ch) nl = std::max(nl, ch.len);
+                    auto is_sep = [&](int t) { return t >= m0 && t < T; };
+                    for (int t = 0; t < nl; ++t) {
+                        for (int ci = 0; ci < nch; ++ci) {
+                            const Chain& ch = pl.ch[ci];
+                            if (t >= ch.len) continue;
+                            const int k = ch.p0 + t;
+                            const bool last = (t == ch.len - 1);
+                            std::vector<int> S;
+                            for (int c = k + 1; c < ch.p0 + ch.len; ++c) S.push_back(c);
+                            for (int q = 0; q < 2; ++q) if (ch.sep[q] >= 0) for (int j = 0; j < pl.sep_w[ch.sep[q]]; ++j) S.push_back(sep_p0[ch.sep[q]] + j);
+                            std::sort(S.begin(), S.end());
+                            auto push = [&](int r, int c, int aj, int flags) { TwinTile e; e.r = (int16_t)r; e.c = (int16_t)c; e.aj = (int16_t)aj; e.flags = (int16_t)flags; e.k = (int16_t)k; e.pad = 0; list.push_back(e); };
+                            const bool fold = !ch.alt && last;      // this step folds the neighbouring chains' accumulated separator updates in
+                            for (size_t a2 = 0; a2 < S.size(); ++a2)
+                                for (size_t b2 = 0; b2 <= a2; ++b2) {
+                                    const int r = S[a2], c = S[b2];
+                                    const bool ss = is_sep(r) && is_sep(c);
+                                    push(r, c, -1, ((ch.alt && ss) ? 1 : 0) | ((last && r == k + 1) ? 2 : 0) | (c == S[0] ? 4 : 0) | ((fold && ss) ? 8 : 0) | ((fold && ci == 0 && r == m0 && c == m0) ? 16 : 0));
+                                }
+                            if (fold && ci == 0)      // separator cross blocks only an accumulating chain writes ((S2, S1) by C1): folded in here, with a zero panel
+                                for (int c2 = 1; c2 < nch; c2 += 2) {
+                                    const Chain& oc = pl.ch[c2];
+                                    if (oc.sep[1] < 0) continue;
+                                    for (int jr = 0; jr < pl.sep_w[oc.sep[1]]; ++jr)
+                                        for (int jc = 0; jc < pl.sep_w[oc.sep[0]]; ++jc) push(sep_p0[oc.sep[1]] + jr, sep_p0[oc.sep[0]] + jc, -1, 8);
+                                }
+                            for (int c : S) push(T, c, -1, ((ch.alt && is_sep(c)) ? 1 : 0) | (c == S[0] ? 4 : 0) | ((fold && is_sep(c)) ? 8 : 0));
+                            for (int aj = ch.p0; aj < k; ++aj) for (int c : S) push(T, c, aj, c == S[0] ? 4 : 0);
+                            {   // the identity row that STARTS at this step is initialised over every separator, not only the adjacent ones: the separator
+                                // stage reads R(k, c) for all of them, and a non-adjacent block would otherwise hold the previous solve's values
+                                std::vector<int> Sall;
+                                for (int c : S) if (!is_sep(c)) Sall.push_back(c);
+                                for (int c = m0; c < T; ++c) Sall.push_back(c);
+                                for (int c : Sall) push(T, c, k, c == Sall[0] ? 4 : 0);
                             }
-                        for (int c : S) { TwinTile e; e.r = (int16_t)T; e.c = (int16_t)c; e.aj = -1; e.flags = (int16_t)((is_b && c >= m0 ? 1 : 0) | (c == S[0] ? 4 : 0) | ((!is_b && last) ? 8 : 0)); list.push_back(e); }
-                        for (int aj = aj_lo; aj <= k; ++aj) for (int c : S) { TwinTile e; e.r = (int16_t)T; e.c = (int16_t)c; e.aj = (int16_t)aj; e.flags = (int16_t)(c == S[0] ? 4 : 0); list.push_back(e); }
-                    };
-                    for (int t = 0; t < std::max(tv.nA, tv.nB); ++t) {
-                        if (t < tv.nA) add_chain(t, t + 1, tv.nA, 0, false, t == tv.nA - 1);
-                        tv.off.push_back((int)list.size());
-                        if (t < tv.nB) add_chain(tv.nA + t, tv.nA + t + 1, m0, tv.nA, true, t == tv.nB - 1);
+                        }
                         tv.off.push_back((int)list.size());
                     }
-                    HIPCK(p, p->d_twin_list.upload(list)); HIPCK(p, p->d_twin_perm.upload(perm)); HIPCK(p, p->d_twin_xmap.upload(xmap));
+                    tv.nlaunch = nl;
+                    HIPCK(p, p->d_twin_list.upload(list)); HIPCK(p, p->d_twin_perm.upload(perm)); HIPCK(p, p->d_twin_xmap.upload(xmap)); HIPCK(p, p->d_twin_fac.upload(fac));
                     HIPCK(p, p->d_twin_alt.alloc((size_t)(cv.Pdpad + TILE) * cv.Pdpad));
                     tv.list = p->d_twin_list.p;
-                    p->dd.twin_nA = tv.nA; p->dd.twin_nB = tv.nB; p->dd.perm = p->d_twin_perm.p; p->dd.xmap = p->d_twin_xmap.p; p->dd.alt = p->d_twin_alt.p;
+                    p->dd.twin_m0 = m0; p->dd.twin_fac = p->d_twin_fac.p; p->dd.perm = p->d_twin_perm.p; p->dd.xmap = p->d_twin_xmap.p; p->dd.alt = p->d_twin_alt.p;
                     p->twin_ok = true;
                 }
             }
         }
-        if (ptime) fprintf(stderr, "[prepare] dense system: %d dims, %d tiles, band %d sub-diagonal tiles -> %s\n", cv.Pd, T, hbt, p->band_ok ? "banded twisted solve in LDS" : p->twin_ok ? "twin multi-launch factorisation" : "dense path");
+        if (ptime) fprintf(stderr, "[prepare] dense system: %d dims, %d tiles, band %d sub-diagonal tiles -> %s\n", cv.Pd, T, hbt, p->band_ok ? "banded twisted solve in LDS" : p->twin_ok ? "multi-chain multi-launch factorisation" : "dense path");
+        if (ptime && p->twin_ok) fprintf(stderr, "[prepare] %d chains, %d + %d dependent launches\n", p->twinv.nchains, p->twinv.nlaunch, p->twinv.T - p->twinv.m0 - 1);
     }
     lap("exchange list, band");
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
@@ -1533,7 +1586,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     else if (w == "twin") v = {(double)(p->twin_ok ? 1 : 0)};
     else if (w == "fact_launches") {      // dependent launches of one factorisation between the profile events 11 and 12 (bench.py's roofline)
         if (p->band_ok) v = {2.0};
-        else if (p->twin_ok) v = {(double)(p->twinv.nA + (p->twinv.T - p->twinv.nA - p->twinv.nB - 1))};
+        else if (p->twin_ok) v = {(double)(p->twinv.nlaunch + (p->twinv.T - p->twinv.m0 - 1))};
         else v = {-1.0};
     }
     else if (w == "chi2") { HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl))); v = {p->h_ctrl->current_chi}; }

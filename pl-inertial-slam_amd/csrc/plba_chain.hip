@@ -102,12 +102,13 @@ __global__ __launch_bounds__(256) void k_chain_schur(DevBuf d, ChainView cv, Dev
             for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ch][u], bv[ch][u], acc, 0, 0, 0);
     }
     // C/D layout: col = lane & 15, row = (lane >> 4) + 4 v
-    // Twin factorisation (dd.twin_nA > 0): the system is written PERMUTED through dd.perm — [top chain | bottom chain reversed |
-    // middle] — the bottom chain's first tile (the natural LAST diagonal tile, turned around) is factored on the spot like tile
-    // (0,0), and the middle block of dd.alt (the bottom chain's accumulator) is cleared.
-    const bool twin = dd.twin_nA > 0;
-    const bool lastdiag = twin && ta == T - 1 && tb == T - 1;
-    const int m0c = (dd.twin_nA + dd.twin_nB) * 32;      // first permuted index of the middle block
+    // Multi-chain factorisation (dd.twin_m0 > 0): the system is written PERMUTED through dd.perm — [chains | separators] — every
+    // chain's first tile is factored on the spot like tile (0,0) (turned around for the chain that is eliminated bottom-up), and
+    // the separator region of dd.alt (the accumulator of every second chain) is cleared.
+    const bool twin = dd.twin_m0 > 0;
+    const int fsel = (!rhs_row && ta == tb) ? (twin ? dd.twin_fac[ta] : (b == 0 ? 0 : -1)) : -1;      // >= 0: this workgroup factors its tile
+    const bool frev = fsel >= 0 && (fsel >> 16) != 0;
+    const int m0c = dd.twin_m0 * 32;      // first permuted index of the separator region
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int lr = tr * 16 + lk + 4 * v, lc = tc * 16 + li;
@@ -123,16 +124,15 @@ __global__ __launch_bounds__(256) void k_chain_schur(DevBuf d, ChainView cv, Dev
             dd.sys[(size_t)pca * ldd + pcb] = out;
             if (ta != tb) dd.sys[(size_t)pcb * ldd + pca] = out;     // keep the matrix symmetric (debug readers; the permuted lower triangle may be the natural upper one)
             if (twin && pca >= m0c && pcb >= m0c) { dd.alt[(size_t)pca * ldd + pcb] = 0.0; if (ta != tb) dd.alt[(size_t)pcb * ldd + pca] = 0.0; }
-            if (b == 0) sC0[lr * LS + lc] = out;
-            else if (lastdiag) sC0[(31 - lr) * LS + (31 - lc)] = out;
+            if (fsel >= 0) sC0[(frev ? 31 - lr : lr) * LS + (frev ? 31 - lc : lc)] = out;
         }
     }
-    if ((b != 0 && !lastdiag) || dd.flow || dd.wide || dd.band) return;
+    if (fsel < 0 || dd.flow || dd.wide || dd.band) return;
     // tile (0,0) is complete in LDS: run the look-ahead pipeline of the factorisation on it right here (L(0,0) -> dd.Lfac,
     // L(0,0)^-1 -> dd.Linv32[0]) instead of in a launch of its own (k_potrf0_32): the first block step follows directly
     look32_reset(S0, threadIdx.x);
     __syncthreads();
-    lookahead_factor32<false>(dd, b == 0 ? 0 : dd.twin_nA, sC0, S0, wv, lane);
+    lookahead_factor32<false>(dd, fsel & 0xffff, sC0, S0, wv, lane);
 }
 
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s) {

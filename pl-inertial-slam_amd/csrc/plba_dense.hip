@@ -444,22 +444,25 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// Two-ended ("twin") factorisation of a block-banded system.  g2o's solver is a SPARSE Cholesky; the reduced camera system is
-// banded in keyframe order (tracks span a few keyframes), so its two ends can be eliminated independently.  Stored permuted
-// as [top nA tiles | bottom nB tiles reversed | middle] (k_chain_schur writes through d.perm) the two ends are two chains of
-// ONE right-looking Cholesky whose steps do not read each other's data: launch t runs step t (chain A) and step nA + t
-// (chain B) side by side, each over its own tile list (its remaining chain tiles, the middle tiles, the right-hand-side row,
-// its identity rows).  Both chains update the middle block: chain B (one tile shorter than chain A) adds its part into
-// d.alt (zeroed by the producer); chain A's LAST step, alone in its launch, folds that in (cold += alt) and factors the first
-// middle tile by look-ahead as any other step does; the ordinary steps finish the middle.  T - 1 dependent launches become
-// nA + (T - nA - nB - 1).
+// Multi-chain ("twin") factorisation of a block-banded system.  g2o's solver is a SPARSE Cholesky; the reduced camera system is
+// banded in keyframe order (tracks span a few keyframes), so stretches of the band that are further apart than its width can
+// be eliminated independently.  The band is cut into chains separated by separators at least as wide as the band — two chains
+// (the two ends, one separator in the middle) for short systems, four chains and three separators for long ones — and stored
+// permuted as [chain 0 | chain 1 | ... | separators] (k_chain_schur writes through d.perm; the last chain is turned around so
+// that it, too, is eliminated towards its separator).  The chains are then stretches of ONE right-looking Cholesky whose steps
+// do not read each other's data: launch t runs step t of every chain side by side, each workgroup taking its tile from a
+// host-built list (the chain's remaining tiles, its adjacent separators, the right-hand-side row, its identity rows).
+// Separator blocks have two writers; every second chain therefore accumulates its separator updates in d.alt (zeroed by the
+// producer) and is one tile shorter, so that the other chains' LAST step — alone in its launch — folds those in (cold += alt)
+// and factors the first separator tile by look-ahead, as any other step does.  Ordinary steps finish the separator region.
+// T - 1 dependent launches become  (longest chain) + (separator tiles - 1):  11 -> 7 at configs[2], 43 -> 18 at configs[4].
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol32_list(DevBuf d, int kA, int kB, int T, const TwinTile* list, int nAent) {
+__global__ __launch_bounds__(256) void k_chol32_list(DevBuf d, int T, const TwinTile* list) {
     __shared__ __attribute__((aligned(16))) double sX[64 * LS];
     __shared__ __attribute__((aligned(16))) double sC[32 * LS];
     __shared__ __attribute__((aligned(16))) Look32 S;
     const TwinTile e = list[blockIdx.x];
-    const int k = (int)blockIdx.x < nAent ? kA : kB;
+    const int k = e.k;
     if (e.aj >= 0) chol32_tile<true>(d, k, T, e.r, e.c, e.aj, 0, (e.flags & 4) != 0, sX, sC, S);
     else chol32_tile<false>(d, k, T, e.r, e.c, 0, e.flags, (e.flags & 4) != 0, sX, sC, S);
 }
@@ -1014,10 +1017,10 @@ static void launch_cholesky_nb(const DevBuf& d, bool use_mfma, hipStream_t s) {
 }
 static bool inverse_panels(const DevBuf& d, bool use_mfma) { return d.fb == 32 && use_mfma; }
 void launch_twin_cholesky(const DevBuf& d, const TwinView& tv, hipStream_t s) {
-    const int T = tv.T, m0 = tv.nA + tv.nB, nl = std::max(tv.nA, tv.nB);
-    for (int t = 0; t < nl; ++t) {
-        const int a0 = tv.off[2 * t], b0 = tv.off[2 * t + 1], e1 = tv.off[2 * t + 2];
-        if (e1 > a0) hipLaunchKernelGGL(k_chol32_list, dim3(e1 - a0), dim3(256), 0, s, d, t, tv.nA + t, T, tv.list + a0, b0 - a0);
+    const int T = tv.T, m0 = tv.m0;
+    for (int t = 0; t < tv.nlaunch; ++t) {
+        const int n = tv.off[t + 1] - tv.off[t];
+        if (n > 0) hipLaunchKernelGGL(k_chol32_list, dim3(n), dim3(256), 0, s, d, T, tv.list + tv.off[t]);
     }
     for (int k = m0; k < T - 1; ++k) {      // the last step (panels only) is folded into k_back_gemv, as in launch_cholesky
         const int nt = T - k - 1;

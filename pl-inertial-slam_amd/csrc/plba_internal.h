@@ -105,9 +105,11 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     int* chol_flags;       // (T32 + 1) x T32 tile flags + T32 inverse flags of the single-launch factorisation (epoch-stamped)
     double* dbgbuf;        // 64 doubles for diagnostic builds (cycle stamps)
     int band;              // 1: the banded twisted solver handles this system (plba_band.hip): k_chain_schur leaves tile (0,0) unfactored
-    // two-ended multi-launch factorisation of a banded system ("twin", plba_dense.hip): the system is stored PERMUTED
-    // [top nA tiles | bottom nB tiles, reversed | middle], so that the two ends are two independent chains of one Cholesky
-    int twin_nA, twin_nB;  // 0: off
+    // multi-chain ("twin") form of the multi-launch factorisation of a banded system (plba_dense.hip): the system is stored
+    // PERMUTED [chain 0 | chain 1 | ... | separators], so that the chains are independent stretches of one Cholesky
+    int twin_m0;           // first (permuted) tile of the separator region; 0: off
+    const int32_t* twin_fac;   // per NATURAL diagonal tile: -1, or the permuted tile it becomes as the first tile of a chain (| 1 << 16: turned
+                               // around) — k_chain_schur factors those on the spot
     const int32_t* perm;   // Ppad: natural dense index -> permuted (k_chain_schur writes through it)
     const int32_t* xmap;   // Ppad: permuted -> natural (k_back_gemv writes x through it)
     double* alt;           // same shape as sys: the bottom chain's updates of the middle block (folded in by the top chain's last step)
@@ -195,14 +197,14 @@ void launch_band_solve(const DevBuf& dd, const BandView& bv, hipStream_t s);    
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s);
 void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);   // writes dd.sys
 // one workgroup of a list-driven block step: block row / column, identity row (-1: a tile of the factorisation proper), flags
-struct TwinTile { int16_t r, c, aj, flags; };      // flags: 1 = writes d.alt instead of d.sys, 2 = no look-ahead on this tile, 4 = c is the step's first trailing column (stores the finished panel block),
+struct TwinTile { int16_t r, c, aj, flags, k, pad; };      // k: the pivot tile of the step this workgroup belongs to      // flags: 1 = writes d.alt instead of d.sys, 2 = no look-ahead on this tile, 4 = c is the step's first trailing column (stores the finished panel block),
                                                    // 8 = add d.alt's tile to the old value first, 16 = this (diagonal) tile is the next pivot: factor it here
 struct TwinView {
-    int T, nA, nB;                 // tiles; length of the top / bottom chain (middle = T - nA - nB >= band width)
-    const TwinTile* list;          // all launches' tiles, launch t = [off[2 t], off[2 t + 1]) chain A, [off[2 t + 1], off[2 t + 2]) chain B
+    int T, m0, nchains, nlaunch;   // tiles; first tile of the separator region; chains; launches of the chain stage
+    const TwinTile* list;          // all launches' tiles: launch t = [off[t], off[t + 1])
     std::vector<int> off;          // host side
 };
-void launch_twin_cholesky(const DevBuf& d, const TwinView& tv, hipStream_t s);      // sys (permuted; tiles 0 and nA factored by the producer) -> Lfac, Ninv
+void launch_twin_cholesky(const DevBuf& d, const TwinView& tv, hipStream_t s);      // sys (permuted; every chain's first tile factored by the producer) -> Lfac, Ninv
 void launch_cholesky(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s, bool tile0_done = false);   // sys -> Lfac (lower) incl. the augmented rows;
                                                                                      // tile0_done: the producer of sys already factored tile (0,0) (k_chain_schur)
 bool chain_schur_factors_tile0(const DevBuf& dd);
