@@ -106,9 +106,12 @@ def parity_and_config4(w, pkg):
     d["landmarks_m"] = float(max(np.abs(g.get_points() - o.get_points()).max(), np.abs(g.get_lines() - o.get_lines()).max()))
     d["tolerance"] = 1e-5
     o.close()
-    t0 = time.perf_counter()
-    prior = g.marginalize(0, pkg.protocol.MARG_NUM)
-    t_marg = time.perf_counter() - t0
+    t_marg = None
+    for _ in range(3):                  # best of three, as for the end-to-end call: the first one pays for module load and first-touch allocations
+        t0 = time.perf_counter()
+        prior = g.marginalize(0, pkg.protocol.MARG_NUM)
+        dt_m = time.perf_counter() - t0
+        t_marg = dt_m if t_marg is None else min(t_marg, dt_m)
     g.close()
     w2 = dict(w); w2["prior"] = prior
     g2 = pkg.new_problem()
