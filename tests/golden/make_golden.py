@@ -83,8 +83,34 @@ def run_preint(pkg):
                 checksum=float(np.abs(out).sum()))
 
 
+LBA_CASES = {"lba": dict(K=6, Np=80, Nl=16, n_fixed=2, seed=0x601D04, variant=0, max_iters=15),
+             "gba": dict(K=6, Np=80, Nl=16, n_fixed=1, seed=0x601D05, variant=1, max_iters=6)}
+
+
+def lba_opts(c):
+    eps = float(np.finfo(float).eps)
+    return dict(variant=1, min_error=eps, min_error_change=eps, max_iters=c["max_iters"]) if c["variant"] else dict(max_iters=c["max_iters"])
+
+
+def run_lba(pkg):
+    """the pre-init visual-only optimiser (MapHandler::levMarquardtOptimizationLBA / ...GBA) on make_visual_window"""
+    out = {}
+    for name, c in LBA_CASES.items():
+        w = pkg.window.make_visual_window(K=c["K"], Np=c["Np"], Nl=c["Nl"], n_fixed=c["n_fixed"], seed=c["seed"])
+        p = orc.new_problem()
+        r = p.lba_visual(w["T_kf_w"], w["kf_loc"], w["xyz"], w["pq"], w["po_pt"], w["po_kf"], w["uv"], w["lo_ln"], w["lo_kf"], w["l3"], w["cam"], **lba_opts(c))
+        p.close()
+        out[name] = dict(meta=dict(c, Ep=int(len(w["po_pt"])), El=int(len(w["lo_ln"]))), iterations=int(r["iterations"]), updates=int(r["updates"]),
+                         err_first=float(r["err_first"]), err_last=(None if not np.isfinite(r["err_last"]) else float(r["err_last"])), lam=float(r["lam"]),
+                         T=r["T"].tolist(), xyz_head=r["xyz"][:5].tolist(), xyz_checksum=float(np.abs(r["xyz"]).sum()), pq_checksum=float(np.abs(r["pq"]).sum()),
+                         pt_moved=int(r["pt_moved"].sum()), ln_moved=int(r["ln_moved"].sum()))
+    return out
+
+
 def main():
     pkg = ge.load_package()
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lba_small.json"), "w") as f:
+        json.dump(run_lba(pkg), f, indent=0)
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "preint_small.json"), "w") as f:
         json.dump(run_preint(pkg), f, indent=0)
     for name, c in CASES.items():

@@ -87,3 +87,33 @@ def test_oracle_reproduces_the_preintegration_golden(pkg, orc):
 @pytest.mark.gpu
 def test_hip_matches_the_preintegration_golden(pkg, hip):
     _check_preint(pkg, pkg.new_problem, 1e-11)
+
+
+def _check_lba(pkg, new_problem, tol):
+    from tests.golden.make_golden import LBA_CASES, lba_opts
+    g = _load("lba_small")
+    for name, c in LBA_CASES.items():
+        e = g[name]
+        assert {k: e["meta"][k] for k in c} == c
+        w = pkg.window.make_visual_window(K=c["K"], Np=c["Np"], Nl=c["Nl"], n_fixed=c["n_fixed"], seed=c["seed"])
+        assert (len(w["po_pt"]), len(w["lo_ln"])) == (e["meta"]["Ep"], e["meta"]["El"])          # the generator itself is pinned
+        p = new_problem()
+        r = p.lba_visual(w["T_kf_w"], w["kf_loc"], w["xyz"], w["pq"], w["po_pt"], w["po_kf"], w["uv"], w["lo_ln"], w["lo_kf"], w["l3"], w["cam"], **lba_opts(c))
+        p.close()
+        assert (r["iterations"], r["updates"]) == (e["iterations"], e["updates"])
+        assert r["err_first"] == pytest.approx(e["err_first"], rel=tol) and r["lam"] == pytest.approx(e["lam"], rel=tol)
+        assert (e["err_last"] is None and not np.isfinite(r["err_last"])) or r["err_last"] == pytest.approx(e["err_last"], rel=1e3 * tol)
+        ptol = max(1e3 * tol, 1e-9)
+        assert np.abs(r["T"] - np.array(e["T"])).max() < ptol
+        assert np.abs(r["xyz"][:5] - np.array(e["xyz_head"])).max() < 10 * ptol
+        assert np.abs(r["xyz"]).sum() == pytest.approx(e["xyz_checksum"], rel=ptol) and np.abs(r["pq"]).sum() == pytest.approx(e["pq_checksum"], rel=ptol)
+        assert (int(r["pt_moved"].sum()), int(r["ln_moved"].sum())) == (e["pt_moved"], e["ln_moved"])
+
+
+def test_oracle_reproduces_the_lba_golden(pkg, orc):
+    _check_lba(pkg, orc.new_problem, 1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_matches_the_lba_golden(pkg, hip):
+    _check_lba(pkg, pkg.new_problem, 1e-9)
