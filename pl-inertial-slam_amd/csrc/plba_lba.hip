@@ -14,7 +14,7 @@
 // Kernel map (one iteration): k_lba_poses -> k_lba_landmarks (thread per landmark, observations landmark-major as
 // the reference's lists are) -> k_lba_posesys (workgroup per local keyframe over its observations) -> k_lba_reduce
 // -> [host: err, lambda] -> k_lba_sysinit -> k_lba_dinv -> k_lba_pairs -> k_lba_rhs -> Cholesky / back-substitution (plba_dense.hip)
-// -> k_lba_backsub -> k_lba_update (gated on solver_ok) -> k_lba_dxnorm -> [host: |DX|].
+// -> k_lba_backsub -> k_lba_update (|DX|^2; the update itself gated on solver_ok) -> [host: |DX|].
 #include "plba_internal.h"
 #include "plba_problem.h"
 
@@ -396,8 +396,6 @@ __device__ bool spd_inv_packed(const double* Hp, double* Dp) {
 }
 template <int N>
 __device__ __forceinline__ void sym_mul_packed(const double* Dp, const double* v, double* o) {
-    constexpr int S = 6;      // packing stride of the 6-wide layout; points pack 3 wide
-    (void)S;
     double M[N][N];
     int q = 0;
 #pragma unroll
