@@ -218,3 +218,24 @@ def test_twin_factorisation_reports_a_non_positive_pivot(pkg, hip):
     g.debug_build(-1e13, True)               # lambda far below zero: indefinite on purpose
     assert g.debug_get("twin")[0] == 1 and g.debug_get("solver_ok")[0] == 0
     g.close()
+
+
+@pytest.mark.parametrize("K,seed,prior,fixed,lam0", [(30, 2, False, False, 0.0), (41, 5, False, True, 1e3), (64, 9, True, False, 0.0), (110, 14, False, False, 0.0),
+                                                     (128, 15, True, False, 1e3), (170, 17, False, True, 0.0)])
+def test_multi_chain_plans_against_the_oracle(pkg, orc, hip, K, seed, prior, fixed, lam0):
+    """tools/soak_solver.py in small: window lengths that give two- and four-chain plans with separators of different widths
+    (a marginalization prior widens the band), fixed keyframes, an overshooting lambda_init (rejected trials)"""
+    w = pkg.window.make_window(K, 12 * K, 3 * K, imu=True, seed=0x50A0 + seed)
+    if prior:
+        p0 = pkg.new_problem(); p0.upload_window(w); pkg.protocol.local_ba(p0); pr = p0.marginalize(0, 50); p0.close()
+        w = pkg.window.make_window(K, 12 * K, 3 * K, imu=True, seed=0x50A0 + seed); w["prior"] = pr
+    if fixed:
+        w["kf"]["fixed_pvr"] = np.zeros(K, np.uint8); w["kf"]["fixed_pvr"][:2] = 1
+    g = pkg.new_problem(user_lambda_init=lam0); g.upload_window(w)
+    o = orc.new_problem(user_lambda_init=lam0); o.upload_window(w)
+    sg, so = g.optimize(5), o.optimize(5)
+    assert g.debug_get("twin")[0] == 1
+    assert (sg.iterations, sg.trials, sg.solver_failures) == (so.iterations, so.trials, so.solver_failures)
+    assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-8)
+    assert max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)) < 1e-8
+    g.close(); o.close()
