@@ -77,7 +77,7 @@ typedef struct {
                                    0 = one launch per 32 columns                                                    (0) */
     int    band_solve;          /* how the band of the compact dense system (after the chain elimination) is used when it has at most
                                    three sub-diagonal 32 x 32 tiles — tracks spanning a few consecutive keyframes, as in a sliding
-                                   window.  1 = from 8 to 48 tiles the band is cut into two or four chains that are eliminated side by
+                                   window.  1 = from 8 to 64 tiles the band is cut into two or four chains that are eliminated side by
                                    side in every launch of the dense factorisation (multi-chain form, plba_dense.hip: T - 1 dependent
                                    launches become about T / 2 or less); longer systems are factored and solved by two workgroups walking the band from
                                    both ends with the window resident in LDS (plba_band.hip).  2 = the in-LDS form from 8 tiles on

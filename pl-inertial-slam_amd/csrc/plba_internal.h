@@ -183,7 +183,7 @@ struct ChainView {
 };
 // banded twisted solve of the compact dense system (plba_band.hip)
 constexpr int BAND_HB = 3;        // sub-diagonal 32 x 32 tiles of the band it supports
-constexpr int TWIN_MAX_TILES = 48;   // longest system (32-column tiles) the two-ended multi-launch factorisation takes (its explicit inverse costs 2 Pd^2
+constexpr int TWIN_MAX_TILES = 64;   // longest system (32-column tiles) the two-ended multi-launch factorisation takes (its explicit inverse costs 2 Pd^2
                                      // doubles); longer ones go to the in-LDS sweep.  configs[4] (44 tiles): twin 0.80 ms / iteration, in-LDS sweep 0.95
 constexpr int BAND_MIN_TILES = 24;   // shortest system (in 32-column tiles) the two-ended sweep is used for: below, one launch per tile is faster
 struct BandView {
