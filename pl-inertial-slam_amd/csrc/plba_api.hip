@@ -875,7 +875,7 @@ static int prepare(plba_problem* p) {
     //   8 <= T < 24  : the two-ended ("twin") form of the multi-launch factorisation (plba_dense.hip): same kernels, the two ends
     //                  of the band eliminated side by side in each launch
     p->band_ok = false; p->twin_ok = false;
-    p->dd.band = 0; p->dd.twin_m0 = 0; p->dd.twin_fac = nullptr; p->dd.perm = nullptr; p->dd.xmap = nullptr; p->dd.alt = nullptr;
+    p->dd.band = 0; p->dd.twin_m0 = 0; p->dd.twin_fac = nullptr; p->dd.perm = nullptr; p->dd.xmap = nullptr; p->dd.alt = nullptr; p->dd.alt2 = nullptr;
     if (p->chain_ok && p->opt.band_solve && !p->dv.flow && !p->dv.wide) {      // (sharded runs: the lists above hold the GLOBAL structure)
         const ChainView& cv = p->cv;
         const int T = cv.Pdpad / 32;
@@ -908,96 +908,169 @@ static int prepare(plba_problem* p) {
                 //   two chains :  C0 (n + 1 tiles) | S1 | C1 (n tiles, eliminated bottom-up)
                 //   four chains:  C0 (n + 1) | S1 | C1 (n) | S2 | C2 (n + 1) | S3 | C3 (n, bottom-up)
                 // separators >= hbt tiles wide (chains must not couple); C1 / C3 accumulate their separator updates in `alt` and are one tile
-                // shorter, so that the last step of C0 / C2 folds those in.  The variant with fewer dependent launches is taken.
-                struct Chain { int nat0, len; bool rev, alt; int sep[2]; int p0; };
-                struct Plan { std::vector<Chain> ch; std::vector<int> sep_nat0, sep_w; int launches; };
-                auto plan_for = [&](int nch) {
-                    Plan pl; pl.launches = 1 << 30;
+                // shorter, so that the last step of C0 / C2 folds those in.  With four chains the separator region [S1 S2 S3] is itself
+                // block-tridiagonal and is taken the same way once more (second stage): S1 top-down and S3 bottom-up (one tile shorter,
+                // accumulating in `alt2`) towards S2.  The variant with the fewest dependent launches is taken.
+                struct Chain { int nat0, len; bool rev; int alt; int stage; std::vector<int> later, rows; int p0; };      // alt: 0 = writes sys, 1 = alt, 2 = alt2
+                struct Region { int nat0, w; };
+                auto build = [&](int nch, bool nested, std::vector<Chain>& chains, int& launches, int& f0_out, int& m0_out, std::vector<int32_t>& perm) {
+                    chains.clear(); launches = 1 << 30;
                     const int nsep = nch - 1;
-                    const int nC = (T - nsep * hbt - nch / 2) / nch;      // nch/2 chains carry the extra tile
-                    if (nC < 1) return pl;
+                    const int nC = (T - nsep * hbt - nch / 2) / nch;      // nch / 2 chains carry the extra tile
+                    if (nC < 1) return;
                     int left = T - nsep * hbt - nch / 2 - nch * nC;      // tiles that do not divide: widen the first separators
+                    std::vector<Region> seps;
                     int at = 0;
                     for (int c = 0; c < nch; ++c) {
-                        Chain ch; ch.nat0 = at; ch.len = nC + ((c & 1) ? 0 : 1); ch.alt = (c & 1) != 0; ch.rev = (c == nch - 1);
-                        ch.sep[0] = c == 0 ? 0 : (c == nch - 1 ? nsep - 1 : c - 1); ch.sep[1] = (c == 0 || c == nch - 1) ? -1 : c; ch.p0 = 0;
+                        Chain ch; ch.nat0 = at; ch.len = nC + ((c & 1) ? 0 : 1); ch.alt = (c & 1) ? 1 : 0; ch.rev = (c == nch - 1); ch.stage = 0; ch.p0 = 0;
                         at += ch.len;
-                        pl.ch.push_back(ch);
-                        if (c < nsep) { const int w = hbt + (left > 0 ? 1 : 0); if (left > 0) --left; pl.sep_nat0.push_back(at); pl.sep_w.push_back(w); at += w; }
+                        chains.push_back(ch);
+                        if (c < nsep) { const int w = hbt + (left > 0 ? 1 : 0); if (left > 0) --left; seps.push_back({at, w}); at += w; }
                     }
-                    int sw = 0; for (int w : pl.sep_w) sw += w;
-                    pl.launches = (nC + 1) + (sw - 1);
-                    return pl;
-                };
-                Plan pl = plan_for(2);
-                { Plan p4 = plan_for(4); if (p4.launches < pl.launches) pl = p4; }
-                if (pl.launches < T - 1) {
-                    TwinView& tv = p->twinv;
-                    const int nch = (int)pl.ch.size(), nsep = nch - 1, n32 = cv.Pdpad;
+                    // permuted positions: level-1 chains, then (nested) S1 | S3 reversed | S2, else the separators in natural order
                     int pt = 0;
-                    for (auto& ch : pl.ch) { ch.p0 = pt; pt += ch.len; }
-                    const int m0 = pt;
-                    std::vector<int> sep_p0(nsep);
-                    for (int q = 0; q < nsep; ++q) { sep_p0[q] = pt; pt += pl.sep_w[q]; }
-                    tv.T = T; tv.m0 = m0; tv.nchains = nch;
-                    std::vector<int32_t> perm(n32), xmap(n32), fac(T, -1);
-                    for (const auto& ch : pl.ch)
-                        for (int j = 0; j < ch.len; ++j)
-                            for (int e = 0; e < 32; ++e) {
-                                const int nat = (ch.nat0 + j) * 32 + e;
-                                perm[nat] = ch.rev ? (ch.p0 + (ch.len - 1 - j)) * 32 + (31 - e) : (ch.p0 + j) * 32 + e;
-                            }
-                    for (int q = 0; q < nsep; ++q)
-                        for (int j = 0; j < pl.sep_w[q] * 32; ++j) perm[pl.sep_nat0[q] * 32 + j] = sep_p0[q] * 32 + j;
+                    for (auto& ch : chains) { ch.p0 = pt; pt += ch.len; }
+                    m0_out = pt;
+                    std::vector<int> sep_p0(nsep, 0);
+                    std::vector<char> sep_rev(nsep, 0);
+                    int lenA = 0, lenB = 0;
+                    if (nested && nsep == 3) {
+                        lenA = seps[0].w; lenB = std::min(seps[2].w, lenA - 1);
+                        if (lenB < 1) return;
+                        sep_p0[0] = pt; pt += seps[0].w;
+                        sep_p0[2] = pt; pt += seps[2].w; sep_rev[2] = 1;
+                        sep_p0[1] = pt; pt += seps[1].w;
+                    } else {
+                        if (nested) return;
+                        for (int q = 0; q < nsep; ++q) { sep_p0[q] = pt; pt += seps[q].w; }
+                    }
+                    perm.assign(cv.Pdpad, 0);
+                    auto map_range = [&](int nat0, int w, int p0, bool rev) {
+                        for (int j = 0; j < w; ++j)
+                            for (int e = 0; e < 32; ++e) perm[(nat0 + j) * 32 + e] = rev ? (p0 + (w - 1 - j)) * 32 + (31 - e) : (p0 + j) * 32 + e;
+                    };
+                    for (const auto& ch : chains) map_range(ch.nat0, ch.len, ch.p0, ch.rev);
+                    for (int q = 0; q < nsep; ++q) map_range(seps[q].nat0, seps[q].w, sep_p0[q], sep_rev[q] != 0);
+                    auto tiles_of = [&](int q) { std::vector<int> v; for (int j = 0; j < seps[q].w; ++j) v.push_back(sep_p0[q] + j); return v; };
+                    for (int c = 0; c < nch; ++c) {      // what a level-1 chain couples with beyond itself: its adjacent separators
+                        std::vector<int> qs;
+                        if (c == 0) qs = {0}; else if (c == nch - 1) qs = {nsep - 1}; else qs = {c - 1, c};
+                        for (int q : qs) { auto v = tiles_of(q); chains[c].later.insert(chains[c].later.end(), v.begin(), v.end()); }
+                        std::sort(chains[c].later.begin(), chains[c].later.end());
+                    }
+                    int stage1 = 0;
+                    for (const auto& ch : chains) stage1 = std::max(stage1, ch.len);
+                    if (nested) {
+                        // second stage: S1 (all of it) and the first lenB tiles of the turned-around S3; what is left of S3 joins S2 as the final block
+                        Chain a; a.nat0 = 0; a.len = lenA; a.rev = false; a.alt = 0; a.stage = 1; a.p0 = sep_p0[0];
+                        Chain b2; b2.nat0 = 0; b2.len = lenB; b2.rev = true; b2.alt = 2; b2.stage = 1; b2.p0 = sep_p0[2];
+                        f0_out = sep_p0[2] + lenB;
+                        for (int t2 = f0_out; t2 < T; ++t2) { a.later.push_back(t2); b2.later.push_back(t2); }
+                        for (int c : {0, 1}) for (int j = 0; j < chains[c].len; ++j) a.rows.push_back(chains[c].p0 + j);      // rows with support on S1's columns
+                        for (int c : {2, 3}) for (int j = 0; j < chains[c].len; ++j) b2.rows.push_back(chains[c].p0 + j);
+                        chains.push_back(a); chains.push_back(b2);
+                        launches = stage1 + lenA + (T - f0_out - 1);
+                    } else {
+                        f0_out = m0_out;
+                        launches = stage1 + (T - f0_out - 1);
+                    }
+                };
+                std::vector<Chain> chains, ctry;
+                std::vector<int32_t> perm, ptry;
+                int launches = 1 << 30, f0 = 0, m0 = 0;
+                for (int variant = 0; variant < 3; ++variant) {
+                    int l = 0, f = 0, m = 0;
+                    build(variant == 0 ? 2 : 4, variant == 2, ctry, l, f, m, ptry);
+                    if (l < launches) { launches = l; f0 = f; m0 = m; chains.swap(ctry); perm.swap(ptry); }
+                }
+                if (launches < T - 1) {
+                    TwinView& tv = p->twinv;
+                    const int n32 = cv.Pdpad;
+                    tv.T = T; tv.m0 = f0; tv.nchains = (int)chains.size();
+                    std::vector<int32_t> xmap(n32), fac(T, -1);
                     for (int i = 0; i < n32; ++i) xmap[perm[i]] = i;
-                    for (const auto& ch : pl.ch) fac[ch.rev ? ch.nat0 + ch.len - 1 : ch.nat0] = ch.p0 | (ch.rev ? 1 << 16 : 0);
+                    for (const auto& ch : chains) if (ch.stage == 0) fac[ch.rev ? ch.nat0 + ch.len - 1 : ch.nat0] = ch.p0 | (ch.rev ? 1 << 16 : 0);
                     std::vector<TwinTile> list;
                     tv.off.assign(1, 0);
-                    int nl = 0;
-                    for (const auto& ch : pl.ch) nl = std::max(nl, ch.len);
-                    auto is_sep = [&](int t) { return t >= m0 && t < T; };
-                    for (int t = 0; t < nl; ++t) {
-                        for (int ci = 0; ci < nch; ++ci) {
-                            const Chain& ch = pl.ch[ci];
-                            if (t >= ch.len) continue;
-                            const int k = ch.p0 + t;
-                            const bool last = (t == ch.len - 1);
-                            std::vector<int> S;
-                            for (int c = k + 1; c < ch.p0 + ch.len; ++c) S.push_back(c);
-                            for (int q = 0; q < 2; ++q) if (ch.sep[q] >= 0) for (int j = 0; j < pl.sep_w[ch.sep[q]]; ++j) S.push_back(sep_p0[ch.sep[q]] + j);
-                            std::sort(S.begin(), S.end());
-                            auto push = [&](int r, int c, int aj, int flags) { TwinTile e; e.r = (int16_t)r; e.c = (int16_t)c; e.aj = (int16_t)aj; e.flags = (int16_t)flags; e.k = (int16_t)k; e.pad = 0; list.push_back(e); };
-                            const bool fold = !ch.alt && last;      // this step folds the neighbouring chains' accumulated separator updates in
-                            for (size_t a2 = 0; a2 < S.size(); ++a2)
-                                for (size_t b2 = 0; b2 <= a2; ++b2) {
-                                    const int r = S[a2], c = S[b2];
-                                    const bool ss = is_sep(r) && is_sep(c);
-                                    push(r, c, -1, ((ch.alt && ss) ? 1 : 0) | ((last && r == k + 1) ? 2 : 0) | (c == S[0] ? 4 : 0) | ((fold && ss) ? 8 : 0) | ((fold && ci == 0 && r == m0 && c == m0) ? 16 : 0));
+                    int nlaunch = 0;
+                    for (int stage = 0; stage < 2; ++stage) {
+                        int nl = 0;
+                        for (const auto& ch : chains) if (ch.stage == stage) nl = std::max(nl, ch.len);
+                        // the tile a sys-writing chain's last step factors by look-ahead: the first tile of the next stage's first chain (or of
+                        // the final block), and — first stage of a nested plan — C2's last step factors the second-stage chain S3's first tile
+                        for (int t = 0; t < nl; ++t) {
+                            int ci_stage = 0;
+                            for (size_t ci = 0; ci < chains.size(); ++ci) {
+                                const Chain& ch = chains[ci];
+                                if (ch.stage != stage) continue;
+                                const int cis = ci_stage++;
+                                if (t >= ch.len) continue;
+                                const int k = ch.p0 + t;
+                                const bool last = (t == ch.len - 1);
+                                std::vector<int> S;
+                                for (int c = k + 1; c < ch.p0 + ch.len; ++c) S.push_back(c);
+                                S.insert(S.end(), ch.later.begin(), ch.later.end());
+                                std::sort(S.begin(), S.end());
+                                const int later0 = ch.later.empty() ? T : *std::min_element(ch.later.begin(), ch.later.end());
+                                auto in_later = [&](int x) { return std::binary_search(ch.later.begin(), ch.later.end(), x); };
+                                auto push = [&](int r, int c, int aj, int flags) { TwinTile e; e.r = (int16_t)r; e.c = (int16_t)c; e.aj = (int16_t)aj; e.flags = (int16_t)flags; e.k = (int16_t)k; e.pad = 0; list.push_back(e); };
+                                const bool fold = ch.alt == 0 && last;      // this step folds the accumulating chains' part of its later tiles in
+                                const int asel = stage == 1 ? 32 : 0;         // second stage accumulates in alt2
+                                // look-ahead targets of a folding step
+                                int look1 = -1;
+                                if (fold) {
+                                    if (stage == 0) {
+                                        bool has_stage1 = false;
+                                        for (const auto& c2 : chains) has_stage1 |= c2.stage == 1;
+                                        if (cis == 0) look1 = has_stage1 ? chains[chains.size() - 2].p0 : f0;        // C0: S1's first tile (= m0), or the final block's
+                                        else if (has_stage1 && cis == 2) look1 = chains.back().p0;                     // C2: the turned-around S3's first tile
+                                    } else if (cis == 0) look1 = f0;                                                     // S1: the final block's first tile
                                 }
-                            if (fold && ci == 0)      // separator cross blocks only an accumulating chain writes ((S2, S1) by C1): folded in here, with a zero panel
-                                for (int c2 = 1; c2 < nch; c2 += 2) {
-                                    const Chain& oc = pl.ch[c2];
-                                    if (oc.sep[1] < 0) continue;
-                                    for (int jr = 0; jr < pl.sep_w[oc.sep[1]]; ++jr)
-                                        for (int jc = 0; jc < pl.sep_w[oc.sep[0]]; ++jc) push(sep_p0[oc.sep[1]] + jr, sep_p0[oc.sep[0]] + jc, -1, 8);
+                                (void)later0;
+                                for (size_t a2 = 0; a2 < S.size(); ++a2)
+                                    for (size_t b2 = 0; b2 <= a2; ++b2) {
+                                        const int r = S[a2], c = S[b2];
+                                        const bool ss = in_later(r) && in_later(c);
+                                        push(r, c, -1, ((ch.alt && ss) ? (1 | asel) : 0) | ((last && r == k + 1) ? 2 : 0) | (c == S[0] ? 4 : 0) | ((fold && ss) ? (8 | asel) : 0) | ((fold && r == look1 && c == look1) ? 16 : 0));
+                                    }
+                                if (fold && stage == 0 && cis == 0)      // separator cross blocks only an accumulating chain writes ((S2, S1) by C1): folded in here, with a zero panel
+                                    for (size_t c2 = 0; c2 < chains.size(); ++c2) {
+                                        const Chain& oc = chains[c2];
+                                        if (oc.stage != 0 || oc.alt == 0 || c2 == 0 || c2 + 1 == chains.size()) continue;
+                                        // oc.later = two separators' tiles: every (r, c) pair with r, c in DIFFERENT separators
+                                        for (int r : oc.later) for (int c : oc.later) {
+                                            if (r <= c) continue;
+                                            bool same = false;      // same separator <=> covered by a sys-writer's own list
+                                            for (size_t c3 = 0; c3 < chains.size(); ++c3) {
+                                                const Chain& sc = chains[c3];
+                                                if (sc.stage != 0 || sc.alt != 0) continue;
+                                                if (std::binary_search(sc.later.begin(), sc.later.end(), r) && std::binary_search(sc.later.begin(), sc.later.end(), c)) same = true;
+                                            }
+                                            if (!same) push(r, c, -1, 8);
+                                        }
+                                    }
+                                for (int c : S) push(T, c, -1, ((ch.alt && in_later(c)) ? (1 | asel) : 0) | (c == S[0] ? 4 : 0) | ((fold && in_later(c)) ? (8 | asel) : 0));
+                                for (int aj : ch.rows) for (int c : S) push(T, c, aj, c == S[0] ? 4 : 0);
+                                for (int aj = ch.p0; aj < k; ++aj) for (int c : S) push(T, c, aj, c == S[0] ? 4 : 0);
+                                {   // the identity row that STARTS at this step is initialised over every later tile of the system, not only the ones this
+                                    // chain couples with: later stages read R(k, c) for all of them, and a block left untouched would hold the previous
+                                    // solve's values
+                                    std::vector<int> Sall;
+                                    for (int c : S) if (c < ch.p0 + ch.len) Sall.push_back(c);
+                                    for (int c = (stage == 0 ? m0 : f0); c < T; ++c) Sall.push_back(c);
+                                    for (int c : Sall) push(T, c, k, c == Sall[0] ? 4 : 0);
                                 }
-                            for (int c : S) push(T, c, -1, ((ch.alt && is_sep(c)) ? 1 : 0) | (c == S[0] ? 4 : 0) | ((fold && is_sep(c)) ? 8 : 0));
-                            for (int aj = ch.p0; aj < k; ++aj) for (int c : S) push(T, c, aj, c == S[0] ? 4 : 0);
-                            {   // the identity row that STARTS at this step is initialised over every separator, not only the adjacent ones: the separator
-                                // stage reads R(k, c) for all of them, and a non-adjacent block would otherwise hold the previous solve's values
-                                std::vector<int> Sall;
-                                for (int c : S) if (!is_sep(c)) Sall.push_back(c);
-                                for (int c = m0; c < T; ++c) Sall.push_back(c);
-                                for (int c : Sall) push(T, c, k, c == Sall[0] ? 4 : 0);
                             }
+                            tv.off.push_back((int)list.size());
                         }
-                        tv.off.push_back((int)list.size());
+                        nlaunch += nl;
                     }
-                    tv.nlaunch = nl;
+                    tv.nlaunch = nlaunch;
                     HIPCK(p, p->d_twin_list.upload(list)); HIPCK(p, p->d_twin_perm.upload(perm)); HIPCK(p, p->d_twin_xmap.upload(xmap)); HIPCK(p, p->d_twin_fac.upload(fac));
-                    HIPCK(p, p->d_twin_alt.alloc((size_t)(cv.Pdpad + TILE) * cv.Pdpad));
+                    HIPCK(p, p->d_twin_alt.alloc((size_t)2 * (cv.Pdpad + TILE) * cv.Pdpad));
                     tv.list = p->d_twin_list.p;
-                    p->dd.twin_m0 = m0; p->dd.twin_fac = p->d_twin_fac.p; p->dd.perm = p->d_twin_perm.p; p->dd.xmap = p->d_twin_xmap.p; p->dd.alt = p->d_twin_alt.p;
+                    p->dd.twin_m0 = m0; p->dd.twin_fac = p->d_twin_fac.p; p->dd.perm = p->d_twin_perm.p; p->dd.xmap = p->d_twin_xmap.p;
+                    p->dd.alt = p->d_twin_alt.p; p->dd.alt2 = p->d_twin_alt.p + (size_t)(cv.Pdpad + TILE) * cv.Pdpad;
                     p->twin_ok = true;
                 }
             }

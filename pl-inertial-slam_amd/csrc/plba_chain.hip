@@ -117,13 +117,16 @@ __global__ __launch_bounds__(256) void k_chain_schur(DevBuf d, ChainView cv, Dev
         const int pcb = twin ? dd.perm[cb] : cb;
         if (rhs_row) {
             dd.sys[(size_t)(cv.Pdpad + lr) * ldd + pcb] = (cb < cv.Pd) ? out : 0.0;
-            if (twin && pcb >= m0c) dd.alt[(size_t)(cv.Pdpad + lr) * ldd + pcb] = 0.0;
+            if (twin && pcb >= m0c) { dd.alt[(size_t)(cv.Pdpad + lr) * ldd + pcb] = 0.0; dd.alt2[(size_t)(cv.Pdpad + lr) * ldd + pcb] = 0.0; }
         } else {
             const int ca = ta * 32 + lr;
             const int pca = twin ? dd.perm[ca] : ca;
             dd.sys[(size_t)pca * ldd + pcb] = out;
             if (ta != tb) dd.sys[(size_t)pcb * ldd + pca] = out;     // keep the matrix symmetric (debug readers; the permuted lower triangle may be the natural upper one)
-            if (twin && pca >= m0c && pcb >= m0c) { dd.alt[(size_t)pca * ldd + pcb] = 0.0; if (ta != tb) dd.alt[(size_t)pcb * ldd + pca] = 0.0; }
+            if (twin && pca >= m0c && pcb >= m0c) {
+                dd.alt[(size_t)pca * ldd + pcb] = 0.0; dd.alt2[(size_t)pca * ldd + pcb] = 0.0;
+                if (ta != tb) { dd.alt[(size_t)pcb * ldd + pca] = 0.0; dd.alt2[(size_t)pcb * ldd + pca] = 0.0; }
+            }
             if (fsel >= 0) sC0[(frev ? 31 - lr : lr) * LS + (frev ? 31 - lc : lc)] = out;
         }
     }

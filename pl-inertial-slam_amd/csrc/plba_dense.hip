@@ -362,14 +362,15 @@ __device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const 
     }
     // the C tile this workgroup updates, fetched in the shadow of the panel products
     const int tr = wv >> 1, tc = wv & 1;
-    double* C = (aug ? d.Nwork + (size_t)(aj * 32) * ld : (to_alt ? d.alt : d.sys) + (size_t)(r * 32) * ld) + c * 32;
+    double* const altb = (tflags & 32) ? d.alt2 : d.alt;
+    double* C = (aug ? d.Nwork + (size_t)(aj * 32) * ld : (to_alt ? altb : d.sys) + (size_t)(r * 32) * ld) + c * 32;
     const bool have_update = (c < T);      // false only for the last step's right-hand-side block
     double cold[4] = {0.0, 0.0, 0.0, 0.0};
     if (have_update && !aug_first) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) cold[v] = C[(size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li];
         if (!aug && add_alt) {      // the other chain's finished part of this middle tile (twin factorisation)
-            const double* Ca = d.alt + (size_t)(r * 32) * ld + c * 32;
+            const double* Ca = altb + (size_t)(r * 32) * ld + c * 32;
 #pragma unroll
             for (int v = 0; v < 4; ++v) cold[v] += Ca[(size_t)(tr * 16 + lk + 4 * v) * ld + tc * 16 + li];
         }
@@ -455,7 +456,9 @@ __global__ __launch_bounds__(256) void k_chol32(DevBuf d, int k, int T) {
 // Separator blocks have two writers; every second chain therefore accumulates its separator updates in d.alt (zeroed by the
 // producer) and is one tile shorter, so that the other chains' LAST step — alone in its launch — folds those in (cold += alt)
 // and factors the first separator tile by look-ahead, as any other step does.  Ordinary steps finish the separator region.
-// T - 1 dependent launches become  (longest chain) + (separator tiles - 1):  11 -> 7 at configs[2], 43 -> 18 at configs[4].
+// With four chains the separator region is block-tridiagonal in its turn and is taken the same way once more (a second stage of
+// two chains, accumulating in d.alt2).  T - 1 dependent launches become  (longest chain) [+ second-stage chain] + (final block - 1):
+// 11 -> 7 at configs[2], 43 -> 15 at configs[4].
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chol32_list(DevBuf d, int T, const TwinTile* list) {
     __shared__ __attribute__((aligned(16))) double sX[64 * LS];

@@ -112,6 +112,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
                                // around) — k_chain_schur factors those on the spot
     const int32_t* perm;   // Ppad: natural dense index -> permuted (k_chain_schur writes through it)
     const int32_t* xmap;   // Ppad: permuted -> natural (k_back_gemv writes x through it)
+    double* alt2;          // ... and of the second stage's accumulating chain (nested plan)
     double* alt;           // same shape as sys: the bottom chain's updates of the middle block (folded in by the top chain's last step)
     int flow;              // 1: single-launch dataflow factorisation (k_chol_flow), 0: one launch per block step
     int wide;              // 1: a launch retires 64 columns (two pipelined 32-column sweeps in the look-ahead workgroup, k_chol64)
@@ -198,9 +199,10 @@ void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s);
 void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);   // writes dd.sys
 // one workgroup of a list-driven block step: block row / column, identity row (-1: a tile of the factorisation proper), flags
 struct TwinTile { int16_t r, c, aj, flags, k, pad; };      // k: the pivot tile of the step this workgroup belongs to      // flags: 1 = writes d.alt instead of d.sys, 2 = no look-ahead on this tile, 4 = c is the step's first trailing column (stores the finished panel block),
-                                                   // 8 = add d.alt's tile to the old value first, 16 = this (diagonal) tile is the next pivot: factor it here
+                                                   // 8 = add d.alt's tile to the old value first, 16 = this (diagonal) tile is the next pivot: factor it here,
+                                                   // 32 = with 1 / 8: d.alt2 instead of d.alt (second stage of a nested plan)
 struct TwinView {
-    int T, m0, nchains, nlaunch;   // tiles; first tile of the separator region; chains; launches of the chain stage
+    int T, m0, nchains, nlaunch;   // tiles; first tile of the FINAL dense block (ordinary steps from there); chains; launches of the chain stages
     const TwinTile* list;          // all launches' tiles: launch t = [off[t], off[t + 1])
     std::vector<int> off;          // host side
 };
