@@ -184,3 +184,33 @@ def test_device_lba_rejects_malformed_lists(pkg, hip):
     with pytest.raises(pkg.abi.PlbaError, match="out of range"):
         _run(g, bad)
     g.close()
+
+
+@pytest.mark.gpu
+def test_lba_call_site_through_the_harness(pkg, orc, hip, tmp_path):
+    """tools/localba_harness.cpp `lba`: MapHandler::localBundleAdjustment's list building on map-shaped objects and
+    levMarquardtOptimizationLBA's body as one plba_lba_visual call, write-back included, against the oracle"""
+    import subprocess
+    from .test_facade import build_harness
+    exe = build_harness()
+    w = pkg.window.make_visual_window(K=7, Np=160, Nl=30, n_fixed=2, seed=33)
+    fin, fout = str(tmp_path / "lba_in.bin"), str(tmp_path / "lba_out.bin")
+    K, Np, Nl, Ep, El = len(w["T_kf_w"]), len(w["xyz"]), len(w["pq"]), len(w["po_pt"]), len(w["lo_ln"])
+    with open(fin, "wb") as f:
+        np.array([K, Np, Nl, Ep, El], np.int32).tofile(f)
+        np.array(w["cam"], np.float64).tofile(f); np.ascontiguousarray(w["T_kf_w"], np.float64).tofile(f); w["kf_loc"].astype(np.int32).tofile(f)
+        np.ascontiguousarray(w["xyz"], np.float64).tofile(f); np.ascontiguousarray(w["pq"], np.float64).tofile(f)
+        w["po_pt"].astype(np.int32).tofile(f); w["po_kf"].astype(np.int32).tofile(f); np.ascontiguousarray(w["uv"], np.float64).tofile(f)
+        w["lo_ln"].astype(np.int32).tofile(f); w["lo_kf"].astype(np.int32).tofile(f); np.ascontiguousarray(w["l3"], np.float64).tofile(f)
+    subprocess.check_call([exe, "lba", fin, fout])
+    raw = np.fromfile(fout, np.uint8)
+    its, ups = np.frombuffer(raw[:8].tobytes(), np.int32)
+    off = 8
+    T = np.frombuffer(raw[off:off + 128 * K].tobytes(), np.float64).reshape(K, 4, 4); off += 128 * K
+    xyz = np.frombuffer(raw[off:off + 24 * Np].tobytes(), np.float64).reshape(Np, 3); off += 24 * Np
+    pq = np.frombuffer(raw[off:off + 48 * Nl].tobytes(), np.float64).reshape(Nl, 6); off += 48 * Nl
+    inl = np.frombuffer(raw[off:off + 4 * (Np + Nl)].tobytes(), np.int32)
+    o = orc.new_problem(); b = _run(o, w); o.close()
+    assert (its, ups) == (b["iterations"], b["updates"])
+    assert np.abs(T - b["T"]).max() < 1e-9 and np.abs(xyz - b["xyz"]).max() < 1e-8 and np.abs(pq - b["pq"]).max() < 1e-8
+    assert np.array_equal(inl[:Np] == 0, b["pt_moved"]) and np.array_equal(inl[Np:] == 0, b["ln_moved"])

@@ -12,6 +12,9 @@
 //   localba_harness nomarg  <window.bin> <result.bin>   MapHandler::localBundleAdjustmentWithImu (USE_MARG off, :5086-5739)
 //   localba_harness gyrbias <in.bin> <out.bin>          MapHandler::IMUInitEstBg (:4989-5036)
 //   localba_harness pgo     <in.bin> <out.bin>          MapHandler::loopClosureOptimizationCovGraphG2O (:4299-4528), g2o part
+//   localba_harness lba     <in.bin> <out.bin>          MapHandler::localBundleAdjustment + levMarquardtOptimizationLBA (:1329-2098): the
+//                                                       pre-init visual-only path, which does not use g2o at all: its list building on
+//                                                       map-shaped objects, then the optimiser's body as one plba_lba_visual call
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +43,117 @@ typedef Eigen::Matrix<double, 6, 6> Matrix6d;
 
 template <typename T> static std::vector<T> rd(FILE* f, size_t n) { std::vector<T> v(n); if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } return v; }
 template <typename T> static void wr(FILE* f, const std::vector<T>& v) { if (!v.empty()) fwrite(v.data(), sizeof(T), v.size(), f); }
+
+// ---- MapHandler::localBundleAdjustment (src/mapHandler.cpp:1329-1439) + levMarquardtOptimizationLBA (:1441-2098) ----------------------
+// Map-shaped objects with the members the two functions touch.  localBundleAdjustment's list building is re-enacted as written
+// (local keyframes first, then per landmark its observations with the local index or -1); the optimiser keeps its signature and
+// its write-back, its body is the flattening of INTEGRATION.md plus one call.
+#include "plba.h"
+#include <array>
+namespace lba_map {
+typedef std::array<int, 6> Vector6i;
+struct KeyFrame { int kf_idx; Matrix4d T_kf_w; bool local; };
+struct MapPoint { int idx; Vector3d point3D; std::vector<Eigen::Vector2d> obs_list; std::vector<int> kf_obs_list; bool inlier = true; };
+struct MapLine { int idx; Eigen::Matrix<double, 6, 1> line3D; std::vector<Vector3d> obs_list; std::vector<int> kf_obs_list; bool inlier = true; };
+struct MapHandler {
+    std::vector<KeyFrame*> map_keyframes;
+    std::vector<MapPoint*> map_points;
+    std::vector<MapLine*> map_lines;
+    double fx, fy, cx, cy;
+    plba_problem* problem = nullptr;
+    plba_lba_stats last;
+
+    int levMarquardtOptimizationLBA(std::vector<double> X_aux, std::vector<int> kf_list, std::vector<int> pt_list, std::vector<int> ls_list,
+                                    std::vector<Vector6i> pt_obs_list, std::vector<Vector6i> ls_obs_list) {
+        // keyframes appearing in the observations -> compact index; kf_loc = position in kf_list or -1 (obs(4) of the reference)
+        std::map<int, int> kfi; std::vector<double> T16; std::vector<int32_t> kf_loc;
+        auto kf_of = [&](const Vector6i& o) {
+            auto it = kfi.find(o[3]); if (it != kfi.end()) return it->second;
+            const Matrix4d& T = map_keyframes[o[3]]->T_kf_w;
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) T16.push_back(T(r, c));
+            kf_loc.push_back(o[4]);
+            return kfi[o[3]] = (int)kf_loc.size() - 1; };
+        std::vector<int32_t> ppt, pkf, lln, lkf; std::vector<double> uv, l3;
+        for (auto& o : pt_obs_list) { ppt.push_back(o[1]); pkf.push_back(kf_of(o)); const auto& z = map_points[o[0]]->obs_list[o[2]]; uv.push_back(z(0)); uv.push_back(z(1)); }
+        for (auto& o : ls_obs_list) { lln.push_back(o[1]); lkf.push_back(kf_of(o)); const auto& z = map_lines[o[0]]->obs_list[o[2]]; l3.push_back(z(0)); l3.push_back(z(1)); l3.push_back(z(2)); }
+        const int Nkf = kf_list.size(), Np = pt_list.size(), Nl = ls_list.size();
+        double *xyz = X_aux.data() + 6 * Nkf, *pq = xyz + 3 * Np;            // the landmark part of X_aux is already the layout plba wants
+        plba_lba_options o; plba_lba_default_options(&o);
+        std::vector<double> Tout(T16.size()); std::vector<uint8_t> pm(Np + 1), lm(Nl + 1);
+        const int rc = plba_lba_visual(problem, &o, (int)kf_loc.size(), T16.data(), kf_loc.data(), Np, xyz, Nl, pq,
+                                       (int)ppt.size(), ppt.data(), pkf.data(), uv.data(), (int)lln.size(), lln.data(), lkf.data(), l3.data(),
+                                       fx, fy, cx, cy, Tout.data(), pm.data(), lm.data(), &last);
+        if (rc != PLBA_OK) { fprintf(stderr, "plba_lba_visual: %s\n", plba_last_error(problem)); return -1; }
+        // write-back as :1925-1970
+        for (int i = 0; i < Nkf; ++i) {
+            const int ci = kfi.at(kf_list[i]);
+            Matrix4d T; for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) T(r, c) = Tout[16 * ci + 4 * r + c];
+            map_keyframes[kf_list[i]]->T_kf_w = T;
+        }
+        for (int i = 0; i < Np; ++i) { MapPoint* mp = map_points[pt_list[i]]; if (pm[i]) mp->inlier = false; for (int c = 0; c < 3; ++c) mp->point3D(c) = xyz[3 * i + c]; }
+        for (int i = 0; i < Nl; ++i) { MapLine* ml = map_lines[ls_list[i]]; if (lm[i]) ml->inlier = false; for (int c = 0; c < 6; ++c) ml->line3D(c) = pq[6 * i + c]; }
+        return last.iterations;
+    }
+
+    void localBundleAdjustment() {      // :1329-1439, list building
+        std::vector<double> X_aux;
+        std::vector<int> kf_list;
+        for (KeyFrame* kf : map_keyframes) if (kf && kf->local) kf_list.push_back(kf->kf_idx);
+        // x_kf_w of the local keyframes heads X_aux in the reference; plba_lba_visual takes logmap_se3(T_kf_w) itself: zeros keep the layout
+        X_aux.assign(6 * kf_list.size(), 0.0);
+        std::vector<Vector6i> pt_obs_list, ls_obs_list; std::vector<int> pt_list, ls_list;
+        auto local_of = [&](int kf) { for (size_t j = 0; j < kf_list.size(); ++j) if (kf_list[j] == kf) return (int)j; return -1; };
+        int lm_local_idx = 0;
+        for (MapPoint* mp : map_points) {
+            if (!mp) continue;
+            for (int c = 0; c < 3; ++c) X_aux.push_back(mp->point3D(c));
+            for (size_t i = 0; i < mp->obs_list.size(); ++i) pt_obs_list.push_back({mp->idx, lm_local_idx, (int)i, mp->kf_obs_list[i], local_of(mp->kf_obs_list[i]), 1});
+            ++lm_local_idx; pt_list.push_back(mp->idx);
+        }
+        lm_local_idx = 0;
+        for (MapLine* ml : map_lines) {
+            if (!ml) continue;
+            for (int c = 0; c < 6; ++c) X_aux.push_back(ml->line3D(c));
+            for (size_t i = 0; i < ml->obs_list.size(); ++i) ls_obs_list.push_back({ml->idx, lm_local_idx, (int)i, ml->kf_obs_list[i], local_of(ml->kf_obs_list[i]), 1});
+            ++lm_local_idx; ls_list.push_back(ml->idx);
+        }
+        levMarquardtOptimizationLBA(X_aux, kf_list, pt_list, ls_list, pt_obs_list, ls_obs_list);
+    }
+};
+}  // namespace lba_map
+
+static int visual_lba(const char* in, const char* out) {
+    FILE* f = fopen(in, "rb");
+    if (!f) { perror("in"); return 2; }
+    auto hdr = rd<int32_t>(f, 5);
+    const int K = hdr[0], Np = hdr[1], Nl = hdr[2], Ep = hdr[3], El = hdr[4];
+    auto cam = rd<double>(f, 4); auto T = rd<double>(f, 16 * (size_t)K); auto loc = rd<int32_t>(f, K);
+    auto xyz = rd<double>(f, 3 * (size_t)Np), pq = rd<double>(f, 6 * (size_t)Nl);
+    auto po_pt = rd<int32_t>(f, Ep), po_kf = rd<int32_t>(f, Ep); auto uv = rd<double>(f, 2 * (size_t)Ep);
+    auto lo_ln = rd<int32_t>(f, El), lo_kf = rd<int32_t>(f, El); auto l3 = rd<double>(f, 3 * (size_t)El);
+    fclose(f);
+    lba_map::MapHandler mh; mh.fx = cam[0]; mh.fy = cam[1]; mh.cx = cam[2]; mh.cy = cam[3];
+    // local keyframes must enumerate in kf_loc order: the window generator numbers them ascending with the keyframe index
+    for (int k = 0; k < K; ++k) { auto* kf = new lba_map::KeyFrame; kf->kf_idx = k; kf->local = loc[k] >= 0; for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) kf->T_kf_w(r, c) = T[16 * k + 4 * r + c]; mh.map_keyframes.push_back(kf); }
+    for (int i = 0; i < Np; ++i) { auto* mp = new lba_map::MapPoint; mp->idx = i; mp->point3D = Vector3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]); mh.map_points.push_back(mp); }
+    for (int e = 0; e < Ep; ++e) { auto* mp = mh.map_points[po_pt[e]]; Eigen::Vector2d z; z(0) = uv[2 * e]; z(1) = uv[2 * e + 1]; mp->obs_list.push_back(z); mp->kf_obs_list.push_back(po_kf[e]); }
+    for (int i = 0; i < Nl; ++i) { auto* ml = new lba_map::MapLine; ml->idx = i; for (int c = 0; c < 6; ++c) ml->line3D(c) = pq[6 * i + c]; mh.map_lines.push_back(ml); }
+    for (int e = 0; e < El; ++e) { auto* ml = mh.map_lines[lo_ln[e]]; ml->obs_list.push_back(Vector3d(l3[3 * e], l3[3 * e + 1], l3[3 * e + 2])); ml->kf_obs_list.push_back(lo_kf[e]); }
+    plba_options po; plba_default_options(&po);
+    if (plba_create(&po, &mh.problem) != PLBA_OK) { fprintf(stderr, "plba_create failed\n"); return 3; }
+    mh.localBundleAdjustment();
+    FILE* g = fopen(out, "wb");
+    if (!g) { perror("out"); return 2; }
+    std::vector<double> oT, oX, oL; std::vector<int32_t> flags;
+    for (auto* kf : mh.map_keyframes) for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) oT.push_back(kf->T_kf_w(r, c));
+    for (auto* mp : mh.map_points) { for (int c = 0; c < 3; ++c) oX.push_back(mp->point3D(c)); flags.push_back(mp->inlier ? 1 : 0); }
+    for (auto* ml : mh.map_lines) { for (int c = 0; c < 6; ++c) oL.push_back(ml->line3D(c)); flags.push_back(ml->inlier ? 1 : 0); }
+    std::vector<int32_t> h2 = {mh.last.iterations, mh.last.updates};
+    wr(g, h2); wr(g, oT); wr(g, oX); wr(g, oL); wr(g, flags);
+    fclose(g);
+    plba_destroy(mh.problem);
+    return 0;
+}
 
 // ---- MapHandler::IMUInitEstBg (src/mapHandler.cpp:4989-5036): one VertexGyrBias, one EdgeGyrBias per keyframe pair ------------
 static int imu_init_est_bg(const char* in, const char* out) {
@@ -147,6 +261,7 @@ int main(int argc, char** argv) {
     if (argc >= 4 && !strcmp(argv[1], "gyrbias")) return imu_init_est_bg(argv[2], argv[3]);
     if (argc >= 4 && !strcmp(argv[1], "pgo")) return pose_graph(argv[2], argv[3]);
     if (argc >= 4 && !strcmp(argv[1], "nomarg")) return local_ba_with_imu(argv[2], argv[3]);
+    if (argc >= 4 && !strcmp(argv[1], "lba")) return visual_lba(argv[2], argv[3]);
     if (argc < 3) { fprintf(stderr, "usage: %s [nomarg|gyrbias|pgo] window.bin result.bin\n", argv[0]); return 2; }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror("window"); return 2; }
