@@ -9,7 +9,12 @@ from oracle import oracle as orc
 
 pkg = g.load_package()
 bad = 0
-cases = [(K, 12 * K, 3 * K, s) for K, s in ((26, 1), (30, 2), (34, 3), (38, 4), (41, 5), (47, 6), (53, 7), (58, 8), (64, 9), (71, 10), (77, 11), (85, 12), (96, 13), (110, 14), (128, 15), (150, 16), (170, 17), (215, 18))]
+if len(sys.argv) > 2 and sys.argv[1] == "--random":      # python tools/soak_solver.py --random N [seed]: N random window lengths 26..260
+    rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    rand_cases = [(int(k), 100 + int(s)) for k, s in zip(rng.integers(26, 261, int(sys.argv[2])), range(int(sys.argv[2])))]
+else:
+    rand_cases = None
+cases = [(K, 12 * K, 3 * K, s) for K, s in rand_cases] if rand_cases else [(K, 12 * K, 3 * K, s) for K, s in ((26, 1), (30, 2), (34, 3), (38, 4), (41, 5), (47, 6), (53, 7), (58, 8), (64, 9), (71, 10), (77, 11), (85, 12), (96, 13), (110, 14), (128, 15), (150, 16), (170, 17), (215, 18))]
 for K, Np, Nl, seed in cases:
     w = pkg.window.make_window(K, Np, Nl, imu=True, seed=0x50A0 + seed)
     if seed % 3 == 0:      # a prior from a previous BA of the same window (forced separators in the chain elimination)
