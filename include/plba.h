@@ -82,6 +82,12 @@ typedef struct {
                                    launches become about T / 2 or less); longer systems are factored and solved by two workgroups walking the band from
                                    both ends with the window resident in LDS (plba_band.hip).  2 = the in-LDS form from 8 tiles on
                                    (tests).  0 = neither.  Wider bands and smaller systems take the plain dense path      (1) */
+    int    marg_exact;          /* pseudo-inverse of the dropped block Amm in plba_marginalize* (IMU/marginalization.cpp:351-353 thresholds
+                                   the eigenvalues of the WHOLE block).  2 = always the dense eigen-decomposition of Amm (m <= 474 at
+                                   the call site).  0 = always block by block (landmark blocks, then the keyframe block of the reduced
+                                   system): identical whenever every discarded direction is a block-local null space.  1 = block by
+                                   block when a device-side certificate proves that (no other eigenvalue of Amm at or below the
+                                   threshold, discarded directions uncoupled), the dense path otherwise                       (1) */
 } plba_options;
 
 void plba_default_options(plba_options* o);
@@ -269,7 +275,8 @@ int plba_lba_visual(plba_problem* p, const plba_lba_options* opt, int K, const d
  * updating it, then exposes named internal buffers: "Hschur" (P*P row-major), "bschur" (P),
  * "bp" (P), "x" (P + 3Np + 6Nl after a solve), "hll_pt" (Np*9), "bl_pt" (Np*3), "hll_ln" (Nl*36),
  * "bl_ln" (Nl*6), "err_pvr" (M*9), "err_bias" (M*6), "err_prior" (n), "pose_dim" (1), "chi2" (1),
- * "maxdiag" (1). */
+ * "maxdiag" (1); "marg_path" (5, after plba_marginalize*): [0] 0 = block-wise pseudo-inverse taken, 1 = dense
+ * eigen-decomposition of Amm; [1..4] the certificate's w_max, smallest kept landmark eigenvalue, tau, smallest pivot. */
 int plba_debug_build(plba_problem* p, double lambda, int do_solve);
 int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, size_t* n);
 /* Stand-alone run of the dense reduced-camera solver (K7): solves A x = b for a symmetric positive

@@ -322,6 +322,8 @@ void orc_default_options(plba_options* o) {
     o->factor_flow = 0;
     o->chain_elim = 1;             /* solver-structure options of the HIP library: ignored here */
     o->wide_steps = 0;
+    o->band_solve = 1;
+    o->marg_exact = 1;             /* the oracle always takes the dense eigen pseudo-inverse (cpp:351-353) */
 }
 const char* orc_backend_name(void) { return "cpu-oracle"; }
 

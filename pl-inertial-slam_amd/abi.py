@@ -23,7 +23,7 @@ class Options(C.Structure):
     _fields_ = [("tau", C.c_double), ("good_step_lower", C.c_double), ("good_step_upper", C.c_double),
                 ("max_trials", C.c_int), ("user_lambda_init", C.c_double), ("marg_eps", C.c_double),
                 ("fix_line_position_jacobian", C.c_int), ("whiten_marg_factors", C.c_int),
-                ("device", C.c_int), ("use_mfma", C.c_int), ("profile", C.c_int), ("factor_block", C.c_int), ("factor_flow", C.c_int), ("chain_elim", C.c_int), ("wide_steps", C.c_int), ("band_solve", C.c_int)]
+                ("device", C.c_int), ("use_mfma", C.c_int), ("profile", C.c_int), ("factor_block", C.c_int), ("factor_flow", C.c_int), ("chain_elim", C.c_int), ("wide_steps", C.c_int), ("band_solve", C.c_int), ("marg_exact", C.c_int)]
 
 
 class Stats(C.Structure):

@@ -65,6 +65,7 @@ void plba_default_options(plba_options* o) {
     o->chain_elim = 1;
     o->wide_steps = 0;
     o->band_solve = 1;
+    o->marg_exact = 1;
 }
 const char* plba_backend_name(void) { return "hip-gfx950"; }
 const char* plba_last_error(const plba_problem* p) { return p ? p->err : g_create_err; }
@@ -1654,6 +1655,8 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     else if (w == "stamps") { HIPCK(p, fetch(d.maxd_part, 80, v)); }
     else if (w == "dbgbuf") { HIPCK(p, fetch(d.dbgbuf, 64, v)); }
     else if (w == "pose_dim") v = {(double)p->P};
+    else if (w == "marg_path") v.assign(p->marg_path, p->marg_path + 5);
+    else if (w == "marg_J") v = p->marg_dbg;
     else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};
     else if (w == "band") v = {(double)(p->band_ok ? 1 : 0)};
     else if (w == "twin") v = {(double)(p->twin_ok ? 1 : 0)};

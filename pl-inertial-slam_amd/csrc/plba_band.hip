@@ -329,12 +329,8 @@ size_t band_lds_bytes(int Pdpad) {
 
 void launch_band_solve(const DevBuf& dd, const BandView& bv, hipStream_t s) {
     const size_t sh = band_lds_bytes(dd.Ppad);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_back), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    if (ensure_dyn_lds(reinterpret_cast<const void*>(k_band_fwd), 160 * 1024) != hipSuccess ||
+        ensure_dyn_lds(reinterpret_cast<const void*>(k_band_back), 160 * 1024) != hipSuccess) return;      // the sticky HIP error surfaces at the caller's hipGetLastError
     hipLaunchKernelGGL(k_band_fwd, dim3(2), dim3(NT), sh, s, dd, bv);
     hipLaunchKernelGGL(k_band_back, dim3(2), dim3(NT), sh, s, dd, bv);
 }

@@ -1003,12 +1003,8 @@ template <int NB>
 static void launch_cholesky_nb(const DevBuf& d, bool use_mfma, hipStream_t s) {
     const int T = d.Ppad / NB;
     const size_t sh = Blk<NB>::lds_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_step<true, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_step<false, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-        attr_set = true;
-    }
+    if (ensure_dyn_lds(reinterpret_cast<const void*>(k_chol_step<true, NB>), (int)sh) != hipSuccess ||
+        ensure_dyn_lds(reinterpret_cast<const void*>(k_chol_step<false, NB>), (int)sh) != hipSuccess) return;      // surfaces at the caller's hipGetLastError
     hipLaunchKernelGGL(k_potrf0<NB>, dim3(1), dim3(64), 0, s, d);
     for (int k = 0; k < T; ++k) {
         const int nt = T - k - 1;
@@ -1115,13 +1111,9 @@ void launch_trsv_back(const DevBuf& d, bool use_mfma, int epoch, hipStream_t s) 
         hipLaunchKernelGGL(k_trsv_flow, dim3(T), dim3(256), 0, s, d, T, epoch);
         return;
     }
-    static bool attr_set = false;
     const size_t sh64 = (size_t)(64 * 64 + 64) * sizeof(double), sh32 = (size_t)(4 * 32 * 34 + 2 * 32 * 32 + 64) * sizeof(double);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_inv_diag<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh64);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_inv_diag<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh32);
-        attr_set = true;
-    }
+    if (ensure_dyn_lds(reinterpret_cast<const void*>(k_inv_diag<64>), (int)sh64) != hipSuccess ||
+        ensure_dyn_lds(reinterpret_cast<const void*>(k_inv_diag<32>), (int)sh32) != hipSuccess) return;      // surfaces at the caller's hipGetLastError
     if (d.fb == 64) hipLaunchKernelGGL(k_inv_diag<64>, dim3(T), dim3(256), sh64, s, d);
     else hipLaunchKernelGGL(k_inv_diag<32>, dim3(T), dim3(256), sh32, s, d);
     hipLaunchKernelGGL(k_trsv_flow, dim3(T), dim3(256), 0, s, d, T, epoch);

@@ -16,7 +16,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "plba.h"
@@ -25,6 +28,22 @@
 namespace plba {
 
 constexpr int TILE = 64;          // dense tile edge (wavefront-wide)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: raise it once per (device, kernel), under a
+// lock, and report a failure instead of letting the launch that needs the LDS fail later.
+inline hipError_t ensure_dyn_lds(const void* func, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = done.find({dev, func});
+    if (it != done.end() && it->second >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done[{dev, func}] = bytes;
+    return e;
+}
 constexpr int MAX_PART = 8192;    // per-block partial sums for deterministic reductions
 
 // LM control block, device-resident; copied back once per trial.

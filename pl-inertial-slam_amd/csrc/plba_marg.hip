@@ -17,7 +17,7 @@
 //            (4) A' = V S V^T by one-sided Jacobi, J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b'   (cpp:364-372).
 //                n <= 100 (the reference's 12-keyframe window keeps <= 7 x 9 + 6 + the old prior's vertices): ONE
 //                workgroup holds G = A'V and V in LDS (2 n^2 doubles <= 160 KB) and runs every round of every sweep
-//                without leaving the CU; larger n: one launch per round (k_jacobi_round).
+//                without leaving the CU; n <= 140 with V in global memory; larger n: two launches per round (k_j2_cols / k_j2_rows).
 //   One stream synchronisation per call: index lists go up through the pinned staging area before the first launch,
 //   results come back through it in two asynchronous copies.
 #include <algorithm>
@@ -192,9 +192,19 @@ __global__ void k_schur_apply(double* A, double* b, int pos, const double* Z, co
 }
 
 
-// landmark blocks in registers: S = 3 (point) / 6 (line), everything unrolled so that M and V never touch scratch memory
+// landmark blocks in registers: S = 3 (point) / 6 (line), everything unrolled so that M and V never touch scratch memory.
+// With `cert` the block also leaves what the certificate of marg_exact = 1 needs (see cert_* below): the shifted inverse
+// sum_{w_k > hi} u_k u_k^T / (w_k - hi), the directions the block-wise path discards (w_k <= hi), the smallest eigenvalue it keeps.
+struct CertBuf {
+    double* pinv_hi;                  // nblk x 36
+    double* udrop;                    // nblk x 36: discarded eigenvectors, one per row
+    int* ndrop;                       // nblk
+    unsigned long long* lam_min_bits; // min over blocks of the smallest kept eigenvalue (bits of a positive double order like integers)
+    unsigned long long* w2max_bits;   // max over discarded directions of |A[:, block] u|^2
+    int* band;                        // an eigenvalue in (eps, hi]: kept by the block-wise path, counted as discarded by the certificate
+};
 template <int S>
-MDEV void pinv_small(const double* A, int pos, int o, double eps, double* out) {
+MDEV void pinv_small(const double* A, int pos, int o, double eps, double* out, bool cert, double hi, const CertBuf cb, int bi) {
     double M[S][S], V[S][S];
 #pragma unroll
     for (int i = 0; i < S; ++i)
@@ -239,13 +249,38 @@ MDEV void pinv_small(const double* A, int pos, int o, double eps, double* out) {
             for (int k = 0; k < S; ++k) { const double w = M[k][k]; if (w > eps) acc += V[i][k] * V[j][k] / w; }
             out[i * MAXB + j] = acc;
         }
+    if (!cert) return;
+    double* ph = cb.pinv_hi + (size_t)bi * 36; double* ud = cb.udrop + (size_t)bi * 36;
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < S; ++k) { const double w = M[k][k]; if (w > hi) acc += V[i][k] * V[j][k] / (w - hi); }
+            ph[i * 6 + j] = acc;
+        }
+    int nd = 0, band = 0;
+    double lmin = 1e300;
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+        const double w = M[k][k];
+        if (w > hi) { lmin = fmin(lmin, w); continue; }
+        if (w > eps) band = 1;
+#pragma unroll
+        for (int i = 0; i < S; ++i) ud[nd * 6 + i] = V[i][k];
+        ++nd;
+    }
+    cb.ndrop[bi] = nd;
+    if (band) atomicOr(cb.band, 1);
+    atomicMin(cb.lam_min_bits, (unsigned long long)__double_as_longlong(lmin));
 }
-__global__ void k_block_pinv_small(const double* A, int pos, const int* boff, const int* bsize, int nblk, double eps, double* Pinv) {
+__global__ __launch_bounds__(64) void k_block_pinv_small(const double* A, int pos, const int* boff, const int* bsize, int nblk, double eps, double* Pinv, bool cert, double hi, CertBuf cb) {
     const int bi = blockIdx.x * blockDim.x + threadIdx.x;
     if (bi >= nblk) return;
     double* out = Pinv + (size_t)bi * MAXB * MAXB;
-    if (bsize[bi] == 3) pinv_small<3>(A, pos, boff[bi], eps, out);
-    else pinv_small<6>(A, pos, boff[bi], eps, out);
+    if (bsize[bi] == 3) pinv_small<3>(A, pos, boff[bi], eps, out, cert, hi, cb, bi);
+    else pinv_small<6>(A, pos, boff[bi], eps, out, cert, hi, cb, bi);
 }
 
 // ---- one-sided Jacobi (Hestenes) of a symmetric positive semi-definite n x n matrix held in LDS by ONE workgroup ------------
@@ -361,9 +396,17 @@ MDEV void jacobi_lds(double* G, double* V, int n, double tol, double noise2, int
 // live in LDS.  A round of the round-robin schedule holds n/2 disjoint pairs, one HALF-wave each: (0) c, s from a_pp, a_qq, a_pq —
 // three scalars, no dot products, which is what the one-sided method spends its time on; (1) its column pair of A and V;
 // barrier; (2) its row pair of A; barrier.  A pair is left alone
-// when |a_pq| <= tol sqrt(|a_pp a_qq|) or |a_pq| <= delta = 8 macheps |A|_F (the absolute rounding every entry carries after a few
-// hundred rotations).  On exit the eigenvalues are the diagonal of A, the eigenvectors the columns of V.
-// The reference's SelfAdjointEigenSolver (tridiagonal QR) has the same absolute accuracy, macheps |A|.
+// when |a_pq| <= tol sqrt(|a_pp a_qq|) (the scaled criterion: small eigenvalues of a positive semi-definite matrix come out with
+// RELATIVE accuracy, which the 1e-8 threshold needs while |A'| ~ 1e7), or when the rotation would be the identity in fp64,
+// |a_pq| <= macheps |a_qq - a_pp| (sin(theta) below half an ulp: what terminates the pairs of a large and a numerically null
+// diagonal entry, whose a_pq is rounding noise that never passes the scaled test), or when |a_pq| <= delta_s, an ABSOLUTE floor for
+// the entries between numerically null directions (true zeros that come out of cancellations among ~1e6 terms: noise of a few
+// macheps |A|, which no criterion relative to that noise can ever call converged).  Round 2 fixed that floor at 8 macheps |A|_F,
+// ~ 9e-9 for these matrices — the size of the 1e-8 threshold itself: eigenvalues within a factor of two of it were classified by
+// their rounding (measured on the far-landmark windows of tests/golden/marg_exact.npz).  Now the floor starts at
+// delta = macheps |A|_F / 16 and doubles with every sweep from the 15th on, so a matrix whose noise is lower converges to that
+// accuracy and the others still terminate (9e-9 is reached in sweep 22).
+// On exit the eigenvalues are the diagonal of A, the eigenvectors the columns of V.
 // 1 / sqrt(x) for a normal positive x: v_rsq_f64 (~ single precision) + two Newton steps; the library routine's range handling
 // is not needed here and costs a third of a round
 MDEV double rsqrt_nr(double x) {
@@ -373,25 +416,28 @@ MDEV double rsqrt_nr(double x) {
     y = y * fma(-hx * y, y, 1.5);
     return y;
 }
-MDEV void jacobi2_lds(double* A, int lda, double* V, int n, double tol, double delta, int max_sweeps, int* s_rot, double* dbg = nullptr) {
+constexpr double JACOBI2_ANG = 1.2e-16;      // |sin(theta)| ~ |a_pq| / |a_qq - a_pp| below this: the rotation is the identity in fp64
+template <int MAXIT>      // pairs a half-wave owns per round: ceil((n / 2) / half-waves) — 1024 threads: 2 up to n = 128, 3 up to 192; 256 threads, n <= 16: 1
+MDEV void jacobi2_lds(double* A, int lda, double* V, int n, double tol, double delta0, int max_sweeps, int* s_rot, double* dbg = nullptr) {
     if (n < 2) return;
     const int lane = threadIdx.x & 63, hl = lane & 31, nh = (blockDim.x >> 6) * 2, half = (threadIdx.x >> 6) * 2 + (lane >> 5);
     const double tol2 = tol * tol;
-    constexpr int MAXIT = 2;      // pairs a half-wave owns per round: 64 pairs / 32 halves (1024 threads), 8 / 8 (256 threads, n <= 16)
-    __shared__ int s_perm[128], s_live;
-    __shared__ unsigned char s_lf[128];
+    __shared__ int s_perm[160], s_live;
+    __shared__ unsigned char s_lf[160];
+    double delta = delta0;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (sweep >= 15) delta *= 2.0;
         // Columns that are already decoupled — every off-diagonal entry at the floor: the exactly zero velocity columns of keyframes
         // no selected factor constrains, and, sweep after sweep, whatever has converged — leave the schedule; a round costs two
         // workgroup barriers however few of its pairs rotate, so the sweeps shrink with the live set (60 -> 39 -> ... at configs[3])
         if (threadIdx.x == 0) s_live = 0;
         __syncthreads();
         for (int j = threadIdx.x; j < n; j += blockDim.x) {
-            const double ajj = fabs(A[(size_t)j * lda + j]);
+            const double ajj = A[(size_t)j * lda + j];
             bool live = false;
             for (int k = 0; k < n; ++k) {
-                const double v = A[(size_t)k * lda + j];
-                if (k != j && v != 0.0 && fabs(v) > delta && v * v > tol2 * ajj * fabs(A[(size_t)k * lda + k])) { live = true; break; }
+                const double v = A[(size_t)k * lda + j], akk = A[(size_t)k * lda + k];
+                if (k != j && v != 0.0 && fabs(v) > delta + JACOBI2_ANG * fabs(akk - ajj) && v * v > tol2 * fabs(ajj * akk)) { live = true; break; }
             }
             s_lf[j] = live ? 1 : 0;
         }
@@ -428,7 +474,7 @@ MDEV void jacobi2_lds(double* A, int lda, double* V, int n, double tol, double d
                 double c = 1.0, sn = 0.0;
                 if (q >= 0) {
                     const double app = A[(size_t)p * lda + p], aqq = A[(size_t)q * lda + q], apq = A[(size_t)q * lda + p];
-                    if (apq != 0.0 && apq * apq > tol2 * fabs(app * aqq) && fabs(apq) > delta) {
+                    if (apq != 0.0 && apq * apq > tol2 * fabs(app * aqq) && fabs(apq) > delta + JACOBI2_ANG * fabs(aqq - app)) {
                         // tan(theta) = sign(a b) |b| / (|a| + h), a = a_qq - a_pp, b = 2 a_pq, h = hypot(a, b)
                         //   =>  c = (|a| + h) r,  s = sign(a b) |b| r,  r = 1 / sqrt(2 h (h + |a|)):  two reciprocal square roots, no division
                         const double a = aqq - app, bb = 2.0 * apq, fa = fabs(a);
@@ -471,7 +517,7 @@ MDEV void jacobi2_lds(double* A, int lda, double* V, int n, double tol, double d
         }
     }
 }
-MDEV double jacobi2_delta(const double* A, int lda, int n, double* s_part) {      // 8 macheps |A|_F  (call with the whole workgroup)
+MDEV double jacobi2_delta(const double* A, int lda, int n, double* s_part) {      // macheps |A|_F / 16  (call with the whole workgroup)
     double f = 0.0;
     for (int t = threadIdx.x; t < n * n; t += blockDim.x) { const double v = A[(size_t)(t / n) * lda + t % n]; f += v * v; }
     f = wave_sum(f);
@@ -480,7 +526,7 @@ MDEV double jacobi2_delta(const double* A, int lda, int n, double* s_part) {    
     double tot = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_part[w];
     __syncthreads();
-    return 8.0 * 1.1102230246251565e-16 * sqrt(tot);
+    return 1.1102230246251565e-16 / 16.0 * sqrt(tot);
 }
 // |g_p . g_q| <= JACOBI_TOL |g_p| |g_q| counts as orthogonal: an n-term fp64 dot product carries ~ n * 1.1e-16 of relative
 // rounding, so 1e-15 (round 1) was never reached and every call ran all its sweeps; 1e-13 leaves eigenvalues good to ~1e-13
@@ -499,7 +545,9 @@ MDEV double jacobi_noise2(const double* G, int n, double* s_part) {
     const double delta = 4.0 * n * 1.1102230246251565e-16;
     return 2.0 * delta * delta * tot;
 }
-constexpr int JLDS_MAX_N = 100;       // 2 * 100 * 100 doubles = 160,000 of the CU's 163,840 bytes of LDS
+constexpr int JLDS_MAX_N = 100;       // A' and V both in LDS: (100 * 101 + 100 * 100) doubles = 160,800 of the CU's 163,840 bytes
+constexpr int JLDS_MAX_N2 = 140;      // A' alone in LDS (140 * 141 doubles = 157,920 bytes), V in global memory: the reference's 12-keyframe
+                                      // window keeps up to 11 x 9 + 6 = 105 dims (src/mapHandler.cpp:6109-6188)
 // eigen pseudo-inverse of the dropped keyframe block (<= 15 dims) of the system the landmarks have been eliminated from
 __global__ __launch_bounds__(256) void k_pose_pinv(const double* A, int pos, int o, int sz, double eps, double* Pinv) {
     __shared__ double G[MAXB * MAXB], V[MAXB * MAXB], lam[MAXB];
@@ -512,7 +560,7 @@ __global__ __launch_bounds__(256) void k_pose_pinv(const double* A, int pos, int
     __shared__ double s_part[16];
     __syncthreads();
     const double delta = jacobi2_delta(G, sz, sz, s_part);
-    jacobi2_lds(G, sz, V, sz, JACOBI2_TOL, delta, 40, &rot);
+    jacobi2_lds<1>(G, sz, V, sz, JACOBI2_TOL, delta, 60, &rot);
     __syncthreads();
     if ((int)threadIdx.x < sz) lam[threadIdx.x] = G[threadIdx.x * sz + threadIdx.x];
     __syncthreads();
@@ -525,24 +573,31 @@ __global__ __launch_bounds__(256) void k_pose_pinv(const double* A, int pos, int
 }
 // the kept block: A' out, eigen square root J0 = sqrt(S) V^T (column-major), r0 = sqrt(S^-1) V^T b'   (cpp:364-372)
 // outp = [Ar n*n | br n | J0 n*n | r0 n]
-__global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const double* b, int pos, int m, int n, double eps, double* outp, double* dbg) {
+__global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const double* b, int pos, int m, int n, double eps, double* outp, double* Vg, double* dbg) {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     const int lda = n | 1;
-    double* G = s_dyn; double* V = s_dyn + (size_t)n * lda;
+    double* G = s_dyn;
+    double* Vl = s_dyn + (size_t)n * lda;      // only when Vg is null
     __shared__ int rot;
     double* Ar = outp; double* br = outp + (size_t)n * n; double* J0 = br + n; double* r0 = J0 + (size_t)n * n;
     for (int t = threadIdx.x; t < n * n; t += blockDim.x) {
         const int c = t / n, r = t % n;
         const double v = 0.5 * (A[(size_t)(m + r) * pos + m + c] + A[(size_t)(m + c) * pos + m + r]);
-        G[(size_t)c * lda + r] = v; Ar[t] = v; V[t] = (r == c) ? 1.0 : 0.0;
+        G[(size_t)c * lda + r] = v; Ar[t] = v;
+        if (Vg) Vg[t] = (r == c) ? 1.0 : 0.0; else Vl[t] = (r == c) ? 1.0 : 0.0;
     }
     for (int t = threadIdx.x; t < n; t += blockDim.x) br[t] = b[m + t];
     __shared__ double s_part[16];
     __syncthreads();
     const double delta = jacobi2_delta(G, lda, n, s_part);
     if (dbg && threadIdx.x == 0) { for (int q = 0; q < 48; ++q) dbg[q] = -1.0; dbg[40] = delta; }
-    jacobi2_lds(G, lda, V, n, JACOBI2_TOL, delta, 40, &rot, dbg);
+    // two instances behind one uniform branch: with V in LDS its accesses stay ds_ instructions; in global memory (100 < n <= 140) a
+    // column pair written in one round is read by another half-wave of this workgroup after the barrier of that round
+    if (!Vg) jacobi2_lds<2>(G, lda, Vl, n, JACOBI2_TOL, delta, 60, &rot, dbg);
+    else if (n <= 128) jacobi2_lds<2>(G, lda, Vg, n, JACOBI2_TOL, delta, 60, &rot, dbg);
+    else jacobi2_lds<3>(G, lda, Vg, n, JACOBI2_TOL, delta, 60, &rot, dbg);
     __syncthreads();
+    const double* V = Vg ? Vg : Vl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int j = wave; j < n; j += nw) {
         const double* v = V + (size_t)j * n;
@@ -555,52 +610,226 @@ __global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const dou
         for (int c = lane; c < n; c += 64) J0[(size_t)c * n + j] = ss * v[c];
         if (lane == 0) r0[j] = sqrt(Si) * vb;
     }
+    if (threadIdx.x == 0) r0[n] = (double)rot;      // columns still live when the last sweep began: >= 2 means the sweep limit was hit
 }
 
-// ---- (4) one-sided Jacobi (Hestenes) on the symmetric positive semi-definite A' ---------------------------------------
-// G (n x n, column-major, starts as A') and V (starts as I); a round rotates n/2 disjoint column pairs.
-__global__ __launch_bounds__(256) void k_jacobi_round(double* G, double* V, int n, int npad, int round, double tol, int* rotated) {
-    __shared__ double s4[3][4];
-    const int i = blockIdx.x;
+// ---- multi-launch Jacobi for blocks that do not fit one workgroup's LDS --------------------------------------------------------
+// (a) The dense eigen pseudo-inverse of the whole dropped block Amm (IMU/marginalization.cpp:351-353; m <= 474 at the call site).
+//     Amm = Jm^T Jm with Jm the first m columns of the stacked Jacobian (R x m, column-major), so its eigen-decomposition is the
+//     singular value decomposition of Jm: one-sided Jacobi (Hestenes) on the COLUMNS OF Jm — rotating column pairs until they are
+//     orthogonal gives V (accumulated) and lambda_j = |g_j|^2 with high RELATIVE accuracy even where lambda_j / |Amm| ~ 1e-15,
+//     which is where the 1e-8 threshold cuts (one-sided Jacobi on Amm itself only reaches n macheps |Amm| ~ 1e-7 absolute:
+//     measured, the discarded subspace then differs from the oracle's).  One workgroup per pair, one launch per round.
+//     A pair is left alone when |g_p . g_q| <= tol |g_p| |g_q|, or when one of the two columns has sunk to the rounding floor
+//     (|g|^2 <= nfloor = (64 macheps)^2 |Jm|_F^2: a numerically null direction — every rank-deficient landmark block has some — whose
+//     content is noise and can never pass the relative test).
+// (b) Kept blocks beyond the in-LDS limit: two-sided Jacobi on A' itself, two launches per round (column pairs, then row pairs).
+__global__ __launch_bounds__(1024) void k_fro_floor(const double* G, size_t count, double* nfloor) {
+    __shared__ double s_part[16];
+    double f = 0.0;
+    for (size_t t = threadIdx.x; t < count; t += blockDim.x) f += G[t] * G[t];
+    f = wave_sum(f);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_part[w];
+        const double c = 64.0 * 1.1102230246251565e-16;
+        nfloor[0] = c * c * tot;      // one-sided: against |g|^2
+        nfloor[1] = 1.1102230246251565e-16 / 16.0 * sqrt(tot);      // two-sided: the starting floor against |a_pq| (jacobi2_lds)
+    }
+}
+MDEV void round_robin_pair(int i, int round, int npad, int& p, int& q) {
     const int mm = npad - 1;
-    int p, q;
     if (i == 0) { p = mm; q = round % mm; }
     else { p = (round + i) % mm; q = (round - i + mm) % mm; }
     if (p > q) { const int t = p; p = q; q = t; }
+}
+// G: rows x n column-major (leading dimension rows), V: n x n
+__global__ __launch_bounds__(256) void k_hestenes_round(double* G, int rows, double* V, int n, int npad, int round, double tol2, const double* nfloor, int* rotated) {
+    __shared__ double s4[3][4];
+    int p, q;
+    round_robin_pair(blockIdx.x, round, npad, p, q);
     if (q >= n) return;                                  // padding column: bye
-    double* gp = G + (size_t)p * n; double* gq = G + (size_t)q * n;
+    double* gp = G + (size_t)p * rows; double* gq = G + (size_t)q * rows;
     double a = 0.0, b = 0.0, g = 0.0;
-    for (int t = threadIdx.x; t < n; t += 256) { const double x = gp[t], y = gq[t]; a += x * x; b += y * y; g += x * y; }
+    for (int t = threadIdx.x; t < rows; t += 256) { const double x = gp[t], y = gq[t]; a += x * x; b += y * y; g += x * y; }
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); g += __shfl_down(g, o, 64); }
     if ((threadIdx.x & 63) == 0) { s4[0][threadIdx.x >> 6] = a; s4[1][threadIdx.x >> 6] = b; s4[2][threadIdx.x >> 6] = g; }
     __syncthreads();
     a = (s4[0][0] + s4[0][1]) + (s4[0][2] + s4[0][3]);
     b = (s4[1][0] + s4[1][1]) + (s4[1][2] + s4[1][3]);
     g = (s4[2][0] + s4[2][1]) + (s4[2][2] + s4[2][3]);
-    if (!(fabs(g) > tol * sqrt(a * b)) || g == 0.0) return;
+    if (!(g * g > tol2 * a * b) || !(fmin(a, b) > nfloor[0]) || g == 0.0) return;
     if (threadIdx.x == 0) atomicAdd(rotated, 1);
-    const double zeta = (b - a) / (2.0 * g);
-    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with zeta = (b - a) / (2 g), written without the division by g
+    const double dd = b - a;
+    const double t = ((dd * g >= 0.0) ? 2.0 : -2.0) * fabs(g) / (fabs(dd) + sqrt(dd * dd + 4.0 * g * g));
     const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+    for (int k = threadIdx.x; k < rows; k += 256) { const double x = gp[k], y = gq[k]; gp[k] = c * x - s * y; gq[k] = s * x + c * y; }
     double* vp = V + (size_t)p * n; double* vq = V + (size_t)q * n;
-    for (int k = threadIdx.x; k < n; k += 256) {
-        const double x = gp[k], y = gq[k];
-        gp[k] = c * x - s * y; gq[k] = s * x + c * y;
-        const double u = vp[k], w = vq[k];
-        vp[k] = c * u - s * w; vq[k] = s * u + c * w;
+    for (int k = threadIdx.x; k < n; k += 256) { const double u = vp[k], w = vq[k]; vp[k] = c * u - s * w; vq[k] = s * u + c * w; }
+}
+// two-sided, phase 1: c, s of pair i from (a_pp, a_qq, a_pq) exactly as jacobi2_lds; rotate columns p, q of A (n x n, symmetric storage) and of V
+__global__ __launch_bounds__(256) void k_j2_cols(double* A, double* V, int n, int npad, int round, double tol2, const double* nfloor, double fscale, double* cs, int* rotated) {
+    int p, q;
+    round_robin_pair(blockIdx.x, round, npad, p, q);
+    double c = 1.0, sn = 0.0;
+    if (q < n) {
+        const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q], apq = A[(size_t)q * n + p];
+        if (apq != 0.0 && apq * apq > tol2 * fabs(app * aqq) && fabs(apq) > fscale * nfloor[1] + JACOBI2_ANG * fabs(aqq - app)) {
+            const double a = aqq - app, bb = 2.0 * apq, fa = fabs(a);
+            const double h = sqrt(fma(a, a, bb * bb));
+            const double r = 1.0 / sqrt(2.0 * h * (h + fa));
+            c = (fa + h) * r;
+            sn = ((a * bb >= 0.0) ? fabs(bb) : -fabs(bb)) * r;
+        }
+    }
+    __syncthreads();      // every thread has read the three scalars before any column element changes
+    if (threadIdx.x == 0) { cs[2 * blockIdx.x] = c; cs[2 * blockIdx.x + 1] = sn; if (sn != 0.0) atomicAdd(rotated, 1); }
+    if (q >= n || sn == 0.0) return;
+    double* ap = A + (size_t)p * n; double* aq = A + (size_t)q * n;
+    double* vp = V + (size_t)p * n; double* vq = V + (size_t)q * n;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const double x = ap[r], y = aq[r], u = vp[r], w = vq[r];
+        ap[r] = c * x - sn * y; aq[r] = sn * x + c * y;
+        vp[r] = c * u - sn * w; vq[r] = sn * u + c * w;
     }
 }
-// eigenvalue_j = v_j . g_j  (>= 0 up to rounding), J0 = diag(sqrt(S)) V^T (column-major), r0 = diag(sqrt(S^-1)) V^T b'
-__global__ void k_eigen_sqrt(const double* G, const double* V, const double* bq, int n, double eps, double* J0, double* r0) {
+// phase 2: rows p, q of A with the same c, s
+__global__ __launch_bounds__(256) void k_j2_rows(double* A, int n, int npad, int round, const double* cs) {
+    int p, q;
+    round_robin_pair(blockIdx.x, round, npad, p, q);
+    const double c = cs[2 * blockIdx.x], sn = cs[2 * blockIdx.x + 1];
+    if (q >= n || sn == 0.0) return;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        double* col = A + (size_t)k * n;
+        const double x = col[p], y = col[q];
+        col[p] = c * x - sn * y; col[q] = sn * x + c * y;
+    }
+}
+// two-sided result: eigenvalues on the diagonal of A.  J0 = diag(sqrt(S)) V^T (column-major), r0 = diag(sqrt(S^-1)) V^T b'
+__global__ void k_eigen_sqrt(const double* A, const double* V, const double* bq, int n, double eps, double* J0, double* r0) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const double* g = G + (size_t)j * n; const double* v = V + (size_t)j * n;
-    double lam = 0.0, vb = 0.0;
-    for (int t = 0; t < n; ++t) { lam += v[t] * g[t]; vb += v[t] * bq[t]; }
+    const double* v = V + (size_t)j * n;
+    const double lam = A[(size_t)j * n + j];
+    double vb = 0.0;
+    for (int t = 0; t < n; ++t) vb += v[t] * bq[t];
     const double S = lam > eps ? lam : 0.0, Si = lam > eps ? 1.0 / lam : 0.0;
     const double ss = sqrt(S);
     for (int c = 0; c < n; ++c) J0[(size_t)c * n + j] = ss * v[c];
     r0[j] = sqrt(Si) * vb;
+}
+// ---- dense pseudo-inverse path: A' = Arr - Arm V diag(1 / lambda > eps) V^T Amr,  b' likewise (cpp:351-362) ------------------
+// lambda_j = |g_j|^2 (the converged columns of Jm are orthogonal), winv_j = 1 / lambda_j where it exceeds eps, else 0: one wave per column
+__global__ __launch_bounds__(256) void k_eig_winv(const double* G, int rows, int n, double eps, double* lam, double* winv) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= n) return;
+    const double* g = G + (size_t)j * rows;
+    double l = 0.0;
+    for (int t = lane; t < rows; t += 64) l += g[t] * g[t];
+    l = wave_sum(l);
+    if (lane == 0) { lam[j] = l; winv[j] = l > eps ? 1.0 / l : 0.0; }
+}
+// Y[j][c] = sum_t V[t][j] A[t][m + c]  (c < n),  Y[j][n] = sum_t V[t][j] b[t]      (j < m: eigenvector j against Amr | bmm)
+__global__ __launch_bounds__(64) void k_vt_amr(const double* V, const double* A, const double* b, int pos, int m, int n, double* Y) {
+    const int j = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
+    if (c > n) return;
+    const double* v = V + (size_t)j * m;
+    double acc = 0.0;
+    if (c < n) for (int t = 0; t < m; ++t) acc += v[t] * A[(size_t)t * pos + m + c];
+    else for (int t = 0; t < m; ++t) acc += v[t] * b[t];
+    Y[(size_t)j * (n + 1) + c] = acc;
+}
+// A[m + r][m + c] -= sum_j Y[j][r] winv_j Y[j][c];  b[m + r] -= sum_j Y[j][r] winv_j Y[j][n]
+__global__ __launch_bounds__(64) void k_dense_schur(double* A, double* b, int pos, int m, int n, const double* Y, const double* winv) {
+    const int r = blockIdx.y, c = blockIdx.x * 64 + threadIdx.x;
+    if (c > n) return;
+    double acc = 0.0;
+    for (int j = 0; j < m; ++j) acc += Y[(size_t)j * (n + 1) + r] * winv[j] * Y[(size_t)j * (n + 1) + c];
+    if (c < n) A[(size_t)(m + r) * pos + m + c] -= acc;
+    else b[m + r] -= acc;
+}
+// ---- certificate of marg_exact = 1: is the block-wise pseudo-inverse the dense one? ---------------------------------------------
+// In the eigenbasis of the landmark blocks Amm = [[P, C~], [C~^T, Lambda]] (P: the dropped keyframe, <= 15 dims; Lambda diagonal).
+// The block-wise path discards the landmark directions with Lambda_i <= eps and then the eigen-directions of
+// P' = P - C~ Lambda^+ C~^T below eps; the dense path discards the eigenvectors of Amm below eps.  They agree (to second order in
+// the tilt |c_i| / lambda_min of the rest) when
+//   (1) every discarded landmark direction is an eigenvector of the WHOLE matrix: its column A[:, block] u_i vanishes
+//       (w_max = max |A[:, block] u_i|, rows outside the block, kept parameters included), and
+//   (2) nothing else of Amm lies at or below the threshold: with the kept Lambda_r > hi = 2 eps, the number of eigenvalues of the
+//       remaining matrix below hi is the negative inertia of S(hi) = P - hi I - C~_r (Lambda_r - hi)^-1 C~_r^T (Sylvester), so
+//       S(hi) - tau I must be positive definite (Cholesky), tau = max(1e4 w_max, 1e3 macheps trace P): then the tilt of a discarded
+//       direction is <= w_max / tau <= 1e-4 and A' moves by <= 1e-8 relative.
+// Anything else — far landmarks whose depth information falls through the threshold, an eigenvalue in (eps, hi], a keyframe block
+// with a null direction of its own — takes the dense path.
+__global__ __launch_bounds__(64) void k_cert_w(const double* A, int pos, const int* boff, const int* bsize, CertBuf cb) {
+    __shared__ double su[36];
+    const int bi = blockIdx.x, lane = threadIdx.x;
+    const int nd = cb.ndrop[bi];
+    if (nd == 0) return;
+    const int s = bsize[bi], o = boff[bi];
+    if (lane < 36) su[lane] = cb.udrop[(size_t)bi * 36 + lane];
+    __syncthreads();
+    for (int i = 0; i < nd; ++i) {
+        double acc2 = 0.0;
+        for (int r = lane; r < pos; r += 64) {
+            if (r >= o && r < o + s) continue;
+            double dsum = 0.0;
+            for (int t = 0; t < s; ++t) dsum += A[(size_t)(o + t) * pos + r] * su[i * 6 + t];      // A is symmetric: row o + t read along r
+            acc2 += dsum * dsum;
+        }
+        acc2 = wave_sum(acc2);
+        if (lane == 0) atomicMax(cb.w2max_bits, (unsigned long long)__double_as_longlong(acc2));
+    }
+}
+// out: cert[0] = 1 when the block-wise path may be taken; diag = [w_max, smallest kept landmark eigenvalue, tau, smallest pivot]
+__global__ __launch_bounds__(256) void k_cert_final(const double* A, int pos, int po, int ps, const int* boff, const int* bsize, int nblk, double hi,
+                                                   CertBuf cb, int* cert, double* diag) {
+    __shared__ double S[MAXB * MAXB];
+    const int t = threadIdx.x;
+    if (t < ps * ps) {
+        const int i = t / ps, j = t % ps;
+        const double* ai = A + (size_t)(po + i) * pos; const double* aj = A + (size_t)(po + j) * pos;      // symmetric: row j for column j
+        double acc = ai[po + j];
+        for (int l = 0; l < nblk; ++l) {
+            const int s = bsize[l], o = boff[l];
+            const double* ph = cb.pinv_hi + (size_t)l * 36;
+            for (int tt = 0; tt < s; ++tt) {
+                const double a = ai[o + tt];
+                if (a == 0.0) continue;
+                double z = 0.0;
+                for (int c = 0; c < s; ++c) z += ph[tt * 6 + c] * aj[o + c];
+                acc -= a * z;
+            }
+        }
+        S[t] = acc;
+    }
+    __syncthreads();
+    if (t != 0) return;
+    const double wmax = sqrt(__longlong_as_double((long long)*cb.w2max_bits));
+    const double lmin = __longlong_as_double((long long)*cb.lam_min_bits);
+    double tr = 0.0;
+    for (int i = 0; i < ps; ++i) tr += fabs(A[(size_t)(po + i) * pos + po + i]);
+    const double tau = fmax(1e4 * wmax, 1e3 * 1.1102230246251565e-16 * tr);
+    bool ok = (*cb.band == 0) && (lmin > tau);
+    double minpiv = 1e300;
+    for (int k = 0; k < ps && ok; ++k) {
+        double d = S[k * ps + k] - hi - tau;
+        for (int q = 0; q < k; ++q) d -= S[k * ps + q] * S[k * ps + q];
+        minpiv = fmin(minpiv, d);
+        if (!(d > 0.0)) { ok = false; break; }
+        const double rd = 1.0 / sqrt(d);
+        S[k * ps + k] = sqrt(d);
+        for (int r = k + 1; r < ps; ++r) {
+            double v = S[r * ps + k];
+            for (int q = 0; q < k; ++q) v -= S[r * ps + q] * S[k * ps + q];
+            S[r * ps + k] = v * rd;
+        }
+    }
+    cert[0] = ok ? 1 : 0;
+    diag[0] = wmax; diag[1] = lmin; diag[2] = tau; diag[3] = minpiv;
 }
 __global__ void k_set_identity(double* V, int n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -611,6 +840,42 @@ __global__ void k_extract_cm(const double* A, int pos, int m, int n, double* G) 
     if (i >= (size_t)n * n) return;
     const int c = (int)(i / n), r = (int)(i % n);
     G[i] = 0.5 * (A[(size_t)(m + r) * pos + m + c] + A[(size_t)(m + c) * pos + m + r]);
+}
+
+__global__ void k_cert_init(CertBuf cb) {
+    *cb.band = 0;
+    *cb.lam_min_bits = (unsigned long long)__double_as_longlong(1e300);
+    *cb.w2max_bits = 0ull;
+}
+
+// (a) above: G = Jm (rows x n, column-major) is rotated in place until its columns are orthogonal; V (n x n) accumulates.
+// (b) above: A (n x n symmetric) is diagonalised in place, V accumulates.
+// The host reads the rotation count of a sweep back (a blocking 4-byte copy) from the sweep on at which such a matrix can first
+// have converged.
+int jacobi_hbm(plba_problem* p, bool two_sided, double* G, int rows, double* V, int n, hipStream_t s) {
+    DArr<double> dfloor, dcs; DArr<int> drot;
+    PLBA_HIPCK(p, dfloor.alloc(2, false)); PLBA_HIPCK(p, drot.alloc(1));
+    hipLaunchKernelGGL(k_set_identity, dim3((int)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, V, n);
+    hipLaunchKernelGGL(k_fro_floor, dim3(1), dim3(1024), 0, s, G, (size_t)rows * n, dfloor.p);
+    if (n < 2) return PLBA_OK;
+    const int npad = (n % 2) ? n + 1 : n;
+    if (two_sided) PLBA_HIPCK(p, dcs.alloc(npad, false));
+    int rotated = 1;
+    double fscale = 1.0;      // the absolute floor of the two-sided form doubles from the 15th sweep on (jacobi2_lds)
+    for (int sweep = 0; sweep < 60 && rotated; ++sweep) {
+        if (sweep >= 15) fscale *= 2.0;
+        PLBA_HIPCK(p, hipMemsetAsync(drot.p, 0, sizeof(int), s));
+        for (int round = 0; round < npad - 1; ++round) {
+            if (two_sided) {
+                hipLaunchKernelGGL(k_j2_cols, dim3(npad / 2), dim3(256), 0, s, G, V, n, npad, round, JACOBI2_TOL * JACOBI2_TOL, dfloor.p, fscale, dcs.p, drot.p);
+                hipLaunchKernelGGL(k_j2_rows, dim3(npad / 2), dim3(256), 0, s, G, n, npad, round, dcs.p);
+            } else
+                hipLaunchKernelGGL(k_hestenes_round, dim3(npad / 2), dim3(256), 0, s, G, rows, V, n, npad, round, JACOBI_TOL * JACOBI_TOL, dfloor.p, drot.p);
+        }
+        if (sweep >= 4) PLBA_HIPCK(p, plba_d2h(p, &rotated, drot.p, sizeof(int)));
+    }
+    if (rotated) PLBA_FAIL(p, PLBA_ERR_NUMERIC, "marginalize: the Jacobi eigen-decomposition of a %d-column block did not converge", n);
+    return PLBA_OK;
 }
 
 struct Param { int pid, size, drop, kf, isbias; };
@@ -698,9 +963,9 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
     const int n = pos - m;
     for (auto& o : obs) { o.col_lm = col[o.col_lm]; o.col_kf = col[o.col_kf]; }
     // ---- device work: every index list goes up before the first launch, one stream synchronisation at the end ----------------
-    DArr<double> dJ, dr, dA, db, dZ, dPinvL, dPinvP, dOut, dG, dV;
+    DArr<double> dJ, dr, dA, db, dZ, dPinvL, dPinvP, dOut, dG, dV, dVm, dLam, dY, dCertD;
     DArr<MargObs> dobs;
-    DArr<int> dboff, dbsize, delimL, delimP, dvcol, dimu, drot;
+    DArr<int> dboff, dbsize, delimL, delimP, dvcol, dimu, dCertI;
     DArr<uint8_t> drestL, drestP;
     struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{s};   // declared after the buffers: runs before they go back to the pool
     DArrStreamScope staged(s, p->have_ctx ? p->ctx.stage : nullptr);      // prepare() has synchronised: the staging area is free again
@@ -723,8 +988,8 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
     PLBA_HIPCK(p, dboff.upload(blk_off)); PLBA_HIPCK(p, dbsize.upload(blk_size)); PLBA_HIPCK(p, delimL.upload(elimL)); PLBA_HIPCK(p, delimP.upload(elimP));
     PLBA_HIPCK(p, drestL.upload(restL)); PLBA_HIPCK(p, drestP.upload(restP));
     PLBA_HIPCK(p, dPinvL.alloc(std::max<size_t>(blk_off.size(), 1) * MAXB * MAXB, false)); PLBA_HIPCK(p, dPinvP.alloc(MAXB * MAXB, false));
-    const size_t nout = 2 * (size_t)n * n + 2 * (size_t)n;
-    PLBA_HIPCK(p, dOut.alloc(nout, false));
+    const size_t nout = 2 * (size_t)n * n + 2 * (size_t)n + 1;      // [A' | b' | J0 | r0 | convergence word of k_marg_finish]
+    PLBA_HIPCK(p, dOut.alloc(nout));
     // (1) factors -> stacked Jacobian
     if (prior_row >= 0) launch_pose_edges(d, state, false, p->rob, true, s);       // refreshes pr_err = EdgeMarginalization::computeError at the final estimate
     {
@@ -733,46 +998,80 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
         if (ob + nimu + pb > 0)
             hipLaunchKernelGGL(k_marg_factors, dim3(ob + nimu + pb), dim3(64), 0, s, d, state, dobs.p, nobs, ob, dimu.p, nimu, prior_row, dvcol.p, dJ.p, dr.p, R);
     }
+    if (getenv("PLBA_MARG_DEBUG")) {      // the stacked Jacobian and residual, for an extended-precision evaluation of the whole step
+        p->marg_dbg.assign(4 + (size_t)R * pos + R, 0.0);
+        p->marg_dbg[0] = R; p->marg_dbg[1] = pos; p->marg_dbg[2] = m; p->marg_dbg[3] = n;
+        PLBA_HIPCK(p, plba_d2h(p, p->marg_dbg.data() + 4, dJ.p, (size_t)R * pos * 8));
+        PLBA_HIPCK(p, plba_d2h(p, p->marg_dbg.data() + 4 + (size_t)R * pos, dr.p, (size_t)R * 8));
+    }
     // (2) A = J^T J, b = J^T r
     launch_ata(dJ.p, R, pos, dA.p, pos, s);
     hipLaunchKernelGGL(k_jt_r, dim3((pos + 3) / 4), dim3(256), 0, s, dJ.p, dr.p, R, pos, db.p);
-    // (3) landmark blocks, then the keyframe block of the reduced system
-    if (!blk_off.empty()) {
-        const int nb = (int)blk_off.size();
-        hipLaunchKernelGGL(k_block_pinv_small, dim3((nb + 63) / 64), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, nb, eps, dPinvL.p);
-        hipLaunchKernelGGL(k_block_Z, dim3((pos + 63) / 64, nb), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, nb, dPinvL.p, dZ.p);
-        hipLaunchKernelGGL(k_schur_apply, dim3((pos + 1 + 15) / 16, (pos + 15) / 16), dim3(16, 16), 0, s, dA.p, db.p, pos, dZ.p, delimL.p, (int)elimL.size(), drestL.p);
+    // (3) pseudo-inverse Schur elimination of the dropped block: block by block, or the dense eigen-decomposition of Amm
+    const int nb = (int)blk_off.size();
+    const double hi = 2.0 * eps;
+    CertBuf cb{};
+    int mode = p->opt.marg_exact;
+    if (mode < 0 || mode > 2) PLBA_FAIL(p, PLBA_ERR_INVALID, "marg_exact = %d (0 block-wise, 1 certified block-wise else dense, 2 dense)", mode);
+    bool blockwise = mode != 2;
+    const bool cert = mode == 1 && m > 0;
+    double cert_diag[4] = {0, 0, 0, 0};
+    if (cert) {
+        PLBA_HIPCK(p, dCertD.alloc((size_t)std::max(nb, 1) * 72 + 8)); PLBA_HIPCK(p, dCertI.alloc((size_t)std::max(nb, 1) + 8));
+        cb.pinv_hi = dCertD.p + 8; cb.udrop = cb.pinv_hi + (size_t)std::max(nb, 1) * 36;
+        cb.ndrop = dCertI.p + 8; cb.band = dCertI.p + 1;
+        cb.lam_min_bits = reinterpret_cast<unsigned long long*>(dCertD.p + 4); cb.w2max_bits = reinterpret_cast<unsigned long long*>(dCertD.p + 5);
+        hipLaunchKernelGGL(k_cert_init, dim3(1), dim3(1), 0, s, cb);
     }
-    if (pose_size > 0) {
-        hipLaunchKernelGGL(k_pose_pinv, dim3(1), dim3(256), 0, s, dA.p, pos, pose_off, pose_size, eps, dPinvP.p);
-        hipLaunchKernelGGL(k_block_Z1, dim3((pos * pose_size + 255) / 256), dim3(256), 0, s, dA.p, pos, pose_off, pose_size, dPinvP.p, dZ.p);
-        hipLaunchKernelGGL(k_schur_apply, dim3((pos + 1 + 15) / 16, (pos + 15) / 16), dim3(16, 16), 0, s, dA.p, db.p, pos, dZ.p, delimP.p, (int)elimP.size(), drestP.p);
+    if (nb > 0 && blockwise)
+        hipLaunchKernelGGL(k_block_pinv_small, dim3((nb + 63) / 64), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, nb, eps, dPinvL.p, cert, hi, cb);
+    if (cert) {
+        if (nb > 0) hipLaunchKernelGGL(k_cert_w, dim3(nb), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, cb);
+        hipLaunchKernelGGL(k_cert_final, dim3(1), dim3(256), 0, s, dA.p, pos, pose_off, pose_size, dboff.p, dbsize.p, nb, hi, cb, dCertI.p, dCertD.p);
+        int ok = 0;
+        PLBA_HIPCK(p, plba_d2h(p, cert_diag, dCertD.p, sizeof cert_diag));      // (blocking: the one decision this call takes on the host)
+        PLBA_HIPCK(p, plba_d2h(p, &ok, dCertI.p, sizeof ok));
+        blockwise = ok != 0;
+    }
+    p->marg_path[0] = blockwise ? 0.0 : 1.0;
+    for (int t = 0; t < 4; ++t) p->marg_path[1 + t] = cert_diag[t];
+    if (blockwise) {
+        // landmark blocks, then the keyframe block of the reduced system
+        if (nb > 0) {
+            hipLaunchKernelGGL(k_block_Z, dim3((pos + 63) / 64, nb), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, nb, dPinvL.p, dZ.p);
+            hipLaunchKernelGGL(k_schur_apply, dim3((pos + 1 + 15) / 16, (pos + 15) / 16), dim3(16, 16), 0, s, dA.p, db.p, pos, dZ.p, delimL.p, (int)elimL.size(), drestL.p);
+        }
+        if (pose_size > 0) {
+            hipLaunchKernelGGL(k_pose_pinv, dim3(1), dim3(256), 0, s, dA.p, pos, pose_off, pose_size, eps, dPinvP.p);
+            hipLaunchKernelGGL(k_block_Z1, dim3((pos * pose_size + 255) / 256), dim3(256), 0, s, dA.p, pos, pose_off, pose_size, dPinvP.p, dZ.p);
+            hipLaunchKernelGGL(k_schur_apply, dim3((pos + 1 + 15) / 16, (pos + 15) / 16), dim3(16, 16), 0, s, dA.p, db.p, pos, dZ.p, delimP.p, (int)elimP.size(), drestP.p);
+        }
+    } else if (m > 0) {
+        // the reference's own form: eigen-decomposition of the whole Amm, eigenvalues <= eps discarded (cpp:351-362)
+        // Amm = Jm^T Jm: the first m columns of the stacked Jacobian (no longer needed as such: A and b are formed) are rotated in place
+        PLBA_HIPCK(p, dVm.alloc((size_t)m * m, false));
+        PLBA_HIPCK(p, dLam.alloc(2 * (size_t)m, false)); PLBA_HIPCK(p, dY.alloc((size_t)m * (n + 1), false));
+        if (int rc = jacobi_hbm(p, false, dJ.p, R, dVm.p, m, s)) return rc;
+        hipLaunchKernelGGL(k_eig_winv, dim3((m + 3) / 4), dim3(256), 0, s, dJ.p, R, m, eps, dLam.p, dLam.p + m);
+        hipLaunchKernelGGL(k_vt_amr, dim3((n + 1 + 63) / 64, m), dim3(64), 0, s, dVm.p, dA.p, db.p, pos, m, n, dY.p);
+        if (n > 0) hipLaunchKernelGGL(k_dense_schur, dim3((n + 1 + 63) / 64, n), dim3(64), 0, s, dA.p, db.p, pos, m, n, dY.p, dLam.p + m);
     }
     // (4) eigen square root of the kept block
     double* oAr = dOut.p; double* obr = oAr + (size_t)n * n; double* oJ0 = obr + n; double* or0 = oJ0 + (size_t)n * n;
-    if (n <= JLDS_MAX_N) {
-        const size_t sh = ((size_t)n * (n | 1) + (size_t)n * n) * sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_marg_finish), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((2 * JLDS_MAX_N * JLDS_MAX_N + JLDS_MAX_N) * sizeof(double))); attr_set = true; }
-        hipLaunchKernelGGL(k_marg_finish, dim3(1), dim3(1024), sh, s, dA.p, db.p, pos, m, n, eps, dOut.p, d.dbgbuf);
+    if (n <= JLDS_MAX_N2) {
+        const bool v_lds = n <= JLDS_MAX_N;
+        const size_t sh = ((size_t)n * (n | 1) + (v_lds ? (size_t)n * n : 0)) * sizeof(double);
+        PLBA_HIPCK(p, ensure_dyn_lds(reinterpret_cast<const void*>(k_marg_finish), 162 * 1000));
+        if (!v_lds) PLBA_HIPCK(p, dV.alloc((size_t)n * n, false));
+        hipLaunchKernelGGL(k_marg_finish, dim3(1), dim3(1024), sh, s, dA.p, db.p, pos, m, n, eps, dOut.p, v_lds ? nullptr : dV.p, d.dbgbuf);
     } else {
-        // larger kept blocks: G and V in HBM, one launch per round, convergence checked on the host once per sweep
-        PLBA_HIPCK(p, dG.alloc((size_t)n * n, false)); PLBA_HIPCK(p, dV.alloc((size_t)n * n, false)); PLBA_HIPCK(p, drot.alloc(1));
+        // larger kept blocks: G and V in HBM, one launch per round
+        PLBA_HIPCK(p, dG.alloc((size_t)n * n, false)); PLBA_HIPCK(p, dV.alloc((size_t)n * n, false));
         const int nn_blocks = (int)(((size_t)n * n + 255) / 256);
         hipLaunchKernelGGL(k_extract_cm, dim3(nn_blocks), dim3(256), 0, s, dA.p, pos, m, n, dG.p);
         PLBA_HIPCK(p, hipMemcpyAsync(oAr, dG.p, (size_t)n * n * 8, hipMemcpyDeviceToDevice, s));      // symmetric: col-major == row-major
         PLBA_HIPCK(p, hipMemcpyAsync(obr, db.p + m, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_set_identity, dim3(nn_blocks), dim3(256), 0, s, dV.p, n);
-        const int npad = (n % 2) ? n + 1 : n;
-        for (int sweep = 0; sweep < 30; ++sweep) {
-            PLBA_HIPCK(p, hipMemsetAsync(drot.p, 0, sizeof(int), s));
-            for (int round = 0; round < npad - 1; ++round)
-                hipLaunchKernelGGL(k_jacobi_round, dim3(npad / 2), dim3(256), 0, s, dG.p, dV.p, n, npad, round, JACOBI_TOL, drot.p);
-            int rotated = 0;
-            PLBA_HIPCK(p, plba_d2h(p, &rotated, drot.p, sizeof(int)));
-            PLBA_HIPCK(p, plba_stream_wait(s));
-            if (rotated == 0) break;
-        }
+        if (int rc = jacobi_hbm(p, true, dG.p, n, dV.p, n, s)) return rc;
         hipLaunchKernelGGL(k_eigen_sqrt, dim3((n + 63) / 64), dim3(64), 0, s, dG.p, dV.p, db.p + m, n, eps, oJ0, or0);
     }
     // ---- results: two asynchronous copies into pinned memory (the staging area's free tail), ONE synchronisation -------------
@@ -789,6 +1088,7 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
     PLBA_HIPCK(p, hipMemcpyAsync(hres + nout, d.kf[state], nkf * 8, hipMemcpyDeviceToHost, s));
     PLBA_HIPCK(p, plba_stream_wait(s));
     PLBA_HIPCK(p, hipGetLastError());
+    if (hres[nout - 1] >= 2.0) PLBA_FAIL(p, PLBA_ERR_NUMERIC, "marginalize: the Jacobi eigen-decomposition of the kept %d x %d block hit its sweep limit", n, n);
     // ---- output (host buffers owned by the caller until plba_prior_free) ----------------------------------------------------------
     out->n = n; out->m = m; out->nv = (int)kept.size();
     out->vid = (int32_t*)calloc(kept.size() + 1, 4); out->size = (int32_t*)calloc(kept.size() + 1, 4); out->idx = (int32_t*)calloc(kept.size() + 1, 4);

@@ -269,9 +269,11 @@ def _project(Rwb, Pwb, Rbc, Pbc, Pw):
     return uv, z
 
 
-def _gen_tracks(rng, K, N, Rwb, Pwb, Rbc, Pbc, is_line):
-    """Landmarks in front of an anchor keyframe, observed in keyframes a..a+L-1 (L ~ U{2..8}) where
-    the projection stays in the image with z > 0.1; keeps generating until N have >= 2 observations."""
+def _gen_tracks(rng, K, N, Rwb, Pwb, Rbc, Pbc, is_line, track=(2, 8), revisit=0.0):
+    """Landmarks in front of an anchor keyframe, observed in keyframes a..a+L-1 (L ~ U{track}, default U{2..8}) where
+    the projection stays in the image with z > 0.1; keeps generating until N have >= 2 observations.
+    revisit > 0: with that probability a landmark is seen again in ONE later keyframe beyond a gap of 1..3 keyframes
+    after its track (a non-consecutive re-observation, as after a short occlusion)."""
     lms, obs_lm, obs_kf, obs_uv = [], [], [], []
     count = 0
     while count < N:
@@ -279,7 +281,10 @@ def _gen_tracks(rng, K, N, Rwb, Pwb, Rbc, Pbc, is_line):
         a = rng.integers(B, 0, K - 1)
         u = rng.uniform(B, 0, IMG_W); v = rng.uniform(B, 0, IMG_H)
         depth = rng.uniform(B, 1.0, 8.0)
-        L = rng.integers(B, 2, 8)
+        L = rng.integers(B, track[0], track[1])
+        if revisit > 0.0:
+            rv = rng.uniform(B) < revisit
+            gap = rng.integers(B, 1, 3)
         Pc = np.stack([(u - CX) / FX * depth, (v - CY) / FY * depth, depth], -1)
         Pw = np.einsum("bij,bj->bi", Rwb[a], Pc @ Rbc.T + Pbc) + Pwb[a]
         if is_line:
@@ -290,6 +295,8 @@ def _gen_tracks(rng, K, N, Rwb, Pwb, Rbc, Pbc, is_line):
             if count >= N:
                 break
             ks = np.arange(a[b], min(a[b] + L[b], K))
+            if revisit > 0.0 and rv[b] and a[b] + L[b] + gap[b] < K:
+                ks = np.append(ks, a[b] + L[b] + gap[b])
             uv_s, z_s = _project(Rwb[ks], Pwb[ks], Rbc, Pbc, Pw[b])
             ok = (z_s > 0.1) & (uv_s[:, 0] >= 0) & (uv_s[:, 0] < IMG_W) & (uv_s[:, 1] >= 0) & (uv_s[:, 1] < IMG_H)
             if is_line:
@@ -306,17 +313,19 @@ def _gen_tracks(rng, K, N, Rwb, Pwb, Rbc, Pbc, is_line):
             np.concatenate(obs_uv))
 
 
-def make_window(K, Np, Nl, imu=True, seed=0x5EED0003, outlier_frac=0.05, t0=0.0, kf_id0=0):
-    """Build one synthetic window.  Returns a dict (see Problem.upload_window) plus 'truth'."""
+def make_window(K, Np, Nl, imu=True, seed=0x5EED0003, outlier_frac=0.05, t0=0.0, kf_id0=0, kf_dt=KF_DT, track=(2, 8), revisit=0.0):
+    """Build one synthetic window.  Returns a dict (see Problem.upload_window) plus 'truth'.
+    kf_dt: keyframe spacing in seconds (a multiple of the 5 ms IMU period); track: range of the track lengths;
+    revisit: probability of a non-consecutive re-observation (see _gen_tracks).  The defaults are SURVEY 8d's."""
     rng = Rng(seed)
     Rbc, Pbc = T_BS[:3, :3].copy(), T_BS[:3, 3].copy()
-    tk = t0 + KF_DT * np.arange(K)
+    tk = t0 + kf_dt * np.arange(K)
     Rwb, Pwb, Vwb = traj_R(tk), traj_p(tk), traj_v(tk)
 
     # ---- landmarks and clean observations -------------------------------------------------
-    pts, po_pt, po_kf, po_uv = _gen_tracks(rng, K, Np, Rwb, Pwb, Rbc, Pbc, False) if Np else \
+    pts, po_pt, po_kf, po_uv = _gen_tracks(rng, K, Np, Rwb, Pwb, Rbc, Pbc, False, track, revisit) if Np else \
         (np.zeros((0, 3)), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2)))
-    lns, lo_ln, lo_kf, lo_uv4 = _gen_tracks(rng, K, Nl, Rwb, Pwb, Rbc, Pbc, True) if Nl else \
+    lns, lo_ln, lo_kf, lo_uv4 = _gen_tracks(rng, K, Nl, Rwb, Pwb, Rbc, Pbc, True, track, revisit) if Nl else \
         (np.zeros((0, 6)), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 4)))
     Ep, El = len(po_pt), len(lo_ln)
 
@@ -342,7 +351,7 @@ def make_window(K, Np, Nl, imu=True, seed=0x5EED0003, outlier_frac=0.05, t0=0.0,
     ba_st = BA_TRUE + rng.normal(3, 1e-2)
     imu_blk = None
     if imu and K > 1:
-        S = int(round(KF_DT / IMU_DT))
+        S = int(round(kf_dt / IMU_DT))
         M = K - 1
         ts = tk[:-1, None] + IMU_DT * (np.arange(S)[None, :] + 0.5)        # mid-interval samples
         Rs = traj_R(ts)

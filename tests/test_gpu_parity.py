@@ -1,5 +1,8 @@
 """GPU parity tests: every stage of the HIP hot path against the CPU oracle on identical seeded
 windows, through the C ABI (include/plba.h).  Tolerances are fp64 rounding scaled by magnitude."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -511,36 +514,88 @@ def test_marginalization_parity(pkg, orc, hip):
     g.close(); o.close()
 
 
-def _far_window(pkg, far):
-    """the landmarks the oldest keyframe sees, pushed out along their rays: Jacobians ~ fx / depth, so the information a view
-    gives on a landmark falls like 1 / depth^2 and its depth direction like 1 / depth^4 — through the 1e-8 threshold"""
-    w = pkg.window.make_window(6, 120, 20, imu=True, seed=31, outlier_frac=0.0)
-    P0 = w["kf"]["P"][0]
-    sp = sorted(set(w["po_pt"][w["po_kf"] == 0].tolist())); sl = sorted(set(w["lo_ln"][w["lo_kf"] == 0].tolist()))
-    w["points"][sp] = P0 + far * (w["points"][sp] - P0)
-    w["lines"][sl] = np.tile(P0, 2) + far * (w["lines"][sl] - np.tile(P0, 2))
-    return w
+def _marg_exact_cases():
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    import marg_cases
+    return marg_cases.CASES, marg_cases.case_window, np.load(os.path.join(here, "marg_exact.npz"))
 
 
-def test_marginalization_structured_pinv_against_the_dense_pinv(pkg, orc, hip):
-    """VERDICT r01 item 2.  The reference thresholds the eigenvalues of the WHOLE dropped block Amm at 1e-8
-    (IMU/marginalization.cpp:351-362, the oracle does the same on the dense matrix); the device eliminates landmark blocks
-    first and thresholds block by block (plba_marg.hip).  The two agree when every discarded direction is a block-local null
-    space — any scene whose landmark depths keep the depth information above 1e-8 (with this camera and a 0.5 m baseline:
-    below ~1.4 km) — and do NOT agree when a discarded direction carries a little information and mixes the keyframe with its
-    landmarks.  This test pins both statements and records the size of the deviation."""
-    dev = {}
-    for far in (1.0, 10.0, 1e3, 1e6, 1e7):
-        w = _far_window(pkg, far)
+def test_marginalization_pinv_of_the_whole_dropped_block(pkg, orc, hip):
+    """VERDICT r02 item 1.  The reference thresholds the eigenvalues of the WHOLE dropped block Amm at 1e-8
+    (IMU/marginalization.cpp:351-362).  Default options (marg_exact = 1): the device takes the cheap block-by-block form only when
+    its certificate proves it identical, else the dense eigen-decomposition of Amm (one-sided Jacobi on the stacked Jacobian's
+    columns).  Arbiter: tests/golden/marg_exact.npz — the step evaluated at 40 digits (make_marg_exact.py) — because where far
+    landmarks put eigenvalues of Amm around the threshold the fp64 oracle is itself only good to ~1e-4 (forming Amm in fp64 moves
+    them; tests/test_oracle_marg.py pins that)."""
+    cases, case_window, gold = _marg_exact_cases()
+    for name, spec in cases:
+        w = case_window(pkg, spec)
         g, o = _pair(pkg, orc, w)
         pg, po = g.marginalize(0, 50), o.marginalize(0, 50)
+        path = g.debug_get("marg_path")
         g.close(); o.close()
-        assert (pg["n"], list(pg["vid"])) == (po["n"], list(po["vid"]))
-        dev[far] = np.abs(pg["Ar"] - po["Ar"]).max() / np.abs(po["Ar"]).max()
-    # realistic depths (7 m, 70 m) and the all-null case (7e7 m: every far direction is below the threshold in both): parity
-    assert dev[1.0] < 1e-9 and dev[10.0] < 1e-7 and dev[1e7] < 1e-9, dev
-    # 7 km and 7000 km: thresholded directions that are not block-local; measured 2.8e-2 and 3.4e-2 of max |A'| on MI355X
-    assert 1e-4 < dev[1e3] < 0.2 and 1e-4 < dev[1e6] < 0.2, dev
+        Ar, br, r0r0 = gold[name + "_Ar"], gold[name + "_br"], float(gold[name + "_r0r0"][0])
+        assert (pg["m"], pg["n"]) == tuple(int(x) for x in gold[name + "_dims"][:2]) and list(pg["vid"]) == list(gold[name + "_vid"])
+        sc, sb = np.abs(Ar).max(), max(np.abs(br).max(), 1.0)
+        dev_A, dev_b = np.abs(pg["Ar"] - Ar).max() / sc, np.abs(pg["br"] - br).max() / sb
+        orc_A = np.abs(po["Ar"] - Ar).max() / sc
+        assert dev_A < 1e-10 and dev_b < 1e-10, (name, dev_A, dev_b)
+        # far landmarks: the dense path must have been taken (the block-wise form is off by up to 3e-2 there, see below)
+        assert int(path[0]) == (1 if spec.get("far", 1.0) >= 1e2 else 0), (name, path)
+        assert dev_A <= orc_A + 1e-12, (name, dev_A, orc_A)
+        # b'^T A'^+ b' weights each eigen-direction by 1 / lambda down to 1e-8: conditioned like A', fp64 reaches 1e-5 .. 1e-3
+        # (device AND oracle, measured against the 40-digit value) — which is why _marg_compare checks it only to 1e-3
+        dev_r, orc_r = abs(pg["r0"] @ pg["r0"] - r0r0) / r0r0, abs(po["r0"] @ po["r0"] - r0r0) / r0r0
+        assert dev_r < 5e-4 and dev_r < 4.0 * orc_r + 1e-4, (name, dev_r, orc_r)
+        # the prior itself: J0^T J0 = A' restricted to its eigenvalues above eps
+        wv, V = np.linalg.eigh(Ar)
+        keep = wv > 1e-8
+        assert np.abs(pg["J0"].T @ pg["J0"] - (V[:, keep] * wv[keep]) @ V[:, keep].T).max() < 1e-7 * sc, name
+
+
+def test_marginalization_forced_paths(pkg, orc, hip):
+    """marg_exact = 2 (always dense) and 0 (always block-wise) against the 40-digit values: the dense form is exact everywhere; the
+    block-wise one only where every discarded direction is a block-local null space (far = 1), and is off by 1e-3 .. 3e-2 of
+    max |A'| on the far-landmark windows — the deviation VERDICT r02 asked to remove from the default path."""
+    cases, case_window, gold = _marg_exact_cases()
+    for name, spec in cases:
+        w = case_window(pkg, spec)
+        dev = {}
+        for mode in (0, 2):
+            g = pkg.new_problem(marg_exact=mode); g.upload_window(w)
+            pg = g.marginalize(0, 50)
+            assert int(g.debug_get("marg_path")[0]) == (1 if mode == 2 else 0)
+            g.close()
+            dev[mode] = np.abs(pg["Ar"] - gold[name + "_Ar"]).max() / np.abs(gold[name + "_Ar"]).max()
+        assert dev[2] < 1e-10, (name, dev)
+        if spec.get("far", 1.0) >= 1e2:
+            assert 1e-4 < dev[0] < 0.2, (name, dev)
+        else:
+            assert dev[0] < 1e-10, (name, dev)
+
+
+@pytest.mark.parametrize("K,dt,n_expect", [(11, 0.1, 96), (12, 0.1, 105), (15, 0.08, 132), (21, 0.05, 186)])
+def test_marginalization_kept_blocks_beyond_100_dims(pkg, orc, hip, K, dt, n_expect):
+    """VERDICT r02 item 4 / ADVICE: tracks over the whole window put every keyframe among the kept parameters — n = 15 + 9 (K - 2):
+    105 at the reference's 12-keyframe window (src/mapHandler.cpp:6109-6188).  n <= 100: A' and V in one workgroup's LDS;
+    n <= 140: A' in LDS, V in global memory (n > 128: three pairs per half-wave); beyond: two-sided Jacobi, two launches per round.
+    Each against the oracle, first slide and chained slide (the old prior as a factor)."""
+    w = pkg.window.make_window(K, 300, 60, imu=True, seed=77, kf_dt=dt, track=(K, K))
+    g, o = _pair(pkg, orc, w)
+    g.optimize(2); o.optimize(2)
+    pg, po = g.marginalize(0, 50), o.marginalize(0, 50)
+    assert pg["n"] == n_expect
+    _marg_compare(pg, po)
+    g.close(); o.close()
+    w["prior"] = po
+    g, o = _pair(pkg, orc, w)
+    g.optimize(2); o.optimize(2)
+    pg2, po2 = g.marginalize(0, 50), o.marginalize(0, 50)
+    assert pg2["n"] == n_expect
+    _marg_compare(pg2, po2)
+    g.close(); o.close()
 
 
 def test_sliding_window_with_device_prior(pkg, orc, hip):
