@@ -102,10 +102,11 @@ typedef struct {
     double chi2_final;          /* activeRobustChi2 of the state left in the problem            */
     double lambda_final;
     double ms_total;            /* wall time of this call, device-synchronised                  */
-    double ms_phase[8];         /* device ms by HIP events when options.profile: [0] linearize launch (observations + IMU / prior
-                                   edges, Jacobians), [1] the dense factorisation launches alone (first-block launch + one per block
+    double ms_phase[8];         /* device ms by HIP events when options.profile: [0] time inside the linearising launches (observations +
+                                   IMU / prior edges, Jacobians) wherever they run — at the head of an iteration, or as the trial pass
+                                   that linearises the trial state while it measures it; plba_debug_get "prof_lin_launches" counts them —, [1] the dense factorisation launches alone (first-block launch + one per block
                                    step; profile >= 1), [2] landmark inverse + assemble + Schur pairs, [3] dense solve (factorisation + back-substitution),
-                                   [4] landmark back-substitution + state update, [5] trial error pass, [6] exchange, [7] landmark Hll + reductions */
+                                   [4] landmark back-substitution + state update, [5] errors-only trial passes, [6] exchange, [7] landmark Hll + reductions */
 } plba_stats;
 
 /* One row per LM trial, for golden traces (tests/golden). */

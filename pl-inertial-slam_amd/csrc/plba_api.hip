@@ -1137,6 +1137,7 @@ static int enqueue_linearize(plba_problem* p, bool first_iter, int iteration) {
         HIPCK(p, hipMemsetAsync(d.bimu, 0, (size_t)d.ld * 8, s));
     }
     MARK(p, 0);
+    p->lin_in_span = !p->spec_lin;      // profile = 2: does the span between events 0 and 2 hold a k_linearize<true> launch?
     if (!p->spec_lin) launch_linearize(d, p->cur, true, p->rob, owns_pose_edges(p), s);   // observations + IMU / prior edges, one launch
     p->spec_lin = false;      // else: already enqueued right behind the previous trial's k_decide (plba_optimize)
     MARK(p, 2);
@@ -1320,9 +1321,14 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             if (p->opt.profile >= 2) st.ms_phase[1] += span(11, 12);
             else if (p->opt.profile == 1 && p->ev_sample) { fact_sampled_ms += span(11, 12); ++fact_samples; }
             if (p->opt.profile >= 2) {
-                if (qmax == 0) { st.ms_phase[0] += span(0, 2); st.ms_phase[7] += span(2, 3); }
+                // ms_phase[0] = time inside k_linearize<true> launches, wherever they run: at the head of an iteration only when the
+                // accepted trial had not linearised that state already (the call's first iteration, or after a rejection); in the
+                // synchronous trial form (jac_sync) the launch between events 8 and 9 IS the linearisation of the trial state.
+                // prof_lin_launches counts the launches bracketed, so that time / count is an average launch duration (bench.py).
+                if (qmax == 0) { if (p->lin_in_span) { st.ms_phase[0] += span(0, 2); ++p->prof_lin_launches; } st.ms_phase[7] += span(2, 3); }
                 st.ms_phase[2] += span(4, 5); st.ms_phase[6] += span(5, 6); st.ms_phase[3] += span(6, 7);
-                st.ms_phase[4] += span(7, 8); st.ms_phase[5] += span(8, 9); st.ms_phase[7] += span(9, 10);
+                st.ms_phase[4] += span(7, 8); st.ms_phase[7] += span(9, 10);
+                if (jac_sync) { st.ms_phase[0] += span(8, 9); ++p->prof_lin_launches; } else st.ms_phase[5] += span(8, 9);
             }
             const Ctrl& c = *p->h_ctrl;
             rho = c.rho;
@@ -1656,6 +1662,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     else if (w == "dbgbuf") { HIPCK(p, fetch(d.dbgbuf, 64, v)); }
     else if (w == "pose_dim") v = {(double)p->P};
     else if (w == "marg_path") v.assign(p->marg_path, p->marg_path + 5);
+    else if (w == "prof_lin_launches") v = {(double)p->prof_lin_launches};
     else if (w == "marg_J") v = p->marg_dbg;
     else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};
     else if (w == "band") v = {(double)(p->band_ok ? 1 : 0)};

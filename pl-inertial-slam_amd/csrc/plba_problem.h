@@ -166,6 +166,8 @@ struct plba_problem {
     bool ev_sample = false;    // profile = 1: this trial's factorisation span is being timed
     unsigned trial_counter = 0;
     bool spec_lin = false;
+    bool lin_in_span = false;
+    long prof_lin_launches = 0;     // profile = 2: k_linearize<true> launches whose time went into plba_stats.ms_phase[0], over the problem's life
     std::vector<double> marg_dbg;            // PLBA_MARG_DEBUG=1: [R, pos, m, n, J (R x pos column-major), r (R)] of the last plba_marginalize* (tools/marg_exact_check.py)
     double marg_path[5] = {0, 0, 0, 0, 0};   // last plba_marginalize*: [0] 0 = block-wise pseudo-inverse, 1 = dense eigen-decomposition of Amm; [1..4] certificate: w_max, smallest kept landmark eigenvalue, tau, smallest pivot
     bool spec_hll = false;
