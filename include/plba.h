@@ -88,6 +88,14 @@ typedef struct {
                                    system): identical whenever every discarded direction is a block-local null space.  1 = block by
                                    block when a device-side certificate proves that (no other eigenvalue of Amm at or below the
                                    threshold, discarded directions uncoupled), the dense path otherwise                       (1) */
+    int    lm_fused;            /* the landmark side of an iteration as fused landmark-major passes (plba_lm_dev.h): observations are
+                                   evaluated in registers where they are needed — the Schur complement as a rank-k update per group of
+                                   landmarks on the matrix cores, back-substitution + trial residuals in one pass — instead of writing a
+                                   record per observation and gathering it three times.  Possible on one GPU when the chain path is in
+                                   effect and no landmark has more than 8 observations or two in one keyframe.  2 = whenever possible;
+                                   1 = when possible and the window holds at least 250 k observations (below, the record-based passes
+                                   k_linearize / k_landmark_hll / k_schur_pairs / k_backsub are faster: measured);
+                                   0 = never                                                                                (1) */
 } plba_options;
 
 void plba_default_options(plba_options* o);

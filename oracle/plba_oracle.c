@@ -324,6 +324,7 @@ void orc_default_options(plba_options* o) {
     o->wide_steps = 0;
     o->band_solve = 1;
     o->marg_exact = 1;             /* the oracle always takes the dense eigen pseudo-inverse (cpp:351-353) */
+    o->lm_fused = 1;
 }
 const char* orc_backend_name(void) { return "cpu-oracle"; }
 

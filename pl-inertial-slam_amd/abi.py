@@ -23,7 +23,7 @@ class Options(C.Structure):
     _fields_ = [("tau", C.c_double), ("good_step_lower", C.c_double), ("good_step_upper", C.c_double),
                 ("max_trials", C.c_int), ("user_lambda_init", C.c_double), ("marg_eps", C.c_double),
                 ("fix_line_position_jacobian", C.c_int), ("whiten_marg_factors", C.c_int),
-                ("device", C.c_int), ("use_mfma", C.c_int), ("profile", C.c_int), ("factor_block", C.c_int), ("factor_flow", C.c_int), ("chain_elim", C.c_int), ("wide_steps", C.c_int), ("band_solve", C.c_int), ("marg_exact", C.c_int)]
+                ("device", C.c_int), ("use_mfma", C.c_int), ("profile", C.c_int), ("factor_block", C.c_int), ("factor_flow", C.c_int), ("chain_elim", C.c_int), ("wide_steps", C.c_int), ("band_solve", C.c_int), ("marg_exact", C.c_int), ("lm_fused", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -447,8 +447,8 @@ class Problem:
         k = w["kf"]
         self.set_keyframes(k["vid_pvr"], k["vid_bias"], k["P"], k["V"], k["q"], k["bg"], k["ba"], k["dbg"], k["dba"],
                            k["fixed_pvr"], k["fixed_bias"])
-        self.set_points(w["points"])
-        self.set_lines(w["lines"])
+        self.set_points(w["points"], w.get("point_fixed"))
+        self.set_lines(w["lines"], w.get("line_fixed"))
         self.set_point_obs(w["po_pt"], w["po_kf"], w["po_uv"], w["po_w"])
         self.set_line_obs(w["lo_ln"], w["lo_kf"], w["lo_l"], w["lo_w"])
         if w.get("imu") is not None:

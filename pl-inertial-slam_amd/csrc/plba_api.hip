@@ -66,6 +66,7 @@ void plba_default_options(plba_options* o) {
     o->wide_steps = 0;
     o->band_solve = 1;
     o->marg_exact = 1;
+    o->lm_fused = 1;
 }
 const char* plba_backend_name(void) { return "hip-gfx950"; }
 const char* plba_last_error(const plba_problem* p) { return p ? p->err : g_create_err; }
@@ -399,6 +400,138 @@ private:
 };
 }  // namespace
 
+
+// ---- fused landmark-major passes: group structure (plba_lm_dev.h) ---------------------------------------------------------------------
+// Landmarks of one kind are ordered by (first keyframe, last keyframe, index) and cut greedily into groups whose observing keyframes
+// fit a window of LMF_W; the observations are re-listed in that order (static data: measurement, weight, window slot, original
+// index), so that a group streams its inputs.  Per group and window-slot pair (p <= q) some landmark couples, one contribution to
+// the pose-pair block (kf[p], kf[q]); the gather lists hold them block by block in ascending group order (a fixed summation order).
+struct LmHost {
+    std::vector<LmGroup> grp;
+    std::vector<int32_t> lm_slot, lm_ob0, ob_orig, blk_ij, blk_start, blk_src, row_kf, row_start, row_src;
+    std::vector<uint8_t> lm_ws8, lm_fixed, cov;
+    std::vector<double> meas_pt, meas_ln, ob_wt;
+};
+static bool lm_structure_fits(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf) {
+    if (p->K >= 65536) return false;
+    for (int s = 0; s < p->L; ++s) {
+        const int a = lm_start[s], b = lm_start[s + 1];
+        if (b - a > LMF_W) return false;
+        for (int x = a; x < b; ++x) for (int y = x + 1; y < b; ++y) if (ob_kf[x] == ob_kf[y]) return false;      // two observations in one keyframe
+    }
+    return true;
+}
+static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf, const std::vector<double>& ob_w, LmHost& H) {
+    const int K = p->K, Np = p->Np, Nl = p->Nl, Ep = p->Ep, L = Np + Nl, E = (int)ob_kf.size();
+    H.cov.assign((size_t)K * K, 0);
+    // (sized up front and filled through raw pointers: half a million push_backs were 1.5 ms of this function at configs[2])
+    H.lm_slot.resize(L); H.lm_ob0.resize(L + 1); H.lm_ws8.resize((size_t)L * LMF_W); H.lm_fixed.resize(L); H.ob_orig.resize(E); H.ob_wt.resize(E);
+    H.meas_pt.resize(2 * (size_t)Ep); H.meas_ln.resize(3 * (size_t)(E - Ep));
+    int nlm = 0, nob = 0;
+    H.lm_ob0[0] = 0;
+    // group size: a workgroup step takes 32 points or 16 lines; as few steps per group as keep the launch within ONE round of workgroups
+    // (two fit a CU: 63 KB of LDS each) — a second round of a handful of stragglers doubled the launch at configs[2] (563 groups) —
+    // and at most 8 (larger groups: fewer parts for the gather pass, but the window of 8 keyframes closes them anyway)
+    int steps = 1;
+    {
+        const long wg_steps = (Np + 31) / 32 + (Nl + 15) / 16;
+        steps = (int)std::min<long>(8, std::max<long>(1, (wg_steps + 439) / 440));
+        if (const char* e = getenv("PLBA_LM_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= 16) steps = v; }
+    }
+    const int gpt = 32 * steps, gln = 16 * steps;
+    std::vector<std::pair<int64_t, int32_t>> blk_c, row_c;      // (key, source)
+    std::vector<int32_t> kmin(L), kmax(L), ord, tmp, cnt(K + 1);
+    std::vector<int32_t> stamp(K, -1), slot_of(K, 0);
+    for (int s = 0; s < L; ++s) {
+        int lo = K, hi = -1;
+        for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) { lo = std::min(lo, ob_kf[e]); hi = std::max(hi, ob_kf[e]); }
+        kmin[s] = lo; kmax[s] = hi;
+    }
+    for (int kind = 0; kind < 2; ++kind) {
+        const int s0 = kind ? Np : 0, s1 = kind ? L : Np, gmax = kind ? gln : gpt;
+        // order by (first keyframe, last keyframe, index): two stable counting sorts; landmarks without an edge are not in the graph
+        ord.clear();
+        for (int s = s0; s < s1; ++s) if (kmax[s] >= 0) ord.push_back(s);
+        for (int pass = 0; pass < 2; ++pass) {
+            const std::vector<int32_t>& key = pass ? kmin : kmax;
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int32_t s : ord) cnt[key[s] + 1]++;
+            for (int k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
+            tmp.resize(ord.size());
+            for (int32_t s : ord) tmp[cnt[key[s]]++] = s;
+            ord.swap(tmp);
+        }
+        size_t at = 0;
+        while (at < ord.size()) {
+            const int gi = (int)H.grp.size();
+            int32_t win[LMF_W];
+            int nw = 0;
+            size_t end = at;
+            while (end < ord.size() && (int)(end - at) < gmax) {
+                const int s = ord[end];
+                int add = 0;
+                for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) if (stamp[ob_kf[e]] != gi) ++add;      // (a landmark's keyframes are distinct: lm_structure_fits)
+                if (nw + add > LMF_W) break;
+                for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) if (stamp[ob_kf[e]] != gi) { stamp[ob_kf[e]] = gi; win[nw++] = ob_kf[e]; }
+                ++end;
+            }
+            std::sort(win, win + nw);
+            LmGroup g;
+            memset(&g, 0, sizeof g);
+            g.lm0 = nlm; g.nlm = (int32_t)(end - at); g.nw = nw; g.is_line = kind;
+            for (int q = 0; q < LMF_W; ++q) { g.kf[q] = q < nw ? win[q] : 0; g.off[q] = q < nw ? p->off_pvr[win[q]] : -1; if (q < nw) slot_of[win[q]] = q; }
+            uint8_t cooc[LMF_W][LMF_W] = {};
+            for (size_t n = at; n < end; ++n) {
+                const int s = ord[n];
+                H.lm_slot[nlm] = s; H.lm_fixed[nlm] = p->lm_fixed[s];
+                int ws[LMF_W], nk = 0, used = 0;
+                for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) {
+                    const int w = slot_of[ob_kf[e]];
+                    ws[nk++] = w; used |= 1 << w;
+                    H.ob_orig[nob] = e; H.ob_wt[nob] = ob_w[e];
+                    if (kind == 0) { H.meas_pt[2 * (size_t)nob] = p->po_uv[2 * (size_t)e]; H.meas_pt[2 * (size_t)nob + 1] = p->po_uv[2 * (size_t)e + 1]; }
+                    else for (int c = 0; c < 3; ++c) H.meas_ln[3 * (size_t)(nob - Ep) + c] = p->lo_l[3 * (size_t)(e - Ep) + c];
+                    ++nob;
+                }
+                {   // the 8 lanes of the landmark's unit(s): lane sub < k writes its observation's slot, the others the unused slots in order
+                    uint8_t* w8 = &H.lm_ws8[(size_t)nlm * LMF_W];
+                    int q = 0;
+                    for (int a2 = 0; a2 < nk; ++a2) w8[q++] = (uint8_t)ws[a2];
+                    for (int sl = 0; sl < LMF_W; ++sl) if (!((used >> sl) & 1)) w8[q++] = (uint8_t)sl;
+                }
+                ++nlm;
+                H.lm_ob0[nlm] = nob;
+                for (int a2 = 0; a2 < nk; ++a2) for (int b2 = a2; b2 < nk; ++b2) cooc[std::min(ws[a2], ws[b2])][std::max(ws[a2], ws[b2])] = 1;
+            }
+            for (int q = 0; q < nw; ++q) {
+                if (g.off[q] < 0) continue;
+                for (int pp = 0; pp <= q; ++pp) {
+                    if (g.off[pp] < 0 || !cooc[pp][q]) continue;
+                    const int i = g.kf[pp], j = g.kf[q];
+                    H.cov[(size_t)i * K + j] = 1; H.cov[(size_t)j * K + i] = 1;
+                    blk_c.push_back({((int64_t)i << 20) | j, gi * 36 + q * (q + 1) / 2 + pp});
+                }
+                if (cooc[q][q]) row_c.push_back({(int64_t)g.kf[q], gi * LMF_W + q});
+            }
+            H.grp.push_back(g);
+            at = end;
+        }
+    }
+    H.lm_slot.resize(nlm); H.lm_ob0.resize(nlm + 1); H.lm_ws8.resize((size_t)nlm * LMF_W); H.lm_fixed.resize(nlm);
+    std::stable_sort(blk_c.begin(), blk_c.end(), [](const std::pair<int64_t, int32_t>& a, const std::pair<int64_t, int32_t>& b) { return a.first < b.first; });
+    std::stable_sort(row_c.begin(), row_c.end(), [](const std::pair<int64_t, int32_t>& a, const std::pair<int64_t, int32_t>& b) { return a.first < b.first; });
+    for (size_t t = 0; t < blk_c.size(); ++t) {
+        if (t == 0 || blk_c[t].first != blk_c[t - 1].first) { H.blk_ij.push_back((int32_t)((blk_c[t].first >> 20) | ((blk_c[t].first & 0xfffff) << 16))); H.blk_start.push_back((int32_t)t); }
+        H.blk_src.push_back(blk_c[t].second);
+    }
+    H.blk_start.push_back((int32_t)blk_c.size());
+    for (size_t t = 0; t < row_c.size(); ++t) {
+        if (t == 0 || row_c[t].first != row_c[t - 1].first) { H.row_kf.push_back((int32_t)row_c[t].first); H.row_start.push_back((int32_t)t); }
+        H.row_src.push_back(row_c[t].second);
+    }
+    H.row_start.push_back((int32_t)row_c.size());
+}
+
 static int prepare(plba_problem* p) {
     if (!p->dirty) return PLBA_OK;
     if (!p->have_cam || !p->K) FAIL(p, PLBA_ERR_STATE, "camera and keyframes must be set before optimize");
@@ -450,10 +583,32 @@ static int prepare(plba_problem* p) {
     for (int i = 0; i < Np; ++i) { memcpy(&p->lm0[(size_t)i * 6], &p->pts[(size_t)i * 3], 24); p->lm_fixed[i] = p->pt_fixed[i]; }
     for (int i = 0; i < Nl; ++i) { memcpy(&p->lm0[(size_t)(Np + i) * 6], &p->lns[(size_t)i * 6], 48); p->lm_fixed[Np + i] = p->ln_fixed[i]; }
     lap("index maps, slots");
+    // ---- fused landmark-major passes: does the structure fit?  (decided for good once the chain maps exist, below) -----------------
+    // lm_fused = 1: from LM_FUSED_MIN_OBS observations on (measured: configs[4], 1.05 M observations, 0.70 -> 0.565 ms per iteration; at
+    // configs[2], 103 k, the record-based passes are still ahead: 0.178 vs 0.190 ms — a launch there is a single round of workgroups and
+    // costs its dependent steps, not its traffic); 2: whenever the structure fits
+    int lm_min_obs = 250000;
+    if (const char* e = getenv("PLBA_LM_MIN_OBS")) lm_min_obs = atoi(e);
+    const bool lm_cand = p->opt.lm_fused != 0 && (p->opt.lm_fused >= 2 || E >= lm_min_obs) && !p->lm_disable && p->world == 1 && E > 0 && p->opt.chain_elim && p->opt.use_mfma
+                         && p->opt.factor_block != 64 && lm_structure_fits(p, lm_start, ob_kf);
+    LmHost LH;
+    if (lm_cand) build_lm_groups(p, lm_start, ob_kf, ob_w, LH);
+    lap("landmark groups");
     // ---- keyframe-pair lists for the Schur complement --------------------------------------------------
     // Counting sort of the (landmark, observation a, observation b >= a) triples by keyframe pair, on a few host threads:
     // thread t owns a contiguous range of landmarks with about 1/T of the triples; per-thread pair counts give every thread
     // its own slice of every pair's entry range, in thread (= landmark) order, so the result is the serial one bit for bit.
+    std::vector<int32_t> pair_i, pair_j, pair_start;
+    int64_t nent = 0;
+    std::vector<int32_t> ent_ei_v, ent_ej_v, ent_slot_v;
+    int32_t *ent_ei = nullptr, *ent_ej = nullptr, *ent_slot = nullptr;
+    bool ent_staged = false;
+    if (lm_cand) {
+        // the fused passes need no pair-entry lists (3 x 4 bytes x 317 k entries at configs[2], the largest item of this function):
+        // only which keyframe pairs are coupled, for the structure of the reduced system
+        for (int i = 0; i < K; ++i) for (int j = i; j < K; ++j) if (LH.cov[(size_t)i * K + j]) { pair_i.push_back(i); pair_j.push_back(j); pair_start.push_back(0); }
+        pair_start.push_back(0);
+    } else {
     const int NT = (E > 60000) ? 8 : (E > 20000) ? 4 : 1;
     std::vector<int> lm_cut(NT + 1, L);
     {
@@ -481,9 +636,7 @@ static int prepare(plba_problem* p) {
             }
     };
     HostPool::get().run(NT, count_range);
-    std::vector<int32_t> pair_i, pair_j, pair_start;
     std::vector<std::vector<int64_t>> tpos(NT, std::vector<int64_t>((size_t)K * K, -1));
-    int64_t nent = 0;
     for (int i = 0; i < K; ++i)
         for (int j = i; j < K; ++j) {
             int64_t c = 0;
@@ -498,10 +651,9 @@ static int prepare(plba_problem* p) {
     pair_start.push_back((int32_t)nent);
     // the three entry arrays are built straight in the pinned staging area when it has room (3 x 4 bytes x 317 k entries at
     // configs[2]: no pageable copy, no second pass over them)
-    std::vector<int32_t> ent_ei_v, ent_ej_v, ent_slot_v;
-    int32_t* ent_ei = (int32_t*)stage_take((size_t)nent * 4); int32_t* ent_ej = ent_ei ? (int32_t*)stage_take((size_t)nent * 4) : nullptr;
-    int32_t* ent_slot = ent_ej ? (int32_t*)stage_take((size_t)nent * 4) : nullptr;
-    const bool ent_staged = ent_slot != nullptr;
+    ent_ei = (int32_t*)stage_take((size_t)nent * 4); ent_ej = ent_ei ? (int32_t*)stage_take((size_t)nent * 4) : nullptr;
+    ent_slot = ent_ej ? (int32_t*)stage_take((size_t)nent * 4) : nullptr;
+    ent_staged = ent_slot != nullptr;
     if (!ent_staged) { ent_ei_v.resize((size_t)nent); ent_ej_v.resize((size_t)nent); ent_slot_v.resize((size_t)nent); ent_ei = ent_ei_v.data(); ent_ej = ent_ej_v.data(); ent_slot = ent_slot_v.data(); }
     auto fill_range = [&](int t) {
         int64_t* pos = tpos[t].data();
@@ -520,6 +672,7 @@ static int prepare(plba_problem* p) {
             }
     };
     HostPool::get().run(NT, fill_range);
+    }
     // Co-observation structure of the keyframes: which pose x pose blocks of the reduced system the landmarks' Schur terms can
     // touch.  A sharded run needs the UNION over the ranks (each holds the pairs of its own landmarks only): one all-reduce
     // (max) of a K x K map per upload, after which every rank derives the same assembly / exchange lists and band.
@@ -558,7 +711,8 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_po_uv.upload(p->po_uv)); HIPCK(p, p->d_lo_l.upload(p->lo_l)); HIPCK(p, p->d_ob_w.upload(ob_w));
     HIPCK(p, p->d_ob_kf.upload(ob_kf)); HIPCK(p, p->d_ob_slot.upload(ob_slot)); HIPCK(p, p->d_lm_start.upload(lm_start));
     HIPCK(p, p->d_level.upload(p->level)); HIPCK(p, p->d_lm_fixed.upload(p->lm_fixed));
-    HIPCK(p, p->d_ob_chi2.alloc(E)); HIPCK(p, p->d_erec.alloc(((size_t)Ep + 2 * (size_t)El) * EREC_UNIT + EREC)); HIPCK(p, p->d_erec2.alloc(((size_t)Ep + 2 * (size_t)El) * EREC_UNIT + EREC)); HIPCK(p, p->d_depth.alloc(E));
+    const size_t nrec = lm_cand ? 0 : ((size_t)Ep + 2 * (size_t)El) * EREC_UNIT;      // the fused passes write no record table (2 x 70 MB at configs[4])
+    HIPCK(p, p->d_ob_chi2.alloc(E)); HIPCK(p, p->d_erec.alloc(nrec + EREC)); HIPCK(p, p->d_erec2.alloc(nrec + EREC)); HIPCK(p, p->d_depth.alloc(E));
     HIPCK(p, p->d_lm_active.alloc(L));
     HIPCK(p, p->d_hll.alloc((size_t)L * 12)); HIPCK(p, p->d_bl.alloc((size_t)L * 6)); HIPCK(p, p->d_dinv.alloc((size_t)L * 12));
     HIPCK(p, p->d_tv.alloc((size_t)L * 6)); HIPCK(p, p->d_xl.alloc((size_t)L * 6));
@@ -614,8 +768,9 @@ static int prepare(plba_problem* p) {
     HIPCK(p, p->d_Linv.alloc((size_t)(p->Ppad / TILE) * TILE * TILE)); HIPCK(p, p->d_flow_flags.alloc(p->Ppad / TILE)); p->flow_epoch = 0;
     HIPCK(p, p->d_chol_flags.alloc((size_t)(p->Ppad / 32 + 2) * (p->Ppad / 32)));
     HIPCK(p, p->d_LT32.alloc((size_t)p->Ppad * 64)); HIPCK(p, p->d_rd32.alloc(p->Ppad));
-    HIPCK(p, p->d_chi_part.alloc((size_t)(E + 255) / 256 + 1)); HIPCK(p, p->d_scale_part.alloc((size_t)(L + 31) / 32 + 33));      // one partial per landmark workgroup (32 landmarks, plba_kernels.hip LML)
-    HIPCK(p, p->d_maxd_part.alloc((size_t)(L + 31) / 32 + 33)); HIPCK(p, p->d_kfdiag.alloc((size_t)K * 6)); HIPCK(p, p->d_posediag.alloc(p->ld));
+    const size_t ngrp = LH.grp.size();      // the fused passes leave one partial per landmark group in the same arrays
+    HIPCK(p, p->d_chi_part.alloc(std::max((size_t)(E + 255) / 256, ngrp) + 1)); HIPCK(p, p->d_scale_part.alloc(std::max((size_t)(L + 31) / 32 + 32, ngrp) + 1));      // one partial per landmark workgroup (32 landmarks, plba_kernels.hip LML)
+    HIPCK(p, p->d_maxd_part.alloc(std::max((size_t)(L + 31) / 32 + 32, ngrp) + 1)); HIPCK(p, p->d_kfdiag.alloc((size_t)K * 6)); HIPCK(p, p->d_posediag.alloc(p->ld));
     HIPCK(p, p->d_red.alloc(8)); HIPCK(p, p->d_ctrl.alloc(1)); HIPCK(p, p->d_trace.alloc(TRACE_CAP)); HIPCK(p, p->d_trace_n.alloc(1));
     lap("alloc + upload");
     if (ptime) fprintf(stderr, "[prepare] pool: %zu hipMalloc, %zu reused so far, %.1f MB cached\n", dev_pool().n_malloc, dev_pool().n_reuse, dev_pool().cached / 1048576.0);
@@ -832,6 +987,47 @@ static int prepare(plba_problem* p) {
         p->h_alist.swap(al);      // kept on the host: the staged upload reads it until the final wait, and the band measurement below
     }
     lap("assembly list");
+    // ---- fused landmark-major passes: final decision, gather complement of the assembly list, upload --------------------------------
+    p->lm_ok = false;
+    memset(&p->lv, 0, sizeof p->lv);
+    if (lm_cand && !p->chain_ok) {      // the fused passes assemble through the structural list of the chain path: rebuild for the record-based passes
+        p->lm_disable = true;
+        const int rc2 = prepare(p);
+        p->lm_disable = false;
+        return rc2;
+    }
+    std::vector<int32_t> al2;      // (function scope: a queued upload without staging room reads the host vector until the final wait)
+    std::vector<uint8_t> colg;
+    if (lm_cand) {
+        const int ld = p->ld;
+        std::vector<uint8_t> in_blk((size_t)p->Ppad * ld, 0);
+        colg.assign(ld, 0);
+        static const int pose6b[6] = {0, 1, 2, 6, 7, 8};
+        for (size_t b = 0; b < LH.blk_ij.size(); ++b) {
+            const int i = LH.blk_ij[b] & 0xffff, j = (LH.blk_ij[b] >> 16) & 0xffff;
+            const int oi = p->off_pvr[i], oj = p->off_pvr[j];
+            for (int r : pose6b) for (int c : pose6b) { in_blk[(size_t)(oi + r) * ld + oj + c] = 1; in_blk[(size_t)(oj + c) * ld + oi + r] = 1; }
+        }
+        for (int32_t k : LH.row_kf) for (int c : pose6b) colg[p->off_pvr[k] + c] = 1;
+        al2.reserve(p->h_alist.size());
+        for (int32_t idx : p->h_alist) if (!in_blk[idx]) al2.push_back(idx);
+        HIPCK(p, p->d_lm_grp.upload(LH.grp)); HIPCK(p, p->d_lmg_slot.upload(LH.lm_slot)); HIPCK(p, p->d_lmg_ob0.upload(LH.lm_ob0)); HIPCK(p, p->d_lmg_orig.upload(LH.ob_orig));
+        HIPCK(p, p->d_lmg_ws8.upload(LH.lm_ws8)); HIPCK(p, p->d_lmg_fixed.upload(LH.lm_fixed)); HIPCK(p, p->d_lmg_level.alloc(E)); HIPCK(p, p->d_lmg_meas_pt.upload(LH.meas_pt)); HIPCK(p, p->d_lmg_meas_ln.upload(LH.meas_ln)); HIPCK(p, p->d_lmg_wt.upload(LH.ob_wt));
+        HIPCK(p, p->d_lmg_blk_ij.upload(LH.blk_ij)); HIPCK(p, p->d_lmg_blk_start.upload(LH.blk_start)); HIPCK(p, p->d_lmg_blk_src.upload(LH.blk_src));
+        HIPCK(p, p->d_lmg_row_kf.upload(LH.row_kf)); HIPCK(p, p->d_lmg_row_start.upload(LH.row_start)); HIPCK(p, p->d_lmg_row_src.upload(LH.row_src));
+        HIPCK(p, p->d_alist2.upload(al2)); HIPCK(p, p->d_col_gather.upload(colg));
+        HIPCK(p, p->d_lmg_part.alloc(LH.grp.size() * (size_t)LMF_PART)); HIPCK(p, p->d_ob_err.alloc(2 * (size_t)E));
+        LmView& lv = p->lv;
+        lv.ngrp = (int)LH.grp.size(); lv.grp = p->d_lm_grp.p; lv.lm_slot = p->d_lmg_slot.p; lv.lm_ob0 = p->d_lmg_ob0.p; lv.ob_orig = p->d_lmg_orig.p; lv.lm_ws8 = p->d_lmg_ws8.p; lv.lm_fixed_g = p->d_lmg_fixed.p; lv.ob_level_g = p->d_lmg_level.p;
+        lv.meas_pt = p->d_lmg_meas_pt.p; lv.meas_ln = p->d_lmg_meas_ln.p; lv.ob_wt = p->d_lmg_wt.p; lv.part = p->d_lmg_part.p;
+        lv.nblk = (int)LH.blk_ij.size(); lv.blk_ij = p->d_lmg_blk_ij.p; lv.blk_start = p->d_lmg_blk_start.p; lv.blk_src = p->d_lmg_blk_src.p;
+        lv.nrow = (int)LH.row_kf.size(); lv.row_kf = p->d_lmg_row_kf.p; lv.row_start = p->d_lmg_row_start.p; lv.row_src = p->d_lmg_row_src.p;
+        lv.alist2 = p->d_alist2.p; lv.nalist2 = (int)al2.size(); lv.col_gather = p->d_col_gather.p;
+        lv.ob_err = nullptr; lv.dbg_out = 0;
+        p->lm_ok = lv.ngrp > 0;
+        if (p->lm_ok) launch_lm_level_sync(d, lv, p->stream);
+    }
+    lap("landmark-group upload");
     // ---- structural exchange list of a sharded run (k_list_pack): every lower-triangle entry of the reduced system that can be
     // non-zero before the factorisation.  Everything else is zero on every rank and need not travel.
     d.xlist = nullptr; d.nxlist = 0;
@@ -1220,6 +1416,49 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
     return PLBA_OK;
 }
 
+// ---- fused landmark-major passes (options.lm_fused; plba_lm_dev.h): the launches of one LM trial ------------------------------------
+//   C  k_lm_schur   chain segments (reading the pose-side accumulators) | groups: linearise + Hll / bl + damped inverse + rank-k update of the group's pose blocks
+//   D  k_lm_gather  blocks assembling the rest | pose-pair blocks = pose-side terms + the groups' parts
+//      chain Schur, factorisation, back-substitution of the dense system (unchanged)
+//   A  k_lm_trial   chain back-substitution segments + keyframe update | groups: landmark back-substitution, update, trial residuals
+//   B  k_pose_trial IMU / prior edges of the trial state (Jacobians into the idle accumulators) + the LM decision in its last workgroup
+// first iteration of a call: pose-side edges + the diagonal pass (chi2, max |H_jj|) + lambda_init instead of nothing before C
+static int lm_enqueue_first(plba_problem* p, int iteration) {
+    const DevBuf& d = p->dv;
+    hipStream_t s = p->stream;
+    HIPCK(p, hipMemsetAsync(d.Himu, 0, (size_t)d.Ppad * d.ld * 8, s));
+    HIPCK(p, hipMemsetAsync(d.bimu, 0, (size_t)d.ld * 8, s));
+    HIPCK(p, hipMemsetAsync(d.kfdiag, 0, (size_t)d.K * 6 * 8, s));
+    MARK(p, 0);
+    launch_pose_edges(d, p->cur, true, p->rob, true, s);
+    launch_lm_schur(d, p->lv, p->cur, p->rob, true, nullptr, false, s);
+    MARK(p, 2);
+    launch_lm_gather(d, p->lv, true, false, false, s);
+    launch_lambda_init_n(d, lm_params(p), p->d_red.p, iteration, p->lv.ngrp, s);
+    MARK(p, 3);
+    return PLBA_OK;
+}
+static int lm_enqueue_system(plba_problem* p, const DevBuf& ds, int state, bool spec) {
+    hipStream_t s = p->stream;
+    launch_lm_schur(ds, p->lv, state, p->rob, false, &p->cv, spec, s);
+    launch_lm_gather(ds, p->lv, false, true, spec, s);
+    return PLBA_OK;
+}
+static int lm_enqueue_solve_and_trial(plba_problem* p) {
+    const DevBuf& d = p->dv;
+    hipStream_t s = p->stream;
+    const int epoch = ++p->flow_epoch;
+    launch_chain_schur(d, p->cv, p->dd, s);
+    MARKF(p, 11);
+    if (p->band_ok) { launch_band_solve(p->dd, p->bandv, s); MARKF(p, 12); }
+    else if (p->twin_ok) { launch_twin_cholesky(p->dd, p->twinv, s); MARKF(p, 12); launch_trsv_back(p->dd, true, epoch, s); }
+    else { launch_cholesky(p->dd, true, epoch, s, chain_schur_factors_tile0(p->dd)); MARKF(p, 12); launch_trsv_back(p->dd, true, epoch, s); }
+    MARK(p, 7);
+    launch_lm_trial(d, p->lv, p->cur, p->cur ^ 1, p->rob, &p->cv, p->dd.x, s);
+    MARK(p, 8);
+    return PLBA_OK;
+}
+
 extern "C" {
 
 int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_flag, plba_stats* out) {
@@ -1249,7 +1488,68 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
     p->spec_lin = false; p->spec_hll = false;
     double fact_sampled_ms = 0.0;
     int fact_samples = 0;
-    for (int it = 0; it < max_iters && !(abort_flag && *abort_flag) && ok; ++it) {
+    p->lm_spec = false;
+    for (int it = 0; it < max_iters && !(abort_flag && *abort_flag) && ok && p->lm_ok; ++it) {
+        // ---- fused landmark-major passes (see lm_enqueue_* above) ------------------------------------------------------------------
+        if (it == 0 && (rc = lm_enqueue_first(p, it))) return rc;
+        double rho = 0.0;
+        int qmax = 0;
+        do {
+            p->ev_sample = (p->opt.profile == 1) && (p->trial_counter++ % PROFILE_SAMPLE == 0);
+            MARK(p, 4);
+            const bool had_spec = p->lm_spec;      // the accepted trial's system is already in the stream
+            if (!p->lm_spec && (rc = lm_enqueue_system(p, d, p->cur, false))) return rc;
+            p->lm_spec = false;
+            MARK(p, 5); MARK(p, 6);
+            if ((rc = lm_enqueue_solve_and_trial(p))) return rc;
+            const int trial = p->cur ^ 1;
+            const unsigned long long seq = ++p->mail_seq;
+            const bool jac_trial = it + 1 < max_iters;      // not the call's last iteration: the trial's pose-side edges are linearised while they are measured
+            DevBuf ds = d;
+            if (jac_trial) { std::swap(ds.Himu, ds.Himu_alt); std::swap(ds.bimu, ds.bimu_alt); std::swap(ds.bprior, ds.bprior_alt); }
+            DecideFusion df{lp, p->d_red.p, p->d_mail, seq};
+            bool spec = false;
+            if (p->opt.profile >= 2) {
+                launch_pose_trial(ds, trial, jac_trial, p->rob, true, p->lv.ngrp, nullptr, s);
+                MARK(p, 9);
+                launch_decide_n(d, lp, p->d_red.p, p->lv.ngrp, p->d_mail, seq, s);
+                MARK(p, 10);
+                HIPCK(p, plba_stream_wait(s));
+            } else {
+                launch_pose_trial(ds, trial, jac_trial, p->rob, true, p->lv.ngrp, &df, s);      // the trial's IMU / prior edges (linearised into the idle accumulators) + the decision
+                if (jac_trial) { if ((rc = lm_enqueue_system(p, ds, trial, true))) return rc; spec = true; }      // gated on the device-side decision
+                long spins = 0;
+                while (__atomic_load_n(&p->h_mail->seq, __ATOMIC_ACQUIRE) != seq) {
+                    if (++spins > (1L << 22)) { HIPCK(p, plba_stream_wait(s)); break; }
+                }
+            }
+            if (__atomic_load_n(&p->h_mail->seq, __ATOMIC_ACQUIRE) != seq) FAIL(p, PLBA_ERR_DEVICE, "LM control block was not delivered by the device");
+            *p->h_ctrl = p->h_mail->c;
+            if (p->opt.profile >= 2) st.ms_phase[1] += span(11, 12);
+            else if (p->opt.profile == 1 && p->ev_sample) { fact_sampled_ms += span(11, 12); ++fact_samples; }
+            if (p->opt.profile >= 2) {
+                // [0]: the linearising Schur pass + assembly (launch C) and the gather (launch D) when this trial issued them; [7]: first-iteration passes
+                if (qmax == 0 && it == 0) st.ms_phase[7] += span(0, 3);
+                if (!had_spec) { st.ms_phase[0] += span(4, 5); ++p->prof_lin_launches; }
+                st.ms_phase[3] += span(6, 7); st.ms_phase[4] += span(7, 8); st.ms_phase[5] += span(8, 9); st.ms_phase[7] += span(9, 10);
+            }
+            const Ctrl& c = *p->h_ctrl;
+            rho = c.rho;
+            lambda = c.lambda;
+            st.trials++;
+            if (c.accepted) {
+                p->cur ^= 1; last_chi = c.current_chi;
+                if (jac_trial) { std::swap(p->dv.Himu, p->dv.Himu_alt); std::swap(p->dv.bimu, p->dv.bimu_alt); std::swap(p->dv.bprior, p->dv.bprior_alt); }
+                p->lm_spec = spec;
+            }
+            else if (!std::isfinite(lambda)) break;
+            qmax++;
+        } while (rho < 0 && qmax < lp.max_trials && !(abort_flag && *abort_flag));
+        st.iterations++;
+        if (qmax == lp.max_trials || rho == 0 || !std::isfinite(lambda)) { ok = false; st.stop_reason = 1; }
+    }
+    p->lm_spec = false;
+    for (int it = 0; it < max_iters && !(abort_flag && *abort_flag) && ok && !p->lm_ok; ++it) {
         if ((rc = enqueue_linearize(p, it == 0, it))) return rc;
         double rho = 0.0;
         int qmax = 0;
@@ -1400,7 +1700,7 @@ int plba_set_levels(plba_problem* p, plba_edge_kind kind, const uint8_t* level) 
     }
     if (kind == PLBA_EDGE_POINT) memcpy(p->level.data(), level, p->Ep);
     else memcpy(p->level.data() + p->Ep, level, p->El);
-    if (!p->dirty && E) HIPCK(p, plba_h2d(p, p->d_level.p, p->level.data(), E));
+    if (!p->dirty && E) { HIPCK(p, plba_h2d(p, p->d_level.p, p->level.data(), E)); if (p->lm_ok) launch_lm_level_sync(p->dv, p->lv, p->stream); }
     return PLBA_OK;
 }
 int plba_get_levels(plba_problem* p, plba_edge_kind kind, uint8_t* level) {
@@ -1427,6 +1727,7 @@ int plba_gate_outliers(plba_problem* p, double thresh, int* np_out, int* nl_out)
     Ctrl* c = d.ctrl;
     HIPCK(p, hipMemsetAsync(&c->n_gate_pt, 0, 2 * sizeof(int), p->stream));
     launch_gate(d, p->cur, thresh, p->stream);
+    if (p->lm_ok) launch_lm_level_sync(d, p->lv, p->stream);      // the fused passes read the levels in group order
     HIPCK(p, hipMemcpyAsync(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, p->stream));
     HIPCK(p, plba_stream_wait(p->stream));
     p->rob.on[PLBA_EDGE_POINT] = 0;    // setRobustKernel(0) on every point / line edge (mapHandler.cpp:6055,6065)
@@ -1592,6 +1893,21 @@ int plba_debug_build(plba_problem* p, double lambda, int do_solve) {
     memset(&c0, 0, sizeof c0);
     c0.solver_ok = 1; c0.ni = 2.0;
     HIPCK(p, plba_h2d(p, d.ctrl, &c0, sizeof c0));
+    if (p->lm_ok) {      // fused landmark-major passes, with the diagnostic outputs the parity tests read (Hll, bl, residuals, xl)
+        p->lv.dbg_out = 1; p->lv.ob_err = p->d_ob_err.p;
+        if ((rc = lm_enqueue_first(p, 0))) return rc;
+        HIPCK(p, plba_stream_wait(p->stream));
+        HIPCK(p, plba_d2h(p, &c0, d.ctrl, sizeof c0));
+        c0.lambda = lambda;
+        HIPCK(p, plba_h2d(p, d.ctrl, &c0, sizeof c0));
+        rc = lm_enqueue_system(p, d, p->cur, false);
+        if (!rc && do_solve) rc = lm_enqueue_solve_and_trial(p);
+        p->lv.dbg_out = 0; p->lv.ob_err = nullptr;
+        if (rc) return rc;
+        HIPCK(p, plba_stream_wait(p->stream));
+        HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl)));
+        return PLBA_OK;
+    }
     if ((rc = enqueue_linearize(p, true, 0))) return rc;
     HIPCK(p, plba_stream_wait(p->stream));
     HIPCK(p, plba_d2h(p, &c0, d.ctrl, sizeof c0));
@@ -1653,6 +1969,11 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
         v.resize((size_t)p->M * nn);
         for (int m = 0; m < p->M; ++m) memcpy(&v[(size_t)m * nn], &h[(size_t)m * 16 + o], nn * 8);
     } else if (w == "err_prior") { HIPCK(p, fetch(d.pr_err, p->pr_nv ? p->pr_n : 0, v)); }
+    else if ((w == "err_pt" || w == "err_ln") && p->lm_ok) {      // the fused passes keep no record table: residuals left by the first-iteration pass of debug_build
+        std::vector<double> h; HIPCK(p, fetch(p->d_ob_err.p, 2 * (size_t)p->E, h));
+        if (w == "err_pt") v.assign(h.begin(), h.begin() + 2 * (size_t)p->Ep);
+        else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { v[3 * (size_t)e] = h[2 * (size_t)(p->Ep + e)]; v[3 * (size_t)e + 1] = h[2 * (size_t)(p->Ep + e) + 1]; } }
+    }
     else if (w == "err_pt" || w == "err_ln") {
         std::vector<double> h; HIPCK(p, fetch(d.erec, ((size_t)p->Ep + 2 * (size_t)p->El) * EREC_UNIT, h));
         if (w == "err_pt") { v.resize((size_t)p->Ep * 2); for (int e = 0; e < p->Ep; ++e) { const size_t o = (size_t)p->ob_pos[e] * EREC_UNIT; v[2 * (size_t)e] = h[o + EREC_PT_E0]; v[2 * (size_t)e + 1] = h[o + EREC_PT_E0 + 1]; } }      // 64-byte point record
@@ -1663,6 +1984,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     else if (w == "pose_dim") v = {(double)p->P};
     else if (w == "marg_path") v.assign(p->marg_path, p->marg_path + 5);
     else if (w == "prof_lin_launches") v = {(double)p->prof_lin_launches};
+    else if (w == "lm_fused") v = {(double)(p->lm_ok ? 1 : 0), (double)p->lv.ngrp, (double)p->lv.nblk};
     else if (w == "marg_J") v = p->marg_dbg;
     else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};
     else if (w == "band") v = {(double)(p->band_ok ? 1 : 0)};

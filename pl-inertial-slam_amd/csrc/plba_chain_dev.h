@@ -41,6 +41,16 @@ struct ChainElimLds {          // LDS of one segment's elimination (a struct so 
     double sA[81];
     int s_step, s_bad;
 };
+// ACC: read the pose-side system straight from what it is assembled from — Himu + Hconst (+ lambda on the diagonal), bimu + bprior —
+// instead of from d.sys: chain blocks and their couplings carry no landmark term, so the segments can run in the SAME launch that
+// assembles d.sys (the fused landmark passes, k_lm_gather) instead of in one behind it.
+template <bool ACC>
+__device__ __forceinline__ double chain_sys_at(const DevBuf& d, int ld, int i, int j, double lambda) {
+    const size_t idx = i >= j ? (size_t)i * ld + j : (size_t)j * ld + i;
+    if (!ACC) return d.sys[idx];
+    return d.Himu[idx] + d.Hconst[idx] + ((i == j && i < d.P) ? lambda : 0.0);
+}
+template <bool ACC = false>
 __device__ __forceinline__ void chain_elim_segment(const DevBuf& d, const ChainView& cv, const int g, ChainElimLds& LDS) {
     auto& sLsub = LDS.sLsub; auto& sLinv = LDS.sLinv; auto& sCg = LDS.sCg; auto& sBg = LDS.sBg; auto& sRhs = LDS.sRhs; auto& sA = LDS.sA;
     int& s_step = LDS.s_step; int& s_bad = LDS.s_bad;
@@ -48,6 +58,7 @@ __device__ __forceinline__ void chain_elim_segment(const DevBuf& d, const ChainV
     const int ld = d.ld;
     const int i0 = cv.seg_start[g], i1 = cv.seg_start[g + 1], n = i1 - i0;      // eliminated blocks of this segment
     if (threadIdx.x == 0) { s_step = 0; s_bad = 0; }
+    const double lambda_acc = ACC ? d.ctrl->lambda : 0.0;
     // ---- stage everything the steps read (one gather per entry, all in flight) --------------------------------------------
     for (int idx = threadIdx.x; idx < n * 162; idx += ELIM_THREADS) {
         const int bi = idx / 162, e = idx % 162;
@@ -56,7 +67,7 @@ __device__ __forceinline__ void chain_elim_segment(const DevBuf& d, const ChainV
         const int ga = e < 81 ? ci[e / 9] : (nxt ? ci[9 + (e - 81) / 9] : -1);
         const int gb = e < 81 ? ci[e % 9] : ci[(e - 81) % 9];
         const bool ok = ga >= 0 && gb >= 0;
-        const double v = sym_at(d.sys, ld, ok ? ga : 0, ok ? gb : 0);
+        const double v = chain_sys_at<ACC>(d, ld, ok ? ga : 0, ok ? gb : 0, lambda_acc);
         sCg[bi][e] = ok ? v : ((e < 81 && e / 9 == e % 9) ? 1.0 : 0.0);
     }
     for (int idx = threadIdx.x; idx < n * 3 * NSLOT * 9; idx += ELIM_THREADS) {
@@ -66,12 +77,12 @@ __device__ __forceinline__ void chain_elim_segment(const DevBuf& d, const ChainV
         const int col = (pos >= 0 && pos < cv.npos) ? cv.slotcol[pos * NSLOT + sl] : -1;
         const int gi = cv.cidx[(i0 + bi) * 9 + r];
         const bool ok = col >= 0 && gi >= 0;
-        const double v = sym_at(d.sys, ld, ok ? gi : 0, ok ? cv.pidx[ok ? col : 0] : 0);
+        const double v = chain_sys_at<ACC>(d, ld, ok ? gi : 0, ok ? cv.pidx[ok ? col : 0] : 0, lambda_acc);
         sBg[bi][e] = ok ? v : 0.0;
     }
     for (int idx = threadIdx.x; idx < n * 9; idx += ELIM_THREADS) {
         const int gi = cv.cidx[i0 * 9 + idx];
-        sRhs[idx / 9][idx % 9] = gi < 0 ? 0.0 : d.sys[(size_t)d.Ppad * ld + gi];
+        sRhs[idx / 9][idx % 9] = gi < 0 ? 0.0 : (ACC ? d.bimu[gi] + d.bprior[gi] : d.sys[(size_t)d.Ppad * ld + gi]);
     }
     __syncthreads();
     if (wv == 0) {

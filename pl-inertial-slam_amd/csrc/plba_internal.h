@@ -145,6 +145,40 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
 
 struct Robust { int on[5]; double delta[5]; };
 
+// ---- fused landmark-major passes (plba_lm_dev.h): group structure built at upload ---------------------------------------------
+constexpr int LMF_W = 8;                              // keyframes in a group's window = observations per landmark the fused passes take
+constexpr int LMF_PART = 36 * 36 + LMF_W * 12;        // doubles a group leaves for the gather pass: 36 pose-pair blocks (p <= q, index
+                                                      // q (q + 1) / 2 + p) x 36 entries, then per window slot bp (6) | bs = Hpl D bl (6)
+struct LmGroup { int32_t lm0, nlm, nw, is_line; int32_t kf[LMF_W]; int32_t off[LMF_W]; };      // landmarks [lm0, lm0 + nlm) of the group order;
+                                                      // window keyframes (ascending) and their kf_off_pvr (-1: fixed pose)
+struct LmView {
+    int ngrp;
+    const LmGroup* grp;
+    const int32_t* lm_slot;       // group order -> landmark slot
+    const int32_t* lm_ob0;        // group order (+ 1): first observation of each landmark in the group-ordered observation arrays
+    const int32_t* ob_orig;       // group order -> unified observation index (ob_level, ob_chi2)
+    const uint8_t* lm_ws8;        // group order, LMF_W per landmark: the window slots its 8 lanes write — the observations' first, then the unused ones
+    const uint8_t* lm_fixed_g;    // group order copy of lm_fixed
+    uint8_t* ob_level_g;          // group order copy of ob_level (refreshed whenever the levels change: launch_lm_level_sync)
+    const double* meas_pt;        // 2 per point observation (group order: points first, [0, Ep))
+    const double* meas_ln;        // 3 per line observation ([Ep, E))
+    const double* ob_wt;          // inv_sigma2
+    double* part;                 // ngrp x LMF_PART
+    int nblk;                     // pose-pair blocks some landmark couples (both keyframes free)
+    const int32_t* blk_ij;        // i | j << 16  (i <= j)
+    const int32_t* blk_start;     // nblk + 1
+    const int32_t* blk_src;       // contributing (group * 36 + pair index), ascending group
+    int nrow;                     // free keyframes with observations
+    const int32_t* row_kf;
+    const int32_t* row_start;     // nrow + 1
+    const int32_t* row_src;       // contributing (group * LMF_W + slot)
+    const int32_t* alist2;        // d.alist without the entries of the gathered blocks
+    int nalist2;
+    const uint8_t* col_gather;    // ld: 1 = the gather pass writes this right-hand-side column
+    double* ob_err;               // E x 2 residuals, written by the first-iteration pass for the parity tests (null: off)
+    int dbg_out;                  // 1: also leave Hll, bl, lm_active, xl where the record-based path leaves them
+};
+
 }  // namespace plba
 
 // ---- launchers implemented in plba_kernels.hip / plba_dense.hip / plba_marg.hip -----------------------
@@ -172,6 +206,14 @@ void launch_list_pack(const DevBuf& d, double* buf, bool unpack, hipStream_t s);
 void launch_tri_pack(const DevBuf& d, double* buf, bool unpack, hipStream_t s);
 void launch_lambda_init2(const DevBuf& d, const LmParams& lp, double* red, bool first_iter, int iteration, bool fused, bool keep_chi, hipStream_t s);
 void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, Mailbox* mail, unsigned long long seq, hipStream_t s);
+// fused landmark-major passes (plba_lm_dev.h)
+void launch_lm_schur(const DevBuf& d, const LmView& lv, int state, const Robust& rb, bool diag_pass, const ChainView* lead /* chain segments riding in front, or null */, bool spec, hipStream_t s);
+void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool add_lambda, bool spec, hipStream_t s);
+void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, const Robust& rb, const ChainView* lead /* chain back-substitution riding in front, or null */, const double* xd, hipStream_t s);
+void launch_pose_trial(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, int nred, const DecideFusion* df, hipStream_t s);      // IMU / prior edges of the trial state + the LM decision
+void launch_lm_level_sync(const DevBuf& d, const LmView& lv, hipStream_t s);
+void launch_lambda_init_n(const DevBuf& d, const LmParams& lp, double* red, int iteration, int nred, hipStream_t s);
+void launch_decide_n(const DevBuf& d, const LmParams& lp, double* red, int nred, Mailbox* mail, unsigned long long seq, hipStream_t s);
 void launch_gate(const DevBuf& d, int state, double thresh, hipStream_t s);
 void launch_cull(const DevBuf& d, int state, double thresh, uint8_t* bad, hipStream_t s);   // per-observation culling flags
 void launch_depth(const DevBuf& d, int state, uint8_t* out, hipStream_t s);

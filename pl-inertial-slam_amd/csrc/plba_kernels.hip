@@ -1480,9 +1480,107 @@ __global__ __launch_bounds__(256) void k_cull(DevBuf d, int state, double thresh
     bad[e] = (chi > thresh || !dpos) ? 1 : 0;
 }
 
+}  // namespace plba
+#include "plba_lm_dev.h"
+namespace plba {
+
+// ---- fused landmark-major passes: kernels (bodies in plba_lm_dev.h) ------------------------------------------------------------------
+// launch C of an iteration: [chain segments, reading the pose-side accumulators directly (they carry no landmark term) | groups]
+template <int MODE>
+__global__ __launch_bounds__(256) void k_lm_schur(DevBuf d, LmView lv, int state, Robust rb, ChainView cv, int nlead, int spec) {
+    if (spec && !d.ctrl->accepted) return;      // enqueued behind the deciding launch: runs only for the state that was accepted
+    __shared__ LmLds S;
+    extern __shared__ __attribute__((aligned(16))) double s_dyn_lm[];      // LmAcc (60 KB) | a chain segment's staging (48 KB)
+    int b = blockIdx.x;
+    if (MODE == 0 && b < nlead) { chain_elim_segment<true>(d, cv, b, *reinterpret_cast<ChainElimLds*>(s_dyn_lm)); return; }
+    b -= nlead;
+    LmAcc& A4 = *reinterpret_cast<LmAcc*>(s_dyn_lm);
+    if (lv.grp[b].is_line) lm_schur_group<true, MODE>(d, lv, b, state, rb, S, A4);
+    else lm_schur_group<false, MODE>(d, lv, b, state, rb, S, A4);
+}
+// launch D: [blocks assembling the part of the system no landmark touches | gather blocks: pose-pair blocks and right-hand-side rows =
+// pose-side terms + the groups' parts]
+__global__ __launch_bounds__(256) void k_lm_gather(DevBuf d, LmView lv, int nasm, int add_lambda, int spec, int diag) {
+    if (spec && !d.ctrl->accepted) return;
+    __shared__ double red[256];
+    int b = blockIdx.x;
+    if (b < nasm) { lm_assemble_rest(d, lv, add_lambda, b, nasm, threadIdx.x, 256); return; }
+    b -= nasm;
+    if (diag) lm_gather_diag(d, lv, b, threadIdx.x, red);
+    else lm_gather_part(d, lv, add_lambda, b, threadIdx.x, red);
+}
+// launch A: [chain back-substitution segments (+ keyframe update) | groups: landmark back-substitution, update, trial residuals]
+__global__ __launch_bounds__(LMB) void k_lm_trial(DevBuf d, LmView lv, int cur, int trial, Robust rb, ChainView cv, const double* xd, int nlead) {
+    static_assert(LMB == 256, "the chain segments ride in this launch");
+    if ((int)blockIdx.x < nlead) { chain_back_segment(d, cv, xd, blockIdx.x, cur, trial); return; }
+    __shared__ LmLds S;
+    const int g = blockIdx.x - nlead;
+    if (g == 0 && nlead == 0) for (int k = threadIdx.x; k < d.K; k += LMB) update_kf_one(d, cur, trial, k);   // keyframe part of update()
+    if (lv.grp[g].is_line) lm_trial_group<true>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
+    else lm_trial_group<false>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
+}
+// launch B: the IMU / prior edges of the trial state (with Jacobians: into the idle accumulators) and, in the workgroup that
+// finishes last, the LM decision over the chi2 partials launch A left (nred of them)
+template <bool JAC>
+__global__ __launch_bounds__(256) void k_pose_trial(DevBuf d, int state, Robust rb, int nred, DecideArgs da) {
+    __shared__ double s4[4];
+    const int m = blockIdx.x;
+    if (m < d.M) pose_edge_block<JAC, 256>(d, state, rb, m, threadIdx.x, nullptr, 0, s4);
+    else if (m == d.M && d.pr_nv > 0) prior_block<JAC>(d, state, nullptr, 0, s4);
+    if (da.fuse) trial_arrive(d, da, nred, s4);
+}
+
 // -------------------------------------------------------------------------------------------------
 // launchers
 // -------------------------------------------------------------------------------------------------
+static_assert(sizeof(ChainElimLds) <= sizeof(LmAcc), "a chain segment's staging shares the dynamic LDS of k_lm_schur");
+void launch_lm_schur(const DevBuf& d, const LmView& lv, int state, const Robust& rb, bool diag_pass, const ChainView* lead, bool spec, hipStream_t s) {
+    const size_t sh = sizeof(LmAcc);
+    if (diag_pass) {
+        if (ensure_dyn_lds(reinterpret_cast<const void*>(k_lm_schur<1>), (int)sh) != hipSuccess) return;      // surfaces at the caller's hipGetLastError
+        hipLaunchKernelGGL(k_lm_schur<1>, dim3(lv.ngrp), dim3(256), sh, s, d, lv, state, rb, ChainView{}, 0, 0);
+        return;
+    }
+    if (ensure_dyn_lds(reinterpret_cast<const void*>(k_lm_schur<0>), (int)sh) != hipSuccess) return;
+    const int nlead = lead ? lead->nseg : 0;
+    hipLaunchKernelGGL(k_lm_schur<0>, dim3(lv.ngrp + nlead), dim3(256), sh, s, d, lv, state, rb, lead ? *lead : ChainView{}, nlead, spec ? 1 : 0);
+}
+void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool add_lambda, bool spec, hipStream_t s) {
+    int nasm = 0;
+    if (!diag_pass) {
+        const size_t n = (size_t)lv.nalist2 + d.ld;
+        nasm = (int)((n + 4 * 256 - 1) / (4 * 256));
+        if (nasm > 1024) nasm = 1024;
+    }
+    const int nb = diag_pass ? lv.nrow : lm_gather_blocks(lv);
+    if (nb + nasm == 0) return;
+    hipLaunchKernelGGL(k_lm_gather, dim3(nasm + nb), dim3(256), 0, s, d, lv, nasm, add_lambda ? 1 : 0, spec ? 1 : 0, diag_pass ? 1 : 0);
+}
+void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, const Robust& rb, const ChainView* lead, const double* xd, hipStream_t s) {
+    const int nlead = lead ? lead->nseg : 0;
+    hipLaunchKernelGGL(k_lm_trial, dim3(lv.ngrp + nlead), dim3(LMB), 0, s, d, lv, cur, trial, rb, lead ? *lead : ChainView{}, xd, nlead);
+}
+void launch_pose_trial(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, int nred, const DecideFusion* df, hipStream_t s) {
+    int nb = with_pose_edges ? d.M + (d.pr_nv > 0 ? 1 : 0) : 0;
+    DecideArgs da{};
+    if (df) { da.lp = df->lp; da.red = df->red; da.mail = df->mail; da.seq = df->seq; da.nblk_lm = nred; da.fuse = 1; if (nb == 0) nb = 1; }      // no pose-side edge: one workgroup just decides
+    if (nb == 0) return;
+    if (jac) hipLaunchKernelGGL(k_pose_trial<true>, dim3(nb), dim3(256), 0, s, d, state, rb, nred, da);
+    else hipLaunchKernelGGL(k_pose_trial<false>, dim3(nb), dim3(256), 0, s, d, state, rb, nred, da);
+}
+void launch_lambda_init_n(const DevBuf& d, const LmParams& lp, double* red, int iteration, int nred, hipStream_t s) {
+    hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(256), 0, s, d, lp, red, 1, iteration, 1, 0, nred, nred);
+}
+__global__ __launch_bounds__(256) void k_lm_level_sync(DevBuf d, LmView lv) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < d.E) lv.ob_level_g[e] = d.ob_level[lv.ob_orig[e]];
+}
+void launch_lm_level_sync(const DevBuf& d, const LmView& lv, hipStream_t s) {
+    if (d.E) hipLaunchKernelGGL(k_lm_level_sync, dim3((d.E + 255) / 256), dim3(256), 0, s, d, lv);
+}
+void launch_decide_n(const DevBuf& d, const LmParams& lp, double* red, int nred, Mailbox* mail, unsigned long long seq, hipStream_t s) {
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, s, d, lp, red, 1, nred, nred, mail, seq);
+}
 int edge_blocks(const DevBuf& d) { return (d.E + 255) / 256; }
 static int lm_blocks(const DevBuf& d) { return (d.L + LML - 1) / LML; }
 

@@ -245,6 +245,15 @@ struct plba_problem {
     plba::BandView bandv{};
     plba::DArr<double> d_band_L, d_band_y, d_band_mid;
     std::vector<int32_t> h_pidx, h_seg_col, h_alist;      // host copies of the chain maps / assembly list (band measurement)
+    // fused landmark-major passes (options.lm_fused; plba_lm_dev.h)
+    bool lm_ok = false;                         // this upload runs them (structure permitting: one GPU, chain path, <= 8 observations per landmark)
+    bool lm_disable = false;                    // prepare() found the structure unfit after the fact and rebuilt for the record-based path
+    bool lm_spec = false;                       // the accepted trial's Schur pass + gather are already in the stream (enqueued behind the decision)
+    plba::LmView lv{};
+    plba::DArr<plba::LmGroup> d_lm_grp;
+    plba::DArr<int32_t> d_lmg_slot, d_lmg_ob0, d_lmg_orig, d_lmg_blk_ij, d_lmg_blk_start, d_lmg_blk_src, d_lmg_row_kf, d_lmg_row_start, d_lmg_row_src, d_alist2;
+    plba::DArr<uint8_t> d_lmg_ws8, d_lmg_fixed, d_lmg_level, d_col_gather;
+    plba::DArr<double> d_lmg_meas_pt, d_lmg_meas_ln, d_lmg_wt, d_lmg_part, d_ob_err;
     bool assembled = false;                     // k_landmark_hll already assembled the pose-side system of this iteration
     plba::DevBuf dv;
     std::vector<plba_trace_row> trace;

@@ -1,0 +1,115 @@
+"""The fused landmark-major passes (options.lm_fused = 2: k_lm_schur / k_lm_gather / k_lm_trial, csrc/plba_lm_dev.h) against the oracle
+and against the record-based passes (lm_fused = 0): the built system stage by stage, the LM protocol through rejections, priors, fixed
+landmarks / keyframes, gating, the fall-back when a landmark has more observations than a group's window takes.  Replaces
+IMU/g2otypes.cpp:286-341, 1306-1359 (linearizeOplus of the point / line edges) + g2o's buildSystem / BlockSolver::solve landmark side."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)) if b.size else 0.0
+
+
+def _pose_delta(a, b, pkg):
+    dphi = max(np.linalg.norm(pkg.window.log_so3(pkg.window.R_from_quat(qb).T @ pkg.window.R_from_quat(qa))) for qa, qb in zip(a["q"], b["q"]))
+    return max(np.abs(a["P"] - b["P"]).max(), np.abs(a["V"] - b["V"]).max(), dphi, np.abs(a["dbg"] - b["dbg"]).max(), np.abs(a["dba"] - b["dba"]).max())
+
+
+WINDOWS = {"k6": lambda pkg: pkg.window.make_window(6, 80, 20, imu=True, seed=5),
+           "k12": lambda pkg: pkg.window.make_window(12, 300, 60, imu=True, seed=0x5EED00AA),
+           "k50": lambda pkg: pkg.window.make_config(3, scale=0.1),
+           "noimu": lambda pkg: pkg.window.make_config(2, scale=0.1),
+           "points_only": lambda pkg: pkg.window.make_window(8, 200, 0, imu=True, seed=77),
+           "lines_only": lambda pkg: pkg.window.make_window(8, 0, 60, imu=True, seed=78)}
+
+
+@pytest.mark.parametrize("name", list(WINDOWS))
+def test_built_system_against_the_oracle(pkg, orc, hip, name):
+    w = WINDOWS[name](pkg)
+    g = pkg.new_problem(lm_fused=2); g.upload_window(w)
+    o = orc.new_problem(); o.upload_window(w)
+    g.debug_build(5.0, True); o.debug_build(5.0, True)
+    assert g.debug_get("lm_fused")[0] == 1
+    for what in ("chi2", "maxdiag", "err_pt", "err_ln", "hll_pt", "bl_pt", "hll_ln", "bl_ln", "bp", "bschur", "Hschur"):
+        assert _rel(g.debug_get(what), o.debug_get(what)) < 1e-9, what
+    assert _rel(g.debug_get("x"), o.debug_get("x")) < 1e-7
+    g.close(); o.close()
+
+
+@pytest.mark.parametrize("name", ["k12", "k50", "noimu"])
+def test_protocol_against_the_oracle_and_the_record_based_passes(pkg, orc, hip, name):
+    w = WINDOWS[name](pkg)
+    res = {}
+    for key, mk in (("fused", lambda: pkg.new_problem(lm_fused=2)), ("record", lambda: pkg.new_problem(lm_fused=0)), ("oracle", orc.new_problem)):
+        q = mk(); q.upload_window(w)
+        r = pkg.protocol.local_ba(q)
+        res[key] = (r, pkg.protocol.results(q), q.trace(), q.edge_chi2(0)[0].copy()); q.close()
+    ro, oo, tro, co = res["oracle"]
+    for key in ("fused", "record"):
+        r, out, tr, chi = res[key]
+        assert r["gated"] == ro["gated"]
+        assert [(t["iteration"], t["trial"], t["accepted"]) for t in tr] == [(t["iteration"], t["trial"], t["accepted"]) for t in tro]
+        assert r["stage2"].chi2_final == pytest.approx(ro["stage2"].chi2_final, rel=1e-9)
+        assert _pose_delta(out, oo, pkg) < 1e-9
+        assert np.abs(out["points"] - oo["points"]).max() < 1e-8 and np.abs(out["lines"] - oo["lines"]).max() < 1e-8
+        assert _rel(chi, co) < 1e-8      # the cached per-edge chi2 "as of the last evaluation pass" 
+
+
+def test_rejected_trials_prior_and_fixed_vertices(pkg, orc, hip):
+    """a window with a marginalization prior, two fixed keyframes, fixed landmarks and a first trial that overshoots (lambda_init far too
+    small on a no-IMU window would be ill-conditioned: here lambda_init = 1e-3 on an IMU window rejects at iteration 0)"""
+    w = pkg.window.make_window(12, 260, 50, imu=True, seed=23)
+    o = orc.new_problem(); o.upload_window(w); pkg.protocol.local_ba(o); pr = o.marginalize(0, 50); o.close()
+    w = pkg.window.make_window(12, 260, 50, imu=True, seed=23)
+    w["prior"] = pr
+    w["kf"]["fixed_pvr"][3] = 1
+    w["point_fixed"] = np.zeros(len(w["points"]), np.uint8); w["point_fixed"][::7] = 1
+    w["line_fixed"] = np.zeros(len(w["lines"]), np.uint8); w["line_fixed"][::5] = 1
+    out = {}
+    for key, mk in (("fused", lambda: pkg.new_problem(lm_fused=2)), ("oracle", orc.new_problem)):
+        q = mk(); q.upload_window(w)
+        st = q.optimize(6)
+        out[key] = (st, q.get_keyframes(), q.get_points(), q.trace()); q.close()
+    sg, kg, pg, tg = out["fused"]; so, ko, po, to = out["oracle"]
+    assert (sg.iterations, sg.trials, sg.solver_failures) == (so.iterations, so.trials, 0)
+    assert [t["accepted"] for t in tg] == [t["accepted"] for t in to]
+    assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-8)
+    assert _pose_delta(kg, ko, pkg) < 1e-8 and np.abs(pg - po).max() < 1e-7
+
+
+def test_replay_is_bit_identical_and_profile_mode_agrees(pkg, hip):
+    w = pkg.window.make_config(3, scale=0.2)
+    g = pkg.new_problem(lm_fused=2); g.upload_window(w)
+    g.optimize(3); g.save_state()
+    a = g.optimize(4); ka = g.get_keyframes(); pa = g.get_points()
+    g.restore_state()
+    b = g.optimize(4); kb = g.get_keyframes(); pb = g.get_points()
+    assert a.chi2_final == b.chi2_final and ka["P"].tobytes() == kb["P"].tobytes() and pa.tobytes() == pb.tobytes()
+    g.close()
+    # the synchronous form (profile = 2: an event after every phase, no speculation) takes the same decisions and ends in the same state
+    h = pkg.new_problem(lm_fused=2, profile=2); h.upload_window(w)
+    h.optimize(3); c = h.optimize(4); kc = h.get_keyframes()
+    assert c.chi2_final == pytest.approx(a.chi2_final, rel=1e-12) and np.abs(kc["P"] - ka["P"]).max() < 1e-12
+    assert c.ms_phase[0] > 0 and c.ms_phase[3] > 0 and c.ms_phase[4] > 0
+    h.close()
+
+
+def test_structure_that_does_not_fit_falls_back(pkg, orc, hip):
+    """tracks over all 12 keyframes: 12 observations per landmark exceed a group's window of 8 — the record-based passes run (and agree
+    with the oracle)"""
+    w = pkg.window.make_window(12, 200, 40, imu=True, seed=77, kf_dt=0.1, track=(12, 12))
+    g = pkg.new_problem(lm_fused=2); g.upload_window(w)
+    o = orc.new_problem(); o.upload_window(w)
+    sg, so = g.optimize(4), o.optimize(4)
+    assert g.debug_get("lm_fused")[0] == 0
+    assert (sg.iterations, sg.trials) == (so.iterations, so.trials) and sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-9)
+    g.close(); o.close()
+
+
+def test_default_takes_the_fused_passes_from_250k_observations(pkg, hip):
+    small = pkg.new_problem(); small.upload_window(pkg.window.make_config(3, scale=0.1)); small.optimize(1)
+    assert small.debug_get("lm_fused")[0] == 0
+    small.close()
