@@ -68,6 +68,15 @@ void hc_rec_edge(const double* camv, const double* nav22, const double* L, const
     const double sl = is_pt ? -1.0 : 1.0;
     Jl6[0] = sl * va.x; Jl6[1] = sl * va.y; Jl6[2] = sl * va.z; Jl6[3] = sl * vb.x; Jl6[4] = sl * vb.y; Jl6[5] = sl * vb.z;
 }
+void hc_so3_exp(const double* w, double* q) { const Q4 r = so3_exp(v3(w[0], w[1], w[2])); q[0] = r.x; q[1] = r.y; q[2] = r.z; q[3] = r.w; }
+void hc_so3_log(const double* q, double* w) { Q4 a; a.x = q[0]; a.y = q[1]; a.z = q[2]; a.w = q[3]; const V3 r = so3_log(a); w[0] = r.x; w[1] = r.y; w[2] = r.z; }
+void hc_so3_jr(const double* w, double* J) { const M3 r = so3_Jr(v3(w[0], w[1], w[2])); memcpy(J, r.a, 72); }
+void hc_so3_jrinv(const double* w, double* J) { const M3 r = so3_JrInv(v3(w[0], w[1], w[2])); memcpy(J, r.a, 72); }
+void hc_bias_error(const double* navi22, const double* navj22, double* e6) {
+    double si[24] = {0}, sj[24] = {0};
+    memcpy(si, navi22, 22 * 8); memcpy(sj, navj22, 22 * 8);
+    bias_error(si, sj, e6);
+}
 void hc_sym3_inv(const double* h6, double lambda, double* d6) { sym3_inv(h6, lambda, d6); }
 void hc_huber(double e, double delta, double* r) { huber(e, delta, r[0], r[1]); }
 void hc_preint_update(double* pre142, const double* w, const double* a, double dt, double gcov, double acov) {

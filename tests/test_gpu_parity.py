@@ -372,9 +372,18 @@ def test_rejected_trials_against_the_oracle_on_an_overshooting_imu_window(pkg, o
         assert a["lam"] == pytest.approx(b["lam"], rel=1e-5) and a["chi2_current"] == pytest.approx(b["chi2_current"], rel=1e-6)
         assert a["chi2_trial"] == pytest.approx(b["chi2_trial"], rel=tol), (a, b)
     assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-6)
-    # eight overshooting iterations from 20 m/s of velocity error: measured 1.3e-5 m/s between the two solvers (positions 1.4e-6 m)
-    assert max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)) < 5e-5
-    g.close(); o.close()
+    # Arbitration: how far apart may two correct fp64 solvers end on THIS window?  The oracle against itself with
+    # its inputs moved by four ulps (points and pixel measurements scaled by 1 + 2^-50) — a perturbation below anything either
+    # implementation controls.  Eight overshooting iterations from 20 m/s of velocity error amplify it to ~1e-5 on the final states;
+    # the HIP path must stay within 4x of that self-sensitivity (and of the 1e-9 floor), which is the data behind the tolerance
+    # that exceeds north_star's 1e-5 here and only here (the BASELINE windows agree to 1e-13: tests/test_golden_full.py).
+    w2 = dict(w); w2["points"] = w["points"] * (1.0 + 2.0 ** -50); w2["po_uv"] = w["po_uv"] * (1.0 + 2.0 ** -50)
+    o2 = orc.new_problem(user_lambda_init=1e4, chain_elim=chain); o2.upload_window(w2); o2.optimize(8)
+    d_self = max(_pose_delta(o2.get_keyframes(), o.get_keyframes(), pkg))
+    d_hip = max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg))
+    print("overshoot window: |HIP - oracle| = %.2e, |oracle(inputs + 4 ulp) - oracle| = %.2e" % (d_hip, d_self))
+    assert d_hip < max(4.0 * d_self, 1e-9) and d_hip < 5e-5, (d_hip, d_self)
+    g.close(); o.close(); o2.close()
 
 
 @pytest.mark.parametrize("chain", [1, 0])
