@@ -150,25 +150,42 @@ def config5_leg(pkg, stream, iters=30):
     return out
 
 
-def cpu_baseline(w, pkg, budget_s=20.0):
-    """The CPU oracle (restatement of the reference's g2o path) timed on this box's host cores on a
-    bounded sample of the same window: stage-2 LM iterations until ~budget_s of CPU work."""
+def cpu_baseline(w, pkg, budget_s=24.0):
+    """The CPU restatement of the reference's g2o path timed on this box's host cores on a bounded sample of the same window
+    (stage-2 LM iterations from the post-gating state), three ways:
+      single_thread_faithful  oracle/plba_oracle.c as the parity tests use it (-O3 -march=x86-64-v3, no contraction, dense Cholesky):
+                              one thread, as the reference's g2o build runs
+      fast_single_thread      the same source built like the reference (-O3 -march=native, reference CMakeLists.txt:41) with the
+                              reduced system factored inside its envelope (a sparse Cholesky, as g2o's LinearSolverEigen is)
+      openmp                  ... and its edge / landmark loops spread over the host cores (OpenMP)
+    `value` is the FASTEST of them (the OpenMP leg) with the threads it used: the >= 10x claim of north_star is made against that."""
     from oracle import oracle as orc
-    p = orc.new_problem()
-    p.upload_window(w)
-    stage1_and_gate(p, pkg)
-    iters, t0 = 0, time.perf_counter()
-    while True:
-        p.restore_state()
-        st = p.optimize(2)
-        iters += st.iterations
-        el = time.perf_counter() - t0
-        if el > budget_s or iters >= 200:
-            break
-    p.close()
-    return dict(value=iters / el, unit="iterations/s", cores=1, kind="port",
-                sample="%d stage-2 LM iterations of the same window on 1 host thread (%.1f s); %d host cores present" % (
-                    iters, el, os.cpu_count() or 0))
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)      # a 1-GPU box's CPU share is 16
+    legs = (("single_thread_faithful", orc.new_problem, 1, 0.4), ("fast_single_thread", lambda: orc.new_fast_problem(threads=1), 1, 0.3),
+            ("openmp", lambda: orc.new_fast_problem(threads=cores), cores, 0.3))
+    out = {}
+    for name, mk, thr, share in legs:
+        p = mk()
+        p.upload_window(w)
+        stage1_and_gate(p, pkg)
+        iters, t0 = 0, time.perf_counter()
+        while True:
+            p.restore_state()
+            st = p.optimize(2)
+            iters += st.iterations
+            el = time.perf_counter() - t0
+            if el > budget_s * share or iters >= 400:
+                break
+        p.close()
+        out[name] = dict(value=iters / el, cores=thr, iterations=iters, seconds=el)
+    best = out["openmp"]
+    return dict(value=best["value"], unit="iterations/s", cores=best["cores"], kind="port",
+                sample="%d stage-2 LM iterations of the same window on %d OpenMP threads (%.1f s); also %d on 1 thread, faithful build (%.1f s), %d on 1 thread, "
+                       "native build with a sparse Cholesky (%.1f s); %d host cores present" % (
+                    best["iterations"], best["cores"], best["seconds"], out["single_thread_faithful"]["iterations"], out["single_thread_faithful"]["seconds"],
+                    out["fast_single_thread"]["iterations"], out["fast_single_thread"]["seconds"], os.cpu_count() or 0),
+                single_thread_faithful=out["single_thread_faithful"]["value"], fast_single_thread=out["fast_single_thread"]["value"],
+                openmp=dict(cores=best["cores"], value=best["value"]))
 
 
 def main():

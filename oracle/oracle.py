@@ -26,7 +26,7 @@ def _abi():
 
 def build(force=False):
     src = os.path.join(_HERE, "plba_oracle.c")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    if force or not os.path.exists(LIB_PATH) or not os.path.exists(os.path.join(_HERE, "_build", "libplba_oracle_fast.so")) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "all"] + (["-B"] if force else []))
     return LIB_PATH
 
@@ -68,6 +68,23 @@ def lib():
 
 def new_problem(**opts):
     return _abi().Problem(lib(), **opts)
+
+
+FAST_LIB_PATH = os.path.join(_HERE, "_build", "libplba_oracle_fast.so")
+_fast = None
+
+
+def new_fast_problem(threads=None, **opts):
+    """bench.py's stronger CPU leg: the same source built -O3 -march=native -fopenmp with an envelope (sparse) Cholesky of the reduced
+    system (oracle/Makefile, PLBA_ORACLE_FAST).  Never the parity checker: its summation orders differ from the faithful build."""
+    global _fast
+    if _fast is None:
+        build()
+        _fast = _abi().Lib(FAST_LIB_PATH, "orc_")
+    if threads is not None:
+        omp = C.CDLL("libgomp.so.1")
+        omp.omp_set_num_threads(int(threads))
+    return _abi().Problem(_fast, **opts)
 
 
 def _d(a):

@@ -904,19 +904,27 @@ static int compute_active_errors(prob_t* p, double* chi_out) {
             if (p->rob_on[PLBA_EDGE_IMU_BIAS]) { huber(c, p->rob_delta[PLBA_EDGE_IMU_BIAS], rho); chi += rho[0]; } else chi += c;
         }
     }
+#ifdef PLBA_ORACLE_FAST
+#pragma omp parallel for schedule(static) reduction(+ : chi)
+#endif
     for (int e = 0; e < p->Ep; ++e) {
         if (p->po_level[e]) continue;
+        double rh[3];
         double* er = p->po_err + 2 * e;
         point_error(p, &p->ns[p->po_kf[e]], p->pt + 3 * p->po_pt[e], p->po_uv + 2 * e, er, NULL);
         double c = p->po_w[e] * (er[0] * er[0] + er[1] * er[1]);
-        if (p->rob_on[PLBA_EDGE_POINT]) { huber(c, p->rob_delta[PLBA_EDGE_POINT], rho); chi += rho[0]; } else chi += c;
+        if (p->rob_on[PLBA_EDGE_POINT]) { huber(c, p->rob_delta[PLBA_EDGE_POINT], rh); chi += rh[0]; } else chi += c;
     }
+#ifdef PLBA_ORACLE_FAST
+#pragma omp parallel for schedule(static) reduction(+ : chi)
+#endif
     for (int e = 0; e < p->El; ++e) {
         if (p->lo_level[e]) continue;
+        double rh[3];
         double* er = p->lo_err + 3 * e;
         line_error(p, &p->ns[p->lo_kf[e]], p->ln + 6 * p->lo_ln[e], p->lo_l + 3 * e, er, NULL);
         double c = p->lo_w[e] * (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]);
-        if (p->rob_on[PLBA_EDGE_LINE]) { huber(c, p->rob_delta[PLBA_EDGE_LINE], rho); chi += rho[0]; } else chi += c;
+        if (p->rob_on[PLBA_EDGE_LINE]) { huber(c, p->rob_delta[PLBA_EDGE_LINE], rh); chi += rh[0]; } else chi += c;
     }
     if (pose_edges_owned(p) && p->pr_nv) {
         int rc = prior_error(p, p->pr_err);
@@ -957,6 +965,115 @@ static void add_grad(double* b, int oi, int ni, const double* A, const double* w
         b[oi + i] += s;
     }
 }
+
+/* constructQuadraticForm of one point / line edge (App. A.4); Hpp / bp: the pose-side accumulators (the problem's own, or a thread's
+ * private copy in the PLBA_ORACLE_FAST build) */
+static void bs_point(prob_t* p, int e, double* Hpp, double* bp) {
+    if (p->po_level[e]) return;
+    int P = p->P;
+    double rho[3];
+    int l = p->po_pt[e], k = p->po_kf[e];
+    double Ji[6], Jj[18];
+    point_linearize(p, &p->ns[k], p->pt + 3 * l, Ji, Jj);
+    const double* er = p->po_err + 2 * e;
+    double w = p->po_w[e];
+    if (p->rob_on[PLBA_EDGE_POINT]) { huber(w * (er[0] * er[0] + er[1] * er[1]), p->rob_delta[PLBA_EDGE_POINT], rho); w *= rho[1]; }
+    double Om[4] = {w, 0, 0, w}, wr[2] = {-w * er[0], -w * er[1]};
+    int lact = (p->pt_xoff[l] >= 0), op = p->off_pvr[k];
+    if (lact) { add_grad(p->bl_pt + 3 * l, 0, 3, Ji, wr, 2); add_block(p->Hll_pt + 9 * l, 3, 0, 3, 0, 3, Ji, Ji, Om, 2); }
+    if (op >= 0) { add_grad(bp, op, 9, Jj, wr, 2); add_block(Hpp, P, op, 9, op, 9, Jj, Jj, Om, 2); }
+    if (lact && op >= 0) add_block(p->Hpl_pt + 27 * (size_t)e, 3, 0, 9, 0, 3, Jj, Ji, Om, 2); /* Hpl = Jj^T Om Ji (9x3) */
+}
+static void bs_line(prob_t* p, int e, double* Hpp, double* bp) {
+    if (p->lo_level[e]) return;
+    int P = p->P;
+    double rho[3];
+    int l = p->lo_ln[e], k = p->lo_kf[e];
+    double Ji[18], Jj[27];
+    line_linearize(p, &p->ns[k], p->ln + 6 * l, p->lo_l + 3 * e, Ji, Jj);
+    const double* er = p->lo_err + 3 * e;
+    double w = p->lo_w[e];
+    if (p->rob_on[PLBA_EDGE_LINE]) { huber(w * (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]), p->rob_delta[PLBA_EDGE_LINE], rho); w *= rho[1]; }
+    double Om[9] = {w, 0, 0, 0, w, 0, 0, 0, w}, wr[3] = {-w * er[0], -w * er[1], -w * er[2]};
+    int lact = (p->ln_xoff[l] >= 0), op = p->off_pvr[k];
+    if (lact) { add_grad(p->bl_ln + 6 * l, 0, 6, Ji, wr, 3); add_block(p->Hll_ln + 36 * l, 6, 0, 6, 0, 6, Ji, Ji, Om, 3); }
+    if (op >= 0) { add_grad(bp, op, 9, Jj, wr, 3); add_block(Hpp, P, op, 9, op, 9, Jj, Jj, Om, 3); }
+    if (lact && op >= 0) add_block(p->Hpl_ln + 54 * (size_t)e, 6, 0, 9, 0, 6, Jj, Ji, Om, 3);
+}
+#ifdef PLBA_ORACLE_FAST
+/* The PLBA_ORACLE_FAST build (oracle/Makefile: -O3 -march=native -ffp-contract=fast -fopenmp; bench.py's stronger CPU leg, never the
+ * parity checker): the same per-edge arithmetic, spread over the host cores by LANDMARK (a landmark's edges are contiguous and its
+ * blocks private to it), pose-side sums into thread-private copies that are added up afterwards; the reduced system factored inside
+ * its envelope (a sparse Cholesky, as g2o's LinearSolverEigen is).  Summation orders differ from the faithful build by rounding. */
+#include <omp.h>
+static void lm_edge_starts(const int32_t* lm_of, int E, int N, int* start) { /* start[l] .. start[l + 1]: the edges of landmark l */
+    int e = 0;
+    for (int l = 0; l < N; ++l) { start[l] = e; while (e < E && lm_of[e] == l) ++e; }
+    start[N] = e;
+}
+/* Landmarks in order of their first keyframe, dealt to the threads in contiguous runs: a thread then touches the pose blocks of a
+ * narrow range of keyframes, and its private copy of the pose-side sums covers the rows [lo, hi] only (full copies, 8 x 4.3 MB at
+ * configs[2], cost more to clear and add up than the edges cost to evaluate: measured). */
+typedef struct { int *ordp, *ordl, *ps, *ls; } fast_order;
+static void fast_order_make(prob_t* p, fast_order* o) {
+    o->ps = (int*)xcalloc(p->Np + 2, sizeof(int)); o->ls = (int*)xcalloc(p->Nl + 2, sizeof(int));
+    lm_edge_starts(p->po_pt, p->Ep, p->Np, o->ps); lm_edge_starts(p->lo_ln, p->El, p->Nl, o->ls);
+    o->ordp = (int*)xcalloc(p->Np + 1, sizeof(int)); o->ordl = (int*)xcalloc(p->Nl + 1, sizeof(int));
+    int* cnt = (int*)xcalloc(p->K + 2, sizeof(int));
+    for (int kind = 0; kind < 2; ++kind) {
+        const int N = kind ? p->Nl : p->Np; const int* st = kind ? o->ls : o->ps; const int32_t* kf = kind ? p->lo_kf : p->po_kf; int* ord = kind ? o->ordl : o->ordp;
+        memset(cnt, 0, (size_t)(p->K + 2) * sizeof(int));
+        for (int l = 0; l < N; ++l) { int k0 = p->K; for (int e = st[l]; e < st[l + 1]; ++e) if (kf[e] < k0) k0 = kf[e]; cnt[(k0 < p->K ? k0 : p->K) + 1]++; }
+        for (int k = 0; k <= p->K; ++k) cnt[k + 1] += cnt[k];
+        for (int l = 0; l < N; ++l) { int k0 = p->K; for (int e = st[l]; e < st[l + 1]; ++e) if (kf[e] < k0) k0 = kf[e]; ord[cnt[k0 < p->K ? k0 : p->K]++] = l; }
+    }
+    free(cnt);
+}
+static void fast_order_free(fast_order* o) { free(o->ordp); free(o->ordl); free(o->ps); free(o->ls); }
+/* fn_pt / fn_ln: the per-landmark work; H receives the pose x pose terms (leading dimension P), v a pose-side vector */
+typedef void (*fast_lm_fn)(prob_t* p, int l, int e0, int e1, double lambda, double* H, double* v);
+static void fast_over_landmarks(prob_t* p, double lambda, fast_lm_fn fn_pt, fast_lm_fn fn_ln, double* Hdst, double* vdst) {
+    const int P = p->P, nt = omp_get_max_threads();
+    fast_order o;
+    fast_order_make(p, &o);
+    double** bufs = (double**)xcalloc(nt + 1, sizeof(double*)); double** vecs = (double**)xcalloc(nt + 1, sizeof(double*));
+    int* lo = (int*)xcalloc(nt + 1, sizeof(int)); int* hi = (int*)xcalloc(nt + 1, sizeof(int));
+#pragma omp parallel num_threads(nt)
+    {
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+        const int p0 = (int)((long)p->Np * t / T), p1 = (int)((long)p->Np * (t + 1) / T), l0 = (int)((long)p->Nl * t / T), l1 = (int)((long)p->Nl * (t + 1) / T);
+        int rlo = P, rhi = -1;
+        for (int q = p0; q < p1; ++q) for (int e = o.ps[o.ordp[q]]; e < o.ps[o.ordp[q] + 1]; ++e) { const int oa = p->off_pvr[p->po_kf[e]]; if (oa >= 0) { if (oa < rlo) rlo = oa; if (oa + 8 > rhi) rhi = oa + 8; } }
+        for (int q = l0; q < l1; ++q) for (int e = o.ls[o.ordl[q]]; e < o.ls[o.ordl[q] + 1]; ++e) { const int oa = p->off_pvr[p->lo_kf[e]]; if (oa >= 0) { if (oa < rlo) rlo = oa; if (oa + 8 > rhi) rhi = oa + 8; } }
+        lo[t] = rlo; hi[t] = rhi;
+        double* buf = (rhi >= rlo) ? (double*)xcalloc((size_t)(rhi - rlo + 1) * P + 1, 8) : NULL;
+        double* vec = (double*)xcalloc(P + 1, 8);
+        bufs[t] = buf; vecs[t] = vec;
+        double* H = buf ? buf - (size_t)rlo * P : NULL;      /* rows [rlo, rhi] of a P x P matrix */
+        for (int q = p0; q < p1; ++q) { const int l = o.ordp[q]; fn_pt(p, l, o.ps[l], o.ps[l + 1], lambda, H, vec); }
+        for (int q = l0; q < l1; ++q) { const int l = o.ordl[q]; fn_ln(p, l, o.ls[l], o.ls[l + 1], lambda, H, vec); }
+#pragma omp barrier
+#pragma omp for schedule(static)
+        for (int r = 0; r < P; ++r) {
+            double* d = Hdst + (size_t)r * P;
+            for (int u = 0; u < T; ++u) {
+                if (!bufs[u] || r < lo[u] || r > hi[u]) continue;
+                const double* src = bufs[u] + (size_t)(r - lo[u]) * P;
+                for (int c = 0; c < P; ++c) d[c] += src[c];
+            }
+            double sv = 0.0;
+            for (int u = 0; u < T; ++u) sv += vecs[u][r];
+            vdst[r] += sv;
+        }
+        free(buf); free(vec);
+    }
+    free(bufs); free(vecs); free(lo); free(hi);
+    fast_order_free(&o);
+}
+static void fast_bs_pt(prob_t* p, int l, int e0, int e1, double lambda, double* H, double* v) { (void)l; (void)lambda; for (int e = e0; e < e1; ++e) bs_point(p, e, H, v); }
+static void fast_bs_ln(prob_t* p, int l, int e0, int e1, double lambda, double* H, double* v) { (void)l; (void)lambda; for (int e = e0; e < e1; ++e) bs_line(p, e, H, v); }
+static void fast_build_edges(prob_t* p) { fast_over_landmarks(p, 0.0, fast_bs_pt, fast_bs_ln, p->Hpp, p->bp); }
+#endif
 
 /* BlockSolver::buildSystem: linearizeOplus + constructQuadraticForm per active edge (App. A.4).
  * Hpp holds the upper block-triangle only (as g2o), mirrored before the dense factorisation. */
@@ -1013,34 +1130,12 @@ static void build_system(prob_t* p) {
             }
         }
     }
-    for (int e = 0; e < p->Ep; ++e) {
-        if (p->po_level[e]) continue;
-        int l = p->po_pt[e], k = p->po_kf[e];
-        double Ji[6], Jj[18];
-        point_linearize(p, &p->ns[k], p->pt + 3 * l, Ji, Jj);
-        const double* er = p->po_err + 2 * e;
-        double w = p->po_w[e];
-        if (p->rob_on[PLBA_EDGE_POINT]) { huber(w * (er[0] * er[0] + er[1] * er[1]), p->rob_delta[PLBA_EDGE_POINT], rho); w *= rho[1]; }
-        double Om[4] = {w, 0, 0, w}, wr[2] = {-w * er[0], -w * er[1]};
-        int lact = (p->pt_xoff[l] >= 0), op = p->off_pvr[k];
-        if (lact) { add_grad(p->bl_pt + 3 * l, 0, 3, Ji, wr, 2); add_block(p->Hll_pt + 9 * l, 3, 0, 3, 0, 3, Ji, Ji, Om, 2); }
-        if (op >= 0) { add_grad(p->bp, op, 9, Jj, wr, 2); add_block(p->Hpp, P, op, 9, op, 9, Jj, Jj, Om, 2); }
-        if (lact && op >= 0) add_block(p->Hpl_pt + 27 * (size_t)e, 3, 0, 9, 0, 3, Jj, Ji, Om, 2); /* Hpl = Jj^T Om Ji (9x3) */
-    }
-    for (int e = 0; e < p->El; ++e) {
-        if (p->lo_level[e]) continue;
-        int l = p->lo_ln[e], k = p->lo_kf[e];
-        double Ji[18], Jj[27];
-        line_linearize(p, &p->ns[k], p->ln + 6 * l, p->lo_l + 3 * e, Ji, Jj);
-        const double* er = p->lo_err + 3 * e;
-        double w = p->lo_w[e];
-        if (p->rob_on[PLBA_EDGE_LINE]) { huber(w * (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]), p->rob_delta[PLBA_EDGE_LINE], rho); w *= rho[1]; }
-        double Om[9] = {w, 0, 0, 0, w, 0, 0, 0, w}, wr[3] = {-w * er[0], -w * er[1], -w * er[2]};
-        int lact = (p->ln_xoff[l] >= 0), op = p->off_pvr[k];
-        if (lact) { add_grad(p->bl_ln + 6 * l, 0, 6, Ji, wr, 3); add_block(p->Hll_ln + 36 * l, 6, 0, 6, 0, 6, Ji, Ji, Om, 3); }
-        if (op >= 0) { add_grad(p->bp, op, 9, Jj, wr, 3); add_block(p->Hpp, P, op, 9, op, 9, Jj, Jj, Om, 3); }
-        if (lact && op >= 0) add_block(p->Hpl_ln + 54 * (size_t)e, 6, 0, 9, 0, 6, Jj, Ji, Om, 3);
-    }
+#ifdef PLBA_ORACLE_FAST
+    fast_build_edges(p);
+#else
+    for (int e = 0; e < p->Ep; ++e) bs_point(p, e, p->Hpp, p->bp);
+    for (int e = 0; e < p->El; ++e) bs_line(p, e, p->Hpp, p->bp);
+#endif
     if (pose_edges_owned(p) && p->pr_nv) { /* EdgeMarginalization::linearizeOplus g2otypes.cpp:1477-1497; multi-edge: all vertex pairs */
         int n = p->pr_n;
         int* off = (int*)xcalloc(p->pr_nv, sizeof(int));
@@ -1166,6 +1261,105 @@ static void chol_solve(const double* L, int n, const double* b, double* x) {
     }
 }
 
+/* BlockSolverX::solve, one landmark (App. A.5): D = (Hll + lambda I)^-1, bschur and Hschur terms of its edges [e0, e1); Hs / coeff: the
+ * problem's own arrays, or a thread's private copies in the PLBA_ORACLE_FAST build */
+static void schur_point(prob_t* p, int l, int e0, int e1, double lambda, double* Hs, double* coeff) {
+    if (p->pt_xoff[l] < 0) return;
+    int P = p->P;
+    double D[9], Dinv[9], db[3];
+    memcpy(D, p->Hll_pt + 9 * l, 72);
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    if (!lu_inverse(D, Dinv, 3)) memset(Dinv, 0, 72);
+    memcpy(p->Dinv_pt + 9 * l, Dinv, 72);
+    m3_v(Dinv, p->bl_pt + 3 * l, db);
+    for (int a = e0; a < e1; ++a) {
+        if (p->po_level[a]) continue;
+        int oa = p->off_pvr[p->po_kf[a]];
+        if (oa < 0) continue;
+        const double* Ba = p->Hpl_pt + 27 * (size_t)a;
+        double BD[27];
+        mat_mul(Ba, Dinv, BD, 9, 3, 3);
+        for (int r = 0; r < 9; ++r) coeff[oa + r] += Ba[r * 3] * db[0] + Ba[r * 3 + 1] * db[1] + Ba[r * 3 + 2] * db[2];
+        for (int b = e0; b < e1; ++b) {
+            if (p->po_level[b]) continue;
+            int ob = p->off_pvr[p->po_kf[b]];
+            if (ob < 0 || ob < oa) continue; /* upper block triangle: pairs (i1, i2 >= i1) */
+            if (ob == oa && b != a) continue;
+            const double* Bb = p->Hpl_pt + 27 * (size_t)b;
+            for (int r = 0; r < 9; ++r)
+                for (int c = 0; c < 9; ++c)
+                    Hs[(size_t)(oa + r) * P + ob + c] -= BD[r * 3] * Bb[c * 3] + BD[r * 3 + 1] * Bb[c * 3 + 1] + BD[r * 3 + 2] * Bb[c * 3 + 2];
+        }
+    }
+}
+static void schur_line(prob_t* p, int l, int e0, int e1, double lambda, double* Hs, double* coeff) {
+    if (p->ln_xoff[l] < 0) return;
+    int P = p->P;
+    double D[36], Dinv[36], db[6];
+    memcpy(D, p->Hll_ln + 36 * l, 288);
+    for (int i = 0; i < 6; ++i) D[i * 7] += lambda;
+    if (!lu_inverse(D, Dinv, 6)) memset(Dinv, 0, 288);
+    memcpy(p->Dinv_ln + 36 * l, Dinv, 288);
+    mat_mul(Dinv, p->bl_ln + 6 * l, db, 6, 6, 1);
+    for (int a = e0; a < e1; ++a) {
+        if (p->lo_level[a]) continue;
+        int oa = p->off_pvr[p->lo_kf[a]];
+        if (oa < 0) continue;
+        const double* Ba = p->Hpl_ln + 54 * (size_t)a;
+        double BD[54];
+        mat_mul(Ba, Dinv, BD, 9, 6, 6);
+        for (int r = 0; r < 9; ++r) { double s = 0; for (int t = 0; t < 6; ++t) s += Ba[r * 6 + t] * db[t]; coeff[oa + r] += s; }
+        for (int b = e0; b < e1; ++b) {
+            if (p->lo_level[b]) continue;
+            int ob = p->off_pvr[p->lo_kf[b]];
+            if (ob < 0 || ob < oa) continue;
+            if (ob == oa && b != a) continue;
+            const double* Bb = p->Hpl_ln + 54 * (size_t)b;
+            for (int r = 0; r < 9; ++r)
+                for (int c = 0; c < 9; ++c) {
+                    double s = 0;
+                    for (int t = 0; t < 6; ++t) s += BD[r * 6 + t] * Bb[c * 6 + t];
+                    Hs[(size_t)(oa + r) * P + ob + c] -= s;
+                }
+        }
+    }
+}
+#ifdef PLBA_ORACLE_FAST
+static void fast_schur(prob_t* p, double lambda, double* coeff) { fast_over_landmarks(p, lambda, schur_point, schur_line, p->Hs, coeff); }
+/* LL^T inside the envelope of the matrix (row i starts at its first non-zero column): the fill of a Cholesky factor stays inside it,
+ * so this is an exact sparse Cholesky for the banded reduced system — what g2o's LinearSolverEigen (simplicial LL^T) does. */
+static int chol_factor_env(double* A, int n, int* first) {
+    for (int i = 0; i < n; ++i) { int f = 0; while (f < i && A[(size_t)i * n + f] == 0.0) ++f; first[i] = f; }
+    for (int i = 0; i < n; ++i) {
+        double* ri = A + (size_t)i * n;
+        for (int j = first[i]; j < i; ++j) {
+            const double* rj = A + (size_t)j * n;
+            double s = ri[j];
+            const int k0 = first[i] > first[j] ? first[i] : first[j];
+            for (int k = k0; k < j; ++k) s -= ri[k] * rj[k];
+            ri[j] = s / rj[j];
+        }
+        double d = ri[i];
+        for (int k = first[i]; k < i; ++k) d -= ri[k] * ri[k];
+        if (!(d > 0.0)) return 0;
+        ri[i] = sqrt(d);
+    }
+    return 1;
+}
+static void chol_solve_env(const double* L, int n, const int* first, const double* b, double* x) {
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int k = first[i]; k < i; ++k) s -= L[(size_t)i * n + k] * x[k];
+        x[i] = s / L[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {      /* column sweep: x_k -= L(i, k) x_i for k in the envelope of row i */
+        x[i] /= L[(size_t)i * n + i];
+        const double xi = x[i];
+        for (int k = first[i]; k < i; ++k) x[k] -= L[(size_t)i * n + k] * xi;
+    }
+}
+#endif
+
 /* setLambda + BlockSolverX::solve with Schur complement (App. A.5) + restoreDiagonal.
  * do_solve = 0 stops after forming Hschur/bschur (diagnostics). */
 static int schur_solve(prob_t* p, double lambda, int do_solve, int* ok_out) {
@@ -1174,73 +1368,16 @@ static int schur_solve(prob_t* p, double lambda, int do_solve, int* ok_out) {
     memcpy(p->Hs, p->Hpp, PP * 8); /* Hschur = Hpp */
     if (p->world <= 1 || p->rank == 0) for (int i = 0; i < P; ++i) p->Hs[(size_t)i * P + i] += lambda;
     double* coeff = (double*)xcalloc(P, 8);
-    /* points */
-    int e = 0;
-    for (int l = 0; l < p->Np; ++l) {
-        int e0 = e;
-        while (e < p->Ep && p->po_pt[e] == l) ++e;
-        if (p->pt_xoff[l] < 0) continue;
-        double D[9], Dinv[9], db[3];
-        memcpy(D, p->Hll_pt + 9 * l, 72);
-        D[0] += lambda; D[4] += lambda; D[8] += lambda;
-        if (!lu_inverse(D, Dinv, 3)) memset(Dinv, 0, 72);
-        memcpy(p->Dinv_pt + 9 * l, Dinv, 72);
-        m3_v(Dinv, p->bl_pt + 3 * l, db);
-        for (int a = e0; a < e; ++a) {
-            if (p->po_level[a]) continue;
-            int oa = p->off_pvr[p->po_kf[a]];
-            if (oa < 0) continue;
-            const double* Ba = p->Hpl_pt + 27 * (size_t)a;
-            double BD[27];
-            mat_mul(Ba, Dinv, BD, 9, 3, 3);
-            for (int r = 0; r < 9; ++r) coeff[oa + r] += Ba[r * 3] * db[0] + Ba[r * 3 + 1] * db[1] + Ba[r * 3 + 2] * db[2];
-            for (int b = e0; b < e; ++b) {
-                if (p->po_level[b]) continue;
-                int ob = p->off_pvr[p->po_kf[b]];
-                if (ob < 0 || ob < oa) continue; /* upper block triangle: pairs (i1, i2 >= i1) */
-                if (ob == oa && b != a) continue;
-                const double* Bb = p->Hpl_pt + 27 * (size_t)b;
-                for (int r = 0; r < 9; ++r)
-                    for (int c = 0; c < 9; ++c)
-                        p->Hs[(size_t)(oa + r) * P + ob + c] -= BD[r * 3] * Bb[c * 3] + BD[r * 3 + 1] * Bb[c * 3 + 1] + BD[r * 3 + 2] * Bb[c * 3 + 2];
-            }
-        }
+#ifdef PLBA_ORACLE_FAST
+    fast_schur(p, lambda, coeff);
+#else
+    {
+        int e = 0;
+        for (int l = 0; l < p->Np; ++l) { int e0 = e; while (e < p->Ep && p->po_pt[e] == l) ++e; schur_point(p, l, e0, e, lambda, p->Hs, coeff); }
+        e = 0;
+        for (int l = 0; l < p->Nl; ++l) { int e0 = e; while (e < p->El && p->lo_ln[e] == l) ++e; schur_line(p, l, e0, e, lambda, p->Hs, coeff); }
     }
-    /* lines */
-    e = 0;
-    for (int l = 0; l < p->Nl; ++l) {
-        int e0 = e;
-        while (e < p->El && p->lo_ln[e] == l) ++e;
-        if (p->ln_xoff[l] < 0) continue;
-        double D[36], Dinv[36], db[6];
-        memcpy(D, p->Hll_ln + 36 * l, 288);
-        for (int i = 0; i < 6; ++i) D[i * 7] += lambda;
-        if (!lu_inverse(D, Dinv, 6)) memset(Dinv, 0, 288);
-        memcpy(p->Dinv_ln + 36 * l, Dinv, 288);
-        mat_mul(Dinv, p->bl_ln + 6 * l, db, 6, 6, 1);
-        for (int a = e0; a < e; ++a) {
-            if (p->lo_level[a]) continue;
-            int oa = p->off_pvr[p->lo_kf[a]];
-            if (oa < 0) continue;
-            const double* Ba = p->Hpl_ln + 54 * (size_t)a;
-            double BD[54];
-            mat_mul(Ba, Dinv, BD, 9, 6, 6);
-            for (int r = 0; r < 9; ++r) { double s = 0; for (int t = 0; t < 6; ++t) s += Ba[r * 6 + t] * db[t]; coeff[oa + r] += s; }
-            for (int b = e0; b < e; ++b) {
-                if (p->lo_level[b]) continue;
-                int ob = p->off_pvr[p->lo_kf[b]];
-                if (ob < 0 || ob < oa) continue;
-                if (ob == oa && b != a) continue;
-                const double* Bb = p->Hpl_ln + 54 * (size_t)b;
-                for (int r = 0; r < 9; ++r)
-                    for (int c = 0; c < 9; ++c) {
-                        double s = 0;
-                        for (int t = 0; t < 6; ++t) s += BD[r * 6 + t] * Bb[c * 6 + t];
-                        p->Hs[(size_t)(oa + r) * P + ob + c] -= s;
-                    }
-            }
-        }
-    }
+#endif
     for (int i = 0; i < P; ++i) p->bs[i] = p->bp[i] - coeff[i];
     free(coeff);
     /* multi-GPU analogue: all-reduce [Hschur | bschur | bp] */
@@ -1259,17 +1396,26 @@ static int schur_solve(prob_t* p, double lambda, int do_solve, int* ok_out) {
     if (!do_solve) { if (ok_out) *ok_out = 1; return PLBA_OK; }
     /* LinearSolverEigen: exact Cholesky of Hschur */
     double* L = (double*)xdup(p->Hs, PP * 8);
+#ifdef PLBA_ORACLE_FAST
+    int* first = (int*)xcalloc(P + 1, sizeof(int));
+    int ok = (P == 0) ? 1 : chol_factor_env(L, P, first);
+    memset(p->x, 0, ((size_t)P + p->Ldim) * 8);
+    if (ok) chol_solve_env(L, P, first, p->bs, p->x);
+    free(first);
+    if (ok) {
+#else
     int ok = (P == 0) ? 1 : chol_factor(L, P);
     memset(p->x, 0, ((size_t)P + p->Ldim) * 8);
     if (ok) {
         chol_solve(L, P, p->bs, p->x);
+#endif
         for (int i = 0; i < P; ++i) if (!isfinite(p->x[i])) ok = 0;
     }
     free(L);
     if (!ok) { memset(p->x, 0, ((size_t)P + p->Ldim) * 8); *ok_out = 0; return PLBA_OK; }
     /* landmarks: xl = Dinv * (bl - Hpl^T xp) */
     double* xl = p->x + P;
-    e = 0;
+    int e = 0;
     for (int l = 0; l < p->Np; ++l) {
         int e0 = e;
         while (e < p->Ep && p->po_pt[e] == l) ++e;
@@ -1340,6 +1486,8 @@ static double now_ms(void) {
 static int global_chi(prob_t* p, double* chi) { return (p->world > 1) ? exchange(p, chi, 1, 0) : PLBA_OK; }
 
 /* SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve (App. A.2, A.3) */
+static double g_t[6];
+#define TPH(i, stmt) do { double t__ = now_ms(); stmt; g_t[i] += now_ms() - t__; } while (0)
 int orc_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_flag, plba_stats* out) {
     if (!p) return PLBA_ERR_INVALID;
     if (!p->have_cam || !p->K) FAIL(p, PLBA_ERR_STATE, "camera and keyframes must be set before optimize");
@@ -1347,16 +1495,16 @@ int orc_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_f
     plba_stats st;
     memset(&st, 0, sizeof st);
     p->trace_n = 0;
-    build_index(p);
+    TPH(0, build_index(p));
     double lambda = 0.0, ni = 2.0;
     int rc, ok = 1;
     for (int it = 0; it < max_iters && !(abort_flag && *abort_flag) && ok; ++it) {
         double currentChi;
-        if ((rc = compute_active_errors(p, &currentChi))) return rc;
+        TPH(1, rc = compute_active_errors(p, &currentChi)); if (rc) return rc;
         if ((rc = global_chi(p, &currentChi))) return rc;
         double tempChi = currentChi;
         if (it == 0) st.chi2_initial = currentChi;
-        build_system(p);
+        TPH(2, build_system(p));
         if (it == 0) {
             if (p->opt.user_lambda_init > 0) lambda = p->opt.user_lambda_init;
             else { double md; if ((rc = max_diag(p, &md))) return rc; lambda = p->opt.tau * md; }
@@ -1367,10 +1515,10 @@ int orc_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_f
         do {
             state_push(p);
             int ok2 = 1;
-            if ((rc = schur_solve(p, lambda, 1, &ok2))) return rc;
+            TPH(3, rc = schur_solve(p, lambda, 1, &ok2)); if (rc) return rc;
             if (!ok2) st.solver_failures++;
-            state_update(p);
-            if ((rc = compute_active_errors(p, &tempChi))) return rc;
+            TPH(4, state_update(p));
+            TPH(1, rc = compute_active_errors(p, &tempChi)); if (rc) return rc;
             if ((rc = global_chi(p, &tempChi))) return rc;
             if (!ok2) tempChi = DBL_MAX;
             /* computeScale: sum x_j (lambda x_j + b_j) over poses and landmarks */
@@ -1413,6 +1561,7 @@ int orc_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_f
     }
     st.lambda_final = lambda;
     st.ms_total = now_ms() - t0;
+    if (getenv("PLBA_ORC_TIMING")) fprintf(stderr, "[oracle] index %.1f errors %.1f build %.1f schur+solve %.1f update %.1f ms (cumulative)\n", g_t[0], g_t[1], g_t[2], g_t[3], g_t[4]);
     if (out) *out = st;
     return PLBA_OK;
 }
