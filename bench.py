@@ -150,6 +150,31 @@ def config5_leg(pkg, stream, iters=30):
     return out
 
 
+def realistic_leg(pkg, stream, iters=100):
+    """the headline windows have tracks over <= 8 CONSECUTIVE keyframes (SURVEY 8d's generator).  This side leg is
+    the reference's own window shape instead — 12 keyframes (include/mapHandler.h:217), tracks over 6 .. 12 of them (most of the
+    window), one landmark in five seen again after a gap — through the default options; it reports which solver / landmark path the
+    structure detection picked and the rate."""
+    import torch
+    w = pkg.window.make_window(12, 2000, 400, imu=True, seed=0x5EED00C0, kf_dt=0.1, track=(6, 12), revisit=0.2)
+    prob = pkg.new_problem()
+    prob.set_stream(stream.cuda_stream)
+    prob.upload_window(w)
+    stage1_and_gate(prob, pkg)
+    run_iterations(prob, 10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done, trials, _ = run_iterations(prob, iters)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = dict(workload="12 KF / 2000 points / 400 lines + IMU, tracks over 6..12 keyframes, 20 % non-consecutive re-observations",
+               iterations_per_s=done / dt, ms_per_iteration=dt / done * 1e3, trials_per_iteration=trials / max(done, 1),
+               point_obs=int(w["meta"]["Ep"]), line_obs=int(w["meta"]["El"]), pose_dim=int(prob.debug_get("pose_dim")[0]), dense_dim=int(prob.debug_get("dense_dim")[0]),
+               twin_factorisation=bool(prob.debug_get("twin")[0]), banded_twisted_solve=bool(prob.debug_get("band")[0]), fused_landmark_passes=bool(prob.debug_get("lm_fused")[0]))
+    prob.close()
+    return out
+
+
 def cpu_baseline(w, pkg, budget_s=24.0):
     """The CPU restatement of the reference's g2o path timed on this box's host cores on a bounded sample of the same window
     (stage-2 LM iterations from the post-gating state), three ways:
@@ -394,6 +419,7 @@ def main():
         out["config"]["end_to_end_iterations_per_s"] = (r2["stage1"].iterations + r2["stage2"].iterations) / e2e
     if world == 1 and cfg_idx == 3 and not args.no_config5_leg:
         out["config"]["configs4_single_gpu"] = config5_leg(pkg, stream)
+        out["config"]["realistic_12kf_window"] = realistic_leg(pkg, stream)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and cfg_idx == 3:
             out["max_pose_delta_vs_cpu"], out["config4_sliding_window"] = parity_and_config4(w_full, pkg)

@@ -67,26 +67,48 @@ class RcclExchange:
     no Python runs inside the LM loop (Problem.set_shard_native)."""
 
     def __init__(self, dist, rank, world, lib_path=None):
+        """Bring-up in three steps, each followed by an all-ranks vote, so that a failure on ONE rank raises on ALL of them instead of
+        leaving the others inside a collective nobody else enters (ADVICE r02): (1) local: dlopen, rank 0 makes the ncclUniqueId;
+        (2) broadcast of the id; (3) ncclCommInitRank (itself a collective) and a vote on its result."""
         import os
         import torch
-        path = lib_path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libplba_rccl.so")
-        self.lib = C.CDLL(path)
-        self.lib.plba_rccl_last_error.restype = C.c_char_p
-        self.lib.plba_rccl_unique_id.argtypes = [C.c_char_p]
-        self.lib.plba_rccl_init.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_char_p]
-        self.lib.plba_rccl_destroy.argtypes = [C.c_void_p]
-        idb = C.create_string_buffer(128)
-        if rank == 0 and self.lib.plba_rccl_unique_id(idb) != 0:
-            raise RuntimeError("plba_rccl_unique_id: %s" % self.lib.plba_rccl_last_error().decode())
-        if world > 1:
-            on_gpu = dist.get_backend() == "nccl"
-            t = torch.tensor(list(idb.raw), dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+        self.comm = C.c_void_p()
+        self.lib = None
+        self.rank, self.world = rank, world
+        on_gpu = world > 1 and dist.get_backend() == "nccl"
+        dev = "cuda" if on_gpu else "cpu"
+
+        def vote(ok, what, err):
+            """MIN over the ranks of a success flag; every rank raises when any of them failed"""
+            if world > 1:
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                all_ok = int(t.item()) == 1
+            else:
+                all_ok = ok
+            if not all_ok:
+                self.close()
+                raise RuntimeError("%s failed on %s: %s" % (what, "this rank" if not ok else "another rank", err or "-"))
+
+        err, idb = None, C.create_string_buffer(128)
+        try:      # (1) local
+            path = lib_path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libplba_rccl.so")
+            self.lib = C.CDLL(path)
+            self.lib.plba_rccl_last_error.restype = C.c_char_p
+            self.lib.plba_rccl_unique_id.argtypes = [C.c_char_p]
+            self.lib.plba_rccl_init.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_char_p]
+            self.lib.plba_rccl_destroy.argtypes = [C.c_void_p]
+            if rank == 0 and self.lib.plba_rccl_unique_id(idb) != 0:
+                err = "plba_rccl_unique_id: %s" % self.lib.plba_rccl_last_error().decode()
+        except OSError as e:
+            err = "loading libplba_rccl.so: %s" % e
+        vote(err is None, "RCCL exchange bring-up (library / unique id)", err)
+        if world > 1:      # (2)
+            t = torch.tensor(list(idb.raw), dtype=torch.uint8, device=dev)
             dist.broadcast(t, src=0)
             idb = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
-        self.comm = C.c_void_p()
-        if self.lib.plba_rccl_init(C.byref(self.comm), rank, world, idb) != 0:
-            raise RuntimeError("plba_rccl_init: %s" % self.lib.plba_rccl_last_error().decode())
-        self.rank, self.world = rank, world
+        rc = self.lib.plba_rccl_init(C.byref(self.comm), rank, world, idb)      # (3)
+        vote(rc == 0, "plba_rccl_init", None if rc == 0 else self.lib.plba_rccl_last_error().decode())
 
     @property
     def fn_addr(self):
@@ -103,6 +125,6 @@ class RcclExchange:
             raise RuntimeError("plba_rccl_allreduce: %s" % self.lib.plba_rccl_last_error().decode())
 
     def close(self):
-        if self.comm:
+        if self.comm and self.lib is not None:
             self.lib.plba_rccl_destroy(self.comm)
-            self.comm = C.c_void_p()
+        self.comm = C.c_void_p()

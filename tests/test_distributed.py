@@ -257,3 +257,52 @@ def test_native_rccl_hook(pkg, hip):
             pr.kill()
     assert g[0] == "ok", g[-1]
     assert g[1] is True and g[2] >= 1
+
+
+def _bringup_vote_worker(rank, world, port, out):
+    """rank 1 cannot load the exchange library: BOTH ranks must raise, after the same number of collectives (no rank left waiting)"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        import torch.distributed as dist
+        import __graft_entry__ as ge
+        pkg = ge.load_package()
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        raised = None
+        try:
+            pkg.distributed.RcclExchange(dist, rank, world, lib_path="/nonexistent/libplba_rccl.so" if rank == 1 else os.path.join(ROOT, "tests", "conftest.py"))
+        except RuntimeError as e:      # (rank 0's "library" is not loadable either — a text file: OSError -> vote; what matters is that both raise)
+            raised = str(e)
+        dist.barrier()      # both ranks get here: nobody is stuck in a broadcast the other never entered
+        out.put((rank, raised))
+        dist.destroy_process_group()
+    except BaseException as e:
+        import traceback
+        out.put(("error", rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+        out.close(); out.join_thread()
+        os._exit(1)
+
+
+def test_rccl_bringup_failure_on_one_rank_raises_on_all(pkg):
+    """a bring-up failure on one rank used to leave the others in dist.broadcast.  Now every step is followed by an
+    all-ranks vote (distributed.RcclExchange.__init__); world size 2 over gloo, no GPU needed."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bringup_vote_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = []
+    try:
+        for _ in range(2):
+            g = q.get(timeout=120)
+            assert g[0] != "error", g[-1]
+            got.append(g)
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert all(r[1] is not None and "failed" in r[1] for r in got), got

@@ -239,3 +239,26 @@ def test_multi_chain_plans_against_the_oracle(pkg, orc, hip, K, seed, prior, fix
     assert sg.chi2_final == pytest.approx(so.chi2_final, rel=1e-8)
     assert max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)) < 1e-8
     g.close(); o.close()
+
+
+def test_realistic_12_keyframe_window_against_the_oracle(pkg, orc, hip):
+    """the reference's own window shape — 12 keyframes, tracks over most of the window (6 .. 12 keyframes), one
+    landmark in five seen again after a gap — through the DEFAULT options: whatever solver / landmark path the structure detection
+    picks (the band of the reduced system is as wide as the system here; no landmark group fits a window of 8 keyframes) must agree
+    with the oracle through the whole protocol and through a marginalization slide."""
+    w = pkg.window.make_window(12, 600, 120, imu=True, seed=0x5EED00C0, kf_dt=0.1, track=(6, 12), revisit=0.2)
+    ks = np.diff(np.flatnonzero(np.diff(np.concatenate([[-1], w["po_pt"], [-2]])))); assert ks.max() > 8      # more observations per landmark than a group's window
+    gaps = [np.diff(w["po_kf"][w["po_pt"] == l]).max() for l in range(0, 600, 7)]; assert max(gaps) > 1      # non-consecutive re-observations exist
+    g = pkg.new_problem(); g.upload_window(w)
+    o = orc.new_problem(); o.upload_window(w)
+    rg, ro = pkg.protocol.local_ba(g), pkg.protocol.local_ba(o)
+    assert g.debug_get("lm_fused")[0] == 0
+    assert rg["gated"] == ro["gated"]
+    assert [t["accepted"] for t in g.trace()] == [t["accepted"] for t in o.trace()]
+    assert rg["stage2"].chi2_final == pytest.approx(ro["stage2"].chi2_final, rel=1e-9)
+    assert max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)) < 1e-9
+    pg, po = g.marginalize(0, pkg.protocol.MARG_NUM), o.marginalize(0, pkg.protocol.MARG_NUM)
+    assert pg["n"] == po["n"] and pg["n"] > 100      # every keyframe of the window among the kept parameters
+    assert np.abs(pg["Ar"] - po["Ar"]).max() < 1e-7 * np.abs(po["Ar"]).max()
+    print("realistic window: dense dim %d of %d, twin %d band %d" % (g.debug_get("dense_dim")[0], g.debug_get("pose_dim")[0], g.debug_get("twin")[0], g.debug_get("band")[0]))
+    g.close(); o.close()
