@@ -830,6 +830,7 @@ public:
     const char* lastError() const { return _err.c_str(); }
     plba_problem* problem() { return _prob; }
     const plba_stats& lastStats() const { return _stats; }
+    int deviceSolves() const { return _device_solves; }      // reduced systems of host-evaluated graphs solved by the device (beyond 384 dims)
 
     // = g2o SparseOptimizer::optimize: returns the number of iterations, -1/0 on failure
     int optimize(int iterations) {
@@ -951,9 +952,12 @@ private:
         std::vector<double> A(H);
         for (int i = 0; i < N; ++i) A[(size_t)i * N + i] += lambda;
         x.assign(N, 0.0);
-        if (N > 384) {
-            if (!_prob) { plba_options o; plba_default_options(&o); if (plba_create(&o, &_prob) != PLBA_OK) _prob = nullptr; }
-            if (_prob) { int ok = 0; if (plba_debug_dense_solve(_prob, N, A.data(), b.data(), x.data(), &ok) == PLBA_OK) return ok != 0; }
+        if (N > 384) {      // the device solves it or nobody does: no silent host path for a system of this size
+            if (!_prob) { plba_options o; plba_default_options(&o); if (plba_create(&o, &_prob) != PLBA_OK) { _prob = nullptr; _err = plba_last_error(nullptr); std::cerr << "[plba g2o facade] " << _err << std::endl; return false; } }
+            int ok = 0;
+            if (plba_debug_dense_solve(_prob, N, A.data(), b.data(), x.data(), &ok) != PLBA_OK) { _err = plba_last_error(_prob); std::cerr << "[plba g2o facade] " << _err << std::endl; return false; }
+            ++_device_solves;
+            return ok != 0;
         }
         for (int j = 0; j < N; ++j) {
             double dj = A[(size_t)j * N + j];
@@ -1273,6 +1277,7 @@ private:
     int _level = 0;
     plba_problem* _prob = nullptr;
     plba_stats _stats;
+    int _device_solves = 0;
     std::string _err;
 };
 

@@ -2830,3 +2830,75 @@ int orc_lba_visual(void* problem, const void* opt_, int K, const double* T_kf_w1
     free(X); free(DX); free(g); free(H);
     return 0;
 }
+
+
+/* ---- MapHandler::tryVioInit, the closed-form steps (src/mapHandler.cpp:4853-4980): gravity, accelerometer bias, velocities -------------
+ * Independent of include/plba_g2o/vio_init.h: the two least-squares problems go through Householder QR here (eigen-decomposition of
+ * the normal equations there).  Layout as vio_init.h: N keyframes, interval m = keyframe m -> m + 1. */
+static void ls3_qr(double* A /* rows x 4: [A | b], overwritten */, int rows, double* x) {
+    for (int k = 0; k < 3; ++k) {
+        double nrm = 0.0;
+        for (int i = k; i < rows; ++i) nrm += A[4 * i + k] * A[4 * i + k];
+        nrm = sqrt(nrm);
+        if (nrm == 0.0) continue;
+        const double alpha = A[4 * k + k] > 0 ? -nrm : nrm;
+        double* v = (double*)xcalloc(rows, 8);
+        for (int i = k; i < rows; ++i) v[i] = A[4 * i + k];
+        v[k] -= alpha;
+        double vv = 0.0;
+        for (int i = k; i < rows; ++i) vv += v[i] * v[i];
+        if (vv > 0.0)
+            for (int c = k; c < 4; ++c) {
+                double d = 0.0;
+                for (int i = k; i < rows; ++i) d += v[i] * A[4 * i + c];
+                d = 2.0 * d / vv;
+                for (int i = k; i < rows; ++i) A[4 * i + c] -= d * v[i];
+            }
+        free(v);
+    }
+    for (int k = 2; k >= 0; --k) { double sacc = A[4 * k + 3]; for (int c = k + 1; c < 3; ++c) sacc -= A[4 * k + c] * x[c]; x[k] = sacc / A[4 * k + k]; }
+}
+void orc_vio_init(int N, const double* dt, const double* dP, const double* dV, const double* JPa, const double* JVa, const double* Rc, const double* pc,
+                  const double* Rb, const double* pb, const double* Rcb, const double* pcb, double* gpre, double* g0, double* ba, double* V) {
+    const int rows = 3 * (N - 2);
+    double* S = (double*)xcalloc((size_t)rows * 4 + 4, 8);
+    for (int pass = 0; pass < 2; ++pass) {
+        memset(S, 0, (size_t)rows * 32);
+        for (int i = 0; i < N - 2; ++i) {
+            const double dt12 = dt[i], dt23 = dt[i + 1];
+            const double *R1 = Rc + 9 * i, *R2 = Rc + 9 * (i + 1), *R3 = Rc + 9 * (i + 2), *p1 = pc + 3 * i, *p2 = pc + 3 * (i + 1), *p3 = pc + 3 * (i + 2);
+            double R1cb[9], R2cb[9], a[3], b[3], c[3], t1[3], t2[3], D12[9], D23[9];
+            m3_mul(R1, Rcb, R1cb); m3_mul(R2, Rcb, R2cb);
+            m3_v(R1cb, dP + 3 * i, a); m3_v(R2cb, dP + 3 * (i + 1), b); m3_v(R1cb, dV + 3 * i, c);
+            for (int t = 0; t < 9; ++t) { D12[t] = R1[t] - R2[t]; D23[t] = R2[t] - R3[t]; }
+            m3_v(D12, pcb, t1); m3_v(D23, pcb, t2);
+            if (pass == 0) {      /* C y = D: C = beta I, D = gamma - lambda (:4853-4893) */
+                const double beta = 0.5 * (dt12 * dt12 * dt23 + dt12 * dt23 * dt23);
+                for (int t = 0; t < 3; ++t) {
+                    const double lam = (p2[t] - p1[t]) * dt23 + (p2[t] - p3[t]) * dt12;
+                    const double gam = -t2[t] * dt12 + t1[t] * dt23 + a[t] * dt23 - b[t] * dt12 - c[t] * dt12 * dt23;      /* (Rc3 - Rc2) pcb = -D23 pcb */
+                    S[4 * (3 * i + t) + t] = beta; S[4 * (3 * i + t) + 3] = gam - lam;
+                }
+            } else {              /* A y = B (:4903-4940) */
+                double F1[9], F2[9], F3[9];
+                m3_mul(R1cb, JPa + 9 * i, F1); m3_mul(R2cb, JPa + 9 * (i + 1), F2); m3_mul(R1cb, JVa + 9 * i, F3);
+                for (int t = 0; t < 3; ++t) {
+                    S[4 * (3 * i + t) + 3] = p2[t] * dt23 - p3[t] * dt12 - p1[t] * dt23 + p2[t] * dt12 + 0.5 * g0[t] * (dt12 * dt12 * dt23 + dt23 * dt23 * dt12)
+                                           - a[t] * dt23 + b[t] * dt12 - t1[t] * dt23 + t2[t] * dt12 + c[t] * dt12 * dt23;
+                    for (int u = 0; u < 3; ++u) S[4 * (3 * i + t) + u] = F1[3 * t + u] * dt23 - F2[3 * t + u] * dt12 - F3[3 * t + u] * dt12 * dt23;
+                }
+            }
+        }
+        if (pass == 0) {
+            ls3_qr(S, rows, gpre);
+            const double n = v3_norm(gpre);
+            for (int t = 0; t < 3; ++t) g0[t] = gpre[t] / n * 9.810;
+        } else ls3_qr(S, rows, ba);
+    }
+    free(S);
+    for (int i = 0; i < N; ++i) {      /* :4955-4980 */
+        double r[3];
+        if (i != N - 1) { m3_v(Rb + 9 * i, dP + 3 * i, r); for (int t = 0; t < 3; ++t) V[3 * i + t] = (pb[3 * (i + 1) + t] - pb[3 * i + t] - 0.5 * g0[t] * dt[i] * dt[i] - r[t]) / dt[i]; }
+        else { m3_v(Rb + 9 * (i - 1), dV + 3 * (i - 1), r); for (int t = 0; t < 3; ++t) V[3 * i + t] = V[3 * (i - 1) + t] + g0[t] * dt[i - 1] + r[t]; }
+    }
+}

@@ -16,7 +16,7 @@ def build_harness():
     import __graft_entry__ as g
     g.build_hip()
     src = os.path.join(ROOT, "tools", "localba_harness.cpp")
-    deps = [src, os.path.join(ROOT, "include", "plba_g2o", "g2o_compat.h"), os.path.join(ROOT, "include", "plba.h")]
+    deps = [src, os.path.join(ROOT, "include", "plba_g2o", "g2o_compat.h"), os.path.join(ROOT, "include", "plba_g2o", "vio_init.h"), os.path.join(ROOT, "include", "plba.h")]
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wno-unknown-pragmas", "-I", os.path.join(ROOT, "include"),
                                "-I", os.path.join(ROOT, "pl-inertial-slam_amd", "csrc"), src, "-o", EXE,

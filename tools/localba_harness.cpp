@@ -15,6 +15,7 @@
 //   localba_harness lba     <in.bin> <out.bin>          MapHandler::localBundleAdjustment + levMarquardtOptimizationLBA (:1329-2098): the
 //                                                       pre-init visual-only path, which does not use g2o at all: its list building on
 //                                                       map-shaped objects, then the optimiser's body as one plba_lba_visual call
+#include "plba_g2o/vio_init.h"
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -200,7 +201,7 @@ static int imu_init_est_bg(const char* in, const char* out) {
 // ---- g2o part of MapHandler::loopClosureOptimizationCovGraphG2O (src/mapHandler.cpp:4299-4528) -------------------------------------
 // vertices: id, fixed flag, se3 6-vector x with estimate SE3Quat::exp(x); kf2kf edges with setInformation, loop-closure edges
 // with `information() = ...`; computeInitialGuess / computeActiveErrors / optimize(maxItersPGO); poses back as SE3Quat::log().
-static int pose_graph(const char* in, const char* out) {
+static int pose_graph(const char* in, const char* out, bool ess_graph = false) {
     FILE* f = fopen(in, "rb");
     if (!f) { perror("in"); return 2; }
     auto hdr = rd<int32_t>(f, 5);
@@ -235,7 +236,7 @@ static int pose_graph(const char* in, const char* out) {
         optimizer.addEdge(e_se3);
     }
     optimizer.initializeOptimization();
-    if (init_guess) optimizer.computeInitialGuess();
+    if (init_guess || ess_graph) optimizer.computeInitialGuess();      // loopClosureOptimizationEssGraphG2O calls it unconditionally (:4163)
     optimizer.computeActiveErrors();
     const double chi0 = optimizer.activeChi2();
     const int done = optimizer.optimize(iters);
@@ -247,6 +248,7 @@ static int pose_graph(const char* in, const char* out) {
         for (int c = 0; c < 6; ++c) res.push_back(x[c]);
     }
     res.push_back(chi0); res.push_back(optimizer.lastStats().chi2_final); res.push_back((double)done); res.push_back((double)optimizer.lastStats().trials);
+    res.push_back((double)optimizer.deviceSolves());
     FILE* o = fopen(out, "wb");
     if (!o) { perror("out"); return 2; }
     wr(o, res);
@@ -257,9 +259,42 @@ static int pose_graph(const char* in, const char* out) {
 
 static int local_ba_with_imu(const char* in, const char* out);
 
+// ---- MapHandler::tryVioInit, the steps between its g2o graphs (src/mapHandler.cpp:4853-4980) ---------------------------------------
+// in: N | dt (N-1) | dP, dV (3 (N-1)) | JPa, JVa (9 (N-1)) | Rc (9 N), pc (3 N) | Rb (9 N), pb (3 N) | Rcb 9, pcb 3
+static int vio_init(const char* in, const char* out) {
+    FILE* f = fopen(in, "rb");
+    if (!f) { perror("in"); return 2; }
+    const int N = rd<int32_t>(f, 1)[0];
+    auto dt = rd<double>(f, N - 1); auto dP = rd<double>(f, 3 * (size_t)(N - 1)); auto dV = rd<double>(f, 3 * (size_t)(N - 1));
+    auto JPa = rd<double>(f, 9 * (size_t)(N - 1)); auto JVa = rd<double>(f, 9 * (size_t)(N - 1));
+    auto Rc = rd<double>(f, 9 * (size_t)N); auto pc = rd<double>(f, 3 * (size_t)N); auto Rb = rd<double>(f, 9 * (size_t)N); auto pb = rd<double>(f, 3 * (size_t)N);
+    auto Rcb = rd<double>(f, 9); auto pcb = rd<double>(f, 3);
+    fclose(f);
+    if (N < 10) { fprintf(stderr, "tryVioInit needs 10 keyframes (:4834)\n"); return 2; }
+    double gpre[3], g0[3], ba[3];
+    std::vector<double> V(3 * (size_t)N);
+    plba_vio::gravity(N, dt.data(), dP.data(), dV.data(), Rc.data(), pc.data(), Rcb.data(), pcb.data(), gpre, g0);
+    plba_vio::acc_bias(N, dt.data(), dP.data(), dV.data(), JPa.data(), JVa.data(), Rc.data(), pc.data(), Rcb.data(), pcb.data(), g0, ba);
+    plba_vio::velocities(N, dt.data(), dP.data(), dV.data(), Rb.data(), pb.data(), g0, V.data());
+    std::vector<double> res(gpre, gpre + 3);
+    res.insert(res.end(), g0, g0 + 3); res.insert(res.end(), ba, ba + 3); res.insert(res.end(), V.begin(), V.end());
+    FILE* o = fopen(out, "wb");
+    if (!o) { perror("out"); return 2; }
+    wr(o, res);
+    fclose(o);
+    printf("vio_init: g0 = (%.4f, %.4f, %.4f), ba = (%.4e, %.4e, %.4e)\n", g0[0], g0[1], g0[2], ba[0], ba[1], ba[2]);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 4 && !strcmp(argv[1], "gyrbias")) return imu_init_est_bg(argv[2], argv[3]);
     if (argc >= 4 && !strcmp(argv[1], "pgo")) return pose_graph(argv[2], argv[3]);
+    // MapHandler::loopClosureOptimizationEssGraphG2O (src/mapHandler.cpp:4068-4297): the same g2o calls as the covisibility-graph
+    // version over the essential graph — every keyframe from the first loop keyframe on (several of them fixed: the loop ends), spanning
+    // tree + strong covisibility + loop edges, computeInitialGuess before optimize.  Its size is what sends the reduced system to the
+    // device (more than 384 dims).
+    if (argc >= 4 && !strcmp(argv[1], "essgraph")) return pose_graph(argv[2], argv[3], true);
+    if (argc >= 4 && !strcmp(argv[1], "vioinit")) return vio_init(argv[2], argv[3]);
     if (argc >= 4 && !strcmp(argv[1], "nomarg")) return local_ba_with_imu(argv[2], argv[3]);
     if (argc >= 4 && !strcmp(argv[1], "lba")) return visual_lba(argv[2], argv[3]);
     if (argc < 3) { fprintf(stderr, "usage: %s [nomarg|gyrbias|pgo] window.bin result.bin\n", argv[0]); return 2; }
