@@ -49,12 +49,13 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r02_pmc_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 correction applied, tools/rocpd_extract.py).
+def pmc_traffic(kernel_prefix, config5=False):
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r03_pmc_traffic.json for configs[2],
+    r03_config5_pmc_traffic.json for configs[4]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950
+    correction applied, tools/rocpd_extract.py, tools/collect_profiles_r03.sh).
     PMC counters cannot be collected from inside this process, so the file is tied to the build it came from by a hash of
     csrc/: None when the file is absent or was measured on different kernel sources (never a stale number)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_config5_pmc_traffic.json" if config5 else "r03_pmc_traffic.json")
     try:
         js = json.load(open(path))
         ks = js["kernels"]
@@ -353,10 +354,14 @@ def main():
     lin_ms = phases2[0] / max(n_lin, 1)
     phase_names = ["linearize_launch", "factorisation_launches", "schur", "dense_solve", "backsub_update", "trial_errors", "exchange", "landmark_blocks_and_reductions"]
     per_iter = {k: float(v / max(done2, 1)) for k, v in zip(phase_names, phases2)}
-    roof_hbm = dict(bound="hbm", kernel="k_linearize<true> (observation pass; IMU / prior edge blocks ride in the same launch)",
+    fused = bool(prob.debug_get("lm_fused")[0])      # the fused landmark-major passes (plba_lm_dev.h) run instead of the record-based ones
+    hbm_kernel = "k_lm_schur<0>" if fused else "k_linearize<true>"
+    roof_hbm = dict(bound="hbm", kernel=("k_lm_schur<0> (fused landmark-major pass: residuals, Jacobians, Hll, damped inverse and the rank-k update of the pose blocks "
+                                         "from the observation arrays; chain segments ride in the same launch)") if fused
+                    else "k_linearize<true> (observation pass; IMU / prior edge blocks ride in the same launch)",
                     achieved=bytes_lin / (lin_ms * 1e-3) / 1e9 if lin_ms > 0 else None,
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=(bytes_lin / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lin_ms > 0 else None,
-                    traffic=pmc_traffic("k_linearize<true>"), algorithmic_bytes_per_launch=bytes_lin, avg_launch_ms=lin_ms, launches_timed=n_lin)
+                    traffic=pmc_traffic(hbm_kernel, config5=(cfg_idx == 5)), algorithmic_bytes_per_launch=bytes_lin, avg_launch_ms=lin_ms, launches_timed=n_lin)
     kname = "k_chol32" if fb == 32 else "k_chol_step"
     banded = bool(prob.debug_get("band")[0])
     twin = bool(prob.debug_get("twin")[0])
@@ -380,7 +385,7 @@ def main():
     ach = flops_fact / n_fact_launches / (fact_ms * 1e-3) / 1e12 if fact_ms > 0 else None
     roof_mfma = dict(bound="mfma", kernel=("k_band_fwd + k_band_back: banded twisted fp64 LL^T of the reduced camera system from both ends in LDS (%d of the P=%d pose dims stay dense after the velocity/bias chain elimination, band of 3 tiles, %d launches per solve)" % (Pdense, P, n_fact_launches)) if banded else ("k_chol32_list / k_chol32: one block step of the two-ended fp64 LL^T of the banded reduced camera system (%d of the P=%d pose dims stay dense after the velocity/bias chain elimination; both ends of the band per launch, %d dependent launches per solve; flops = the banded factorisation's)" % (Pdense, P, n_fact_launches)) if twin else "%s: one block step of the dense fp64 LL^T of the reduced camera system (%d of the P=%d pose dims stay dense after the velocity/bias chain elimination, %d launches per solve)" % (kname, Pdense, P, n_fact_launches),
                      achieved=ach, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=(ach / FP64_MFMA_PEAK_TFLOPS) if ach else None,
-                     traffic=pmc_traffic(kname), algorithmic_flops_per_launch=flops_fact / n_fact_launches, avg_launch_ms=fact_ms)
+                     traffic=pmc_traffic(kname, config5=(cfg_idx == 5)), algorithmic_flops_per_launch=flops_fact / n_fact_launches, avg_launch_ms=fact_ms)
     # the factorisation launches are the largest single consumer of an iteration (profiles/r01_*_kernel_stats.csv)
     roofline = roof_mfma
 
@@ -392,7 +397,7 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": name, "K": cfg["K"], "points": cfg["Np"], "lines": cfg["Nl"], "point_obs": int(Ep), "line_obs": int(El),
                    "pose_dim": P, "trials_per_iteration": trials / max(done, 1), "protocol": "stage-2 LM iterations (no Huber on point/line edges) replayed from the post-gating state",
-                   "global_iterations_per_s": done / dt, "dense_dim": Pdense, "exchange": xch_kind, "banded_twisted_solve": banded, "twin_factorisation": twin,
+                   "global_iterations_per_s": done / dt, "dense_dim": Pdense, "exchange": xch_kind, "banded_twisted_solve": banded, "twin_factorisation": twin, "fused_landmark_passes": fused,
                    "value_definition": "global LM iterations/s of ONE window (total work fixed as N grows: its landmarks are sharded over the N ranks)",
                    "algorithmic_bytes_per_iteration": b_iter,
                    "hbm_frac_whole_iteration": b_iter / (dt / done) / 1e9 / (HBM_PEAK_GBS * world)},

@@ -1438,9 +1438,10 @@ static int lm_enqueue_first(plba_problem* p, int iteration) {
     MARK(p, 3);
     return PLBA_OK;
 }
-static int lm_enqueue_system(plba_problem* p, const DevBuf& ds, int state, bool spec) {
+static int lm_enqueue_system(plba_problem* p, const DevBuf& ds, int state, bool spec, bool mark = false) {
     hipStream_t s = p->stream;
     launch_lm_schur(ds, p->lv, state, p->rob, false, &p->cv, spec, s);
+    if (mark) MARK(p, 5);      // profile = 2: [4, 5] = k_lm_schur alone (the pass over every observation), [5, 6] = gather + assembly
     launch_lm_gather(ds, p->lv, false, true, spec, s);
     return PLBA_OK;
 }
@@ -1498,9 +1499,9 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             p->ev_sample = (p->opt.profile == 1) && (p->trial_counter++ % PROFILE_SAMPLE == 0);
             MARK(p, 4);
             const bool had_spec = p->lm_spec;      // the accepted trial's system is already in the stream
-            if (!p->lm_spec && (rc = lm_enqueue_system(p, d, p->cur, false))) return rc;
+            if (!p->lm_spec && (rc = lm_enqueue_system(p, d, p->cur, false, true))) return rc;
             p->lm_spec = false;
-            MARK(p, 5); MARK(p, 6);
+            MARK(p, 6);
             if ((rc = lm_enqueue_solve_and_trial(p))) return rc;
             const int trial = p->cur ^ 1;
             const unsigned long long seq = ++p->mail_seq;
@@ -1530,7 +1531,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             if (p->opt.profile >= 2) {
                 // [0]: the linearising Schur pass + assembly (launch C) and the gather (launch D) when this trial issued them; [7]: first-iteration passes
                 if (qmax == 0 && it == 0) st.ms_phase[7] += span(0, 3);
-                if (!had_spec) { st.ms_phase[0] += span(4, 5); ++p->prof_lin_launches; }
+                if (!had_spec) { st.ms_phase[0] += span(4, 5); ++p->prof_lin_launches; st.ms_phase[2] += span(5, 6); }
                 st.ms_phase[3] += span(6, 7); st.ms_phase[4] += span(7, 8); st.ms_phase[5] += span(8, 9); st.ms_phase[7] += span(9, 10);
             }
             const Ctrl& c = *p->h_ctrl;

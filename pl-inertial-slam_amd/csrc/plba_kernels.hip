@@ -116,15 +116,20 @@ DEV void decide_body(const DevBuf& d, const LmParams& lp, double* red, int fused
 DEV void publish(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }     // sc1: visible to a same-launch reader on another XCD
 
 // Every workgroup of the trial-error launch ends here: its results have gone out with sc1 stores; once they are drained it
-// counts itself, and the last one to arrive reads everybody's (sc1 loads) and decides.  The arrival counter is the release ->
-// flag -> acquire pair the CDNA guide prescribes for a cross-workgroup hand-off (acq_rel at agent scope: every arriver releases its
-// partial sums, the last one acquires all of them); the sc1 accesses and the vmcnt drain stay as belt and braces.
+// counts itself, and the last one to arrive reads everybody's (sc1 loads) and decides.
+// Ordering: the hand-off is TARGETED, not a fence.  The few words that cross workgroups are written with agent-scope atomic
+// stores (write-through past the XCD's L2), `s_waitcnt vmcnt(0)` waits for their acknowledgement, the barrier orders thread 0's
+// counter increment (an agent-scope RMW, performed at the same coherence point) after them, and the last arriver reads the
+// words back with agent-scope atomic loads.  An acq_rel counter instead (the generic release -> flag -> acquire pattern) was
+// measured in round 3: a release at agent scope is `buffer_wbl2 sc1` — it writes back EVERY dirty line of the XCD's L2, i.e.
+// the records / blocks this very launch is producing — once per workgroup: k_linearize<true> 18.3 -> 26.2 us, k_schur_pairs
+// 29.7 -> 49.7 us (profiles/r03_acqrel_kernel_stats.csv), 5.6 k -> 4.1 k iterations/s.  Relaxed + targeted it stays.
 DEV void trial_arrive(const DevBuf& d, const DecideArgs& da, int nblk_edges, double* s4) {
     __shared__ int s_lastblk;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int prev = __hip_atomic_fetch_add(d.trial_cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const int prev = __hip_atomic_fetch_add(d.trial_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_lastblk = (prev == (int)gridDim.x - 1) ? 1 : 0;
         if (s_lastblk) __hip_atomic_store(d.trial_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
     }
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(256) void k_kfdiag(DevBuf d, int state) {
         if (t < 6) __hip_atomic_store(&d.schur_part[(size_t)m.slot * 48 + t], s_v[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t == 0) s_lastc = (__hip_atomic_fetch_add(&d.pair_cnt[m.ch0], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == m.nch - 1) ? 1 : 0;
+        if (t == 0) s_lastc = (__hip_atomic_fetch_add(&d.pair_cnt[m.ch0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == m.nch - 1) ? 1 : 0;
         __syncthreads();
         if (!s_lastc) return;
         if (t == 0) __hip_atomic_store(&d.pair_cnt[m.ch0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (t < nred) __hip_atomic_store(&part[t], s_in[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t == 0) s_last = (__hip_atomic_fetch_add(&d.pair_cnt[p], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nch - 1) ? 1 : 0;      // release -> flag -> acquire
+        if (t == 0) s_last = (__hip_atomic_fetch_add(&d.pair_cnt[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nch - 1) ? 1 : 0;      // targeted hand-off, see trial_arrive
         __syncthreads();
         SSTAMP(3);
 #ifdef PLBA_STAMPS_LM

@@ -20,7 +20,7 @@ def stats(db, out):
             w.writerow([r[0], r[1], r[2], "%.1f" % r[3], "%.2f" % (100.0 * r[2] / tot), r[4], r[5]])
 
 
-def pmc(db_fetch, db_write, out):
+def pmc(db_fetch, db_write, out, bench_json=None, command=None):
     res = {}
     for db, name in ((db_fetch, "FETCH_SIZE"), (db_write, "WRITE_SIZE")):
         c = sqlite3.connect(db).cursor()
@@ -36,8 +36,20 @@ def pmc(db_fetch, db_write, out):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for f in sorted(glob.glob(os.path.join(root, "pl-inertial-slam_amd", "csrc", "*.h*"))):
         h.update(open(f, "rb").read())
+    # algorithmic bytes per launch (32 B per point observation, 40 B per line observation, 24 / 48 B per landmark) of the
+    # kernels that pass over every observation once, from the workload the bench line names
+    if bench_json:
+        try:
+            cfg = json.loads([l for l in open(bench_json).read().splitlines() if l.startswith("{")][-1])["config"]
+            alg = 32 * cfg["point_obs"] + 40 * cfg["line_obs"] + 24 * cfg["points"] + 48 * cfg["lines"]
+            for k, v in res.items():
+                if any(t in k for t in ("k_lm_schur<0>", "k_lm_trial", "k_linearize<true>", "k_linearize<false>")) and "traffic_bytes_per_launch" in v:
+                    v["algorithmic_bytes_per_launch"] = alg
+                    v["traffic_over_algorithmic"] = v["traffic_bytes_per_launch"] / alg
+        except (OSError, ValueError, KeyError, IndexError):
+            pass
     json.dump({"note": "per-launch averages; traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction of MI355X_MICROARCH.md; "
-                       "command: rocprofv3 --pmc <counter> -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-config5-leg (one pass per counter)",
+                       "command: " + (command or "rocprofv3 --pmc <counter> -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-config5-leg") + " (one pass per counter)",
                "csrc_sha16": h.hexdigest()[:16],      # bench.py quotes these numbers only for the kernel sources they were measured on
                "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
 
@@ -46,4 +58,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None, sys.argv[6] if len(sys.argv) > 6 else None)
