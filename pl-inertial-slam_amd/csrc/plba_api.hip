@@ -429,13 +429,20 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     H.meas_pt.resize(2 * (size_t)Ep); H.meas_ln.resize(3 * (size_t)(E - Ep));
     int nlm = 0, nob = 0;
     H.lm_ob0[0] = 0;
-    // group size: a workgroup step takes 32 points or 16 lines; as few steps per group as keep the launch within ONE round of workgroups
-    // (two fit a CU: 63 KB of LDS each) — a second round of a handful of stragglers doubled the launch at configs[2] (563 groups) —
-    // and at most 8 (larger groups: fewer parts for the gather pass, but the window of 8 keyframes closes them anyway)
+    // group size: a workgroup step takes 32 points or 16 lines.  Two workgroups share a CU (registers), so `slots` of them run at once and
+    // the launch takes R rounds of groups: the smallest R whose groups stay within 16 steps, the groups sized to fill the R rounds
+    // (configs[4]: 8750 workgroup-steps; 8 steps gave 1095 groups = 2.14 rounds, i.e. three — 9 steps give 973, two rounds, 25 % less)
     int steps = 1;
     {
+        static int slots = 0;
+        if (!slots) { int dev = 0, cus = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256; slots = 2 * std::max(cus, 1); }
         const long wg_steps = (Np + 31) / 32 + (Nl + 15) / 16;
-        steps = (int)std::min<long>(8, std::max<long>(1, (wg_steps + 439) / 440));
+        for (int R = 1; R <= 64; ++R) {
+            const long cap = (long)(0.94 * R * slots);
+            steps = (int)std::max<long>(1, (wg_steps + cap - 1) / cap);
+            if (steps <= 16) break;
+        }
+        steps = std::min(steps, 16);
         if (const char* e = getenv("PLBA_LM_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= 16) steps = v; }
     }
     const int gpt = 32 * steps, gln = 16 * steps;
@@ -493,11 +500,12 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
                     else for (int c = 0; c < 3; ++c) H.meas_ln[3 * (size_t)(nob - Ep) + c] = p->lo_l[3 * (size_t)(e - Ep) + c];
                     ++nob;
                 }
-                {   // the 8 lanes of the landmark's unit(s): lane sub < k writes its observation's slot, the others the unused slots in order
+                {   // the 8 lanes of the landmark's unit(s) ARE the window slots: lane w takes the observation made from keyframe win[w] (its
+                    // offset in the landmark's range), or none (0xFF) — so a lane's camera block, operand rows and accumulators never move
                     uint8_t* w8 = &H.lm_ws8[(size_t)nlm * LMF_W];
-                    int q = 0;
-                    for (int a2 = 0; a2 < nk; ++a2) w8[q++] = (uint8_t)ws[a2];
-                    for (int sl = 0; sl < LMF_W; ++sl) if (!((used >> sl) & 1)) w8[q++] = (uint8_t)sl;
+                    for (int sl = 0; sl < LMF_W; ++sl) w8[sl] = 0xFF;
+                    for (int a2 = 0; a2 < nk; ++a2) w8[ws[a2]] = (uint8_t)a2;
+                    (void)used;
                 }
                 ++nlm;
                 H.lm_ob0[nlm] = nob;
@@ -1018,6 +1026,8 @@ static int prepare(plba_problem* p) {
         HIPCK(p, p->d_alist2.upload(al2)); HIPCK(p, p->d_col_gather.upload(colg));
         HIPCK(p, p->d_lmg_part.alloc(LH.grp.size() * (size_t)LMF_PART)); HIPCK(p, p->d_ob_err.alloc(2 * (size_t)E));
         LmView& lv = p->lv;
+        p->lm_hist.assign(20, 0.0);      // diagnostics: groups by number of workgroup steps (points 1..8 | lines 1..8), window widths
+        for (const LmGroup& g : LH.grp) { const int st = ((g.is_line ? 2 * g.nlm : g.nlm) + 31) / 32; p->lm_hist[(g.is_line ? 8 : 0) + std::min(std::max(st, 1), 8) - 1] += 1.0; p->lm_hist[16] += g.nw; p->lm_hist[17] += st; }
         lv.ngrp = (int)LH.grp.size(); lv.grp = p->d_lm_grp.p; lv.lm_slot = p->d_lmg_slot.p; lv.lm_ob0 = p->d_lmg_ob0.p; lv.ob_orig = p->d_lmg_orig.p; lv.lm_ws8 = p->d_lmg_ws8.p; lv.lm_fixed_g = p->d_lmg_fixed.p; lv.ob_level_g = p->d_lmg_level.p;
         lv.meas_pt = p->d_lmg_meas_pt.p; lv.meas_ln = p->d_lmg_meas_ln.p; lv.ob_wt = p->d_lmg_wt.p; lv.part = p->d_lmg_part.p;
         lv.nblk = (int)LH.blk_ij.size(); lv.blk_ij = p->d_lmg_blk_ij.p; lv.blk_start = p->d_lmg_blk_start.p; lv.blk_src = p->d_lmg_blk_src.p;
@@ -1985,6 +1995,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     else if (w == "pose_dim") v = {(double)p->P};
     else if (w == "marg_path") v.assign(p->marg_path, p->marg_path + 5);
     else if (w == "prof_lin_launches") v = {(double)p->prof_lin_launches};
+    else if (w == "lm_groups") v = p->lm_hist;
     else if (w == "lm_fused") v = {(double)(p->lm_ok ? 1 : 0), (double)p->lv.ngrp, (double)p->lv.nblk};
     else if (w == "marg_J") v = p->marg_dbg;
     else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};

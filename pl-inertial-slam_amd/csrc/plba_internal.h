@@ -157,7 +157,7 @@ struct LmView {
     const int32_t* lm_slot;       // group order -> landmark slot
     const int32_t* lm_ob0;        // group order (+ 1): first observation of each landmark in the group-ordered observation arrays
     const int32_t* ob_orig;       // group order -> unified observation index (ob_level, ob_chi2)
-    const uint8_t* lm_ws8;        // group order, LMF_W per landmark: the window slots its 8 lanes write — the observations' first, then the unused ones
+    const uint8_t* lm_ws8;        // group order, LMF_W per landmark: per window slot, the offset (in the landmark's observation range) of the observation made from that keyframe, 0xFF = none
     const uint8_t* lm_fixed_g;    // group order copy of lm_fixed
     uint8_t* ob_level_g;          // group order copy of ob_level (refreshed whenever the levels change: launch_lm_level_sync)
     const double* meas_pt;        // 2 per point observation (group order: points first, [0, Ep))

@@ -1494,10 +1494,10 @@ namespace plba {
 // ---- fused landmark-major passes: kernels (bodies in plba_lm_dev.h) ------------------------------------------------------------------
 // launch C of an iteration: [chain segments, reading the pose-side accumulators directly (they carry no landmark term) | groups]
 template <int MODE>
-__global__ __launch_bounds__(256) void k_lm_schur(DevBuf d, LmView lv, int state, Robust rb, ChainView cv, int nlead, int spec) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lm_schur(DevBuf d, LmView lv, int state, Robust rb, ChainView cv, int nlead, int spec) {
     if (spec && !d.ctrl->accepted) return;      // enqueued behind the deciding launch: runs only for the state that was accepted
     __shared__ LmLds S;
-    extern __shared__ __attribute__((aligned(16))) double s_dyn_lm[];      // LmAcc (60 KB) | a chain segment's staging (48 KB)
+    extern __shared__ __attribute__((aligned(16))) double s_dyn_lm[];      // LmAcc (36 KB) | a chain segment's staging (48 KB)
     int b = blockIdx.x;
     if (MODE == 0 && b < nlead) { chain_elim_segment<true>(d, cv, b, *reinterpret_cast<ChainElimLds*>(s_dyn_lm)); return; }
     b -= nlead;
@@ -1540,9 +1540,8 @@ __global__ __launch_bounds__(256) void k_pose_trial(DevBuf d, int state, Robust 
 // -------------------------------------------------------------------------------------------------
 // launchers
 // -------------------------------------------------------------------------------------------------
-static_assert(sizeof(ChainElimLds) <= sizeof(LmAcc), "a chain segment's staging shares the dynamic LDS of k_lm_schur");
 void launch_lm_schur(const DevBuf& d, const LmView& lv, int state, const Robust& rb, bool diag_pass, const ChainView* lead, bool spec, hipStream_t s) {
-    const size_t sh = sizeof(LmAcc);
+    const size_t sh = sizeof(LmAcc) > sizeof(ChainElimLds) ? sizeof(LmAcc) : sizeof(ChainElimLds);      // a chain segment's staging shares the dynamic LDS
     if (diag_pass) {
         if (ensure_dyn_lds(reinterpret_cast<const void*>(k_lm_schur<1>), (int)sh) != hipSuccess) return;      // surfaces at the caller's hipGetLastError
         hipLaunchKernelGGL(k_lm_schur<1>, dim3(lv.ngrp), dim3(256), sh, s, d, lv, state, rb, ChainView{}, 0, 0);

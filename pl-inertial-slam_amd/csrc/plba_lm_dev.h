@@ -39,8 +39,7 @@ struct LmLds {
     int koff[LMF_W];
 };
 struct LmAcc {                           // k_lm_schur only
-    double op[LMF_SCOLS * LMF_ROWS];     // operand of the rank-k update, [k-column][row] (36 KB); after the last step: the group's 11 output tiles
-    double vh[LMF_HCOLS * LMF_ROWS];     // first the right-hand-side vectors [unit][slot][bp 6 | bs 6], then the operand of sum Jp^T w Jp (24 KB)
+    double op[4 * 24 * LMF_ROWS];        // per wave: the step's operand of A' A'^T, [k-column][row] (4 x 9 KB); after the last step: the waves' tiles and vectors
 };
 
 DEV double quad_or_sum(double v) { return quad_sum(v); }
@@ -155,30 +154,34 @@ DEV void lm_lowerT_mul(const double* Li, const double* v, double* o) {     // o 
     o[2] = Li[5] * v[2];
 }
 struct LmStep {      // one lane's share of a step's inputs (prefetched a step ahead)
-    int slot, k, e, ws, orig;      // ws: the window slot this lane writes in the operands — its observation's, or (a lane without one) one of the slots
-                                   // none of the unit's observations uses: the 8 lanes of a unit cover the 8 slots, so the operand never needs clearing
+    int slot, k, e, ws, orig;      // ws: the window slot of this lane (= lane & 7: the 8 lanes of a unit ARE the 8 slots, with or without an observation,
+                                   // so the operand never needs clearing)
     bool uvalid, has, lvl0, fixed;
     double meas[3], wt, L[6];
 };
+// the loads of a step come in two dependent levels: the unit's indices (LmIdx), then its landmark and its lane's observation
+struct LmIdx { int slot, e; bool uvalid, has, fixed; };
 template <bool IS_LINE>
-DEV void lm_load(const DevBuf& d, const LmView& lv, const LmGroup& g, int state, int step, int wv, int lane, LmStep& s) {
+DEV void lm_load_idx(const LmView& lv, const LmGroup& g, int step, int wv, int lane, LmIdx& x) {
     const int unit = step * LMF_UNITS + wv * 8 + (lane >> 3), sub = lane & 7;
     const int n = IS_LINE ? (unit >> 1) : unit;
-    s.uvalid = n < g.nlm;
-    s.slot = 0; s.k = 0; s.e = 0; s.ws = sub; s.orig = 0; s.has = false; s.lvl0 = false; s.fixed = true; s.wt = 0.0;      // (a unit past the group's end: its 8 lanes zero the 8 slots)
+    x.uvalid = n < g.nlm; x.slot = 0; x.e = 0; x.has = false; x.fixed = true;
+    if (!x.uvalid) return;
+    const int gi = g.lm0 + n;
+    x.slot = lv.lm_slot[gi];
+    const int off = lv.lm_ws8[(size_t)gi * LMF_W + sub];      // lane = window slot
+    x.has = off != 0xFF;
+    x.e = lv.lm_ob0[gi] + (x.has ? off : 0);
+    x.fixed = lv.lm_fixed_g[gi] != 0;
+}
+template <bool IS_LINE>
+DEV void lm_load_data(const DevBuf& d, const LmView& lv, int state, int lane, const LmIdx& x, LmStep& s) {
+    s.uvalid = x.uvalid; s.slot = x.slot; s.k = 0; s.e = x.e; s.ws = lane & 7; s.orig = 0; s.has = x.has; s.lvl0 = false; s.fixed = x.fixed; s.wt = 0.0;
 #pragma unroll
     for (int t = 0; t < 3; ++t) s.meas[t] = 0.0;
 #pragma unroll
     for (int t = 0; t < 6; ++t) s.L[t] = 0.0;
-    if (!s.uvalid) return;
-    const int gi = g.lm0 + n;
-    s.slot = lv.lm_slot[gi];
-    const int e0 = lv.lm_ob0[gi];
-    s.k = lv.lm_ob0[gi + 1] - e0;
-    s.has = sub < s.k;
-    s.e = e0 + sub;
-    s.fixed = lv.lm_fixed_g[gi] != 0;
-    s.ws = lv.lm_ws8[(size_t)gi * LMF_W + sub];
+    if (!s.uvalid) return;      // (a unit past the group's end: its 8 lanes zero the 8 slots)
     const double* Lp = d.lm[state] + (size_t)s.slot * 6;
     s.L[0] = Lp[0]; s.L[1] = Lp[1]; s.L[2] = Lp[2];
     if (IS_LINE) { s.L[3] = Lp[3]; s.L[4] = Lp[4]; s.L[5] = Lp[5]; }
@@ -188,6 +191,12 @@ DEV void lm_load(const DevBuf& d, const LmView& lv, const LmGroup& g, int state,
         if (IS_LINE) { const double* m = lv.meas_ln + (size_t)(s.e - d.Ep) * 3; s.meas[0] = m[0]; s.meas[1] = m[1]; s.meas[2] = m[2]; }
         else { const double2 m = reinterpret_cast<const double2*>(lv.meas_pt)[s.e]; s.meas[0] = m.x; s.meas[1] = m.y; }
     }
+}
+template <bool IS_LINE>
+DEV void lm_load(const DevBuf& d, const LmView& lv, const LmGroup& g, int state, int step, int wv, int lane, LmStep& s) {
+    LmIdx x;
+    lm_load_idx<IS_LINE>(lv, g, step, wv, lane, x);
+    lm_load_data<IS_LINE>(d, lv, state, lane, x, s);
 }
 
 // camera blocks (and kf_off_pvr) of the group's window at `state`
@@ -204,16 +213,24 @@ DEV void lm_stage_window(const DevBuf& d, const LmGroup& g, int state, LmLds& S)
 // computeLambdaInit needs (max |Hll_jj| per group; diag of sum Jp^T w Jp per window slot, left in the bp part of the group's
 // output), the cached per-edge chi2 — no landmark inverse, no rank-k update.
 //
-// A step takes 32 units (8 per wave).  All lanes write their unit's 3 k-columns of the operand of A' A'^T (96 columns x 48 rows,
-// shared by the workgroup) and their right-hand-side 6-vectors; after a barrier each WAVE owns some of the 16 x 16 output tiles
-// and runs them over all 96 columns (so a wave carries 4 tiles' accumulators, not 11: what lets two workgroups share a CU);
-// the waves with one tile add up the right-hand-side vectors meanwhile.  The same again for sum Jp^T w Jp with 2 (1) columns per
-// unit, whose operand takes the place of the vector table.  Four workgroup barriers per step.
+// The WAVES of a workgroup run decoupled: a step of a wave takes 8 units; the 8 lanes of a unit are the 8 window slots (lm_load), so
+// a lane's keyframe never changes.  What stays inside the lane is accumulated in registers over the whole group: the diagonal block
+// sum Jp^T w Jp of its slot (21 entries), the right-hand-side parts bp = -sum Jp^T w e and bs = sum A' y (6 + 6).  What couples the
+// slots — A' A'^T — goes through a WAVE-PRIVATE operand panel in LDS (24 k-columns x 48 rows) and the wave's own six 16 x 16
+// accumulator tiles (36 v_mfma_f64_16x16x4_f64 per step): no workgroup barrier inside the loop, only the in-order LDS queue of the
+// wave itself.  At the end of the group the four waves' tiles and vectors are added in a fixed order through LDS.
+constexpr int LMF_WCOLS = 24;                 // k-columns of a wave's operand panel (8 units x 3)
+constexpr int LMF_NVEC = 33;                  // per-lane vector accumulators: 21 (H, lower by rows) + 6 (bp) + 6 (bs)
+DEV void lm_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 template <bool IS_LINE, int MODE>
 DEV void lm_schur_group(const DevBuf& d, const LmView& lv, const int gidx, const int state, const Robust& rb, LmLds& S, LmAcc& A4) {
     constexpr int NR = IS_LINE ? 1 : 2;
     const LmGroup g = lv.grp[gidx];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 7, li = lane & 15, lk = lane >> 4;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 7, li = lane & 15, lk = lane >> 4, u8 = lane >> 3;
     const double lambda = MODE == 0 ? d.ctrl->lambda : 0.0;
     lm_stage_window(d, g, state, S);
     const int nunits = IS_LINE ? 2 * g.nlm : g.nlm;
@@ -228,22 +245,24 @@ DEV void lm_schur_group(const DevBuf& d, const LmView& lv, const int gidx, const
 #endif
     LmStep cur;
     lm_load<IS_LINE>(d, lv, g, state, 0, wv, lane, cur);
+    LmIdx ix1;      // indices of step + 1 (a step ahead of the data they lead to: the two levels of loads never wait for each other)
+    ix1.uvalid = false; ix1.slot = 0; ix1.e = 0; ix1.has = false; ix1.fixed = true;
+    if (nsteps > 1) lm_load_idx<IS_LINE>(lv, g, 1, wv, lane, ix1);
     __syncthreads();
-    // tiles of this wave (row offsets of the A and B fragments): A' A'^T lower tiles (0,0) (1,0) | (1,1) (2,0) | (2,1) | (2,2);
-    // sum Jp^T w Jp tiles holding a slot's diagonal block (a slot's 6 rows may straddle two 16-row tiles): (2,2) | - | (0,0) (1,0) | (1,1) (2,1)
-    const bool s2 = wv < 2, h1 = wv != 1, h2 = wv >= 2;
-    double4v_lm accS0 = (double4v_lm){0.0, 0.0, 0.0, 0.0}, accS1 = accS0, accH0 = accS0, accH1 = accS0;
-    double accV = 0.0, chi_acc = 0.0, maxd = 0.0;      // accV: wave 2, lanes (slot, dof): bp; wave 3: bs
-    double* op = A4.op;
-    double* vt = A4.vh;
-    const int u32 = wv * 8 + (lane >> 3);      // unit inside the step
+    const double* kc = S.kc[0][sub];
+    const bool kfree = S.koff[sub] >= 0;
+    const double4v_lm z4 = (double4v_lm){0.0, 0.0, 0.0, 0.0};
+    double4v_lm a00 = z4, a10 = z4, a11 = z4, a20 = z4, a21 = z4, a22 = z4;      // lower tiles of A' A'^T, this wave's units only
+    double vec[LMF_NVEC];
+#pragma unroll
+    for (int t = 0; t < LMF_NVEC; ++t) vec[t] = 0.0;
+    double chi_acc = 0.0, maxd = 0.0;
+    double* op = A4.op + wv * (LMF_WCOLS * LMF_ROWS);
     for (int step = 0; step < nsteps; ++step) {
-        LmStep nxt;
-        if (step + 1 < nsteps) lm_load<IS_LINE>(d, lv, g, state, step + 1, wv, lane, nxt);      // in flight while this step computes
         FSTAMP(1);
         LmRows<NR> r;
-        const int rowsel = IS_LINE ? ((lane >> 3) & 1) : 0;
-        lm_eval<IS_LINE, NR>(d, rb, S.kc[0][cur.ws], cur.has && S.koff[cur.ws] >= 0, cur.L, cur.meas, cur.wt, cur.has, cur.lvl0, rowsel, true, r);
+        const int rowsel = IS_LINE ? (u8 & 1) : 0;
+        lm_eval<IS_LINE, NR>(d, rb, kc, cur.has && kfree, cur.L, cur.meas, cur.wt, cur.has, cur.lvl0, rowsel, true, r);
         FSTAMP(2);
         double h[6], b[3];
         int nact;
@@ -265,32 +284,39 @@ DEV void lm_schur_group(const DevBuf& d, const LmView& lv, const int gidx, const
             for (int t = 0; t < 3; ++t) bo[t] = b[t];
             if (!IS_LINE || rowsel == 0) d.lm_active[cur.slot] = active ? 1 : 0;
         }
-        const int wslot = cur.ws;
-        double* v = vt + (u32 * LMF_W + wslot) * 12;
         if (MODE == 1) {
             if (active && sub == 0) maxd = fmax(maxd, fmax(fmax(fabs(h[0]), fabs(h[3])), fabs(h[5])));
-            // diag of Jp^T w Jp of this observation -> the vector table, summed per slot below
+            // diag of Jp^T w Jp of this observation, per slot (left in the bp part of the output)
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 double q = 0.0;
 #pragma unroll
                 for (int a = 0; a < NR; ++a) q += r.wj * r.j[a][c] * r.j[a][c];
-                v[c] = q;
+                vec[21 + c] += q;
             }
-            __syncthreads();
-            if (wv == 2 && lane < LMF_ROWS) {
-                const int p = lane / 6, c = lane % 6;
-#pragma unroll 8
-                for (int q = 0; q < LMF_UNITS; ++q) accV += vt[(q * LMF_W + p) * 12 + c];
-            }
-            __syncthreads();
+            LmStep nxt;
+            if (step + 1 < nsteps) lm_load_data<IS_LINE>(d, lv, state, lane, ix1, nxt);
+            if (step + 2 < nsteps) lm_load_idx<IS_LINE>(lv, g, step + 2, wv, lane, ix1);
+            cur = nxt;
         } else {
             double Li[6], y[3], u[NR][3];
             lm_chol_inv(h, lambda, active, Li);
             lm_lower_mul(Li, b, y);
 #pragma unroll
             for (int a = 0; a < NR; ++a) lm_lower_mul(Li, r.l[a], u[a]);
-            // A' = wr sum_rows j (x) u  (6 x 3) -> k-columns 3 u32 + m, rows 6 slot + c;  gs = A' y;  gp = -wr sum_rows j e
+            // A' = wr sum_rows j (x) u  (6 x 3) -> k-columns 3 u8 + m, rows 6 slot + c;  bs += A' y;  bp -= wr sum_rows j e;  H += wr sum_rows j j^T
+            // (with js = sqrt(wr) j, us = sqrt(wr) u, es = sqrt(wr) e: one scaled copy of the rows instead of j and wr j side by side)
+            const double sw = r.wj > 0.0 ? r.wj * lm_rsqrt(r.wj) : 0.0;      // (a lane without observation or with a gated one: zero rows)
+            double es[NR];
+#pragma unroll
+            for (int a = 0; a < NR; ++a) {
+                es[a] = sw * r.e[a];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) r.j[a][c] *= sw;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) u[a][m] *= sw;
+            }
+            int hidx = 0;
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 double A3[3];
@@ -299,112 +325,98 @@ DEV void lm_schur_group(const DevBuf& d, const LmView& lv, const int gidx, const
                     double q = 0.0;
 #pragma unroll
                     for (int a = 0; a < NR; ++a) q += r.j[a][c] * u[a][m];
-                    A3[m] = r.wj * q;      // (a lane without observation or with a gated one: all zeros)
-                    op[(3 * u32 + m) * LMF_ROWS + 6 * wslot + c] = A3[m];
+                    A3[m] = q;
+                    op[(3 * u8 + m) * LMF_ROWS + 6 * sub + c] = q;
                 }
                 double q = 0.0;
 #pragma unroll
-                for (int a = 0; a < NR; ++a) q += r.j[a][c] * r.e[a];
-                v[c] = -r.wj * q;
-                v[6 + c] = A3[0] * y[0] + A3[1] * y[1] + A3[2] * y[2];
+                for (int a = 0; a < NR; ++a) q += r.j[a][c] * es[a];
+                vec[21 + c] -= q;
+                vec[27 + c] += A3[0] * y[0] + A3[1] * y[1] + A3[2] * y[2];
+#pragma unroll
+                for (int c2 = 0; c2 <= c; ++c2) {
+                    double hq = 0.0;
+#pragma unroll
+                    for (int a = 0; a < NR; ++a) hq += r.j[a][c] * r.j[a][c2];
+#ifndef PLBA_X_NOH
+                    vec[hidx++] += hq;
+#else
+                    (void)hq; (void)hidx;
+#endif
+                }
             }
             FSTAMP(4);
-            __syncthreads();
-            // ---- rank-k update, this wave's tiles over the step's 96 k-columns; the one-tile waves also sum the right-hand-side vectors ----
-            // (one loop per wave, with the fragments each tile pair shares read once: the operand is streamed from LDS by all four waves)
-            if (wv == 0) {      // (0,0) (1,0)
-#pragma unroll 4
-                for (int s4 = 0; s4 < LMF_SCOLS / 4; ++s4) {
-                    const double* col = op + (4 * s4 + lk) * LMF_ROWS + li;
-                    const double f0 = col[0], f1 = col[16];
-                    accS0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, accS0, 0, 0, 0);
-                    accS1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f0, accS1, 0, 0, 0);
-                }
-            } else if (wv == 1) {      // (1,1) (2,0)
-#pragma unroll 4
-                for (int s4 = 0; s4 < LMF_SCOLS / 4; ++s4) {
-                    const double* col = op + (4 * s4 + lk) * LMF_ROWS + li;
-                    const double f0 = col[0], f1 = col[16], f2 = col[32];
-                    accS0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, accS0, 0, 0, 0);
-                    accS1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f0, accS1, 0, 0, 0);
-                }
-            } else if (wv == 2) {      // (2,1)
-#pragma unroll 4
-                for (int s4 = 0; s4 < LMF_SCOLS / 4; ++s4) {
-                    const double* col = op + (4 * s4 + lk) * LMF_ROWS + li;
-                    accS0 = __builtin_amdgcn_mfma_f64_16x16x4f64(col[32], col[16], accS0, 0, 0, 0);
-                }
-            } else {      // (2,2)
-#pragma unroll 4
-                for (int s4 = 0; s4 < LMF_SCOLS / 4; ++s4) {
-                    const double f2 = op[(4 * s4 + lk) * LMF_ROWS + li + 32];
-                    accS0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f2, accS0, 0, 0, 0);
-                }
-            }
-            if (wv >= 2 && lane < LMF_ROWS) {
-                const int p = lane / 6, c = lane % 6 + (wv == 3 ? 6 : 0);
-#pragma unroll 8
-                for (int q = 0; q < LMF_UNITS; ++q) accV += vt[(q * LMF_W + p) * 12 + c];
+            // the next step's inputs are requested HERE — this step's evaluation is over, so its registers are free — and arrive during the
+            // matrix phase; the indices of the step after that ride along
+            LmStep nxt;
+            if (step + 1 < nsteps) lm_load_data<IS_LINE>(d, lv, state, lane, ix1, nxt);
+            if (step + 2 < nsteps) lm_load_idx<IS_LINE>(lv, g, step + 2, wv, lane, ix1);
+            lm_wave_sync();
+            // ---- rank-24 update of the wave's six lower tiles ----
+#pragma unroll 2
+            for (int s4 = 0; s4 < LMF_WCOLS / 4; ++s4) {
+                const double* col = op + (4 * s4 + lk) * LMF_ROWS + li;
+                const double f0 = col[0], f1 = col[16], f2 = col[32];
+#ifdef PLBA_X_NOMFMA
+                a00[0] += f0 * f1 * f2;
+                continue;
+#endif
+                a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, a00, 0, 0, 0);
+                a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f0, a10, 0, 0, 0);
+                a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, a11, 0, 0, 0);
+                a20 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f0, a20, 0, 0, 0);
+                a21 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f1, a21, 0, 0, 0);
+                a22 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f2, a22, 0, 0, 0);
             }
             FSTAMP(5);
-            __syncthreads();
-            // ---- sum Jp^T w Jp: k-columns NR u32 + a hold sqrt(wr) j_a (the operand takes the vector table's place) ----------------------
-            const double sw = r.wj > 0.0 ? r.wj * lm_rsqrt(r.wj) : 0.0;
-#pragma unroll
-            for (int a = 0; a < NR; ++a)
-#pragma unroll
-                for (int c = 0; c < 6; ++c) vt[(NR * u32 + a) * LMF_ROWS + 6 * wslot + c] = sw * r.j[a][c];
-            __syncthreads();
-            if (wv == 2) {      // (0,0) (1,0)
-#pragma unroll 4
-                for (int s4 = 0; s4 < (LMF_UNITS * NR) / 4; ++s4) {
-                    const double* col = vt + (4 * s4 + lk) * LMF_ROWS + li;
-                    const double f0 = col[0], f1 = col[16];
-                    accH0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, accH0, 0, 0, 0);
-                    accH1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f0, accH1, 0, 0, 0);
-                }
-            } else if (wv == 3) {      // (1,1) (2,1)
-#pragma unroll 4
-                for (int s4 = 0; s4 < (LMF_UNITS * NR) / 4; ++s4) {
-                    const double* col = vt + (4 * s4 + lk) * LMF_ROWS + li;
-                    const double f1 = col[16], f2 = col[32];
-                    accH0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, accH0, 0, 0, 0);
-                    accH1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f1, accH1, 0, 0, 0);
-                }
-            } else if (wv == 0) {      // (2,2)
-#pragma unroll 4
-                for (int s4 = 0; s4 < (LMF_UNITS * NR) / 4; ++s4) {
-                    const double f2 = vt[(4 * s4 + lk) * LMF_ROWS + li + 32];
-                    accH0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f2, f2, accH0, 0, 0, 0);
-                }
-            }
-            FSTAMP(6);
-            __syncthreads();
+            lm_wave_sync();      // (the next step's operand writes stay behind these reads)
+            cur = nxt;
         }
         FSTAMP(7);
-        cur = nxt;
     }
     FSTAMP1(8);
-    // ---- the group's parts go out: every tile lives in exactly one wave ------------------------------------------------------------------
-    double* part = lv.part + (size_t)gidx * LMF_PART;
-    double* cb = A4.op;      // 11 tiles x 256 doubles = 22.5 KB of the 36 KB operand (free after the loop's last barrier)
-    if (MODE == 0) {
-        // tile slots: A' A'^T lower tiles I (I + 1) / 2 + J = 0 .. 5; sum Jp^T w Jp tiles (0,0) (1,0) (1,1) (2,1) (2,2) = 6 .. 10
-        const int tS0 = wv == 0 ? 0 : wv == 1 ? 2 : wv == 2 ? 4 : 5, tS1 = wv == 0 ? 1 : 3;
-        const int tH0 = wv == 0 ? 10 : wv == 2 ? 6 : 8, tH1 = wv == 2 ? 7 : 9;
+    // ---- the group's parts go out: waves added in a fixed order ---------------------------------------------------------------------------
+    // vectors: over the 8 units of the wave (lanes with the same slot), then over the waves through LDS
 #pragma unroll
-        for (int v4 = 0; v4 < 4; ++v4) {
-            const int o = (lk + 4 * v4) * 16 + li;
-            cb[tS0 * 256 + o] = accS0[v4];
-            if (s2) cb[tS1 * 256 + o] = accS1[v4];
-            if (h1) cb[tH0 * 256 + o] = accH0[v4];
-            if (h2) cb[tH1 * 256 + o] = accH1[v4];
-        }
+    for (int t = 0; t < LMF_NVEC; ++t) {
+        double v = vec[t];
+        v += shfl_xor8(v);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        vec[t] = v;
     }
     chi_acc = wave_sum(chi_acc); maxd = wave_max(maxd);
+    __syncthreads();      // every wave is done with its operand panel: the region now takes the tiles and the vectors
+    double* cb = A4.op;                                   // [2][6 tiles][256]
+    double* vs = A4.op + 2 * 6 * 256;                     // [4 waves][8 slots][LMF_NVEC]
+    if (lane < LMF_W) {
+#pragma unroll
+        for (int t = 0; t < LMF_NVEC; ++t) vs[(wv * LMF_W + lane) * LMF_NVEC + t] = vec[t];
+    }
     if (lane == 0) { S.red[wv][0] = chi_acc; S.red[wv][1] = maxd; }
+    if (MODE == 0) {
+        double* mine = cb + (wv & 1) * (6 * 256);
+        if (wv < 2) {
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const int o = (lk + 4 * v4) * 16 + li;
+                mine[0 * 256 + o] = a00[v4]; mine[1 * 256 + o] = a10[v4]; mine[2 * 256 + o] = a11[v4];
+                mine[3 * 256 + o] = a20[v4]; mine[4 * 256 + o] = a21[v4]; mine[5 * 256 + o] = a22[v4];
+            }
+        }
+        __syncthreads();
+        if (wv >= 2) {
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const int o = (lk + 4 * v4) * 16 + li;
+                mine[0 * 256 + o] += a00[v4]; mine[1 * 256 + o] += a10[v4]; mine[2 * 256 + o] += a11[v4];
+                mine[3 * 256 + o] += a20[v4]; mine[4 * 256 + o] += a21[v4]; mine[5 * 256 + o] += a22[v4];
+            }
+        }
+    }
     __syncthreads();
     FSTAMP1(9);
+    double* part = lv.part + (size_t)gidx * LMF_PART;
     if (MODE == 0) {
         // entry (r, c) of pair block (p <= q): rows a = 6 p + r, b = 6 q + c of the local system, read from the lower tiles
         for (int idx = threadIdx.x; idx < 36 * 36; idx += 256) {
@@ -414,13 +426,20 @@ DEV void lm_schur_group(const DevBuf& d, const LmView& lv, const int gidx, const
             int a = 6 * p + r, b2 = 6 * q + c;
             if (a < b2) { const int tmp = a; a = b2; b2 = tmp; }      // symmetric: take the lower-triangle copy
             const int ta = a >> 4, tb = b2 >> 4;
-            const double sv = cb[(ta * (ta + 1) / 2 + tb) * 256 + (a & 15) * 16 + (b2 & 15)];
+            const int o = (ta * (ta + 1) / 2 + tb) * 256 + (a & 15) * 16 + (b2 & 15);
+            const double sv = cb[o] + cb[6 * 256 + o];
             double hv = 0.0;
-            if (p == q) hv = cb[(6 + ((ta == tb) ? 2 * ta : 2 * ta - 1)) * 256 + (a & 15) * 16 + (b2 & 15)];      // tiles (0,0) (1,0) (1,1) (2,1) (2,2)
+            if (p == q) {
+                const int hr = r >= c ? r : c, hc = r >= c ? c : r, k = hr * (hr + 1) / 2 + hc;
+                hv = (vs[(0 * LMF_W + p) * LMF_NVEC + k] + vs[(1 * LMF_W + p) * LMF_NVEC + k]) + (vs[(2 * LMF_W + p) * LMF_NVEC + k] + vs[(3 * LMF_W + p) * LMF_NVEC + k]);
+            }
             part[idx] = hv - sv;
         }
     }
-    if (lane < LMF_ROWS && (wv == 2 || (MODE == 0 && wv == 3))) part[36 * 36 + (lane / 6) * 12 + (wv == 3 ? 6 : 0) + lane % 6] = accV;
+    if ((int)threadIdx.x < LMF_W * 12 && (MODE == 0 || threadIdx.x % 12 < 6)) {
+        const int p = threadIdx.x / 12, k = 21 + threadIdx.x % 12;
+        part[36 * 36 + threadIdx.x] = (vs[(0 * LMF_W + p) * LMF_NVEC + k] + vs[(1 * LMF_W + p) * LMF_NVEC + k]) + (vs[(2 * LMF_W + p) * LMF_NVEC + k] + vs[(3 * LMF_W + p) * LMF_NVEC + k]);
+    }
     if (threadIdx.x == 0) {
         d.chi_part[gidx] = (S.red[0][0] + S.red[1][0]) + (S.red[2][0] + S.red[3][0]);
         if (MODE == 1) d.maxd_part[gidx] = fmax(fmax(S.red[0][1], S.red[1][1]), fmax(S.red[2][1], S.red[3][1]));
@@ -576,14 +595,18 @@ DEV void lm_trial_group(const DevBuf& d, const LmView& lv, const int gidx, const
     const int nsteps = (nunits + LMF_UNITS - 1) / LMF_UNITS;
     LmStep cur;
     lm_load<IS_LINE>(d, lv, g, cur_state, 0, wv, lane, cur);
+    LmIdx ix1;      // indices of step + 1, a step ahead of the data they lead to (see lm_schur_group)
+    ix1.uvalid = false; ix1.slot = 0; ix1.e = 0; ix1.has = false; ix1.fixed = true;
+    if (nsteps > 1) lm_load_idx<IS_LINE>(lv, g, 1, wv, lane, ix1);
     __syncthreads();
     double chi_acc = 0.0, sc_acc = 0.0;
     for (int step = 0; step < nsteps; ++step) {
-        LmStep nxt;
-        if (step + 1 < nsteps) lm_load<IS_LINE>(d, lv, g, cur_state, step + 1, wv, lane, nxt);
         LmRows<NR> r;
         const int rowsel = IS_LINE ? ((lane >> 3) & 1) : 0;
         lm_eval<IS_LINE, NR>(d, rb, S.kc[0][cur.ws], cur.has && S.koff[cur.ws] >= 0, cur.L, cur.meas, cur.wt, cur.has, cur.lvl0, rowsel, true, r);
+        LmStep nxt;
+        if (step + 1 < nsteps) lm_load_data<IS_LINE>(d, lv, cur_state, lane, ix1, nxt);      // in flight during the rest of the step
+        if (step + 2 < nsteps) lm_load_idx<IS_LINE>(lv, g, step + 2, wv, lane, ix1);
         double h[6], b[3];
         int nact;
         lm_hll<NR>(r, h, b, nact);

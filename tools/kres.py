@@ -1,9 +1,9 @@
 """Kernel resource usage of one HIP source: python tools/kres.py pl-inertial-slam_amd/csrc/plba_marg.hip [name-filter]
 (hipcc -Rpass-analysis=kernel-resource-usage, one line per kernel: VGPRs, AGPRs, scratch bytes per lane, spills, LDS, occupancy)."""
-import re, subprocess, sys
+import os, re, subprocess, sys
 src = sys.argv[1]; flt = sys.argv[2] if len(sys.argv) > 2 else ""
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-I", "include", "-I", "pl-inertial-slam_amd/csrc",
-       "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+       "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("PLBA_EXTRA_FLAGS", "").split()
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None; rows = []
 for line in out.splitlines():
