@@ -438,7 +438,7 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
         if (!slots) { int dev = 0, cus = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256; slots = 2 * std::max(cus, 1); }
         const long wg_steps = (Np + 31) / 32 + (Nl + 15) / 16;
         for (int R = 1; R <= 64; ++R) {
-            const long cap = (long)(0.94 * R * slots);
+            const long cap = (long)(0.97 * R * slots);
             steps = (int)std::max<long>(1, (wg_steps + cap - 1) / cap);
             if (steps <= 16) break;
         }
@@ -802,7 +802,7 @@ static int prepare(plba_problem* p) {
     d.pair_i = p->d_pair_i.p; d.pair_j = p->d_pair_j.p; d.pair_start = p->d_pair_start.p; d.ent_pi = p->d_ent_pi.p; d.ent_pj = p->d_ent_pj.p; d.ent_slot = p->d_ent_slot.p; d.ob_pos = p->d_ob_pos.p;
     d.ch_meta = p->d_ch_meta.p;
     d.schur_part = p->d_schur_part.p; d.pair_cnt = p->d_pair_cnt.p;
-    HIPCK(p, p->d_trial_cnt.alloc(1)); d.trial_cnt = p->d_trial_cnt.p;
+    HIPCK(p, p->d_trial_cnt.alloc(2)); d.trial_cnt = p->d_trial_cnt.p; d.back_cnt = reinterpret_cast<unsigned*>(p->d_trial_cnt.p + 1); p->back_epoch = 0;
     d.imu_i = p->d_imu_i.p; d.imu_j = p->d_imu_j.p; d.imu_pre = p->d_imu_pre.p; d.imu_info_pvr = p->d_imu_ipvr.p; d.imu_info_bias = p->d_imu_ibias.p;
     d.imu_err = p->d_imu_err.p; d.imu_chi = p->d_imu_chi.p;
     d.pr_n = p->pr_n; d.pr_nv = p->pr_nv;
@@ -1430,8 +1430,9 @@ static int enqueue_solve(plba_problem* p, bool do_solve, bool need_dinv) {
 //   C  k_lm_schur   chain segments (reading the pose-side accumulators) | groups: linearise + Hll / bl + damped inverse + rank-k update of the group's pose blocks
 //   D  k_lm_gather  blocks assembling the rest | pose-pair blocks = pose-side terms + the groups' parts
 //      chain Schur, factorisation, back-substitution of the dense system (unchanged)
-//   A  k_lm_trial   chain back-substitution segments + keyframe update | groups: landmark back-substitution, update, trial residuals
-//   B  k_pose_trial IMU / prior edges of the trial state (Jacobians into the idle accumulators) + the LM decision in its last workgroup
+//   A  k_lm_trial   chain back-substitution segments + keyframe update | groups: landmark back-substitution, update, trial residuals |
+//                   IMU / prior edges of the trial state (Jacobians into the idle accumulators; they wait, inside the launch, for the chain
+//                   segments that produce the trial keyframes); the LM decision in the launch's last workgroup
 // first iteration of a call: pose-side edges + the diagonal pass (chi2, max |H_jj|) + lambda_init instead of nothing before C
 static int lm_enqueue_first(plba_problem* p, int iteration) {
     const DevBuf& d = p->dv;
@@ -1465,7 +1466,6 @@ static int lm_enqueue_solve_and_trial(plba_problem* p) {
     else if (p->twin_ok) { launch_twin_cholesky(p->dd, p->twinv, s); MARKF(p, 12); launch_trsv_back(p->dd, true, epoch, s); }
     else { launch_cholesky(p->dd, true, epoch, s, chain_schur_factors_tile0(p->dd)); MARKF(p, 12); launch_trsv_back(p->dd, true, epoch, s); }
     MARK(p, 7);
-    launch_lm_trial(d, p->lv, p->cur, p->cur ^ 1, p->rob, &p->cv, p->dd.x, s);
     MARK(p, 8);
     return PLBA_OK;
 }
@@ -1521,13 +1521,13 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             DecideFusion df{lp, p->d_red.p, p->d_mail, seq};
             bool spec = false;
             if (p->opt.profile >= 2) {
-                launch_pose_trial(ds, trial, jac_trial, p->rob, true, p->lv.ngrp, nullptr, s);
+                launch_lm_trial(ds, p->lv, p->cur, trial, jac_trial, p->rob, &p->cv, p->dd.x, (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1), nullptr, s);
                 MARK(p, 9);
                 launch_decide_n(d, lp, p->d_red.p, p->lv.ngrp, p->d_mail, seq, s);
                 MARK(p, 10);
                 HIPCK(p, plba_stream_wait(s));
             } else {
-                launch_pose_trial(ds, trial, jac_trial, p->rob, true, p->lv.ngrp, &df, s);      // the trial's IMU / prior edges (linearised into the idle accumulators) + the decision
+                launch_lm_trial(ds, p->lv, p->cur, trial, jac_trial, p->rob, &p->cv, p->dd.x, (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1), &df, s);      // the trial's IMU / prior edges (linearised into the idle accumulators) | landmark groups; + the decision
                 if (jac_trial) { if ((rc = lm_enqueue_system(p, ds, trial, true))) return rc; spec = true; }      // gated on the device-side decision
                 long spins = 0;
                 while (__atomic_load_n(&p->h_mail->seq, __ATOMIC_ACQUIRE) != seq) {
@@ -1536,6 +1536,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             }
             if (__atomic_load_n(&p->h_mail->seq, __ATOMIC_ACQUIRE) != seq) FAIL(p, PLBA_ERR_DEVICE, "LM control block was not delivered by the device");
             *p->h_ctrl = p->h_mail->c;
+            if (p->h_ctrl->sync_fail) FAIL(p, PLBA_ERR_DEVICE, "k_lm_trial: the pose-side blocks waited for the chain back-substitution beyond their bound");
             if (p->opt.profile >= 2) st.ms_phase[1] += span(11, 12);
             else if (p->opt.profile == 1 && p->ev_sample) { fact_sampled_ms += span(11, 12); ++fact_samples; }
             if (p->opt.profile >= 2) {
@@ -1912,7 +1913,10 @@ int plba_debug_build(plba_problem* p, double lambda, int do_solve) {
         c0.lambda = lambda;
         HIPCK(p, plba_h2d(p, d.ctrl, &c0, sizeof c0));
         rc = lm_enqueue_system(p, d, p->cur, false);
-        if (!rc && do_solve) rc = lm_enqueue_solve_and_trial(p);
+        if (!rc && do_solve) {
+            rc = lm_enqueue_solve_and_trial(p);
+            if (!rc) launch_lm_trial(d, p->lv, p->cur, p->cur ^ 1, false, p->rob, &p->cv, p->dd.x, (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1), nullptr, p->stream);      // (errors only: the accumulators keep the built system)
+        }
         p->lv.dbg_out = 0; p->lv.ob_err = nullptr;
         if (rc) return rc;
         HIPCK(p, plba_stream_wait(p->stream));

@@ -49,7 +49,7 @@ constexpr int MAX_PART = 8192;    // per-block partial sums for deterministic re
 // LM control block, device-resident; copied back once per trial.
 struct Ctrl {
     double lambda, ni, current_chi, temp_chi, scale, rho, maxdiag, pad0;
-    int accepted, solver_ok, iteration, trial, n_gate_pt, n_gate_ln, n_fail, pad1;
+    int accepted, solver_ok, iteration, trial, n_gate_pt, n_gate_ln, n_fail, sync_fail /* an in-launch wait ran into its bound */;
 };
 // Pinned, device-mapped host memory k_decide writes the control block into at the end of every LM trial: the host
 // polls `seq` instead of paying for a device-to-host copy launch plus a stream synchronisation per trial.
@@ -100,6 +100,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     int nxlist;
     int* pair_cnt;         // arrival counters (indexed by a pair's first chunk slot), zero between launches
     int* trial_cnt;        // arrival counter of the trial-error launch's workgroups (the last one decides), zero between launches
+    unsigned* back_cnt;    // chain back-substitution segments finished, all k_lm_trial launches so far (monotonic; the launch's pose-side blocks wait for it)
     // IMU
     const int32_t *imu_i, *imu_j;
     const double *imu_pre, *imu_info_pvr, *imu_info_bias;
@@ -209,8 +210,7 @@ void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused,
 // fused landmark-major passes (plba_lm_dev.h)
 void launch_lm_schur(const DevBuf& d, const LmView& lv, int state, const Robust& rb, bool diag_pass, const ChainView* lead /* chain segments riding in front, or null */, bool spec, hipStream_t s);
 void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool add_lambda, bool spec, hipStream_t s);
-void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, const Robust& rb, const ChainView* lead /* chain back-substitution riding in front, or null */, const double* xd, hipStream_t s);
-void launch_pose_trial(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, int nred, const DecideFusion* df, hipStream_t s);      // IMU / prior edges of the trial state + the LM decision
+void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, bool jac, const Robust& rb, const ChainView* lead, const double* xd, unsigned back_target, const DecideFusion* df, hipStream_t s);      // A: chain back-substitution | landmark groups | the trial's pose-side edges (+ the LM decision)
 void launch_lm_level_sync(const DevBuf& d, const LmView& lv, hipStream_t s);
 void launch_lambda_init_n(const DevBuf& d, const LmParams& lp, double* red, int iteration, int nred, hipStream_t s);
 void launch_decide_n(const DevBuf& d, const LmParams& lp, double* red, int nred, Mailbox* mail, unsigned long long seq, hipStream_t s);

@@ -104,8 +104,9 @@ DEV int quad_sum_i(int v) {
 // -------------------------------------------------------------------------------------------------
 struct DecideArgs;
 // arrive != null (the trial pass with Jacobians): the block counts itself in for the LM decision as soon as its chi2 is out, and goes on
-template <bool JAC, int NT> DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane, const DecideArgs* arrive = nullptr, int nblk_edges = 0, double* s4 = nullptr);
-template <bool JAC> DEV void prior_block(const DevBuf& d, int state, const DecideArgs* arrive = nullptr, int nblk_edges = 0, double* s4a = nullptr);
+struct LeadWait;
+template <bool JAC, int NT> DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane, const DecideArgs* arrive = nullptr, int nblk_edges = 0, double* s4 = nullptr, const LeadWait* lw = nullptr);
+template <bool JAC> DEV void prior_block(const DevBuf& d, int state, const DecideArgs* arrive = nullptr, int nblk_edges = 0, double* s4a = nullptr, const LeadWait* lw = nullptr);
 // End of a trial folded into the trial-error launch (one GPU): the workgroup that finishes last takes the LM decision
 // (decide_body = what k_decide does), so the decision is out one launch earlier.  The trial-error launch is normally the
 // JAC = true instance: steps are accepted far more often than not, so the trial state is linearised in the same pass that
@@ -114,6 +115,27 @@ template <bool JAC> DEV void prior_block(const DevBuf& d, int state, const Decid
 struct DecideArgs { LmParams lp; double* red; Mailbox* mail; unsigned long long seq; int nblk_lm; int fuse; };
 DEV void decide_body(const DevBuf& d, const LmParams& lp, double* red, int fused, int nblk_edges, int nblk_lm, Mailbox* mail, unsigned long long seq, double* s4, bool coherent);
 DEV void publish(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }     // sc1: visible to a same-launch reader on another XCD
+DEV double fetch(const double* p, bool coherent) { return coherent ? __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; }
+// In-launch hand-off (k_lm_trial): the pose-side blocks of the trial need the keyframe states the chain back-substitution segments of the
+// SAME launch produce.  The segments have the lowest block indices — they are resident before any waiter can be — publish their
+// keyframes (sc1 stores), drain, and count themselves in on a monotonic counter; a waiter polls it (bounded: a bound that is hit is
+// reported through Ctrl::sync_fail and fails the call, it never hangs the queue) and then reads the states with sc1 loads.
+struct LeadWait { const unsigned* cnt; unsigned target; int* fail; };
+DEV void lead_done(unsigned* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DEV void lead_wait(const LeadWait& w) {
+    if (threadIdx.x == 0 && w.cnt) {
+        int n = 0;
+        while ((int)(__hip_atomic_load(const_cast<unsigned*>(w.cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - w.target) < 0) {      // (wrap-safe)
+            __builtin_amdgcn_s_sleep(16);
+            if (++n > (1 << 20)) { __hip_atomic_store(w.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+}
 
 // Every workgroup of the trial-error launch ends here: its results have gone out with sc1 stores; once they are drained it
 // counts itself, and the last one to arrive reads everybody's (sc1 loads) and decides.
@@ -782,7 +804,7 @@ DEV void update_kf_one(const DevBuf& d, int cur, int trial, int k) {
         for (int i = 0; i < 6; ++i) tmp[16 + i] = s[16 + i] + d.x[ob + i];
     }
 #pragma unroll
-    for (int i = 0; i < KF_STRIDE; ++i) o[i] = tmp[i];
+    for (int i = 0; i < KF_STRIDE; ++i) publish(o + i, tmp[i]);      // (sc1: the pose-side blocks of the SAME launch may read it, k_lm_trial)
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -805,7 +827,7 @@ DEV void update_kf_vals(const DevBuf& d, int trial, int k, const double* s /*KF_
     }
     double* o = d.kf[trial] + (size_t)k * KF_STRIDE;
 #pragma unroll
-    for (int i = 0; i < KF_STRIDE; ++i) o[i] = tmp[i];
+    for (int i = 0; i < KF_STRIDE; ++i) publish(o + i, tmp[i]);
 }
 
 DEV void chain_back_segment(const DevBuf& d, const ChainView& cv, const double* xd, const int g, const int cur, const int trial) {
@@ -865,7 +887,7 @@ DEV void chain_back_segment(const DevBuf& d, const ChainView& cv, const double* 
         sM[idx / 81][81 + idx % 81] = cv.Lsub[(size_t)i0 * 81 + idx];
     }
     // ---- the dense solution ---------------------------------------------------------------------------------------------------
-    if (g == 0) for (int c = t; c < cv.Pd; c += BACK_THREADS) d.x[cv.pidx[c]] = xd[c];
+    if (g == 0) for (int c = t; c < cv.Pd; c += BACK_THREADS) publish(&d.x[cv.pidx[c]], xd[c]);      // (x is read by the deciding workgroup of the same launch)
     for (int c = t; c < wn; c += BACK_THREADS) sxw[c] = xd[wlo + c];
     double u9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ub6[6] = {0, 0, 0, 0, 0, 0};
     if (kf_k >= 0) {
@@ -914,7 +936,7 @@ DEV void chain_back_segment(const DevBuf& d, const ChainView& cv, const double* 
             for (int q = 0; q < 9; ++q) xi = fma(Li[q * 9 + r], lane_bcast(tt, q), xi);         // (L_ii^-T t)_r ; L^-1 is lower: zeros where q < r
             xn = xi;
             const int gi = cv.cidx[(i0 + i) * 9 + r];
-            if (lane < 9) { sxc[i * 9 + r] = gi >= 0 ? xi : 0.0; if (gi >= 0) d.x[gi] = xi; }
+            if (lane < 9) { sxc[i * 9 + r] = gi >= 0 ? xi : 0.0; if (gi >= 0) publish(&d.x[gi], xi); }
         }
     }
     __syncthreads();
@@ -927,7 +949,7 @@ DEV void chain_back_segment(const DevBuf& d, const ChainView& cv, const double* 
 #pragma unroll
             for (int i = 0; i < 6; ++i) ub6[i] = sxc[e_blk * 9 + 3 + i];
             // the pose part of this keyframe's step in system order (the same values workgroup 0 scatters)
-            if (op >= 0) { d.x[op] = u9[0]; d.x[op + 1] = u9[1]; d.x[op + 2] = u9[2]; d.x[op + 6] = u9[6]; d.x[op + 7] = u9[7]; d.x[op + 8] = u9[8]; }
+            if (op >= 0) { publish(&d.x[op], u9[0]); publish(&d.x[op + 1], u9[1]); publish(&d.x[op + 2], u9[2]); publish(&d.x[op + 6], u9[6]); publish(&d.x[op + 7], u9[7]); publish(&d.x[op + 8], u9[8]); }
         }
         update_kf_vals(d, trial, kf_k, ks, u9, ub6, op >= 0, ob >= 0);
     }
@@ -1046,7 +1068,8 @@ __global__ void k_update_kf(DevBuf d, int cur, int trial) {
 // pose-side system with fp64 atomics (a handful of edges share a destination block).
 // -------------------------------------------------------------------------------------------------
 template <bool JAC, int NT>
-DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane, const DecideArgs* arrive, int nblk_edges, double* s4) {
+DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane, const DecideArgs* arrive, int nblk_edges, double* s4, const LeadWait* lw) {
+    __shared__ double sKF[2 * KF_STRIDE];      // (k_lm_trial) the two keyframe states, read coherently once their producers have counted in
     __shared__ double sJ[9 * 24];     // [J0 | J1 | J2] row-major 9 x 24
     __shared__ double sOJ[9 * 24];
     __shared__ double sE[16];
@@ -1056,6 +1079,12 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
     const int ki = d.imu_i[m], kj = d.imu_j[m];
     const double* si = d.kf[state] + (size_t)ki * KF_STRIDE;
     const double* sj = d.kf[state] + (size_t)kj * KF_STRIDE;
+    if (lw) {
+        lead_wait(*lw);
+        if (lane < 2 * KF_STRIDE) sKF[lane] = fetch((lane < KF_STRIDE ? si : sj - KF_STRIDE) + lane, true);
+        __syncthreads();
+        si = sKF; sj = sKF + KF_STRIDE;
+    }
     const double* pre = d.imu_pre + (size_t)m * PRE_STRIDE;
     const double* Om = d.imu_info_pvr + (size_t)m * 81;
     const double* Ob = d.imu_info_bias + (size_t)m * 36;
@@ -1234,11 +1263,18 @@ __global__ __launch_bounds__(256) void k_pose_edges(DevBuf d, int state, Robust 
 // K4: marginalization prior edge (one workgroup): dx, e = r0 + J0 dx, chi2 = |e|^2, g += -J0^T e.
 // Its Hessian J0^T J0 is constant and pre-scattered into Hconst at upload.
 template <bool JAC>
-DEV void prior_block(const DevBuf& d, int state, const DecideArgs* arrive, int nblk_edges, double* s4a) {
+DEV void prior_block(const DevBuf& d, int state, const DecideArgs* arrive, int nblk_edges, double* s4a, const LeadWait* lw) {
     __shared__ double s4[4];
     const int n = d.pr_n;
+    if (lw) lead_wait(*lw);
     for (int v = threadIdx.x; v < d.pr_nv; v += 256) {
         const double* s = d.kf[state] + (size_t)d.pr_kf[v] * KF_STRIDE;
+        double sc[KF_STRIDE];
+        if (lw) {
+#pragma unroll
+            for (int i = 0; i < KF_STRIDE; ++i) sc[i] = fetch(s + i, true);
+            s = sc;
+        }
         const double* x0 = d.pr_x0 + d.pr_x0off[v];
         double* dx = d.pr_dx + d.pr_idx[v];
         if (d.pr_isbias[v]) prior_dx_bias(s, x0, dx);
@@ -1318,7 +1354,6 @@ __global__ __launch_bounds__(256) void k_tri_pack(DevBuf d, double* buf, int unp
 }
 
 // k_reduce inlined into the LM control kernels for the single-GPU path (no exchange between reduce and control)
-DEV double fetch(const double* p, bool coherent) { return coherent ? __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; }
 // coherent: the partial sums come from other workgroups of the SAME launch (sc1 loads), not from an earlier kernel
 DEV void reduce_inline(const DevBuf& d, int nblk_edges, int nblk_lm, double* red, double* s4, bool coherent = false) {
     double c = 0.0, sc = 0.0, md = 0.0;
@@ -1371,9 +1406,9 @@ DEV void decide_body(const DevBuf& d, const LmParams& lp, double* red, int fused
         for (int i = threadIdx.x; i < nblk_edges; i += 256) cs += fetch(&d.chi_part[i], coherent);
         for (int i = threadIdx.x; i < d.M; i += 256) cs += fetch(&d.imu_chi[(size_t)i * 4 + 2], coherent) + fetch(&d.imu_chi[(size_t)i * 4 + 3], coherent);
         if (threadIdx.x == 0 && d.pr_nv > 0) cs += fetch(&d.pr_chi[0], coherent);
-        for (int i = threadIdx.x; i < nblk_lm; i += 256) { sc += d.scale_part[i]; md = fmax(md, d.maxd_part[i]); }
+        for (int i = threadIdx.x; i < nblk_lm; i += 256) { sc += fetch(&d.scale_part[i], coherent); md = fmax(md, d.maxd_part[i]); }
     }
-    if (sok) for (int j = threadIdx.x; j < d.P; j += 256) { const double xj = d.x[j]; sp += xj * (lambda * xj + d.bpg[j]); }
+    if (sok) for (int j = threadIdx.x; j < d.P; j += 256) { const double xj = fetch(&d.x[j], coherent); sp += xj * (lambda * xj + d.bpg[j]); }
     cs = wave_sum(cs); sc = wave_sum(sc); md = wave_max(md); sp = wave_sum(sp);
     if ((threadIdx.x & 63) == 0) { double* r = s_r[threadIdx.x >> 6]; r[0] = cs; r[1] = sc; r[2] = md; r[3] = sp; }
     __syncthreads();
@@ -1422,6 +1457,7 @@ DEV void decide_body(const DevBuf& d, const LmParams& lp, double* red, int fused
     c->solver_ok = 1;
     if (mail) {     // hand the decision to the host: payload, system-scope fence, then the sequence number it polls
         mail->c = *c;
+        mail->c.sync_fail = __hip_atomic_load(&c->sync_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (possibly set by another workgroup of this launch)
         __threadfence_system();
         __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -1516,25 +1552,35 @@ __global__ __launch_bounds__(256) void k_lm_gather(DevBuf d, LmView lv, int nasm
     if (diag) lm_gather_diag(d, lv, b, threadIdx.x, red);
     else lm_gather_part(d, lv, add_lambda, b, threadIdx.x, red);
 }
-// launch A: [chain back-substitution segments (+ keyframe update) | groups: landmark back-substitution, update, trial residuals]
-__global__ __launch_bounds__(LMB) void k_lm_trial(DevBuf d, LmView lv, int cur, int trial, Robust rb, ChainView cv, const double* xd, int nlead) {
-    static_assert(LMB == 256, "the chain segments ride in this launch");
-    if ((int)blockIdx.x < nlead) { chain_back_segment(d, cv, xd, blockIdx.x, cur, trial); return; }
-    __shared__ LmLds S;
-    const int g = blockIdx.x - nlead;
-    if (g == 0 && nlead == 0) for (int k = threadIdx.x; k < d.K; k += LMB) update_kf_one(d, cur, trial, k);   // keyframe part of update()
-    if (lv.grp[g].is_line) lm_trial_group<true>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
-    else lm_trial_group<false>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
-}
-// launch B: the IMU / prior edges of the trial state (with Jacobians: into the idle accumulators) and, in the workgroup that
-// finishes last, the LM decision over the chi2 partials launch A left (nred of them)
+// launch A: [chain back-substitution segments + the keyframes' update | groups: landmark back-substitution, update, trial residuals | the
+// IMU / prior edges of the trial state — with Jacobians: into the idle accumulators]; the workgroup that finishes last takes the LM
+// decision (da.fuse).  The pose-side blocks need the trial keyframes of the segments in front (lead_wait); they come LAST so that they
+// fill the slots the second round of groups leaves free instead of delaying the first: their serial per-edge math (16 us) and the
+// chain segments (17 us) then run in the shadow of the landmark pass — as launches of their own they cost 22 us / 17 us of an iteration.
 template <bool JAC>
-__global__ __launch_bounds__(256) void k_pose_trial(DevBuf d, int state, Robust rb, int nred, DecideArgs da) {
+__global__ __launch_bounds__(LMB) void k_lm_trial(DevBuf d, LmView lv, int cur, int trial, Robust rb, ChainView cv, const double* xd, int nlead, int npose, unsigned back_target, DecideArgs da) {
+    static_assert(LMB == 256, "chain_back_segment's thread layout");
     __shared__ double s4[4];
-    const int m = blockIdx.x;
-    if (m < d.M) pose_edge_block<JAC, 256>(d, state, rb, m, threadIdx.x, nullptr, 0, s4);
-    else if (m == d.M && d.pr_nv > 0) prior_block<JAC>(d, state, nullptr, 0, s4);
-    if (da.fuse) trial_arrive(d, da, nred, s4);
+    const int b = blockIdx.x;
+    if (b < nlead) {
+        chain_back_segment(d, cv, xd, b, cur, trial);
+        lead_done(d.back_cnt);
+    } else if (b < nlead + lv.ngrp) {
+        __shared__ LmLds S;
+        const int g = b - nlead;
+        if (g == 0 && nlead == 0) {      // no chain segments: this group stands in for them (keyframe part of update(), one count)
+            for (int k = threadIdx.x; k < d.K; k += LMB) update_kf_one(d, cur, trial, k);
+            lead_done(d.back_cnt);
+        }
+        if (lv.grp[g].is_line) lm_trial_group<true>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
+        else lm_trial_group<false>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
+    } else {
+        const int m = b - nlead - lv.ngrp;
+        const LeadWait lw{d.back_cnt, back_target, &d.ctrl->sync_fail};
+        if (m < d.M) pose_edge_block<JAC, 256>(d, trial, rb, m, threadIdx.x, nullptr, 0, s4, &lw);
+        else prior_block<JAC>(d, trial, nullptr, 0, s4, &lw);
+    }
+    if (da.fuse) trial_arrive(d, da, lv.ngrp, s4);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1562,17 +1608,13 @@ void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool ad
     if (nb + nasm == 0) return;
     hipLaunchKernelGGL(k_lm_gather, dim3(nasm + nb), dim3(256), 0, s, d, lv, nasm, add_lambda ? 1 : 0, spec ? 1 : 0, diag_pass ? 1 : 0);
 }
-void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, const Robust& rb, const ChainView* lead, const double* xd, hipStream_t s) {
-    const int nlead = lead ? lead->nseg : 0;
-    hipLaunchKernelGGL(k_lm_trial, dim3(lv.ngrp + nlead), dim3(LMB), 0, s, d, lv, cur, trial, rb, lead ? *lead : ChainView{}, xd, nlead);
-}
-void launch_pose_trial(const DevBuf& d, int state, bool jac, const Robust& rb, bool with_pose_edges, int nred, const DecideFusion* df, hipStream_t s) {
-    int nb = with_pose_edges ? d.M + (d.pr_nv > 0 ? 1 : 0) : 0;
+void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, bool jac, const Robust& rb, const ChainView* lead, const double* xd, unsigned back_target, const DecideFusion* df, hipStream_t s) {
+    const int nlead = lead ? lead->nseg : 0, npose = d.M + (d.pr_nv > 0 ? 1 : 0);
     DecideArgs da{};
-    if (df) { da.lp = df->lp; da.red = df->red; da.mail = df->mail; da.seq = df->seq; da.nblk_lm = nred; da.fuse = 1; if (nb == 0) nb = 1; }      // no pose-side edge: one workgroup just decides
-    if (nb == 0) return;
-    if (jac) hipLaunchKernelGGL(k_pose_trial<true>, dim3(nb), dim3(256), 0, s, d, state, rb, nred, da);
-    else hipLaunchKernelGGL(k_pose_trial<false>, dim3(nb), dim3(256), 0, s, d, state, rb, nred, da);
+    if (df) { da.lp = df->lp; da.red = df->red; da.mail = df->mail; da.seq = df->seq; da.nblk_lm = lv.ngrp; da.fuse = 1; }
+    const dim3 grid(nlead + lv.ngrp + npose);
+    if (jac) hipLaunchKernelGGL(k_lm_trial<true>, grid, dim3(LMB), 0, s, d, lv, cur, trial, rb, lead ? *lead : ChainView{}, xd, nlead, npose, back_target, da);
+    else hipLaunchKernelGGL(k_lm_trial<false>, grid, dim3(LMB), 0, s, d, lv, cur, trial, rb, lead ? *lead : ChainView{}, xd, nlead, npose, back_target, da);
 }
 void launch_lambda_init_n(const DevBuf& d, const LmParams& lp, double* red, int iteration, int nred, hipStream_t s) {
     hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(256), 0, s, d, lp, red, 1, iteration, 1, 0, nred, nred);

@@ -661,7 +661,7 @@ DEV void lm_trial_group(const DevBuf& d, const LmView& lv, const int gidx, const
     __syncthreads();
     if (threadIdx.x == 0) {
         const double c = (S.red[0][0] + S.red[1][0]) + (S.red[2][0] + S.red[3][0]), s = (S.red[0][1] + S.red[1][1]) + (S.red[2][1] + S.red[3][1]);
-        d.chi_part[gidx] = c; d.scale_part[gidx] = s;
+        publish(&d.chi_part[gidx], c); publish(&d.scale_part[gidx], s);      // (read by the launch's last workgroup: trial_arrive)
     }
 }
 

@@ -248,6 +248,7 @@ struct plba_problem {
     // fused landmark-major passes (options.lm_fused; plba_lm_dev.h)
     bool lm_ok = false;                         // this upload runs them (structure permitting: one GPU, chain path, <= 8 observations per landmark)
     std::vector<double> lm_hist;                // diagnostics (plba_debug_get "lm_groups")
+    unsigned back_epoch = 0;                    // k_lm_trial launches since the counters were allocated (DevBuf::back_cnt)
     bool lm_disable = false;                    // prepare() found the structure unfit after the fact and rebuilt for the record-based path
     bool lm_spec = false;                       // the accepted trial's Schur pass + gather are already in the stream (enqueued behind the decision)
     plba::LmView lv{};
