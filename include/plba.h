@@ -93,8 +93,8 @@ typedef struct {
                                    landmarks on the matrix cores, back-substitution + trial residuals in one pass — instead of writing a
                                    record per observation and gathering it three times.  Possible on one GPU when the chain path is in
                                    effect and no landmark has more than 8 observations or two in one keyframe.  2 = whenever possible;
-                                   1 = when possible and the window holds at least 250 k observations (below, the record-based passes
-                                   k_linearize / k_landmark_hll / k_schur_pairs / k_backsub are faster: measured);
+                                   1 = when possible and the window holds at least 40 k observations (BASELINE configs[1] .. [4]; below,
+                                   the record-based passes k_linearize / k_landmark_hll / k_schur_pairs / k_backsub run: DESIGN.md 4a);
                                    0 = never                                                                                (1) */
 } plba_options;
 

@@ -351,6 +351,7 @@ class HostPool {
 public:
     static HostPool& get() { static HostPool p; return p; }
     void run(int n, const std::function<void(int)>& f) {
+        finish();      // (an asynchronous job of this thread)
         if (n <= 1) { f(0); return; }
         std::lock_guard<std::mutex> serial(run_m_);      // one job at a time (problems on different host threads)
         ensure(n - 1);
@@ -363,6 +364,36 @@ public:
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [&] { return pending_ == 0; });
         job_ = nullptr;
+    }
+    // start(n, f): the workers take f(0..n-1) while the caller goes on; finish() (the caller helps with what is left) joins.  One
+    // asynchronous job at a time; a run() from the same thread in between joins it first.
+    void start(int n, std::function<void(int)> f) {
+        finish();
+        run_m_.lock();
+        ensure(n);
+        async_f_ = std::move(f);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &async_f_; njobs_ = n; next_ = 0; pending_ = n; ++gen_;
+        }
+        async_ = true; async_owner_ = std::this_thread::get_id();
+        cv_.notify_all();
+    }
+    void finish() {
+        if (!async_ || async_owner_ != std::this_thread::get_id()) return;
+        std::unique_lock<std::mutex> lk(m_);
+        while (next_ < njobs_) {
+            const int i = next_++;
+            lk.unlock();
+            async_f_(i);
+            lk.lock();
+            --pending_;
+        }
+        done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+        lk.unlock();
+        async_ = false;
+        run_m_.unlock();
     }
     ~HostPool() {
         { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
@@ -397,6 +428,9 @@ private:
     int njobs_ = 0, next_ = 0, pending_ = 0;
     unsigned long long gen_ = 0;
     bool stop_ = false;
+    std::function<void(int)> async_f_;
+    bool async_ = false;
+    std::thread::id async_owner_;
 };
 }  // namespace
 
@@ -406,29 +440,53 @@ private:
 // fit a window of LMF_W; the observations are re-listed in that order (static data: measurement, weight, window slot, original
 // index), so that a group streams its inputs.  Per group and window-slot pair (p <= q) some landmark couples, one contribution to
 // the pose-pair block (kf[p], kf[q]); the gather lists hold them block by block in ascending group order (a fixed summation order).
-struct LmHost {
-    std::vector<LmGroup> grp;
-    std::vector<int32_t> lm_slot, lm_ob0, ob_orig, blk_ij, blk_start, blk_src, row_kf, row_start, row_src;
-    std::vector<uint8_t> lm_ws8, lm_fixed, cov;
-    std::vector<double> meas_pt, meas_ln, ob_wt;
-};
-static bool lm_structure_fits(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf) {
+static bool lm_structure_fits(const plba_problem* p, const std::vector<int32_t>& lm_start) {
     if (p->K >= 65536) return false;
-    for (int s = 0; s < p->L; ++s) {
-        const int a = lm_start[s], b = lm_start[s + 1];
-        if (b - a > LMF_W) return false;
-        for (int x = a; x < b; ++x) for (int y = x + 1; y < b; ++y) if (ob_kf[x] == ob_kf[y]) return false;      // two observations in one keyframe
+    for (int s = 0; s < p->L; ++s) if (lm_start[s + 1] - lm_start[s] > LMF_W) return false;
+    return true;      // (two observations of a landmark in one keyframe are refused at upload; build_lm_groups still checks and returns false)
+}
+// Three phases.  (1) serial and light: order, group boundaries and windows, offsets.  (2) the gather lists, from the windows alone: every
+// pair of free window keyframes of a group is listed — a pair no landmark of the group happens to couple contributes an exact zero
+// block — so that neither the lists nor the structure of the reduced system wait for (3) the per-landmark / per-observation tables,
+// which the host worker pool fills WHILE prepare() goes on allocating and uploading (the largest single item of a BA call's host side:
+// 2.5 ms on one thread at configs[2]); lm_groups_finish() joins before they are uploaded.
+static void lm_fill_groups(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf, const std::vector<double>& ob_w, LmHost& H, int t) {
+    const int Ep = p->Ep;
+    for (int gi = H.gcut[t]; gi < H.gcut[t + 1]; ++gi) {
+        const LmGroup& g = H.grp[gi];
+        const int kind = g.is_line;
+        int l = g.lm0, ob = H.span_ob0[gi];
+        for (int n = H.span_at[gi]; n < H.span_end[gi]; ++n, ++l) {
+            const int s = H.ordall[n];
+            H.lm_slot[l] = s; H.lm_fixed[l] = p->lm_fixed[s]; H.lm_ob0[l] = ob;
+            // the 8 lanes of the landmark's unit(s) ARE the window slots: lane w takes the observation made from keyframe kf[w] (its
+            // offset in the landmark's range), or none (0xFF) — so a lane's camera block, operand rows and accumulators never move
+            uint8_t* w8 = &H.lm_ws8[(size_t)l * LMF_W];
+            for (int sl = 0; sl < LMF_W; ++sl) w8[sl] = 0xFF;
+            int nk = 0;
+            for (int e = lm_start[s]; e < lm_start[s + 1]; ++e, ++ob, ++nk) {
+                int w = 0;
+                while (g.kf[w] != ob_kf[e]) ++w;      // (<= 8 window keyframes, all of the landmark's are among them)
+                if (w8[w] != 0xFF) H.bad[t] = 1;      // two observations in one keyframe: not expressible
+                w8[w] = (uint8_t)nk;
+                H.ob_orig[ob] = e; H.ob_wt[ob] = ob_w[e];
+                if (kind == 0) { H.meas_pt[2 * (size_t)ob] = p->po_uv[2 * (size_t)e]; H.meas_pt[2 * (size_t)ob + 1] = p->po_uv[2 * (size_t)e + 1]; }
+                else for (int c = 0; c < 3; ++c) H.meas_ln[3 * (size_t)(ob - Ep) + c] = p->lo_l[3 * (size_t)(e - Ep) + c];
+            }
+        }
     }
+}
+static bool lm_groups_finish(LmHost& H) {      // false: a keyframe observes a landmark twice (refused at upload; checked all the same)
+    HostPool::get().finish();
+    for (int b : H.bad) if (b) return false;
     return true;
 }
 static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf, const std::vector<double>& ob_w, LmHost& H) {
     const int K = p->K, Np = p->Np, Nl = p->Nl, Ep = p->Ep, L = Np + Nl, E = (int)ob_kf.size();
     H.cov.assign((size_t)K * K, 0);
-    // (sized up front and filled through raw pointers: half a million push_backs were 1.5 ms of this function at configs[2])
-    H.lm_slot.resize(L); H.lm_ob0.resize(L + 1); H.lm_ws8.resize((size_t)L * LMF_W); H.lm_fixed.resize(L); H.ob_orig.resize(E); H.ob_wt.resize(E);
-    H.meas_pt.resize(2 * (size_t)Ep); H.meas_ln.resize(3 * (size_t)(E - Ep));
-    int nlm = 0, nob = 0;
-    H.lm_ob0[0] = 0;
+    const bool gt = getenv("PLBA_PREP_TIMING") != nullptr;
+    auto g0 = std::chrono::steady_clock::now();
+    auto glap = [&](const char* what) { if (!gt) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[prepare]   groups: %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - g0).count()); g0 = t; };
     // group size: a workgroup step takes 32 points or 16 lines.  Two workgroups share a CU (registers), so `slots` of them run at once and
     // the launch takes R rounds of groups: the smallest R whose groups stay within 16 steps, the groups sized to fill the R rounds
     // (configs[4]: 8750 workgroup-steps; 8 steps gave 1095 groups = 2.14 rounds, i.e. three — 9 steps give 973, two rounds, 25 % less)
@@ -446,14 +504,19 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
         if (const char* e = getenv("PLBA_LM_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= 16) steps = v; }
     }
     const int gpt = 32 * steps, gln = 16 * steps;
-    std::vector<std::pair<int64_t, int32_t>> blk_c, row_c;      // (key, source)
-    std::vector<int32_t> kmin(L), kmax(L), ord, tmp, cnt(K + 1);
-    std::vector<int32_t> stamp(K, -1), slot_of(K, 0);
-    for (int s = 0; s < L; ++s) {
+    // ---- phase 1 -----------------------------------------------------------------------------------------------------------------------
+    std::vector<int32_t>& kmin = H.kmin; std::vector<int32_t>& kmax = H.kmax; std::vector<int32_t>& ord = H.ord; std::vector<int32_t>& tmp = H.tmp;
+    std::vector<int32_t>& cnt = H.cnt; std::vector<int32_t>& ordall = H.ordall; std::vector<int32_t>& stamp = H.stamp;
+    kmin.resize(L); kmax.resize(L); cnt.assign(K + 1, 0); stamp.assign(K, -1); ordall.clear();
+    H.grp.clear(); H.span_at.clear(); H.span_end.clear(); H.span_ob0.clear();
+    H.blk_c.clear(); H.row_c.clear(); H.blk_ij.clear(); H.blk_start.clear(); H.row_kf.clear(); H.row_start.clear();
+    for (int s = 0; s < L; ++s) {      // (ob_kf ascends within a landmark when the caller lists observations in keyframe order; not assumed)
         int lo = K, hi = -1;
         for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) { lo = std::min(lo, ob_kf[e]); hi = std::max(hi, ob_kf[e]); }
         kmin[s] = lo; kmax[s] = hi;
     }
+    glap("kmin / kmax");
+    int nlm = 0, nob = 0;
     for (int kind = 0; kind < 2; ++kind) {
         const int s0 = kind ? Np : 0, s1 = kind ? L : Np, gmax = kind ? gln : gpt;
         // order by (first keyframe, last keyframe, index): two stable counting sorts; landmarks without an edge are not in the graph
@@ -468,76 +531,80 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
             for (int32_t s : ord) tmp[cnt[key[s]]++] = s;
             ord.swap(tmp);
         }
+        const int base = (int)ordall.size();
         size_t at = 0;
         while (at < ord.size()) {
             const int gi = (int)H.grp.size();
             int32_t win[LMF_W];
-            int nw = 0;
+            int nw = 0, gob = 0;
             size_t end = at;
             while (end < ord.size() && (int)(end - at) < gmax) {
                 const int s = ord[end];
                 int add = 0;
-                for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) if (stamp[ob_kf[e]] != gi) ++add;      // (a landmark's keyframes are distinct: lm_structure_fits)
+                for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) if (stamp[ob_kf[e]] != gi) ++add;      // (a duplicate keyframe inside one landmark is caught in phase 3)
                 if (nw + add > LMF_W) break;
                 for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) if (stamp[ob_kf[e]] != gi) { stamp[ob_kf[e]] = gi; win[nw++] = ob_kf[e]; }
+                gob += lm_start[s + 1] - lm_start[s];
                 ++end;
             }
             std::sort(win, win + nw);
             LmGroup g;
             memset(&g, 0, sizeof g);
             g.lm0 = nlm; g.nlm = (int32_t)(end - at); g.nw = nw; g.is_line = kind;
-            for (int q = 0; q < LMF_W; ++q) { g.kf[q] = q < nw ? win[q] : 0; g.off[q] = q < nw ? p->off_pvr[win[q]] : -1; if (q < nw) slot_of[win[q]] = q; }
-            uint8_t cooc[LMF_W][LMF_W] = {};
-            for (size_t n = at; n < end; ++n) {
-                const int s = ord[n];
-                H.lm_slot[nlm] = s; H.lm_fixed[nlm] = p->lm_fixed[s];
-                int ws[LMF_W], nk = 0, used = 0;
-                for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) {
-                    const int w = slot_of[ob_kf[e]];
-                    ws[nk++] = w; used |= 1 << w;
-                    H.ob_orig[nob] = e; H.ob_wt[nob] = ob_w[e];
-                    if (kind == 0) { H.meas_pt[2 * (size_t)nob] = p->po_uv[2 * (size_t)e]; H.meas_pt[2 * (size_t)nob + 1] = p->po_uv[2 * (size_t)e + 1]; }
-                    else for (int c = 0; c < 3; ++c) H.meas_ln[3 * (size_t)(nob - Ep) + c] = p->lo_l[3 * (size_t)(e - Ep) + c];
-                    ++nob;
-                }
-                {   // the 8 lanes of the landmark's unit(s) ARE the window slots: lane w takes the observation made from keyframe win[w] (its
-                    // offset in the landmark's range), or none (0xFF) — so a lane's camera block, operand rows and accumulators never move
-                    uint8_t* w8 = &H.lm_ws8[(size_t)nlm * LMF_W];
-                    for (int sl = 0; sl < LMF_W; ++sl) w8[sl] = 0xFF;
-                    for (int a2 = 0; a2 < nk; ++a2) w8[ws[a2]] = (uint8_t)a2;
-                    (void)used;
-                }
-                ++nlm;
-                H.lm_ob0[nlm] = nob;
-                for (int a2 = 0; a2 < nk; ++a2) for (int b2 = a2; b2 < nk; ++b2) cooc[std::min(ws[a2], ws[b2])][std::max(ws[a2], ws[b2])] = 1;
-            }
+            for (int q = 0; q < LMF_W; ++q) { g.kf[q] = q < nw ? win[q] : 0; g.off[q] = q < nw ? p->off_pvr[win[q]] : -1; }
+            H.grp.push_back(g);
+            H.span_at.push_back(base + (int32_t)at); H.span_end.push_back(base + (int32_t)end); H.span_ob0.push_back(nob);
+            // ---- phase 2 for this group: its window's pose pairs and right-hand-side rows (in group order = the fixed summation order) ----
             for (int q = 0; q < nw; ++q) {
                 if (g.off[q] < 0) continue;
                 for (int pp = 0; pp <= q; ++pp) {
-                    if (g.off[pp] < 0 || !cooc[pp][q]) continue;
+                    if (g.off[pp] < 0) continue;
                     const int i = g.kf[pp], j = g.kf[q];
                     H.cov[(size_t)i * K + j] = 1; H.cov[(size_t)j * K + i] = 1;
-                    blk_c.push_back({((int64_t)i << 20) | j, gi * 36 + q * (q + 1) / 2 + pp});
+                    H.blk_c.push_back({(int64_t)i * K + j, gi * 36 + q * (q + 1) / 2 + pp});
                 }
-                if (cooc[q][q]) row_c.push_back({(int64_t)g.kf[q], gi * LMF_W + q});
+                H.row_c.push_back({(int64_t)g.kf[q], gi * LMF_W + q});
             }
-            H.grp.push_back(g);
+            nlm += (int)(end - at); nob += gob;
             at = end;
         }
+        ordall.insert(ordall.end(), ord.begin(), ord.end());
     }
-    H.lm_slot.resize(nlm); H.lm_ob0.resize(nlm + 1); H.lm_ws8.resize((size_t)nlm * LMF_W); H.lm_fixed.resize(nlm);
-    std::stable_sort(blk_c.begin(), blk_c.end(), [](const std::pair<int64_t, int32_t>& a, const std::pair<int64_t, int32_t>& b) { return a.first < b.first; });
-    std::stable_sort(row_c.begin(), row_c.end(), [](const std::pair<int64_t, int32_t>& a, const std::pair<int64_t, int32_t>& b) { return a.first < b.first; });
-    for (size_t t = 0; t < blk_c.size(); ++t) {
-        if (t == 0 || blk_c[t].first != blk_c[t - 1].first) { H.blk_ij.push_back((int32_t)((blk_c[t].first >> 20) | ((blk_c[t].first & 0xfffff) << 16))); H.blk_start.push_back((int32_t)t); }
-        H.blk_src.push_back(blk_c[t].second);
+    glap("order + boundaries");
+    // stable counting sorts by key (K * K resp. K buckets): equal keys stay in group order
+    {
+        std::vector<int32_t>& c2 = H.c2; std::vector<int32_t>& pos = H.pos;
+        c2.assign((size_t)K * K + 1, 0);
+        for (const auto& b : H.blk_c) c2[b.first + 1]++;
+        for (size_t k = 0; k < (size_t)K * K; ++k) c2[k + 1] += c2[k];
+        H.blk_src.resize(H.blk_c.size());
+        for (size_t k = 0; k < (size_t)K * K; ++k) if (c2[k + 1] > c2[k]) { const int i = (int)(k / K), j = (int)(k % K); H.blk_ij.push_back((int32_t)(i | (j << 16))); H.blk_start.push_back(c2[k]); }
+        H.blk_start.push_back((int32_t)H.blk_c.size());
+        pos.assign(c2.begin(), c2.end() - 1);
+        for (const auto& b : H.blk_c) H.blk_src[pos[b.first]++] = b.second;
+        c2.assign(K + 1, 0);
+        for (const auto& r : H.row_c) c2[r.first + 1]++;
+        for (int k = 0; k < K; ++k) c2[k + 1] += c2[k];
+        H.row_src.resize(H.row_c.size());
+        for (int k = 0; k < K; ++k) if (c2[k + 1] > c2[k]) { H.row_kf.push_back(k); H.row_start.push_back(c2[k]); }
+        H.row_start.push_back((int32_t)H.row_c.size());
+        pos.assign(c2.begin(), c2.end() - 1);
+        for (const auto& r : H.row_c) H.row_src[pos[r.first]++] = r.second;
     }
-    H.blk_start.push_back((int32_t)blk_c.size());
-    for (size_t t = 0; t < row_c.size(); ++t) {
-        if (t == 0 || row_c[t].first != row_c[t - 1].first) { H.row_kf.push_back((int32_t)row_c[t].first); H.row_start.push_back((int32_t)t); }
-        H.row_src.push_back(row_c[t].second);
-    }
-    H.row_start.push_back((int32_t)row_c.size());
+    glap("gather lists");
+    // ---- phase 3: the tables, group by group, on the worker pool; joined by lm_groups_finish() -------------------------------------------------
+    const int ngrp = (int)H.grp.size();
+    H.lm_slot.resize(nlm); H.lm_ob0.resize(nlm + 1); H.lm_ws8.resize((size_t)nlm * LMF_W); H.lm_fixed.resize(nlm); H.ob_orig.resize(nob); H.ob_wt.resize(nob);
+    H.meas_pt.resize(2 * (size_t)Ep); H.meas_ln.resize(3 * (size_t)(E - Ep));
+    H.lm_ob0[nlm] = nob;
+    const int NT = E > 400000 ? 16 : E > 60000 ? 8 : E > 20000 ? 4 : 1;
+    H.gcut.assign(NT + 1, ngrp);
+    H.gcut[0] = 0;
+    for (int t = 1, g = 0; t < NT; ++t) { while (g < ngrp && H.span_ob0[g] < (int64_t)nob * t / NT) ++g; H.gcut[t] = g; }
+    H.bad.assign(NT, 0);
+    glap("table allocation");
+    const plba_problem* pp = p; const std::vector<int32_t>* ls = &lm_start; const std::vector<int32_t>* ok = &ob_kf; const std::vector<double>* ow = &ob_w; LmHost* Hp = &H;
+    HostPool::get().start(NT, [pp, ls, ok, ow, Hp](int t) { lm_fill_groups(pp, *ls, *ok, *ow, *Hp, t); });
 }
 
 static int prepare(plba_problem* p) {
@@ -577,10 +644,19 @@ static int prepare(plba_problem* p) {
     for (int e = 0; e < Ep; ++e) { ob_kf[e] = p->po_kf[e]; ob_slot[e] = p->po_pt[e]; ob_w[e] = p->po_w[e]; lm_start[p->po_pt[e] + 1]++; }
     for (int e = 0; e < El; ++e) { ob_kf[Ep + e] = p->lo_kf[e]; ob_slot[Ep + e] = Np + p->lo_ln[e]; ob_w[Ep + e] = p->lo_w[e]; lm_start[Np + p->lo_ln[e] + 1]++; }
     for (int s = 0; s < L; ++s) lm_start[s + 1] += lm_start[s];
+    // ---- fused landmark-major passes: does the structure fit?  (decided for good once the chain maps exist, below) -----------------
+    // lm_fused = 1: from 40 k observations on.  Measured after the third form of the Schur pass (decoupled waves, lane = window slot; ms
+    // per LM trial, record-based | fused): configs[0] 9 k observations 0.074 | 0.069, configs[1] 52 k 0.130 | 0.124, configs[2] 103 k
+    // 0.179 | 0.169, configs[4] 1.05 M 0.695 | 0.453.  Below the threshold the record-based passes stay: windows of that size are the
+    // reference's real ones (12 keyframes, tracks longer than a group's window of 8, which do not fit anyway).  2: whenever the structure fits
+    int lm_min_obs = 40000;
+    if (const char* e = getenv("PLBA_LM_MIN_OBS")) lm_min_obs = atoi(e);
+    const bool lm_cand = p->opt.lm_fused != 0 && (p->opt.lm_fused >= 2 || E >= lm_min_obs) && !p->lm_disable && p->world == 1 && E > 0 && p->opt.chain_elim && p->opt.use_mfma
+                         && p->opt.factor_block != 64 && lm_structure_fits(p, lm_start);
     // keyframe-major record positions (stable: landmark order inside a keyframe), in EREC_UNIT = 64-byte units: a point
     // record takes one unit, a line record two, packed back to back (plba_math.h)
-    p->ob_pos.assign(E, 0);
-    {
+    p->ob_pos.assign(lm_cand ? 0 : E, 0);
+    if (!lm_cand) {      // (the fused passes write no records)
         std::vector<int32_t> cntk(K + 1, 0);
         for (int e = 0; e < E; ++e) cntk[ob_kf[e] + 1] += (e < Ep) ? 1 : 2;
         for (int k = 0; k < K; ++k) cntk[k + 1] += cntk[k];
@@ -591,16 +667,11 @@ static int prepare(plba_problem* p) {
     for (int i = 0; i < Np; ++i) { memcpy(&p->lm0[(size_t)i * 6], &p->pts[(size_t)i * 3], 24); p->lm_fixed[i] = p->pt_fixed[i]; }
     for (int i = 0; i < Nl; ++i) { memcpy(&p->lm0[(size_t)(Np + i) * 6], &p->lns[(size_t)i * 6], 48); p->lm_fixed[Np + i] = p->ln_fixed[i]; }
     lap("index maps, slots");
-    // ---- fused landmark-major passes: does the structure fit?  (decided for good once the chain maps exist, below) -----------------
-    // lm_fused = 1: from LM_FUSED_MIN_OBS observations on (measured: configs[4], 1.05 M observations, 0.70 -> 0.565 ms per iteration; at
-    // configs[2], 103 k, the record-based passes are still ahead: 0.178 vs 0.190 ms — a launch there is a single round of workgroups and
-    // costs its dependent steps, not its traffic); 2: whenever the structure fits
-    int lm_min_obs = 250000;
-    if (const char* e = getenv("PLBA_LM_MIN_OBS")) lm_min_obs = atoi(e);
-    const bool lm_cand = p->opt.lm_fused != 0 && (p->opt.lm_fused >= 2 || E >= lm_min_obs) && !p->lm_disable && p->world == 1 && E > 0 && p->opt.chain_elim && p->opt.use_mfma
-                         && p->opt.factor_block != 64 && lm_structure_fits(p, lm_start, ob_kf);
-    LmHost LH;
+    if (!p->ctx.lm_host) p->ctx.lm_host = new LmHost;      // (stays with the cached context)
+    LmHost& LH = *p->ctx.lm_host;
+    struct PoolJoin { ~PoolJoin() { HostPool::get().finish(); } } join_tables;      // (declared after the vectors the asynchronous fill reads: joined before they go)
     if (lm_cand) build_lm_groups(p, lm_start, ob_kf, ob_w, LH);
+    else LH.grp.clear();
     lap("landmark groups");
     // ---- keyframe-pair lists for the Schur complement --------------------------------------------------
     // Counting sort of the (landmark, observation a, observation b >= a) triples by keyframe pair, on a few host threads:
@@ -1006,19 +1077,28 @@ static int prepare(plba_problem* p) {
     }
     std::vector<int32_t> al2;      // (function scope: a queued upload without staging room reads the host vector until the final wait)
     std::vector<uint8_t> colg;
+    if (lm_cand && !lm_groups_finish(LH)) {      // (defensive: a keyframe observing a landmark twice — plba_set_*_obs refuses that) rebuild for the record-based passes
+        p->lm_disable = true;
+        const int rc2 = prepare(p);
+        p->lm_disable = false;
+        return rc2;
+    }
+    lap("landmark tables joined");
     if (lm_cand) {
         const int ld = p->ld;
-        std::vector<uint8_t> in_blk((size_t)p->Ppad * ld, 0);
+        // the structural assembly list minus what k_lm_gather writes: the 6 x 6 pose blocks of keyframe pairs some group's window holds
+        // (LH.cov) and the right-hand-side columns of the observed keyframes
+        std::vector<int32_t> dim_kf(ld, -1);      // system dim -> keyframe, for the six pose dims (dp, dphi) of a free keyframe only
         colg.assign(ld, 0);
         static const int pose6b[6] = {0, 1, 2, 6, 7, 8};
-        for (size_t b = 0; b < LH.blk_ij.size(); ++b) {
-            const int i = LH.blk_ij[b] & 0xffff, j = (LH.blk_ij[b] >> 16) & 0xffff;
-            const int oi = p->off_pvr[i], oj = p->off_pvr[j];
-            for (int r : pose6b) for (int c : pose6b) { in_blk[(size_t)(oi + r) * ld + oj + c] = 1; in_blk[(size_t)(oj + c) * ld + oi + r] = 1; }
-        }
+        for (int k = 0; k < K; ++k) if (p->off_pvr[k] >= 0) for (int c : pose6b) dim_kf[p->off_pvr[k] + c] = k;
         for (int32_t k : LH.row_kf) for (int c : pose6b) colg[p->off_pvr[k] + c] = 1;
         al2.reserve(p->h_alist.size());
-        for (int32_t idx : p->h_alist) if (!in_blk[idx]) al2.push_back(idx);
+        for (int32_t idx : p->h_alist) {
+            const int r = idx / ld, c = idx - r * ld;
+            const int kr = r < ld ? dim_kf[r] : -1, kc = dim_kf[c];
+            if (!(kr >= 0 && kc >= 0 && LH.cov[(size_t)kr * K + kc])) al2.push_back(idx);
+        }
         HIPCK(p, p->d_lm_grp.upload(LH.grp)); HIPCK(p, p->d_lmg_slot.upload(LH.lm_slot)); HIPCK(p, p->d_lmg_ob0.upload(LH.lm_ob0)); HIPCK(p, p->d_lmg_orig.upload(LH.ob_orig));
         HIPCK(p, p->d_lmg_ws8.upload(LH.lm_ws8)); HIPCK(p, p->d_lmg_fixed.upload(LH.lm_fixed)); HIPCK(p, p->d_lmg_level.alloc(E)); HIPCK(p, p->d_lmg_meas_pt.upload(LH.meas_pt)); HIPCK(p, p->d_lmg_meas_ln.upload(LH.meas_ln)); HIPCK(p, p->d_lmg_wt.upload(LH.ob_wt));
         HIPCK(p, p->d_lmg_blk_ij.upload(LH.blk_ij)); HIPCK(p, p->d_lmg_blk_start.upload(LH.blk_start)); HIPCK(p, p->d_lmg_blk_src.upload(LH.blk_src));

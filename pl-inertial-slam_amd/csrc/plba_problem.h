@@ -146,6 +146,20 @@ struct DArr {
 
 }  // namespace plba
 
+namespace plba {
+// host image of the fused landmark-major passes' group structure (build_lm_groups, plba_api.hip); kept with the cached context
+// (HostCtx) so that its tables are not re-allocated (and their pages not re-faulted) by every BA call
+struct LmHost {
+    std::vector<LmGroup> grp;
+    std::vector<int32_t> lm_slot, lm_ob0, ob_orig, blk_ij, blk_start, blk_src, row_kf, row_start, row_src;
+    std::vector<uint8_t> lm_ws8, lm_fixed, cov;
+    std::vector<double> meas_pt, meas_ln, ob_wt;
+    // scratch of the build
+    std::vector<int32_t> kmin, kmax, ord, tmp, cnt, ordall, stamp, span_at, span_end, span_ob0, gcut, bad, c2, pos;
+    std::vector<std::pair<int64_t, int32_t>> blk_c, row_c;
+};
+}  // namespace plba
+
 struct HostCtx {           // per-problem runtime objects, cached across problems (plba_create / plba_destroy)
     int device = 0;
     hipStream_t stream = nullptr;
@@ -153,7 +167,9 @@ struct HostCtx {           // per-problem runtime objects, cached across problem
     void* h_mail = nullptr;      // mapped, coherent mailbox the decision kernel writes and the host polls
     void* d_mail = nullptr;      // its device address
     plba::StageArea* stage = nullptr;   // pinned upload staging (heap object: HostCtx is copied around by value)
+    plba::LmHost* lm_host = nullptr;    // the group tables of the fused passes: megabytes whose pages a fresh problem would fault in again
 };
+
 
 struct plba_problem {
     HostCtx ctx;

@@ -109,7 +109,10 @@ def test_structure_that_does_not_fit_falls_back(pkg, orc, hip):
     g.close(); o.close()
 
 
-def test_default_takes_the_fused_passes_from_250k_observations(pkg, hip):
+def test_default_takes_the_fused_passes_from_40k_observations(pkg, hip):
     small = pkg.new_problem(); small.upload_window(pkg.window.make_config(3, scale=0.1)); small.optimize(1)
     assert small.debug_get("lm_fused")[0] == 0
     small.close()
+    big = pkg.new_problem(); big.upload_window(pkg.window.make_config(2)); big.optimize(1)      # BASELINE configs[1]: 52 k observations
+    assert big.debug_get("lm_fused")[0] == 1
+    big.close()
