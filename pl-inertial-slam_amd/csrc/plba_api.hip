@@ -933,6 +933,7 @@ static int prepare(plba_problem* p) {
                 const double cost = 9.0 * steps + 2.0 * seg;
                 if (cost < best_cost) { best_cost = cost; best_seg = seg; }
             }
+            if (const char* e = getenv("PLBA_CHAIN_SEG")) { const int v = atoi(e); if (v >= 1 && v <= CHAIN_SEG) best_seg = v; }      // (measurement knob)
             const int SEG = best_seg;
             const std::vector<char> is_sep = separators(SEG);
             std::vector<int32_t> cidx, epos, seg_start, seg_col, pidx, ppos, pslot, slotcol((size_t)npos * CHAIN_NSLOT, -1);
