@@ -920,7 +920,12 @@ static int prepare(plba_problem* p) {
             return sep;
         };
         if (ok) {
-            // segment length: the dense factorisation costs ~9 us per 32-wide block step, a chain step ~2 us
+            // segment length: the dense factorisation costs ~9 us per 32-wide block step, a chain step ~2 us.  (What the number of DEPENDENT
+            // launches of the multi-chain plan does with the segment length is not monotonic — the band's width in tiles depends on how the
+            // segment windows fall on tile boundaries: tools/sweep_chain_seg.sh at configs[2]: 4 -> 375 dims, 7 launches; 6 -> 357, 6; 7 ->
+            // 348, 7; 8 -> 339, 6; and 8 there costs the trial launch 3 us of chain back-substitution for the 9 us the solve gains.  A model
+            // that followed the occupied tile count picked 7 and, at configs[4], 1410 dims / 17 launches instead of 1392 / 15: dropped.
+            // PLBA_CHAIN_SEG forces a length for measurements.)
             int best_seg = 1; double best_cost = 1e300;
             for (int seg = 1; seg <= CHAIN_SEG; ++seg) {
                 const std::vector<char> sp = separators(seg);
@@ -985,6 +990,20 @@ static int prepare(plba_problem* p) {
                     if (ukf.empty()) ukf.push_back(-1);      // keep the array non-empty; nukf stays 0
                     cv.nukf = (ukf[0] < 0) ? 0 : (int)ukf.size();
                     HIPCK(p, p->d_kfpos.upload(pos_of_kf)); HIPCK(p, p->d_ekf.upload(ekf)); HIPCK(p, p->d_ukf.upload(ukf));
+                    {   // chain_back_segment: everything a thread needs to know about the keyframe it updates, in one 80-byte record
+                        std::vector<int32_t> bkf((size_t)(nseg * CHAIN_SEG + std::max(cv.nukf, 1)) * 20, -1);
+                        auto fill = [&](int32_t* o, int kf, bool eliminated) {
+                            o[0] = kf; o[1] = p->off_pvr[kf]; o[2] = p->off_bias[kf];
+                            const int q = pos_of_kf[kf];
+                            if (q >= 0) {
+                                for (int i = 0; i < 6; ++i) o[3 + i] = slotcol[(size_t)q * CHAIN_NSLOT + i];
+                                if (!eliminated) for (int i = 0; i < 9; ++i) o[9 + i] = slotcol[(size_t)q * CHAIN_NSLOT + 6 + i];      // a separator's chain dims sit in the dense solution
+                            }
+                        };
+                        for (int g = 0; g < nseg; ++g) for (int t = 0; t < seg_start[g + 1] - seg_start[g]; ++t) fill(&bkf[(size_t)(g * CHAIN_SEG + t) * 20], ekf[seg_start[g] + t], true);
+                        for (int u = 0; u < cv.nukf; ++u) fill(&bkf[(size_t)(nseg * CHAIN_SEG + u) * 20], ukf[u], false);
+                        HIPCK(p, p->d_bkf.upload(bkf)); cv.bkf = p->d_bkf.p;
+                    }
                     std::vector<int32_t> trow(2 * (size_t)(cv.Pdpad / 32), 0);
                     for (int tb = 0; tb < cv.Pdpad / 32; ++tb) {
                         int glo = -1, ghi = -1;
@@ -994,6 +1013,38 @@ static int prepare(plba_problem* p) {
                     }
                     HIPCK(p, p->d_trow.upload(trow)); cv.trow = p->d_trow.p;
                     cv.kfpos = p->d_kfpos.p; cv.ekf = p->d_ekf.p; cv.ukf = p->d_ukf.p;
+                }
+                {   // chain_elim_segment's staging as one level of indices (it was three dependent rounds of loads: 11 us of a 19 us segment at
+                    // configs[2]).  A fixed-size region per segment, laid out for CHAIN_SEG blocks and padded with -3 (skip): the loads of the
+                    // indices then depend on nothing but the kernel arguments
+                    constexpr int NB = 3 * CHAIN_NSLOT * 9, REG = CHAIN_SEG * (162 + NB + 9);
+                    std::vector<int32_t> esrc((size_t)nseg * REG, -3);
+                    const int ld = p->ld, P = p->P;
+                    auto code = [&](int a, int b) -> int32_t { const int hi = std::max(a, b), lo = std::min(a, b); return (int32_t)((size_t)hi * ld + lo) | ((a == b && a < P) ? (1 << 30) : 0); };
+                    for (int g = 0; g < nseg; ++g) {
+                        const int i0 = seg_start[g], n = seg_start[g + 1] - i0;
+                        int32_t* oC = &esrc[(size_t)g * REG]; int32_t* oB = oC + CHAIN_SEG * 162; int32_t* oR = oB + CHAIN_SEG * NB;
+                        for (int bi = 0; bi < n; ++bi)
+                            for (int e = 0; e < 162; ++e) {
+                                const int32_t* ci = &cidx[(size_t)(i0 + bi) * 9];
+                                const bool nxt = bi + 1 < n;
+                                const int ga = e < 81 ? ci[e / 9] : (nxt ? ci[9 + (e - 81) / 9] : -1);
+                                const int gb = e < 81 ? ci[e % 9] : ci[(e - 81) % 9];
+                                oC[bi * 162 + e] = (ga >= 0 && gb >= 0) ? code(ga, gb) : ((e < 81 && e / 9 == e % 9) ? -2 : -1);
+                            }
+                        for (int bi = 0; bi < n; ++bi)
+                            for (int e = 0; e < NB; ++e) {
+                                const int dl = e / (CHAIN_NSLOT * 9), sl = (e / 9) % CHAIN_NSLOT, r = e % 9;
+                                const int pos = epos[i0 + bi] + dl - 1;
+                                const int col = (pos >= 0 && pos < npos) ? slotcol[(size_t)pos * CHAIN_NSLOT + sl] : -1;
+                                const int gi = cidx[(size_t)(i0 + bi) * 9 + r];
+                                oB[bi * NB + e] = (col >= 0 && gi >= 0) ? code(gi, pidx[col]) : -1;
+                            }
+                        for (int idx = 0; idx < n * 9; ++idx) oR[idx] = cidx[(size_t)i0 * 9 + idx] >= 0 ? cidx[(size_t)i0 * 9 + idx] : -1;      // (right-hand side: the system index itself)
+                    }
+                    if ((size_t)p->Ppad * ld >= ((size_t)1 << 30)) ok = false;      // (the diagonal flag needs bit 30)
+                    HIPCK(p, p->d_esrc.upload(esrc));
+                    cv.esrc = p->d_esrc.p; cv.esrc_off = nullptr;
                 }
                 p->d_W.release();      // must come back zero: the kernels only ever write inside each segment's window
                 HIPCK(p, p->d_W.alloc((size_t)(nel * 9 + 4) * cv.Wld)); HIPCK(p, p->d_Ldinv.alloc((size_t)nel * 81)); HIPCK(p, p->d_Lsub.alloc((size_t)nel * 81));
@@ -1017,7 +1068,7 @@ static int prepare(plba_problem* p) {
     }
     lap("chain maps + buffers");
     d.Ninv = nullptr; d.Nwork = nullptr;
-    HIPCK(p, p->d_dbgbuf.alloc(64)); d.dbgbuf = p->d_dbgbuf.p; p->dd.dbgbuf = d.dbgbuf;
+    HIPCK(p, p->d_dbgbuf.alloc(128)); d.dbgbuf = p->d_dbgbuf.p; p->dd.dbgbuf = d.dbgbuf;
     if (!p->chain_ok && p->P > 0 && p->Ppad / 32 <= NINV_MAX_T) { HIPCK(p, p->d_Ninv.alloc((size_t)2 * p->Ppad * p->ld)); d.Ninv = p->d_Ninv.p; d.Nwork = d.Ninv + (size_t)p->Ppad * p->ld; }
     // ---- structural assembly list (assemble_part): with the chain elimination on, sys is written by the assembly pass and
     // by k_schur_pairs only, so the entries neither of them can make non-zero never need touching again
@@ -2076,7 +2127,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
         else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { const size_t o = (size_t)p->ob_pos[p->Ep + e] * EREC_UNIT; v[3 * (size_t)e] = h[o + 13]; v[3 * (size_t)e + 1] = h[o + 14]; } }
     } else if (w == "erec") { HIPCK(p, fetch(d.erec, ((size_t)p->Ep + 2 * (size_t)p->El) * EREC_UNIT, v)); }
     else if (w == "stamps") { HIPCK(p, fetch(d.maxd_part, 80, v)); }
-    else if (w == "dbgbuf") { HIPCK(p, fetch(d.dbgbuf, 64, v)); }
+    else if (w == "dbgbuf") { HIPCK(p, fetch(d.dbgbuf, 128, v)); }
     else if (w == "pose_dim") v = {(double)p->P};
     else if (w == "marg_path") v.assign(p->marg_path, p->marg_path + 5);
     else if (w == "prof_lin_launches") v = {(double)p->prof_lin_launches};

@@ -59,32 +59,47 @@ __device__ __forceinline__ void chain_elim_segment(const DevBuf& d, const ChainV
     const int i0 = cv.seg_start[g], i1 = cv.seg_start[g + 1], n = i1 - i0;      // eliminated blocks of this segment
     if (threadIdx.x == 0) { s_step = 0; s_bad = 0; }
     const double lambda_acc = ACC ? d.ctrl->lambda : 0.0;
-    // ---- stage everything the steps read (one gather per entry, all in flight) --------------------------------------------
-    for (int idx = threadIdx.x; idx < n * 162; idx += ELIM_THREADS) {
-        const int bi = idx / 162, e = idx % 162;
-        const int32_t* ci = cv.cidx + (i0 + bi) * 9;
-        const bool nxt = bi + 1 < n;
-        const int ga = e < 81 ? ci[e / 9] : (nxt ? ci[9 + (e - 81) / 9] : -1);
-        const int gb = e < 81 ? ci[e % 9] : ci[(e - 81) % 9];
-        const bool ok = ga >= 0 && gb >= 0;
-        const double v = chain_sys_at<ACC>(d, ld, ok ? ga : 0, ok ? gb : 0, lambda_acc);
-        sCg[bi][e] = ok ? v : ((e < 81 && e / 9 == e % 9) ? 1.0 : 0.0);
-    }
-    for (int idx = threadIdx.x; idx < n * 3 * NSLOT * 9; idx += ELIM_THREADS) {
-        const int bi = idx / (3 * NSLOT * 9), e = idx % (3 * NSLOT * 9);
-        const int dl = e / (NSLOT * 9), sl = (e / 9) % NSLOT, r = e % 9;
-        const int pos = cv.epos[i0 + bi] + dl - 1;
-        const int col = (pos >= 0 && pos < cv.npos) ? cv.slotcol[pos * NSLOT + sl] : -1;
-        const int gi = cv.cidx[(i0 + bi) * 9 + r];
-        const bool ok = col >= 0 && gi >= 0;
-        const double v = chain_sys_at<ACC>(d, ld, ok ? gi : 0, ok ? cv.pidx[ok ? col : 0] : 0, lambda_acc);
-        sBg[bi][e] = ok ? v : 0.0;
-    }
-    for (int idx = threadIdx.x; idx < n * 9; idx += ELIM_THREADS) {
-        const int gi = cv.cidx[i0 * 9 + idx];
-        sRhs[idx / 9][idx % 9] = gi < 0 ? 0.0 : (ACC ? d.bimu[gi] + d.bprior[gi] : d.sys[(size_t)d.Ppad * ld + gi]);
+#ifdef PLBA_STAMPS_LM
+    unsigned long long ets[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; ets[0] = __builtin_readcyclecounter();
+#define ESTAMP(i) ets[i] = __builtin_readcyclecounter()
+#else
+#define ESTAMP(i) do {} while (0)
+#endif
+    // ---- stage everything the steps read: one level of host-built indices (cv.esrc: a fixed-size region per segment, so these loads wait
+    // for nothing but the kernel arguments), every gather in flight at once ----------------------------------------------------------------
+    {
+        constexpr int NBB = 3 * NSLOT * 9, NCB = SEGMAX * (162 + NBB), REG = NCB + SEGMAX * 9;
+        const int32_t* src = cv.esrc + (size_t)g * REG;
+        double* flatC = &sCg[0][0];      // [SEGMAX][162]
+        double* flatB = &sBg[0][0];      // [SEGMAX][3 * NSLOT * 9]
+        constexpr int PER = (NCB + ELIM_THREADS - 1) / ELIM_THREADS;
+        int32_t code[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { const int idx = q * ELIM_THREADS + threadIdx.x; code[q] = idx < NCB ? src[idx] : -3; }
+        double va[PER], vb[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {      // (every gather issued before the first one is used)
+            const int32_t c = code[q];
+            const size_t off = c >= 0 ? (size_t)(c & 0x3fffffff) : 0;
+            va[q] = ACC ? d.Himu[off] : d.sys[off];
+            vb[q] = ACC ? d.Hconst[off] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx = q * ELIM_THREADS + threadIdx.x;
+            const int32_t c = code[q];
+            if (c == -3) continue;
+            const double v = c >= 0 ? va[q] + vb[q] + ((ACC && (c >> 30)) ? lambda_acc : 0.0) : (c == -2 ? 1.0 : 0.0);
+            if (idx < SEGMAX * 162) flatC[idx] = v; else flatB[idx - SEGMAX * 162] = v;
+        }
+        for (int idx = threadIdx.x; idx < SEGMAX * 9; idx += ELIM_THREADS) {
+            const int gi = src[NCB + idx];
+            if (gi == -3) continue;
+            sRhs[idx / 9][idx % 9] = gi < 0 ? 0.0 : (ACC ? d.bimu[gi] + d.bprior[gi] : d.sys[(size_t)d.Ppad * ld + gi]);
+        }
     }
     __syncthreads();
+    ESTAMP(1);
     if (wv == 0) {
         // ---- the chain wave ----------------------------------------------------------------------------------------------
         bool bad = false;
@@ -150,8 +165,14 @@ __device__ __forceinline__ void chain_elim_segment(const DevBuf& d, const ChainV
             }
             asm volatile("" ::: "memory");
             lds_store(&s_step, i + 1);        // a wave's LDS operations execute in order: the data above is visible first
+#ifdef PLBA_STAMPS_LM
+            if (i < 8) ets[2 + i] = __builtin_readcyclecounter();
+#endif
         }
         if (bad && lane == 0) d.ctrl->solver_ok = 0;
+#ifdef PLBA_STAMPS_LM
+        if (ACC && lane == 0 && g == 1) { for (int q = 0; q < 10; ++q) d.dbgbuf[64 + q] = (double)(ets[q] - ets[0]); d.dbgbuf[75] = (double)n; }
+#endif
         return;
     }
     // ---- column lanes: w_i = L_ii^-1 (B_i - L_{i,i-1} w_{i-1}) over the dense columns of the segment's window + the rhs -------
@@ -204,6 +225,10 @@ __device__ __forceinline__ void chain_elim_segment(const DevBuf& d, const ChainV
         }
     }
     if (s_bad && threadIdx.x == 64) d.ctrl->solver_ok = 0;
+#ifdef PLBA_STAMPS_LM
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ACC && threadIdx.x == 64 && g == 1) { d.dbgbuf[76] = (double)(__builtin_readcyclecounter() - ets[0]); d.dbgbuf[77] = (double)(ets[1] - ets[0]); }
+#endif
 }
 
 

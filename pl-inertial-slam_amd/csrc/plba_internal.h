@@ -239,6 +239,11 @@ struct ChainView {
     const int32_t* ekf;           // nel: keyframe of each eliminated block (its segment's workgroup applies that keyframe's step)
     const int32_t* ukf;           // nukf keyframes whose whole step sits in the dense solution (separators, fixed): workgroup 0 applies it
     int nukf;
+    const int32_t* esrc;          // what chain_elim_segment stages, as ONE level of indices: a fixed region per segment, CHAIN_SEG x (162 entries of C | 3 x 15 x 9
+                                  // of B | 9 of the right-hand side); code = offset into the pose-side system (bit 30: on its diagonal), -1 = 0, -2 = 1, -3 = skip
+    const int32_t* esrc_off;      // (unused)
+    const int32_t* bkf;           // chain_back_segment's keyframe descriptors, one level instead of four: (nseg x CHAIN_SEG + nukf) x 20 ints
+                                  // [kf, off_pvr, off_bias, dense columns of the 6 pose dims, of the 9 chain dims (separators only), pad]
     double* W;                    // (nel * 9 + 4) x Wld:  L^-1 [B | b_c], column Pd = w_b; zero outside each segment's window
     double* Ldinv;                // nel x 81: L_ii^-1, row-major
     double* Lsub;                 // nel x 81: L_{i+1,i}

@@ -860,26 +860,23 @@ DEV void chain_back_segment(const DevBuf& d, const ChainView& cv, const double* 
         for (int u = 0; u < UFAST; ++u) { const int c = ll + 16 * u; wr[q][u] = Wr[c < wn ? c : 0]; }
         wbv[q] = Wr[cv.Pd - wlo];
     }
-    // (b) the keyframe this thread will update (threads [0, n): the segment's; workgroup 0, threads [64, 64 + nukf): the rest)
+    // (b) the keyframe this thread will update (threads [0, n): the segment's; workgroup 0, threads [64, 64 + nukf): the rest): one
+    // host-built descriptor, then its state — two levels of loads where the index maps took four
     int kf_k = -1, e_blk = -1;
-    if (t < n) { e_blk = t; kf_k = cv.ekf[i0 + t]; }
-    else if (g == 0 && t >= 64 && t - 64 < cv.nukf && t - 64 < BACK_THREADS - 64) kf_k = cv.ukf[t - 64];
+    const int32_t* kd = nullptr;
+    if (t < n) { e_blk = t; kd = cv.bkf + (size_t)(g * CHAIN_SEG + t) * 20; }
+    else if (g == 0 && t >= 64 && t - 64 < cv.nukf && t - 64 < BACK_THREADS - 64) kd = cv.bkf + (size_t)(cv.nseg * CHAIN_SEG + (t - 64)) * 20;
     double ks[KF_STRIDE];
     int op = -1, ob = -1, pc[6] = {-1, -1, -1, -1, -1, -1}, cc[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
-    if (kf_k >= 0) {
+    if (kd) {
+        const int4* k4 = reinterpret_cast<const int4*>(kd);
+        const int4 a0 = k4[0], a1 = k4[1], a2 = k4[2], a3 = k4[3], a4 = k4[4];
+        kf_k = a0.x; op = a0.y; ob = a0.z;
+        pc[0] = a0.w; pc[1] = a1.x; pc[2] = a1.y; pc[3] = a1.z; pc[4] = a1.w; pc[5] = a2.x;
+        cc[0] = a2.y; cc[1] = a2.z; cc[2] = a2.w; cc[3] = a3.x; cc[4] = a3.y; cc[5] = a3.z; cc[6] = a3.w; cc[7] = a4.x; cc[8] = a4.y;
         const double* sp = d.kf[cur] + (size_t)kf_k * KF_STRIDE;
 #pragma unroll
         for (int i = 0; i < KF_STRIDE; ++i) ks[i] = sp[i];
-        op = d.kf_off_pvr[kf_k]; ob = d.kf_off_bias[kf_k];
-        const int q = cv.kfpos[kf_k];
-        if (q >= 0) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) pc[i] = cv.slotcol[q * NSLOT + i];
-            if (e_blk < 0) {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) cc[i] = cv.slotcol[q * NSLOT + 6 + i];      // a separator's chain dims sit in the dense solution
-            }
-        }
     }
     // (c) the factors
     for (int idx = t; idx < n * 81; idx += BACK_THREADS) {
