@@ -17,6 +17,7 @@
 // -> k_lba_backsub -> k_lba_update (|DX|^2; the update itself gated on solver_ok) -> [host: |DX|].
 #include "plba_internal.h"
 #include "plba_problem.h"
+#include <chrono>
 
 #define HIPCK(p, call) PLBA_HIPCK(p, call)
 #define FAIL(p, code, ...) PLBA_FAIL(p, code, __VA_ARGS__)
@@ -26,9 +27,27 @@ namespace {
 
 constexpr int REC = 14;      // per-observation record: Jp[6], Jl[6] (points use 3), w, |e|
 
+// The pass-to-pass control of the optimiser (error comparison, lambda schedule, the three exits) lives on the device: a pass is enqueued
+// without waiting for the one before — the host only polls a mapped mailbox one pass behind, to stop enqueuing — and every kernel
+// of a pass returns at once when an earlier pass has ended the run (`done`).  Round 2 read `err` and `|DX|` back with two blocking
+// copies per pass: 0.31 ms per pass of which 0.13 ms kernels.
+struct LbaCtl {
+    double err, err_prev, lambda, lambda_next, err_first, dx2;
+    int iters, updates, do_update, done, failed, pad;
+};
+struct LbaMail {       // laid over the problem's mapped Mailbox (plba_internal.h): same size, `seq` at the same offset
+    LbaCtl c;
+    char pad[sizeof(Ctrl) - sizeof(LbaCtl)];
+    unsigned long long seq;
+};
+static_assert(sizeof(LbaCtl) <= sizeof(Ctrl) && sizeof(LbaMail) == sizeof(Mailbox), "the LBA mailbox reuses the problem's mapped mailbox");
 struct LbaDev {
     int K, Nkf, Np, Nl, Ep, El, P, Ppad, ld;
     double fx, fy, cx, cy, homog_th;
+    double lambda_k, min_error, min_error_change;      // plba_lba_options: what the device-side control needs
+    int variant;
+    LbaCtl* ctl;
+    LbaMail* mail;             // mapped host memory
     const double* Tmap;        // K x 16 row-major map poses (T_kf_w)
     const int32_t* kf_loc;     // K
     const int32_t* loc_kf;     // Nkf
@@ -161,6 +180,7 @@ __global__ void k_lba_init(LbaDev d) {
 // inverse poses of this pass: points take the iterate for local keyframes after the first pass (:1726-1730), lines take the
 // map pose throughout (:1790) unless use_iter
 __global__ void k_lba_poses(LbaDev d, int later_pass, int use_iter) {
+    if (d.ctl->done) return;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= d.K) return;
     const int loc = d.kf_loc[k];
@@ -206,6 +226,7 @@ constexpr int LM_NT = 128;
 __device__ __forceinline__ int diag_q(int a) { return a * 6 - a * (a - 1) / 2; }      // packed index of (a, a)
 // thread per landmark: its observations' records, Hll (packed upper), gl, and the error sum
 __global__ void __launch_bounds__(LM_NT) k_lba_landmarks(LbaDev d) {
+    if (d.ctl->done) return;
     const int l = blockIdx.x * LM_NT + threadIdx.x, L = d.Np + d.Nl;
     double err = 0.0, hm = 0.0;
     if (l < L) {
@@ -294,6 +315,7 @@ __device__ __forceinline__ void block_sum(double* acc, double* sh /* KF_NT / 64 
     if (threadIdx.x < NV) { double v = 0.0; for (int w = 0; w < KF_NT / 64; ++w) v += sh[w * NV + threadIdx.x]; acc[0] = v; }
 }
 __global__ void __launch_bounds__(KF_NT) k_lba_posesys(LbaDev d) {
+    if (d.ctl->done) return;
     const int i = blockIdx.x;
     __shared__ double sh[(KF_NT / 64) * 27];
     double acc[27];
@@ -318,7 +340,15 @@ __global__ void __launch_bounds__(KF_NT) k_lba_posesys(LbaDev d) {
     else if (threadIdx.x < 27) d.gp[6 * i + threadIdx.x - 21] = acc[0];
 }
 // scal[0] = sum of the error partials (fixed order), scal[1] = max |H_ii| over the whole diagonal (:1653-1658)
-__global__ void __launch_bounds__(256) k_lba_reduce(LbaDev d, int nblk) {
+__device__ void lba_deliver(const LbaDev& d, unsigned long long seq) {      // control block -> mapped mailbox, then the sequence number the host polls
+    d.mail->c = *d.ctl;
+    __threadfence_system();
+    __hip_atomic_store(&d.mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// + the first half of the pass's control (levMarquardtOptimizationLBA :1650-1659, :1882-1900): normalisation of the error as coded, the two
+// exits on the error, whether the step of this pass will be applied, the next lambda
+__global__ void __launch_bounds__(256) k_lba_reduce(LbaDev d, int nblk, int it, unsigned long long seq) {
+    if (d.ctl->done) return;
     __shared__ double sh[256], shm[256];
     double hm = 0.0, e = 0.0;
     for (int b = threadIdx.x; b < nblk; b += 256) { e += d.part[b]; hm = fmax(hm, d.part[nblk + b]); }
@@ -329,11 +359,34 @@ __global__ void __launch_bounds__(256) k_lba_reduce(LbaDev d, int nblk) {
         if ((int)threadIdx.x < s) { sh[threadIdx.x] += sh[threadIdx.x + s]; shm[threadIdx.x] = fmax(shm[threadIdx.x], shm[threadIdx.x + s]); }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { d.scal[0] = sh[0]; d.scal[1] = shm[0]; }
+    if (threadIdx.x == 0) {
+        d.scal[0] = sh[0]; d.scal[1] = shm[0];
+        LbaCtl* c = d.ctl;
+        double err = sh[0];
+        if (it == 0) {
+            c->err_first = err / (double)(d.Ep + d.El);      // reported only
+            err /= 0.0;                    // :1650 as coded (both counters are still 0): +inf, which makes the first comparison of :1894 a "success" (DESIGN.md 9)
+            c->lambda *= d.variant == 1 ? (double)(int)shm[0] : shm[0];      // :1653-1659; GBA declares `int Hmax` (:2468)
+        } else {
+            if (d.variant == 1) err /= 0.0;      // GBA :2744 divides by the zero counters in every pass
+            else err /= (double)(d.Np + d.Nl);   // :1882 as coded
+            if (fabs(err - c->err_prev) < d.min_error_change || err < d.min_error) { c->err = err; c->iters = it; c->done = 1; lba_deliver(d, seq); return; }
+        }
+        int do_update = 1;
+        double lambda_next = c->lambda;
+        if (it > 0) { if (err > c->err_prev) { lambda_next = c->lambda / d.lambda_k; do_update = 0; } else lambda_next = c->lambda * d.lambda_k; }
+        c->err = err; c->do_update = do_update; c->lambda_next = lambda_next;
+    }
 }
 // pose system before the Schur complement: damped diagonal blocks, unit padding, solver flag
-__global__ void k_lba_sysinit(LbaDev d, double lambda) {
+__global__ void k_lba_sysinit(LbaDev d) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d.ctl->done) {      // the run has ended: the (ungated) factorisation launches behind this one get the identity, not a cleared matrix
+        if (t == 0) d.ctrl->solver_ok = 1;
+        if (t < d.Ppad) d.sys[(size_t)t * d.ld + t] = 1.0;
+        return;
+    }
+    const double lambda = d.ctl->lambda;
     if (t == 0) { d.ctrl->solver_ok = 1; }
     if (t < d.Nkf * 36) {
         const int i = t / 36, a = (t % 36) / 6, b = t % 6;
@@ -448,7 +501,9 @@ __device__ void dinv_landmark(const LbaDev& d, int l, double lambda) {
         u[6] = wa * sg; u[7] = 0.0;
     }
 }
-__global__ void __launch_bounds__(LM_NT) k_lba_dinv(LbaDev d, double lambda) {
+__global__ void __launch_bounds__(LM_NT) k_lba_dinv(LbaDev d) {
+    if (d.ctl->done) return;
+    const double lambda = d.ctl->lambda;
     const int l = blockIdx.x * LM_NT + threadIdx.x;
     if (l >= d.Np + d.Nl) return;
     if (l < d.Np) dinv_landmark<3>(d, l, lambda); else dinv_landmark<6>(d, l, lambda);
@@ -458,6 +513,7 @@ __global__ void __launch_bounds__(LM_NT) k_lba_dinv(LbaDev d, double lambda) {
 // add per element and chunk (the only atomics of the iteration; a pair has few chunks).
 constexpr int PAIR_CHUNK = 256;
 __global__ void __launch_bounds__(64) k_lba_pairs(LbaDev d) {
+    if (d.ctl->done) return;
     const int32_t* ck = d.chunk + 4 * (size_t)blockIdx.x;
     const int la = ck[0], lb = ck[1], lane = threadIdx.x;
     double acc[36];
@@ -497,6 +553,7 @@ __global__ void __launch_bounds__(64) k_lba_pairs(LbaDev d) {
 }
 // right-hand side of the reduced system: gp - sum over the keyframe's observations of Jp s  (workgroup per local keyframe, fixed order)
 __global__ void __launch_bounds__(KF_NT) k_lba_rhs(LbaDev d) {
+    if (d.ctl->done) return;
     const int i = blockIdx.x;
     __shared__ double sh[(KF_NT / 64) * 6];
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -533,6 +590,7 @@ __device__ void backsub_landmark(const LbaDev& d, int l, double* out) {
     sym_mul_packed<N>(Dp, v, out);
 }
 __global__ void __launch_bounds__(LM_NT) k_lba_backsub(LbaDev d) {
+    if (d.ctl->done) return;
     const int l = blockIdx.x * LM_NT + threadIdx.x;
     double nn = 0.0;
     if (l < d.Np) {
@@ -549,7 +607,9 @@ __global__ void __launch_bounds__(LM_NT) k_lba_backsub(LbaDev d) {
     if (threadIdx.x == 0) d.part[blockIdx.x] = sh[0];
 }
 // |DX|^2 (:1911) and, when the step is taken and the solve succeeded, the update of :1901-1910
-__global__ void __launch_bounds__(256) k_lba_update(LbaDev d, int nblk, int do_update) {
+__global__ void __launch_bounds__(256) k_lba_update(LbaDev d, int nblk) {
+    if (d.ctl->done) return;
+    const int do_update = d.ctl->do_update;
     const bool ok = d.ctrl->solver_ok != 0;
     if (blockIdx.x == 0) {
         __shared__ double sh[256];
@@ -569,6 +629,19 @@ __global__ void __launch_bounds__(256) k_lba_update(LbaDev d, int nblk, int do_u
         se3_exp(d.Xp + 6 * t, Tp); se3_exp(d.x + 6 * t, Td); se3_inv(Td, Tdi); se3_mul(Tp, Tdi, Tc);
         se3_log(Tc, d.Xp + 6 * t);
     }
+}
+// the second half of the pass's control (:1901-1932), in a launch of its own: every workgroup of k_lba_update must have applied the step
+// before `done` may stop anything
+__global__ void k_lba_post(LbaDev d, int it, unsigned long long seq) {
+    LbaCtl* c = d.ctl;
+    if (c->done) return;
+    if (!d.ctrl->solver_ok) { c->failed = 1; c->iters = it; c->done = 1; lba_deliver(d, seq); return; }      // the reference's LDL^T has no such exit: a non-positive pivot ends the run here
+    c->dx2 = d.scal[2];
+    c->lambda = c->lambda_next;
+    if (c->do_update) c->updates += 1;
+    c->err_prev = c->err;
+    if (it > 0 && sqrt(d.scal[2]) < d.min_error_change) { c->iters = it + 1; c->done = 1; }
+    lba_deliver(d, seq);
 }
 __global__ void k_lba_final(LbaDev d) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -712,54 +785,62 @@ int plba_lba_visual(plba_problem* p, const plba_lba_options* opt, int K, const d
     dd.fb = (p->opt.factor_block == 64) ? 64 : 32; dd.chol_flags = cflags.p; dd.flow = p->opt.factor_flow != 0; dd.wide = p->opt.wide_steps != 0 && !dd.flow;
     if (Ninv.p) { dd.Ninv = Ninv.p; dd.Nwork = Ninv.p + (size_t)Ppad * ld; }
 
+    // ---- device-side control block + the problem's mapped mailbox ---------------------------------------------------------------------
+    DArr<LbaCtl> dctl;
+    HIPCK(p, dctl.alloc(1));
+    LbaCtl c0; memset(&c0, 0, sizeof c0);
+    c0.err_prev = 999999999.9; c0.lambda = opt->lambda_lm; c0.lambda_next = opt->lambda_lm;
+    HIPCK(p, plba_h2d(p, dctl.p, &c0, sizeof c0));
+    d.ctl = dctl.p; d.mail = reinterpret_cast<LbaMail*>(p->d_mail);
+    d.lambda_k = opt->lambda_k; d.min_error = opt->min_error; d.min_error_change = opt->min_error_change; d.variant = opt->variant;
+    volatile LbaMail* hm = reinterpret_cast<volatile LbaMail*>(p->h_mail);
+    const unsigned long long seq0 = p->mail_seq;      // sequence numbers go on from the problem's: never one the mailbox has held before
+    p->mail_seq += (unsigned long long)std::max(opt->max_iters, 0) + 1;
+
+    const bool ltime = getenv("PLBA_PREP_TIMING") != nullptr;
+    if (ltime) HIPCK(p, plba_stream_wait(s));
+    const auto lt0 = std::chrono::steady_clock::now();
     auto grid = [](size_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); };
     hipLaunchKernelGGL(k_lba_init, grid(Nkf, 64), dim3(64), 0, s, d);
-    double err = 0.0, err_prev = 999999999.9, lambda = opt->lambda_lm, scal[4];
-    int iters, updates = 0;
-    bool failed = false;
     memset(st, 0, sizeof *st);
-    for (iters = 0; iters < opt->max_iters; ++iters) {
-        hipLaunchKernelGGL(k_lba_poses, grid(K, 64), dim3(64), 0, s, d, iters > 0 ? 1 : 0, opt->use_iterate_poses);
+    bool stop = false;
+    for (int it = 0; it < opt->max_iters && !stop; ++it) {
+        const unsigned long long seq = seq0 + (unsigned long long)it + 1;
+        hipLaunchKernelGGL(k_lba_poses, grid(K, 64), dim3(64), 0, s, d, it > 0 ? 1 : 0, opt->use_iterate_poses);
         hipLaunchKernelGGL(k_lba_landmarks, dim3(nblk), dim3(LM_NT), 0, s, d);
         hipLaunchKernelGGL(k_lba_posesys, dim3(Nkf), dim3(KF_NT), 0, s, d);
-        hipLaunchKernelGGL(k_lba_reduce, dim3(1), dim3(256), 0, s, d, nblk);
-        HIPCK(p, plba_d2h(p, scal, dscal.p, 16));
-        err = scal[0];
-        if (iters == 0) {
-            st->err_first = err / (double)(Ep + El);      // reported only
-            err /= 0.0;                    // :1650 as coded (both counters are still 0): +inf, which makes the first comparison of :1894 a "success" (DESIGN.md §9)
-            lambda *= opt->variant == 1 ? (double)(int)scal[1] : scal[1];      // :1653-1659; GBA declares `int Hmax` (:2468)
-        } else {
-            if (opt->variant == 1) err /= 0.0;      // GBA :2744 divides by the zero counters in every pass
-            else err /= (double)(Np + Nl);          // :1882 as coded
-            if (fabs(err - err_prev) < opt->min_error_change || err < opt->min_error) break;
-        }
-        int do_update = 1;
-        double lambda_next = lambda;
-        if (iters > 0) { if (err > err_prev) { lambda_next = lambda / opt->lambda_k; do_update = 0; } else lambda_next = lambda * opt->lambda_k; }
+        hipLaunchKernelGGL(k_lba_reduce, dim3(1), dim3(256), 0, s, d, nblk, it, seq);
         HIPCK(p, hipMemsetAsync(sys.p, 0, sysn * 8, s));
-        hipLaunchKernelGGL(k_lba_sysinit, grid(std::max(Nkf * 36, Ppad), 256), dim3(256), 0, s, d, lambda);
-        hipLaunchKernelGGL(k_lba_dinv, dim3(nblk), dim3(LM_NT), 0, s, d, lambda);
+        hipLaunchKernelGGL(k_lba_sysinit, grid(std::max(Nkf * 36, Ppad), 256), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_lba_dinv, dim3(nblk), dim3(LM_NT), 0, s, d);
         if (nchunk) hipLaunchKernelGGL(k_lba_pairs, dim3(nchunk), dim3(64), 0, s, d);
         hipLaunchKernelGGL(k_lba_rhs, dim3(Nkf), dim3(KF_NT), 0, s, d);
-        launch_cholesky(dd, p->opt.use_mfma != 0, iters + 1, s);
-        launch_trsv_back(dd, p->opt.use_mfma != 0, iters + 1, s);
+        launch_cholesky(dd, p->opt.use_mfma != 0, it + 1, s);      // (not gated: after the run has ended it factors the unit padding of a cleared system, at most one pass of it)
+        launch_trsv_back(dd, p->opt.use_mfma != 0, it + 1, s);
         hipLaunchKernelGGL(k_lba_backsub, dim3(nblk), dim3(LM_NT), 0, s, d);
-        hipLaunchKernelGGL(k_lba_update, grid(std::max<size_t>(nl, Nkf), 256), dim3(256), 0, s, d, nblk, do_update);
-        Ctrl c;
-        HIPCK(p, plba_d2h(p, scal, dscal.p, 32));
-        HIPCK(p, plba_d2h(p, &c, ctrl.p, sizeof c));
-        HIPCK(p, hipGetLastError());
-        if (!c.solver_ok) { failed = true; break; }      // the reference's LDL^T has no such exit: a non-positive pivot ends the run here
-        lambda = lambda_next;
-        if (do_update) ++updates;
-        if (iters > 0 && sqrt(scal[2]) < opt->min_error_change) { err_prev = err; ++iters; break; }
-        err_prev = err;
+        hipLaunchKernelGGL(k_lba_update, grid(std::max<size_t>(nl, Nkf), 256), dim3(256), 0, s, d, nblk);
+        hipLaunchKernelGGL(k_lba_post, dim3(1), dim3(1), 0, s, d, it, seq);
+        // one pass behind: has pass it - 1 ended the run?  (pass `it` is in the queue already, the device never waits for this)
+        if (it > 0) {
+            const unsigned long long want = seq - 1;
+            long spins = 0;
+            while (__atomic_load_n(const_cast<const unsigned long long*>(&hm->seq), __ATOMIC_ACQUIRE) < want) {      // (what the mailbox held before is <= seq0)
+                if (++spins > (1L << 22)) { HIPCK(p, plba_stream_wait(s)); break; }
+            }
+            if (hm->c.done) stop = true;
+        }
     }
     hipLaunchKernelGGL(k_lba_final, grid(K, 64), dim3(64), 0, s, d);
     HIPCK(p, plba_d2h(p, T_out16, dTout.p, (size_t)16 * K * 8));
     HIPCK(p, plba_d2h(p, hXl.data(), dXl.p, nl * 8));
+    LbaCtl cend;
+    HIPCK(p, plba_d2h(p, &cend, dctl.p, sizeof cend));
+    if (ltime) fprintf(stderr, "[lba] passes + read-back %.3f ms (%d passes)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lt0).count(), cend.done ? cend.iters : opt->max_iters);
     HIPCK(p, hipGetLastError());
+    const int iters = cend.done ? cend.iters : opt->max_iters, updates = cend.updates;
+    const double err = cend.err, lambda = cend.lambda;
+    const bool failed = cend.failed != 0;
+    st->err_first = cend.err_first;
     // :1944-1970: a landmark that moved more than 1 cm is flagged (the reference clears its `inlier`)
     for (int i = 0; i < Np; ++i) {
         double n2 = 0.0;
