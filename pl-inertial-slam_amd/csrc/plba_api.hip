@@ -651,7 +651,7 @@ static int prepare(plba_problem* p) {
     // reference's real ones (12 keyframes, tracks longer than a group's window of 8, which do not fit anyway).  2: whenever the structure fits
     int lm_min_obs = 40000;
     if (const char* e = getenv("PLBA_LM_MIN_OBS")) lm_min_obs = atoi(e);
-    const bool lm_cand = p->opt.lm_fused != 0 && (p->opt.lm_fused >= 2 || E >= lm_min_obs) && !p->lm_disable && p->world == 1 && E > 0 && p->opt.chain_elim && p->opt.use_mfma
+    const bool lm_cand = p->opt.lm_fused != 0 && (p->opt.lm_fused >= 2 || E >= lm_min_obs) && !p->lm_disable && E > 0 && p->opt.chain_elim && p->opt.use_mfma
                          && p->opt.factor_block != 64 && lm_structure_fits(p, lm_start);
     // keyframe-major record positions (stable: landmark order inside a keyframe), in EREC_UNIT = 64-byte units: a point
     // record takes one unit, a line record two, packed back to back (plba_math.h)
@@ -1573,19 +1573,41 @@ static int lm_enqueue_first(plba_problem* p, int iteration) {
     HIPCK(p, hipMemsetAsync(d.bimu, 0, (size_t)d.ld * 8, s));
     HIPCK(p, hipMemsetAsync(d.kfdiag, 0, (size_t)d.K * 6 * 8, s));
     MARK(p, 0);
-    launch_pose_edges(d, p->cur, true, p->rob, true, s);
+    if (owns_pose_edges(p)) launch_pose_edges(d, p->cur, true, p->rob, true, s);
     launch_lm_schur(d, p->lv, p->cur, p->rob, true, nullptr, false, s);
     MARK(p, 2);
     launch_lm_gather(d, p->lv, true, false, false, s);
-    launch_lambda_init_n(d, lm_params(p), p->d_red.p, iteration, p->lv.ngrp, s);
+    if (p->world > 1) {      // chi2 (sum), max |Hll_jj| (max) and the pose diagonal (sum) become global before computeLambdaInit, as on the record-based path
+        int rc;
+        launch_reduce_n(d, owns_pose_edges(p), p->d_red.p, p->lv.ngrp, s);
+        launch_posediag(d, s);
+        if ((rc = exchange(p, p->d_red.p, 1, 0))) return rc;
+        if ((rc = exchange(p, p->d_red.p + 2, 1, 1))) return rc;
+        if ((rc = exchange(p, d.posediag, (size_t)d.P, 0))) return rc;
+        launch_lambda_init2(d, lm_params(p), p->d_red.p, true, iteration, false, false, s);
+    } else launch_lambda_init_n(d, lm_params(p), p->d_red.p, iteration, p->lv.ngrp, s);
     MARK(p, 3);
     return PLBA_OK;
 }
 static int lm_enqueue_system(plba_problem* p, const DevBuf& ds, int state, bool spec, bool mark = false) {
     hipStream_t s = p->stream;
-    launch_lm_schur(ds, p->lv, state, p->rob, false, &p->cv, spec, s);
+    const bool sharded = p->world > 1;
+    // one GPU: the chain elimination segments ride in front of the groups (they read the pose-side accumulators directly).  Sharded: the
+    // accumulators live on rank 0 alone, so the segments run on the all-reduced system, as a launch of their own behind the exchange
+    launch_lm_schur(ds, p->lv, state, p->rob, false, sharded ? nullptr : &p->cv, spec, s);
     if (mark) MARK(p, 5);      // profile = 2: [4, 5] = k_lm_schur alone (the pass over every observation), [5, 6] = gather + assembly
-    launch_lm_gather(ds, p->lv, false, true, spec, s);
+    launch_lm_gather(ds, p->lv, false, !sharded || owns_pose_edges(p), spec, s);      // lambda (and the unit padding) from one rank only
+    if (sharded) {
+        // only the entries that can be non-zero before the factorisation (pose x pose, IMU / prior blocks, diagonal) and the two rhs rows travel
+        const size_t npk = list_packed_size(ds);
+        if (p->d_xbuf.n < npk) HIPCK(p, p->d_xbuf.alloc(npk, false));
+        launch_list_pack(ds, p->d_xbuf.p, false, s);
+        int rc = exchange(p, p->d_xbuf.p, npk, 0);
+        if (rc) return rc;
+        launch_list_pack(ds, p->d_xbuf.p, true, s);
+        HIPCK(p, hipMemcpyAsync(ds.bpg, ds.sys + (size_t)(ds.Ppad + 1) * ds.ld, (size_t)ds.ld * 8, hipMemcpyDeviceToDevice, s));
+        launch_chain_elim(ds, p->cv, s);
+    }
     return PLBA_OK;
 }
 static int lm_enqueue_solve_and_trial(plba_problem* p) {
@@ -1652,14 +1674,25 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             if (jac_trial) { std::swap(ds.Himu, ds.Himu_alt); std::swap(ds.bimu, ds.bimu_alt); std::swap(ds.bprior, ds.bprior_alt); }
             DecideFusion df{lp, p->d_red.p, p->d_mail, seq};
             bool spec = false;
-            if (p->opt.profile >= 2) {
-                launch_lm_trial(ds, p->lv, p->cur, trial, jac_trial, p->rob, &p->cv, p->dd.x, (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1), nullptr, s);
+            const bool sharded = p->world > 1;
+            if (p->opt.profile >= 2 || sharded) {
+                launch_lm_trial(ds, p->lv, p->cur, trial, jac_trial, p->rob, &p->cv, p->dd.x, (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1), owns_pose_edges(p), nullptr, s);
                 MARK(p, 9);
-                launch_decide_n(d, lp, p->d_red.p, p->lv.ngrp, p->d_mail, seq, s);
+                if (sharded) {      // [chi2, landmark part of the scale] become global; every rank then takes the same decision
+                    launch_reduce_n(d, owns_pose_edges(p), p->d_red.p, p->lv.ngrp, s);
+                    if ((rc = exchange(p, p->d_red.p, 2, 0))) return rc;
+                    launch_decide(d, lp, p->d_red.p, false, p->d_mail, seq, s);
+                } else launch_decide_n(d, lp, p->d_red.p, p->lv.ngrp, p->d_mail, seq, s);
                 MARK(p, 10);
-                HIPCK(p, plba_stream_wait(s));
+                if (p->opt.profile >= 2) HIPCK(p, plba_stream_wait(s));
+                else {
+                    long spins = 0;
+                    while (__atomic_load_n(&p->h_mail->seq, __ATOMIC_ACQUIRE) != seq) {
+                        if (++spins > (1L << 22)) { HIPCK(p, plba_stream_wait(s)); break; }
+                    }
+                }
             } else {
-                launch_lm_trial(ds, p->lv, p->cur, trial, jac_trial, p->rob, &p->cv, p->dd.x, (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1), &df, s);      // the trial's IMU / prior edges (linearised into the idle accumulators) | landmark groups; + the decision
+                launch_lm_trial(ds, p->lv, p->cur, trial, jac_trial, p->rob, &p->cv, p->dd.x, (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1), true, &df, s);      // the trial's IMU / prior edges (linearised into the idle accumulators) | landmark groups; + the decision
                 if (jac_trial) { if ((rc = lm_enqueue_system(p, ds, trial, true))) return rc; spec = true; }      // gated on the device-side decision
                 long spins = 0;
                 while (__atomic_load_n(&p->h_mail->seq, __ATOMIC_ACQUIRE) != seq) {
@@ -2047,7 +2080,7 @@ int plba_debug_build(plba_problem* p, double lambda, int do_solve) {
         rc = lm_enqueue_system(p, d, p->cur, false);
         if (!rc && do_solve) {
             rc = lm_enqueue_solve_and_trial(p);
-            if (!rc) launch_lm_trial(d, p->lv, p->cur, p->cur ^ 1, false, p->rob, &p->cv, p->dd.x, (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1), nullptr, p->stream);      // (errors only: the accumulators keep the built system)
+            if (!rc) launch_lm_trial(d, p->lv, p->cur, p->cur ^ 1, false, p->rob, &p->cv, p->dd.x, (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1), true, nullptr, p->stream);      // (errors only: the accumulators keep the built system)
         }
         p->lv.dbg_out = 0; p->lv.ob_err = nullptr;
         if (rc) return rc;

@@ -210,7 +210,9 @@ void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused,
 // fused landmark-major passes (plba_lm_dev.h)
 void launch_lm_schur(const DevBuf& d, const LmView& lv, int state, const Robust& rb, bool diag_pass, const ChainView* lead /* chain segments riding in front, or null */, bool spec, hipStream_t s);
 void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool add_lambda, bool spec, hipStream_t s);
-void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, bool jac, const Robust& rb, const ChainView* lead, const double* xd, unsigned back_target, const DecideFusion* df, hipStream_t s);      // A: chain back-substitution | landmark groups | the trial's pose-side edges (+ the LM decision)
+void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, bool jac, const Robust& rb, const ChainView* lead, const double* xd, unsigned back_target, bool with_pose_edges, const DecideFusion* df, hipStream_t s);
+void launch_reduce_n(const DevBuf& d, bool owns_pose_edges, double* red, int nred, hipStream_t s);
+void launch_posediag(const DevBuf& d, hipStream_t s);      // A: chain back-substitution | landmark groups | the trial's pose-side edges (+ the LM decision)
 void launch_lm_level_sync(const DevBuf& d, const LmView& lv, hipStream_t s);
 void launch_lambda_init_n(const DevBuf& d, const LmParams& lp, double* red, int iteration, int nred, hipStream_t s);
 void launch_decide_n(const DevBuf& d, const LmParams& lp, double* red, int nred, Mailbox* mail, unsigned long long seq, hipStream_t s);

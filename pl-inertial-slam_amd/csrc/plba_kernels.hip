@@ -1605,13 +1605,21 @@ void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool ad
     if (nb + nasm == 0) return;
     hipLaunchKernelGGL(k_lm_gather, dim3(nasm + nb), dim3(256), 0, s, d, lv, nasm, add_lambda ? 1 : 0, spec ? 1 : 0, diag_pass ? 1 : 0);
 }
-void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, bool jac, const Robust& rb, const ChainView* lead, const double* xd, unsigned back_target, const DecideFusion* df, hipStream_t s) {
-    const int nlead = lead ? lead->nseg : 0, npose = d.M + (d.pr_nv > 0 ? 1 : 0);
+void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, bool jac, const Robust& rb, const ChainView* lead, const double* xd, unsigned back_target, bool with_pose_edges, const DecideFusion* df, hipStream_t s) {
+    const int nlead = lead ? lead->nseg : 0, npose = with_pose_edges ? d.M + (d.pr_nv > 0 ? 1 : 0) : 0;      // (a sharded run: rank 0 owns the pose-side edges)
     DecideArgs da{};
     if (df) { da.lp = df->lp; da.red = df->red; da.mail = df->mail; da.seq = df->seq; da.nblk_lm = lv.ngrp; da.fuse = 1; }
     const dim3 grid(nlead + lv.ngrp + npose);
     if (jac) hipLaunchKernelGGL(k_lm_trial<true>, grid, dim3(LMB), 0, s, d, lv, cur, trial, rb, lead ? *lead : ChainView{}, xd, nlead, npose, back_target, da);
     else hipLaunchKernelGGL(k_lm_trial<false>, grid, dim3(LMB), 0, s, d, lv, cur, trial, rb, lead ? *lead : ChainView{}, xd, nlead, npose, back_target, da);
+}
+// sharded runs of the fused passes: the local sums go out for the all-reduce instead of being consumed by the control kernel
+void launch_reduce_n(const DevBuf& d, bool owns_pose_edges, double* red, int nred, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, d, nred, nred, owns_pose_edges ? 1 : 0, red);
+}
+void launch_posediag(const DevBuf& d, hipStream_t s) {
+    hipLaunchKernelGGL(k_posediag, dim3((d.ld + 255) / 256), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_posediag_kf, dim3((d.K * 6 + 255) / 256), dim3(256), 0, s, d);
 }
 void launch_lambda_init_n(const DevBuf& d, const LmParams& lp, double* red, int iteration, int nred, hipStream_t s) {
     hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(256), 0, s, d, lp, red, 1, iteration, 1, 0, nred, nred);

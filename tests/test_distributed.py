@@ -24,7 +24,7 @@ WIN_SMALL = (8, 240, 50, 0xD157, 5, 10)          # K, points, lines, seed, stage
 WIN_K200 = (200, 6000, 1200, 0x5EED0005, 2, 2)    # the BASELINE configs[4] window shape (P = 2985) at a landmark count the oracle finishes
 
 
-def _worker(rank, world, port, use_hip, out, win=WIN_SMALL):
+def _worker(rank, world, port, use_hip, out, win=WIN_SMALL, opts=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -39,7 +39,7 @@ def _worker(rank, world, port, use_hip, out, win=WIN_SMALL):
         ws = pkg.window.shard_window(w, rank, world)
         if use_hip:
             torch.cuda.set_device(0)
-            p = pkg.new_problem()
+            p = pkg.new_problem(**(opts or {}))
             p.upload_window(ws)
             p.set_shard(rank, world, pkg.distributed.make_allreduce(dist, 0, None, via_host=True))
         else:
@@ -50,8 +50,9 @@ def _worker(rank, world, port, use_hip, out, win=WIN_SMALL):
         res = pkg.protocol.results(p)
         tr = p.trace()
         lo, hi = ws["shard"]["pt_range"]
+        fused = int(p.debug_get("lm_fused")[0]) if use_hip else 0
         out.put((rank, res["P"], res["V"], res["q"], res["dbg"], res["points"], (lo, hi), r["gated"], r["stage2"].chi2_final,
-                 [t["accepted"] for t in tr]))
+                 [t["accepted"] for t in tr], fused))
         p.close()
         dist.barrier()
         dist.destroy_process_group()
@@ -62,12 +63,12 @@ def _worker(rank, world, port, use_hip, out, win=WIN_SMALL):
         os._exit(1)
 
 
-def _run(world, use_hip, win=WIN_SMALL):
+def _run(world, use_hip, win=WIN_SMALL, opts=None):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, use_hip, q, win)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, use_hip, q, win, opts)) for r in range(world)]
     for p in procs:
         p.start()
     got = []
@@ -111,6 +112,17 @@ def test_sharded_oracle_world2_gloo(pkg, orc):
 @pytest.mark.gpu
 def test_sharded_hip_world2_gloo_host_staged(pkg, orc, hip):
     _check(_run(2, True), pkg, orc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("win", [WIN_SMALL, WIN_K200])
+def test_sharded_hip_world2_fused_landmark_passes(pkg, orc, hip, win):
+    """the fused landmark-major passes on two landmark shards (lm_fused = 2: these windows are below the default's 40 k observations):
+    groups of the local landmarks only, gather + structural all-reduce, chain elimination behind the exchange, the trial launch
+    without a riding decision, [chi2, scale] all-reduced — equal to the unsharded oracle, bit-identical across the ranks"""
+    got = _run(2, True, win, {"lm_fused": 2})
+    assert all(g[10] == 1 for g in got), "the fused passes were meant to run"
+    _check(got, pkg, orc, win)
 
 
 @pytest.mark.gpu
