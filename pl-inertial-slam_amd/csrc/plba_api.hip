@@ -607,6 +607,32 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     HostPool::get().start(NT, [pp, ls, ok, ow, Hp](int t) { lm_fill_groups(pp, *ls, *ok, *ow, *Hp, t); });
 }
 
+// Dependent launches the multi-chain factorisation needs for T tiles of 32 columns and a band of hbt sub-diagonal tiles: the same
+// arithmetic as the plan builder in prepare() (two chains; four chains; four chains with the separator region taken as a second
+// stage), without building anything — used to choose the chain elimination's segment length.
+static int twin_launch_estimate(int T, int hbt) {
+    if (T < 8 || hbt < 1) return T;
+    int best = T - 1;
+    for (int variant = 0; variant < 3; ++variant) {
+        const int nch = variant == 0 ? 2 : 4, nsep = nch - 1;
+        const bool nested = variant == 2;
+        const int nC = (T - nsep * hbt - nch / 2) / nch;
+        if (nC < 1) continue;
+        int left = T - nsep * hbt - nch / 2 - nch * nC;
+        int w[3] = {0, 0, 0};
+        for (int q = 0; q < nsep; ++q) { w[q] = hbt + (left > 0 ? 1 : 0); if (left > 0) --left; }
+        const int stage1 = nC + 1, m0 = nch * nC + nch / 2;
+        int launches;
+        if (nested) {
+            const int lenA = w[0], lenB = std::min(w[2], lenA - 1);
+            if (lenB < 1) continue;
+            launches = stage1 + lenA + (T - (m0 + w[0] + lenB) - 1);
+        } else launches = stage1 + (T - m0 - 1);
+        best = std::min(best, launches);
+    }
+    return best + 1;      // + the launch that ends the factorisation (k_chol32's last step)
+}
+
 static int prepare(plba_problem* p) {
     if (!p->dirty) return PLBA_OK;
     if (!p->have_cam || !p->K) FAIL(p, PLBA_ERR_STATE, "camera and keyframes must be set before optimize");
@@ -920,22 +946,39 @@ static int prepare(plba_problem* p) {
             return sep;
         };
         if (ok) {
-            // segment length: the dense factorisation costs ~9 us per 32-wide block step, a chain step ~2 us.  (What the number of DEPENDENT
-            // launches of the multi-chain plan does with the segment length is not monotonic — the band's width in tiles depends on how the
-            // segment windows fall on tile boundaries: tools/sweep_chain_seg.sh at configs[2]: 4 -> 375 dims, 7 launches; 6 -> 357, 6; 7 ->
-            // 348, 7; 8 -> 339, 6; and 8 there costs the trial launch 3 us of chain back-substitution for the 9 us the solve gains.  A model
-            // that followed the occupied tile count picked 7 and, at configs[4], 1410 dims / 17 launches instead of 1392 / 15: dropped.
-            // PLBA_CHAIN_SEG forces a length for measurements.)
+            // segment length.  Longer segments leave fewer separators dense — fewer tiles for the factorisation — but what counts is the number
+            // of DEPENDENT launches of the multi-chain plan, which is not monotonic in it: the band's width in tiles depends on where the
+            // segment windows fall on tile boundaries (configs[2]: 4 blocks -> 375 dims, 7 launches; 6 -> 357, 6; 7 -> 348, 7; 8 -> 339, 6).
+            // So every candidate gets its dense layout, its band and the plan builder's launch count (twin_launch_estimate), ~10.3 us per
+            // launch; a chain block costs the trial launch ~2.3 us of back-substitution in front of the IMU edge blocks where that path is
+            // the launch's critical one (small windows), nothing where the landmark pass is longer.  tools/ab_env.py, one process, medians,
+            // configs[2]: 4 -> 0.1720 ms per trial, 5 -> 0.1744, 6 -> 0.1672, 8 -> 0.1708: the order this cost gives.
             int best_seg = 1; double best_cost = 1e300;
+            const double block_cost = E > 300000 ? 0.1 : 2.3;
             for (int seg = 1; seg <= CHAIN_SEG; ++seg) {
                 const std::vector<char> sp = separators(seg);
-                int pd = 0;
+                std::vector<int> ds(npos + 1, 0);      // first dense column of each position
                 for (int q = 0; q < npos; ++q) {
-                    if (pos_pose[q] >= 0) pd += 6;
-                    if (sp[q]) for (int c = 0; c < 9; ++c) pd += pos_c[q][c] >= 0;
+                    int w = pos_pose[q] >= 0 ? 6 : 0;
+                    if (sp[q]) for (int c = 0; c < 9; ++c) w += pos_c[q][c] >= 0;
+                    ds[q + 1] = ds[q] + w;
                 }
-                const int steps = ((pd + TILE - 1) / TILE) * TILE / 32;
-                const double cost = 9.0 * steps + 2.0 * seg;
+                const int pd = ds[npos], T = ((pd + TILE - 1) / TILE) * TILE / 32;
+                int hb = 0;
+                auto span = [&](int qa, int qb) { if (ds[qb + 1] > ds[qa]) hb = std::max(hb, (ds[qb + 1] - 1) / 32 - ds[qa] / 32); };      // positions qa <= qb couple
+                for (int i = 0; i < K; ++i) for (int j2 = i; j2 < K; ++j2)
+                    if (cov[(size_t)i * K + j2] && pos_of_kf[i] >= 0 && pos_of_kf[j2] >= 0) span(std::min(pos_of_kf[i], pos_of_kf[j2]), std::max(pos_of_kf[i], pos_of_kf[j2]));
+                for (int q = 0, run0 = -1; q <= npos; ++q) {      // a segment's window: the positions around its run of eliminated blocks
+                    const bool el = q < npos && !sp[q];
+                    if (el && run0 < 0) run0 = q;
+                    if (!el && run0 >= 0) { span(std::max(run0 - 1, 0), std::min(q, npos - 1)); run0 = -1; }
+                }
+                for (int q = 0; q + 1 < npos; ++q) span(q, q + 1);      // IMU edges between neighbours
+                { int lo = npos, hi = -1; for (int q = 0; q < npos; ++q) if (forced[q]) { lo = std::min(lo, q); hi = std::max(hi, q); } if (hi >= 0) span(lo, hi); }      // the prior's kept vertices
+                const bool twin = p->opt.band_solve == 1 && T <= TWIN_MAX_TILES;
+                const int launches = twin ? twin_launch_estimate(T, hb) : T;
+                const double cost = 10.3 * launches + block_cost * seg;
+                if (ptime) fprintf(stderr, "[prepare]   chain segments of %d: %d dense dims, %d tiles, band %d -> %d launches (cost %.1f)\n", seg, pd, T, hb, launches, cost);
                 if (cost < best_cost) { best_cost = cost; best_seg = seg; }
             }
             if (const char* e = getenv("PLBA_CHAIN_SEG")) { const int v = atoi(e); if (v >= 1 && v <= CHAIN_SEG) best_seg = v; }      // (measurement knob)

@@ -1,0 +1,28 @@
+"""A/B timing of environment knobs in ONE process (same box, same clocks): python tools/ab_env.py 3 PLBA_CHAIN_SEG=4 PLBA_CHAIN_SEG=6 PLBA_CHAIN_SEG=8
+Each variant gets a fresh problem per round (the knobs are read in prepare()); rounds alternate; ms per LM trial of stage-2 iterations
+replayed from the saved post-gating state, best of 8 replays per round."""
+import os, sys, time
+sys.path.insert(0, '.')
+import __graft_entry__ as ge
+pkg = ge.load_package()
+cfg = int(sys.argv[1])
+variants = [dict(kv.split("=") for kv in a.split(",") if kv) if a != "-" else {} for a in sys.argv[2:]]
+w = pkg.window.make_config(cfg)
+res = {i: [] for i in range(len(variants))}
+for rnd in range(5):
+    for i, v in enumerate(variants):
+        for k in list(os.environ):
+            if k.startswith("PLBA_") and k not in ("PLBA_EXTRA_FLAGS",): del os.environ[k]
+        os.environ.update(v)
+        g = pkg.new_problem(); g.upload_window(w)
+        g.optimize(5); g.gate_outliers(); g.save_state()
+        best = 1e9
+        for rep in range(8):
+            g.restore_state()
+            t0 = time.perf_counter(); s = g.optimize(10); dt = time.perf_counter() - t0
+            best = min(best, dt / max(s.trials, 1))
+        res[i].append(best * 1e3)
+        g.close()
+for i, v in enumerate(variants):
+    r = sorted(res[i])
+    print("%-40s median %.4f  min %.4f  max %.4f ms per trial" % (v or "(default)", r[len(r) // 2], r[0], r[-1]))
