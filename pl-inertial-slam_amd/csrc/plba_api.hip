@@ -487,18 +487,28 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     const bool gt = getenv("PLBA_PREP_TIMING") != nullptr;
     auto g0 = std::chrono::steady_clock::now();
     auto glap = [&](const char* what) { if (!gt) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[prepare]   groups: %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - g0).count()); g0 = t; };
-    // group size: a workgroup step takes 32 points or 16 lines.  Two workgroups share a CU (registers), so `slots` of them run at once and
-    // the launch takes R rounds of groups: the smallest R whose groups stay within 16 steps, the groups sized to fill the R rounds
-    // (configs[4]: 8750 workgroup-steps; 8 steps gave 1095 groups = 2.14 rounds, i.e. three — 9 steps give 973, two rounds, 25 % less)
+    // group size: a workgroup step takes 32 points or 16 lines.
+    // Large windows: two workgroups share a CU (registers), so `slots` of them run at once and the launch takes R rounds of groups: the
+    // smallest R whose groups stay within 16 steps, the groups sized to fill the R rounds (configs[4]: 8750 workgroup-steps; 8 steps gave
+    // 1095 groups = 2.14 rounds, i.e. three — 9 steps give 973, two rounds, 25 % less).
+    // Windows that fit ONE round: about one group per CU instead of two — the launch's other workgroups (chain segments, IMU edge blocks:
+    // the trial launch's critical path at this size) then do not share their SIMDs with a group.  tools/ab_env.py, configs[2] (1125
+    // workgroup-steps incl. lines at 16 per step: 876), ms per LM trial: 2 steps 0.1722, 3 (292 groups) 0.1694, 4 (220 groups + 50 IMU edge
+    // blocks + 10 chain segments on 256 CUs) 0.1561, 5 0.1585, 6 0.1611; configs[1]: 1 step 0.1200, 2 (219 groups) 0.1143, 3 0.1181.
     int steps = 1;
     {
-        static int slots = 0;
-        if (!slots) { int dev = 0, cus = 256; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256; slots = 2 * std::max(cus, 1); }
+        static int cus = 0;
+        if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256; }
+        const int slots = 2 * cus;
         const long wg_steps = (Np + 31) / 32 + (Nl + 15) / 16;
-        for (int R = 1; R <= 64; ++R) {
-            const long cap = (long)(0.97 * R * slots);
-            steps = (int)std::max<long>(1, (wg_steps + cap - 1) / cap);
-            if (steps <= 16) break;
+        const long cap1 = std::max<long>(32, (long)(1.12 * cus) - (p->M + 1) - (p->M / 4 + 1));      // one group per CU, with room for the IMU edge blocks and the chain segments
+        steps = (int)std::max<long>(1, (wg_steps + cap1 - 1) / cap1);
+        if (steps > 16) {
+            for (int R = 1; R <= 64; ++R) {
+                const long cap = (long)(0.97 * R * slots);
+                steps = (int)std::max<long>(1, (wg_steps + cap - 1) / cap);
+                if (steps <= 16) break;
+            }
         }
         steps = std::min(steps, 16);
         if (const char* e = getenv("PLBA_LM_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= 16) steps = v; }
