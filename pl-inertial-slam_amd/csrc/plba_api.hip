@@ -1626,11 +1626,10 @@ static int lm_enqueue_first(plba_problem* p, int iteration) {
     HIPCK(p, hipMemsetAsync(d.bimu, 0, (size_t)d.ld * 8, s));
     HIPCK(p, hipMemsetAsync(d.kfdiag, 0, (size_t)d.K * 6 * 8, s));
     MARK(p, 0);
-    if (owns_pose_edges(p)) launch_pose_edges(d, p->cur, true, p->rob, true, s);
-    launch_lm_schur(d, p->lv, p->cur, p->rob, true, nullptr, false, s);
+    launch_lm_schur(d, p->lv, p->cur, p->rob, true, nullptr, false, s, owns_pose_edges(p));      // (+ the pose-side edges, behind the groups)
     MARK(p, 2);
-    launch_lm_gather(d, p->lv, true, false, false, s);
-    if (p->world > 1) {      // chi2 (sum), max |Hll_jj| (max) and the pose diagonal (sum) become global before computeLambdaInit, as on the record-based path
+    if (p->world > 1) {
+        launch_lm_gather(d, p->lv, true, false, false, s);      // chi2 (sum), max |Hll_jj| (max) and the pose diagonal (sum) become global before computeLambdaInit, as on the record-based path
         int rc;
         launch_reduce_n(d, owns_pose_edges(p), p->d_red.p, p->lv.ngrp, s);
         launch_posediag(d, s);
@@ -1638,7 +1637,7 @@ static int lm_enqueue_first(plba_problem* p, int iteration) {
         if ((rc = exchange(p, p->d_red.p + 2, 1, 1))) return rc;
         if ((rc = exchange(p, d.posediag, (size_t)d.P, 0))) return rc;
         launch_lambda_init2(d, lm_params(p), p->d_red.p, true, iteration, false, false, s);
-    } else launch_lambda_init_n(d, lm_params(p), p->d_red.p, iteration, p->lv.ngrp, s);
+    } else launch_lambda_init_n(d, p->lv, lm_params(p), p->d_red.p, iteration, p->lv.ngrp, s);      // (+ the diagonal gather)
     MARK(p, 3);
     return PLBA_OK;
 }
@@ -1689,12 +1688,8 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
     hipStream_t s = p->stream;
     plba_stats st;
     memset(&st, 0, sizeof st);
-    Ctrl c0;
-    memset(&c0, 0, sizeof c0);
-    c0.solver_ok = 1; c0.ni = 2.0;
-    HIPCK(p, plba_h2d(p, d.ctrl, &c0, sizeof c0));
-    HIPCK(p, hipMemsetAsync(d.trace_n, 0, sizeof(int), s));
-    HIPCK(p, plba_stream_wait(s));   // c0 lives on the stack
+    launch_ctrl_reset(d, s);      // (a kernel, not an upload + wait: the call starts without a synchronisation)
+    p->trace.clear();
     const LmParams lp = lm_params(p);
     bool ok = true;
     double last_chi = 0.0, lambda = 0.0;
@@ -1754,6 +1749,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             }
             if (__atomic_load_n(&p->h_mail->seq, __ATOMIC_ACQUIRE) != seq) FAIL(p, PLBA_ERR_DEVICE, "LM control block was not delivered by the device");
             *p->h_ctrl = p->h_mail->c;
+            if ((int)p->trace.size() < TRACE_CAP) p->trace.push_back(p->h_mail->row);      // the trace is kept from the mailbox: no read-back at the end of the call
             if (p->h_ctrl->sync_fail) FAIL(p, PLBA_ERR_DEVICE, "k_lm_trial: the pose-side blocks waited for the chain back-substitution beyond their bound");
             if (p->opt.profile >= 2) st.ms_phase[1] += span(11, 12);
             else if (p->opt.profile == 1 && p->ev_sample) { fact_sampled_ms += span(11, 12); ++fact_samples; }
@@ -1848,6 +1844,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             }
             if (__atomic_load_n(&p->h_mail->seq, __ATOMIC_ACQUIRE) != seq) FAIL(p, PLBA_ERR_DEVICE, "LM control block was not delivered by the device");
             *p->h_ctrl = p->h_mail->c;
+            if ((int)p->trace.size() < TRACE_CAP) p->trace.push_back(p->h_mail->row);      // the trace is kept from the mailbox: no read-back at the end of the call
             if (p->opt.profile >= 2) st.ms_phase[1] += span(11, 12);
             else if (p->opt.profile == 1 && p->ev_sample) { fact_sampled_ms += span(11, 12); ++fact_samples; }
             if (p->opt.profile >= 2) {
@@ -1880,16 +1877,11 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
     if (p->opt.profile == 1 && fact_samples > 0) st.ms_phase[1] = fact_sampled_ms / fact_samples * st.trials;      // sampled trials scaled to all
     if (abort_flag && *abort_flag && st.stop_reason == 0 && st.iterations < max_iters) st.stop_reason = 2;
     // trace + stats
-    int ntr = 0;
-    HIPCK(p, plba_d2h(p, &ntr, d.trace_n, sizeof(int)));
-    ntr = std::min(ntr, TRACE_CAP);
-    p->trace.resize(ntr);
-    if (ntr) HIPCK(p, plba_d2h(p, p->trace.data(), d.trace, sizeof(plba_trace_row) * ntr));
-    if (ntr) {
+    const int ntr = (int)p->trace.size();
+    if (ntr) {      // (trace rows and the final control block arrived through the mailbox, trial by trial)
         st.chi2_initial = p->trace[0].chi2_current;
         st.chi2_final = p->trace[0].chi2_current;
         for (const auto& r : p->trace) if (r.accepted) st.chi2_final = r.chi2_trial;
-        HIPCK(p, plba_d2h(p, p->h_ctrl, d.ctrl, sizeof(Ctrl)));
         st.solver_failures = p->h_ctrl->n_fail;
         st.lambda_final = p->h_ctrl->lambda;
     } else {

@@ -56,6 +56,7 @@ struct Ctrl {
 struct Mailbox {
     Ctrl c;
     unsigned long long seq;
+    plba_trace_row row;      // the trial's trace row (also appended to the device-side trace): the host keeps the trace from here, no read-back at the end of a call
 };
 
 // one chunk (<= 256 entries) of a keyframe pair's entry list: everything k_schur_pairs needs to know up front, 32 bytes
@@ -207,14 +208,15 @@ void launch_list_pack(const DevBuf& d, double* buf, bool unpack, hipStream_t s);
 void launch_tri_pack(const DevBuf& d, double* buf, bool unpack, hipStream_t s);
 void launch_lambda_init2(const DevBuf& d, const LmParams& lp, double* red, bool first_iter, int iteration, bool fused, bool keep_chi, hipStream_t s);
 void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, Mailbox* mail, unsigned long long seq, hipStream_t s);
+void launch_ctrl_reset(const DevBuf& d, hipStream_t s);      // control block and trace counter of a fresh plba_optimize call
 // fused landmark-major passes (plba_lm_dev.h)
-void launch_lm_schur(const DevBuf& d, const LmView& lv, int state, const Robust& rb, bool diag_pass, const ChainView* lead /* chain segments riding in front, or null */, bool spec, hipStream_t s);
+void launch_lm_schur(const DevBuf& d, const LmView& lv, int state, const Robust& rb, bool diag_pass, const ChainView* lead /* chain segments riding in front, or null */, bool spec, hipStream_t s, bool with_pose_edges = false);
 void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool add_lambda, bool spec, hipStream_t s);
 void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, bool jac, const Robust& rb, const ChainView* lead, const double* xd, unsigned back_target, bool with_pose_edges, const DecideFusion* df, hipStream_t s);
 void launch_reduce_n(const DevBuf& d, bool owns_pose_edges, double* red, int nred, hipStream_t s);
 void launch_posediag(const DevBuf& d, hipStream_t s);      // A: chain back-substitution | landmark groups | the trial's pose-side edges (+ the LM decision)
 void launch_lm_level_sync(const DevBuf& d, const LmView& lv, hipStream_t s);
-void launch_lambda_init_n(const DevBuf& d, const LmParams& lp, double* red, int iteration, int nred, hipStream_t s);
+void launch_lambda_init_n(const DevBuf& d, const LmView& lv, const LmParams& lp, double* red, int iteration, int nred, hipStream_t s);
 void launch_decide_n(const DevBuf& d, const LmParams& lp, double* red, int nred, Mailbox* mail, unsigned long long seq, hipStream_t s);
 void launch_gate(const DevBuf& d, int state, double thresh, hipStream_t s);
 void launch_cull(const DevBuf& d, int state, double thresh, uint8_t* bad, hipStream_t s);   // per-observation culling flags

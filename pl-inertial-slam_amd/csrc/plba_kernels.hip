@@ -1426,12 +1426,11 @@ DEV void decide_body(const DevBuf& d, const LmParams& lp, double* red, int fused
     scale += 1e-3;
     const double rho = (c->current_chi - tempChi) / scale;
     const int n = *d.trace_n;
-    if (n < d.trace_cap) {
-        plba_trace_row* tr = d.trace + n;
-        tr->iteration = c->iteration; tr->trial = c->trial; tr->solver_ok = c->solver_ok;
-        tr->lambda = lambda; tr->chi2_current = c->current_chi; tr->chi2_trial = tempChi; tr->scale = scale; tr->rho = rho;
-        tr->accepted = (rho > 0 && isfinite(tempChi)) ? 1 : 0;
-    }
+    plba_trace_row row;
+    row.iteration = c->iteration; row.trial = c->trial; row.solver_ok = c->solver_ok;
+    row.lambda = lambda; row.chi2_current = c->current_chi; row.chi2_trial = tempChi; row.scale = scale; row.rho = rho;
+    row.accepted = (rho > 0 && isfinite(tempChi)) ? 1 : 0;
+    if (n < d.trace_cap) d.trace[n] = row;
     *d.trace_n = n + 1;
     c->temp_chi = tempChi; c->scale = scale; c->rho = rho;
     if (rho > 0 && isfinite(tempChi)) {
@@ -1454,6 +1453,7 @@ DEV void decide_body(const DevBuf& d, const LmParams& lp, double* red, int fused
     c->solver_ok = 1;
     if (mail) {     // hand the decision to the host: payload, system-scope fence, then the sequence number it polls
         mail->c = *c;
+        mail->row = row;
         mail->c.sync_fail = __hip_atomic_load(&c->sync_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (possibly set by another workgroup of this launch)
         __threadfence_system();
         __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1534,6 +1534,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int b = blockIdx.x;
     if (MODE == 0 && b < nlead) { chain_elim_segment<true>(d, cv, b, *reinterpret_cast<ChainElimLds*>(s_dyn_lm)); return; }
     b -= nlead;
+    if (MODE == 1 && b >= lv.ngrp) {      // first iteration of a call: the pose-side edges (with Jacobians) ride behind the groups instead of in a launch of their own
+        const int m = b - lv.ngrp;
+        if (m < d.M) pose_edge_block<true, 256>(d, state, rb, m, threadIdx.x);
+        else prior_block<true>(d, state);
+        return;
+    }
     LmAcc& A4 = *reinterpret_cast<LmAcc*>(s_dyn_lm);
     if (lv.grp[b].is_line) lm_schur_group<true, MODE>(d, lv, b, state, rb, S, A4);
     else lm_schur_group<false, MODE>(d, lv, b, state, rb, S, A4);
@@ -1583,11 +1589,12 @@ __global__ __launch_bounds__(LMB) void k_lm_trial(DevBuf d, LmView lv, int cur, 
 // -------------------------------------------------------------------------------------------------
 // launchers
 // -------------------------------------------------------------------------------------------------
-void launch_lm_schur(const DevBuf& d, const LmView& lv, int state, const Robust& rb, bool diag_pass, const ChainView* lead, bool spec, hipStream_t s) {
+void launch_lm_schur(const DevBuf& d, const LmView& lv, int state, const Robust& rb, bool diag_pass, const ChainView* lead, bool spec, hipStream_t s, bool with_pose_edges) {
     const size_t sh = sizeof(LmAcc) > sizeof(ChainElimLds) ? sizeof(LmAcc) : sizeof(ChainElimLds);      // a chain segment's staging shares the dynamic LDS
     if (diag_pass) {
         if (ensure_dyn_lds(reinterpret_cast<const void*>(k_lm_schur<1>), (int)sh) != hipSuccess) return;      // surfaces at the caller's hipGetLastError
-        hipLaunchKernelGGL(k_lm_schur<1>, dim3(lv.ngrp), dim3(256), sh, s, d, lv, state, rb, ChainView{}, 0, 0);
+        const int npose = with_pose_edges ? d.M + (d.pr_nv > 0 ? 1 : 0) : 0;
+        hipLaunchKernelGGL(k_lm_schur<1>, dim3(lv.ngrp + npose), dim3(256), sh, s, d, lv, state, rb, ChainView{}, 0, 0);
         return;
     }
     if (ensure_dyn_lds(reinterpret_cast<const void*>(k_lm_schur<0>), (int)sh) != hipSuccess) return;
@@ -1621,8 +1628,41 @@ void launch_posediag(const DevBuf& d, hipStream_t s) {
     hipLaunchKernelGGL(k_posediag, dim3((d.ld + 255) / 256), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_posediag_kf, dim3((d.K * 6 + 255) / 256), dim3(256), 0, s, d);
 }
-void launch_lambda_init_n(const DevBuf& d, const LmParams& lp, double* red, int iteration, int nred, hipStream_t s) {
-    hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(256), 0, s, d, lp, red, 1, iteration, 1, 0, nred, nred);
+// first iteration of a call on the fused path, one GPU: what k_lm_gather's diagonal pass + k_lambda_init did in two launches — the groups'
+// diagonal parts summed per keyframe (fixed order), the pose diagonal, chi2, computeLambdaInit
+__global__ __launch_bounds__(256) void k_lm_lambda_init(DevBuf d, LmView lv, LmParams lp, double* red, int iteration, int nred) {
+    __shared__ double s4[4];
+    reduce_inline(d, nred, nred, red, s4);
+    for (int r = threadIdx.x; r < d.ld; r += 256) d.posediag[r] = (r < d.P) ? d.Himu[(size_t)r * d.ld + r] + d.Hconst[(size_t)r * d.ld + r] : 0.0;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < lv.nrow * 6; idx += 256) {
+        const int k = idx / 6, c = idx - 6 * k;
+        double v = 0.0;
+        for (int q = lv.row_start[k]; q < lv.row_start[k + 1]; ++q) {
+            const int src = lv.row_src[q];
+            v += lv.part[(size_t)(src / LMF_W) * LMF_PART + 36 * 36 + (src % LMF_W) * 12 + c];
+        }
+        const int kf = lv.row_kf[k], o = d.kf_off_pvr[kf];
+        d.kfdiag[kf * 6 + c] = v;
+        if (o >= 0) d.posediag[o + pmap(c)] += v;
+    }
+    __syncthreads();
+    double md = 0.0;
+    for (int r = threadIdx.x; r < d.P; r += 256) md = fmax(md, fabs(d.posediag[r]));
+    double mx = block_max_256(md, s4);
+    if (threadIdx.x == 0) {
+        Ctrl* c = d.ctrl;
+        c->current_chi = red[0];
+        c->iteration = iteration;
+        c->trial = 0;
+        mx = fmax(mx, red[2]);
+        c->maxdiag = mx;
+        c->lambda = lp.user_lambda > 0 ? lp.user_lambda : lp.tau * mx;
+        c->ni = 2.0;
+    }
+}
+void launch_lambda_init_n(const DevBuf& d, const LmView& lv, const LmParams& lp, double* red, int iteration, int nred, hipStream_t s) {
+    hipLaunchKernelGGL(k_lm_lambda_init, dim3(1), dim3(256), 0, s, d, lv, lp, red, iteration, nred);
 }
 __global__ __launch_bounds__(256) void k_lm_level_sync(DevBuf d, LmView lv) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -1738,6 +1778,13 @@ void launch_reduce(const DevBuf& d, bool owns_pose_edges, double* red, hipStream
 void launch_lambda_init2(const DevBuf& d, const LmParams& lp, double* red, bool first_iter, int iteration, bool fused, bool keep_chi, hipStream_t s) {
     hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(256), 0, s, d, lp, red, first_iter ? 1 : 0, iteration, fused ? 1 : 0, keep_chi ? 1 : 0, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0);
 }
+__global__ void k_ctrl_reset(Ctrl* c, int* trace_n) {
+    Ctrl z;
+    memset(&z, 0, sizeof z);
+    z.solver_ok = 1; z.ni = 2.0;
+    *c = z; *trace_n = 0;
+}
+void launch_ctrl_reset(const DevBuf& d, hipStream_t s) { hipLaunchKernelGGL(k_ctrl_reset, dim3(1), dim3(1), 0, s, d.ctrl, d.trace_n); }
 void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused, Mailbox* mail, unsigned long long seq, hipStream_t s) {
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, s, d, lp, red, fused ? 1 : 0, d.E ? edge_blocks(d) : 0, d.L ? lm_blocks(d) : 0, mail, seq);
 }

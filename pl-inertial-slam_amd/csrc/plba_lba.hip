@@ -18,6 +18,7 @@
 #include "plba_internal.h"
 #include "plba_problem.h"
 #include <chrono>
+#include <cstddef>
 
 #define HIPCK(p, call) PLBA_HIPCK(p, call)
 #define FAIL(p, code, ...) PLBA_FAIL(p, code, __VA_ARGS__)
@@ -39,8 +40,9 @@ struct LbaMail {       // laid over the problem's mapped Mailbox (plba_internal.
     LbaCtl c;
     char pad[sizeof(Ctrl) - sizeof(LbaCtl)];
     unsigned long long seq;
+    char pad2[sizeof(Mailbox) - sizeof(Ctrl) - sizeof(unsigned long long)];
 };
-static_assert(sizeof(LbaCtl) <= sizeof(Ctrl) && sizeof(LbaMail) == sizeof(Mailbox), "the LBA mailbox reuses the problem's mapped mailbox");
+static_assert(sizeof(LbaCtl) <= sizeof(Ctrl) && sizeof(LbaMail) == sizeof(Mailbox) && offsetof(LbaMail, seq) == offsetof(Mailbox, seq), "the LBA mailbox reuses the problem's mapped mailbox");
 struct LbaDev {
     int K, Nkf, Np, Nl, Ep, El, P, Ppad, ld;
     double fx, fy, cx, cy, homog_th;
