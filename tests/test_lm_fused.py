@@ -116,3 +116,13 @@ def test_default_takes_the_fused_passes_from_40k_observations(pkg, hip):
     big = pkg.new_problem(); big.upload_window(pkg.window.make_config(2)); big.optimize(1)      # BASELINE configs[1]: 52 k observations
     assert big.debug_get("lm_fused")[0] == 1
     big.close()
+
+
+def test_random_window_shapes_against_the_oracle():
+    """tools/soak_fused.py, 24 random windows (keyframe counts 3..70, track mixes, points / lines only, IMU or not, priors, fixed keyframes
+    and landmarks, gating between two calls, large and small initial damping) with lm_fused = 2 against the oracle, in a process of its
+    own.  (200 cases of seed 31: all agree; the tool's header says what is compared.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_fused.py"), "24", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
