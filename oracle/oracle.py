@@ -87,6 +87,22 @@ def new_fast_problem(threads=None, **opts):
     return _abi().Problem(_fast, **opts)
 
 
+QUAD_LIB_PATH = os.path.join(_HERE, "_build", "libplba_oracle_quad.so")
+_quad = None
+
+
+def new_quad_problem(**opts):
+    """The arbiter of ill-conditioned cases: the same source in __float128 (oracle/make_quad.py builds it; real-double entry points
+    orcq_* for upload_window / optimize / gate_outliers / the getters only).  Container only: tests use the fixtures it generated."""
+    global _quad
+    if _quad is None:
+        src = os.path.join(_HERE, "plba_oracle.c")
+        if not os.path.exists(QUAD_LIB_PATH) or os.path.getmtime(QUAD_LIB_PATH) < os.path.getmtime(src):
+            subprocess.run([sys.executable, os.path.join(_HERE, "make_quad.py")], check=True)
+        _quad = _abi().Lib(QUAD_LIB_PATH, "orcq_", optional=True)
+    return _abi().Problem(_quad, **opts)
+
+
 def _d(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
 

@@ -141,7 +141,7 @@ def _u8(a):
 class Lib:
     """A loaded implementation of plba.h (``prefix`` selects plba_* or orc_*)."""
 
-    def __init__(self, path, prefix):
+    def __init__(self, path, prefix, optional=False):
         self.path = str(path)
         self.prefix = prefix
         self.cdll = C.CDLL(self.path)
@@ -157,7 +157,7 @@ class Lib:
             f.restype = res
             f.argtypes = args
             self.fn[name] = f
-        if missing:
+        if missing and not optional:      # (optional: a library that implements a subset — the quad-precision oracle build, oracle/make_quad.py)
             raise PlbaError("%s does not export: %s" % (self.path, ", ".join(missing)))
 
     def backend_name(self):

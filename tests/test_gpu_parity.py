@@ -331,21 +331,19 @@ def test_rejected_trials_with_imu_edges(pkg, orc, hip):
     g1.close(); g0.close()
 
 
-def _overshoot_window(pkg, seed, rot=0.6, vel=20.0, pts=0.1, K=10, Np=150, Nl=30):
-    """an IMU window started so far from the optimum that damped Gauss-Newton steps overshoot and get rejected: rotations off
-    by `rot` rad, velocities by `vel` m/s, points by `pts` m (small: a point pushed through the camera plane makes the Schur
-    complement cancel catastrophically, and then NO two fp64 solvers agree)"""
-    W = pkg.window
-    w = W.make_window(K, Np, Nl, imu=True, seed=seed)
-    rng = np.random.default_rng(seed)
-    kf = w["kf"]
-    q = kf["q"].copy()
-    for k in range(1, K):
-        q[k] = W.quat_from_R(W.R_from_quat(q[k]) @ W.exp_so3(rng.normal(size=3) * rot))
-    kf["q"] = q
-    kf["V"] = kf["V"] + np.vstack([np.zeros((1, 3)), rng.normal(size=(K - 1, 3)) * vel])
-    w["points"] = w["points"] + rng.normal(size=w["points"].shape) * pts
-    return w
+def _overshoot_window(pkg, seed, **kw):
+    import os, sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if here not in sys.path: sys.path.insert(0, here)
+    import overshoot_cases
+    return overshoot_cases.overshoot_window(pkg, seed, **kw)
+
+
+def _overshoot_quad(name):
+    """tests/golden/overshoot_quad.json: the window run through the quad-precision build of the oracle (make_overshoot_quad.py)"""
+    import json, os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "overshoot_quad.json")))[name]
+    return {k: np.asarray(v) for k, v in d["kf"].items()}, d
 
 
 def _trace_key(tr):
@@ -383,6 +381,15 @@ def test_rejected_trials_against_the_oracle_on_an_overshooting_imu_window(pkg, o
     d_hip = max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg))
     print("overshoot window: |HIP - oracle| = %.2e, |oracle(inputs + 4 ulp) - oracle| = %.2e" % (d_hip, d_self))
     assert d_hip < max(4.0 * d_self, 1e-9) and d_hip < 5e-5, (d_hip, d_self)
+    # ... and against the QUAD-precision run of the same algorithm (tests/golden/overshoot_quad.json, generated by the
+    # __float128 build of the oracle): the HIP path may be no further from it than 4 x the fp64 oracle is — both are fp64 solvers whose
+    # rounding this trajectory amplifies by ~1e11 — and takes the quad run's decisions
+    kq, fq = _overshoot_quad("seed81")
+    d_hip_q = max(_pose_delta(g.get_keyframes(), kq, pkg))
+    d_orc_q = max(_pose_delta(o.get_keyframes(), kq, pkg))
+    print("                  |HIP - quad| = %.2e, |oracle64 - quad| = %.2e" % (d_hip_q, d_orc_q))
+    assert d_hip_q <= 4.0 * d_orc_q + 1e-9, (d_hip_q, d_orc_q)
+    assert [(r["iteration"], r["trial"], r["accepted"]) for r in tg] == [(r["iteration"], r["trial"], r["accepted"]) for r in fq["trace"]]
     g.close(); o.close(); o2.close()
 
 
