@@ -22,6 +22,18 @@ def _free_port():
 
 WIN_SMALL = (8, 240, 50, 0xD157, 5, 10)          # K, points, lines, seed, stage-1 / stage-2 iterations
 WIN_K200 = (200, 6000, 1200, 0x5EED0005, 2, 2)    # the BASELINE configs[4] window shape (P = 2985) at a landmark count the oracle finishes
+WIN_PRIOR = (12, 360, 80, 0xD158, 5, 10, True)      # ... with the marginalization prior of a previous slide (rank 0 owns it; forced separators in the chain)
+WIN_K200_PRIOR = (200, 6000, 1200, 0x5EED0006, 2, 2, True)      # configs[4] in its stated form: 200 keyframes + prior, sharded
+
+
+def _window(pkg, orc, win):
+    """the (unsharded) window of a case; with a prior: the one the ORACLE's marginalization of the same window's first BA leaves —
+    deterministic, so every rank and the reference derive the same"""
+    w = pkg.window.make_window(win[0], win[1], win[2], imu=True, seed=win[3])
+    if len(win) > 6 and win[6]:
+        o = orc.new_problem(); o.upload_window(w); pkg.protocol.local_ba(o, stage1=2, stage2=2); pr = o.marginalize(0, 50); o.close()
+        w = pkg.window.make_window(win[0], win[1], win[2], imu=True, seed=win[3]); w["prior"] = pr
+    return w
 
 
 def _worker(rank, world, port, use_hip, out, win=WIN_SMALL, opts=None):
@@ -35,7 +47,7 @@ def _worker(rank, world, port, use_hip, out, win=WIN_SMALL, opts=None):
     pkg = ge.load_package()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        w = pkg.window.make_window(win[0], win[1], win[2], imu=True, seed=win[3])
+        w = _window(pkg, orc, win)
         ws = pkg.window.shard_window(w, rank, world)
         if use_hip:
             torch.cuda.set_device(0)
@@ -88,7 +100,7 @@ def _run(world, use_hip, win=WIN_SMALL, opts=None):
 
 
 def _check(got, pkg, orc, win=WIN_SMALL):
-    w = pkg.window.make_window(win[0], win[1], win[2], imu=True, seed=win[3])
+    w = _window(pkg, orc, win)
     ref = orc.new_problem(); ref.upload_window(w)
     rr = pkg.protocol.local_ba(ref, stage1=win[4], stage2=win[5])
     res = pkg.protocol.results(ref)
@@ -109,6 +121,11 @@ def test_sharded_oracle_world2_gloo(pkg, orc):
     _check(_run(2, False), pkg, orc)
 
 
+def test_sharded_oracle_world2_gloo_with_prior(pkg, orc):
+    """the oracle's own sharded mode with a marginalization prior (owned by rank 0) == its unsharded solve"""
+    _check(_run(2, False, WIN_PRIOR), pkg, orc, WIN_PRIOR)
+
+
 @pytest.mark.gpu
 def test_sharded_hip_world2_gloo_host_staged(pkg, orc, hip):
     _check(_run(2, True), pkg, orc)
@@ -122,6 +139,17 @@ def test_sharded_hip_world2_fused_landmark_passes(pkg, orc, hip, win):
     without a riding decision, [chi2, scale] all-reduced — equal to the unsharded oracle, bit-identical across the ranks"""
     got = _run(2, True, win, {"lm_fused": 2})
     assert all(g[10] == 1 for g in got), "the fused passes were meant to run"
+    _check(got, pkg, orc, win)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("win,opts", [(WIN_PRIOR, None), (WIN_PRIOR, {"lm_fused": 2}), (WIN_K200_PRIOR, {"lm_fused": 2})])
+def test_sharded_hip_world2_with_marginalization_prior(pkg, orc, hip, win, opts):
+    """BASELINE configs[4] in its stated form is a SHARDED window WITH the prior of the previous slide: rank 0 owns the prior edge and its
+    constant Hessian block, the chain elimination keeps the prior's keyframes as separators, the structural exchange list carries the
+    prior block — record-based passes and fused passes, small window and the 200-keyframe one, against the unsharded oracle"""
+    got = _run(2, True, win, opts)
+    if opts: assert all(g[10] == 1 for g in got)
     _check(got, pkg, orc, win)
 
 
