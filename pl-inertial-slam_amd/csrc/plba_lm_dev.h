@@ -7,7 +7,7 @@
 //
 //   k_lm_schur  (K1-K2 + K5 + K6: computeError / linearizeOplus of the point and line edges, constructQuadraticForm, the landmark
 //               side of BlockSolver::solve; IMU/g2otypes.cpp:286-341, 1306-1359)
-//               per landmark (8 lanes, one per observation): residuals, Jacobian rows, Huber weight; Hll, bl by a fixed-order DPP
+//               per landmark (8 lanes, one per window keyframe): residuals, Jacobian rows, Huber weight; Hll, bl by a fixed-order DPP
 //               reduction over the 8 lanes; (Hll + lambda I) = R R^T; A'_e = Hpl_e R^-T (6 x 3).  The landmark's whole contribution to
 //               the reduced camera system is then  sum_e Hpp_e - A' A'^T  over its window of keyframes — a rank-3 update of a
 //               48 x 48 matrix per landmark, accumulated over the landmarks of a GROUP (<= 8 keyframes in its window, built at
@@ -20,8 +20,10 @@
 //
 // Layout of a workgroup: 4 waves x 8 "units" x 8 lanes.  A unit is one 3-dim landmark block: a point (two residual rows per
 // observation) or one END POINT of a line (one row per observation; a line is two neighbouring units — its Hll is exactly
-// block-diagonal 3 + 3).  Lane `sub` of a unit owns the unit's sub-th observation.  Waves run decoupled (no workgroup barrier
-// inside the loop over landmarks); a group's four partial sums are added in wave order at the end.
+// block-diagonal 3 + 3).  The 8 lanes of a unit ARE the 8 keyframe slots of the group's window: lane w takes the unit's observation made
+// from window keyframe w, or none (lm_ws8), so a lane's camera block, its rows of the local system and its register accumulators never
+// move.  Waves run decoupled (no workgroup barrier inside the loop over landmarks); a group's four partial sums are added in wave order
+// at the end.
 #pragma once
 
 namespace plba {
