@@ -1267,7 +1267,7 @@ static int prepare(plba_problem* p) {
     //   8 <= T < 24  : the two-ended ("twin") form of the multi-launch factorisation (plba_dense.hip): same kernels, the two ends
     //                  of the band eliminated side by side in each launch
     p->band_ok = false; p->twin_ok = false;
-    p->dd.band = 0; p->dd.twin_m0 = 0; p->dd.twin_fac = nullptr; p->dd.perm = nullptr; p->dd.xmap = nullptr; p->dd.alt = nullptr; p->dd.alt2 = nullptr;
+    p->dd.band = 0; p->dd.twin_m0 = 0; p->dd.twin_fac = nullptr; p->dd.cs_order = nullptr; p->dd.perm = nullptr; p->dd.xmap = nullptr; p->dd.alt = nullptr; p->dd.alt2 = nullptr;
     if (p->chain_ok && p->opt.band_solve && !p->dv.flow && !p->dv.wide) {      // (sharded runs: the lists above hold the GLOBAL structure)
         const ChainView& cv = p->cv;
         const int T = cv.Pdpad / 32;
@@ -1459,6 +1459,14 @@ static int prepare(plba_problem* p) {
                     }
                     tv.nlaunch = nlaunch;
                     HIPCK(p, p->d_twin_list.upload(list)); HIPCK(p, p->d_twin_perm.upload(perm)); HIPCK(p, p->d_twin_xmap.upload(xmap)); HIPCK(p, p->d_twin_fac.upload(fac));
+                    {   // k_chain_schur's workgroup order: at 44 tiles the launch is two rounds of workgroups, and a chain's first tile — 6 us of
+                        // factorisation behind its own Schur update — must not start in the second one
+                        std::vector<int32_t> order;
+                        for (int t2 = 0; t2 < T; ++t2) if (fac[t2] >= 0) order.push_back((t2 << 16) | t2);
+                        for (int dist = 0; dist <= T; ++dist) for (int ta = dist; ta < T; ++ta) { const int tb = ta - dist; if (dist == 0 && fac[ta] >= 0) continue; order.push_back((ta << 16) | tb); }
+                        for (int tb = 0; tb < T; ++tb) order.push_back((T << 16) | tb);
+                        HIPCK(p, p->d_cs_order.upload(order)); p->dd.cs_order = p->d_cs_order.p;
+                    }
                     HIPCK(p, p->d_twin_alt.alloc((size_t)2 * (cv.Pdpad + TILE) * cv.Pdpad));
                     tv.list = p->d_twin_list.p;
                     p->dd.twin_m0 = m0; p->dd.twin_fac = p->d_twin_fac.p; p->dd.perm = p->d_twin_perm.p; p->dd.xmap = p->d_twin_xmap.p;

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void k_chain_schur(DevBuf d, ChainView cv, Dev
     const int T = cv.Pdpad / 32;
     const int b = blockIdx.x, ntri = T * (T + 1) / 2;
     int ta, tb;
-    if (b < ntri) {
+    if (dd.cs_order) { const int o = dd.cs_order[b]; ta = o >> 16; tb = o & 0xffff; }      // (the workgroups with the longest path — a tile factored on the spot — are dispatched first)
+    else if (b < ntri) {
         ta = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
         while ((ta + 1) * (ta + 2) / 2 <= b) ++ta;
         while (ta * (ta + 1) / 2 > b) --ta;

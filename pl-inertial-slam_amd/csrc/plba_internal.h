@@ -129,6 +129,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
     // multi-chain ("twin") form of the multi-launch factorisation of a banded system (plba_dense.hip): the system is stored
     // PERMUTED [chain 0 | chain 1 | ... | separators], so that the chains are independent stretches of one Cholesky
     int twin_m0;           // first (permuted) tile of the separator region; 0: off
+    const int32_t* cs_order;   // k_chain_schur: tile (ta << 16 | tb) of each workgroup — the tiles that are factored on the spot first, then the band, then the rest; null = natural order
     const int32_t* twin_fac;   // per NATURAL diagonal tile: -1, or the permuted tile it becomes as the first tile of a chain (| 1 << 16: turned
                                // around) — k_chain_schur factors those on the spot
     const int32_t* perm;   // Ppad: natural dense index -> permuted (k_chain_schur writes through it)
