@@ -1209,12 +1209,12 @@ static int prepare(plba_problem* p) {
         HIPCK(p, p->d_lmg_blk_ij.upload(LH.blk_ij)); HIPCK(p, p->d_lmg_blk_start.upload(LH.blk_start)); HIPCK(p, p->d_lmg_blk_src.upload(LH.blk_src));
         HIPCK(p, p->d_lmg_row_kf.upload(LH.row_kf)); HIPCK(p, p->d_lmg_row_start.upload(LH.row_start)); HIPCK(p, p->d_lmg_row_src.upload(LH.row_src));
         HIPCK(p, p->d_alist2.upload(al2)); HIPCK(p, p->d_col_gather.upload(colg));
-        HIPCK(p, p->d_lmg_part.alloc(LH.grp.size() * (size_t)LMF_PART)); HIPCK(p, p->d_ob_err.alloc(2 * (size_t)E));
+        HIPCK(p, p->d_lmg_part.alloc(LH.grp.size() * (size_t)LMF_PART)); HIPCK(p, p->d_ob_err.alloc(2 * (size_t)E)); HIPCK(p, p->d_lmg_chi.alloc(E));
         LmView& lv = p->lv;
         p->lm_hist.assign(20, 0.0);      // diagnostics: groups by number of workgroup steps (points 1..8 | lines 1..8), window widths
         for (const LmGroup& g : LH.grp) { const int st = ((g.is_line ? 2 * g.nlm : g.nlm) + 31) / 32; p->lm_hist[(g.is_line ? 8 : 0) + std::min(std::max(st, 1), 8) - 1] += 1.0; p->lm_hist[16] += g.nw; p->lm_hist[17] += st; }
         lv.ngrp = (int)LH.grp.size(); lv.grp = p->d_lm_grp.p; lv.lm_slot = p->d_lmg_slot.p; lv.lm_ob0 = p->d_lmg_ob0.p; lv.ob_orig = p->d_lmg_orig.p; lv.lm_ws8 = p->d_lmg_ws8.p; lv.lm_fixed_g = p->d_lmg_fixed.p; lv.ob_level_g = p->d_lmg_level.p;
-        lv.meas_pt = p->d_lmg_meas_pt.p; lv.meas_ln = p->d_lmg_meas_ln.p; lv.ob_wt = p->d_lmg_wt.p; lv.part = p->d_lmg_part.p;
+        lv.meas_pt = p->d_lmg_meas_pt.p; lv.meas_ln = p->d_lmg_meas_ln.p; lv.ob_wt = p->d_lmg_wt.p; lv.part = p->d_lmg_part.p; lv.ob_chi_g = p->d_lmg_chi.p; p->lm_chi_dirty = false;
         lv.nblk = (int)LH.blk_ij.size(); lv.blk_ij = p->d_lmg_blk_ij.p; lv.blk_start = p->d_lmg_blk_start.p; lv.blk_src = p->d_lmg_blk_src.p;
         lv.nrow = (int)LH.row_kf.size(); lv.row_kf = p->d_lmg_row_kf.p; lv.row_start = p->d_lmg_row_start.p; lv.row_src = p->d_lmg_row_src.p;
         lv.alist2 = p->d_alist2.p; lv.nalist2 = (int)al2.size(); lv.col_gather = p->d_col_gather.p;
@@ -1684,6 +1684,11 @@ static int lm_enqueue_solve_and_trial(plba_problem* p) {
     return PLBA_OK;
 }
 
+static void lm_chi_sync(plba_problem* p) {
+    if (p->lm_ok && p->lm_chi_dirty) launch_lm_chi_sync(p->dv, p->lv, p->stream);
+    p->lm_chi_dirty = false;
+}
+
 extern "C" {
 
 int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_flag, plba_stats* out) {
@@ -1713,6 +1718,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
     for (int it = 0; it < max_iters && !(abort_flag && *abort_flag) && ok && p->lm_ok; ++it) {
         // ---- fused landmark-major passes (see lm_enqueue_* above) ------------------------------------------------------------------
         if (it == 0 && (rc = lm_enqueue_first(p, it))) return rc;
+        p->lm_chi_dirty = true;      // (the cached per-observation chi2 now lives in group order: lm_chi_sync before anything reads DevBuf::ob_chi2)
         double rho = 0.0;
         int qmax = 0;
         do {
@@ -1895,6 +1901,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
     } else {
         // no iteration ran: report the chi2 of the current estimate (computeActiveErrors only)
         launch_linearize(d, p->cur, false, p->rob, owns_pose_edges(p), s);
+        p->lm_chi_dirty = false;
         launch_reduce(d, owns_pose_edges(p), p->d_red.p, s);
         if (p->world > 1 && (rc = exchange(p, p->d_red.p, 1, 0))) return rc;
         double chi = 0.0;
@@ -1914,6 +1921,7 @@ int plba_recompute_errors(plba_problem* p) {
     if (rc) return rc;
     HIPCK(p, hipSetDevice(p->device));
     launch_linearize(p->dv, p->cur, false, p->rob, owns_pose_edges(p), p->stream);
+    p->lm_chi_dirty = false;      // (ob_chi2 was just rewritten in place)
     HIPCK(p, plba_stream_wait(p->stream));
     return PLBA_OK;
 }
@@ -1956,6 +1964,7 @@ int plba_gate_outliers(plba_problem* p, double thresh, int* np_out, int* nl_out)
     const DevBuf& d = p->dv;
     Ctrl* c = d.ctrl;
     HIPCK(p, hipMemsetAsync(&c->n_gate_pt, 0, 2 * sizeof(int), p->stream));
+    lm_chi_sync(p);
     launch_gate(d, p->cur, thresh, p->stream);
     if (p->lm_ok) launch_lm_level_sync(d, p->lv, p->stream);      // the fused passes read the levels in group order
     HIPCK(p, hipMemcpyAsync(p->h_ctrl, d.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, p->stream));
@@ -1976,6 +1985,7 @@ int plba_cull_observations(plba_problem* p, double thresh, uint8_t* bad_point, u
     const int E = p->Ep + p->El;
     std::vector<uint8_t> bad((size_t)std::max(E, 1), 0);
     if (E) {
+        lm_chi_sync(p);
         launch_cull(d, p->cur, thresh, p->d_depth.p, p->stream);
         HIPCK(p, plba_stream_wait(p->stream));
         HIPCK(p, plba_d2h(p, bad.data(), p->d_depth.p, (size_t)E));
@@ -1999,7 +2009,7 @@ int plba_get_edge_chi2(plba_problem* p, plba_edge_kind kind, double* chi2, uint8
     HIPCK(p, plba_stream_wait(p->stream));
     if (kind == PLBA_EDGE_POINT || kind == PLBA_EDGE_LINE) {
         const int o = kind == PLBA_EDGE_POINT ? 0 : p->Ep, n = kind == PLBA_EDGE_POINT ? p->Ep : p->El;
-        if (chi2 && n) HIPCK(p, plba_d2h(p, chi2, d.ob_chi2 + o, (size_t)n * 8));
+        if (chi2 && n) { lm_chi_sync(p); HIPCK(p, plba_d2h(p, chi2, d.ob_chi2 + o, (size_t)n * 8)); }
         if (dpos && n) {
             launch_depth(d, p->cur, p->d_depth.p, p->stream);
             HIPCK(p, plba_stream_wait(p->stream));
@@ -2126,6 +2136,7 @@ int plba_debug_build(plba_problem* p, double lambda, int do_solve) {
     if (p->lm_ok) {      // fused landmark-major passes, with the diagnostic outputs the parity tests read (Hll, bl, residuals, xl)
         p->lv.dbg_out = 1; p->lv.ob_err = p->d_ob_err.p;
         if ((rc = lm_enqueue_first(p, 0))) return rc;
+        p->lm_chi_dirty = true;
         HIPCK(p, plba_stream_wait(p->stream));
         HIPCK(p, plba_d2h(p, &c0, d.ctrl, sizeof c0));
         c0.lambda = lambda;

@@ -160,6 +160,7 @@ struct LmView {
     const int32_t* lm_slot;       // group order -> landmark slot
     const int32_t* lm_ob0;        // group order (+ 1): first observation of each landmark in the group-ordered observation arrays
     const int32_t* ob_orig;       // group order -> unified observation index (ob_level, ob_chi2)
+    double* ob_chi_g;             // E, GROUP order: the cached per-observation chi2 the fused passes leave (coalesced; k_lm_chi_sync scatters it into ob_chi2 for the gating / culling / read-back that follow a call)
     const uint8_t* lm_ws8;        // group order, LMF_W per landmark: per window slot, the offset (in the landmark's observation range) of the observation made from that keyframe, 0xFF = none
     const uint8_t* lm_fixed_g;    // group order copy of lm_fixed
     uint8_t* ob_level_g;          // group order copy of ob_level (refreshed whenever the levels change: launch_lm_level_sync)
@@ -217,6 +218,7 @@ void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, bool
 void launch_reduce_n(const DevBuf& d, bool owns_pose_edges, double* red, int nred, hipStream_t s);
 void launch_posediag(const DevBuf& d, hipStream_t s);      // A: chain back-substitution | landmark groups | the trial's pose-side edges (+ the LM decision)
 void launch_lm_level_sync(const DevBuf& d, const LmView& lv, hipStream_t s);
+void launch_lm_chi_sync(const DevBuf& d, const LmView& lv, hipStream_t s);
 void launch_lambda_init_n(const DevBuf& d, const LmView& lv, const LmParams& lp, double* red, int iteration, int nred, hipStream_t s);
 void launch_decide_n(const DevBuf& d, const LmParams& lp, double* red, int nred, Mailbox* mail, unsigned long long seq, hipStream_t s);
 void launch_gate(const DevBuf& d, int state, double thresh, hipStream_t s);

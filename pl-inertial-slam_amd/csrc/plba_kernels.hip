@@ -1668,6 +1668,13 @@ __global__ __launch_bounds__(256) void k_lm_level_sync(DevBuf d, LmView lv) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < d.E) lv.ob_level_g[e] = d.ob_level[lv.ob_orig[e]];
 }
+__global__ __launch_bounds__(256) void k_lm_chi_sync(DevBuf d, LmView lv) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < d.E && lv.ob_level_g[e] == 0) d.ob_chi2[lv.ob_orig[e]] = lv.ob_chi_g[e];      // (a gated observation keeps the value it was gated on, as on the record-based path)
+}
+void launch_lm_chi_sync(const DevBuf& d, const LmView& lv, hipStream_t s) {
+    if (d.E) hipLaunchKernelGGL(k_lm_chi_sync, dim3((d.E + 255) / 256), dim3(256), 0, s, d, lv);
+}
 void launch_lm_level_sync(const DevBuf& d, const LmView& lv, hipStream_t s) {
     if (d.E) hipLaunchKernelGGL(k_lm_level_sync, dim3((d.E + 255) / 256), dim3(256), 0, s, d, lv);
 }

@@ -188,7 +188,7 @@ DEV void lm_load_data(const DevBuf& d, const LmView& lv, int state, int lane, co
     s.L[0] = Lp[0]; s.L[1] = Lp[1]; s.L[2] = Lp[2];
     if (IS_LINE) { s.L[3] = Lp[3]; s.L[4] = Lp[4]; s.L[5] = Lp[5]; }
     if (s.has) {
-        s.orig = lv.ob_orig[s.e]; s.wt = lv.ob_wt[s.e];
+        s.orig = lv.ob_err ? lv.ob_orig[s.e] : 0; s.wt = lv.ob_wt[s.e];      // (the original index: only the parity tests' residual dump needs it)
         s.lvl0 = lv.ob_level_g[s.e] == 0;
         if (IS_LINE) { const double* m = lv.meas_ln + (size_t)(s.e - d.Ep) * 3; s.meas[0] = m[0]; s.meas[1] = m[1]; s.meas[2] = m[2]; }
         else { const double2 m = reinterpret_cast<const double2*>(lv.meas_pt)[s.e]; s.meas[0] = m.x; s.meas[1] = m.y; }
@@ -273,7 +273,7 @@ DEV void lm_schur_group(const DevBuf& d, const LmView& lv, const int gidx, const
         const bool active = cur.uvalid && nact > 0 && !cur.fixed;
         if (!IS_LINE || rowsel == 0) chi_acc += r.rho;
         if (MODE == 1 && r.act && (!IS_LINE || rowsel == 0)) {
-            d.ob_chi2[cur.orig] = r.chi;
+            lv.ob_chi_g[cur.e] = r.chi;
             if (lv.ob_err) { lv.ob_err[2 * (size_t)cur.orig] = r.e[0]; }
         }
         if (MODE == 1 && lv.ob_err && r.act) lv.ob_err[2 * (size_t)cur.orig + (IS_LINE ? rowsel : 1)] = r.e[NR - 1];
@@ -654,7 +654,7 @@ DEV void lm_trial_group(const DevBuf& d, const LmView& lv, const int gidx, const
         lm_eval<IS_LINE, NR>(d, rb, S.kc[1][cur.ws], false, Ltr, cur.meas, cur.wt, cur.has, cur.lvl0, rowsel, false, rt);
         if (!IS_LINE || rowsel == 0) {
             chi_acc += rt.rho;
-            if (rt.act) d.ob_chi2[cur.orig] = rt.chi;
+            if (rt.act) lv.ob_chi_g[cur.e] = rt.chi;      // (group order: the unit's lanes write neighbouring words; in original order these were 1 M scattered 8-byte stores at configs[4])
         }
         cur = nxt;
     }

@@ -265,6 +265,7 @@ struct plba_problem {
     // fused landmark-major passes (options.lm_fused; plba_lm_dev.h)
     bool lm_ok = false;                         // this upload runs them (structure permitting: one GPU, chain path, <= 8 observations per landmark)
     std::vector<double> lm_hist;                // diagnostics (plba_debug_get "lm_groups")
+    bool lm_chi_dirty = false;                  // the fused passes' group-order chi2 cache is newer than DevBuf::ob_chi2
     unsigned back_epoch = 0;                    // k_lm_trial launches since the counters were allocated (DevBuf::back_cnt)
     bool lm_disable = false;                    // prepare() found the structure unfit after the fact and rebuilt for the record-based path
     bool lm_spec = false;                       // the accepted trial's Schur pass + gather are already in the stream (enqueued behind the decision)
@@ -272,7 +273,7 @@ struct plba_problem {
     plba::DArr<plba::LmGroup> d_lm_grp;
     plba::DArr<int32_t> d_lmg_slot, d_lmg_ob0, d_lmg_orig, d_lmg_blk_ij, d_lmg_blk_start, d_lmg_blk_src, d_lmg_row_kf, d_lmg_row_start, d_lmg_row_src, d_alist2;
     plba::DArr<uint8_t> d_lmg_ws8, d_lmg_fixed, d_lmg_level, d_col_gather;
-    plba::DArr<double> d_lmg_meas_pt, d_lmg_meas_ln, d_lmg_wt, d_lmg_part, d_ob_err;
+    plba::DArr<double> d_lmg_meas_pt, d_lmg_meas_ln, d_lmg_wt, d_lmg_chi, d_lmg_part, d_ob_err;
     bool assembled = false;                     // k_landmark_hll already assembled the pose-side system of this iteration
     plba::DevBuf dv;
     std::vector<plba_trace_row> trace;
