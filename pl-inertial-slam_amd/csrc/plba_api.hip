@@ -989,7 +989,7 @@ static int prepare(plba_problem* p) {
                 const int launches = twin ? twin_launch_estimate(T, hb) : T;
                 const double cost = 10.3 * launches + block_cost * seg;
                 if (ptime) fprintf(stderr, "[prepare]   chain segments of %d: %d dense dims, %d tiles, band %d -> %d launches (cost %.1f)\n", seg, pd, T, hb, launches, cost);
-                if (cost < best_cost) { best_cost = cost; best_seg = seg; }
+                if (cost < best_cost) { best_cost = cost; best_seg = seg; p->seg_launch_est = launches; }
             }
             if (const char* e = getenv("PLBA_CHAIN_SEG")) { const int v = atoi(e); if (v >= 1 && v <= CHAIN_SEG) best_seg = v; }      // (measurement knob)
             const int SEG = best_seg;
@@ -2234,6 +2234,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};
     else if (w == "band") v = {(double)(p->band_ok ? 1 : 0)};
     else if (w == "twin") v = {(double)(p->twin_ok ? 1 : 0)};
+    else if (w == "fact_launches_estimate") v = {(double)p->seg_launch_est};      // what the segment-length choice expected (twin_launch_estimate): fact_launches + 1 when the plan is built
     else if (w == "fact_launches") {      // dependent launches of one factorisation between the profile events 11 and 12 (bench.py's roofline)
         if (p->band_ok) v = {2.0};
         else if (p->twin_ok) v = {(double)(p->twinv.nlaunch + (p->twinv.T - p->twinv.m0 - 1))};

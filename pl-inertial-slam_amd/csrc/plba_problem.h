@@ -265,6 +265,7 @@ struct plba_problem {
     // fused landmark-major passes (options.lm_fused; plba_lm_dev.h)
     bool lm_ok = false;                         // this upload runs them (structure permitting: one GPU, chain path, <= 8 observations per landmark)
     std::vector<double> lm_hist;                // diagnostics (plba_debug_get "lm_groups")
+    int seg_launch_est = 0;                     // dependent factorisation launches the chain segment-length choice expected (diagnostics)
     bool lm_chi_dirty = false;                  // the fused passes' group-order chi2 cache is newer than DevBuf::ob_chi2
     unsigned back_epoch = 0;                    // k_lm_trial launches since the counters were allocated (DevBuf::back_cnt)
     bool lm_disable = false;                    // prepare() found the structure unfit after the fact and rebuilt for the record-based path

@@ -658,3 +658,15 @@ def test_ba_call_time_does_not_depend_on_other_problems_alive(pkg, hip):
     busy = [call() for _ in range(6)]
     other.close()
     assert max(busy) < 2.0 * solo + 2e-3, (solo, busy)
+
+
+@pytest.mark.parametrize("K", [26, 34, 50, 77, 128, 200])
+def test_segment_length_choice_predicts_the_plan_that_is_built(pkg, hip, K):
+    """prepare() chooses the chain elimination's segment length by the number of dependent launches the multi-chain factorisation will need
+    (twin_launch_estimate: the plan builder's arithmetic restated for every candidate's dense layout and band).  The estimate for the chosen
+    length must be what the plan that is then BUILT needs — the two pieces of arithmetic are separate code."""
+    w = pkg.window.make_window(K, 12 * K, 3 * K, imu=True, seed=0xC0DE + K)
+    g = pkg.new_problem(); g.upload_window(w); g.optimize(1)
+    assert int(g.debug_get("twin")[0]) == 1
+    assert int(g.debug_get("fact_launches_estimate")[0]) == int(g.debug_get("fact_launches")[0]) + 1
+    g.close()
