@@ -118,6 +118,26 @@ def test_default_takes_the_fused_passes_from_40k_observations(pkg, hip):
     big.close()
 
 
+def test_cached_edge_chi2_after_the_fused_passes(pkg, orc, hip):
+    """the fused passes keep the per-observation chi2 of the last evaluation in GROUP order; what a caller reads (plba_get_edge_chi2, gating,
+    culling: e->chi2() of the reference's call site, mapHandler.cpp:6047-6066, 5541-5620) is in the observations' own order and equals the
+    oracle's — after a call, after gating (a gated observation keeps the value it was gated on), and after the second call"""
+    w = pkg.window.make_window(9, 260, 50, imu=True, seed=0xC41)
+    g = pkg.new_problem(lm_fused=2); g.upload_window(w)
+    o = orc.new_problem(); o.upload_window(w)
+    for step in ("call 1", "gate", "call 2", "cull"):
+        if step.startswith("call"): g.optimize(4); o.optimize(4)
+        elif step == "gate": assert g.gate_outliers() == o.gate_outliers()
+        else:
+            cg, co = g.cull_observations(), o.cull_observations()
+            assert (cg["bad_points"] == co["bad_points"]).all() and (cg["bad_lines"] == co["bad_lines"]).all()
+        for kind in (pkg.abi.EDGE_POINT, pkg.abi.EDGE_LINE):
+            a, b = g.edge_chi2(kind)[0], o.edge_chi2(kind)[0]
+            assert np.abs(a - b).max() <= 1e-8 * max(np.abs(b).max(), 1.0), (step, kind)
+    assert g.debug_get("lm_fused")[0] == 1
+    g.close(); o.close()
+
+
 def test_random_window_shapes_against_the_oracle():
     """tools/soak_fused.py, 24 random windows (keyframe counts 3..70, track mixes, points / lines only, IMU or not, priors, fixed keyframes
     and landmarks, gating between two calls, large and small initial damping) with lm_fused = 2 against the oracle, in a process of its
