@@ -1684,6 +1684,13 @@ static int lm_enqueue_solve_and_trial(plba_problem* p) {
     return PLBA_OK;
 }
 
+// the count the trial launch's pose-side blocks wait for: every chain segment of every k_lm_trial launch so far (lead_wait).
+// PLBA_TEST_LEAD_WAIT_FAIL (fault injection, tests/test_lm_fused.py): a count that is never reached — the wait must run into its bound,
+// set Ctrl::sync_fail and fail the call; it must not hang the queue.
+static unsigned lm_back_target(plba_problem* p) {
+    const unsigned t = (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1);
+    return getenv("PLBA_TEST_LEAD_WAIT_FAIL") ? t + 1000u : t;
+}
 static void lm_chi_sync(plba_problem* p) {
     if (p->lm_ok && p->lm_chi_dirty) launch_lm_chi_sync(p->dv, p->lv, p->stream);
     p->lm_chi_dirty = false;
@@ -1738,7 +1745,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
             bool spec = false;
             const bool sharded = p->world > 1;
             if (p->opt.profile >= 2 || sharded) {
-                launch_lm_trial(ds, p->lv, p->cur, trial, jac_trial, p->rob, &p->cv, p->dd.x, (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1), owns_pose_edges(p), nullptr, s);
+                launch_lm_trial(ds, p->lv, p->cur, trial, jac_trial, p->rob, &p->cv, p->dd.x, lm_back_target(p), owns_pose_edges(p), nullptr, s);
                 MARK(p, 9);
                 if (sharded) {      // [chi2, landmark part of the scale] become global; every rank then takes the same decision
                     launch_reduce_n(d, owns_pose_edges(p), p->d_red.p, p->lv.ngrp, s);
@@ -1754,7 +1761,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
                     }
                 }
             } else {
-                launch_lm_trial(ds, p->lv, p->cur, trial, jac_trial, p->rob, &p->cv, p->dd.x, (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1), true, &df, s);      // the trial's IMU / prior edges (linearised into the idle accumulators) | landmark groups; + the decision
+                launch_lm_trial(ds, p->lv, p->cur, trial, jac_trial, p->rob, &p->cv, p->dd.x, lm_back_target(p), true, &df, s);      // the trial's IMU / prior edges (linearised into the idle accumulators) | landmark groups; + the decision
                 if (jac_trial) { if ((rc = lm_enqueue_system(p, ds, trial, true))) return rc; spec = true; }      // gated on the device-side decision
                 long spins = 0;
                 while (__atomic_load_n(&p->h_mail->seq, __ATOMIC_ACQUIRE) != seq) {
@@ -2144,7 +2151,7 @@ int plba_debug_build(plba_problem* p, double lambda, int do_solve) {
         rc = lm_enqueue_system(p, d, p->cur, false);
         if (!rc && do_solve) {
             rc = lm_enqueue_solve_and_trial(p);
-            if (!rc) launch_lm_trial(d, p->lv, p->cur, p->cur ^ 1, false, p->rob, &p->cv, p->dd.x, (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1), true, nullptr, p->stream);      // (errors only: the accumulators keep the built system)
+            if (!rc) launch_lm_trial(d, p->lv, p->cur, p->cur ^ 1, false, p->rob, &p->cv, p->dd.x, lm_back_target(p), true, nullptr, p->stream);      // (errors only: the accumulators keep the built system)
         }
         p->lv.dbg_out = 0; p->lv.ob_err = nullptr;
         if (rc) return rc;

@@ -138,6 +138,24 @@ def test_cached_edge_chi2_after_the_fused_passes(pkg, orc, hip):
     g.close(); o.close()
 
 
+def test_in_launch_wait_fails_loudly_when_its_condition_never_comes(pkg, hip, monkeypatch):
+    """the trial launch's pose-side blocks wait, inside the launch, for the chain segments in front of them (lead_wait).  Fault injection:
+    a count that is never reached.  The wait is bounded — it must run into its bound, report through Ctrl::sync_fail and fail the call with
+    PLBA_ERR_DEVICE; the queue must stay usable (the next call, without the fault, succeeds)."""
+    w = pkg.window.make_window(8, 200, 40, imu=True, seed=0xFA11)
+    g = pkg.new_problem(lm_fused=2); g.upload_window(w)
+    g.optimize(1)
+    monkeypatch.setenv("PLBA_TEST_LEAD_WAIT_FAIL", "1")
+    with pytest.raises(pkg.abi.PlbaError, match="waited for the chain back-substitution"):
+        g.optimize(2)
+    monkeypatch.delenv("PLBA_TEST_LEAD_WAIT_FAIL")
+    g.close()
+    g2 = pkg.new_problem(lm_fused=2); g2.upload_window(w)
+    st = g2.optimize(3)
+    assert st.iterations == 3 and st.chi2_final < st.chi2_initial
+    g2.close()
+
+
 def test_random_window_shapes_against_the_oracle():
     """tools/soak_fused.py, 24 random windows (keyframe counts 3..70, track mixes, points / lines only, IMU or not, priors, fixed keyframes
     and landmarks, gating between two calls, large and small initial damping) with lm_fused = 2 against the oracle, in a process of its
