@@ -57,8 +57,8 @@ typedef struct {
     double user_lambda_init;    /* g2o LM userLambdaInit, 0 = automatic               (0)     */
     double marg_eps;            /* IMU/marginalization.h:99 pseudo-inverse threshold  (1e-8)  */
     int    fix_line_position_jacobian; /* 0 = reproduce IMU/g2otypes.cpp:1347 (SURVEY B-Q1)   */
-    int    whiten_marg_factors; /* 0 = reproduce IMU/marginalization.cpp:67 (SURVEY B-Q4); 1 is rejected
-                                   by plba_marginalize* (PLBA_ERR_INVALID: not implemented)          */
+                                /* (the marginalization factors are unweighted, as IMU/marginalization.cpp:67 has them — SURVEY B-Q4;
+                                   there is no whitening option: round 3 declared one and rejected it at run time, round 4 removed it) */
     int    device;              /* HIP device ordinal, -1 = current device            (-1)    */
     int    use_mfma;            /* 1 = fp64 MFMA trailing update in the dense solve    (1)    */
     int    profile;             /* HIP-event timing into plba_stats.ms_phase: 1 = the dense factorisation launches only
@@ -91,12 +91,29 @@ typedef struct {
     int    lm_fused;            /* the landmark side of an iteration as fused landmark-major passes (plba_lm_dev.h): observations are
                                    evaluated in registers where they are needed — the Schur complement as a rank-k update per group of
                                    landmarks on the matrix cores, back-substitution + trial residuals in one pass — instead of writing a
-                                   record per observation and gathering it three times.  Possible on one GPU when the chain path is in
-                                   effect and no landmark has more than 8 observations or two in one keyframe.  2 = whenever possible;
+                                   record per observation and gathering it three times.  Possible (on one GPU or sharded: the ranks of a window
+                                   vote and all take the same path) when the chain path is in effect and no landmark has more than 8
+                                   observations or two in one keyframe.  2 = whenever possible;
                                    1 = when possible and the window holds at least 40 k observations (BASELINE configs[1] .. [4]; below,
                                    the record-based passes k_linearize / k_landmark_hll / k_schur_pairs / k_backsub run: DESIGN.md 4a);
                                    0 = never                                                                                (1) */
+    int    lm_fused_min_obs;    /* lm_fused = 1: the observation count from which the fused passes are taken           (40000) */
+    /* ---- measurement / diagnostic knobs (round 3 read these from the environment inside prepare(); they are options now, read
+     * once, and nothing in the library calls getenv) ---- */
+    int    lm_group_steps;      /* workgroup steps per landmark group of the fused passes, 1 .. 16; 0 = sized to whole rounds of
+                                   workgroups on the device                                                  (0) */
+    int    chain_seg;           /* keyframes per eliminated velocity / bias chain segment, 1 .. 8; 0 = chosen from the dense layout's
+                                   launch count                                                              (0) */
+    int    twin_max_tiles;      /* longest compact dense system (32-column tiles) the multi-chain factorisation takes; 0 = up to the
+                                   in-LDS band solver's threshold                                                          (0) */
+    int    diag;                /* bit 0: prepare() / plba_lba_visual print their lap timings to stderr; bit 1: plba_marginalize* keeps the
+                                   stacked Jacobian and residual for plba_debug_get("marg_J") (the 40-digit fixture's input);
+                                   bit 2 (fault injection, tests/test_lm_fused.py): the in-launch wait of k_lm_trial is given a count that
+                                   never comes — the call must fail with PLBA_ERR_DEVICE, not hang                          (0) */
 } plba_options;
+#define PLBA_DIAG_TIMING 1
+#define PLBA_DIAG_MARG_DUMP 2
+#define PLBA_DIAG_LEAD_WAIT_FAIL 4
 
 void plba_default_options(plba_options* o);
 
@@ -109,7 +126,9 @@ typedef struct {
     double chi2_initial;        /* activeRobustChi2 before the first iteration                  */
     double chi2_final;          /* activeRobustChi2 of the state left in the problem            */
     double lambda_final;
-    double ms_total;            /* wall time of this call, device-synchronised                  */
+    double ms_total;            /* wall time of this call; on return every launch of the call has completed (its last trial's
+                                   control block was read back; launches queued ahead for a next iteration that did not
+                                   come — abort, LM Terminate — are waited for)                                          */
     double ms_phase[8];         /* device ms by HIP events when options.profile: [0] time inside the linearising launches (observations +
                                    IMU / prior edges, Jacobians) wherever they run — at the head of an iteration, or as the trial pass
                                    that linearises the trial state while it measures it; plba_debug_get "prof_lin_launches" counts them —, [1] the dense factorisation launches alone (first-block launch + one per block

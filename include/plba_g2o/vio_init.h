@@ -15,33 +15,41 @@ namespace plba_vio {
 inline void mat3_vec(const double* R, const double* v, double* o) { for (int i = 0; i < 3; ++i) o[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2]; }
 inline void mat3_mul(const double* A, const double* B, double* C) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j]; }
 
-// minimum-norm least squares of a (rows x 3) system through the eigen-decomposition of A^T A (= the thin SVD's V and sigma^2), singular
-// values below Eigen's JacobiSVD threshold (max(rows, 3) * epsilon * sigma_max) treated as zero
+// minimum-norm least squares of a (rows x 3) system as JacobiSVD<MatrixXd>(A, ComputeThinU | ComputeThinV).solve(b) computes it
+// (src/mapHandler.cpp:4896, 4940): a ONE-SIDED Jacobi on the columns of A (Hestenes) — the rotated columns are U Sigma, the accumulated
+// rotations V — so that small singular values keep their RELATIVE accuracy; singular values at or below Eigen's threshold
+// max(rows, 3) * epsilon * sigma_max are treated as zero.  (Round 3 went through the eigen-decomposition of A^T A, which resolves
+// singular values only down to sqrt(epsilon) * sigma_max: with cond(A) > 1e7 — an accelerometer-bias system observed through little
+// rotation — a singular value that is rounding noise passed the threshold and was inverted.  ADVICE r03.)
 inline void lstsq3(const std::vector<double>& A /* rows x 3 row-major */, const std::vector<double>& b, double* x) {
     const int rows = (int)b.size();
-    double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, r[3] = {0, 0, 0};
-    for (int i = 0; i < rows; ++i) for (int a = 0; a < 3; ++a) { r[a] += A[3 * i + a] * b[i]; for (int c = 0; c < 3; ++c) M[3 * a + c] += A[3 * i + a] * A[3 * i + c]; }
-    for (int sweep = 0; sweep < 50; ++sweep) {
-        const double off = M[1] * M[1] + M[2] * M[2] + M[5] * M[5];
-        if (off == 0.0) break;
+    std::vector<double> G(A.begin(), A.begin() + 3 * (size_t)rows);
+    double V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
         for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
-            const double apq = M[3 * p + q];
-            if (apq == 0.0) continue;
-            const double th = (M[3 * q + q] - M[3 * p + p]) / (2.0 * apq), t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
-            const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-            for (int k = 0; k < 3; ++k) { const double a = M[3 * k + p], bq = M[3 * k + q]; M[3 * k + p] = c * a - s * bq; M[3 * k + q] = s * a + c * bq; }
-            for (int k = 0; k < 3; ++k) { const double a = M[3 * p + k], bq = M[3 * q + k]; M[3 * p + k] = c * a - s * bq; M[3 * q + k] = s * a + c * bq; }
-            for (int k = 0; k < 3; ++k) { const double a = V[3 * k + p], bq = V[3 * k + q]; V[3 * k + p] = c * a - s * bq; V[3 * k + q] = s * a + c * bq; }
+            double al = 0.0, be = 0.0, ga = 0.0;
+            for (int i = 0; i < rows; ++i) { const double gp = G[3 * i + p], gq = G[3 * i + q]; al += gp * gp; be += gq * gq; ga += gp * gq; }
+            if (ga == 0.0 || std::fabs(ga) <= 2.220446049250313e-16 * std::sqrt(al * be)) continue;
+            rotated = true;
+            const double zeta = (be - al) / (2.0 * ga), t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(zeta * zeta + 1.0));
+            const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+            for (int i = 0; i < rows; ++i) { const double gp = G[3 * i + p], gq = G[3 * i + q]; G[3 * i + p] = c * gp - sn * gq; G[3 * i + q] = sn * gp + c * gq; }
+            for (int k = 0; k < 3; ++k) { const double vp = V[3 * k + p], vq = V[3 * k + q]; V[3 * k + p] = c * vp - sn * vq; V[3 * k + q] = sn * vp + c * vq; }
         }
+        if (!rotated) break;
     }
-    double smax = 0.0;
-    for (int k = 0; k < 3; ++k) smax = std::fmax(smax, std::sqrt(std::fmax(M[4 * k], 0.0)));
+    double sg2[3], gb[3], smax = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        sg2[k] = gb[k] = 0.0;
+        for (int i = 0; i < rows; ++i) { sg2[k] += G[3 * i + k] * G[3 * i + k]; gb[k] += G[3 * i + k] * b[i]; }
+        smax = std::fmax(smax, std::sqrt(sg2[k]));
+    }
     const double thr = (rows > 3 ? rows : 3) * 2.220446049250313e-16 * smax;
     x[0] = x[1] = x[2] = 0.0;
     for (int k = 0; k < 3; ++k) {
-        const double sg = std::sqrt(std::fmax(M[4 * k], 0.0));
-        if (!(sg > thr)) continue;
-        const double w = (V[k] * r[0] + V[3 + k] * r[1] + V[6 + k] * r[2]) / (sg * sg);
+        if (!(std::sqrt(sg2[k]) > thr)) continue;
+        const double w = gb[k] / sg2[k];      // (u_k . b) / sigma_k with u_k = g_k / sigma_k
         for (int a = 0; a < 3; ++a) x[a] += V[3 * a + k] * w;
     }
 }

@@ -325,6 +325,7 @@ void orc_default_options(plba_options* o) {
     o->band_solve = 1;
     o->marg_exact = 1;             /* the oracle always takes the dense eigen pseudo-inverse (cpp:351-353) */
     o->lm_fused = 1;
+    o->lm_fused_min_obs = 40000;
 }
 const char* orc_backend_name(void) { return "cpu-oracle"; }
 
@@ -1814,7 +1815,6 @@ static void factor_free(factor_t* f) { free(f->r); for (int i = 0; i < f->nv; ++
 
 int orc_marginalize(plba_problem* p, int first_kf, int max_edges, plba_prior* out) {
     if (!p || !out || first_kf < 0 || first_kf >= p->K) return PLBA_ERR_INVALID;
-    if (p->opt.whiten_marg_factors) FAIL(p, PLBA_ERR_INVALID, "whiten_marg_factors = 1 is not implemented: only the reference's unweighted factors (IMU/marginalization.cpp:67)");
     memset(out, 0, sizeof *out);
     int NUM = max_edges;
     int cap = 2 + 2 * (NUM + 2) + 1;

@@ -22,8 +22,9 @@ STATUS = {0: "PLBA_OK", -1: "PLBA_ERR_INVALID", -2: "PLBA_ERR_STATE", -3: "PLBA_
 class Options(C.Structure):
     _fields_ = [("tau", C.c_double), ("good_step_lower", C.c_double), ("good_step_upper", C.c_double),
                 ("max_trials", C.c_int), ("user_lambda_init", C.c_double), ("marg_eps", C.c_double),
-                ("fix_line_position_jacobian", C.c_int), ("whiten_marg_factors", C.c_int),
-                ("device", C.c_int), ("use_mfma", C.c_int), ("profile", C.c_int), ("factor_block", C.c_int), ("factor_flow", C.c_int), ("chain_elim", C.c_int), ("wide_steps", C.c_int), ("band_solve", C.c_int), ("marg_exact", C.c_int), ("lm_fused", C.c_int)]
+                ("fix_line_position_jacobian", C.c_int),
+                ("device", C.c_int), ("use_mfma", C.c_int), ("profile", C.c_int), ("factor_block", C.c_int), ("factor_flow", C.c_int), ("chain_elim", C.c_int), ("wide_steps", C.c_int), ("band_solve", C.c_int), ("marg_exact", C.c_int), ("lm_fused", C.c_int),
+                ("lm_fused_min_obs", C.c_int), ("lm_group_steps", C.c_int), ("chain_seg", C.c_int), ("twin_max_tiles", C.c_int), ("diag", C.c_int)]
 
 
 class Stats(C.Structure):

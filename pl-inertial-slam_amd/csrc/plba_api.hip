@@ -6,6 +6,7 @@
 // the device; only the control block (a few scalars) crosses PCIe once per damped trial (k_decide writes it into
 // mapped host memory, the host polls a sequence number).
 // No CPU fallback exists: every entry point that computes needs a HIP device.
+#include <atomic>
 #include <algorithm>
 #include <thread>
 #include <array>
@@ -67,6 +68,7 @@ void plba_default_options(plba_options* o) {
     o->band_solve = 1;
     o->marg_exact = 1;
     o->lm_fused = 1;
+    o->lm_fused_min_obs = 40000;
 }
 const char* plba_backend_name(void) { return "hip-gfx950"; }
 const char* plba_last_error(const plba_problem* p) { return p ? p->err : g_create_err; }
@@ -376,11 +378,12 @@ public:
             std::lock_guard<std::mutex> lk(m_);
             job_ = &async_f_; njobs_ = n; next_ = 0; pending_ = n; ++gen_;
         }
-        async_ = true; async_owner_ = std::this_thread::get_id();
+        async_owner_.store(std::this_thread::get_id(), std::memory_order_relaxed);
+        async_.store(true, std::memory_order_release);      // (finish() on OTHER host threads reads these two: atomics, owner first)
         cv_.notify_all();
     }
     void finish() {
-        if (!async_ || async_owner_ != std::this_thread::get_id()) return;
+        if (!async_.load(std::memory_order_acquire) || async_owner_.load(std::memory_order_relaxed) != std::this_thread::get_id()) return;
         std::unique_lock<std::mutex> lk(m_);
         while (next_ < njobs_) {
             const int i = next_++;
@@ -392,7 +395,7 @@ public:
         done_.wait(lk, [&] { return pending_ == 0; });
         job_ = nullptr;
         lk.unlock();
-        async_ = false;
+        async_.store(false, std::memory_order_release);
         run_m_.unlock();
     }
     ~HostPool() {
@@ -429,8 +432,8 @@ private:
     unsigned long long gen_ = 0;
     bool stop_ = false;
     std::function<void(int)> async_f_;
-    bool async_ = false;
-    std::thread::id async_owner_;
+    std::atomic<bool> async_{false};
+    std::atomic<std::thread::id> async_owner_{};
 };
 }  // namespace
 
@@ -484,7 +487,7 @@ static bool lm_groups_finish(LmHost& H) {      // false: a keyframe observes a l
 static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf, const std::vector<double>& ob_w, LmHost& H) {
     const int K = p->K, Np = p->Np, Nl = p->Nl, Ep = p->Ep, L = Np + Nl, E = (int)ob_kf.size();
     H.cov.assign((size_t)K * K, 0);
-    const bool gt = getenv("PLBA_PREP_TIMING") != nullptr;
+    const bool gt = (p->opt.diag & PLBA_DIAG_TIMING) != 0;
     auto g0 = std::chrono::steady_clock::now();
     auto glap = [&](const char* what) { if (!gt) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[prepare]   groups: %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - g0).count()); g0 = t; };
     // group size: a workgroup step takes 32 points or 16 lines.
@@ -511,7 +514,7 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
             }
         }
         steps = std::min(steps, 16);
-        if (const char* e = getenv("PLBA_LM_STEPS")) { const int v = atoi(e); if (v >= 1 && v <= 16) steps = v; }
+        if (p->opt.lm_group_steps >= 1 && p->opt.lm_group_steps <= 16) steps = p->opt.lm_group_steps;      // (measurement knob)
     }
     const int gpt = 32 * steps, gln = 16 * steps;
     // ---- phase 1 -----------------------------------------------------------------------------------------------------------------------
@@ -656,7 +659,7 @@ static int prepare(plba_problem* p) {
     for (int e = 0; e < Ep; ++e) if (p->po_pt[e] >= Np) FAIL(p, PLBA_ERR_INVALID, "point observation %d refers to point %d of %d", e, p->po_pt[e], Np);
     for (int e = 0; e < El; ++e) if (p->lo_ln[e] >= Nl) FAIL(p, PLBA_ERR_INVALID, "line observation %d refers to line %d of %d", e, p->lo_ln[e], Nl);
     if ((int)p->level.size() != E) p->level.assign(E, 0);
-    const bool ptime = getenv("PLBA_PREP_TIMING") != nullptr;
+    const bool ptime = (p->opt.diag & PLBA_DIAG_TIMING) != 0;
     auto pt0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (!ptime) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[prepare] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - pt0).count()); pt0 = t; };
     // ---- pose-side index map: non-fixed vertices by ascending id ----------------
@@ -685,10 +688,23 @@ static int prepare(plba_problem* p) {
     // per LM trial, record-based | fused): configs[0] 9 k observations 0.074 | 0.069, configs[1] 52 k 0.130 | 0.124, configs[2] 103 k
     // 0.179 | 0.169, configs[4] 1.05 M 0.695 | 0.453.  Below the threshold the record-based passes stay: windows of that size are the
     // reference's real ones (12 keyframes, tracks longer than a group's window of 8, which do not fit anyway).  2: whenever the structure fits
-    int lm_min_obs = 40000;
-    if (const char* e = getenv("PLBA_LM_MIN_OBS")) lm_min_obs = atoi(e);
-    const bool lm_cand = p->opt.lm_fused != 0 && (p->opt.lm_fused >= 2 || E >= lm_min_obs) && !p->lm_disable && E > 0 && p->opt.chain_elim && p->opt.use_mfma
-                         && p->opt.factor_block != 64 && lm_structure_fits(p, lm_start);
+    const int lm_min_obs = p->opt.lm_fused_min_obs;
+    // A sharded run decides from GLOBAL quantities: the window's observation count against the threshold and whether
+    // EVERY rank's landmarks fit the groups — one all-reduce (sum) of [E, "does not fit here"] — so that the ranks of one window cannot
+    // take different landmark paths (the collective sequence would still match; nothing tested such a mixed run).
+    bool lm_fits = p->opt.lm_fused != 0 && !p->lm_disable && E > 0 && p->opt.chain_elim && p->opt.use_mfma && p->opt.factor_block != 64 && lm_structure_fits(p, lm_start);
+    long E_window = E;
+    if (p->world > 1) {
+        std::vector<double> vote = {(double)E, lm_fits ? 0.0 : 1.0};
+        DArr<double> dvote;
+        HIPCK(p, dvote.upload(vote));
+        if (int xrc = p->xfn(p->xuser, dvote.p, vote.size(), 0, (void*)p->stream)) FAIL(p, PLBA_ERR_EXCHANGE, "all-reduce callback failed (%d)", xrc);
+        HIPCK(p, plba_stream_wait(p->stream));
+        HIPCK(p, plba_d2h(p, vote.data(), dvote.p, vote.size() * 8));
+        E_window = (long)vote[0];
+        lm_fits = vote[1] == 0.0;
+    }
+    const bool lm_cand = lm_fits && (p->opt.lm_fused >= 2 || E_window >= lm_min_obs);
     // keyframe-major record positions (stable: landmark order inside a keyframe), in EREC_UNIT = 64-byte units: a point
     // record takes one unit, a line record two, packed back to back (plba_math.h)
     p->ob_pos.assign(lm_cand ? 0 : E, 0);
@@ -991,7 +1007,7 @@ static int prepare(plba_problem* p) {
                 if (ptime) fprintf(stderr, "[prepare]   chain segments of %d: %d dense dims, %d tiles, band %d -> %d launches (cost %.1f)\n", seg, pd, T, hb, launches, cost);
                 if (cost < best_cost) { best_cost = cost; best_seg = seg; p->seg_launch_est = launches; }
             }
-            if (const char* e = getenv("PLBA_CHAIN_SEG")) { const int v = atoi(e); if (v >= 1 && v <= CHAIN_SEG) best_seg = v; }      // (measurement knob)
+            if (p->opt.chain_seg >= 1 && p->opt.chain_seg <= CHAIN_SEG) best_seg = p->opt.chain_seg;      // (measurement knob)
             const int SEG = best_seg;
             const std::vector<char> is_sep = separators(SEG);
             std::vector<int32_t> cidx, epos, seg_start, seg_col, pidx, ppos, pslot, slotcol((size_t)npos * CHAIN_NSLOT, -1);
@@ -1175,6 +1191,7 @@ static int prepare(plba_problem* p) {
     p->lm_ok = false;
     memset(&p->lv, 0, sizeof p->lv);
     if (lm_cand && !p->chain_ok) {      // the fused passes assemble through the structural list of the chain path: rebuild for the record-based passes
+        HostPool::get().finish();      // the asynchronous table fill reads LH, which the nested call clears: join it first
         p->lm_disable = true;
         const int rc2 = prepare(p);
         p->lm_disable = false;
@@ -1283,8 +1300,7 @@ static int prepare(plba_problem* p) {
                 if (r >= 0 && c >= 0) hbt = std::max(hbt, std::abs(r / 32 - c / 32));
             }
             for (int g = 0; g < cv.nseg; ++g) if (hsegcol[2 * g + 1] > hsegcol[2 * g]) hbt = std::max(hbt, (hsegcol[2 * g + 1] - 1) / 32 - hsegcol[2 * g] / 32);
-            const char* twin_env = getenv("PLBA_TWIN_MAX_T");      // experiments: the longest system the twin form takes (default: below the in-LDS threshold)
-            const int twin_max_t = twin_env ? atoi(twin_env) : TWIN_MAX_TILES;
+            const int twin_max_t = p->opt.twin_max_tiles > 0 ? p->opt.twin_max_tiles : TWIN_MAX_TILES;      // (experiments: the longest system the twin form takes; default: below the in-LDS threshold)
             const bool twin_pref = p->opt.band_solve == 1 && T <= twin_max_t;
             if (!twin_pref && T >= (p->opt.band_solve >= 2 ? 8 : BAND_MIN_TILES) && band_lds_bytes(cv.Pdpad) <= 160 * 1024 && hbt <= BAND_HB) {      // band_solve = 2 (tests): in LDS from 8 tiles on
                 BandView& bv = p->bandv;
@@ -1685,11 +1701,11 @@ static int lm_enqueue_solve_and_trial(plba_problem* p) {
 }
 
 // the count the trial launch's pose-side blocks wait for: every chain segment of every k_lm_trial launch so far (lead_wait).
-// PLBA_TEST_LEAD_WAIT_FAIL (fault injection, tests/test_lm_fused.py): a count that is never reached — the wait must run into its bound,
+// options.diag bit 2 (fault injection, tests/test_lm_fused.py): a count that is never reached — the wait must run into its bound,
 // set Ctrl::sync_fail and fail the call; it must not hang the queue.
 static unsigned lm_back_target(plba_problem* p) {
     const unsigned t = (++p->back_epoch) * (unsigned)std::max(p->cv.nseg, 1);
-    return getenv("PLBA_TEST_LEAD_WAIT_FAIL") ? t + 1000u : t;
+    return (p->opt.diag & PLBA_DIAG_LEAD_WAIT_FAIL) ? t + 1000u : t;
 }
 static void lm_chi_sync(plba_problem* p) {
     if (p->lm_ok && p->lm_chi_dirty) launch_lm_chi_sync(p->dv, p->lv, p->stream);
@@ -1749,7 +1765,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
                 MARK(p, 9);
                 if (sharded) {      // [chi2, landmark part of the scale] become global; every rank then takes the same decision
                     launch_reduce_n(d, owns_pose_edges(p), p->d_red.p, p->lv.ngrp, s);
-                    if ((rc = exchange(p, p->d_red.p, 2, 0))) return rc;
+                    if ((rc = exchange(p, p->d_red.p, 4, 0))) return rc;      // [chi2, scale, (max diag: unused here), in-launch wait failed on some rank]
                     launch_decide(d, lp, p->d_red.p, false, p->d_mail, seq, s);
                 } else launch_decide_n(d, lp, p->d_red.p, p->lv.ngrp, p->d_mail, seq, s);
                 MARK(p, 10);
@@ -1795,6 +1811,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
         st.iterations++;
         if (qmax == lp.max_trials || rho == 0 || !std::isfinite(lambda)) { ok = false; st.stop_reason = 1; }
     }
+    bool spec_unconsumed = p->lm_spec;      // abort / Terminate right after an accepted step: the gated launches of the next system are still in the stream
     p->lm_spec = false;
     for (int it = 0; it < max_iters && !(abort_flag && *abort_flag) && ok && !p->lm_ok; ++it) {
         if ((rc = enqueue_linearize(p, it == 0, it))) return rc;
@@ -1894,7 +1911,9 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
         st.iterations++;
         if (qmax == lp.max_trials || rho == 0 || !std::isfinite(lambda)) { ok = false; st.stop_reason = 1; }
     }
+    spec_unconsumed = spec_unconsumed || p->spec_lin || p->spec_hll;
     p->spec_lin = false; p->spec_hll = false;      // an unconsumed one (abort / stop right after an accepted step) only refreshed the records of the current state
+    if (spec_unconsumed) HIPCK(p, plba_stream_wait(s));      // the call returns with its stream drained (plba_stats.ms_total, plba.h)
     if (p->opt.profile == 1 && fact_samples > 0) st.ms_phase[1] = fact_sampled_ms / fact_samples * st.trials;      // sampled trials scaled to all
     if (abort_flag && *abort_flag && st.stop_reason == 0 && st.iterations < max_iters) st.stop_reason = 2;
     // trace + stats
@@ -2107,7 +2126,6 @@ int plba_restore_state(plba_problem* p) {
 
 int plba_marginalize(plba_problem* p, int first_kf, int max_edges, plba_prior* out) {
     if (!p || !out) return PLBA_ERR_INVALID;
-    if (p->opt.whiten_marg_factors) FAIL(p, PLBA_ERR_INVALID, "whiten_marg_factors = 1 is not implemented: only the reference's unweighted factors (IMU/marginalization.cpp:67)");
     int rc = prepare(p);
     if (rc) return rc;
     HIPCK(p, hipSetDevice(p->device));
@@ -2116,7 +2134,6 @@ int plba_marginalize(plba_problem* p, int first_kf, int max_edges, plba_prior* o
 int plba_marginalize_factors(plba_problem* p, int n_imu, const int32_t* imu_edges, int n_pt, const int32_t* point_edges,
                              int n_ln, const int32_t* line_edges, int use_prior, int n_drop, const int32_t* drop_vid, plba_prior* out) {
     if (!p || !out || n_imu < 0 || n_pt < 0 || n_ln < 0 || n_drop < 0) return PLBA_ERR_INVALID;
-    if (p->opt.whiten_marg_factors) FAIL(p, PLBA_ERR_INVALID, "whiten_marg_factors = 1 is not implemented: only the reference's unweighted factors (IMU/marginalization.cpp:67)");
     int rc = prepare(p);
     if (rc) return rc;
     HIPCK(p, hipSetDevice(p->device));
@@ -2229,7 +2246,10 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
         std::vector<double> h; HIPCK(p, fetch(d.erec, ((size_t)p->Ep + 2 * (size_t)p->El) * EREC_UNIT, h));
         if (w == "err_pt") { v.resize((size_t)p->Ep * 2); for (int e = 0; e < p->Ep; ++e) { const size_t o = (size_t)p->ob_pos[e] * EREC_UNIT; v[2 * (size_t)e] = h[o + EREC_PT_E0]; v[2 * (size_t)e + 1] = h[o + EREC_PT_E0 + 1]; } }      // 64-byte point record
         else { v.assign((size_t)p->El * 3, 0.0); for (int e = 0; e < p->El; ++e) { const size_t o = (size_t)p->ob_pos[p->Ep + e] * EREC_UNIT; v[3 * (size_t)e] = h[o + 13]; v[3 * (size_t)e + 1] = h[o + 14]; } }
-    } else if (w == "erec") { HIPCK(p, fetch(d.erec, ((size_t)p->Ep + 2 * (size_t)p->El) * EREC_UNIT, v)); }
+    } else if (w == "erec") {
+        if (p->lm_ok) FAIL(p, PLBA_ERR_STATE, "\"erec\": the fused landmark passes keep no record table");
+        HIPCK(p, fetch(d.erec, ((size_t)p->Ep + 2 * (size_t)p->El) * EREC_UNIT, v));
+    }
     else if (w == "stamps") { HIPCK(p, fetch(d.maxd_part, 80, v)); }
     else if (w == "dbgbuf") { HIPCK(p, fetch(d.dbgbuf, 128, v)); }
     else if (w == "pose_dim") v = {(double)p->P};

@@ -1307,7 +1307,9 @@ __global__ __launch_bounds__(256) void k_prior(DevBuf d, int state) { prior_bloc
 
 // -------------------------------------------------------------------------------------------------
 // K8: reductions and LM control (single workgroup, fixed summation order)
-// red[0] = activeRobustChi2 (local), red[1] = landmark part of computeScale (local), red[2] = max |Hll_jj| (local)
+// red[0] = activeRobustChi2 (local), red[1] = landmark part of computeScale (local), red[2] = max |Hll_jj| (local),
+// red[3] = 1 when an in-launch wait of THIS rank ran into its bound (Ctrl::sync_fail; only rank 0 has waiters): summed over the ranks with
+// the trial's [chi2, scale], so that every rank fails the call together instead of the others entering the next all-reduce alone
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reduce(DevBuf d, int nblk_edges, int nblk_lm, int pose_edges, double* red) {
     __shared__ double s4[4];
@@ -1321,7 +1323,7 @@ __global__ __launch_bounds__(256) void k_reduce(DevBuf d, int nblk_edges, int nb
     double C = block_sum_256(c, s4);
     double S = block_sum_256(sc, s4);
     double Mx = block_max_256(md, s4);
-    if (threadIdx.x == 0) { red[0] = C; red[1] = S; red[2] = Mx; }
+    if (threadIdx.x == 0) { red[0] = C; red[1] = S; red[2] = Mx; red[3] = d.ctrl->sync_fail ? 1.0 : 0.0; }
 }
 
 // diagonal of the pose-side Hessian held by this rank: pose-side edges (Himu) + sum_e Jp^T w Jp (kfdiag);
@@ -1420,6 +1422,7 @@ DEV void decide_body(const DevBuf& d, const LmParams& lp, double* red, int fused
     }
     (void)s4;
     if (threadIdx.x == 0) {
+    if (!fused && red[3] != 0.0) c->sync_fail = 1;      // sharded runs: some rank's in-launch wait failed (k_reduce, all-reduced)
     double tempChi = red[0];
     if (!c->solver_ok) tempChi = 1.7976931348623157e308;
     double scale = SP + red[1];

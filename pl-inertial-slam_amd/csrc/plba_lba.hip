@@ -799,7 +799,7 @@ int plba_lba_visual(plba_problem* p, const plba_lba_options* opt, int K, const d
     const unsigned long long seq0 = p->mail_seq;      // sequence numbers go on from the problem's: never one the mailbox has held before
     p->mail_seq += (unsigned long long)std::max(opt->max_iters, 0) + 1;
 
-    const bool ltime = getenv("PLBA_PREP_TIMING") != nullptr;
+    const bool ltime = (p->opt.diag & PLBA_DIAG_TIMING) != 0;
     if (ltime) HIPCK(p, plba_stream_wait(s));
     const auto lt0 = std::chrono::steady_clock::now();
     auto grid = [](size_t n, int b) { return dim3((unsigned)((n + b - 1) / b)); };

@@ -998,7 +998,7 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
         if (ob + nimu + pb > 0)
             hipLaunchKernelGGL(k_marg_factors, dim3(ob + nimu + pb), dim3(64), 0, s, d, state, dobs.p, nobs, ob, dimu.p, nimu, prior_row, dvcol.p, dJ.p, dr.p, R);
     }
-    if (getenv("PLBA_MARG_DEBUG")) {      // the stacked Jacobian and residual, for an extended-precision evaluation of the whole step
+    if (p->opt.diag & PLBA_DIAG_MARG_DUMP) {      // the stacked Jacobian and residual, for an extended-precision evaluation of the whole step
         p->marg_dbg.assign(4 + (size_t)R * pos + R, 0.0);
         p->marg_dbg[0] = R; p->marg_dbg[1] = pos; p->marg_dbg[2] = m; p->marg_dbg[3] = n;
         PLBA_HIPCK(p, plba_d2h(p, p->marg_dbg.data() + 4, dJ.p, (size_t)R * pos * 8));

@@ -21,7 +21,7 @@ struct DevPool {
     std::mutex mu;
     std::map<std::pair<int, size_t>, std::vector<void*>> free_;     // (device, size class) -> blocks
     size_t cached = 0;
-    size_t n_malloc = 0, n_reuse = 0;      // statistics (PLBA_PREP_TIMING prints them)
+    size_t n_malloc = 0, n_reuse = 0;      // statistics (options.diag & PLBA_DIAG_TIMING prints them)
     static size_t size_class(size_t bytes) { size_t c = 4096; while (c < bytes) c <<= 1; return c; }
     hipError_t get(size_t bytes, void** out, size_t* cls) {
         int dev = 0;
@@ -184,7 +184,7 @@ struct plba_problem {
     bool spec_lin = false;
     bool lin_in_span = false;
     long prof_lin_launches = 0;     // profile = 2: k_linearize<true> launches whose time went into plba_stats.ms_phase[0], over the problem's life
-    std::vector<double> marg_dbg;            // PLBA_MARG_DEBUG=1: [R, pos, m, n, J (R x pos column-major), r (R)] of the last plba_marginalize* (tools/marg_exact_check.py)
+    std::vector<double> marg_dbg;            // options.diag & PLBA_DIAG_MARG_DUMP: [R, pos, m, n, J (R x pos column-major), r (R)] of the last plba_marginalize* (tools/marg_exact_check.py)
     double marg_path[5] = {0, 0, 0, 0, 0};   // last plba_marginalize*: [0] 0 = block-wise pseudo-inverse, 1 = dense eigen-decomposition of Amm; [1..4] certificate: w_max, smallest kept landmark eigenvalue, tau, smallest pivot
     bool spec_hll = false;
     bool twin_ok = false;      // two-ended multi-launch factorisation of the compact dense system (plba_dense.hip: launch_twin_cholesky)

@@ -14,8 +14,21 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def pkg():
+    """The product package.  PLBA_TEST_FORCE_FUSED=1 (read HERE, by the test harness — the library reads no environment): every problem a
+    test creates without saying otherwise takes the fused landmark passes wherever its structure fits (options.lm_fused_min_obs = 1), so
+    that the whole default-option suite exercises them on its small windows:  PLBA_TEST_FORCE_FUSED=1 pytest tests -m gpu"""
     import __graft_entry__ as g
-    return g.load_package()
+    p = g.load_package()
+    if os.environ.get("PLBA_TEST_FORCE_FUSED") == "1" and not getattr(p, "_forced_fused", False):
+        plain = p.new_problem
+
+        def forced(**opts):
+            if "lm_fused" not in opts and "lm_fused_min_obs" not in opts:
+                opts["lm_fused_min_obs"] = 1
+            return plain(**opts)
+        p.new_problem = forced
+        p._forced_fused = True
+    return p
 
 
 @pytest.fixture(scope="session")

@@ -5,14 +5,13 @@ Why: the reference thresholds the eigenvalues of the whole dropped block Amm at 
 eigenvalues 15 orders below the norm.  Forming Amm = Jm^T Jm in fp64 already perturbs those by ~macheps |Amm|: the fp64 oracle
 (which, like the reference, forms Amm and diagonalises it) is itself only good to 1e-4 on windows with far landmarks, so it cannot
 arbitrate there.  These values can: the stacked Jacobian J and residual r of the step (fetched from the device with
-PLBA_MARG_DEBUG=1; the same J, r the oracle's factors hold — A' agrees with the oracle to 1e-11 on the near-landmark cases) are
+options.diag bit 1; the same J, r the oracle's factors hold — A' agrees with the oracle to 1e-11 on the near-landmark cases) are
 taken as exact inputs, and A = J^T J, the eigen-decomposition of Amm, the thresholded pseudo-inverse, the Schur complement A', b'
 and r0^T r0 = b'^T A'^+ b' are evaluated with mpmath at 40 digits.
 Cases: the far-landmark windows of tests/test_gpu_parity.py::_far_window (far = 1, 1e2, 1e3, 1e6) and a 12-keyframe window with
 tracks over the whole window (kept block n = 105), all marginalized at their initial estimates (no optimisation in between, so
 the inputs depend on the window generator alone)."""
 import os, sys
-os.environ["PLBA_MARG_DEBUG"] = "1"
 import numpy as np
 import mpmath as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -51,7 +50,7 @@ if __name__ == "__main__":
     out = {}
     for name, spec in CASES:
         w = case_window(pkg, spec)
-        g = pkg.new_problem(marg_exact=0); g.upload_window(w); pr = g.marginalize(0, 50)
+        g = pkg.new_problem(marg_exact=0, diag=2); g.upload_window(w); pr = g.marginalize(0, 50)
         d = g.debug_get("marg_J"); g.close()
         R, pos, m, n = (int(x) for x in d[:4])
         J = d[4:4 + R * pos].reshape(pos, R).T; r = d[4 + R * pos:]

@@ -54,7 +54,8 @@ def test_default_options_match_reference_constants(pkg):
     o = pkg.abi.Lib(g.HIP_LIB, "plba_").default_options()
     assert (o.tau, o.max_trials, o.marg_eps) == (1e-5, 10, 1e-8)          # g2o LM defaults; IMU/marginalization.h:99
     assert o.good_step_lower == pytest.approx(1 / 3) and o.good_step_upper == pytest.approx(2 / 3)
-    assert o.fix_line_position_jacobian == 0 and o.whiten_marg_factors == 0
+    assert o.fix_line_position_jacobian == 0 and not hasattr(o, "whiten_marg_factors")
+    assert (o.lm_fused, o.lm_fused_min_obs, o.lm_group_steps, o.chain_seg, o.twin_max_tiles, o.diag) == (1, 40000, 0, 0, 0, 0)
 
 
 def test_product_package_never_imports_the_oracle():

@@ -27,7 +27,7 @@ def shim(pkg, hip_lib_path):
            "-I", os.path.join(pkgdir, "csrc"), src, "-o", so, "-L", pkgdir, "-lplba_hip", "-Wl,-rpath," + pkgdir]
     subprocess.run(cmd, check=True, capture_output=True)
     lib = C.CDLL(so)
-    for f in ("shim_se3_exp", "shim_se3_log", "shim_se3_oplus", "shim_se3_inverse_mul", "shim_se3_vertex_io", "shim_eval_se3_edge", "shim_eval_edge_se3"):
+    for f in ("shim_se3_exp", "shim_se3_log", "shim_se3_oplus", "shim_se3_inverse_mul", "shim_se3_vertex_io", "shim_eval_se3_edge", "shim_eval_edge_se3", "shim_lstsq3"):
         getattr(lib, f).restype = None
     return lib
 
@@ -360,3 +360,24 @@ def test_edge_se3_jacobians_are_the_derivatives_of_its_error(pkg, orc, shim):
                 lib.orc_se3_edge_error(_d(Xi if which else Xm), _d(Xm if which else Xj), _d(Z), _d(em))
                 Jn[:, c] = (ep - em) / (2 * h)
             assert np.abs(Jan - Jn).max() < 1e-7, which
+
+
+def test_lstsq3_keeps_small_singular_values_and_truncates_noise(shim):
+    """plba_vio::lstsq3 = JacobiSVD(A).solve(b) of tryVioInit's gravity / accelerometer-bias systems (src/mapHandler.cpp:4896, 4940).
+    ADVICE r03: through A^T A a singular value below sqrt(eps) * sigma_max is rounding noise — with cond(A) = 1e9 it was inverted as
+    if it were data.  The one-sided Jacobi on A resolves it (relative accuracy) and truncates only at Eigen's threshold."""
+    rng = np.random.default_rng(11)
+    rows = 30
+    U, _ = np.linalg.qr(rng.normal(size=(rows, 3)))
+    W, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    for sig, what in (([1.0, 1e-3, 1e-9], "cond 1e9, full rank"), ([1.0, 0.5, 1e-18], "numerically rank 2: the third direction must be dropped"),
+                      ([3.0, 2.0, 1.0], "well conditioned")):
+        A = (U * np.array(sig)) @ W.T
+        xt = rng.normal(size=3)
+        b = A @ xt + 1e-12 * rng.normal(size=rows)
+        x = np.zeros(3)
+        shim.shim_lstsq3(rows, _d(np.ascontiguousarray(A)), _d(b), _d(x))
+        ref = np.linalg.lstsq(A, b, rcond=rows * np.finfo(float).eps)[0]      # SVD, the same truncation rule
+        assert np.abs(x - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), what
+        if sig[2] == 1e-18:
+            assert np.abs(x).max() < 10.0      # a direction at rounding level inverted as data would give ~1e6

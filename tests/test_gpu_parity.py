@@ -300,35 +300,42 @@ def test_observation_culling_flags_match_the_oracle(pkg, orc, hip):
 
 def test_rejected_trials_with_imu_edges(pkg, orc, hip):
     """retries on the default path (chain elimination, queued-ahead linearisation gated on the device-side decision, double
-    buffered IMU accumulators): a rejected step must leave records and accumulators of the current state untouched"""
+    buffered IMU accumulators): a rejected step must leave records and accumulators of the current state untouched.
+    lambda = 1e-6 on landmarks perturbed by a metre: the damped systems are conditioned ~1e10 and fp64 solvers agree to a few digits
+    only (first trial: oracle 588843, record-based passes 588734, fused passes 588718.5, EXACT 588718.7), so the values are held to the
+    QUAD-precision run of the same window (tests/golden/fused_overshoot_quad.json, case rejected_small) with the fp64 oracle's own
+    distance from it as the yardstick; what must agree exactly is the control flow.  (Round 3 compared against the fp64 oracle and
+    the two device paths with each other at 1e-7: under the forced-fused suite that failed — the fused passes are the MORE accurate
+    of the three, their square-root form of the Schur complement does not cancel.)"""
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fused_overshoot_quad.json")) as f:
+        fx = json.load(f)["rejected_small"]
     w = pkg.window.make_window(10, 150, 30, imu=True, seed=77)
     w["points"] = w["points"] + np.random.default_rng(1).normal(size=w["points"].shape) * 1.0
-    g, o = _pair(pkg, orc, w, user_lambda_init=1e-6)
-    sg, so = g.optimize(6), o.optimize(6)
-    tg, to = g.trace(), o.trace()
-    assert any(not r["accepted"] for r in to), "the scenario is meant to produce rejected trials"
-    assert [r["accepted"] for r in tg] == [r["accepted"] for r in to]
-    assert [(r["iteration"], r["trial"]) for r in tg] == [(r["iteration"], r["trial"]) for r in to]
-    # lambda = 1e-6 on landmarks perturbed by a metre: the damped systems are conditioned ~1e10, so the two solvers agree to
-    # a few digits only (the first trial already: 588734 vs 588843); what must agree exactly is the control flow
-    assert tg[0]["chi2_current"] == pytest.approx(to[0]["chi2_current"], rel=1e-10)      # same start
-    for a, b in zip(tg, to):
-        assert a["lam"] == pytest.approx(b["lam"], rel=3e-2)
-        assert a["chi2_current"] == pytest.approx(b["chi2_current"], rel=3e-2)
-    # rejected steps restore the state (chi2_current unchanged) and raise lambda
-    for a, b in zip(tg[:-1], tg[1:]):
-        if not a["accepted"] and b["iteration"] == a["iteration"]:
-            assert b["lam"] > a["lam"] and b["chi2_current"] == a["chi2_current"]
-    assert sg.chi2_final <= sg.chi2_initial
-    g.close(); o.close()
-    # the chain path and the dense path solve the same first (identical) system to many more digits than either agrees with
-    # the CPU solver; later trials start from states that already differ in the fourth digit
-    g1 = pkg.new_problem(user_lambda_init=1e-6); g1.upload_window(w)
-    g0 = pkg.new_problem(user_lambda_init=1e-6, chain_elim=0); g0.upload_window(w)
-    g1.optimize(6); g0.optimize(6)
-    assert g1.trace()[0]["chi2_trial"] == pytest.approx(g0.trace()[0]["chi2_trial"], rel=1e-7)
-    assert [r["accepted"] for r in g1.trace()] == [r["accepted"] for r in g0.trace()]
-    g1.close(); g0.close()
+    assert (int(w["meta"]["Ep"]), int(w["meta"]["El"])) == (fx["meta"]["Ep"], fx["meta"]["El"])
+    q, o = fx["trace"], fx["trace_fp64_oracle"]
+    dec = lambda tr: [(r["iteration"], r["trial"], r["accepted"]) for r in tr]
+    assert any(not r["accepted"] for r in q), "the scenario is meant to produce rejected trials"
+
+    def far(tr):      # largest relative distance of lambda / chi2 from the exact run
+        return max(abs(a[k] - b[k]) / abs(b[k]) for a, b in zip(tr, q) for k in ("lam", "chi2_current", "chi2_trial"))
+    yard = far(o)
+    for opts in (dict(), dict(chain_elim=0)):
+        g = pkg.new_problem(user_lambda_init=1e-6, **opts); g.upload_window(w)
+        sg = g.optimize(6)
+        tg = g.trace()
+        assert dec(tg) == dec(q), opts
+        assert tg[0]["chi2_current"] == pytest.approx(q[0]["chi2_current"], rel=1e-10)      # same start
+        assert far(tg) <= 4 * yard, (opts, far(tg), yard)
+        assert abs(tg[0]["chi2_trial"] - q[0]["chi2_trial"]) <= abs(o[0]["chi2_trial"] - q[0]["chi2_trial"])      # the first damped solve: no worse than the CPU fp64 solver
+        # rejected steps restore the state (chi2_current unchanged) and raise lambda
+        for a, b in zip(tg[:-1], tg[1:]):
+            if not a["accepted"] and b["iteration"] == a["iteration"]:
+                assert b["lam"] > a["lam"] and b["chi2_current"] == a["chi2_current"]
+        assert sg.chi2_final <= sg.chi2_initial
+        kf = g.get_keyframes()
+        assert max(float(np.abs(kf[k] - np.asarray(fx["kf"][k])).max()) for k in fx["kf"]) <= 4 * max(fx["fp64_oracle_abs_diff"].values())
+        g.close()
 
 
 def _overshoot_window(pkg, seed, **kw):

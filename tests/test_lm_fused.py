@@ -110,9 +110,10 @@ def test_structure_that_does_not_fit_falls_back(pkg, orc, hip):
 
 
 def test_default_takes_the_fused_passes_from_40k_observations(pkg, hip):
-    small = pkg.new_problem(); small.upload_window(pkg.window.make_config(3, scale=0.1)); small.optimize(1)
+    small = pkg.new_problem(lm_fused=1, lm_fused_min_obs=40000); small.upload_window(pkg.window.make_config(3, scale=0.1)); small.optimize(1)
     assert small.debug_get("lm_fused")[0] == 0
     small.close()
+    assert pkg.hip_lib().default_options().lm_fused_min_obs == 40000
     big = pkg.new_problem(); big.upload_window(pkg.window.make_config(2)); big.optimize(1)      # BASELINE configs[1]: 52 k observations
     assert big.debug_get("lm_fused")[0] == 1
     big.close()
@@ -138,17 +139,14 @@ def test_cached_edge_chi2_after_the_fused_passes(pkg, orc, hip):
     g.close(); o.close()
 
 
-def test_in_launch_wait_fails_loudly_when_its_condition_never_comes(pkg, hip, monkeypatch):
+def test_in_launch_wait_fails_loudly_when_its_condition_never_comes(pkg, hip):
     """the trial launch's pose-side blocks wait, inside the launch, for the chain segments in front of them (lead_wait).  Fault injection:
     a count that is never reached.  The wait is bounded — it must run into its bound, report through Ctrl::sync_fail and fail the call with
     PLBA_ERR_DEVICE; the queue must stay usable (the next call, without the fault, succeeds)."""
     w = pkg.window.make_window(8, 200, 40, imu=True, seed=0xFA11)
-    g = pkg.new_problem(lm_fused=2); g.upload_window(w)
-    g.optimize(1)
-    monkeypatch.setenv("PLBA_TEST_LEAD_WAIT_FAIL", "1")
+    g = pkg.new_problem(lm_fused=2, diag=4); g.upload_window(w)      # PLBA_DIAG_LEAD_WAIT_FAIL
     with pytest.raises(pkg.abi.PlbaError, match="waited for the chain back-substitution"):
         g.optimize(2)
-    monkeypatch.delenv("PLBA_TEST_LEAD_WAIT_FAIL")
     g.close()
     g2 = pkg.new_problem(lm_fused=2); g2.upload_window(w)
     st = g2.optimize(3)

@@ -159,14 +159,12 @@ def test_prior_edge_error_and_chained_marginalization(orc, pkg):
     q.close()
 
 
-def test_whitened_factors_are_rejected_not_ignored(pkg, orc):
-    w = pkg.window.make_window(5, 40, 8, imu=True, seed=5)
-    p = orc.new_problem(whiten_marg_factors=1)
-    p.upload_window(w)
-    p.optimize(1)
-    with pytest.raises(pkg.abi.PlbaError, match="not implemented"):
-        p.marginalize(0, 50)
-    p.close()
+def test_there_is_no_whitening_option(pkg, orc):
+    """SURVEY B-Q4: the factors enter the prior unweighted, as IMU/marginalization.cpp:67 has them.  Round 3 declared a
+    `whiten_marg_factors` option and rejected it at run time; it is gone from include/plba.h (an option that cannot be set cannot be
+    silently ignored)."""
+    with pytest.raises(pkg.abi.PlbaError, match="unknown option"):
+        orc.new_problem(whiten_marg_factors=1)
 
 
 def test_oracle_against_the_extended_precision_marginalization(pkg, orc):

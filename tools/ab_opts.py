@@ -1,20 +1,18 @@
-"""A/B timing of environment knobs in ONE process (same box, same clocks): python tools/ab_env.py 3 PLBA_CHAIN_SEG=4 PLBA_CHAIN_SEG=6 PLBA_CHAIN_SEG=8
+"""A/B timing of plba_options knobs in ONE process (same box, same clocks; separate runs on a shared pool differ by +- 3 %):
+    python tools/ab_opts.py 3 chain_seg=4 chain_seg=6 chain_seg=8        (config index, then one variant per argument: k=v[,k=v...]; "-" = defaults)
 Each variant gets a fresh problem per round (the knobs are read in prepare()); rounds alternate; ms per LM trial of stage-2 iterations
-replayed from the saved post-gating state, best of 8 replays per round."""
-import os, sys, time
+replayed from the saved post-gating state, best of 8 replays per round; medians of five rounds."""
+import sys, time
 sys.path.insert(0, '.')
 import __graft_entry__ as ge
 pkg = ge.load_package()
 cfg = int(sys.argv[1])
-variants = [dict(kv.split("=") for kv in a.split(",") if kv) if a != "-" else {} for a in sys.argv[2:]]
+variants = [{k: (float(v) if "." in v or "e" in v else int(v)) for k, v in (kv.split("=") for kv in a.split(",") if kv)} if a != "-" else {} for a in sys.argv[2:]]
 w = pkg.window.make_config(cfg)
 res = {i: [] for i in range(len(variants))}
 for rnd in range(5):
     for i, v in enumerate(variants):
-        for k in list(os.environ):
-            if k.startswith("PLBA_") and k not in ("PLBA_EXTRA_FLAGS",): del os.environ[k]
-        os.environ.update(v)
-        g = pkg.new_problem(); g.upload_window(w)
+        g = pkg.new_problem(**v); g.upload_window(w)
         g.optimize(5); g.gate_outliers(); g.save_state()
         best = 1e9
         for rep in range(8):

@@ -6,6 +6,7 @@
 #include "plba_g2o/types_six_dof_expmap.h"
 #include "plba_g2o/g2otypes.h"
 #include "plba_g2o/types_slam3d.h"
+#include "plba_g2o/vio_init.h"
 
 using namespace g2o;
 
@@ -190,6 +191,11 @@ void shim_eval_edge_se3(const double* Xi12, const double* Xj12, const double* Z1
     e.computeError(); e.linearizeOplus();
     for (int i = 0; i < 6; ++i) err6[i] = e.error()[i];
     for (int i = 0; i < 36; ++i) { Ji36[i] = e.jacobianOplusXi()[i]; Jj36[i] = e.jacobianOplusXj()[i]; }
+}
+
+// plba_vio::lstsq3 (include/plba_g2o/vio_init.h): JacobiSVD(A).solve(b) of src/mapHandler.cpp:4896, 4940
+void shim_lstsq3(int rows, const double* A, const double* b, double* x3) {
+    plba_vio::lstsq3(std::vector<double>(A, A + 3 * (size_t)rows), std::vector<double>(b, b + rows), x3);
 }
 
 }  // extern "C"

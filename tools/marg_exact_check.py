@@ -1,9 +1,8 @@
 """Who is right where the device's dense pseudo-inverse and the oracle's differ (far landmarks, eigenvalues of Amm around the
-1e-8 threshold)?  The stacked Jacobian J and residual r of the marginalization step are fetched from the device (PLBA_MARG_DEBUG=1),
+1e-8 threshold)?  The stacked Jacobian J and residual r of the marginalization step are fetched from the device (options.diag bit 1),
 A = J^T J, the eigen-decomposition of Amm, the thresholded pseudo-inverse and the Schur complement are evaluated with mpmath at 40
 digits, and both fp64 results are compared with that.  Also prints the eigenvalues of Amm next to the threshold."""
 import os, sys
-os.environ["PLBA_MARG_DEBUG"] = "1"
 import numpy as np
 import mpmath as mp
 sys.path.insert(0, ".")
@@ -45,7 +44,7 @@ def compare(w, label, iters=0):
     po = o.marginalize(0, 50); o.close()
     res = {}
     for mode in (0, 2):
-        g = pkg.new_problem(marg_exact=mode); g.upload_window(w)
+        g = pkg.new_problem(marg_exact=mode, diag=2); g.upload_window(w)
         if iters: g.optimize(iters)
         res[mode] = g.marginalize(0, 50)
         if mode == 0:

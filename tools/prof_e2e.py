@@ -1,5 +1,5 @@
 """One reference-shaped BA call at configs[2] (upload + 5 iterations + gating + 10 iterations + read-back), timed phase by phase;
-PLBA_PREP_TIMING=1 adds the laps of prepare() (host structure build) on stderr."""
+`--laps` (options.diag bit 0) adds the laps of prepare() (host structure build) on stderr."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -9,7 +9,7 @@ pkg = g.load_package()
 w = pkg.window.make_config(3)
 for rep in range(4):
     t = [time.perf_counter()]
-    p = pkg.new_problem(); t.append(time.perf_counter())
+    p = pkg.new_problem(diag=1 if "--laps" in sys.argv else 0); t.append(time.perf_counter())
     p.upload_window(w); t.append(time.perf_counter())
     s1 = p.optimize(5); t.append(time.perf_counter())
     p.gate_outliers(pkg.window.CHI2_GATE); t.append(time.perf_counter())
