@@ -61,6 +61,13 @@ def _trace_dist(tr, ref):
     return d
 
 
+# measured on MI355X (round 4), |HIP - quad| on the final keyframe states / on lambda, chi2 over the trace — next to the fp64 oracle's:
+#   rej40k_c 1.1e-14 / 2.5e-13 (oracle64 1.1e-13 / 3.0e-12);  rej40k_a 1.0e-11 / 1.0e-8 (oracle64 1.5e-4 / 2.2e-2);
+#   rejected_small 2.2e-10 / 1.3e-6 (oracle64 4.0e-4 / 0.63).  The square-root form of the fused Schur pass (A' = Hpl R^-T, S -= A' A'^T)
+#   does not cancel where Hpp - Hpl D Hpl^T does.  BOUND = those x ~100, so that a regression towards the oracle's accuracy fails.
+BOUND = {"rej40k_c": (1e-9, 1e-9), "rej40k_a": (1e-9, 1e-6), "rejected_small": (1e-7, 1e-4)}
+
+
 @pytest.mark.parametrize("name", ["rej40k_c", "rej40k_a", "rejected_small"])
 def test_fused_passes_follow_the_exact_trajectory_through_rejected_trials(pkg, hip, name):
     w, fx, c = _load(pkg, name)
@@ -73,6 +80,7 @@ def test_fused_passes_follow_the_exact_trajectory_through_rejected_trials(pkg, h
     t_or, t_hip = _trace_dist(o, q), _trace_dist(tr, q)
     print("%s: |HIP - quad| %.2e (oracle64 %.2e) states, %.2e (oracle64 %.2e) trace" % (name, d_hip, d_or, t_hip, t_or))
     assert d_hip <= max(4 * d_or, 1e-9) and t_hip <= max(4 * t_or, 1e-9)
+    assert d_hip <= BOUND[name][0] and t_hip <= BOUND[name][1]
     assert st.chi2_final == pytest.approx(fx["chi2_final"], rel=max(4 * t_or, 1e-9))
 
 
@@ -88,6 +96,9 @@ def test_where_fp64_solvers_part_the_device_is_no_further_from_exact_than_the_or
     print("rej40k_b: |HIP - quad| %.2e, |oracle64 - quad| %.2e; trials in step with the exact run: HIP %d of %d, oracle64 %d" % (d_hip, d_or, n_same, len(q), n_same_or))
     assert d_hip <= 4 * d_or
     assert n_same >= n_same_or      # it follows the exact decisions at least as long as the CPU fp64 implementation does
+    # measured (round 4): the device stays in step with the exact run through all 8 trials and ends 3.9e-7 from it; the fp64 oracle
+    # leaves it at the sixth trial and ends 8.2e-2 away
+    assert n_same == len(q) and d_hip <= 1e-4
     # the first damped solve (identical inputs): the device's chi2 must be at least as close to the exact one as the oracle's
     assert abs(tr[0]["chi2_trial"] - q[0]["chi2_trial"]) <= 4 * abs(o[0]["chi2_trial"] - q[0]["chi2_trial"]) + 1e-9 * q[0]["chi2_trial"]
 
