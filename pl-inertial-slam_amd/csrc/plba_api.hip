@@ -440,12 +440,13 @@ private:
 
 // ---- fused landmark-major passes: group structure (plba_lm_dev.h) ---------------------------------------------------------------------
 // Landmarks of one kind are ordered by (first keyframe, last keyframe, index) and cut greedily into groups whose observing keyframes
-// fit a window of LMF_W; the observations are re-listed in that order (static data: measurement, weight, window slot, original
+// fit a window of LMF_W (standard groups: landmarks with at most 8 observations) or LMF_W2 = 16 (wide groups: 9 .. 16 observations —
+// round 4: the reference's 12-keyframe window with tracks over most of it); the observations are re-listed in that order (static data: measurement, weight, window slot, original
 // index), so that a group streams its inputs.  Per group and window-slot pair (p <= q) some landmark couples, one contribution to
 // the pose-pair block (kf[p], kf[q]); the gather lists hold them block by block in ascending group order (a fixed summation order).
 static bool lm_structure_fits(const plba_problem* p, const std::vector<int32_t>& lm_start) {
     if (p->K >= 65536) return false;
-    for (int s = 0; s < p->L; ++s) if (lm_start[s + 1] - lm_start[s] > LMF_W) return false;
+    for (int s = 0; s < p->L; ++s) if (lm_start[s + 1] - lm_start[s] > LMF_W2) return false;
     return true;      // (two observations of a landmark in one keyframe are refused at upload; build_lm_groups still checks and returns false)
 }
 // Three phases.  (1) serial and light: order, group boundaries and windows, offsets.  (2) the gather lists, from the windows alone: every
@@ -457,19 +458,19 @@ static void lm_fill_groups(const plba_problem* p, const std::vector<int32_t>& lm
     const int Ep = p->Ep;
     for (int gi = H.gcut[t]; gi < H.gcut[t + 1]; ++gi) {
         const LmGroup& g = H.grp[gi];
-        const int kind = g.is_line;
+        const int kind = g.kind & 1, wmax = H.wmax;
         int l = g.lm0, ob = H.span_ob0[gi];
         for (int n = H.span_at[gi]; n < H.span_end[gi]; ++n, ++l) {
             const int s = H.ordall[n];
             H.lm_slot[l] = s; H.lm_fixed[l] = p->lm_fixed[s]; H.lm_ob0[l] = ob;
             // the 8 lanes of the landmark's unit(s) ARE the window slots: lane w takes the observation made from keyframe kf[w] (its
             // offset in the landmark's range), or none (0xFF) — so a lane's camera block, operand rows and accumulators never move
-            uint8_t* w8 = &H.lm_ws8[(size_t)l * LMF_W];
-            for (int sl = 0; sl < LMF_W; ++sl) w8[sl] = 0xFF;
+            uint8_t* w8 = &H.lm_ws8[(size_t)l * wmax];
+            for (int sl = 0; sl < wmax; ++sl) w8[sl] = 0xFF;
             int nk = 0;
             for (int e = lm_start[s]; e < lm_start[s + 1]; ++e, ++ob, ++nk) {
                 int w = 0;
-                while (g.kf[w] != ob_kf[e]) ++w;      // (<= 8 window keyframes, all of the landmark's are among them)
+                while (g.kf[w] != ob_kf[e]) ++w;      // (<= 8 / 16 window keyframes, all of the landmark's are among them)
                 if (w8[w] != 0xFF) H.bad[t] = 1;      // two observations in one keyframe: not expressible
                 w8[w] = (uint8_t)nk;
                 H.ob_orig[ob] = e; H.ob_wt[ob] = ob_w[e];
@@ -498,12 +499,15 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     // the trial launch's critical path at this size) then do not share their SIMDs with a group.  tools/ab_env.py, configs[2] (1125
     // workgroup-steps incl. lines at 16 per step: 876), ms per LM trial: 2 steps 0.1722, 3 (292 groups) 0.1694, 4 (220 groups + 50 IMU edge
     // blocks + 10 chain segments on 256 CUs) 0.1561, 5 0.1585, 6 0.1611; configs[1]: 1 step 0.1200, 2 (219 groups) 0.1143, 3 0.1181.
+    int nwide_pt = 0, nwide_ln = 0;      // landmarks with more than LMF_W observations: wide groups (two units per landmark block)
+    for (int s = 0; s < L; ++s) if (lm_start[s + 1] - lm_start[s] > LMF_W) ++(s < Np ? nwide_pt : nwide_ln);
+    const bool any_wide = nwide_pt + nwide_ln > 0;
     int steps = 1;
     {
         static int cus = 0;
         if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256; }
         const int slots = 2 * cus;
-        const long wg_steps = (Np + 31) / 32 + (Nl + 15) / 16;
+        const long wg_steps = (Np - nwide_pt + 31) / 32 + (Nl - nwide_ln + 15) / 16 + (nwide_pt + 15) / 16 + (nwide_ln + 7) / 8;
         const long cap1 = std::max<long>(32, (long)(1.12 * cus) - (p->M + 1) - (p->M / 4 + 1));      // one group per CU, with room for the IMU edge blocks and the chain segments
         steps = (int)std::max<long>(1, (wg_steps + cap1 - 1) / cap1);
         if (steps > 16) {
@@ -516,7 +520,10 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
         steps = std::min(steps, 16);
         if (p->opt.lm_group_steps >= 1 && p->opt.lm_group_steps <= 16) steps = p->opt.lm_group_steps;      // (measurement knob)
     }
-    const int gpt = 32 * steps, gln = 16 * steps;
+    const int gpt = 32 * steps, gln = 16 * steps;      // (a wide group's landmark blocks take two units: half as many per step)
+    // wide groups exist only where some landmark has more than LMF_W observations; the gather buffer's layout (pair blocks per group,
+    // window slots) is the problem's: 36 / 8 when every group is standard
+    H.wmax = any_wide ? LMF_W2 : LMF_W; H.npair = H.wmax * (H.wmax + 1) / 2;
     // ---- phase 1 -----------------------------------------------------------------------------------------------------------------------
     std::vector<int32_t>& kmin = H.kmin; std::vector<int32_t>& kmax = H.kmax; std::vector<int32_t>& ord = H.ord; std::vector<int32_t>& tmp = H.tmp;
     std::vector<int32_t>& cnt = H.cnt; std::vector<int32_t>& ordall = H.ordall; std::vector<int32_t>& stamp = H.stamp;
@@ -530,11 +537,12 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     }
     glap("kmin / kmax");
     int nlm = 0, nob = 0;
-    for (int kind = 0; kind < 2; ++kind) {
-        const int s0 = kind ? Np : 0, s1 = kind ? L : Np, gmax = kind ? gln : gpt;
+    for (int kind4 = 0; kind4 < (any_wide ? 4 : 2); ++kind4) {      // points, lines; then the wide points, wide lines
+        const int kind = kind4 & 1, wide = kind4 >> 1, W = wide ? LMF_W2 : LMF_W;
+        const int s0 = kind ? Np : 0, s1 = kind ? L : Np, gmax = (kind ? gln : gpt) / (wide ? 2 : 1);
         // order by (first keyframe, last keyframe, index): two stable counting sorts; landmarks without an edge are not in the graph
         ord.clear();
-        for (int s = s0; s < s1; ++s) if (kmax[s] >= 0) ord.push_back(s);
+        for (int s = s0; s < s1; ++s) if (kmax[s] >= 0 && (lm_start[s + 1] - lm_start[s] > LMF_W) == (wide != 0)) ord.push_back(s);
         for (int pass = 0; pass < 2; ++pass) {
             const std::vector<int32_t>& key = pass ? kmin : kmax;
             std::fill(cnt.begin(), cnt.end(), 0);
@@ -548,14 +556,14 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
         size_t at = 0;
         while (at < ord.size()) {
             const int gi = (int)H.grp.size();
-            int32_t win[LMF_W];
+            int32_t win[LMF_W2];
             int nw = 0, gob = 0;
             size_t end = at;
             while (end < ord.size() && (int)(end - at) < gmax) {
                 const int s = ord[end];
                 int add = 0;
                 for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) if (stamp[ob_kf[e]] != gi) ++add;      // (a duplicate keyframe inside one landmark is caught in phase 3)
-                if (nw + add > LMF_W) break;
+                if (nw + add > W) break;
                 for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) if (stamp[ob_kf[e]] != gi) { stamp[ob_kf[e]] = gi; win[nw++] = ob_kf[e]; }
                 gob += lm_start[s + 1] - lm_start[s];
                 ++end;
@@ -563,8 +571,8 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
             std::sort(win, win + nw);
             LmGroup g;
             memset(&g, 0, sizeof g);
-            g.lm0 = nlm; g.nlm = (int32_t)(end - at); g.nw = nw; g.is_line = kind;
-            for (int q = 0; q < LMF_W; ++q) { g.kf[q] = q < nw ? win[q] : 0; g.off[q] = q < nw ? p->off_pvr[win[q]] : -1; }
+            g.lm0 = nlm; g.nlm = (int32_t)(end - at); g.nw = nw; g.kind = kind | (wide << 1);
+            for (int q = 0; q < LMF_W2; ++q) { g.kf[q] = q < nw ? win[q] : 0; g.off[q] = q < nw ? p->off_pvr[win[q]] : -1; }
             H.grp.push_back(g);
             H.span_at.push_back(base + (int32_t)at); H.span_end.push_back(base + (int32_t)end); H.span_ob0.push_back(nob);
             // ---- phase 2 for this group: its window's pose pairs and right-hand-side rows (in group order = the fixed summation order) ----
@@ -574,9 +582,9 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
                     if (g.off[pp] < 0) continue;
                     const int i = g.kf[pp], j = g.kf[q];
                     H.cov[(size_t)i * K + j] = 1; H.cov[(size_t)j * K + i] = 1;
-                    H.blk_c.push_back({(int64_t)i * K + j, gi * 36 + q * (q + 1) / 2 + pp});
+                    H.blk_c.push_back({(int64_t)i * K + j, gi * H.npair + q * (q + 1) / 2 + pp});
                 }
-                H.row_c.push_back({(int64_t)g.kf[q], gi * LMF_W + q});
+                H.row_c.push_back({(int64_t)g.kf[q], gi * H.wmax + q});
             }
             nlm += (int)(end - at); nob += gob;
             at = end;
@@ -607,7 +615,7 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     glap("gather lists");
     // ---- phase 3: the tables, group by group, on the worker pool; joined by lm_groups_finish() -------------------------------------------------
     const int ngrp = (int)H.grp.size();
-    H.lm_slot.resize(nlm); H.lm_ob0.resize(nlm + 1); H.lm_ws8.resize((size_t)nlm * LMF_W); H.lm_fixed.resize(nlm); H.ob_orig.resize(nob); H.ob_wt.resize(nob);
+    H.lm_slot.resize(nlm); H.lm_ob0.resize(nlm + 1); H.lm_ws8.resize((size_t)nlm * H.wmax); H.lm_fixed.resize(nlm); H.ob_orig.resize(nob); H.ob_wt.resize(nob);
     H.meas_pt.resize(2 * (size_t)Ep); H.meas_ln.resize(3 * (size_t)(E - Ep));
     H.lm_ob0[nlm] = nob;
     const int NT = E > 400000 ? 16 : E > 60000 ? 8 : E > 20000 ? 4 : 1;
@@ -1226,11 +1234,11 @@ static int prepare(plba_problem* p) {
         HIPCK(p, p->d_lmg_blk_ij.upload(LH.blk_ij)); HIPCK(p, p->d_lmg_blk_start.upload(LH.blk_start)); HIPCK(p, p->d_lmg_blk_src.upload(LH.blk_src));
         HIPCK(p, p->d_lmg_row_kf.upload(LH.row_kf)); HIPCK(p, p->d_lmg_row_start.upload(LH.row_start)); HIPCK(p, p->d_lmg_row_src.upload(LH.row_src));
         HIPCK(p, p->d_alist2.upload(al2)); HIPCK(p, p->d_col_gather.upload(colg));
-        HIPCK(p, p->d_lmg_part.alloc(LH.grp.size() * (size_t)LMF_PART)); HIPCK(p, p->d_ob_err.alloc(2 * (size_t)E)); HIPCK(p, p->d_lmg_chi.alloc(E));
+        HIPCK(p, p->d_lmg_part.alloc(LH.grp.size() * (size_t)(LH.npair * 36 + LH.wmax * 12))); HIPCK(p, p->d_ob_err.alloc(2 * (size_t)E)); HIPCK(p, p->d_lmg_chi.alloc(E));
         LmView& lv = p->lv;
         p->lm_hist.assign(20, 0.0);      // diagnostics: groups by number of workgroup steps (points 1..8 | lines 1..8), window widths
-        for (const LmGroup& g : LH.grp) { const int st = ((g.is_line ? 2 * g.nlm : g.nlm) + 31) / 32; p->lm_hist[(g.is_line ? 8 : 0) + std::min(std::max(st, 1), 8) - 1] += 1.0; p->lm_hist[16] += g.nw; p->lm_hist[17] += st; }
-        lv.ngrp = (int)LH.grp.size(); lv.grp = p->d_lm_grp.p; lv.lm_slot = p->d_lmg_slot.p; lv.lm_ob0 = p->d_lmg_ob0.p; lv.ob_orig = p->d_lmg_orig.p; lv.lm_ws8 = p->d_lmg_ws8.p; lv.lm_fixed_g = p->d_lmg_fixed.p; lv.ob_level_g = p->d_lmg_level.p;
+        for (const LmGroup& g : LH.grp) { const int st = (((g.kind & 1) ? 2 * g.nlm : g.nlm) * ((g.kind & 2) ? 2 : 1) + 31) / 32; p->lm_hist[((g.kind & 1) ? 8 : 0) + std::min(std::max(st, 1), 8) - 1] += 1.0; p->lm_hist[16] += g.nw; p->lm_hist[17] += st; if (g.kind & 2) p->lm_hist[18] += 1.0; }
+        lv.ngrp = (int)LH.grp.size(); lv.grp = p->d_lm_grp.p; lv.lm_slot = p->d_lmg_slot.p; lv.lm_ob0 = p->d_lmg_ob0.p; lv.ob_orig = p->d_lmg_orig.p; lv.lm_ws8 = p->d_lmg_ws8.p; lv.wmax = LH.wmax; lv.npair = LH.npair; lv.part_stride = LH.npair * 36 + LH.wmax * 12; lv.lm_fixed_g = p->d_lmg_fixed.p; lv.ob_level_g = p->d_lmg_level.p;
         lv.meas_pt = p->d_lmg_meas_pt.p; lv.meas_ln = p->d_lmg_meas_ln.p; lv.ob_wt = p->d_lmg_wt.p; lv.part = p->d_lmg_part.p; lv.ob_chi_g = p->d_lmg_chi.p; p->lm_chi_dirty = false;
         lv.nblk = (int)LH.blk_ij.size(); lv.blk_ij = p->d_lmg_blk_ij.p; lv.blk_start = p->d_lmg_blk_start.p; lv.blk_src = p->d_lmg_blk_src.p;
         lv.nrow = (int)LH.row_kf.size(); lv.row_kf = p->d_lmg_row_kf.p; lv.row_start = p->d_lmg_row_start.p; lv.row_src = p->d_lmg_row_src.p;
@@ -2256,7 +2264,7 @@ int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, s
     else if (w == "marg_path") v.assign(p->marg_path, p->marg_path + 5);
     else if (w == "prof_lin_launches") v = {(double)p->prof_lin_launches};
     else if (w == "lm_groups") v = p->lm_hist;
-    else if (w == "lm_fused") v = {(double)(p->lm_ok ? 1 : 0), (double)p->lv.ngrp, (double)p->lv.nblk};
+    else if (w == "lm_fused") v = {(double)(p->lm_ok ? 1 : 0), (double)p->lv.ngrp, (double)p->lv.nblk, p->lm_ok && p->lm_hist.size() > 18 ? p->lm_hist[18] : 0.0 /* wide groups */};
     else if (w == "marg_J") v = p->marg_dbg;
     else if (w == "dense_dim") v = {(double)(p->chain_ok ? p->cv.Pd : p->P)};
     else if (w == "band") v = {(double)(p->band_ok ? 1 : 0)};

@@ -149,11 +149,14 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
 struct Robust { int on[5]; double delta[5]; };
 
 // ---- fused landmark-major passes (plba_lm_dev.h): group structure built at upload ---------------------------------------------
-constexpr int LMF_W = 8;                              // keyframes in a group's window = observations per landmark the fused passes take
-constexpr int LMF_PART = 36 * 36 + LMF_W * 12;        // doubles a group leaves for the gather pass: 36 pose-pair blocks (p <= q, index
-                                                      // q (q + 1) / 2 + p) x 36 entries, then per window slot bp (6) | bs = Hpl D bl (6)
-struct LmGroup { int32_t lm0, nlm, nw, is_line; int32_t kf[LMF_W]; int32_t off[LMF_W]; };      // landmarks [lm0, lm0 + nlm) of the group order;
-                                                      // window keyframes (ascending) and their kf_off_pvr (-1: fixed pose)
+constexpr int LMF_W = 8;                              // keyframes in a STANDARD group's window = observations per landmark it takes
+constexpr int LMF_W2 = 16;                            // ... in a WIDE group's (round 4): landmarks seen from 9 .. 16 keyframes — the reference's own 12-keyframe
+                                                      // sliding window (include/mapHandler.h:217) with tracks over most of it.  A wide landmark takes two 8-lane
+                                                      // units (window slots 0 - 7 | 8 - 15), plba_lm_dev.h
+// A group leaves for the gather pass: npair pose-pair blocks (p <= q, index q (q + 1) / 2 + p) x 36 entries, then per window slot bp (6) |
+// bs = Hpl D bl (6).  npair / the stride are the problem's (LmView): 36 / 8 slots when every group is standard, 136 / 16 slots otherwise.
+struct LmGroup { int32_t lm0, nlm, nw, kind /* bit 0: lines, bit 1: wide */; int32_t kf[LMF_W2]; int32_t off[LMF_W2]; };      // landmarks [lm0, lm0 + nlm) of the group
+                                                      // order; window keyframes (ascending) and their kf_off_pvr (-1: fixed pose)
 struct LmView {
     int ngrp;
     const LmGroup* grp;
@@ -161,21 +164,22 @@ struct LmView {
     const int32_t* lm_ob0;        // group order (+ 1): first observation of each landmark in the group-ordered observation arrays
     const int32_t* ob_orig;       // group order -> unified observation index (ob_level, ob_chi2)
     double* ob_chi_g;             // E, GROUP order: the cached per-observation chi2 the fused passes leave (coalesced; k_lm_chi_sync scatters it into ob_chi2 for the gating / culling / read-back that follow a call)
-    const uint8_t* lm_ws8;        // group order, LMF_W per landmark: per window slot, the offset (in the landmark's observation range) of the observation made from that keyframe, 0xFF = none
+    int wmax, npair, part_stride; // 8 / 36 / 36 * 36 + 8 * 12 when every group is standard; 16 / 136 / 136 * 36 + 16 * 12 when some are wide
+    const uint8_t* lm_ws8;        // group order, wmax per landmark: per window slot, the offset (in the landmark's observation range) of the observation made from that keyframe, 0xFF = none
     const uint8_t* lm_fixed_g;    // group order copy of lm_fixed
     uint8_t* ob_level_g;          // group order copy of ob_level (refreshed whenever the levels change: launch_lm_level_sync)
     const double* meas_pt;        // 2 per point observation (group order: points first, [0, Ep))
     const double* meas_ln;        // 3 per line observation ([Ep, E))
     const double* ob_wt;          // inv_sigma2
-    double* part;                 // ngrp x LMF_PART
+    double* part;                 // ngrp x part_stride
     int nblk;                     // pose-pair blocks some landmark couples (both keyframes free)
     const int32_t* blk_ij;        // i | j << 16  (i <= j)
     const int32_t* blk_start;     // nblk + 1
-    const int32_t* blk_src;       // contributing (group * 36 + pair index), ascending group
+    const int32_t* blk_src;       // contributing (group * npair + pair index), ascending group
     int nrow;                     // free keyframes with observations
     const int32_t* row_kf;
     const int32_t* row_start;     // nrow + 1
-    const int32_t* row_src;       // contributing (group * LMF_W + slot)
+    const int32_t* row_src;       // contributing (group * wmax + slot)
     const int32_t* alist2;        // d.alist without the entries of the gathered blocks
     int nalist2;
     const uint8_t* col_gather;    // ld: 1 = the gather pass writes this right-hand-side column

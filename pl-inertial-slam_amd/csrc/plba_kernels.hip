@@ -1544,8 +1544,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     }
     LmAcc& A4 = *reinterpret_cast<LmAcc*>(s_dyn_lm);
-    if (lv.grp[b].is_line) lm_schur_group<true, MODE>(d, lv, b, state, rb, S, A4);
-    else lm_schur_group<false, MODE>(d, lv, b, state, rb, S, A4);
+    const int kind = lv.grp[b].kind;      // bit 0: lines, bit 1: wide (landmarks seen from 9 .. 16 keyframes)
+    if (kind == 0) lm_schur_group<false, MODE>(d, lv, b, state, rb, S, A4);
+    else if (kind == 1) lm_schur_group<true, MODE>(d, lv, b, state, rb, S, A4);
+    else if (kind == 2) lm_schur_group_wide<false, MODE>(d, lv, b, state, rb, S, A4);
+    else lm_schur_group_wide<true, MODE>(d, lv, b, state, rb, S, A4);
 }
 // launch D: [blocks assembling the part of the system no landmark touches | gather blocks: pose-pair blocks and right-hand-side rows =
 // pose-side terms + the groups' parts]
@@ -1578,8 +1581,11 @@ __global__ __launch_bounds__(LMB) void k_lm_trial(DevBuf d, LmView lv, int cur, 
             for (int k = threadIdx.x; k < d.K; k += LMB) update_kf_one(d, cur, trial, k);
             lead_done(d.back_cnt);
         }
-        if (lv.grp[g].is_line) lm_trial_group<true>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
-        else lm_trial_group<false>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
+        const int kind = lv.grp[g].kind;
+        if (kind == 0) lm_trial_group<false, false>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
+        else if (kind == 1) lm_trial_group<true, false>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
+        else if (kind == 2) lm_trial_group<false, true>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
+        else lm_trial_group<true, true>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
     } else {
         const int m = b - nlead - lv.ngrp;
         const LeadWait lw{d.back_cnt, back_target, &d.ctrl->sync_fail};
@@ -1643,7 +1649,7 @@ __global__ __launch_bounds__(256) void k_lm_lambda_init(DevBuf d, LmView lv, LmP
         double v = 0.0;
         for (int q = lv.row_start[k]; q < lv.row_start[k + 1]; ++q) {
             const int src = lv.row_src[q];
-            v += lv.part[(size_t)(src / LMF_W) * LMF_PART + 36 * 36 + (src % LMF_W) * 12 + c];
+            v += lv.part[(size_t)(src / lv.wmax) * lv.part_stride + lv.npair * 36 + (src % lv.wmax) * 12 + c];
         }
         const int kf = lv.row_kf[k], o = d.kf_off_pvr[kf];
         d.kfdiag[kf * 6 + c] = v;

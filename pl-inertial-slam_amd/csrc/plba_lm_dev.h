@@ -34,11 +34,11 @@ constexpr int LMF_UNITS = 32;            // units per workgroup step (4 waves x 
 constexpr int LMF_ROWS = 6 * LMF_W;      // 48: rows of a group's local system (slot-major, 6 per keyframe of the window)
 constexpr int LMF_SCOLS = 3 * LMF_UNITS; // 96: k-columns of a step's operand of A' A'^T
 constexpr int LMF_HCOLS = 2 * LMF_UNITS; // 64: ... of sum Jp^T w Jp (points; lines use half)
-struct LmLds {
-    double kc[2][LMF_W][KFCAM_STRIDE];   // camera blocks of the window keyframes: [0] linearisation state, [1] trial state (k_lm_trial)
-    double xs[LMF_W][6];                 // pose step (dp, dphi) of the window keyframes (k_lm_trial)
+struct LmLds {                           // (sized for a wide group's 16 window slots; a standard group uses the first 8)
+    double kc[2][LMF_W2][KFCAM_STRIDE];  // camera blocks of the window keyframes: [0] linearisation state, [1] trial state (k_lm_trial)
+    double xs[LMF_W2][6];                // pose step (dp, dphi) of the window keyframes (k_lm_trial)
     double red[4][8];
-    int koff[LMF_W];
+    int koff[LMF_W2];
 };
 struct LmAcc {                           // k_lm_schur only
     double op[4 * 24 * LMF_ROWS];        // per wave: the step's operand of A' A'^T, [k-column][row] (4 x 9 KB); after the last step: the waves' tiles and vectors
@@ -107,8 +107,9 @@ DEV void lm_eval(const DevBuf& d, const Robust& rb, const double* kc, bool kf_fr
     }
 }
 
-// Hll (upper 6) and bl (3) of the unit, summed over its 8 lanes in a fixed order; every lane ends up with the totals
-template <int NR>
+// Hll (upper 6) and bl (3) of the unit, summed over its 8 lanes (WIDE: over the 16 lanes of the landmark's two units) in a fixed order;
+// every lane ends up with the totals
+template <int NR, bool WIDE = false>
 DEV void lm_hll(const LmRows<NR>& r, double* h, double* b, int& nact) {
 #pragma unroll
     for (int t = 0; t < 6; ++t) h[t] = 0.0;
@@ -122,10 +123,11 @@ DEV void lm_hll(const LmRows<NR>& r, double* h, double* b, int& nact) {
         b[0] -= r.wr * l[0] * r.e[a]; b[1] -= r.wr * l[1] * r.e[a]; b[2] -= r.wr * l[2] * r.e[a];
     }
 #pragma unroll
-    for (int t = 0; t < 6; ++t) h[t] = quad_sum(h[t]);
+    for (int t = 0; t < 6; ++t) { h[t] = quad_sum(h[t]); if (WIDE) h[t] += shfl_xor8(h[t]); }
 #pragma unroll
-    for (int t = 0; t < 3; ++t) b[t] = quad_sum(b[t]);
+    for (int t = 0; t < 3; ++t) { b[t] = quad_sum(b[t]); if (WIDE) b[t] += shfl_xor8(b[t]); }
     nact = quad_sum_i(r.act ? 1 : 0);
+    if (WIDE) nact += __builtin_amdgcn_update_dpp(0, nact, 0x128, 0xf, 0xf, false);      // row_ror:8: the landmark's other unit
 }
 // (Hll + lambda I) = R R^T;  Li = R^-1 (lower: [00, 10, 11, 20, 21, 22]), so that D = (Hll + lambda I)^-1 = Li^T Li.  Zero when the
 // unit is inactive or the block is not positive definite (the record-based path leaves D = 0 there as well)
@@ -163,22 +165,24 @@ struct LmStep {      // one lane's share of a step's inputs (prefetched a step a
 };
 // the loads of a step come in two dependent levels: the unit's indices (LmIdx), then its landmark and its lane's observation
 struct LmIdx { int slot, e; bool uvalid, has, fixed; };
-template <bool IS_LINE>
+// WIDE: a landmark block takes TWO neighbouring units — window slots 0 - 7 and 8 - 15 — so a point is 2 units and a line 4
+// (end point P: slots 0 - 7 | 8 - 15, then end point Q likewise); the lane's window slot is 8 (unit & 1) + (lane & 7)
+template <bool IS_LINE, bool WIDE = false>
 DEV void lm_load_idx(const LmView& lv, const LmGroup& g, int step, int wv, int lane, LmIdx& x) {
-    const int unit = step * LMF_UNITS + wv * 8 + (lane >> 3), sub = lane & 7;
-    const int n = IS_LINE ? (unit >> 1) : unit;
+    const int unit = step * LMF_UNITS + wv * 8 + (lane >> 3), sub = WIDE ? 8 * ((lane >> 3) & 1) + (lane & 7) : (lane & 7);
+    const int n = WIDE ? (IS_LINE ? (unit >> 2) : (unit >> 1)) : (IS_LINE ? (unit >> 1) : unit);
     x.uvalid = n < g.nlm; x.slot = 0; x.e = 0; x.has = false; x.fixed = true;
     if (!x.uvalid) return;
     const int gi = g.lm0 + n;
     x.slot = lv.lm_slot[gi];
-    const int off = lv.lm_ws8[(size_t)gi * LMF_W + sub];      // lane = window slot
+    const int off = lv.lm_ws8[(size_t)gi * lv.wmax + sub];      // lane = window slot
     x.has = off != 0xFF;
     x.e = lv.lm_ob0[gi] + (x.has ? off : 0);
     x.fixed = lv.lm_fixed_g[gi] != 0;
 }
-template <bool IS_LINE>
+template <bool IS_LINE, bool WIDE = false>
 DEV void lm_load_data(const DevBuf& d, const LmView& lv, int state, int lane, const LmIdx& x, LmStep& s) {
-    s.uvalid = x.uvalid; s.slot = x.slot; s.k = 0; s.e = x.e; s.ws = lane & 7; s.orig = 0; s.has = x.has; s.lvl0 = false; s.fixed = x.fixed; s.wt = 0.0;
+    s.uvalid = x.uvalid; s.slot = x.slot; s.k = 0; s.e = x.e; s.ws = WIDE ? 8 * ((lane >> 3) & 1) + (lane & 7) : (lane & 7); s.orig = 0; s.has = x.has; s.lvl0 = false; s.fixed = x.fixed; s.wt = 0.0;
 #pragma unroll
     for (int t = 0; t < 3; ++t) s.meas[t] = 0.0;
 #pragma unroll
@@ -194,16 +198,16 @@ DEV void lm_load_data(const DevBuf& d, const LmView& lv, int state, int lane, co
         else { const double2 m = reinterpret_cast<const double2*>(lv.meas_pt)[s.e]; s.meas[0] = m.x; s.meas[1] = m.y; }
     }
 }
-template <bool IS_LINE>
+template <bool IS_LINE, bool WIDE = false>
 DEV void lm_load(const DevBuf& d, const LmView& lv, const LmGroup& g, int state, int step, int wv, int lane, LmStep& s) {
     LmIdx x;
-    lm_load_idx<IS_LINE>(lv, g, step, wv, lane, x);
-    lm_load_data<IS_LINE>(d, lv, state, lane, x, s);
+    lm_load_idx<IS_LINE, WIDE>(lv, g, step, wv, lane, x);
+    lm_load_data<IS_LINE, WIDE>(d, lv, state, lane, x, s);
 }
 
 // camera blocks (and kf_off_pvr) of the group's window at `state`
 DEV void lm_stage_window(const DevBuf& d, const LmGroup& g, int state, LmLds& S) {
-    if ((int)threadIdx.x < LMF_W) {
+    if ((int)threadIdx.x < LMF_W2) {
         const int p = threadIdx.x;
         if (p < g.nw) { kfcam_make(d.cam, d.kf[state] + (size_t)g.kf[p] * KF_STRIDE, S.kc[0][p]); S.koff[p] = g.off[p]; }
         else { for (int t = 0; t < KFCAM_STRIDE; ++t) S.kc[0][p][t] = 0.0; S.koff[p] = -1; }
@@ -418,7 +422,7 @@ DEV void lm_schur_group(const DevBuf& d, const LmView& lv, const int gidx, const
     }
     __syncthreads();
     FSTAMP1(9);
-    double* part = lv.part + (size_t)gidx * LMF_PART;
+    double* part = lv.part + (size_t)gidx * lv.part_stride;
     if (MODE == 0) {
         // entry (r, c) of pair block (p <= q): rows a = 6 p + r, b = 6 q + c of the local system, read from the lower tiles
         for (int idx = threadIdx.x; idx < 36 * 36; idx += 256) {
@@ -440,7 +444,7 @@ DEV void lm_schur_group(const DevBuf& d, const LmView& lv, const int gidx, const
     }
     if ((int)threadIdx.x < LMF_W * 12 && (MODE == 0 || threadIdx.x % 12 < 6)) {
         const int p = threadIdx.x / 12, k = 21 + threadIdx.x % 12;
-        part[36 * 36 + threadIdx.x] = (vs[(0 * LMF_W + p) * LMF_NVEC + k] + vs[(1 * LMF_W + p) * LMF_NVEC + k]) + (vs[(2 * LMF_W + p) * LMF_NVEC + k] + vs[(3 * LMF_W + p) * LMF_NVEC + k]);
+        part[lv.npair * 36 + threadIdx.x] = (vs[(0 * LMF_W + p) * LMF_NVEC + k] + vs[(1 * LMF_W + p) * LMF_NVEC + k]) + (vs[(2 * LMF_W + p) * LMF_NVEC + k] + vs[(3 * LMF_W + p) * LMF_NVEC + k]);
     }
     if (threadIdx.x == 0) {
         d.chi_part[gidx] = (S.red[0][0] + S.red[1][0]) + (S.red[2][0] + S.red[3][0]);
@@ -455,6 +459,205 @@ DEV void lm_schur_group(const DevBuf& d, const LmView& lv, const int gidx, const
         d.dbgbuf[o + 11] = (double)nsteps; d.dbgbuf[o + 12] = (double)(long long)__builtin_amdgcn_s_memrealtime();
     }
 #endif
+}
+
+// ---- k_lm_schur: one WIDE group (round 4) -----------------------------------------------------------------------------------------
+// Landmarks seen from 9 .. 16 keyframes: the reference's sliding window holds 12 (include/mapHandler.h:217) and its tracks span most
+// of it (kf_obs_list, src/mapHandler.cpp:5296-5413) — with 8-slot groups alone such a window sent the WHOLE problem to the record-based
+// passes.  A wide landmark block takes two neighbouring 8-lane units (window slots 0 - 7 | 8 - 15): 4 points or 2 lines per wave step.
+// Everything per lane is as in lm_schur_group (evaluation, register accumulators of the lane's slot); what differs:
+//   * Hll / bl are summed over the block's 16 lanes;
+//   * the local system has 96 rows: 21 lower 16 x 16 tiles (15 while the window holds <= 13 keyframes: rows 78 .. 95 are empty).  A wave
+//     cannot hold them all, so the four waves SHARE one operand panel (48 k-columns x 96 rows: wave w writes k-columns 12 w .. 12 w + 11,
+//     one column triple per landmark block) and each wave owns a quarter of the tiles over ALL 48 k-columns: two workgroup barriers per
+//     step (panel written | panel consumed).  The decoupled-waves form of the standard group is worth 1.6 x; it does not fit
+//     here, and wide groups are the small windows' case — launch-bound, not flop-bound;
+//   * a tile has ONE owner, so the group's output goes from the accumulator registers straight to the gather buffer.
+__device__ const signed char LMW_TILE[2][4][6][2] = {
+    {{{0, 0}, {1, 0}, {1, 1}, {2, 0}, {-1, -1}, {-1, -1}}, {{2, 1}, {2, 2}, {3, 0}, {3, 1}, {-1, -1}, {-1, -1}},
+     {{3, 2}, {3, 3}, {4, 0}, {4, 1}, {-1, -1}, {-1, -1}}, {{4, 2}, {4, 3}, {4, 4}, {-1, -1}, {-1, -1}, {-1, -1}}},
+    {{{0, 0}, {1, 0}, {1, 1}, {2, 0}, {2, 1}, {2, 2}}, {{3, 3}, {4, 3}, {4, 4}, {5, 3}, {5, 4}, {-1, -1}},
+     {{3, 0}, {3, 1}, {3, 2}, {4, 0}, {5, 5}, {-1, -1}}, {{4, 1}, {4, 2}, {5, 0}, {5, 1}, {5, 2}, {-1, -1}}}};
+constexpr int LMW_ROWS = 6 * LMF_W2;          // 96
+constexpr int LMW_KCOLS = 48;                 // 4 waves x 4 landmark blocks x 3
+template <bool IS_LINE, int MODE>
+DEV void lm_schur_group_wide(const DevBuf& d, const LmView& lv, const int gidx, const int state, const Robust& rb, LmLds& S, LmAcc& A4) {
+    constexpr int NR = IS_LINE ? 1 : 2;
+    static_assert(sizeof(LmAcc) >= sizeof(double) * LMW_KCOLS * LMW_ROWS, "the wide panel shares the standard groups' dynamic LDS");
+    const LmGroup g = lv.grp[gidx];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, u8 = lane >> 3;
+    const int slot = 8 * (u8 & 1) + (lane & 7);      // the lane's window slot
+    const int blk = u8 >> 1;                         // the landmark block inside the wave (0 .. 3)
+    const double lambda = MODE == 0 ? d.ctrl->lambda : 0.0;
+    lm_stage_window(d, g, state, S);
+    const int nunits = (IS_LINE ? 4 : 2) * g.nlm;
+    const int nsteps = (nunits + LMF_UNITS - 1) / LMF_UNITS;
+    LmStep cur;
+    lm_load<IS_LINE, true>(d, lv, g, state, 0, wv, lane, cur);
+    LmIdx ix1;
+    ix1.uvalid = false; ix1.slot = 0; ix1.e = 0; ix1.has = false; ix1.fixed = true;
+    if (nsteps > 1) lm_load_idx<IS_LINE, true>(lv, g, 1, wv, lane, ix1);
+    __syncthreads();
+    const double* kc = S.kc[0][slot];
+    const bool kfree = S.koff[slot] >= 0;
+    // this wave's tiles
+    const int var = g.nw > 13 ? 1 : 0;
+    int ra[6], rb6[6], ntile = 0;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int ti = LMW_TILE[var][wv][t][0], tj = LMW_TILE[var][wv][t][1];
+        ra[t] = 16 * (ti < 0 ? 0 : ti); rb6[t] = 16 * (tj < 0 ? 0 : tj);
+        if (ti >= 0) ntile = t + 1;
+    }
+    const double4v_lm z4 = (double4v_lm){0.0, 0.0, 0.0, 0.0};
+    double4v_lm acc[6] = {z4, z4, z4, z4, z4, z4};
+    double vec[LMF_NVEC];
+#pragma unroll
+    for (int t = 0; t < LMF_NVEC; ++t) vec[t] = 0.0;
+    double chi_acc = 0.0, maxd = 0.0;
+    double* op = A4.op;      // [k-column][row]: 48 x 96, shared by the four waves
+    for (int step = 0; step < nsteps; ++step) {
+        LmRows<NR> r;
+        const int rowsel = IS_LINE ? (blk & 1) : 0;
+        lm_eval<IS_LINE, NR>(d, rb, kc, cur.has && kfree, cur.L, cur.meas, cur.wt, cur.has, cur.lvl0, rowsel, true, r);
+        double h[6], b[3];
+        int nact;
+        lm_hll<NR, true>(r, h, b, nact);
+        const bool active = cur.uvalid && nact > 0 && !cur.fixed;
+        if (!IS_LINE || rowsel == 0) chi_acc += r.rho;
+        if (MODE == 1 && r.act && (!IS_LINE || rowsel == 0)) {
+            lv.ob_chi_g[cur.e] = r.chi;
+            if (lv.ob_err) { lv.ob_err[2 * (size_t)cur.orig] = r.e[0]; }
+        }
+        if (MODE == 1 && lv.ob_err && r.act) lv.ob_err[2 * (size_t)cur.orig + (IS_LINE ? rowsel : 1)] = r.e[NR - 1];
+        if (lv.dbg_out && cur.uvalid && (lane & 15) == 0) {      // diagnostics of the parity tests: Hll, bl in the record-based path's layout
+            double* ho = d.hll + (size_t)cur.slot * 12 + (IS_LINE ? 6 * rowsel : 0);
+            double* bo = d.bl + (size_t)cur.slot * 6 + (IS_LINE ? 3 * rowsel : 0);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) ho[t] = h[t];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) bo[t] = b[t];
+            if (!IS_LINE || rowsel == 0) d.lm_active[cur.slot] = active ? 1 : 0;
+        }
+        if (MODE == 1) {
+            if (active && (lane & 15) == 0) maxd = fmax(maxd, fmax(fmax(fabs(h[0]), fabs(h[3])), fabs(h[5])));
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double q = 0.0;
+#pragma unroll
+                for (int a = 0; a < NR; ++a) q += r.wj * r.j[a][c] * r.j[a][c];
+                vec[21 + c] += q;
+            }
+            LmStep nxt;
+            if (step + 1 < nsteps) lm_load_data<IS_LINE, true>(d, lv, state, lane, ix1, nxt);
+            if (step + 2 < nsteps) lm_load_idx<IS_LINE, true>(lv, g, step + 2, wv, lane, ix1);
+            cur = nxt;
+            continue;
+        }
+        double Li[6], y[3], u[NR][3];
+        lm_chol_inv(h, lambda, active, Li);
+        lm_lower_mul(Li, b, y);
+#pragma unroll
+        for (int a = 0; a < NR; ++a) lm_lower_mul(Li, r.l[a], u[a]);
+        const double sw = r.wj > 0.0 ? r.wj * lm_rsqrt(r.wj) : 0.0;
+        double es[NR];
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+            es[a] = sw * r.e[a];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) r.j[a][c] *= sw;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) u[a][m] *= sw;
+        }
+        int hidx = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double A3[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                double q = 0.0;
+#pragma unroll
+                for (int a = 0; a < NR; ++a) q += r.j[a][c] * u[a][m];
+                A3[m] = q;
+                op[(12 * wv + 3 * blk + m) * LMW_ROWS + 6 * slot + c] = q;
+            }
+            double q = 0.0;
+#pragma unroll
+            for (int a = 0; a < NR; ++a) q += r.j[a][c] * es[a];
+            vec[21 + c] -= q;
+            vec[27 + c] += A3[0] * y[0] + A3[1] * y[1] + A3[2] * y[2];
+#pragma unroll
+            for (int c2 = 0; c2 <= c; ++c2) {
+                double hq = 0.0;
+#pragma unroll
+                for (int a = 0; a < NR; ++a) hq += r.j[a][c] * r.j[a][c2];
+                vec[hidx++] += hq;
+            }
+        }
+        LmStep nxt;
+        if (step + 1 < nsteps) lm_load_data<IS_LINE, true>(d, lv, state, lane, ix1, nxt);
+        if (step + 2 < nsteps) lm_load_idx<IS_LINE, true>(lv, g, step + 2, wv, lane, ix1);
+        __syncthreads();      // the panel of this step is complete
+#pragma unroll 2
+        for (int s4 = 0; s4 < LMW_KCOLS / 4; ++s4) {
+            const double* col = op + (4 * s4 + lk) * LMW_ROWS + li;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                if (t < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(col[ra[t]], col[rb6[t]], acc[t], 0, 0, 0);
+        }
+        __syncthreads();      // ... and consumed: the next step may overwrite it
+        cur = nxt;
+    }
+    // ---- the group's parts go out ---------------------------------------------------------------------------------------------------------
+    // vectors: over the 4 landmark blocks of the wave (lanes with the same slot), then over the waves through LDS
+#pragma unroll
+    for (int t = 0; t < LMF_NVEC; ++t) {
+        double v = vec[t];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        vec[t] = v;
+    }
+    chi_acc = wave_sum(chi_acc); maxd = wave_max(maxd);
+    __syncthreads();
+    double* vs = A4.op;                                   // [4 waves][16 slots][LMF_NVEC]
+    if (lane < LMF_W2) {                                  // (lanes 0 .. 15 hold slots 0 .. 15)
+#pragma unroll
+        for (int t = 0; t < LMF_NVEC; ++t) vs[(wv * LMF_W2 + lane) * LMF_NVEC + t] = vec[t];
+    }
+    if (lane == 0) { S.red[wv][0] = chi_acc; S.red[wv][1] = maxd; }
+    __syncthreads();
+    double* part = lv.part + (size_t)gidx * lv.part_stride;
+    if (MODE == 0) {
+        // lower entry (a >= b) of the local system -> entry (r, c) of pair block (p <= q): a = 6 q + c, b = 6 p + r (lm_schur_group's layout)
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            if (t >= ntile) continue;
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                const int a = ra[t] + lk + 4 * v4, b2 = rb6[t] + li;
+                if (a < b2) continue;      // (upper half of a diagonal tile: the mirror image is written below)
+                const int q = a / 6, c = a - 6 * q, pq = b2 / 6, rr = b2 - 6 * pq;
+                if (q >= g.nw) continue;
+                double hv = 0.0;
+                if (pq == q) {
+                    const int k = c * (c + 1) / 2 + rr;      // (c >= rr)
+                    hv = (vs[(0 * LMF_W2 + q) * LMF_NVEC + k] + vs[(1 * LMF_W2 + q) * LMF_NVEC + k]) + (vs[(2 * LMF_W2 + q) * LMF_NVEC + k] + vs[(3 * LMF_W2 + q) * LMF_NVEC + k]);
+                }
+                const double val = hv - acc[t][v4];
+                double* blkp = part + (size_t)(q * (q + 1) / 2 + pq) * 36;
+                blkp[rr * 6 + c] = val;
+                if (pq == q && rr != c) blkp[c * 6 + rr] = val;
+            }
+        }
+    }
+    if ((int)threadIdx.x < LMF_W2 * 12 && (MODE == 0 || threadIdx.x % 12 < 6)) {
+        const int pslot = threadIdx.x / 12, k = 21 + threadIdx.x % 12;
+        part[lv.npair * 36 + threadIdx.x] = (vs[(0 * LMF_W2 + pslot) * LMF_NVEC + k] + vs[(1 * LMF_W2 + pslot) * LMF_NVEC + k]) + (vs[(2 * LMF_W2 + pslot) * LMF_NVEC + k] + vs[(3 * LMF_W2 + pslot) * LMF_NVEC + k]);
+    }
+    if (threadIdx.x == 0) {
+        d.chi_part[gidx] = (S.red[0][0] + S.red[1][0]) + (S.red[2][0] + S.red[3][0]);
+        if (MODE == 1) d.maxd_part[gidx] = fmax(fmax(S.red[0][1], S.red[1][1]), fmax(S.red[2][1], S.red[3][1]));
+    }
 }
 
 // ---- k_lm_gather: assembly of the landmark-coupled part of the reduced system -------------------------------------------------------
@@ -473,11 +676,11 @@ DEV void lm_gather_part(const DevBuf& d, const LmView& lv, int add_lambda, int b
         if (ch < 7) {
             int s = n0 + ch;
             for (; s + 7 < n1; s += 14) {
-                const int src0 = lv.blk_src[s], src1 = lv.blk_src[s + 7];      // group * 36 + pair index
-                a0 += lv.part[(size_t)(src0 / 36) * LMF_PART + (src0 % 36) * 36 + rc];
-                a1 += lv.part[(size_t)(src1 / 36) * LMF_PART + (src1 % 36) * 36 + rc];
+                const int src0 = lv.blk_src[s], src1 = lv.blk_src[s + 7];      // group * npair + pair index
+                a0 += lv.part[(size_t)(src0 / lv.npair) * lv.part_stride + (src0 % lv.npair) * 36 + rc];
+                a1 += lv.part[(size_t)(src1 / lv.npair) * lv.part_stride + (src1 % lv.npair) * 36 + rc];
             }
-            if (s < n1) { const int src0 = lv.blk_src[s]; a0 += lv.part[(size_t)(src0 / 36) * LMF_PART + (src0 % 36) * 36 + rc]; }
+            if (s < n1) { const int src0 = lv.blk_src[s]; a0 += lv.part[(size_t)(src0 / lv.npair) * lv.part_stride + (src0 % lv.npair) * 36 + rc]; }
         }
         s_red[tid] = a0 + a1;
         __syncthreads();
@@ -503,8 +706,8 @@ DEV void lm_gather_part(const DevBuf& d, const LmView& lv, int add_lambda, int b
     double acc = 0.0;
     if (ch < 21)
         for (int s = n0 + ch; s < n1; s += 21) {
-            const int src = lv.row_src[s];      // group * LMF_W + slot
-            acc += lv.part[(size_t)(src / LMF_W) * LMF_PART + 36 * 36 + (src % LMF_W) * 12 + t];
+            const int src = lv.row_src[s];      // group * wmax + slot
+            acc += lv.part[(size_t)(src / lv.wmax) * lv.part_stride + lv.npair * 36 + (src % lv.wmax) * 12 + t];
         }
     s_red[tid] = acc;
     __syncthreads();
@@ -527,7 +730,7 @@ DEV void lm_gather_diag(const DevBuf& d, const LmView& lv, int bid, int tid, dou
     if (ch < 21 && t < 6)
         for (int s = lv.row_start[k] + ch; s < lv.row_start[k + 1]; s += 21) {
             const int src = lv.row_src[s];
-            acc += lv.part[(size_t)(src / LMF_W) * LMF_PART + 36 * 36 + (src % LMF_W) * 12 + t];
+            acc += lv.part[(size_t)(src / lv.wmax) * lv.part_stride + lv.npair * 36 + (src % lv.wmax) * 12 + t];
         }
     s_red[tid] = acc;
     __syncthreads();
@@ -563,14 +766,14 @@ DEV void lm_assemble_rest(const DevBuf& d, const LmView& lv, int add_lambda, int
 
 // ---- k_lm_trial: one group ----------------------------------------------------------------------------------------------------------
 // xd / cv: the pose step is read from the dense solution when the chain segments ride in the same launch (they are still writing d.x)
-template <bool IS_LINE>
+template <bool IS_LINE, bool WIDE = false>
 DEV void lm_trial_group(const DevBuf& d, const LmView& lv, const int gidx, const int cur_state, const int trial, const Robust& rb, const ChainView& cv, const double* xd, const bool from_dense, LmLds& S) {
     constexpr int NR = IS_LINE ? 1 : 2;
     const LmGroup g = lv.grp[gidx];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 7;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = WIDE ? (lane & 15) : (lane & 7);      // sub == 0: the landmark block's first lane
     const double lambda = d.ctrl->lambda;
     const bool sok = d.ctrl->solver_ok != 0;
-    if ((int)threadIdx.x < LMF_W) {
+    if ((int)threadIdx.x < (WIDE ? LMF_W2 : LMF_W)) {
         const int p = threadIdx.x;
         double u9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (p < g.nw) {
@@ -593,25 +796,25 @@ DEV void lm_trial_group(const DevBuf& d, const LmView& lv, const int gidx, const
         }
         S.xs[p][0] = u9[0]; S.xs[p][1] = u9[1]; S.xs[p][2] = u9[2]; S.xs[p][3] = u9[6]; S.xs[p][4] = u9[7]; S.xs[p][5] = u9[8];
     }
-    const int nunits = IS_LINE ? 2 * g.nlm : g.nlm;
+    const int nunits = (IS_LINE ? 2 * g.nlm : g.nlm) * (WIDE ? 2 : 1);
     const int nsteps = (nunits + LMF_UNITS - 1) / LMF_UNITS;
     LmStep cur;
-    lm_load<IS_LINE>(d, lv, g, cur_state, 0, wv, lane, cur);
+    lm_load<IS_LINE, WIDE>(d, lv, g, cur_state, 0, wv, lane, cur);
     LmIdx ix1;      // indices of step + 1, a step ahead of the data they lead to (see lm_schur_group)
     ix1.uvalid = false; ix1.slot = 0; ix1.e = 0; ix1.has = false; ix1.fixed = true;
-    if (nsteps > 1) lm_load_idx<IS_LINE>(lv, g, 1, wv, lane, ix1);
+    if (nsteps > 1) lm_load_idx<IS_LINE, WIDE>(lv, g, 1, wv, lane, ix1);
     __syncthreads();
     double chi_acc = 0.0, sc_acc = 0.0;
     for (int step = 0; step < nsteps; ++step) {
         LmRows<NR> r;
-        const int rowsel = IS_LINE ? ((lane >> 3) & 1) : 0;
+        const int rowsel = IS_LINE ? ((lane >> (WIDE ? 4 : 3)) & 1) : 0;
         lm_eval<IS_LINE, NR>(d, rb, S.kc[0][cur.ws], cur.has && S.koff[cur.ws] >= 0, cur.L, cur.meas, cur.wt, cur.has, cur.lvl0, rowsel, true, r);
         LmStep nxt;
-        if (step + 1 < nsteps) lm_load_data<IS_LINE>(d, lv, cur_state, lane, ix1, nxt);      // in flight during the rest of the step
-        if (step + 2 < nsteps) lm_load_idx<IS_LINE>(lv, g, step + 2, wv, lane, ix1);
+        if (step + 1 < nsteps) lm_load_data<IS_LINE, WIDE>(d, lv, cur_state, lane, ix1, nxt);      // in flight during the rest of the step
+        if (step + 2 < nsteps) lm_load_idx<IS_LINE, WIDE>(lv, g, step + 2, wv, lane, ix1);
         double h[6], b[3];
         int nact;
-        lm_hll<NR>(r, h, b, nact);
+        lm_hll<NR, WIDE>(r, h, b, nact);
         const bool active = cur.uvalid && nact > 0 && !cur.fixed && sok;
         double Li[6];
         lm_chol_inv(h, lambda, active, Li);
@@ -629,7 +832,7 @@ DEV void lm_trial_group(const DevBuf& d, const LmView& lv, const int gidx, const
             }
         }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) cv3[t] = quad_sum(cv3[t]);
+        for (int t = 0; t < 3; ++t) { cv3[t] = quad_sum(cv3[t]); if (WIDE) cv3[t] += shfl_xor8(cv3[t]); }
         double rhs[3] = {b[0] - cv3[0], b[1] - cv3[1], b[2] - cv3[2]}, tt[3], xl[3];
         lm_lower_mul(Li, rhs, tt);
         lm_lowerT_mul(Li, tt, xl);
@@ -644,7 +847,7 @@ DEV void lm_trial_group(const DevBuf& d, const LmView& lv, const int gidx, const
         double Ltr[6];
         if (!IS_LINE) { Ltr[0] = cur.L[0] + xl[0]; Ltr[1] = cur.L[1] + xl[1]; Ltr[2] = cur.L[2] + xl[2]; Ltr[3] = Ltr[4] = Ltr[5] = 0.0; }
         else {
-            const double o0 = shfl_xor8(xl[0]), o1 = shfl_xor8(xl[1]), o2 = shfl_xor8(xl[2]);      // the line's other end point
+            const double o0 = WIDE ? __shfl_xor(xl[0], 16) : shfl_xor8(xl[0]), o1 = WIDE ? __shfl_xor(xl[1], 16) : shfl_xor8(xl[1]), o2 = WIDE ? __shfl_xor(xl[2], 16) : shfl_xor8(xl[2]);      // the line's other end point
             const double* xa = rowsel == 0 ? xl : nullptr;
             Ltr[0] = cur.L[0] + (rowsel == 0 ? xl[0] : o0); Ltr[1] = cur.L[1] + (rowsel == 0 ? xl[1] : o1); Ltr[2] = cur.L[2] + (rowsel == 0 ? xl[2] : o2);
             Ltr[3] = cur.L[3] + (rowsel == 0 ? o0 : xl[0]); Ltr[4] = cur.L[4] + (rowsel == 0 ? o1 : xl[1]); Ltr[5] = cur.L[5] + (rowsel == 0 ? o2 : xl[2]);

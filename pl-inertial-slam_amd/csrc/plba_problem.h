@@ -151,6 +151,7 @@ namespace plba {
 // (HostCtx) so that its tables are not re-allocated (and their pages not re-faulted) by every BA call
 struct LmHost {
     std::vector<LmGroup> grp;
+    int wmax = 8, npair = 36;      // window slots / pose-pair blocks per group in the gather buffer: 16 / 136 when wide groups exist
     std::vector<int32_t> lm_slot, lm_ob0, ob_orig, blk_ij, blk_start, blk_src, row_kf, row_start, row_src;
     std::vector<uint8_t> lm_ws8, lm_fixed, cov;
     std::vector<double> meas_pt, meas_ln, ob_wt;

@@ -18,7 +18,27 @@ def _pose_delta(a, b, pkg):
     return max(np.abs(a["P"] - b["P"]).max(), np.abs(a["V"] - b["V"]).max(), dphi, np.abs(a["dbg"] - b["dbg"]).max(), np.abs(a["dba"] - b["dba"]).max())
 
 
+def _mixed_window(pkg):
+    """a 30-keyframe window of ordinary tracks (2 .. 8 keyframes) in which every tenth landmark is seen from 9 .. 14 keyframes: standard and
+    wide groups side by side"""
+    w = pkg.window.make_window(30, 1500, 300, imu=True, seed=0x5EED0A1)
+    wl = pkg.window.make_window(30, 150, 30, imu=True, seed=0x5EED0A1, track=(9, 14))
+    out = dict(w)
+    out["points"] = np.vstack([w["points"], wl["points"]]); out["lines"] = np.vstack([w["lines"], wl["lines"]])
+    out["po_pt"] = np.concatenate([w["po_pt"], wl["po_pt"] + len(w["points"])]).astype(np.int32); out["po_kf"] = np.concatenate([w["po_kf"], wl["po_kf"]])
+    out["po_uv"] = np.vstack([w["po_uv"], wl["po_uv"]]); out["po_w"] = np.concatenate([w["po_w"], wl["po_w"]])
+    out["lo_ln"] = np.concatenate([w["lo_ln"], wl["lo_ln"] + len(w["lines"])]).astype(np.int32); out["lo_kf"] = np.concatenate([w["lo_kf"], wl["lo_kf"]])
+    out["lo_l"] = np.vstack([w["lo_l"], wl["lo_l"]]); out["lo_w"] = np.concatenate([w["lo_w"], wl["lo_w"]])
+    return out
+
+
 WINDOWS = {"k6": lambda pkg: pkg.window.make_window(6, 80, 20, imu=True, seed=5),
+           # wide groups (round 4): landmarks seen from 9 .. 16 keyframes
+           "k12_long": lambda pkg: pkg.window.make_window(12, 600, 120, imu=True, seed=0x5EED00C0, kf_dt=0.1, track=(6, 12), revisit=0.2),      # the reference's window shape
+           "k16_all": lambda pkg: pkg.window.make_window(16, 200, 40, imu=True, seed=79, kf_dt=0.1, track=(16, 16)),      # every landmark in every keyframe: 16-slot windows, all 21 tiles
+           "k14_points": lambda pkg: pkg.window.make_window(14, 300, 0, imu=True, seed=80, kf_dt=0.1, track=(9, 14)),
+           "k14_lines": lambda pkg: pkg.window.make_window(14, 0, 90, imu=True, seed=81, kf_dt=0.1, track=(9, 14)),
+           "mixed30": _mixed_window,
            "k12": lambda pkg: pkg.window.make_window(12, 300, 60, imu=True, seed=0x5EED00AA),
            "k50": lambda pkg: pkg.window.make_config(3, scale=0.1),
            "noimu": lambda pkg: pkg.window.make_config(2, scale=0.1),
@@ -33,13 +53,14 @@ def test_built_system_against_the_oracle(pkg, orc, hip, name):
     o = orc.new_problem(); o.upload_window(w)
     g.debug_build(5.0, True); o.debug_build(5.0, True)
     assert g.debug_get("lm_fused")[0] == 1
+    assert (g.debug_get("lm_fused")[3] > 0) == (name in ("k12_long", "k16_all", "k14_points", "k14_lines", "mixed30"))      # wide groups exactly where tracks exceed 8 keyframes
     for what in ("chi2", "maxdiag", "err_pt", "err_ln", "hll_pt", "bl_pt", "hll_ln", "bl_ln", "bp", "bschur", "Hschur"):
         assert _rel(g.debug_get(what), o.debug_get(what)) < 1e-9, what
     assert _rel(g.debug_get("x"), o.debug_get("x")) < 1e-7
     g.close(); o.close()
 
 
-@pytest.mark.parametrize("name", ["k12", "k50", "noimu"])
+@pytest.mark.parametrize("name", ["k12", "k50", "noimu", "k12_long", "k16_all", "mixed30"])
 def test_protocol_against_the_oracle_and_the_record_based_passes(pkg, orc, hip, name):
     w = WINDOWS[name](pkg)
     res = {}
@@ -98,9 +119,9 @@ def test_replay_is_bit_identical_and_profile_mode_agrees(pkg, hip):
 
 
 def test_structure_that_does_not_fit_falls_back(pkg, orc, hip):
-    """tracks over all 12 keyframes: 12 observations per landmark exceed a group's window of 8 — the record-based passes run (and agree
-    with the oracle)"""
-    w = pkg.window.make_window(12, 200, 40, imu=True, seed=77, kf_dt=0.1, track=(12, 12))
+    """tracks over all 18 keyframes: 18 observations per landmark exceed even a wide group's window of 16 — the record-based passes run
+    (and agree with the oracle)"""
+    w = pkg.window.make_window(18, 200, 40, imu=True, seed=77, kf_dt=0.05, track=(18, 18))
     g = pkg.new_problem(lm_fused=2); g.upload_window(w)
     o = orc.new_problem(); o.upload_window(w)
     sg, so = g.optimize(4), o.optimize(4)

@@ -1,5 +1,6 @@
 """Soak run of the fused landmark-major passes (lm_fused = 2) against the oracle over random window shapes the test-suite does not
-enumerate: keyframe counts 3..70, landmark counts from a handful to thousands, track lengths 2..8 in every mix, points only / lines
+enumerate: keyframe counts 3..70, landmark counts from a handful to thousands, track lengths 2..8 — and, in a third of the cases, up to 16
+(wide groups) — in every mix, points only / lines
 only, with and without IMU edges, marginalization priors, fixed keyframes and fixed landmarks, gating between two stages, huge and
 tiny initial damping (rejections).  One line per case; exits non-zero on the first disagreement.
     python tools/soak_fused.py [N] [seed]"""
@@ -27,6 +28,7 @@ for case in range(N):
     if not imu and Np + Nl < 4 * K:      # without IMU edges a window needs landmarks to be determined at all: (under-determined ones fit to chi2 = 1e-25
         Np = max(Np, 4 * K)              # and their LM decisions are rounding noise, on every path)
     lo = int(rng.integers(2, 6)); hi = int(rng.integers(lo, 9))
+    if rng.integers(0, 3) == 0: lo = int(rng.integers(2, 11)); hi = int(rng.integers(max(lo, 9), 17))      # tracks over 9 .. 16 keyframes: wide groups next to standard ones
     seed = 0xF05E + case
     w = pkg.window.make_window(K, Np, Nl, imu=imu, seed=seed, track=(lo, min(hi, K)))
     tag = []
