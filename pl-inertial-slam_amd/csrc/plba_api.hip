@@ -537,8 +537,9 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     }
     glap("kmin / kmax");
     int nlm = 0, nob = 0;
-    for (int kind4 = 0; kind4 < (any_wide ? 4 : 2); ++kind4) {      // points, lines; then the wide points, wide lines
-        const int kind = kind4 & 1, wide = kind4 >> 1, W = wide ? LMF_W2 : LMF_W;
+    for (int kind4 = 0; kind4 < 4; ++kind4) {      // points, wide points, lines, wide lines: every point observation before every line observation (meas_pt / meas_ln)
+        const int kind = kind4 >> 1, wide = kind4 & 1, W = wide ? LMF_W2 : LMF_W;
+        if (wide && !any_wide) continue;
         const int s0 = kind ? Np : 0, s1 = kind ? L : Np, gmax = (kind ? gln : gpt) / (wide ? 2 : 1);
         // order by (first keyframe, last keyframe, index): two stable counting sorts; landmarks without an edge are not in the graph
         ord.clear();

@@ -183,3 +183,41 @@ def test_random_window_shapes_against_the_oracle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_fused.py"), "24", "5"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_numerically_singular_landmark_blocks(pkg, orc, hip):
+    """What the fused passes do where (Hll + lambda I) is not positive definite in fp64 — lm_chol_inv (csrc/plba_lm_dev.h) against g2o's plain
+    block inverse (VERDICT r03 item 1 asked to match it or test the difference).  Hll = sum w Jl^T Jl is positive
+    semi-definite and lambda > 0, so the block is positive definite in exact arithmetic; a pivot <= 0 needs lambda below the rounding of Hll
+    (lambda / |Hll| < 1e-16).  g2o's own lambda (tau * max diagonal >= 1e-5 * 1e4) is 20 orders above that; the case exists only for a
+    caller-supplied userLambdaInit.  Three landmarks reduced to ONE active observation each (rank-2 Hll):
+      * lambda_init = 1e-6 (block conditioned 1e11): Cholesky and LU agree — all three implementations take the same four steps;
+      * lambda_init = 1e-30 (numerically singular): the oracle — g2o's LU inverse of a singular block, entries ~1e16, then an indefinite
+        reduced system — fails all 10 factorisations and terminates where it started, and so do the record-based passes; the fused passes'
+        square-root form stays finite: the singular direction gets D = 0 (that landmark coordinate is not moved in this trial), the
+        reduced system stays positive definite and LM goes on.  The difference is recorded here, not hidden: the fused path must make
+        progress and stay finite; it is NOT required to reproduce a run of ten failed factorisations."""
+    w = pkg.window.make_window(6, 80, 20, imu=True, seed=5)
+    lev = np.zeros(len(w["po_pt"]), np.uint8)
+    seen = set()
+    for e, pt in enumerate(w["po_pt"]):
+        if pt in (0, 1, 2):
+            if pt in seen: lev[e] = 1
+            seen.add(int(pt))
+    res = {}
+    for lam in (1e-6, 1e-30):
+        for name, mk in (("oracle", lambda: orc.new_problem(user_lambda_init=lam)), ("record", lambda: pkg.new_problem(user_lambda_init=lam, lm_fused=0)),
+                         ("fused", lambda: pkg.new_problem(user_lambda_init=lam, lm_fused=2))):
+            p = mk(); p.upload_window(w); p.set_levels(pkg.abi.EDGE_POINT, lev)
+            st = p.optimize(4)
+            res[(lam, name)] = (st, [t["accepted"] for t in p.trace()], p.get_keyframes(), p.get_points())
+            p.close()
+    so, do, ko, _ = res[(1e-6, "oracle")]
+    for name in ("record", "fused"):
+        s, dcs, k, _ = res[(1e-6, name)]
+        assert dcs == do and s.chi2_final == pytest.approx(so.chi2_final, rel=1e-6) and _pose_delta(k, ko, pkg) < 1e-6
+    so, do, _, _ = res[(1e-30, "oracle")]
+    assert so.solver_failures == 10 and so.stop_reason == 1 and not any(do)      # the reference's arithmetic on a singular block: no step is ever taken
+    sf, df, kf, pf = res[(1e-30, "fused")]
+    assert sf.solver_failures == 0 and all(df) and sf.chi2_final < 0.2 * sf.chi2_initial
+    assert all(np.isfinite(kf[k]).all() for k in kf) and np.isfinite(pf).all()
