@@ -1528,6 +1528,7 @@ static int prepare(plba_problem* p) {
     p->cur = 0;
     p->saved_valid = true;
     p->dirty = false;
+    ++p->state_epoch;
     return PLBA_OK;
 }
 
@@ -1734,6 +1735,7 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
     plba_stats st;
     memset(&st, 0, sizeof st);
     launch_ctrl_reset(d, s);      // (a kernel, not an upload + wait: the call starts without a synchronisation)
+    ++p->state_epoch;
     p->trace.clear();
     const LmParams lp = lm_params(p);
     bool ok = true;
@@ -2089,28 +2091,36 @@ int plba_get_keyframes(plba_problem* p, double* P3, double* V3, double* q4, doub
     }
     return PLBA_OK;
 }
-static int get_lm(plba_problem* p, std::vector<double>& h) {
+// the write-back of a BA call reads points AND lines (mapHandler.cpp:6202-6239): the landmark array comes to the host once per state
+// (state_epoch: bumped by every upload, optimize and restore) and both getters are served from that mirror
+static int get_lm(plba_problem* p, const std::vector<double>*& hp) {
     int rc = prepare(p);
     if (rc) return rc;
+    std::vector<double>& h = p->res_lm;
+    hp = &h;
+    if (p->res_lm_epoch == p->state_epoch && h.size() == (size_t)p->L * 6) return PLBA_OK;
     HIPCK(p, hipSetDevice(p->device));
     HIPCK(p, plba_stream_wait(p->stream));
     h.resize((size_t)p->L * 6);
     if (p->L) HIPCK(p, plba_d2h(p, h.data(), p->dv.lm[p->cur], h.size() * 8));
+    p->res_lm_epoch = p->state_epoch;
     return PLBA_OK;
 }
 int plba_get_points(plba_problem* p, double* xyz) {
     if (!p || !xyz) return PLBA_ERR_INVALID;
-    std::vector<double> h;
-    int rc = get_lm(p, h);
+    const std::vector<double>* hp = nullptr;
+    int rc = get_lm(p, hp);
     if (rc) return rc;
+    const std::vector<double>& h = *hp;
     for (int i = 0; i < p->Np; ++i) memcpy(xyz + 3 * (size_t)i, &h[(size_t)i * 6], 24);
     return PLBA_OK;
 }
 int plba_get_lines(plba_problem* p, double* l) {
     if (!p || !l) return PLBA_ERR_INVALID;
-    std::vector<double> h;
-    int rc = get_lm(p, h);
+    const std::vector<double>* hp = nullptr;
+    int rc = get_lm(p, hp);
     if (rc) return rc;
+    const std::vector<double>& h = *hp;
     for (int i = 0; i < p->Nl; ++i) memcpy(l + 6 * (size_t)i, &h[(size_t)(p->Np + i) * 6], 48);
     return PLBA_OK;
 }
@@ -2128,6 +2138,7 @@ int plba_restore_state(plba_problem* p) {
     int rc = prepare(p);
     if (rc) return rc;
     HIPCK(p, hipSetDevice(p->device));
+    ++p->state_epoch;
     HIPCK(p, hipMemcpyAsync(p->dv.kf[p->cur], p->d_kf_saved.p, (size_t)p->K * KF_STRIDE * 8, hipMemcpyDeviceToDevice, p->stream));
     if (p->L) HIPCK(p, hipMemcpyAsync(p->dv.lm[p->cur], p->d_lm_saved.p, (size_t)p->L * 6 * 8, hipMemcpyDeviceToDevice, p->stream));
     return PLBA_OK;

@@ -1641,19 +1641,36 @@ void launch_posediag(const DevBuf& d, hipStream_t s) {
 // diagonal parts summed per keyframe (fixed order), the pose diagonal, chi2, computeLambdaInit
 __global__ __launch_bounds__(256) void k_lm_lambda_init(DevBuf d, LmView lv, LmParams lp, double* red, int iteration, int nred) {
     __shared__ double s4[4];
+    __shared__ double s_part[256];
     reduce_inline(d, nred, nred, red, s4);
     for (int r = threadIdx.x; r < d.ld; r += 256) d.posediag[r] = (r < d.P) ? d.Himu[(size_t)r * d.ld + r] + d.Hconst[(size_t)r * d.ld + r] : 0.0;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < lv.nrow * 6; idx += 256) {
-        const int k = idx / 6, c = idx - 6 * k;
+    // per keyframe and pose dimension: the groups' diagonal parts, the contributions dealt to nch lane groups (a small window has a
+    // dozen keyframes and hundreds of groups: one lane per entry walked them all, 40 us) and added in a fixed order
+    const int nent = lv.nrow * 6;
+    const int nch = nent > 0 && nent <= 128 ? 256 / nent : 1;
+    for (int base = 0; base < nent; base += 256) {
+        const int idx = base + (int)threadIdx.x % (nch > 1 ? nent : 256), ch = nch > 1 ? (int)threadIdx.x / nent : 0;
         double v = 0.0;
-        for (int q = lv.row_start[k]; q < lv.row_start[k + 1]; ++q) {
-            const int src = lv.row_src[q];
-            v += lv.part[(size_t)(src / lv.wmax) * lv.part_stride + lv.npair * 36 + (src % lv.wmax) * 12 + c];
+        const bool live = idx < nent && ch < nch;
+        int k = 0, c = 0;
+        if (live) {
+            k = idx / 6; c = idx - 6 * k;
+            for (int q = lv.row_start[k] + ch; q < lv.row_start[k + 1]; q += nch) {
+                const int src = lv.row_src[q];
+                v += lv.part[(size_t)(src / lv.wmax) * lv.part_stride + lv.npair * 36 + (src % lv.wmax) * 12 + c];
+            }
         }
-        const int kf = lv.row_kf[k], o = d.kf_off_pvr[kf];
-        d.kfdiag[kf * 6 + c] = v;
-        if (o >= 0) d.posediag[o + pmap(c)] += v;
+        if (nch > 1) {
+            s_part[threadIdx.x] = v;
+            __syncthreads();
+            if (live && ch == 0) { v = 0.0; for (int q = 0; q < nch; ++q) v += s_part[q * nent + idx]; }
+        }
+        if (live && ch == 0) {
+            const int kf = lv.row_kf[k], o = d.kf_off_pvr[kf];
+            d.kfdiag[kf * 6 + c] = v;
+            if (o >= 0) d.posediag[o + pmap(c)] += v;
+        }
     }
     __syncthreads();
     double md = 0.0;

@@ -265,6 +265,8 @@ struct plba_problem {
     std::vector<int32_t> h_pidx, h_seg_col, h_alist;      // host copies of the chain maps / assembly list (band measurement)
     // fused landmark-major passes (options.lm_fused; plba_lm_dev.h)
     bool lm_ok = false;                         // this upload runs them (structure permitting: one GPU, chain path, <= 8 observations per landmark)
+    unsigned long long state_epoch = 1, res_lm_epoch = 0;      // estimates on the device changed | the host mirror of the landmark array is of that epoch
+    std::vector<double> res_lm;                 // plba_get_points / plba_get_lines: one read-back per state
     std::vector<double> lm_hist;                // diagnostics (plba_debug_get "lm_groups")
     int seg_launch_est = 0;                     // dependent factorisation launches the chain segment-length choice expected (diagnostics)
     bool lm_chi_dirty = false;                  // the fused passes' group-order chi2 cache is newer than DevBuf::ob_chi2
