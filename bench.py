@@ -151,14 +151,10 @@ def config5_leg(pkg, stream, iters=30):
     return out
 
 
-def realistic_leg(pkg, stream, iters=100):
-    """the headline windows have tracks over <= 8 CONSECUTIVE keyframes (SURVEY 8d's generator).  This side leg is
-    the reference's own window shape instead — 12 keyframes (include/mapHandler.h:217), tracks over 6 .. 12 of them (most of the
-    window), one landmark in five seen again after a gap — through the default options; it reports which solver / landmark path the
-    structure detection picked and the rate."""
+def _side_leg(pkg, stream, w, iters, **opts):
+    """stage-2 LM iterations of one window, timed like the headline (replayed from the post-gating state), with the given options"""
     import torch
-    w = pkg.window.make_window(12, 2000, 400, imu=True, seed=0x5EED00C0, kf_dt=0.1, track=(6, 12), revisit=0.2)
-    prob = pkg.new_problem()
+    prob = pkg.new_problem(**opts)
     prob.set_stream(stream.cuda_stream)
     prob.upload_window(w)
     stage1_and_gate(prob, pkg)
@@ -168,11 +164,41 @@ def realistic_leg(pkg, stream, iters=100):
     done, trials, _ = run_iterations(prob, iters)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out = dict(workload="12 KF / 2000 points / 400 lines + IMU, tracks over 6..12 keyframes, 20 % non-consecutive re-observations",
-               iterations_per_s=done / dt, ms_per_iteration=dt / done * 1e3, trials_per_iteration=trials / max(done, 1),
-               point_obs=int(w["meta"]["Ep"]), line_obs=int(w["meta"]["El"]), pose_dim=int(prob.debug_get("pose_dim")[0]), dense_dim=int(prob.debug_get("dense_dim")[0]),
-               twin_factorisation=bool(prob.debug_get("twin")[0]), banded_twisted_solve=bool(prob.debug_get("band")[0]), fused_landmark_passes=bool(prob.debug_get("lm_fused")[0]))
+    lmf = prob.debug_get("lm_fused")
+    out = dict(iterations_per_s=done / dt, ms_per_iteration=dt / done * 1e3, trials_per_iteration=trials / max(done, 1),
+               pose_dim=int(prob.debug_get("pose_dim")[0]), dense_dim=int(prob.debug_get("dense_dim")[0]),
+               twin_factorisation=bool(prob.debug_get("twin")[0]), banded_twisted_solve=bool(prob.debug_get("band")[0]),
+               fused_landmark_passes=bool(lmf[0]), wide_groups=int(lmf[3]) if len(lmf) > 3 else 0)
     prob.close()
+    return out
+
+
+def realistic_leg(pkg, stream, iters=100):
+    """The reference's own window shape — 12 keyframes (include/mapHandler.h:217), tracks over 6 .. 12 of them (most of the window), one
+    landmark in five seen again after a gap — instead of SURVEY 8d's generator (tracks over <= 8 consecutive keyframes).  Round 4: the
+    fused landmark passes take such a window (wide groups for the tracks over 9 .. 12 keyframes); the leg reports the DEFAULT options'
+    choice and rate, and both landmark paths forced, side by side."""
+    w = pkg.window.make_window(12, 2000, 400, imu=True, seed=0x5EED00C0, kf_dt=0.1, track=(6, 12), revisit=0.2)
+    out = dict(workload="12 KF / 2000 points / 400 lines + IMU, tracks over 6..12 keyframes, 20 % non-consecutive re-observations",
+               point_obs=int(w["meta"]["Ep"]), line_obs=int(w["meta"]["El"]))
+    out.update(_side_leg(pkg, stream, w, iters))
+    out["record_based_passes"] = {k: v for k, v in _side_leg(pkg, stream, w, iters, lm_fused=0).items() if k in ("iterations_per_s", "ms_per_iteration")}
+    f = _side_leg(pkg, stream, w, iters, lm_fused=2)
+    out["fused_passes_forced"] = {k: f[k] for k in ("iterations_per_s", "ms_per_iteration", "fused_landmark_passes", "wide_groups")}
+    return out
+
+
+def long_track_leg(pkg, stream, iters=60):
+    """the headline depends on the generator's band structure (tracks over <= 8 CONSECUTIVE keyframes give a reduced
+    camera system with a band of two 32-column tiles).  The same 50 KF / 20k points / 4k lines + IMU with tracks over 2 .. 15 keyframes and
+    one landmark in five seen again up to 30 keyframes later (a place revisited): a reduced system WITHOUT a usable band (the plain dense
+    factorisation, one launch per 32 columns) and landmarks for standard and wide groups side by side.  Default options; the solver and
+    landmark path are reported.  (With re-observation gaps of 1 .. 3 keyframes only, the band survives — three tiles — and the multi-chain
+    factorisation still runs: 0.252 ms per iteration, measured in round 4.)"""
+    w = pkg.window.make_window(50, 20000, 4000, imu=True, seed=0x5EED00D0, track=(2, 15), revisit=0.2, revisit_gap=(1, 30))
+    out = dict(workload="50 KF / 20k points / 4k lines + IMU, tracks over 2..15 keyframes, 20 % re-observed after a gap of 1..30 keyframes (no band in the reduced system)",
+               point_obs=int(w["meta"]["Ep"]), line_obs=int(w["meta"]["El"]))
+    out.update(_side_leg(pkg, stream, w, iters))
     return out
 
 
@@ -404,6 +430,11 @@ def main():
         "roofline": roofline,
         "roofline_hbm_kernel": roof_hbm,
         "phase_ms_per_iteration": per_iter,
+        # what a scaling curve is made of (rank 0's profile = 2 pass, every phase bracketed by events): the landmark-parallel part shrinks
+        # with N, the reduced-camera solve is replicated on every rank, the exchange is what N > 1 adds
+        "scaling_phases_ms_per_iteration": {
+            "sharded_landmark_side": per_iter["linearize_launch"] + per_iter["schur"] + per_iter["backsub_update"] + per_iter["trial_errors"] + per_iter["landmark_blocks_and_reductions"],
+            "replicated_solve": per_iter["dense_solve"], "exchange": per_iter["exchange"]},
     }
     if world == 1:
         # end-to-end cost of one reference-shaped BA call incl. PCIe: SoA upload + structure build + 5+10 LM
@@ -425,6 +456,7 @@ def main():
     if world == 1 and cfg_idx == 3 and not args.no_config5_leg:
         out["config"]["configs4_single_gpu"] = config5_leg(pkg, stream)
         out["config"]["realistic_12kf_window"] = realistic_leg(pkg, stream)
+        out["config"]["long_track_50kf_window"] = long_track_leg(pkg, stream)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and cfg_idx == 3:
             out["max_pose_delta_vs_cpu"], out["config4_sliding_window"] = parity_and_config4(w_full, pkg)

@@ -1687,11 +1687,13 @@ static int lm_enqueue_system(plba_problem* p, const DevBuf& ds, int state, bool 
         // only the entries that can be non-zero before the factorisation (pose x pose, IMU / prior blocks, diagonal) and the two rhs rows travel
         const size_t npk = list_packed_size(ds);
         if (p->d_xbuf.n < npk) HIPCK(p, p->d_xbuf.alloc(npk, false));
+        if (mark) MARK(p, 13);      // profile = 2: [13, 14] = pack + all-reduce + unpack of the structural entries (ms_phase[6])
         launch_list_pack(ds, p->d_xbuf.p, false, s);
         int rc = exchange(p, p->d_xbuf.p, npk, 0);
         if (rc) return rc;
         launch_list_pack(ds, p->d_xbuf.p, true, s);
         HIPCK(p, hipMemcpyAsync(ds.bpg, ds.sys + (size_t)(ds.Ppad + 1) * ds.ld, (size_t)ds.ld * 8, hipMemcpyDeviceToDevice, s));
+        if (mark) MARK(p, 14);
         launch_chain_elim(ds, p->cv, s);
     }
     return PLBA_OK;
@@ -1776,7 +1778,9 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
                 MARK(p, 9);
                 if (sharded) {      // [chi2, landmark part of the scale] become global; every rank then takes the same decision
                     launch_reduce_n(d, owns_pose_edges(p), p->d_red.p, p->lv.ngrp, s);
+                    MARK(p, 15);
                     if ((rc = exchange(p, p->d_red.p, 4, 0))) return rc;      // [chi2, scale, (max diag: unused here), in-launch wait failed on some rank]
+                    MARK(p, 16);
                     launch_decide(d, lp, p->d_red.p, false, p->d_mail, seq, s);
                 } else launch_decide_n(d, lp, p->d_red.p, p->lv.ngrp, p->d_mail, seq, s);
                 MARK(p, 10);
@@ -1806,6 +1810,10 @@ int plba_optimize(plba_problem* p, int max_iters, const volatile uint8_t* abort_
                 if (qmax == 0 && it == 0) st.ms_phase[7] += span(0, 3);
                 if (!had_spec) { st.ms_phase[0] += span(4, 5); ++p->prof_lin_launches; st.ms_phase[2] += span(5, 6); }
                 st.ms_phase[3] += span(6, 7); st.ms_phase[4] += span(7, 8); st.ms_phase[5] += span(8, 9); st.ms_phase[7] += span(9, 10);
+                if (sharded) {      // the two all-reduces of a trial, out of the phases they sit in
+                    const double x1 = had_spec ? 0.0 : span(13, 14), x2 = span(15, 16);
+                    st.ms_phase[6] += x1 + x2; st.ms_phase[2] -= x1; st.ms_phase[7] -= x2;
+                }
             }
             const Ctrl& c = *p->h_ctrl;
             rho = c.rho;

@@ -1529,7 +1529,10 @@ namespace plba {
 
 // ---- fused landmark-major passes: kernels (bodies in plba_lm_dev.h) ------------------------------------------------------------------
 // launch C of an iteration: [chain segments, reading the pose-side accumulators directly (they carry no landmark term) | groups]
-template <int MODE>
+// WIDE_OK: the instantiation that also carries the wide groups' code (landmarks over 9 .. 16 keyframes); a window without such landmarks
+// (lv.wmax == 8: every BASELINE config) runs the instantiation without it — inlined next to the standard groups' code the wide path cost
+// them registers (k_lm_schur<0> 24.7 -> 26.2 us at configs[2], profiles/r04_*), as a separate instantiation it costs nothing
+template <int MODE, bool WIDE_OK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_lm_schur(DevBuf d, LmView lv, int state, Robust rb, ChainView cv, int nlead, int spec) {
     if (spec && !d.ctrl->accepted) return;      // enqueued behind the deciding launch: runs only for the state that was accepted
     __shared__ LmLds S;
@@ -1547,8 +1550,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int kind = lv.grp[b].kind;      // bit 0: lines, bit 1: wide (landmarks seen from 9 .. 16 keyframes)
     if (kind == 0) lm_schur_group<false, MODE>(d, lv, b, state, rb, S, A4);
     else if (kind == 1) lm_schur_group<true, MODE>(d, lv, b, state, rb, S, A4);
-    else if (kind == 2) lm_schur_group_wide<false, MODE>(d, lv, b, state, rb, S, A4);
-    else lm_schur_group_wide<true, MODE>(d, lv, b, state, rb, S, A4);
+    else if (WIDE_OK && kind == 2) lm_schur_group_wide<false, MODE>(d, lv, b, state, rb, S, A4);
+    else if (WIDE_OK) lm_schur_group_wide<true, MODE>(d, lv, b, state, rb, S, A4);
 }
 // launch D: [blocks assembling the part of the system no landmark touches | gather blocks: pose-pair blocks and right-hand-side rows =
 // pose-side terms + the groups' parts]
@@ -1566,7 +1569,7 @@ __global__ __launch_bounds__(256) void k_lm_gather(DevBuf d, LmView lv, int nasm
 // decision (da.fuse).  The pose-side blocks need the trial keyframes of the segments in front (lead_wait); they come LAST so that they
 // fill the slots the second round of groups leaves free instead of delaying the first: their serial per-edge math (16 us) and the
 // chain segments (17 us) then run in the shadow of the landmark pass — as launches of their own they cost 22 us / 17 us of an iteration.
-template <bool JAC>
+template <bool JAC, bool WIDE_OK>
 __global__ __launch_bounds__(LMB) void k_lm_trial(DevBuf d, LmView lv, int cur, int trial, Robust rb, ChainView cv, const double* xd, int nlead, int npose, unsigned back_target, DecideArgs da) {
     static_assert(LMB == 256, "chain_back_segment's thread layout");
     __shared__ double s4[4];
@@ -1584,8 +1587,8 @@ __global__ __launch_bounds__(LMB) void k_lm_trial(DevBuf d, LmView lv, int cur, 
         const int kind = lv.grp[g].kind;
         if (kind == 0) lm_trial_group<false, false>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
         else if (kind == 1) lm_trial_group<true, false>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
-        else if (kind == 2) lm_trial_group<false, true>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
-        else lm_trial_group<true, true>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
+        else if (WIDE_OK && kind == 2) lm_trial_group<false, true>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
+        else if (WIDE_OK) lm_trial_group<true, true>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
     } else {
         const int m = b - nlead - lv.ngrp;
         const LeadWait lw{d.back_cnt, back_target, &d.ctrl->sync_fail};
@@ -1600,15 +1603,20 @@ __global__ __launch_bounds__(LMB) void k_lm_trial(DevBuf d, LmView lv, int cur, 
 // -------------------------------------------------------------------------------------------------
 void launch_lm_schur(const DevBuf& d, const LmView& lv, int state, const Robust& rb, bool diag_pass, const ChainView* lead, bool spec, hipStream_t s, bool with_pose_edges) {
     const size_t sh = sizeof(LmAcc) > sizeof(ChainElimLds) ? sizeof(LmAcc) : sizeof(ChainElimLds);      // a chain segment's staging shares the dynamic LDS
+    const bool wide = lv.wmax > LMF_W;
     if (diag_pass) {
-        if (ensure_dyn_lds(reinterpret_cast<const void*>(k_lm_schur<1>), (int)sh) != hipSuccess) return;      // surfaces at the caller's hipGetLastError
+        const void* fn = wide ? reinterpret_cast<const void*>(k_lm_schur<1, true>) : reinterpret_cast<const void*>(k_lm_schur<1, false>);
+        if (ensure_dyn_lds(fn, (int)sh) != hipSuccess) return;      // surfaces at the caller's hipGetLastError
         const int npose = with_pose_edges ? d.M + (d.pr_nv > 0 ? 1 : 0) : 0;
-        hipLaunchKernelGGL(k_lm_schur<1>, dim3(lv.ngrp + npose), dim3(256), sh, s, d, lv, state, rb, ChainView{}, 0, 0);
+        if (wide) hipLaunchKernelGGL((k_lm_schur<1, true>), dim3(lv.ngrp + npose), dim3(256), sh, s, d, lv, state, rb, ChainView{}, 0, 0);
+        else hipLaunchKernelGGL((k_lm_schur<1, false>), dim3(lv.ngrp + npose), dim3(256), sh, s, d, lv, state, rb, ChainView{}, 0, 0);
         return;
     }
-    if (ensure_dyn_lds(reinterpret_cast<const void*>(k_lm_schur<0>), (int)sh) != hipSuccess) return;
+    const void* fn = wide ? reinterpret_cast<const void*>(k_lm_schur<0, true>) : reinterpret_cast<const void*>(k_lm_schur<0, false>);
+    if (ensure_dyn_lds(fn, (int)sh) != hipSuccess) return;
     const int nlead = lead ? lead->nseg : 0;
-    hipLaunchKernelGGL(k_lm_schur<0>, dim3(lv.ngrp + nlead), dim3(256), sh, s, d, lv, state, rb, lead ? *lead : ChainView{}, nlead, spec ? 1 : 0);
+    if (wide) hipLaunchKernelGGL((k_lm_schur<0, true>), dim3(lv.ngrp + nlead), dim3(256), sh, s, d, lv, state, rb, lead ? *lead : ChainView{}, nlead, spec ? 1 : 0);
+    else hipLaunchKernelGGL((k_lm_schur<0, false>), dim3(lv.ngrp + nlead), dim3(256), sh, s, d, lv, state, rb, lead ? *lead : ChainView{}, nlead, spec ? 1 : 0);
 }
 void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool add_lambda, bool spec, hipStream_t s) {
     int nasm = 0;
@@ -1626,8 +1634,12 @@ void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, bool
     DecideArgs da{};
     if (df) { da.lp = df->lp; da.red = df->red; da.mail = df->mail; da.seq = df->seq; da.nblk_lm = lv.ngrp; da.fuse = 1; }
     const dim3 grid(nlead + lv.ngrp + npose);
-    if (jac) hipLaunchKernelGGL(k_lm_trial<true>, grid, dim3(LMB), 0, s, d, lv, cur, trial, rb, lead ? *lead : ChainView{}, xd, nlead, npose, back_target, da);
-    else hipLaunchKernelGGL(k_lm_trial<false>, grid, dim3(LMB), 0, s, d, lv, cur, trial, rb, lead ? *lead : ChainView{}, xd, nlead, npose, back_target, da);
+    const bool wide = lv.wmax > LMF_W;
+    const ChainView cvl = lead ? *lead : ChainView{};
+    if (jac && wide) hipLaunchKernelGGL((k_lm_trial<true, true>), grid, dim3(LMB), 0, s, d, lv, cur, trial, rb, cvl, xd, nlead, npose, back_target, da);
+    else if (jac) hipLaunchKernelGGL((k_lm_trial<true, false>), grid, dim3(LMB), 0, s, d, lv, cur, trial, rb, cvl, xd, nlead, npose, back_target, da);
+    else if (wide) hipLaunchKernelGGL((k_lm_trial<false, true>), grid, dim3(LMB), 0, s, d, lv, cur, trial, rb, cvl, xd, nlead, npose, back_target, da);
+    else hipLaunchKernelGGL((k_lm_trial<false, false>), grid, dim3(LMB), 0, s, d, lv, cur, trial, rb, cvl, xd, nlead, npose, back_target, da);
 }
 // sharded runs of the fused passes: the local sums go out for the all-reduce instead of being consumed by the control kernel
 void launch_reduce_n(const DevBuf& d, bool owns_pose_edges, double* red, int nred, hipStream_t s) {

@@ -167,8 +167,14 @@ struct LmStep {      // one lane's share of a step's inputs (prefetched a step a
 struct LmIdx { int slot, e; bool uvalid, has, fixed; };
 // WIDE: a landmark block takes TWO neighbouring units — window slots 0 - 7 and 8 - 15 — so a point is 2 units and a line 4
 // (end point P: slots 0 - 7 | 8 - 15, then end point Q likewise); the lane's window slot is 8 (unit & 1) + (lane & 7)
+// The group descriptor is NOT copied into a local: its window arrays are indexed by the thread (g.kf[p]), which put the whole struct into
+// scratch memory — 80 (round 3) / 144 bytes per LANE written at the start of every workgroup, ~10 MB per launch at configs[2]: the
+// "wasted writes" of profiles/r03_pmc_traffic.json (WRITE_SIZE 8.75 MB against 3.3 MB of outputs).  The scalars the loop needs travel
+// in LmHead (registers); the window arrays are read from global memory where they are used, once.
+struct LmHead { int lm0, nlm, nw; };
+DEV LmHead lm_head(const LmGroup& g) { LmHead h; h.lm0 = g.lm0; h.nlm = g.nlm; h.nw = g.nw; return h; }
 template <bool IS_LINE, bool WIDE = false>
-DEV void lm_load_idx(const LmView& lv, const LmGroup& g, int step, int wv, int lane, LmIdx& x) {
+DEV void lm_load_idx(const LmView& lv, const LmHead& g, int step, int wv, int lane, LmIdx& x) {
     const int unit = step * LMF_UNITS + wv * 8 + (lane >> 3), sub = WIDE ? 8 * ((lane >> 3) & 1) + (lane & 7) : (lane & 7);
     const int n = WIDE ? (IS_LINE ? (unit >> 2) : (unit >> 1)) : (IS_LINE ? (unit >> 1) : unit);
     x.uvalid = n < g.nlm; x.slot = 0; x.e = 0; x.has = false; x.fixed = true;
@@ -199,17 +205,17 @@ DEV void lm_load_data(const DevBuf& d, const LmView& lv, int state, int lane, co
     }
 }
 template <bool IS_LINE, bool WIDE = false>
-DEV void lm_load(const DevBuf& d, const LmView& lv, const LmGroup& g, int state, int step, int wv, int lane, LmStep& s) {
+DEV void lm_load(const DevBuf& d, const LmView& lv, const LmHead& g, int state, int step, int wv, int lane, LmStep& s) {
     LmIdx x;
     lm_load_idx<IS_LINE, WIDE>(lv, g, step, wv, lane, x);
     lm_load_data<IS_LINE, WIDE>(d, lv, state, lane, x, s);
 }
 
 // camera blocks (and kf_off_pvr) of the group's window at `state`
-DEV void lm_stage_window(const DevBuf& d, const LmGroup& g, int state, LmLds& S) {
+DEV void lm_stage_window(const DevBuf& d, const LmGroup* gp, int nw, int state, LmLds& S) {
     if ((int)threadIdx.x < LMF_W2) {
         const int p = threadIdx.x;
-        if (p < g.nw) { kfcam_make(d.cam, d.kf[state] + (size_t)g.kf[p] * KF_STRIDE, S.kc[0][p]); S.koff[p] = g.off[p]; }
+        if (p < nw) { kfcam_make(d.cam, d.kf[state] + (size_t)gp->kf[p] * KF_STRIDE, S.kc[0][p]); S.koff[p] = gp->off[p]; }
         else { for (int t = 0; t < KFCAM_STRIDE; ++t) S.kc[0][p][t] = 0.0; S.koff[p] = -1; }
     }
 }
@@ -235,10 +241,11 @@ DEV void lm_wave_sync() {
 template <bool IS_LINE, int MODE>
 DEV void lm_schur_group(const DevBuf& d, const LmView& lv, const int gidx, const int state, const Robust& rb, LmLds& S, LmAcc& A4) {
     constexpr int NR = IS_LINE ? 1 : 2;
-    const LmGroup g = lv.grp[gidx];
+    const LmGroup* gp = lv.grp + gidx;
+    const LmHead g = lm_head(*gp);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 7, li = lane & 15, lk = lane >> 4, u8 = lane >> 3;
     const double lambda = MODE == 0 ? d.ctrl->lambda : 0.0;
-    lm_stage_window(d, g, state, S);
+    lm_stage_window(d, gp, g.nw, state, S);
     const int nunits = IS_LINE ? 2 * g.nlm : g.nlm;
     const int nsteps = (nunits + LMF_UNITS - 1) / LMF_UNITS;
 #ifdef PLBA_STAMPS_LMF
@@ -484,12 +491,13 @@ template <bool IS_LINE, int MODE>
 DEV void lm_schur_group_wide(const DevBuf& d, const LmView& lv, const int gidx, const int state, const Robust& rb, LmLds& S, LmAcc& A4) {
     constexpr int NR = IS_LINE ? 1 : 2;
     static_assert(sizeof(LmAcc) >= sizeof(double) * LMW_KCOLS * LMW_ROWS, "the wide panel shares the standard groups' dynamic LDS");
-    const LmGroup g = lv.grp[gidx];
+    const LmGroup* gp = lv.grp + gidx;
+    const LmHead g = lm_head(*gp);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, u8 = lane >> 3;
     const int slot = 8 * (u8 & 1) + (lane & 7);      // the lane's window slot
     const int blk = u8 >> 1;                         // the landmark block inside the wave (0 .. 3)
     const double lambda = MODE == 0 ? d.ctrl->lambda : 0.0;
-    lm_stage_window(d, g, state, S);
+    lm_stage_window(d, gp, g.nw, state, S);
     const int nunits = (IS_LINE ? 4 : 2) * g.nlm;
     const int nsteps = (nunits + LMF_UNITS - 1) / LMF_UNITS;
     LmStep cur;
@@ -769,7 +777,8 @@ DEV void lm_assemble_rest(const DevBuf& d, const LmView& lv, int add_lambda, int
 template <bool IS_LINE, bool WIDE = false>
 DEV void lm_trial_group(const DevBuf& d, const LmView& lv, const int gidx, const int cur_state, const int trial, const Robust& rb, const ChainView& cv, const double* xd, const bool from_dense, LmLds& S) {
     constexpr int NR = IS_LINE ? 1 : 2;
-    const LmGroup g = lv.grp[gidx];
+    const LmGroup* gp = lv.grp + gidx;
+    const LmHead g = lm_head(*gp);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = WIDE ? (lane & 15) : (lane & 7);      // sub == 0: the landmark block's first lane
     const double lambda = d.ctrl->lambda;
     const bool sok = d.ctrl->solver_ok != 0;
@@ -777,7 +786,7 @@ DEV void lm_trial_group(const DevBuf& d, const LmView& lv, const int gidx, const
         const int p = threadIdx.x;
         double u9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (p < g.nw) {
-            const int k = g.kf[p], o = g.off[p];
+            const int k = gp->kf[p], o = gp->off[p];
             const double* s = d.kf[cur_state] + (size_t)k * KF_STRIDE;
             if (o >= 0 && sok) {
                 if (from_dense) { const int32_t* sc = cv.slotcol + cv.kfpos[k] * NSLOT; u9[0] = xd[sc[0]]; u9[1] = xd[sc[1]]; u9[2] = xd[sc[2]]; u9[6] = xd[sc[3]]; u9[7] = xd[sc[4]]; u9[8] = xd[sc[5]]; }

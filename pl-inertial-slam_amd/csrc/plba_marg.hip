@@ -784,16 +784,20 @@ __global__ __launch_bounds__(64) void k_cert_w(const double* A, int pos, const i
         if (lane == 0) atomicMax(cb.w2max_bits, (unsigned long long)__double_as_longlong(acc2));
     }
 }
-// out: cert[0] = 1 when the block-wise path may be taken; diag = [w_max, smallest kept landmark eigenvalue, tau, smallest pivot]
-__global__ __launch_bounds__(256) void k_cert_final(const double* A, int pos, int po, int ps, const int* boff, const int* bsize, int nblk, double hi,
-                                                   CertBuf cb, int* cert, double* diag) {
+// out: diag = [w_max, smallest kept landmark eigenvalue, tau, smallest pivot, 1 when the block-wise path may be taken] — ONE read-back
+// One wave per entry of S(hi) (round 4: a lane per landmark block, summed in a fixed order; one thread walked all ~100 blocks per entry
+// before, 0.1 ms of dependent loads), then the 15 x 15 Cholesky in lane 0 of the workgroup that arrives last.
+__global__ __launch_bounds__(64) void k_cert_final(const double* A, int pos, int po, int ps, const int* boff, const int* bsize, int nblk, double hi,
+                                                  CertBuf cb, int* cert, double* diag, double* Sg, unsigned* arrive) {
     __shared__ double S[MAXB * MAXB];
-    const int t = threadIdx.x;
-    if (t < ps * ps) {
-        const int i = t / ps, j = t % ps;
+    __shared__ int s_last;
+    const int t = blockIdx.x, lane = threadIdx.x;
+    {
+        const int i = ps ? t / ps : 0, j = ps ? t % ps : 0;
         const double* ai = A + (size_t)(po + i) * pos; const double* aj = A + (size_t)(po + j) * pos;      // symmetric: row j for column j
-        double acc = ai[po + j];
-        for (int l = 0; l < nblk; ++l) {
+        double acc = 0.0;
+        if (ps > 0)
+        for (int l = lane; l < nblk; l += 64) {
             const int s = bsize[l], o = boff[l];
             const double* ph = cb.pinv_hi + (size_t)l * 36;
             for (int tt = 0; tt < s; ++tt) {
@@ -804,10 +808,20 @@ __global__ __launch_bounds__(256) void k_cert_final(const double* A, int pos, in
                 acc -= a * z;
             }
         }
-        S[t] = acc;
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            if (ps > 0) __hip_atomic_store(&Sg[t], ai[po + j] + acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (prev == gridDim.x - 1) ? 1 : 0;
+            if (s_last) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
-    if (t != 0) return;
+    if (!s_last) return;
+    for (int q = lane; q < ps * ps; q += 64) S[q] = __hip_atomic_load(&Sg[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (lane != 0) return;
     const double wmax = sqrt(__longlong_as_double((long long)*cb.w2max_bits));
     const double lmin = __longlong_as_double((long long)*cb.lam_min_bits);
     double tr = 0.0;
@@ -829,7 +843,7 @@ __global__ __launch_bounds__(256) void k_cert_final(const double* A, int pos, in
         }
     }
     cert[0] = ok ? 1 : 0;
-    diag[0] = wmax; diag[1] = lmin; diag[2] = tau; diag[3] = minpiv;
+    diag[0] = wmax; diag[1] = lmin; diag[2] = tau; diag[3] = minpiv; diag[6] = ok ? 1.0 : 0.0;      // ([4], [5]: the atomically reduced lam_min / w_max^2 bits)
 }
 __global__ void k_set_identity(double* V, int n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1015,10 +1029,11 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
     if (mode < 0 || mode > 2) PLBA_FAIL(p, PLBA_ERR_INVALID, "marg_exact = %d (0 block-wise, 1 certified block-wise else dense, 2 dense)", mode);
     bool blockwise = mode != 2;
     const bool cert = mode == 1 && m > 0;
-    double cert_diag[4] = {0, 0, 0, 0};
+    double cert_diag[7] = {0, 0, 0, 0, 0, 0, 0};
+    constexpr int CERT_HDR = 8 + MAXB * MAXB + 8;      // [diag (8) | S(hi) (15 x 15) | arrival counter (8)] ahead of the per-block tables
     if (cert) {
-        PLBA_HIPCK(p, dCertD.alloc((size_t)std::max(nb, 1) * 72 + 8)); PLBA_HIPCK(p, dCertI.alloc((size_t)std::max(nb, 1) + 8));
-        cb.pinv_hi = dCertD.p + 8; cb.udrop = cb.pinv_hi + (size_t)std::max(nb, 1) * 36;
+        PLBA_HIPCK(p, dCertD.alloc((size_t)std::max(nb, 1) * 72 + CERT_HDR)); PLBA_HIPCK(p, dCertI.alloc((size_t)std::max(nb, 1) + 8));
+        cb.pinv_hi = dCertD.p + CERT_HDR; cb.udrop = cb.pinv_hi + (size_t)std::max(nb, 1) * 36;
         cb.ndrop = dCertI.p + 8; cb.band = dCertI.p + 1;
         cb.lam_min_bits = reinterpret_cast<unsigned long long*>(dCertD.p + 4); cb.w2max_bits = reinterpret_cast<unsigned long long*>(dCertD.p + 5);
         hipLaunchKernelGGL(k_cert_init, dim3(1), dim3(1), 0, s, cb);
@@ -1027,11 +1042,10 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
         hipLaunchKernelGGL(k_block_pinv_small, dim3((nb + 63) / 64), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, nb, eps, dPinvL.p, cert, hi, cb);
     if (cert) {
         if (nb > 0) hipLaunchKernelGGL(k_cert_w, dim3(nb), dim3(64), 0, s, dA.p, pos, dboff.p, dbsize.p, cb);
-        hipLaunchKernelGGL(k_cert_final, dim3(1), dim3(256), 0, s, dA.p, pos, pose_off, pose_size, dboff.p, dbsize.p, nb, hi, cb, dCertI.p, dCertD.p);
-        int ok = 0;
+        hipLaunchKernelGGL(k_cert_final, dim3(std::max(pose_size * pose_size, 1)), dim3(64), 0, s, dA.p, pos, pose_off, pose_size, dboff.p, dbsize.p, nb, hi, cb, dCertI.p, dCertD.p,
+                           dCertD.p + 8, reinterpret_cast<unsigned*>(dCertD.p + 8 + MAXB * MAXB));
         PLBA_HIPCK(p, plba_d2h(p, cert_diag, dCertD.p, sizeof cert_diag));      // (blocking: the one decision this call takes on the host)
-        PLBA_HIPCK(p, plba_d2h(p, &ok, dCertI.p, sizeof ok));
-        blockwise = ok != 0;
+        blockwise = cert_diag[6] != 0.0;
     }
     p->marg_path[0] = blockwise ? 0.0 : 1.0;
     for (int t = 0; t < 4; ++t) p->marg_path[1 + t] = cert_diag[t];

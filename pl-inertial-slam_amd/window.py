@@ -269,11 +269,12 @@ def _project(Rwb, Pwb, Rbc, Pbc, Pw):
     return uv, z
 
 
-def _gen_tracks(rng, K, N, Rwb, Pwb, Rbc, Pbc, is_line, track=(2, 8), revisit=0.0):
+def _gen_tracks(rng, K, N, Rwb, Pwb, Rbc, Pbc, is_line, track=(2, 8), revisit=0.0, revisit_gap=(1, 3)):
     """Landmarks in front of an anchor keyframe, observed in keyframes a..a+L-1 (L ~ U{track}, default U{2..8}) where
     the projection stays in the image with z > 0.1; keeps generating until N have >= 2 observations.
-    revisit > 0: with that probability a landmark is seen again in ONE later keyframe beyond a gap of 1..3 keyframes
-    after its track (a non-consecutive re-observation, as after a short occlusion)."""
+    revisit > 0: with that probability a landmark is seen again in ONE later keyframe beyond a gap of revisit_gap (default 1..3)
+    keyframes after its track (a non-consecutive re-observation, as after a short occlusion; a long gap — tens of keyframes — is a
+    place revisited: it couples keyframes far apart and leaves the reduced camera system without a band)."""
     lms, obs_lm, obs_kf, obs_uv = [], [], [], []
     count = 0
     while count < N:
@@ -284,7 +285,7 @@ def _gen_tracks(rng, K, N, Rwb, Pwb, Rbc, Pbc, is_line, track=(2, 8), revisit=0.
         L = rng.integers(B, track[0], track[1])
         if revisit > 0.0:
             rv = rng.uniform(B) < revisit
-            gap = rng.integers(B, 1, 3)
+            gap = rng.integers(B, revisit_gap[0], revisit_gap[1])
         Pc = np.stack([(u - CX) / FX * depth, (v - CY) / FY * depth, depth], -1)
         Pw = np.einsum("bij,bj->bi", Rwb[a], Pc @ Rbc.T + Pbc) + Pwb[a]
         if is_line:
@@ -313,7 +314,7 @@ def _gen_tracks(rng, K, N, Rwb, Pwb, Rbc, Pbc, is_line, track=(2, 8), revisit=0.
             np.concatenate(obs_uv))
 
 
-def make_window(K, Np, Nl, imu=True, seed=0x5EED0003, outlier_frac=0.05, t0=0.0, kf_id0=0, kf_dt=KF_DT, track=(2, 8), revisit=0.0):
+def make_window(K, Np, Nl, imu=True, seed=0x5EED0003, outlier_frac=0.05, t0=0.0, kf_id0=0, kf_dt=KF_DT, track=(2, 8), revisit=0.0, revisit_gap=(1, 3)):
     """Build one synthetic window.  Returns a dict (see Problem.upload_window) plus 'truth'.
     kf_dt: keyframe spacing in seconds (a multiple of the 5 ms IMU period); track: range of the track lengths;
     revisit: probability of a non-consecutive re-observation (see _gen_tracks).  The defaults are SURVEY 8d's."""
@@ -323,9 +324,9 @@ def make_window(K, Np, Nl, imu=True, seed=0x5EED0003, outlier_frac=0.05, t0=0.0,
     Rwb, Pwb, Vwb = traj_R(tk), traj_p(tk), traj_v(tk)
 
     # ---- landmarks and clean observations -------------------------------------------------
-    pts, po_pt, po_kf, po_uv = _gen_tracks(rng, K, Np, Rwb, Pwb, Rbc, Pbc, False, track, revisit) if Np else \
+    pts, po_pt, po_kf, po_uv = _gen_tracks(rng, K, Np, Rwb, Pwb, Rbc, Pbc, False, track, revisit, revisit_gap) if Np else \
         (np.zeros((0, 3)), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2)))
-    lns, lo_ln, lo_kf, lo_uv4 = _gen_tracks(rng, K, Nl, Rwb, Pwb, Rbc, Pbc, True, track, revisit) if Nl else \
+    lns, lo_ln, lo_kf, lo_uv4 = _gen_tracks(rng, K, Nl, Rwb, Pwb, Rbc, Pbc, True, track, revisit, revisit_gap) if Nl else \
         (np.zeros((0, 6)), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 4)))
     Ep, El = len(po_pt), len(lo_ln)
 

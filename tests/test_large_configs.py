@@ -249,10 +249,10 @@ def test_realistic_12_keyframe_window_against_the_oracle(pkg, orc, hip):
     w = pkg.window.make_window(12, 600, 120, imu=True, seed=0x5EED00C0, kf_dt=0.1, track=(6, 12), revisit=0.2)
     ks = np.diff(np.flatnonzero(np.diff(np.concatenate([[-1], w["po_pt"], [-2]])))); assert ks.max() > 8      # more observations per landmark than a group's window
     gaps = [np.diff(w["po_kf"][w["po_pt"] == l]).max() for l in range(0, 600, 7)]; assert max(gaps) > 1      # non-consecutive re-observations exist
-    g = pkg.new_problem(); g.upload_window(w)
+    g = pkg.new_problem(lm_fused=2); g.upload_window(w)      # the fused passes take the window since round 4 (wide groups); default options: below
     o = orc.new_problem(); o.upload_window(w)
     rg, ro = pkg.protocol.local_ba(g), pkg.protocol.local_ba(o)
-    assert g.debug_get("lm_fused")[0] == 0
+    assert g.debug_get("lm_fused")[0] == 1 and g.debug_get("lm_fused")[3] > 0      # ... with wide groups for the tracks over 9 .. 12 keyframes
     assert rg["gated"] == ro["gated"]
     assert [t["accepted"] for t in g.trace()] == [t["accepted"] for t in o.trace()]
     assert rg["stage2"].chi2_final == pytest.approx(ro["stage2"].chi2_final, rel=1e-9)
@@ -261,4 +261,32 @@ def test_realistic_12_keyframe_window_against_the_oracle(pkg, orc, hip):
     assert pg["n"] == po["n"] and pg["n"] > 100      # every keyframe of the window among the kept parameters
     assert np.abs(pg["Ar"] - po["Ar"]).max() < 1e-7 * np.abs(po["Ar"]).max()
     print("realistic window: dense dim %d of %d, twin %d band %d" % (g.debug_get("dense_dim")[0], g.debug_get("pose_dim")[0], g.debug_get("twin")[0], g.debug_get("band")[0]))
-    g.close(); o.close()
+    g.close()
+    d = pkg.new_problem(); d.upload_window(w)      # DEFAULT options: whichever landmark path the size threshold picks, the same results
+    rd = pkg.protocol.local_ba(d)
+    assert rd["gated"] == ro["gated"] and rd["stage2"].chi2_final == pytest.approx(ro["stage2"].chi2_final, rel=1e-9)
+    assert max(_pose_delta(d.get_keyframes(), o.get_keyframes(), pkg)) < 1e-9
+    d.close(); o.close()
+
+
+def test_long_track_50_keyframe_window_against_the_oracle(pkg, orc, hip):
+    """a 50-keyframe window whose tracks span 2 .. 15 keyframes, one landmark in five seen again up to 30
+    keyframes later — no usable band in the reduced camera system (plain dense factorisation), standard and wide landmark groups side by side — through
+    the whole protocol with default options and with the fused passes forced, against the oracle.  (bench.py times the full-size window
+    of this shape as config.long_track_50kf_window.)"""
+    w = pkg.window.make_window(50, 4000, 800, imu=True, seed=0x5EED00D0, track=(2, 15), revisit=0.2, revisit_gap=(1, 30))
+    ks = np.diff(np.flatnonzero(np.diff(np.concatenate([[-1], w["po_pt"], [-2]])))); assert 8 < ks.max() <= 16
+    span = max(int(np.ptp(w["po_kf"][w["po_pt"] == l])) for l in range(0, 4000, 25)); assert span >= 20      # keyframes 20+ apart share landmarks: no band
+    o = orc.new_problem(); o.upload_window(w)
+    ro = pkg.protocol.local_ba(o)
+    for opts in (dict(), dict(lm_fused=2)):
+        g = pkg.new_problem(**opts); g.upload_window(w)
+        rg = pkg.protocol.local_ba(g)
+        if opts: assert g.debug_get("lm_fused")[0] == 1 and g.debug_get("lm_fused")[3] > 0
+        print("long-track window %s: dense dim %d, twin %d band %d, pose-pair blocks %d" % (opts, g.debug_get("dense_dim")[0], g.debug_get("twin")[0], g.debug_get("band")[0], g.debug_get("lm_fused")[2]))
+        assert rg["gated"] == ro["gated"]
+        assert [t["accepted"] for t in g.trace()] == [t["accepted"] for t in o.trace()]
+        assert rg["stage2"].chi2_final == pytest.approx(ro["stage2"].chi2_final, rel=1e-9)
+        assert max(_pose_delta(g.get_keyframes(), o.get_keyframes(), pkg)) < 1e-9
+        g.close()
+    o.close()
