@@ -530,10 +530,18 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     kmin.resize(L); kmax.resize(L); cnt.assign(K + 1, 0); stamp.assign(K, -1); ordall.clear();
     H.grp.clear(); H.span_at.clear(); H.span_end.clear(); H.span_ob0.clear();
     H.blk_c.clear(); H.row_c.clear(); H.blk_ij.clear(); H.blk_start.clear(); H.row_kf.clear(); H.row_start.clear();
-    for (int s = 0; s < L; ++s) {      // (ob_kf ascends within a landmark when the caller lists observations in keyframe order; not assumed)
-        int lo = K, hi = -1;
-        for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) { lo = std::min(lo, ob_kf[e]); hi = std::max(hi, ob_kf[e]); }
-        kmin[s] = lo; kmax[s] = hi;
+    {
+        const int NTK = E > 60000 ? 8 : E > 20000 ? 4 : 1;      // (independent per landmark: the worker pool takes it in ranges)
+        int32_t* kmn = kmin.data(); int32_t* kmx = kmax.data();
+        const int32_t* ls = lm_start.data(); const int32_t* ok = ob_kf.data();
+        HostPool::get().run(NTK, [=](int t) {
+            const int s0 = (int)((long)L * t / NTK), s1 = (int)((long)L * (t + 1) / NTK);
+            for (int s = s0; s < s1; ++s) {      // (ob_kf ascends within a landmark when the caller lists observations in keyframe order; not assumed)
+                int lo = K, hi = -1;
+                for (int e = ls[s]; e < ls[s + 1]; ++e) { lo = std::min(lo, ok[e]); hi = std::max(hi, ok[e]); }
+                kmn[s] = lo; kmx[s] = hi;
+            }
+        });
     }
     glap("kmin / kmax");
     int nlm = 0, nob = 0;
@@ -1670,6 +1678,13 @@ static int lm_enqueue_first(plba_problem* p, int iteration) {
         if ((rc = exchange(p, p->d_red.p, 1, 0))) return rc;
         if ((rc = exchange(p, p->d_red.p + 2, 1, 1))) return rc;
         if ((rc = exchange(p, d.posediag, (size_t)d.P, 0))) return rc;
+        launch_lambda_init2(d, lm_params(p), p->d_red.p, true, iteration, false, false, s);
+    } else if (p->lv.nrow * 6 > 256) {
+        // long windows (configs[4]: 200 keyframes): the one-workgroup form below walks 1200 diagonal entries x hundreds of groups, 98 us;
+        // the sharded path's launches — a workgroup per keyframe for the diagonal gather — take a quarter of that
+        launch_lm_gather(d, p->lv, true, false, false, s);
+        launch_reduce_n(d, true, p->d_red.p, p->lv.ngrp, s);
+        launch_posediag(d, s);
         launch_lambda_init2(d, lm_params(p), p->d_red.p, true, iteration, false, false, s);
     } else launch_lambda_init_n(d, p->lv, lm_params(p), p->d_red.p, iteration, p->lv.ngrp, s);      // (+ the diagonal gather)
     MARK(p, 3);

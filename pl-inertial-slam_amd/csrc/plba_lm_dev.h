@@ -848,8 +848,11 @@ DEV void lm_trial_group(const DevBuf& d, const LmView& lv, const int gidx, const
         if (sub == 0 && cur.uvalid) {
             if (active) sc_acc += xl[0] * (lambda * xl[0] + b[0]) + xl[1] * (lambda * xl[1] + b[1]) + xl[2] * (lambda * xl[2] + b[2]);
             double* Lt = d.lm[trial] + (size_t)cur.slot * 6 + (IS_LINE ? 3 * rowsel : 0);
-            const double* Lc = cur.L + (IS_LINE ? 3 * rowsel : 0);
-            Lt[0] = Lc[0] + xl[0]; Lt[1] = Lc[1] + xl[1]; Lt[2] = Lc[2] + xl[2];
+            // (selects, not `cur.L + 3 * rowsel`: an index the compiler cannot resolve puts the whole prefetched step into scratch memory —
+            // 104 bytes per lane and step, 6.6 MB per launch at configs[2] before round 4)
+            const bool second = IS_LINE && rowsel != 0;
+            const double c0 = second ? cur.L[3] : cur.L[0], c1 = second ? cur.L[4] : cur.L[1], c2 = second ? cur.L[5] : cur.L[2];
+            Lt[0] = c0 + xl[0]; Lt[1] = c1 + xl[1]; Lt[2] = c2 + xl[2];
             if (lv.dbg_out) { double* xo = d.xl + (size_t)cur.slot * 6 + (IS_LINE ? 3 * rowsel : 0); xo[0] = xl[0]; xo[1] = xl[1]; xo[2] = xl[2]; }
         }
         // residual of the trial state
