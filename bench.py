@@ -50,12 +50,12 @@ def csrc_sha16():
 
 
 def pmc_traffic(kernel_prefix, config5=False):
-    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r03_pmc_traffic.json for configs[2],
-    r03_config5_pmc_traffic.json for configs[4]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950
-    correction applied, tools/rocpd_extract.py, tools/collect_profiles_r03.sh).
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r04_pmc_traffic.json for configs[2],
+    r04_config5_pmc_traffic.json for configs[4]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950
+    correction applied, tools/rocpd_extract.py, tools/collect_profiles_r04.sh).
     PMC counters cannot be collected from inside this process, so the file is tied to the build it came from by a hash of
     csrc/: None when the file is absent or was measured on different kernel sources (never a stale number)."""
-    path = os.path.join(ROOT, "profiles", "r03_config5_pmc_traffic.json" if config5 else "r03_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_config5_pmc_traffic.json" if config5 else "r04_pmc_traffic.json")
     try:
         js = json.load(open(path))
         ks = js["kernels"]
@@ -381,7 +381,7 @@ def main():
     phase_names = ["linearize_launch", "factorisation_launches", "schur", "dense_solve", "backsub_update", "trial_errors", "exchange", "landmark_blocks_and_reductions"]
     per_iter = {k: float(v / max(done2, 1)) for k, v in zip(phase_names, phases2)}
     fused = bool(prob.debug_get("lm_fused")[0])      # the fused landmark-major passes (plba_lm_dev.h) run instead of the record-based ones
-    hbm_kernel = "k_lm_schur<0>" if fused else "k_linearize<true>"
+    hbm_kernel = "k_lm_schur<0" if fused else "k_linearize<true>"      # (k_lm_schur<0, false>: the instantiation without the wide groups' code)
     roof_hbm = dict(bound="hbm", kernel=("k_lm_schur<0> (fused landmark-major pass: residuals, Jacobians, Hll, damped inverse and the rank-k update of the pose blocks "
                                          "from the observation arrays; chain segments ride in the same launch)") if fused
                     else "k_linearize<true> (observation pass; IMU / prior edge blocks ride in the same launch)",

@@ -43,7 +43,7 @@ def pmc(db_fetch, db_write, out, bench_json=None, command=None):
             cfg = json.loads([l for l in open(bench_json).read().splitlines() if l.startswith("{")][-1])["config"]
             alg = 32 * cfg["point_obs"] + 40 * cfg["line_obs"] + 24 * cfg["points"] + 48 * cfg["lines"]
             for k, v in res.items():
-                if any(t in k for t in ("k_lm_schur<0>", "k_lm_trial", "k_linearize<true>", "k_linearize<false>")) and "traffic_bytes_per_launch" in v:
+                if any(t in k for t in ("k_lm_schur<0", "k_lm_trial", "k_linearize<true>", "k_linearize<false>")) and "traffic_bytes_per_launch" in v:
                     v["algorithmic_bytes_per_launch"] = alg
                     v["traffic_over_algorithmic"] = v["traffic_bytes_per_launch"] / alg
         except (OSError, ValueError, KeyError, IndexError):
