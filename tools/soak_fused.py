@@ -68,9 +68,22 @@ for case in range(N):
     if not loose: same = same and (sa1.solver_failures + sa.solver_failures) == (sb1.solver_failures + sb.solver_failures)
     t = 1e3 if loose else 1.0
     ok = same and dP < 1e-6 * t and dV < 1e-5 * t and dq < 1e-6 * t and (loose or (dpt < 1e-5 and dln < 1e-5)) and abs(sa.chi2_final - sb.chi2_final) <= 1e-6 * t * max(abs(sb.chi2_final), 1e-9)
+    verdict = "ok" if ok else "MISMATCH"
+    nf_hip, nf_orc = sa1.solver_failures + sa.solver_failures, sb1.solver_failures + sb.solver_failures
+    if not ok and nf_orc > nf_hip and max(dP, dV, dq) < 1e-3:
+        # the fp64 ORACLE failed a factorisation the device did not (its Hpp - Hpl D Hpl^T cancels where the fused square-root form does not:
+        # tests/test_fused_overshoot.py): the quad-precision build of the oracle arbitrates — trial counts and gating must be ITS
+        try:
+            q = orc.new_quad_problem(user_lambda_init=lam); q.upload_window(w)
+            sq1 = q.optimize(4); gq = q.gate_outliers(); sq = q.optimize(4); kq = q.get_keyframes(); q.close()
+            dq_quad = max(np.abs(ka[k] - kq[k]).max() for k in ("P", "q"))
+            if (sa1.iterations, sa1.trials, sa.iterations, sa.trials) == (sq1.iterations, sq1.trials, sq.iterations, sq.trials) and ga == gq and sq1.solver_failures + sq.solver_failures == nf_hip and dq_quad < 1e-6:
+                ok, verdict = True, "ok (the fp64 oracle failed %d factorisation(s); decisions = the quad-precision oracle's, |HIP - quad| %.1e)" % (nf_orc - nf_hip, dq_quad)
+        except Exception as e:      # noqa: BLE001 — no quad build on this box: the mismatch stands
+            verdict = "MISMATCH (quad arbiter unavailable: %s)" % e
     print("%3d K=%2d Np=%4d Nl=%4d tracks %d..%d imu %d lam %-6g %-22s fused %d groups %3d | trials %d+%d / %d+%d gated %s/%s chi2 %.6e / %.6e fails %d/%d dP %.1e dV %.1e dq %.1e dl %.1e %s" %
           (case, K, Np, Nl, lo, min(hi, K), imu, lam, "+".join(tag), fused, int(a.debug_get("lm_fused")[1]), sa1.trials, sa.trials, sb1.trials, sb.trials, ga, gb,
-           sa.chi2_final, sb.chi2_final, sa1.solver_failures + sa.solver_failures, sb1.solver_failures + sb.solver_failures, dP, dV, dq, max(dpt, dln), "ok" if ok else "MISMATCH"), flush=True)
+           sa.chi2_final, sb.chi2_final, nf_hip, nf_orc, dP, dV, dq, max(dpt, dln), verdict), flush=True)
     bad += not ok
     a.close(); b.close()
 print("%d cases, %d mismatches" % (N, bad))
