@@ -1089,6 +1089,21 @@ static int prepare(plba_problem* p) {
                         for (int g = 0; g < nseg; ++g) for (int t = 0; t < seg_start[g + 1] - seg_start[g]; ++t) fill(&bkf[(size_t)(g * CHAIN_SEG + t) * 20], ekf[seg_start[g] + t], true);
                         for (int u = 0; u < cv.nukf; ++u) fill(&bkf[(size_t)(nseg * CHAIN_SEG + u) * 20], ukf[u], false);
                         HIPCK(p, p->d_bkf.upload(bkf)); cv.bkf = p->d_bkf.p;
+                        // per IMU edge: the segment whose back-substitution yields its keyframes' chain dims (-1: both sit in the dense solution) and
+                        // the two keyframes' descriptors above (-1: no free dims) — the trial launch's IMU edge blocks form their two trial
+                        // states THEMSELVES instead of waiting for the segments' workgroups (pose_edge_block, round 4)
+                        std::vector<int32_t> desc_of_kf(K, -1), seg_of_kf(K, -1);
+                        for (int g = 0; g < nseg; ++g) for (int t = 0; t < seg_start[g + 1] - seg_start[g]; ++t) { const int kf = ekf[seg_start[g] + t]; desc_of_kf[kf] = g * CHAIN_SEG + t; seg_of_kf[kf] = g; }
+                        for (int u = 0; u < cv.nukf; ++u) if (pos_of_kf[ukf[u]] >= 0) desc_of_kf[ukf[u]] = nseg * CHAIN_SEG + u;
+                        std::vector<int32_t> iloc((size_t)std::max(M, 1) * 4, -1);
+                        bool iloc_ok = true;
+                        for (int m = 0; m < M; ++m) {
+                            const int ki = p->imu_i[m], kj = p->imu_j[m];
+                            const int gi = seg_of_kf[ki], gj = seg_of_kf[kj];
+                            if (gi >= 0 && gj >= 0 && gi != gj) iloc_ok = false;      // (cannot happen: a separator sits between two segments)
+                            iloc[4 * (size_t)m] = gi >= 0 ? gi : gj; iloc[4 * (size_t)m + 1] = desc_of_kf[ki]; iloc[4 * (size_t)m + 2] = desc_of_kf[kj];
+                        }
+                        HIPCK(p, p->d_imu_loc.upload(iloc)); cv.imu_loc = iloc_ok ? p->d_imu_loc.p : nullptr;
                     }
                     std::vector<int32_t> trow(2 * (size_t)(cv.Pdpad / 32), 0);
                     for (int tb = 0; tb < cv.Pdpad / 32; ++tb) {

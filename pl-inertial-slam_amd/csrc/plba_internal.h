@@ -255,6 +255,7 @@ struct ChainView {
     const int32_t* esrc_off;      // (unused)
     const int32_t* bkf;           // chain_back_segment's keyframe descriptors, one level instead of four: (nseg x CHAIN_SEG + nukf) x 20 ints
                                   // [kf, off_pvr, off_bias, dense columns of the 6 pose dims, of the 9 chain dims (separators only), pad]
+    const int32_t* imu_loc;       // M x 4: [segment of the edge's keyframes (-1: none eliminated), descriptor (bkf index) of keyframe i, of keyframe j, pad]; null: off
     double* W;                    // (nel * 9 + 4) x Wld:  L^-1 [B | b_c], column Pd = w_b; zero outside each segment's window
     double* Ldinv;                // nel x 81: L_ii^-1, row-major
     double* Lsub;                 // nel x 81: L_{i+1,i}

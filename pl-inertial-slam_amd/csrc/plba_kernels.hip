@@ -105,7 +105,8 @@ DEV int quad_sum_i(int v) {
 struct DecideArgs;
 // arrive != null (the trial pass with Jacobians): the block counts itself in for the LM decision as soon as its chi2 is out, and goes on
 struct LeadWait;
-template <bool JAC, int NT> DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane, const DecideArgs* arrive = nullptr, int nblk_edges = 0, double* s4 = nullptr, const LeadWait* lw = nullptr);
+struct LocalStates;
+template <bool JAC, int NT> DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane, const DecideArgs* arrive = nullptr, int nblk_edges = 0, double* s4 = nullptr, const LeadWait* lw = nullptr, const LocalStates* loc = nullptr);
 template <bool JAC> DEV void prior_block(const DevBuf& d, int state, const DecideArgs* arrive = nullptr, int nblk_edges = 0, double* s4a = nullptr, const LeadWait* lw = nullptr);
 // End of a trial folded into the trial-error launch (one GPU): the workgroup that finishes last takes the LM decision
 // (decide_body = what k_decide does), so the decision is out one launch earlier.  The trial-error launch is normally the
@@ -815,8 +816,8 @@ DEV void update_kf_one(const DevBuf& d, int cur, int trial, int k) {
 //   part of the step from the dense solution `xd` itself, never from d.x.
 // -------------------------------------------------------------------------------------------------
 // state update of one keyframe from explicit step values (update_kf_one without the trip through d.x)
-DEV void update_kf_vals(const DevBuf& d, int trial, int k, const double* s /*KF_STRIDE, current state*/, const double* u9, const double* ub6, bool has_pvr, bool has_bias) {
-    double tmp[KF_STRIDE];
+// the keyframe part of update(): trial state = state (+) step   (one function for the segments' global update and the IMU edge blocks' local copies)
+DEV void kf_trial_state(const DevBuf& d, const double* s /*KF_STRIDE, current state*/, const double* u9, const double* ub6, bool has_pvr, bool has_bias, double* tmp) {
 #pragma unroll
     for (int i = 0; i < KF_STRIDE; ++i) tmp[i] = s[i];
     const bool ok = d.ctrl->solver_ok != 0;
@@ -825,12 +826,21 @@ DEV void update_kf_vals(const DevBuf& d, int trial, int k, const double* s /*KF_
 #pragma unroll
         for (int i = 0; i < 6; ++i) tmp[16 + i] = s[16 + i] + ub6[i];
     }
+}
+DEV void update_kf_vals(const DevBuf& d, int trial, int k, const double* s /*KF_STRIDE, current state*/, const double* u9, const double* ub6, bool has_pvr, bool has_bias) {
+    double tmp[KF_STRIDE];
+    kf_trial_state(d, s, u9, ub6, has_pvr, has_bias, tmp);
     double* o = d.kf[trial] + (size_t)k * KF_STRIDE;
 #pragma unroll
     for (int i = 0; i < KF_STRIDE; ++i) publish(o + i, tmp[i]);
 }
 
-DEV void chain_back_segment(const DevBuf& d, const ChainView& cv, const double* xd, const int g, const int cur, const int trial) {
+// LOCAL (round 4): only the segment's solution, left in LDS (returned) — no keyframe is updated and nothing is published.  The trial
+// launch's IMU edge blocks call it for the segment their two keyframes belong to and form the two trial states themselves, instead
+// of waiting in-launch for the segment's own workgroup (an in-launch hand-off costs ~4 us on this machine; the
+// redundant back-substitution runs on compute units that would otherwise idle).
+template <bool LOCAL = false>
+DEV const double* chain_back_segment(const DevBuf& d, const ChainView& cv, const double* xd, const int g, const int cur, const int trial) {
     constexpr int BACK_THREADS = LMB;
     constexpr int UFAST = 5;               // 16 lanes x 5 = 80 window columns on the all-in-flight path (6-slot interior positions)
     __shared__ double sv[SEGMAX * 9];
@@ -864,7 +874,8 @@ DEV void chain_back_segment(const DevBuf& d, const ChainView& cv, const double* 
     // host-built descriptor, then its state — two levels of loads where the index maps took four
     int kf_k = -1, e_blk = -1;
     const int32_t* kd = nullptr;
-    if (t < n) { e_blk = t; kd = cv.bkf + (size_t)(g * CHAIN_SEG + t) * 20; }
+    if (LOCAL) {}
+    else if (t < n) { e_blk = t; kd = cv.bkf + (size_t)(g * CHAIN_SEG + t) * 20; }
     else if (g == 0 && t >= 64 && t - 64 < cv.nukf && t - 64 < BACK_THREADS - 64) kd = cv.bkf + (size_t)(cv.nseg * CHAIN_SEG + (t - 64)) * 20;
     double ks[KF_STRIDE];
     int op = -1, ob = -1, pc[6] = {-1, -1, -1, -1, -1, -1}, cc[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
@@ -884,7 +895,7 @@ DEV void chain_back_segment(const DevBuf& d, const ChainView& cv, const double* 
         sM[idx / 81][81 + idx % 81] = cv.Lsub[(size_t)i0 * 81 + idx];
     }
     // ---- the dense solution ---------------------------------------------------------------------------------------------------
-    if (g == 0) for (int c = t; c < cv.Pd; c += BACK_THREADS) publish(&d.x[cv.pidx[c]], xd[c]);      // (x is read by the deciding workgroup of the same launch)
+    if (!LOCAL && g == 0) for (int c = t; c < cv.Pd; c += BACK_THREADS) publish(&d.x[cv.pidx[c]], xd[c]);      // (x is read by the deciding workgroup of the same launch)
     for (int c = t; c < wn; c += BACK_THREADS) sxw[c] = xd[wlo + c];
     double u9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ub6[6] = {0, 0, 0, 0, 0, 0};
     if (kf_k >= 0) {
@@ -933,11 +944,12 @@ DEV void chain_back_segment(const DevBuf& d, const ChainView& cv, const double* 
             for (int q = 0; q < 9; ++q) xi = fma(Li[q * 9 + r], lane_bcast(tt, q), xi);         // (L_ii^-T t)_r ; L^-1 is lower: zeros where q < r
             xn = xi;
             const int gi = cv.cidx[(i0 + i) * 9 + r];
-            if (lane < 9) { sxc[i * 9 + r] = gi >= 0 ? xi : 0.0; if (gi >= 0) publish(&d.x[gi], xi); }
+            if (lane < 9) { sxc[i * 9 + r] = gi >= 0 ? xi : 0.0; if (!LOCAL && gi >= 0) publish(&d.x[gi], xi); }
         }
     }
     __syncthreads();
     CSTAMP(3);
+    if (LOCAL) return sxc;
     // ---- keyframe part of update() -----------------------------------------------------------------------------------------
     if (kf_k >= 0) {
         if (e_blk >= 0) {
@@ -956,7 +968,10 @@ DEV void chain_back_segment(const DevBuf& d, const ChainView& cv, const double* 
     CSTAMP(4);
     if (threadIdx.x == 0 && g < 2) { for (int q = 0; q < 5; ++q) d.dbgbuf[48 + 6 * g + q] = (double)(cts[q] - cts[0]); d.dbgbuf[48 + 6 * g + 5] = (double)(long long)__builtin_amdgcn_s_memrealtime(); }
 #endif
+    return sxc;
 }
+// what an IMU edge block needs to form its two keyframes' trial states locally
+struct LocalStates { const ChainView* cv; const double* xd; int cur; };
 
 // -------------------------------------------------------------------------------------------------
 // landmark back-substitution + landmark update (+ landmark part of computeScale)
@@ -1065,7 +1080,7 @@ __global__ void k_update_kf(DevBuf d, int cur, int trial) {
 // pose-side system with fp64 atomics (a handful of edges share a destination block).
 // -------------------------------------------------------------------------------------------------
 template <bool JAC, int NT>
-DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane, const DecideArgs* arrive, int nblk_edges, double* s4, const LeadWait* lw) {
+DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, int lane, const DecideArgs* arrive, int nblk_edges, double* s4, const LeadWait* lw, const LocalStates* loc) {
     __shared__ double sKF[2 * KF_STRIDE];      // (k_lm_trial) the two keyframe states, read coherently once their producers have counted in
     __shared__ double sJ[9 * 24];     // [J0 | J1 | J2] row-major 9 x 24
     __shared__ double sOJ[9 * 24];
@@ -1076,7 +1091,48 @@ DEV void pose_edge_block(const DevBuf& d, int state, const Robust& rb, int m, in
     const int ki = d.imu_i[m], kj = d.imu_j[m];
     const double* si = d.kf[state] + (size_t)ki * KF_STRIDE;
     const double* sj = d.kf[state] + (size_t)kj * KF_STRIDE;
-    if (lw) {
+    if (loc && loc->cv->imu_loc) {
+        // (k_lm_trial, round 4) the two trial states are formed HERE: the chain dims of the edge's keyframes from a local back-substitution of
+        // their segment (or from the dense solution: separators), the pose dims from the dense solution, the same kf_trial_state the
+        // segment's own workgroup publishes — bit-identical states, no in-launch wait
+        const ChainView& cvl = *loc->cv;
+        const int32_t* il = cvl.imu_loc + 4 * (size_t)m;
+        const int seg = il[0];
+        const double* sxc = nullptr;
+        if (seg >= 0) sxc = chain_back_segment<true>(d, cvl, loc->xd, seg, loc->cur, state);      // (ends with a workgroup barrier)
+        if (lane < 2) {
+            const int k = lane ? kj : ki, dsc = il[1 + lane];
+            const double* s = d.kf[loc->cur] + (size_t)k * KF_STRIDE;
+            double ks[KF_STRIDE], u9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ub6[6] = {0, 0, 0, 0, 0, 0}, tmp[KF_STRIDE];
+#pragma unroll
+            for (int i = 0; i < KF_STRIDE; ++i) ks[i] = s[i];
+            bool has_pvr = false, has_bias = false;
+            if (dsc >= 0) {
+                const int32_t* kd = cvl.bkf + (size_t)dsc * 20;
+                has_pvr = kd[1] >= 0; has_bias = kd[2] >= 0;
+                const int ps[6] = {0, 1, 2, 6, 7, 8};
+#pragma unroll
+                for (int i = 0; i < 6; ++i) if (kd[3 + i] >= 0) u9[ps[i]] = loc->xd[kd[3 + i]];
+                const int e = dsc - seg * CHAIN_SEG;
+                if (seg >= 0 && e >= 0 && e < CHAIN_SEG && dsc < cvl.nseg * CHAIN_SEG) {      // an eliminated block of the segment: its chain dims come from the local back-substitution
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) u9[3 + i] = sxc[e * 9 + i];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) ub6[i] = sxc[e * 9 + 3 + i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) if (kd[9 + i] >= 0) u9[3 + i] = loc->xd[kd[9 + i]];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) if (kd[12 + i] >= 0) ub6[i] = loc->xd[kd[12 + i]];
+                }
+            }
+            kf_trial_state(d, ks, u9, ub6, has_pvr, has_bias, tmp);
+#pragma unroll
+            for (int i = 0; i < KF_STRIDE; ++i) sKF[lane * KF_STRIDE + i] = tmp[i];
+        }
+        __syncthreads();
+        si = sKF; sj = sKF + KF_STRIDE;
+    } else if (lw) {
         lead_wait(*lw);
         if (lane < 2 * KF_STRIDE) sKF[lane] = fetch((lane < KF_STRIDE ? si : sj - KF_STRIDE) + lane, true);
         __syncthreads();
@@ -1592,8 +1648,9 @@ __global__ __launch_bounds__(LMB) void k_lm_trial(DevBuf d, LmView lv, int cur, 
     } else {
         const int m = b - nlead - lv.ngrp;
         const LeadWait lw{d.back_cnt, back_target, &d.ctrl->sync_fail};
-        if (m < d.M) pose_edge_block<JAC, 256>(d, trial, rb, m, threadIdx.x, nullptr, 0, s4, &lw);
-        else prior_block<JAC>(d, trial, nullptr, 0, s4, &lw);
+        const LocalStates loc{&cv, xd, cur};      // (the chain segments ride in this launch: nlead > 0)
+        if (m < d.M) pose_edge_block<JAC, 256>(d, trial, rb, m, threadIdx.x, nullptr, 0, s4, &lw, nlead > 0 ? &loc : nullptr);
+        else prior_block<JAC>(d, trial, nullptr, 0, s4, &lw);      // (the prior touches many keyframes: it waits for the segments as before)
     }
     if (da.fuse) trial_arrive(d, da, lv.ngrp, s4);
 }

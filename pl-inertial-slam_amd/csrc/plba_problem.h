@@ -230,7 +230,7 @@ struct plba_problem {
     plba::DArr<double> d_hll, d_bl, d_dinv, d_tv, d_xl;
     plba::DArr<int32_t> d_pair_i, d_pair_j, d_pair_start, d_ent_pi, d_ent_pj, d_ent_slot, d_ob_pos;
     plba::DArr<int32_t> d_kfpos, d_ekf, d_ukf, d_trow, d_xlist, d_alist;
-    plba::DArr<int32_t> d_esrc, d_esrc_off, d_bkf;
+    plba::DArr<int32_t> d_esrc, d_esrc_off, d_bkf, d_imu_loc;
     plba::DArr<int> d_trial_cnt;
     plba::DArr<plba::ChunkMeta> d_ch_meta;
     plba::DArr<double> d_schur_part;

@@ -161,17 +161,21 @@ def test_cached_edge_chi2_after_the_fused_passes(pkg, orc, hip):
 
 
 def test_in_launch_wait_fails_loudly_when_its_condition_never_comes(pkg, hip):
-    """the trial launch's pose-side blocks wait, inside the launch, for the chain segments in front of them (lead_wait).  Fault injection:
-    a count that is never reached.  The wait is bounded — it must run into its bound, report through Ctrl::sync_fail and fail the call with
-    PLBA_ERR_DEVICE; the queue must stay usable (the next call, without the fault, succeeds)."""
-    w = pkg.window.make_window(8, 200, 40, imu=True, seed=0xFA11)
+    """the trial launch's prior-edge block waits, inside the launch, for the chain segments in front of it (lead_wait; the IMU edge blocks
+    form their two trial states themselves since round 4 and wait for nothing).  Fault injection: a count that is never reached.  The wait
+    is bounded — it must run into its bound, report through Ctrl::sync_fail and fail the call with PLBA_ERR_DEVICE; the queue must stay
+    usable (the next call, without the fault, succeeds)."""
+    w = pkg.window.make_window(20, 500, 100, imu=True, seed=0xFA11)      # (long enough for chain segments beyond the keyframes the prior keeps dense)
+    p0 = pkg.new_problem(); p0.upload_window(w); pkg.protocol.local_ba(p0); pr = p0.marginalize(0, 50); p0.close()      # a prior from a previous BA of the window
+    w = pkg.window.make_window(20, 500, 100, imu=True, seed=0xFA11); w["prior"] = pr
     g = pkg.new_problem(lm_fused=2, diag=4); g.upload_window(w)      # PLBA_DIAG_LEAD_WAIT_FAIL
     with pytest.raises(pkg.abi.PlbaError, match="waited for the chain back-substitution"):
         g.optimize(2)
+    assert g.debug_get("lm_fused")[0] == 1
     g.close()
     g2 = pkg.new_problem(lm_fused=2); g2.upload_window(w)
     st = g2.optimize(3)
-    assert st.iterations == 3 and st.chi2_final < st.chi2_initial
+    assert st.iterations == 3 and st.chi2_final < st.chi2_initial and g2.debug_get("lm_fused")[0] == 1
     g2.close()
 
 
