@@ -1317,6 +1317,12 @@ static int prepare(plba_problem* p) {
     //                  of the band eliminated side by side in each launch
     p->band_ok = false; p->twin_ok = false;
     p->dd.band = 0; p->dd.twin_m0 = 0; p->dd.twin_fac = nullptr; p->dd.cs_order = nullptr; p->dd.perm = nullptr; p->dd.xmap = nullptr; p->dd.alt = nullptr; p->dd.alt2 = nullptr;
+    p->dd.wtw = nullptr;
+    if (p->chain_ok && p->lm_ok && p->world <= 1) {      // fused landmark path on one GPU: the chain Schur complement's W^T W tiles are formed in the gather launch
+        const int T = p->cv.Pdpad / 32;
+        HIPCK(p, p->d_wtw.alloc((size_t)(T * (T + 1) / 2 + T) * 1024, false));
+        p->dd.wtw = p->d_wtw.p;
+    }
     if (p->chain_ok && p->opt.band_solve && !p->dv.flow && !p->dv.wide) {      // (sharded runs: the lists above hold the GLOBAL structure)
         const ChainView& cv = p->cv;
         const int T = cv.Pdpad / 32;
@@ -1712,7 +1718,8 @@ static int lm_enqueue_system(plba_problem* p, const DevBuf& ds, int state, bool 
     // accumulators live on rank 0 alone, so the segments run on the all-reduced system, as a launch of their own behind the exchange
     launch_lm_schur(ds, p->lv, state, p->rob, false, sharded ? nullptr : &p->cv, spec, s);
     if (mark) MARK(p, 5);      // profile = 2: [4, 5] = k_lm_schur alone (the pass over every observation), [5, 6] = gather + assembly
-    launch_lm_gather(ds, p->lv, false, !sharded || owns_pose_edges(p), spec, s);      // lambda (and the unit padding) from one rank only
+    // (one GPU: the gather launch also forms the W^T W tiles of the chain Schur complement — k_chain_schur then only subtracts them)
+    launch_lm_gather(ds, p->lv, false, !sharded || owns_pose_edges(p), spec, s, p->dd.wtw ? &p->cv : nullptr, p->dd.wtw ? &p->dd : nullptr);      // lambda (and the unit padding) from one rank only
     if (sharded) {
         // only the entries that can be non-zero before the factorisation (pose x pose, IMU / prior blocks, diagonal) and the two rhs rows travel
         const size_t npk = list_packed_size(ds);
@@ -1732,7 +1739,7 @@ static int lm_enqueue_solve_and_trial(plba_problem* p) {
     const DevBuf& d = p->dv;
     hipStream_t s = p->stream;
     const int epoch = ++p->flow_epoch;
-    launch_chain_schur(d, p->cv, p->dd, s);
+    launch_chain_schur(d, p->cv, p->dd, s, p->dd.wtw != nullptr);
     MARKF(p, 11);
     if (p->band_ok) { launch_band_solve(p->dd, p->bandv, s); MARKF(p, 12); }
     else if (p->twin_ok) { launch_twin_cholesky(p->dd, p->twinv, s); MARKF(p, 12); launch_trsv_back(p->dd, true, epoch, s); }

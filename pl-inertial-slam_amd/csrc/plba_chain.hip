@@ -42,34 +42,24 @@ __global__ __launch_bounds__(ELIM_THREADS) void k_chain_elim(DevBuf d, ChainView
 // dd.sys tile (ta, tb), ta >= tb, of the dense system  A - W_B^T W_B  (32 x 32, matrix cores); the tiles of block row
 // ta == Pdpad / 32 carry the right-hand side  b_d - W_B^T w_b  in their first row.  Only the rows of W that belong to
 // segments whose column window meets both tiles are read (everything else in those columns is zero).
+// PRE (round 4, fused landmark path on one GPU): the W^T W products were formed by extra workgroups of the k_lm_gather launch (they need W
+// alone — the chain elimination's output — not the assembled system) and left in dd.wtw, workgroup b's 1024 values at b * 1024 + 4 t; this
+// launch then only subtracts them and factors the chains' first tiles: one memory round and the matrix-core loop less on the path of the
+// on-the-spot factorisation.
+template <bool PRE>
 __global__ __launch_bounds__(256) void k_chain_schur(DevBuf d, ChainView cv, DevBuf dd) {
     __shared__ __attribute__((aligned(16))) double sC0[32 * LS];      // workgroup 0: the first diagonal tile, factored on the spot
     __shared__ __attribute__((aligned(16))) Look32 S0;
     const int T = cv.Pdpad / 32;
-    const int b = blockIdx.x, ntri = T * (T + 1) / 2;
+    const int b = blockIdx.x;
     int ta, tb;
-    if (dd.cs_order) { const int o = dd.cs_order[b]; ta = o >> 16; tb = o & 0xffff; }      // (the workgroups with the longest path — a tile factored on the spot — are dispatched first)
-    else if (b < ntri) {
-        ta = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
-        while ((ta + 1) * (ta + 2) / 2 <= b) ++ta;
-        while (ta * (ta + 1) / 2 > b) --ta;
-        tb = b - ta * (ta + 1) / 2;
-    } else { ta = T; tb = b - ntri; }
+    chain_schur_tile_of(cv, dd, b, ta, tb);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const int tr = wv >> 1, tc = wv & 1;
     const int ldd = dd.ld;
     const bool rhs_row = (ta == T);
-    const int acol = rhs_row ? cv.Pd : ta * 32 + tr * 16 + li;     // rhs row: every output row uses w_b; only row 0 is kept
-    const int bcol = tb * 32 + tc * 16 + li;
-    const bool a_ok = rhs_row || acol < cv.Pd, b_ok = bcol < cv.Pd;
-    const double* Wa = cv.W + (a_ok ? acol : cv.Wld - 1);          // column Wld - 1 is zero padding (Wld >= Pd + 2)
-    const double* Wb = cv.W + (b_ok ? bcol : cv.Wld - 1);
-    // The workgroup's cost is dependent memory rounds, so there are two: (1) the tile's row range of W (cv.trow: the
-    // segments whose column window meets a 32-column block are consecutive, and so are their rows) and the index map
-    // of the A entries, (2) the W rows themselves — three 32-row chunks in flight, more only when several segments
-    // meet the tile — together with those entries of A.
-    int rlo = cv.trow[2 * tb], rhi = cv.trow[2 * tb + 1];
-    if (!rhs_row) { rlo = max(rlo, cv.trow[2 * ta]); rhi = min(rhi, cv.trow[2 * ta + 1]); }
+    double4v acc;
+    if (PRE) acc = *reinterpret_cast<const double4v*>(dd.wtw + (size_t)b * 1024 + 4 * threadIdx.x);
     double aold[4];
     {
         const int cb = tb * 32 + tc * 16 + li;
@@ -84,24 +74,7 @@ __global__ __launch_bounds__(256) void k_chain_schur(DevBuf d, ChainView cv, Dev
             }
         }
     }
-    double4v acc = (double4v){0.0, 0.0, 0.0, 0.0};
-    constexpr int NCH = 3;
-    for (int s0 = rlo; s0 < rhi; s0 += 32 * NCH) {
-        double av[NCH][8], bv[NCH][8];
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int r = s0 + 32 * ch + 4 * u + lk;
-                const bool in = r < rhi;
-                av[ch][u] = in ? Wa[(size_t)r * cv.Wld] : 0.0;
-                bv[ch][u] = in ? Wb[(size_t)r * cv.Wld] : 0.0;
-            }
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ch][u], bv[ch][u], acc, 0, 0, 0);
-    }
+    if (!PRE) acc = chain_wtw_tile(cv, ta, tb);
     // C/D layout: col = lane & 15, row = (lane >> 4) + 4 v
     // Multi-chain factorisation (dd.twin_m0 > 0): the system is written PERMUTED through dd.perm — [chains | separators] — every
     // chain's first tile is factored on the spot like tile (0,0) (turned around for the chain that is eliminated bottom-up), and
@@ -143,9 +116,10 @@ void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s) {
     hipLaunchKernelGGL(k_chain_elim, dim3(cv.nseg), dim3(ELIM_THREADS), 0, s, d, cv);
 }
 bool chain_schur_factors_tile0(const DevBuf& dd) { return !dd.flow && !dd.wide && !dd.band; }
-void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s) {
+void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s, bool products_done) {
     const int T = cv.Pdpad / 32;
-    hipLaunchKernelGGL(k_chain_schur, dim3(T * (T + 1) / 2 + T), dim3(256), 0, s, d, cv, dd);
+    if (products_done) hipLaunchKernelGGL(k_chain_schur<true>, dim3(T * (T + 1) / 2 + T), dim3(256), 0, s, d, cv, dd);
+    else hipLaunchKernelGGL(k_chain_schur<false>, dim3(T * (T + 1) / 2 + T), dim3(256), 0, s, d, cv, dd);
 }
 
 }  // namespace plba

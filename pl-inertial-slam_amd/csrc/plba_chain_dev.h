@@ -232,4 +232,51 @@ __device__ __forceinline__ void chain_elim_segment(const DevBuf& d, const ChainV
 }
 
 
+// ---- k_chain_schur's two halves (shared with k_lm_gather since round 4) ---------------------------------------------------------------
+// tile (ta, tb) of workgroup b: lower tiles in dd.cs_order (or natural order), then the right-hand-side row (ta == T)
+__device__ __forceinline__ void chain_schur_tile_of(const ChainView& cv, const DevBuf& dd, int b, int& ta, int& tb) {
+    const int T = cv.Pdpad / 32, ntri = T * (T + 1) / 2;
+    if (dd.cs_order) { const int o = dd.cs_order[b]; ta = o >> 16; tb = o & 0xffff; }      // (the workgroups with the longest path — a tile factored on the spot — are dispatched first)
+    else if (b < ntri) {
+        ta = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
+        while ((ta + 1) * (ta + 2) / 2 <= b) ++ta;
+        while (ta * (ta + 1) / 2 > b) --ta;
+        tb = b - ta * (ta + 1) / 2;
+    } else { ta = T; tb = b - ntri; }
+}
+// acc = (W^T W)(tile ta, tb): only the rows of W that belong to segments whose column window meets both tiles are read.  C/D layout of the
+// 16 x 16 sub-tile of wave (tr, tc): col = lane & 15, row = (lane >> 4) + 4 v
+__device__ __forceinline__ double4v chain_wtw_tile(const ChainView& cv, int ta, int tb) {
+    const int T = cv.Pdpad / 32;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int tr = wv >> 1, tc = wv & 1;
+    const bool rhs_row = (ta == T);
+    const int acol = rhs_row ? cv.Pd : ta * 32 + tr * 16 + li;     // rhs row: every output row uses w_b; only row 0 is kept
+    const int bcol = tb * 32 + tc * 16 + li;
+    const bool a_ok = rhs_row || acol < cv.Pd, b_ok = bcol < cv.Pd;
+    const double* Wa = cv.W + (a_ok ? acol : cv.Wld - 1);          // column Wld - 1 is zero padding (Wld >= Pd + 2)
+    const double* Wb = cv.W + (b_ok ? bcol : cv.Wld - 1);
+    int rlo = cv.trow[2 * tb], rhi = cv.trow[2 * tb + 1];
+    if (!rhs_row) { rlo = max(rlo, cv.trow[2 * ta]); rhi = min(rhi, cv.trow[2 * ta + 1]); }
+    double4v acc = (double4v){0.0, 0.0, 0.0, 0.0};
+    constexpr int NCH = 3;
+    for (int s0 = rlo; s0 < rhi; s0 += 32 * NCH) {
+        double av[NCH][8], bv[NCH][8];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = s0 + 32 * ch + 4 * u + lk;
+                const bool in = r < rhi;
+                av[ch][u] = in ? Wa[(size_t)r * cv.Wld] : 0.0;
+                bv[ch][u] = in ? Wb[(size_t)r * cv.Wld] : 0.0;
+            }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ch][u], bv[ch][u], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 }  // namespace plba

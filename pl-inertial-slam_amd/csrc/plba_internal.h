@@ -134,6 +134,7 @@ struct DevBuf {  // trivially-copyable view of device pointers passed to kernels
                                // around) — k_chain_schur factors those on the spot
     const int32_t* perm;   // Ppad: natural dense index -> permuted (k_chain_schur writes through it)
     const int32_t* xmap;   // Ppad: permuted -> natural (k_back_gemv writes x through it)
+    double* wtw;           // (T (T + 1) / 2 + T) x 1024: the W^T W tile of every k_chain_schur workgroup, when the k_lm_gather launch forms them (round 4)
     double* alt2;          // ... and of the second stage's accumulating chain (nested plan)
     double* alt;           // same shape as sys: the bottom chain's updates of the middle block (folded in by the top chain's last step)
     int flow;              // 1: single-launch dataflow factorisation (k_chol_flow), 0: one launch per block step
@@ -217,7 +218,7 @@ void launch_decide(const DevBuf& d, const LmParams& lp, double* red, bool fused,
 void launch_ctrl_reset(const DevBuf& d, hipStream_t s);      // control block and trace counter of a fresh plba_optimize call
 // fused landmark-major passes (plba_lm_dev.h)
 void launch_lm_schur(const DevBuf& d, const LmView& lv, int state, const Robust& rb, bool diag_pass, const ChainView* lead /* chain segments riding in front, or null */, bool spec, hipStream_t s, bool with_pose_edges = false);
-void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool add_lambda, bool spec, hipStream_t s);
+void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool add_lambda, bool spec, hipStream_t s, const ChainView* wtw_cv = nullptr, const DevBuf* wtw_dd = nullptr);      // wtw_*: + the W^T W tiles of the chain Schur complement
 void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, bool jac, const Robust& rb, const ChainView* lead, const double* xd, unsigned back_target, bool with_pose_edges, const DecideFusion* df, hipStream_t s);
 void launch_reduce_n(const DevBuf& d, bool owns_pose_edges, double* red, int nred, hipStream_t s);
 void launch_posediag(const DevBuf& d, hipStream_t s);      // A: chain back-substitution | landmark groups | the trial's pose-side edges (+ the LM decision)
@@ -274,7 +275,7 @@ struct BandView {
 size_t band_lds_bytes(int Pdpad);
 void launch_band_solve(const DevBuf& dd, const BandView& bv, hipStream_t s);      // dd.sys (+ rhs row) -> dd.x
 void launch_chain_elim(const DevBuf& d, const ChainView& cv, hipStream_t s);
-void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s);   // writes dd.sys
+void launch_chain_schur(const DevBuf& d, const ChainView& cv, const DevBuf& dd, hipStream_t s, bool products_done = false);   // writes dd.sys; products_done: W^T W is in dd.wtw (the gather launch formed it)
 // one workgroup of a list-driven block step: block row / column, identity row (-1: a tile of the factorisation proper), flags
 struct TwinTile { int16_t r, c, aj, flags, k, pad; };      // k: the pivot tile of the step this workgroup belongs to      // flags: 1 = writes d.alt instead of d.sys, 2 = no look-ahead on this tile, 4 = c is the step's first trailing column (stores the finished panel block),
                                                    // 8 = add d.alt's tile to the old value first, 16 = this (diagonal) tile is the next pivot: factor it here,

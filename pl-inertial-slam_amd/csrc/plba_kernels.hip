@@ -1611,10 +1611,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 // launch D: [blocks assembling the part of the system no landmark touches | gather blocks: pose-pair blocks and right-hand-side rows =
 // pose-side terms + the groups' parts]
-__global__ __launch_bounds__(256) void k_lm_gather(DevBuf d, LmView lv, int nasm, int add_lambda, int spec, int diag) {
+// (+ since round 4, behind them: one workgroup per tile of the chain Schur complement's W^T W — it needs the chain elimination's W from the
+// launch before, not this launch's output — left in dd.wtw for k_chain_schur<PRE>)
+__global__ __launch_bounds__(256) void k_lm_gather(DevBuf d, LmView lv, int nasm, int add_lambda, int spec, int diag, ChainView cv, DevBuf dd, int ngather) {
     if (spec && !d.ctrl->accepted) return;
     __shared__ double red[256];
     int b = blockIdx.x;
+    if (b >= ngather) {
+        int ta, tb;
+        chain_schur_tile_of(cv, dd, b - ngather, ta, tb);
+        const double4v acc = chain_wtw_tile(cv, ta, tb);
+        *reinterpret_cast<double4v*>(dd.wtw + (size_t)(b - ngather) * 1024 + 4 * threadIdx.x) = acc;
+        return;
+    }
     if (b < nasm) { lm_assemble_rest(d, lv, add_lambda, b, nasm, threadIdx.x, 256); return; }
     b -= nasm;
     if (diag) lm_gather_diag(d, lv, b, threadIdx.x, red);
@@ -1675,7 +1684,7 @@ void launch_lm_schur(const DevBuf& d, const LmView& lv, int state, const Robust&
     if (wide) hipLaunchKernelGGL((k_lm_schur<0, true>), dim3(lv.ngrp + nlead), dim3(256), sh, s, d, lv, state, rb, lead ? *lead : ChainView{}, nlead, spec ? 1 : 0);
     else hipLaunchKernelGGL((k_lm_schur<0, false>), dim3(lv.ngrp + nlead), dim3(256), sh, s, d, lv, state, rb, lead ? *lead : ChainView{}, nlead, spec ? 1 : 0);
 }
-void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool add_lambda, bool spec, hipStream_t s) {
+void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool add_lambda, bool spec, hipStream_t s, const ChainView* wtw_cv, const DevBuf* wtw_dd) {
     int nasm = 0;
     if (!diag_pass) {
         const size_t n = (size_t)lv.nalist2 + d.ld;
@@ -1683,8 +1692,11 @@ void launch_lm_gather(const DevBuf& d, const LmView& lv, bool diag_pass, bool ad
         if (nasm > 1024) nasm = 1024;
     }
     const int nb = diag_pass ? lv.nrow : lm_gather_blocks(lv);
-    if (nb + nasm == 0) return;
-    hipLaunchKernelGGL(k_lm_gather, dim3(nasm + nb), dim3(256), 0, s, d, lv, nasm, add_lambda ? 1 : 0, spec ? 1 : 0, diag_pass ? 1 : 0);
+    int ntile = 0;
+    if (wtw_cv && wtw_dd && wtw_dd->wtw) { const int T = wtw_cv->Pdpad / 32; ntile = T * (T + 1) / 2 + T; }
+    if (nb + nasm + ntile == 0) return;
+    hipLaunchKernelGGL(k_lm_gather, dim3(nasm + nb + ntile), dim3(256), 0, s, d, lv, nasm, add_lambda ? 1 : 0, spec ? 1 : 0, diag_pass ? 1 : 0,
+                       ntile ? *wtw_cv : ChainView{}, ntile ? *wtw_dd : DevBuf{}, nasm + nb);
 }
 void launch_lm_trial(const DevBuf& d, const LmView& lv, int cur, int trial, bool jac, const Robust& rb, const ChainView* lead, const double* xd, unsigned back_target, bool with_pose_edges, const DecideFusion* df, hipStream_t s) {
     const int nlead = lead ? lead->nseg : 0, npose = with_pose_edges ? d.M + (d.pr_nv > 0 ? 1 : 0) : 0;      // (a sharded run: rank 0 owns the pose-side edges)

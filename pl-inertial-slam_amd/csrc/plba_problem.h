@@ -192,6 +192,7 @@ struct plba_problem {
     plba::TwinView twinv;
     plba::DArr<plba::TwinTile> d_twin_list;
     plba::DArr<int32_t> d_twin_perm, d_twin_xmap, d_twin_fac, d_cs_order;
+    plba::DArr<double> d_wtw;          // W^T W tiles of the chain Schur complement (fused landmark path, one GPU: formed in the gather launch)
     plba::DArr<double> d_twin_alt;     // ... and so are its landmark blocks and the pose-side assembly     // the next iteration's linearisation is already in the stream (enqueued behind k_decide)
     // ---- host copy of the uploaded graph -------------------------------------------------------
     bool have_cam = false;
