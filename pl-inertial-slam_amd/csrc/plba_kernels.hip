@@ -1638,7 +1638,21 @@ template <bool JAC, bool WIDE_OK>
 __global__ __launch_bounds__(LMB) void k_lm_trial(DevBuf d, LmView lv, int cur, int trial, Robust rb, ChainView cv, const double* xd, int nlead, int npose, unsigned back_target, DecideArgs da) {
     static_assert(LMB == 256, "chain_back_segment's thread layout");
     __shared__ double s4[4];
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    // With chain segments in front, the IMU edge blocks wait for nothing (they form their trial states themselves) and are the launch's longest
+    // workgroups (a local back-substitution, then the serial per-edge math): they are dispatched right behind the segments, ahead of the groups.
+    // The prior block still waits for the segments and stays LAST.  Without segments the old order holds (the edge blocks wait for group 0).
+    // Only while the launch is one round of workgroups (configs[2]: 280; ab_opts 0.1445 -> 0.1373 ms per trial with both changes): at
+    // configs[4] (1183 workgroups, two rounds of groups) 200 edge blocks at the head delay the first round of groups — 0.4257 -> 0.4310 —
+    // and stay at the tail, where they fill the slots the second round leaves free.
+    const int nimu_first = (nlead > 0 && npose > 0 && cv.imu_loc && gridDim.x <= 512) ? min(npose, d.M) : 0;
+    if (b >= nlead && b < nlead + nimu_first) {
+        const LocalStates loc{&cv, xd, cur};
+        pose_edge_block<JAC, 256>(d, trial, rb, b - nlead, threadIdx.x, nullptr, 0, s4, nullptr, &loc);
+        if (da.fuse) trial_arrive(d, da, lv.ngrp, s4);
+        return;
+    }
+    if (b >= nlead + nimu_first) b -= nimu_first;
     if (b < nlead) {
         chain_back_segment(d, cv, xd, b, cur, trial);
         lead_done(d.back_cnt);
@@ -1655,10 +1669,9 @@ __global__ __launch_bounds__(LMB) void k_lm_trial(DevBuf d, LmView lv, int cur, 
         else if (WIDE_OK && kind == 2) lm_trial_group<false, true>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
         else if (WIDE_OK) lm_trial_group<true, true>(d, lv, g, cur, trial, rb, cv, xd, nlead != 0, S);
     } else {
-        const int m = b - nlead - lv.ngrp;
+        const int m = b - nlead - lv.ngrp + nimu_first;      // (the edge blocks dispatched early are not in this range)
         const LeadWait lw{d.back_cnt, back_target, &d.ctrl->sync_fail};
-        const LocalStates loc{&cv, xd, cur};      // (the chain segments ride in this launch: nlead > 0)
-        if (m < d.M) pose_edge_block<JAC, 256>(d, trial, rb, m, threadIdx.x, nullptr, 0, s4, &lw, nlead > 0 ? &loc : nullptr);
+        if (m < d.M) pose_edge_block<JAC, 256>(d, trial, rb, m, threadIdx.x, nullptr, 0, s4, &lw);
         else prior_block<JAC>(d, trial, nullptr, 0, s4, &lw);      // (the prior touches many keyframes: it waits for the segments as before)
     }
     if (da.fuse) trial_arrive(d, da, lv.ngrp, s4);
