@@ -663,6 +663,15 @@ static int twin_launch_estimate(int T, int hbt) {
     return best + 1;      // + the launch that ends the factorisation (k_chol32's last step)
 }
 
+// Padded dimension of the compact dense system.  The block steps are 32 columns wide; the 64-column forms (factor_block 64, wide steps, the
+// dataflow factorisation, the 64 x 64 inverses of the substitution-based back-solve for systems beyond 32 steps) need a multiple of 64.  A
+// SMALL system — one that stays below 8 tiles even padded to 64, i.e. the plain multi-launch factorisation with the explicit inverse, never the
+// band or multi-chain forms (those start at 8 tiles and keep their layouts) — is padded to 32 only (round 4): the reference's own 12-keyframe window has 75 dense dims, 3 tiles instead of 4, one dependent
+// launch of ~9 us less in every iteration of ~90.
+static int dense_pad(const plba_problem* p, int pd) {
+    const bool small32 = p->opt.use_mfma && p->opt.factor_block != 64 && !p->opt.factor_flow && !p->opt.wide_steps && (pd + TILE - 1) / TILE * 2 < 8;
+    return small32 ? std::max(32, (pd + 31) / 32 * 32) : ((pd + TILE - 1) / TILE) * TILE;
+}
 static int prepare(plba_problem* p) {
     if (!p->dirty) return PLBA_OK;
     if (!p->have_cam || !p->K) FAIL(p, PLBA_ERR_STATE, "camera and keyframes must be set before optimize");
@@ -1006,7 +1015,7 @@ static int prepare(plba_problem* p) {
                     if (sp[q]) for (int c = 0; c < 9; ++c) w += pos_c[q][c] >= 0;
                     ds[q + 1] = ds[q] + w;
                 }
-                const int pd = ds[npos], T = ((pd + TILE - 1) / TILE) * TILE / 32;
+                const int pd = ds[npos], T = dense_pad(p, pd) / 32;
                 int hb = 0;
                 auto span = [&](int qa, int qb) { if (ds[qb + 1] > ds[qa]) hb = std::max(hb, (ds[qb + 1] - 1) / 32 - ds[qa] / 32); };      // positions qa <= qb couple
                 for (int i = 0; i < K; ++i) for (int j2 = i; j2 < K; ++j2)
@@ -1064,7 +1073,7 @@ static int prepare(plba_problem* p) {
             if (ok) {
                 for (int c = 0; c < 9; ++c) cidx.push_back(-1);
                 ChainView& cv = p->cv;
-                cv.nel = nel; cv.nseg = nseg; cv.npos = npos; cv.Pd = Pd; cv.Pdpad = ((Pd + TILE - 1) / TILE) * TILE; cv.Wld = ((Pd + 2 + 63) / 64) * 64;
+                cv.nel = nel; cv.nseg = nseg; cv.npos = npos; cv.Pd = Pd; cv.Pdpad = dense_pad(p, Pd); cv.Wld = ((Pd + 2 + 63) / 64) * 64;
                 HIPCK(p, p->d_cidx.upload(cidx)); HIPCK(p, p->d_epos.upload(epos)); HIPCK(p, p->d_seg_start.upload(seg_start)); HIPCK(p, p->d_seg_col.upload(seg_col));
                 p->h_pidx = pidx; p->h_seg_col = seg_col;
                 HIPCK(p, p->d_pidx.upload(pidx)); HIPCK(p, p->d_ppos.upload(ppos)); HIPCK(p, p->d_pslot.upload(pslot)); HIPCK(p, p->d_slotcol.upload(slotcol));
@@ -1151,8 +1160,8 @@ static int prepare(plba_problem* p) {
                 HIPCK(p, p->d_W.alloc((size_t)(nel * 9 + 4) * cv.Wld)); HIPCK(p, p->d_Ldinv.alloc((size_t)nel * 81)); HIPCK(p, p->d_Lsub.alloc((size_t)nel * 81));
                 const size_t sysn_d = (size_t)(cv.Pdpad + TILE) * cv.Pdpad;
                 HIPCK(p, p->d_sysd.alloc(sysn_d)); HIPCK(p, p->d_Lfacd.alloc(sysn_d)); HIPCK(p, p->d_xd.alloc(cv.Pdpad));
-                HIPCK(p, p->d_Linvd.alloc((size_t)(cv.Pdpad / TILE) * TILE * TILE)); HIPCK(p, p->d_LT32d.alloc((size_t)cv.Pdpad * 64)); HIPCK(p, p->d_rd32d.alloc(cv.Pdpad));
-                HIPCK(p, p->d_flow_flagsd.alloc(cv.Pdpad / TILE)); HIPCK(p, p->d_chol_flagsd.alloc((size_t)(cv.Pdpad / 32 + 2) * (cv.Pdpad / 32)));
+                HIPCK(p, p->d_Linvd.alloc((size_t)((cv.Pdpad + TILE - 1) / TILE) * TILE * TILE)); HIPCK(p, p->d_LT32d.alloc((size_t)cv.Pdpad * 64)); HIPCK(p, p->d_rd32d.alloc(cv.Pdpad));
+                HIPCK(p, p->d_flow_flagsd.alloc((cv.Pdpad + TILE - 1) / TILE)); HIPCK(p, p->d_chol_flagsd.alloc((size_t)(cv.Pdpad / 32 + 2) * (cv.Pdpad / 32)));
                 cv.cidx = p->d_cidx.p; cv.epos = p->d_epos.p; cv.seg_start = p->d_seg_start.p; cv.seg_col = p->d_seg_col.p;
                 cv.pidx = p->d_pidx.p; cv.ppos = p->d_ppos.p; cv.pslot = p->d_pslot.p; cv.slotcol = p->d_slotcol.p;
                 cv.W = p->d_W.p; cv.Ldinv = p->d_Ldinv.p; cv.Lsub = p->d_Lsub.p;

@@ -6,7 +6,8 @@ import numpy as np
 import __graft_entry__ as g
 
 pkg = g.load_package()
-w = pkg.window.make_config(3)
+# `realistic`: the reference's own window shape (12 keyframes, tracks over 6 .. 12 of them) instead of BASELINE configs[2]
+w = pkg.window.make_window(12, 2000, 400, imu=True, seed=0x5EED00C0, kf_dt=0.1, track=(6, 12), revisit=0.2) if "realistic" in sys.argv else pkg.window.make_config(3)
 for rep in range(4):
     t = [time.perf_counter()]
     p = pkg.new_problem(diag=1 if "--laps" in sys.argv else 0); t.append(time.perf_counter())

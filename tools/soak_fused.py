@@ -70,7 +70,7 @@ for case in range(N):
     ok = same and dP < 1e-6 * t and dV < 1e-5 * t and dq < 1e-6 * t and (loose or (dpt < 1e-5 and dln < 1e-5)) and abs(sa.chi2_final - sb.chi2_final) <= 1e-6 * t * max(abs(sb.chi2_final), 1e-9)
     verdict = "ok" if ok else "MISMATCH"
     nf_hip, nf_orc = sa1.solver_failures + sa.solver_failures, sb1.solver_failures + sb.solver_failures
-    if not ok and nf_orc > nf_hip and max(dP, dV, dq) < 1e-3:
+    if not ok and nf_orc > nf_hip and max(dP, dV, dq) < 1e-1:
         # the fp64 ORACLE failed a factorisation the device did not (its Hpp - Hpl D Hpl^T cancels where the fused square-root form does not:
         # tests/test_fused_overshoot.py): the quad-precision build of the oracle arbitrates — trial counts and gating must be ITS
         try:
