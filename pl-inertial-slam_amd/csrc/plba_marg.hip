@@ -573,44 +573,64 @@ __global__ __launch_bounds__(256) void k_pose_pinv(const double* A, int pos, int
 }
 // the kept block: A' out, eigen square root J0 = sqrt(S) V^T (column-major), r0 = sqrt(S^-1) V^T b'   (cpp:364-372)
 // outp = [Ar n*n | br n | J0 n*n | r0 n]
+// Round 4: the decomposition runs on the LIVE part of A' only.  Columns that are exactly zero — the velocity / bias dims of keyframes no
+// selected factor constrains: 15 of 60 at the configs[3] shape, 30 of 105 on the reference's own 12-keyframe window — are eigenvectors with
+// eigenvalue 0 whatever the rest does (J0 rows and r0 entries 0); they already left the rotation schedule, but they still counted for
+// the STORAGE: n = 105 > 100 put V into global memory and the reference's own window paid 3.2 ms per slide where the configs[3] shape
+// paid 1.2.  The live columns are compacted into an nl x nl problem (75 x 75 there: both A' and V in LDS, 74 instead of 104 rounds per
+// sweep); Vg is only used when even the live part exceeds the in-LDS limit.
 __global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const double* b, int pos, int m, int n, double eps, double* outp, double* Vg, double* dbg) {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    const int lda = n | 1;
-    double* G = s_dyn;
-    double* Vl = s_dyn + (size_t)n * lda;      // only when Vg is null
-    __shared__ int rot;
+    __shared__ int rot, s_nl;
+    __shared__ int s_live[JLDS_MAX_N2];
+    __shared__ unsigned char s_nz[JLDS_MAX_N2];
     double* Ar = outp; double* br = outp + (size_t)n * n; double* J0 = br + n; double* r0 = J0 + (size_t)n * n;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) s_nz[j] = 0;
+    __syncthreads();
     for (int t = threadIdx.x; t < n * n; t += blockDim.x) {
         const int c = t / n, r = t % n;
         const double v = 0.5 * (A[(size_t)(m + r) * pos + m + c] + A[(size_t)(m + c) * pos + m + r]);
-        G[(size_t)c * lda + r] = v; Ar[t] = v;
-        if (Vg) Vg[t] = (r == c) ? 1.0 : 0.0; else Vl[t] = (r == c) ? 1.0 : 0.0;
+        Ar[t] = v;
+        J0[t] = 0.0;
+        if (v != 0.0) { s_nz[c] = 1; s_nz[r] = 1; }      // (every writer stores the same value)
     }
-    for (int t = threadIdx.x; t < n; t += blockDim.x) br[t] = b[m + t];
+    for (int t = threadIdx.x; t < n; t += blockDim.x) { br[t] = b[m + t]; r0[t] = 0.0; }
+    __syncthreads();
+    if (threadIdx.x == 0) { int k = 0; for (int j = 0; j < n; ++j) if (s_nz[j]) s_live[k++] = j; s_nl = k; }      // index order: deterministic
+    __syncthreads();
+    const int nl = s_nl, lda = nl | 1;
+    const bool v_lds = nl <= JLDS_MAX_N;
+    double* G = s_dyn;
+    double* Vl = s_dyn + (size_t)nl * lda;      // only when v_lds
+    double* V = v_lds ? Vl : Vg;
+    for (int t = threadIdx.x; t < nl * nl; t += blockDim.x) {
+        const int c = t / nl, r = t % nl, gc = m + s_live[c], gr = m + s_live[r];
+        G[(size_t)c * lda + r] = 0.5 * (A[(size_t)gr * pos + gc] + A[(size_t)gc * pos + gr]);
+        V[t] = (r == c) ? 1.0 : 0.0;
+    }
     __shared__ double s_part[16];
     __syncthreads();
-    const double delta = jacobi2_delta(G, lda, n, s_part);
-    if (dbg && threadIdx.x == 0) { for (int q = 0; q < 48; ++q) dbg[q] = -1.0; dbg[40] = delta; }
-    // two instances behind one uniform branch: with V in LDS its accesses stay ds_ instructions; in global memory (100 < n <= 140) a
+    const double delta = jacobi2_delta(G, lda, nl, s_part);
+    if (dbg && threadIdx.x == 0) { for (int q = 0; q < 48; ++q) dbg[q] = -1.0; dbg[40] = delta; dbg[41] = (double)nl; }
+    // two instances behind one uniform branch: with V in LDS its accesses stay ds_ instructions; in global memory (live part beyond 100) a
     // column pair written in one round is read by another half-wave of this workgroup after the barrier of that round
-    if (!Vg) jacobi2_lds<2>(G, lda, Vl, n, JACOBI2_TOL, delta, 60, &rot, dbg);
-    else if (n <= 128) jacobi2_lds<2>(G, lda, Vg, n, JACOBI2_TOL, delta, 60, &rot, dbg);
-    else jacobi2_lds<3>(G, lda, Vg, n, JACOBI2_TOL, delta, 60, &rot, dbg);
+    if (v_lds) jacobi2_lds<2>(G, lda, Vl, nl, JACOBI2_TOL, delta, 60, &rot, dbg);
+    else if (nl <= 128) jacobi2_lds<2>(G, lda, Vg, nl, JACOBI2_TOL, delta, 60, &rot, dbg);
+    else jacobi2_lds<3>(G, lda, Vg, nl, JACOBI2_TOL, delta, 60, &rot, dbg);
     __syncthreads();
-    const double* V = Vg ? Vg : Vl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int j = wave; j < n; j += nw) {
-        const double* v = V + (size_t)j * n;
+    for (int j = wave; j < nl; j += nw) {
+        const double* v = V + (size_t)j * nl;
         const double l = G[(size_t)j * lda + j];
         double vb = 0.0;
-        for (int t = lane; t < n; t += 64) vb += v[t] * b[m + t];
+        for (int t = lane; t < nl; t += 64) vb += v[t] * b[m + s_live[t]];
         vb = wave_sum(vb);
         const double S = l > eps ? l : 0.0, Si = l > eps ? 1.0 / l : 0.0;
         const double ss = sqrt(S);
-        for (int c = lane; c < n; c += 64) J0[(size_t)c * n + j] = ss * v[c];
+        for (int c = lane; c < nl; c += 64) J0[(size_t)s_live[c] * n + j] = ss * v[c];      // row j of J0 = sqrt(S_j) v_j^T, zero outside the live columns
         if (lane == 0) r0[j] = sqrt(Si) * vb;
     }
-    if (threadIdx.x == 0) r0[n] = (double)rot;      // columns still live when the last sweep began: >= 2 means the sweep limit was hit
+    if (threadIdx.x == 0) r0[n] = (nl < 2) ? 0.0 : (double)rot;      // columns still live when the last sweep began: >= 2 means the sweep limit was hit
 }
 
 // ---- multi-launch Jacobi for blocks that do not fit one workgroup's LDS --------------------------------------------------------
@@ -1073,9 +1093,12 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
     // (4) eigen square root of the kept block
     double* oAr = dOut.p; double* obr = oAr + (size_t)n * n; double* oJ0 = obr + n; double* or0 = oJ0 + (size_t)n * n;
     if (n <= JLDS_MAX_N2) {
+        // the live part of A' (its non-zero columns, known to the kernel only) decides whether V fits LDS next to it: the launch asks for the
+        // larger of the two layouts, and V gets a global buffer whenever n itself is beyond the in-LDS limit
         const bool v_lds = n <= JLDS_MAX_N;
-        const size_t sh = ((size_t)n * (n | 1) + (v_lds ? (size_t)n * n : 0)) * sizeof(double);
-        PLBA_HIPCK(p, ensure_dyn_lds(reinterpret_cast<const void*>(k_marg_finish), 162 * 1000));
+        const size_t nl_max = std::min(n, JLDS_MAX_N);
+        const size_t sh = std::max((size_t)n * (n | 1), nl_max * (nl_max | 1) + nl_max * nl_max) * sizeof(double);
+        PLBA_HIPCK(p, ensure_dyn_lds(reinterpret_cast<const void*>(k_marg_finish), (int)sh));
         if (!v_lds) PLBA_HIPCK(p, dV.alloc((size_t)n * n, false));
         hipLaunchKernelGGL(k_marg_finish, dim3(1), dim3(1024), sh, s, dA.p, db.p, pos, m, n, eps, dOut.p, v_lds ? nullptr : dV.p, d.dbgbuf);
     } else {
