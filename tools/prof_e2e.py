@@ -8,9 +8,9 @@ import __graft_entry__ as g
 pkg = g.load_package()
 # `realistic`: the reference's own window shape (12 keyframes, tracks over 6 .. 12 of them) instead of BASELINE configs[2]
 w = pkg.window.make_window(12, 2000, 400, imu=True, seed=0x5EED00C0, kf_dt=0.1, track=(6, 12), revisit=0.2) if "realistic" in sys.argv else pkg.window.make_config(3)
-for rep in range(4):
+for rep in range(int(os.environ.get("REPS", "4"))):
     t = [time.perf_counter()]
-    p = pkg.new_problem(diag=1 if "--laps" in sys.argv else 0); t.append(time.perf_counter())
+    p = pkg.new_problem(diag=1 if "--laps" in sys.argv else 0, **({"lm_fused": 2} if "--fused" in sys.argv else {"lm_fused": 0} if "--record" in sys.argv else {})); t.append(time.perf_counter())
     p.upload_window(w); t.append(time.perf_counter())
     s1 = p.optimize(5); t.append(time.perf_counter())
     p.gate_outliers(pkg.window.CHI2_GATE); t.append(time.perf_counter())
