@@ -24,15 +24,17 @@ WIN_SMALL = (8, 240, 50, 0xD157, 5, 10)          # K, points, lines, seed, stage
 WIN_K200 = (200, 6000, 1200, 0x5EED0005, 2, 2)    # the BASELINE configs[4] window shape (P = 2985) at a landmark count the oracle finishes
 WIN_PRIOR = (12, 360, 80, 0xD158, 5, 10, True)      # ... with the marginalization prior of a previous slide (rank 0 owns it; forced separators in the chain)
 WIN_K200_PRIOR = (200, 6000, 1200, 0x5EED0006, 2, 2, True)      # configs[4] in its stated form: 200 keyframes + prior, sharded
+WIN_LONG = (12, 600, 120, 0x5EED00C0, 5, 10, False, dict(kf_dt=0.1, track=(6, 12), revisit=0.2))      # the reference's window shape: tracks over 9 .. 12 keyframes take the wide groups (round 4)
 
 
 def _window(pkg, orc, win):
     """the (unsharded) window of a case; with a prior: the one the ORACLE's marginalization of the same window's first BA leaves —
     deterministic, so every rank and the reference derive the same"""
-    w = pkg.window.make_window(win[0], win[1], win[2], imu=True, seed=win[3])
+    kw = win[7] if len(win) > 7 else {}
+    w = pkg.window.make_window(win[0], win[1], win[2], imu=True, seed=win[3], **kw)
     if len(win) > 6 and win[6]:
         o = orc.new_problem(); o.upload_window(w); pkg.protocol.local_ba(o, stage1=2, stage2=2); pr = o.marginalize(0, 50); o.close()
-        w = pkg.window.make_window(win[0], win[1], win[2], imu=True, seed=win[3]); w["prior"] = pr
+        w = pkg.window.make_window(win[0], win[1], win[2], imu=True, seed=win[3], **kw); w["prior"] = pr
     return w
 
 
@@ -132,7 +134,7 @@ def test_sharded_hip_world2_gloo_host_staged(pkg, orc, hip):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("win", [WIN_SMALL, WIN_K200])
+@pytest.mark.parametrize("win", [WIN_SMALL, WIN_K200, WIN_LONG])
 def test_sharded_hip_world2_fused_landmark_passes(pkg, orc, hip, win):
     """the fused landmark-major passes on two landmark shards (lm_fused = 2: these windows are below the default's 40 k observations):
     groups of the local landmarks only, gather + structural all-reduce, chain elimination behind the exchange, the trial launch
