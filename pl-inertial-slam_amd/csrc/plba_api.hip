@@ -534,12 +534,20 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
         const int NTK = E > 60000 ? 8 : E > 20000 ? 4 : 1;      // (independent per landmark: the worker pool takes it in ranges)
         int32_t* kmn = kmin.data(); int32_t* kmx = kmax.data();
         const int32_t* ls = lm_start.data(); const int32_t* ok = ob_kf.data();
+        // up to 256 keyframes: the set of a landmark's keyframes as a bit mask too, so that the greedy cut below tests "does this landmark
+        // still fit the group's window" with an OR and a popcount per landmark instead of a pass over its observations (round 4: 0.42 ms
+        // of a BA call's host side at configs[2], 103 k observations; beyond 256 keyframes the stamp array does it)
+        const int NWm = K <= 256 ? (K + 63) / 64 : 0;
+        H.kmask.resize((size_t)NWm * L);
+        uint64_t* km = H.kmask.data();
         HostPool::get().run(NTK, [=](int t) {
             const int s0 = (int)((long)L * t / NTK), s1 = (int)((long)L * (t + 1) / NTK);
             for (int s = s0; s < s1; ++s) {      // (ob_kf ascends within a landmark when the caller lists observations in keyframe order; not assumed)
                 int lo = K, hi = -1;
-                for (int e = ls[s]; e < ls[s + 1]; ++e) { lo = std::min(lo, ok[e]); hi = std::max(hi, ok[e]); }
+                uint64_t m[4] = {0, 0, 0, 0};
+                for (int e = ls[s]; e < ls[s + 1]; ++e) { lo = std::min(lo, ok[e]); hi = std::max(hi, ok[e]); if (NWm) m[ok[e] >> 6] |= (uint64_t)1 << (ok[e] & 63); }
                 kmn[s] = lo; kmx[s] = hi;
+                for (int q = 0; q < NWm; ++q) km[(size_t)s * NWm + q] = m[q];
             }
         });
     }
@@ -568,16 +576,32 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
             int32_t win[LMF_W2];
             int nw = 0, gob = 0;
             size_t end = at;
-            while (end < ord.size() && (int)(end - at) < gmax) {
-                const int s = ord[end];
-                int add = 0;
-                for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) if (stamp[ob_kf[e]] != gi) ++add;      // (a duplicate keyframe inside one landmark is caught in phase 3)
-                if (nw + add > W) break;
-                for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) if (stamp[ob_kf[e]] != gi) { stamp[ob_kf[e]] = gi; win[nw++] = ob_kf[e]; }
-                gob += lm_start[s + 1] - lm_start[s];
-                ++end;
+            const int NWm = (int)(H.kmask.size() / (size_t)std::max(L, 1));
+            if (NWm) {
+                uint64_t gm[4] = {0, 0, 0, 0};
+                while (end < ord.size() && (int)(end - at) < gmax) {
+                    const int s = ord[end];
+                    const uint64_t* m = &H.kmask[(size_t)s * NWm];
+                    int cntw = 0;
+                    for (int q = 0; q < NWm; ++q) cntw += __builtin_popcountll(gm[q] | m[q]);
+                    if (cntw > W) break;
+                    for (int q = 0; q < NWm; ++q) gm[q] |= m[q];
+                    gob += lm_start[s + 1] - lm_start[s];
+                    ++end;
+                }
+                for (int q = 0; q < NWm; ++q) for (uint64_t b = gm[q]; b; b &= b - 1) win[nw++] = q * 64 + __builtin_ctzll(b);      // (ascending)
+            } else {
+                while (end < ord.size() && (int)(end - at) < gmax) {
+                    const int s = ord[end];
+                    int add = 0;
+                    for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) if (stamp[ob_kf[e]] != gi) ++add;      // (a duplicate keyframe inside one landmark is caught in phase 3)
+                    if (nw + add > W) break;
+                    for (int e = lm_start[s]; e < lm_start[s + 1]; ++e) if (stamp[ob_kf[e]] != gi) { stamp[ob_kf[e]] = gi; win[nw++] = ob_kf[e]; }
+                    gob += lm_start[s + 1] - lm_start[s];
+                    ++end;
+                }
+                std::sort(win, win + nw);
             }
-            std::sort(win, win + nw);
             LmGroup g;
             memset(&g, 0, sizeof g);
             g.lm0 = nlm; g.nlm = (int32_t)(end - at); g.nw = nw; g.kind = kind | (wide << 1);
@@ -678,6 +702,20 @@ static int prepare(plba_problem* p) {
     if ((int)p->po_pt.size() != p->Ep) p->Ep = 0;
     HIPCK(p, hipSetDevice(p->device));
     DArrStreamScope zero_fill_on(p->stream, p->have_ctx ? p->ctx.stage : nullptr);      // fresh buffers are cleared, and uploads queued, on the stream their kernels run on
+    // the small ones among them in two blocks, one memset and one copy per flush (plba_problem.h, DevBatch)
+    struct DevBatchScope {
+        DevBatch* prev;
+        explicit DevBatchScope(DevBatch* b) : prev(darr_batch()) { darr_batch() = b; }
+        ~DevBatchScope() { darr_batch() = prev; }
+    };
+    if (!p->d_batch_z.p) { HIPCK(p, p->d_batch_z.alloc(DevBatch::ZCAP, false)); HIPCK(p, p->d_batch_u.alloc(DevBatch::UCAP, false)); }
+    {
+        DevBatch& b = p->batch;
+        b.z = p->d_batch_z.p; b.zcap = DevBatch::ZCAP; b.zused = b.zdone = 0;
+        b.uh = (char*)stage_take(DevBatch::UCAP);      // (no pinned staging area: the uploads go one by one)
+        b.u = b.uh ? p->d_batch_u.p : nullptr; b.ucap = DevBatch::UCAP; b.uused = b.udone = 0; b.n_batched = 0;
+    }
+    DevBatchScope batch_small(&p->batch);
     const int K = p->K, Np = p->Np, Nl = p->Nl, Ep = p->Ep, El = p->El, M = p->M;
     const int L = Np + Nl, E = Ep + El;
     p->L = L; p->E = E;
@@ -723,7 +761,7 @@ static int prepare(plba_problem* p) {
     if (p->world > 1) {
         std::vector<double> vote = {(double)E, lm_fits ? 0.0 : 1.0};
         DArr<double> dvote;
-        HIPCK(p, dvote.upload(vote));
+        HIPCK(p, dvote.upload(vote)); HIPCK(p, darr_flush());
         if (int xrc = p->xfn(p->xuser, dvote.p, vote.size(), 0, (void*)p->stream)) FAIL(p, PLBA_ERR_EXCHANGE, "all-reduce callback failed (%d)", xrc);
         HIPCK(p, plba_stream_wait(p->stream));
         HIPCK(p, plba_d2h(p, vote.data(), dvote.p, vote.size() * 8));
@@ -839,7 +877,7 @@ static int prepare(plba_problem* p) {
         std::vector<double> cd((size_t)K * K);
         for (size_t t = 0; t < cd.size(); ++t) cd[t] = cov[t];
         DArr<double> dcov;
-        HIPCK(p, dcov.upload(cd));
+        HIPCK(p, dcov.upload(cd)); HIPCK(p, darr_flush());
         if (int xrc = p->xfn(p->xuser, dcov.p, cd.size(), 1, (void*)p->stream)) FAIL(p, PLBA_ERR_EXCHANGE, "all-reduce callback failed (%d)", xrc);
         HIPCK(p, plba_stream_wait(p->stream));
         HIPCK(p, plba_d2h(p, cd.data(), dcov.p, cd.size() * 8));
@@ -1278,6 +1316,7 @@ static int prepare(plba_problem* p) {
         lv.alist2 = p->d_alist2.p; lv.nalist2 = (int)al2.size(); lv.col_gather = p->d_col_gather.p;
         lv.ob_err = nullptr; lv.dbg_out = 0;
         p->lm_ok = lv.ngrp > 0;
+        HIPCK(p, darr_flush());
         if (p->lm_ok) launch_lm_level_sync(d, lv, p->stream);
     }
     lap("landmark-group upload");
@@ -1545,7 +1584,7 @@ static int prepare(plba_problem* p) {
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
     if (p->pr_nv > 0 && p->rank == 0) {
         const int n = p->pr_n;
-        HIPCK(p, p->d_pr_H.alloc((size_t)n * n));
+        HIPCK(p, p->d_pr_H.alloc((size_t)n * n)); HIPCK(p, darr_flush());
         launch_ata(p->d_pr_J0.p, n, n, p->d_pr_H.p, n, p->stream);
         std::vector<double> H((size_t)n * n), Hc((size_t)p->Ppad * p->ld, 0.0);
         HIPCK(p, plba_stream_wait(p->stream));
@@ -1561,8 +1600,10 @@ static int prepare(plba_problem* p) {
         }
         HIPCK(p, plba_h2d(p, p->d_Hconst.p, Hc.data(), Hc.size() * 8));
     }
+    HIPCK(p, darr_flush());
     HIPCK(p, plba_stream_wait(p->stream));      // the uploads above were queued on the stream from host vectors that end here
     lap("final stream sync");
+    if (ptime) fprintf(stderr, "[prepare] %zu small buffers in the batch blocks: %.0f KB cleared, %.0f KB copied\n", p->batch.n_batched, p->batch.zused / 1024.0, p->batch.uused / 1024.0);
     p->cur = 0;
     p->saved_valid = true;
     p->dirty = false;

@@ -89,13 +89,45 @@ inline void* stage_take(size_t bytes) {
     return r;
 }
 
+// prepare() creates ~150 buffers per BA call, most of them a few kilobytes (index maps, per-keyframe tables, the lists of the reduced
+// system): one hipMemsetAsync or hipMemcpyAsync each is ~4 us of host time, 0.5 ms per call — a third of a 15-iteration optimize().
+// Inside a DevBatchScope the SMALL ones are bump-allocated from two device blocks the problem keeps: `z` for the zero-filled ones
+// (cleared by ONE hipMemsetAsync per flush) and `u` for the uploads (filled through a pinned mirror `uh` at the same offsets and copied by ONE
+// hipMemcpyAsync per flush).  darr_flush() runs before anything on the stream reads them (every kernel launch inside prepare(), and its
+// end); the blocks start over with the next prepare(), which re-creates every buffer that lives in them.
+struct DevBatch {
+    static constexpr size_t SMALL = (size_t)256 << 10, ZCAP = (size_t)8 << 20, UCAP = (size_t)4 << 20;
+    char* z = nullptr; size_t zcap = 0, zused = 0, zdone = 0;
+    char* u = nullptr; char* uh = nullptr; size_t ucap = 0, uused = 0, udone = 0;
+    size_t n_batched = 0;
+    static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+    void* take_zero(size_t bytes) { const size_t need = al(bytes); if (!z || zused + need > zcap) return nullptr; void* r = z + zused; zused += need; ++n_batched; return r; }
+    bool take_upload(size_t bytes, void** dev, void** host) { const size_t need = al(bytes); if (!u || !uh || uused + need > ucap) return false; *dev = u + uused; *host = uh + uused; uused += need; ++n_batched; return true; }
+};
+inline DevBatch*& darr_batch() { static thread_local DevBatch* b = nullptr; return b; }
+inline hipError_t darr_flush() {
+    DevBatch* b = darr_batch();
+    if (!b) return hipSuccess;
+    hipError_t e = hipSuccess;
+    if (b->zused > b->zdone) { e = hipMemsetAsync(b->z + b->zdone, 0, b->zused - b->zdone, darr_stream()); b->zdone = b->zused; }
+    if (e == hipSuccess && b->uused > b->udone) { e = hipMemcpyAsync(b->u + b->udone, b->uh + b->udone, b->uused - b->udone, hipMemcpyHostToDevice, darr_stream()); b->udone = b->uused; }
+    return e;
+}
+
 template <class T>
 struct DArr {
     T* p = nullptr;
     size_t n = 0;
-    size_t cls = 0;          // pool size class of the block behind p
+    size_t cls = 0;          // pool size class of the block behind p (batched: its aligned size)
+    bool batched = false;    // p points into the problem's batch blocks (DevBatch), not at a pool block
+    void drop_batched() { if (batched) { p = nullptr; n = 0; cls = 0; batched = false; } }
     hipError_t alloc(size_t cnt, bool zero = true) {
         if (cnt == 0) cnt = 1;
+        if (DevBatch* b = darr_batch()) {
+            drop_batched();      // the batch blocks start over with every prepare()
+            if (zero && cnt * sizeof(T) <= DevBatch::SMALL)
+                if (void* q = b->take_zero(cnt * sizeof(T))) { release(); p = (T*)q; n = cnt; cls = DevBatch::al(cnt * sizeof(T)); batched = true; return hipSuccess; }
+        }
         if (!p || cnt * sizeof(T) > cls) {
             release();
             hipError_t e = dev_pool().get(cnt * sizeof(T), (void**)&p, &cls);
@@ -115,6 +147,15 @@ struct DArr {
     // With a stream set (DArrStreamScope) the copy is queued on it: the CALLER keeps `h` alive and unchanged until it
     // has synchronised that stream (prepare() does, once, at its end) instead of paying a synchronisation per buffer.
     hipError_t upload(const std::vector<T>& h) {
+        if (DevBatch* b = darr_batch()) {
+            void *dev, *host;
+            if (!h.empty() && h.size() * sizeof(T) <= DevBatch::SMALL && b->take_upload(h.size() * sizeof(T), &dev, &host)) {
+                drop_batched(); release();
+                p = (T*)dev; n = h.size(); cls = DevBatch::al(h.size() * sizeof(T)); batched = true;
+                memcpy(host, h.data(), h.size() * sizeof(T));
+                return hipSuccess;
+            }
+        }
         hipError_t e = alloc(h.size(), h.empty());
         if (e != hipSuccess || h.empty()) return e;
         const size_t bytes = h.size() * sizeof(T);
@@ -137,7 +178,7 @@ struct DArr {
         if (e != hipSuccess || cnt == 0) return e;
         return hipMemcpyAsync(p, src, cnt * sizeof(T), hipMemcpyHostToDevice, darr_stream());
     }
-    void release() { if (p) dev_pool().put(p, cls); p = nullptr; n = 0; cls = 0; }
+    void release() { if (p && !batched) dev_pool().put(p, cls); p = nullptr; n = 0; cls = 0; batched = false; }
     DArr() = default;
     DArr(const DArr&) = delete;
     DArr& operator=(const DArr&) = delete;
@@ -158,6 +199,7 @@ struct LmHost {
     // scratch of the build
     std::vector<int32_t> kmin, kmax, ord, tmp, cnt, ordall, stamp, span_at, span_end, span_ob0, gcut, bad, c2, pos;
     std::vector<std::pair<int64_t, int32_t>> blk_c, row_c;
+    std::vector<uint64_t> kmask;
 };
 }  // namespace plba
 
@@ -192,6 +234,8 @@ struct plba_problem {
     plba::TwinView twinv;
     plba::DArr<plba::TwinTile> d_twin_list;
     plba::DArr<int32_t> d_twin_perm, d_twin_xmap, d_twin_fac, d_cs_order;
+    plba::DArr<char> d_batch_z, d_batch_u;      // the blocks prepare()'s small buffers are bump-allocated from (plba::DevBatch)
+    plba::DevBatch batch;
     plba::DArr<double> d_wtw;          // W^T W tiles of the chain Schur complement (fused landmark path, one GPU: formed in the gather launch)
     plba::DArr<double> d_twin_alt;     // ... and so are its landmark blocks and the pose-side assembly     // the next iteration's linearisation is already in the stream (enqueued behind k_decide)
     // ---- host copy of the uploaded graph -------------------------------------------------------
