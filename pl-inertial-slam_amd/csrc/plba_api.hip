@@ -372,7 +372,7 @@ public:
     void start(int n, std::function<void(int)> f) {
         finish();
         run_m_.lock();
-        ensure(n);
+        ensure(std::min(n, 12));
         async_f_ = std::move(f);
         {
             std::lock_guard<std::mutex> lk(m_);
@@ -651,7 +651,9 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     H.lm_slot.resize(nlm); H.lm_ob0.resize(nlm + 1); H.lm_ws8.resize((size_t)nlm * H.wmax); H.lm_fixed.resize(nlm); H.ob_orig.resize(nob); H.ob_wt.resize(nob);
     H.meas_pt.resize(2 * (size_t)Ep); H.meas_ln.resize(3 * (size_t)(E - Ep));
     H.lm_ob0[nlm] = nob;
-    const int NT = E > 400000 ? 16 : E > 60000 ? 8 : E > 20000 ? 4 : 1;
+    // more jobs than threads from 60 k observations on: they are dealt dynamically, and the caller takes what is left when it joins (round 4:
+    // with 8 jobs on 8 sleeping workers the join had become the critical path of prepare(), 0.1 ms of waiting at configs[2])
+    const int NT = E > 400000 ? 32 : E > 60000 ? 16 : E > 20000 ? 4 : 1;
     H.gcut.assign(NT + 1, ngrp);
     H.gcut[0] = 0;
     for (int t = 1, g = 0; t < NT; ++t) { while (g < ngrp && H.span_ob0[g] < (int64_t)nob * t / NT) ++g; H.gcut[t] = g; }
@@ -902,7 +904,14 @@ static int prepare(plba_problem* p) {
     // ---- upload ----------------------------------------------------------------------------------------------------
     const size_t sysn = (size_t)(p->Ppad + TILE) * p->ld;
     HIPCK(p, p->d_kf[0].upload(p->kf0)); HIPCK(p, p->d_kf[1].upload(p->kf0)); HIPCK(p, p->d_kf_saved.upload(p->kf0));
-    HIPCK(p, p->d_lm[0].upload(p->lm0)); HIPCK(p, p->d_lm[1].upload(p->lm0)); HIPCK(p, p->d_lm_saved.upload(p->lm0));
+    // the landmarks' three images (current, trial, saved): one pass through the staging area, two copies on the device (1.2 MB each at configs[2])
+    HIPCK(p, p->d_lm[0].upload(p->lm0));
+    if (p->lm0.size() * 8 <= DevBatch::SMALL) { HIPCK(p, p->d_lm[1].upload(p->lm0)); HIPCK(p, p->d_lm_saved.upload(p->lm0)); }
+    else {
+        HIPCK(p, p->d_lm[1].alloc(p->lm0.size(), false)); HIPCK(p, p->d_lm_saved.alloc(p->lm0.size(), false));
+        HIPCK(p, hipMemcpyAsync(p->d_lm[1].p, p->d_lm[0].p, p->lm0.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+        HIPCK(p, hipMemcpyAsync(p->d_lm_saved.p, p->d_lm[0].p, p->lm0.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+    }
     HIPCK(p, p->d_po_uv.upload(p->po_uv)); HIPCK(p, p->d_lo_l.upload(p->lo_l)); HIPCK(p, p->d_ob_w.upload(ob_w));
     HIPCK(p, p->d_ob_kf.upload(ob_kf)); HIPCK(p, p->d_ob_slot.upload(ob_slot)); HIPCK(p, p->d_lm_start.upload(lm_start));
     HIPCK(p, p->d_level.upload(p->level)); HIPCK(p, p->d_lm_fixed.upload(p->lm_fixed));
@@ -1295,10 +1304,14 @@ static int prepare(plba_problem* p) {
         for (int k = 0; k < K; ++k) if (p->off_pvr[k] >= 0) for (int c : pose6b) dim_kf[p->off_pvr[k] + c] = k;
         for (int32_t k : LH.row_kf) for (int c : pose6b) colg[p->off_pvr[k] + c] = 1;
         al2.reserve(p->h_alist.size());
-        for (int32_t idx : p->h_alist) {
-            const int r = idx / ld, c = idx - r * ld;
-            const int kr = r < ld ? dim_kf[r] : -1, kc = dim_kf[c];
-            if (!(kr >= 0 && kc >= 0 && LH.cov[(size_t)kr * K + kc])) al2.push_back(idx);
+        {
+            int r = 0, r0 = 0, kr = dim_kf[0];      // (the list ascends: the row is tracked, not divided out)
+            const uint8_t* covr = kr >= 0 ? &LH.cov[(size_t)kr * K] : nullptr;
+            for (int32_t idx : p->h_alist) {
+                while (idx >= r0 + ld) { ++r; r0 += ld; kr = r < ld ? dim_kf[r] : -1; covr = kr >= 0 ? &LH.cov[(size_t)kr * K] : nullptr; }
+                const int kc = dim_kf[idx - r0];
+                if (!(covr && kc >= 0 && covr[kc])) al2.push_back(idx);
+            }
         }
         HIPCK(p, p->d_lm_grp.upload(LH.grp)); HIPCK(p, p->d_lmg_slot.upload(LH.lm_slot)); HIPCK(p, p->d_lmg_ob0.upload(LH.lm_ob0)); HIPCK(p, p->d_lmg_orig.upload(LH.ob_orig));
         HIPCK(p, p->d_lmg_ws8.upload(LH.lm_ws8)); HIPCK(p, p->d_lmg_fixed.upload(LH.lm_fixed)); HIPCK(p, p->d_lmg_level.alloc(E)); HIPCK(p, p->d_lmg_meas_pt.upload(LH.meas_pt)); HIPCK(p, p->d_lmg_meas_ln.upload(LH.meas_ln)); HIPCK(p, p->d_lmg_wt.upload(LH.ob_wt));
