@@ -15,6 +15,11 @@
  *  - matrices are row-major unless a name says colmajor.
  *  - keyframes are addressed by their index k in [0,K) in the arrays of plba_set_keyframes
  *    (ascending vertex id); points/lines by their index in plba_set_points / plba_set_lines.
+ *  - a problem handle may be re-used for the next window (the reference builds a fresh optimizer per local BA,
+ *    src/mapHandler.cpp:5799): every array stays until its plba_set_* is called again, so a window WITHOUT IMU edges or
+ *    a prior clears the previous one's with M = 0 / n = 0; edges that still refer to keyframes or landmarks the current
+ *    window does not have make plba_optimize fail with PLBA_ERR_INVALID (checked again at every structure build).
+ *    Results do not depend on what the handle held before (tests/test_gpu_parity.py).
  *
  * What each entry point replaces in the reference is cited next to it.
  */

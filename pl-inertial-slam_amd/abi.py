@@ -455,6 +455,8 @@ class Problem:
         if w.get("imu") is not None:
             im = w["imu"]
             self.set_imu_edges(im["kf_i"], im["kf_j"], im["preint"], im["info_pvr"], im["info_bias"])
+        else:      # a handle keeps its arrays until they are set again: a window without IMU edges clears the previous window's
+            self.set_imu_edges(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 142)), np.zeros((0, 81)), np.zeros((0, 36)))
         self.set_prior(w.get("prior"))
         for kind, d in w["huber"].items():
             self.set_robust(kind, True, d)

@@ -722,8 +722,13 @@ static int prepare(plba_problem* p) {
     const int L = Np + Nl, E = Ep + El;
     p->L = L; p->E = E;
     // the observation arrays may refer to landmarks uploaded later/earlier: re-check ranges
-    for (int e = 0; e < Ep; ++e) if (p->po_pt[e] >= Np) FAIL(p, PLBA_ERR_INVALID, "point observation %d refers to point %d of %d", e, p->po_pt[e], Np);
-    for (int e = 0; e < El; ++e) if (p->lo_ln[e] >= Nl) FAIL(p, PLBA_ERR_INVALID, "line observation %d refers to line %d of %d", e, p->lo_ln[e], Nl);
+    // ... and a handle that is re-used for the next window keeps every array until it is set again: edges that still refer to the
+    // previous window's keyframes are refused here (they were range-checked against the keyframes of THEIR upload)
+    for (int e = 0; e < Ep; ++e) if (p->po_pt[e] >= Np || p->po_kf[e] >= K) FAIL(p, PLBA_ERR_INVALID, "point observation %d refers to point %d of %d / keyframe %d of %d", e, p->po_pt[e], Np, p->po_kf[e], K);
+    for (int e = 0; e < El; ++e) if (p->lo_ln[e] >= Nl || p->lo_kf[e] >= K) FAIL(p, PLBA_ERR_INVALID, "line observation %d refers to line %d of %d / keyframe %d of %d", e, p->lo_ln[e], Nl, p->lo_kf[e], K);
+    for (int m = 0; m < M; ++m)
+        if (p->imu_i[m] >= K || p->imu_j[m] >= K || p->vid_bias[p->imu_i[m]] < 0 || p->vid_bias[p->imu_j[m]] < 0)
+            FAIL(p, PLBA_ERR_INVALID, "imu edge %d joins keyframes %d and %d of %d (edges of a previous window? set them again, or clear them with M = 0)", m, p->imu_i[m], p->imu_j[m], K);
     if ((int)p->level.size() != E) p->level.assign(E, 0);
     const bool ptime = (p->opt.diag & PLBA_DIAG_TIMING) != 0;
     auto pt0 = std::chrono::steady_clock::now();

@@ -677,3 +677,53 @@ def test_segment_length_choice_predicts_the_plan_that_is_built(pkg, hip, K):
     assert int(g.debug_get("twin")[0]) == 1
     assert int(g.debug_get("fact_launches_estimate")[0]) == int(g.debug_get("fact_launches")[0]) + 1
     g.close()
+
+
+def test_a_problem_handle_reused_across_windows_matches_fresh_handles(pkg, hip):
+    """prepare() bump-allocates its small device buffers from two blocks the problem keeps and starts them over with every upload
+    (csrc/plba_problem.h, DevBatch): a handle that takes window A, then a larger window B with IMU edges and a prior-free chain path,
+    then A again — with gating, a state save / restore and a read-back in between — must give, bit for bit, what a fresh handle gives for
+    each of them (the reference builds a fresh optimizer per local BA, src/mapHandler.cpp:5799; a binding that keeps the handle must not
+    see the previous window)."""
+    wa = pkg.window.make_window(6, 120, 30, imu=False, seed=11)
+    wb = pkg.window.make_window(12, 900, 200, imu=True, seed=12, kf_dt=0.1, track=(6, 12), revisit=0.2)
+    wc = pkg.window.make_config(3, scale=0.5)      # 51 k observations: the fused landmark passes, multi-chain factorisation
+
+    def run(p, w):
+        p.upload_window(w)
+        s1 = p.optimize(3); p.gate_outliers(pkg.window.CHI2_GATE); p.save_state(); s2 = p.optimize(3)
+        kf, pts, lns = p.get_keyframes(), p.get_points(), p.get_lines()
+        return (s1.chi2_final, s2.chi2_final, s2.trials), kf, pts, lns
+
+    fresh = {}
+    for name, w in (("a", wa), ("b", wb), ("c", wc)):
+        p = pkg.new_problem(); fresh[name] = run(p, w); p.close()
+    p = pkg.new_problem()
+    for name, w in (("a", wa), ("c", wc), ("b", wb), ("a", wa), ("b", wb), ("c", wc)):
+        st, kf, pts, lns = run(p, w)
+        fst, fkf, fpts, flns = fresh[name]
+        assert st == fst, (name, st, fst)
+        for k in fkf: assert np.array_equal(np.asarray(kf[k]), np.asarray(fkf[k])), (name, k)
+        assert np.array_equal(pts, fpts) and np.array_equal(lns, flns), name
+    p.close()
+
+
+def test_edges_of_a_previous_window_are_refused_not_dereferenced(pkg, hip):
+    """a re-used handle whose IMU edges still name keyframes 0 .. 11 of the previous window, given a 6-keyframe window through the raw
+    setters (NOT upload_window, which clears them): plba_optimize must fail with PLBA_ERR_INVALID — before round 4's check the edges were
+    uploaded as they were and the kernels read keyframes that do not exist"""
+    wb = pkg.window.make_window(12, 300, 60, imu=True, seed=12)
+    wa = pkg.window.make_window(6, 120, 30, imu=False, seed=11)
+    p = pkg.new_problem(); p.upload_window(wb); p.optimize(1)
+    k = wa["kf"]
+    p.set_keyframes(k["vid_pvr"], k["vid_bias"], k["P"], k["V"], k["q"], k["bg"], k["ba"], k["dbg"], k["dba"], k["fixed_pvr"], k["fixed_bias"])
+    p.set_points(wa["points"], wa.get("point_fixed")); p.set_lines(wa["lines"], wa.get("line_fixed"))
+    p.set_point_obs(wa["po_pt"], wa["po_kf"], wa["po_uv"], wa["po_w"]); p.set_line_obs(wa["lo_ln"], wa["lo_kf"], wa["lo_l"], wa["lo_w"])
+    with pytest.raises(Exception) as ei:
+        p.optimize(1)
+    assert "imu edge" in str(ei.value)
+    p.set_imu_edges(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 142)), np.zeros((0, 81)), np.zeros((0, 36)))
+    st = p.optimize(2)
+    q = pkg.new_problem(); q.upload_window(wa); sq = q.optimize(2)
+    assert st.chi2_final == sq.chi2_final
+    p.close(); q.close()
