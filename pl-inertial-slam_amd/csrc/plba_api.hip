@@ -240,6 +240,7 @@ int plba_set_point_obs(plba_problem* p, int Ep, const int32_t* pt, const int32_t
     p->po_uv.assign(uv, uv + 2 * (size_t)Ep);
     p->po_w.assign(Ep, 1.0);
     if (w) for (int e = 0; e < Ep; ++e) p->po_w[e] = (double)(float)w[e];   // const float& invSigma2 (mapHandler.cpp:5340)
+    p->level.assign((size_t)p->Ep + p->El, 0);      // new edges are level 0 (g2o); a re-used handle does not inherit the previous window's
     p->dirty = true;
     return PLBA_OK;
 }
@@ -254,6 +255,7 @@ int plba_set_line_obs(plba_problem* p, int El, const int32_t* ln, const int32_t*
     p->lo_l.assign(l3, l3 + 3 * (size_t)El);
     p->lo_w.assign(El, 1.0);
     if (w) for (int e = 0; e < El; ++e) p->lo_w[e] = (double)(float)w[e];
+    p->level.assign((size_t)p->Ep + p->El, 0);
     p->dirty = true;
     return PLBA_OK;
 }

@@ -691,7 +691,9 @@ def test_a_problem_handle_reused_across_windows_matches_fresh_handles(pkg, hip):
 
     def run(p, w):
         p.upload_window(w)
-        s1 = p.optimize(3); p.gate_outliers(pkg.window.CHI2_GATE); p.save_state(); s2 = p.optimize(3)
+        s1 = p.optimize(3); p.gate_outliers(pkg.window.CHI2_GATE)
+        lev = np.zeros(len(w["po_pt"]), np.uint8); lev[:7] = 1; p.set_levels(pkg.abi.EDGE_POINT, lev)      # (levels the caller sets are the window's, not the handle's)
+        p.save_state(); s2 = p.optimize(3)
         kf, pts, lns = p.get_keyframes(), p.get_points(), p.get_lines()
         return (s1.chi2_final, s2.chi2_final, s2.trials), kf, pts, lns
 
@@ -699,7 +701,7 @@ def test_a_problem_handle_reused_across_windows_matches_fresh_handles(pkg, hip):
     for name, w in (("a", wa), ("b", wb), ("c", wc)):
         p = pkg.new_problem(); fresh[name] = run(p, w); p.close()
     p = pkg.new_problem()
-    for name, w in (("a", wa), ("c", wc), ("b", wb), ("a", wa), ("b", wb), ("c", wc)):
+    for name, w in (("a", wa), ("c", wc), ("b", wb), ("b", wb), ("a", wa), ("b", wb), ("c", wc)):
         st, kf, pts, lns = run(p, w)
         fst, fkf, fpts, flns = fresh[name]
         assert st == fst, (name, st, fst)
