@@ -97,8 +97,8 @@ typedef struct {
                                    evaluated in registers where they are needed — the Schur complement as a rank-k update per group of
                                    landmarks on the matrix cores, back-substitution + trial residuals in one pass — instead of writing a
                                    record per observation and gathering it three times.  Possible (on one GPU or sharded: the ranks of a window
-                                   vote and all take the same path) when the chain path is in effect and no landmark has more than 8
-                                   observations or two in one keyframe.  2 = whenever possible;
+                                   vote and all take the same path) when the chain path is in effect and no landmark has more than 16
+                                   observations (9 .. 16: wide groups, two 8-lane units per landmark block) or two in one keyframe.  2 = whenever possible;
                                    1 = when possible and the window holds at least 40 k observations (BASELINE configs[1] .. [4]; below,
                                    the record-based passes k_linearize / k_landmark_hll / k_schur_pairs / k_backsub run: DESIGN.md 4a);
                                    0 = never                                                                                (1) */
@@ -198,7 +198,9 @@ int plba_set_prior(plba_problem* p, int n, int nv, const int32_t* vid, const int
                    const int32_t* idx_minus_m, const double* x0_packed,
                    const double* J0_colmajor, const double* r0);  /* nv == 0 clears; mapHandler.cpp:6007-6034 */
 int plba_set_robust(plba_problem* p, plba_edge_kind kind, int enabled, double huber_delta); /* setRobustKernel/setDelta */
-int plba_set_levels(plba_problem* p, plba_edge_kind kind, const uint8_t* level);           /* setLevel, POINT/LINE only */
+/* setLevel, POINT/LINE only.  New edges are level 0: plba_set_point_obs resets the levels of BOTH kinds (the point count moves
+ * the line range), plba_set_line_obs those of the line edges only. */
+int plba_set_levels(plba_problem* p, plba_edge_kind kind, const uint8_t* level);
 int plba_get_levels(plba_problem* p, plba_edge_kind kind, uint8_t* level);
 
 /* ---- multi-GPU: this problem holds a landmark shard; pose-side edges are added by rank 0 only */
@@ -224,6 +226,14 @@ int plba_get_trace(plba_problem* p, plba_trace_row* rows, int cap, int* n);
  * covisibility bookkeeping) is host map surgery and stays with the caller.  Returns the number of bad observations. */
 int plba_cull_observations(plba_problem* p, double chi2_thresh, uint8_t* bad_point, uint8_t* bad_line, int* n_point_out, int* n_line_out);
 
+/* ---- dense symmetric positive definite solve on the device (K7 stand-alone) ------------------------------------------
+ * Solves A x = b for an n x n row-major A with the kernels plba_optimize uses for the reduced camera system (block
+ * LL^T on the fp64 matrix cores + back-substitution): what g2o's LinearSolverEigen / LinearSolverCholmod do for the
+ * pose graphs of loopClosureOptimizationEssGraphG2O / ...CovGraphG2O (src/mapHandler.cpp:4068-4297, 4299-4470), whose
+ * host-evaluated graphs the facade sends here once they exceed 384 dims (include/plba_g2o/g2o_compat.h, solveHost).
+ * *ok = 0 on a non-positive pivot (g2o: "Cholesky failure").  `p` supplies the device, the stream and the error text. */
+int plba_dense_solve(plba_problem* p, int n, const double* A, const double* b, double* x, int* ok);
+
 /* ---- results (write-back of mapHandler.cpp:6202-6239) --------------------------------------- */
 int plba_get_keyframes(plba_problem* p, double* P3, double* V3, double* q_xyzw4, double* dbg3, double* dba3);
 int plba_get_points(plba_problem* p, double* xyz3);
@@ -243,6 +253,9 @@ int  plba_marginalize_factors(plba_problem* p, int n_imu, const int32_t* imu_edg
                               int n_ln, const int32_t* line_edges, int use_prior, int n_drop, const int32_t* drop_vid,
                               plba_prior* out);
 void plba_prior_free(plba_prior* pr);
+/* MarginalizationInfo::eps (IMU/marginalization.h:99 — a public, mutable member; the thresholds of
+ * IMU/marginalization.cpp:353,365-366 read it): replaces options.marg_eps for the following plba_marginalize* calls. */
+int  plba_set_marg_eps(plba_problem* p, double eps);
 
 /* ---- IMU preintegration producer (upstream of plba_set_imu_edges) --------------------------
  * KeyFrame::ComputeIMUPreIntSinceLastFrame (src/keyFrame.cpp:139-172) for M keyframe intervals at once: per interval
@@ -312,8 +325,7 @@ int plba_lba_visual(plba_problem* p, const plba_lba_options* opt, int K, const d
  * eigen-decomposition of Amm; [1..4] the certificate's w_max, smallest kept landmark eigenvalue, tau, smallest pivot. */
 int plba_debug_build(plba_problem* p, double lambda, int do_solve);
 int plba_debug_get(plba_problem* p, const char* what, double* out, size_t cap, size_t* n);
-/* Stand-alone run of the dense reduced-camera solver (K7): solves A x = b for a symmetric positive
- * definite n x n row-major A with the same kernels optimize() uses; *ok = 0 on a non-positive pivot. */
+/* the same entry under its round-1 name (tests/test_gpu_parity.py); product code calls plba_dense_solve */
 int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double* b, double* x, int* ok);
 
 #ifdef __cplusplus

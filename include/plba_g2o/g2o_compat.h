@@ -16,7 +16,7 @@
 // runs the HIP kernels.  The OTHER g2o users of the same translation unit (src/mapHandler.cpp: IMUInitEstBg :4989-5036, a
 // 1-vertex EdgeGyrBias problem; the pose-graph optimisers :4068-4297, :4299-4528, VertexSE3 / EdgeSE3) are tiny problems
 // over host-evaluated edge types: those graphs run g2o's Levenberg / Gauss-Newton loop on the host, over
-// the edges' own computeError() / linearizeOplus(), with a dense Cholesky (on the device through plba_debug_dense_solve
+// the edges' own computeError() / linearizeOplus(), with a dense Cholesky (on the device through plba_dense_solve
 // once the system is large).  A graph mixing the two families is rejected.
 #pragma once
 
@@ -955,7 +955,7 @@ private:
         if (N > 384) {      // the device solves it or nobody does: no silent host path for a system of this size
             if (!_prob) { plba_options o; plba_default_options(&o); if (plba_create(&o, &_prob) != PLBA_OK) { _prob = nullptr; _err = plba_last_error(nullptr); std::cerr << "[plba g2o facade] " << _err << std::endl; return false; } }
             int ok = 0;
-            if (plba_debug_dense_solve(_prob, N, A.data(), b.data(), x.data(), &ok) != PLBA_OK) { _err = plba_last_error(_prob); std::cerr << "[plba g2o facade] " << _err << std::endl; return false; }
+            if (plba_dense_solve(_prob, N, A.data(), b.data(), x.data(), &ok) != PLBA_OK) { _err = plba_last_error(_prob); std::cerr << "[plba g2o facade] " << _err << std::endl; return false; }
             ++_device_solves;
             return ok != 0;
         }
@@ -1070,6 +1070,7 @@ public:
             }
         }
         plba_prior pr;
+        if (plba_set_marg_eps(_prob, out->eps) != PLBA_OK) { _err = "MarginalizationInfo::eps must be finite and >= 0"; return false; }      // IMU/marginalization.h:99
         const int rc = plba_marginalize_factors(_prob, (int)imu.size(), imu.data(), (int)pts.size(), pts.data(), (int)lns.size(), lns.data(),
                                                 use_prior, (int)drop.size(), drop.data(), &pr);
         if (rc != PLBA_OK) { _err = plba_last_error(_prob); return false; }

@@ -513,6 +513,11 @@ int orc_set_robust(plba_problem* p, plba_edge_kind kind, int enabled, double del
     p->rob_delta[kind] = delta;
     return PLBA_OK;
 }
+int orc_set_marg_eps(plba_problem* p, double eps) {      /* MarginalizationInfo::eps, IMU/marginalization.h:99 */
+    if (!p || !(eps >= 0.0) || !isfinite(eps)) return PLBA_ERR_INVALID;
+    p->opt.marg_eps = eps;
+    return PLBA_OK;
+}
 int orc_set_levels(plba_problem* p, plba_edge_kind kind, const uint8_t* level) {
     if (!p || !level) return PLBA_ERR_INVALID;
     if (kind == PLBA_EDGE_POINT) memcpy(p->po_level, level, p->Ep);
@@ -1735,6 +1740,7 @@ int orc_debug_dense_solve(plba_problem* p, int n, const double* A, const double*
     if (ok) *ok = good;
     return PLBA_OK;
 }
+int orc_dense_solve(plba_problem* p, int n, const double* A, const double* b, double* x, int* ok) { return orc_debug_dense_solve(p, n, A, b, x, ok); }
 
 /* ============================================================================================
  * 7. marginalization (IMU/marginalization.cpp:38-147, 291-384; call site mapHandler.cpp:6075-6199)

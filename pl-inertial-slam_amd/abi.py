@@ -96,12 +96,14 @@ SIGNATURES = {
     "marginalize_factors": (C.c_int, [_P, C.c_int, c_int32_p, C.c_int, c_int32_p, C.c_int, c_int32_p, C.c_int, C.c_int, c_int32_p, C.POINTER(Prior)]),
     "preintegrate": (C.c_int, [_P, C.c_int, c_int32_p, C.POINTER(C.c_longdouble), c_double_p, c_double_p, C.POINTER(C.c_longdouble), C.POINTER(C.c_longdouble), c_double_p, c_double_p, C.c_double, C.c_double, c_double_p]),
     "prior_free": (None, [C.POINTER(Prior)]),
+    "set_marg_eps": (C.c_int, [_P, C.c_double]),
     "lba_default_options": (None, [C.POINTER(LbaOptions)]),
     "lba_visual": (C.c_int, [_P, C.POINTER(LbaOptions), C.c_int, c_double_p, c_int32_p, C.c_int, c_double_p, C.c_int, c_double_p,
                              C.c_int, c_int32_p, c_int32_p, c_double_p, C.c_int, c_int32_p, c_int32_p, c_double_p,
                              C.c_double, C.c_double, C.c_double, C.c_double, c_double_p, c_uint8_p, c_uint8_p, C.POINTER(LbaStats)]),
     "debug_build": (C.c_int, [_P, C.c_double, C.c_int]),
     "debug_get": (C.c_int, [_P, C.c_char_p, c_double_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "dense_solve": (C.c_int, [_P, C.c_int, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
     "debug_dense_solve": (C.c_int, [_P, C.c_int, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
 }
 
@@ -368,6 +370,9 @@ class Problem:
     def restore_state(self):
         self.call("restore_state")
 
+    def set_marg_eps(self, eps):
+        self.call("set_marg_eps", float(eps))
+
     def marginalize(self, first_kf=0, max_edges=50):
         pr = Prior()
         self.call("marginalize", int(first_kf), int(max_edges), C.byref(pr))
@@ -418,12 +423,15 @@ class Problem:
         self.call("debug_get", what.encode(), _dp(a), n.value, C.byref(n))
         return a[:n.value]
 
-    def debug_dense_solve(self, A, b):
+    def dense_solve(self, A, b, entry="dense_solve"):
         A = _f64(A); b = _f64(b)
         n = len(b)
         x = np.zeros(n); ok = C.c_int(0)
-        self.call("debug_dense_solve", n, _dp(A), _dp(b), _dp(x), C.byref(ok))
+        self.call(entry, n, _dp(A), _dp(b), _dp(x), C.byref(ok))
         return x, bool(ok.value)
+
+    def debug_dense_solve(self, A, b):
+        return self.dense_solve(A, b, entry="debug_dense_solve")
 
     def preintegrate(self, sample_start, t, gyr, acc, t_prev, t_curr, bg, ba, gyr_meas_cov, acc_meas_cov):
         """KeyFrame::ComputeIMUPreIntSinceLastFrame for M intervals (plba_preintegrate); time stamps as np.longdouble."""

@@ -255,7 +255,10 @@ int plba_set_line_obs(plba_problem* p, int El, const int32_t* ln, const int32_t*
     p->lo_l.assign(l3, l3 + 3 * (size_t)El);
     p->lo_w.assign(El, 1.0);
     if (w) for (int e = 0; e < El; ++e) p->lo_w[e] = (double)(float)w[e];
-    p->level.assign((size_t)p->Ep + p->El, 0);
+    // the new line edges are level 0; the POINT edges' levels stay (set_point_obs -> set_levels(POINT) -> set_line_obs used
+    // to drop them).  plba_set_point_obs still resets both ranges: Ep moves the line range's offset.
+    p->level.resize((size_t)p->Ep + p->El);
+    std::fill(p->level.begin() + std::min((size_t)p->Ep, p->level.size()), p->level.end(), (uint8_t)0);
     p->dirty = true;
     return PLBA_OK;
 }
@@ -301,6 +304,11 @@ int plba_set_robust(plba_problem* p, plba_edge_kind kind, int enabled, double de
     p->rob.delta[kind] = delta;
     return PLBA_OK;
 }
+int plba_set_marg_eps(plba_problem* p, double eps) {
+    if (!p || !(eps >= 0.0) || !std::isfinite(eps)) return PLBA_ERR_INVALID;
+    p->opt.marg_eps = eps;
+    return PLBA_OK;
+}
 int plba_set_shard(plba_problem* p, int rank, int world, plba_allreduce_fn fn, void* user) {
     if (!p || world < 1 || rank < 0 || rank >= world) return PLBA_ERR_INVALID;
     if (world > 1 && !fn) FAIL(p, PLBA_ERR_INVALID, "a sharded problem needs an all-reduce callback");
@@ -310,7 +318,7 @@ int plba_set_shard(plba_problem* p, int rank, int world, plba_allreduce_fn fn, v
 }
 
 
-int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double* b, double* x, int* ok) {
+int plba_dense_solve(plba_problem* p, int n, const double* A, const double* b, double* x, int* ok) {
     if (!p || n <= 0 || !A || !b || !x) return PLBA_ERR_INVALID;
     HIPCK(p, hipSetDevice(p->device));
     const int Ppad = std::max(TILE, (n + TILE - 1) / TILE * TILE), ld = Ppad;
@@ -341,6 +349,7 @@ int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double
     if (ok) *ok = c0.solver_ok;
     return PLBA_OK;
 }
+int plba_debug_dense_solve(plba_problem* p, int n, const double* A, const double* b, double* x, int* ok) { return plba_dense_solve(p, n, A, b, x, ok); }
 
 }  // extern "C"
 
@@ -715,7 +724,7 @@ static int prepare(plba_problem* p) {
     if (!p->d_batch_z.p) { HIPCK(p, p->d_batch_z.alloc(DevBatch::ZCAP, false)); HIPCK(p, p->d_batch_u.alloc(DevBatch::UCAP, false)); }
     {
         DevBatch& b = p->batch;
-        b.z = p->d_batch_z.p; b.zcap = DevBatch::ZCAP; b.zused = b.zdone = 0;
+        b.z = p->d_batch_z.p; b.zcap = DevBatch::ZCAP; b.zused = b.zdone = 0; ++b.gen;
         b.uh = (char*)stage_take(DevBatch::UCAP);      // (no pinned staging area: the uploads go one by one)
         b.u = b.uh ? p->d_batch_u.p : nullptr; b.ucap = DevBatch::UCAP; b.uused = b.udone = 0; b.n_batched = 0;
     }
@@ -726,11 +735,24 @@ static int prepare(plba_problem* p) {
     // the observation arrays may refer to landmarks uploaded later/earlier: re-check ranges
     // ... and a handle that is re-used for the next window keeps every array until it is set again: edges that still refer to the
     // previous window's keyframes are refused here (they were range-checked against the keyframes of THEIR upload)
-    for (int e = 0; e < Ep; ++e) if (p->po_pt[e] >= Np || p->po_kf[e] >= K) FAIL(p, PLBA_ERR_INVALID, "point observation %d refers to point %d of %d / keyframe %d of %d", e, p->po_pt[e], Np, p->po_kf[e], K);
-    for (int e = 0; e < El; ++e) if (p->lo_ln[e] >= Nl || p->lo_kf[e] >= K) FAIL(p, PLBA_ERR_INVALID, "line observation %d refers to line %d of %d / keyframe %d of %d", e, p->lo_ln[e], Nl, p->lo_kf[e], K);
-    for (int m = 0; m < M; ++m)
+    // A sharded run must not fail on ONE rank here: each rank holds its own observation shard, and a rank that returned alone
+    // would leave the others blocked in the vote below.  The verdict is carried into that all-reduce and every rank fails together.
+    bool local_invalid = false;
+    auto invalid = [&](const char* fmt, int a, int b, int c, int d2, int e2) { if (!local_invalid) snprintf(p->err, sizeof p->err, fmt, a, b, c, d2, e2); local_invalid = true; };
+    for (int e = 0; e < Ep && !local_invalid; ++e) if (p->po_pt[e] >= Np || p->po_kf[e] >= K) invalid("point observation %d refers to point %d of %d / keyframe %d of %d", e, p->po_pt[e], Np, p->po_kf[e], K);
+    for (int e = 0; e < El && !local_invalid; ++e) if (p->lo_ln[e] >= Nl || p->lo_kf[e] >= K) invalid("line observation %d refers to line %d of %d / keyframe %d of %d", e, p->lo_ln[e], Nl, p->lo_kf[e], K);
+    for (int m = 0; m < M && !local_invalid; ++m)
         if (p->imu_i[m] >= K || p->imu_j[m] >= K || p->vid_bias[p->imu_i[m]] < 0 || p->vid_bias[p->imu_j[m]] < 0)
-            FAIL(p, PLBA_ERR_INVALID, "imu edge %d joins keyframes %d and %d of %d (edges of a previous window? set them again, or clear them with M = 0)", m, p->imu_i[m], p->imu_j[m], K);
+            invalid("imu edge %d joins keyframes %d and %d of %d (edges of a previous window? set them again, or clear them with M = %d)", m, p->imu_i[m], p->imu_j[m], K, 0);
+    if (local_invalid && p->world <= 1) return PLBA_ERR_INVALID;
+    if (local_invalid) {      // take part in the window's vote (the first collective of every rank's prepare()) and return with the others
+        std::vector<double> vote = {0.0, 1.0, 1.0};
+        DArr<double> dvote;
+        HIPCK(p, dvote.upload(vote)); HIPCK(p, darr_flush());
+        if (int xrc = p->xfn(p->xuser, dvote.p, vote.size(), 0, (void*)p->stream)) { snprintf(p->err, sizeof p->err, "all-reduce callback failed (%d)", xrc); return PLBA_ERR_EXCHANGE; }
+        HIPCK(p, plba_stream_wait(p->stream));
+        return PLBA_ERR_INVALID;      // (p->err holds this rank's finding)
+    }
     if ((int)p->level.size() != E) p->level.assign(E, 0);
     const bool ptime = (p->opt.diag & PLBA_DIAG_TIMING) != 0;
     auto pt0 = std::chrono::steady_clock::now();
@@ -768,7 +790,7 @@ static int prepare(plba_problem* p) {
     bool lm_fits = p->opt.lm_fused != 0 && !p->lm_disable && E > 0 && p->opt.chain_elim && p->opt.use_mfma && p->opt.factor_block != 64 && lm_structure_fits(p, lm_start);
     long E_window = E;
     if (p->world > 1) {
-        std::vector<double> vote = {(double)E, lm_fits ? 0.0 : 1.0};
+        std::vector<double> vote = {(double)E, lm_fits ? 0.0 : 1.0, 0.0};      // [2]: ranks whose shard failed its range checks (above)
         DArr<double> dvote;
         HIPCK(p, dvote.upload(vote)); HIPCK(p, darr_flush());
         if (int xrc = p->xfn(p->xuser, dvote.p, vote.size(), 0, (void*)p->stream)) FAIL(p, PLBA_ERR_EXCHANGE, "all-reduce callback failed (%d)", xrc);
@@ -776,6 +798,10 @@ static int prepare(plba_problem* p) {
         HIPCK(p, plba_d2h(p, vote.data(), dvote.p, vote.size() * 8));
         E_window = (long)vote[0];
         lm_fits = vote[1] == 0.0;
+        if (vote[2] != 0.0) {      // some rank's shard does not belong to this window: all ranks return, none enters the next collective alone
+            snprintf(p->err, sizeof p->err, "%d rank(s) of the sharded window hold edges that refer to keyframes / landmarks the window does not have", (int)vote[2]);
+            return PLBA_ERR_INVALID;
+        }
     }
     const bool lm_cand = lm_fits && (p->opt.lm_fused >= 2 || E_window >= lm_min_obs);
     // keyframe-major record positions (stable: landmark order inside a keyframe), in EREC_UNIT = 64-byte units: a point
@@ -1295,6 +1321,9 @@ static int prepare(plba_problem* p) {
     std::vector<int32_t> al2;      // (function scope: a queued upload without staging room reads the host vector until the final wait)
     std::vector<uint8_t> colg;
     if (lm_cand && !lm_groups_finish(LH)) {      // (defensive: a keyframe observing a landmark twice — plba_set_*_obs refuses that) rebuild for the record-based passes
+        // a sharded run cannot re-enter prepare() on ONE rank (its vote and co-observation all-reduces would have no partners: ADVICE r04).
+        // The arrays only change through plba_set_*_obs, whose check_obs refuses such input, so this cannot be reached; if it ever is, fail.
+        if (p->world > 1) FAIL(p, PLBA_ERR_STATE, "landmark groups: two observations of one landmark in one keyframe (refused at upload; internal error)");
         p->lm_disable = true;
         const int rc2 = prepare(p);
         p->lm_disable = false;
@@ -1624,6 +1653,19 @@ static int prepare(plba_problem* p) {
     HIPCK(p, plba_stream_wait(p->stream));      // the uploads above were queued on the stream from host vectors that end here
     lap("final stream sync");
     if (ptime) fprintf(stderr, "[prepare] %zu small buffers in the batch blocks: %.0f KB cleared, %.0f KB copied\n", p->batch.n_batched, p->batch.zused / 1024.0, p->batch.uused / 1024.0);
+    // buffers this window did not re-create must not keep a pointer into the batch blocks, which now hold other buffers (the
+    // failure class of the re-used-handle fault of round 4): the conditionally allocated ones are dropped when their stamp is old
+    p->d_imu_loc.expire(p->batch); p->d_ob_err.expire(p->batch); p->d_Ninvd.expire(p->batch); p->d_Ninv.expire(p->batch); p->d_pr_H.expire(p->batch);
+    p->d_lm_grp.expire(p->batch); p->d_lmg_slot.expire(p->batch); p->d_lmg_ob0.expire(p->batch); p->d_lmg_orig.expire(p->batch); p->d_lmg_blk_ij.expire(p->batch);
+    p->d_lmg_blk_start.expire(p->batch); p->d_lmg_blk_src.expire(p->batch); p->d_lmg_row_kf.expire(p->batch); p->d_lmg_row_start.expire(p->batch); p->d_lmg_row_src.expire(p->batch);
+    p->d_alist2.expire(p->batch); p->d_lmg_ws8.expire(p->batch); p->d_lmg_fixed.expire(p->batch); p->d_lmg_level.expire(p->batch); p->d_col_gather.expire(p->batch);
+    p->d_lmg_meas_pt.expire(p->batch); p->d_lmg_meas_ln.expire(p->batch); p->d_lmg_wt.expire(p->batch); p->d_lmg_chi.expire(p->batch); p->d_lmg_part.expire(p->batch);
+    p->d_twin_list.expire(p->batch); p->d_twin_perm.expire(p->batch); p->d_twin_xmap.expire(p->batch); p->d_twin_fac.expire(p->batch); p->d_cs_order.expire(p->batch);
+    p->d_xlist.expire(p->batch); p->d_alist.expire(p->batch); p->d_trow.expire(p->batch); p->d_bkf.expire(p->batch); p->d_esrc.expire(p->batch);
+    p->d_cidx.expire(p->batch); p->d_epos.expire(p->batch); p->d_seg_start.expire(p->batch); p->d_seg_col.expire(p->batch); p->d_pidx.expire(p->batch); p->d_ppos.expire(p->batch);
+    p->d_pslot.expire(p->batch); p->d_slotcol.expire(p->batch); p->d_kfpos.expire(p->batch); p->d_ekf.expire(p->batch); p->d_ukf.expire(p->batch);
+    p->d_Ldinv.expire(p->batch); p->d_Lsub.expire(p->batch); p->d_xd.expire(p->batch); p->d_Linvd.expire(p->batch); p->d_rd32d.expire(p->batch); p->d_flow_flagsd.expire(p->batch); p->d_chol_flagsd.expire(p->batch);
+    p->d_band_y.expire(p->batch); p->d_band_mid.expire(p->batch);
     p->cur = 0;
     p->saved_valid = true;
     p->dirty = false;

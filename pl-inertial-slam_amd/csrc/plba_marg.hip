@@ -831,14 +831,17 @@ __global__ __launch_bounds__(64) void k_cert_final(const double* A, int pos, int
         acc = wave_sum(acc);
         if (lane == 0) {
             if (ps > 0) __hip_atomic_store(&Sg[t], ai[po + j] + acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // release / acquire on the arrival counter: the Sg stores happen-before the last workgroup's loads by the memory
+            // model, not by what gfx950's L2 happens to do.  (A 15 x 15 grid, once per slide: the L2 write-back a release costs is nothing
+            // here — unlike in the LM loop's hand-offs)
+            const unsigned prev = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (prev == gridDim.x - 1) ? 1 : 0;
             if (s_last) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
     if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (int q = lane; q < ps * ps; q += 64) S[q] = __hip_atomic_load(&Sg[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (lane != 0) return;

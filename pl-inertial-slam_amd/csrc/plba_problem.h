@@ -100,6 +100,7 @@ struct DevBatch {
     char* z = nullptr; size_t zcap = 0, zused = 0, zdone = 0;
     char* u = nullptr; char* uh = nullptr; size_t ucap = 0, uused = 0, udone = 0;
     size_t n_batched = 0;
+    unsigned gen = 0;      // bumped when the blocks start over (prepare()): a DArr stamped with an older generation points at memory that now belongs to other buffers
     static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
     void* take_zero(size_t bytes) { const size_t need = al(bytes); if (!z || zused + need > zcap) return nullptr; void* r = z + zused; zused += need; ++n_batched; return r; }
     bool take_upload(size_t bytes, void** dev, void** host) { const size_t need = al(bytes); if (!u || !uh || uused + need > ucap) return false; *dev = u + uused; *host = uh + uused; uused += need; ++n_batched; return true; }
@@ -120,13 +121,18 @@ struct DArr {
     size_t n = 0;
     size_t cls = 0;          // pool size class of the block behind p (batched: its aligned size)
     bool batched = false;    // p points into the problem's batch blocks (DevBatch), not at a pool block
+    unsigned bgen = 0;       // ... of this generation of the blocks (a batched buffer that the next prepare() does not re-create must not stay usable)
     void drop_batched() { if (batched) { p = nullptr; n = 0; cls = 0; batched = false; } }
+    // null unless the buffer is a pool block or a batched one of the CURRENT generation: for the conditionally allocated buffers
+    // (d_imu_loc, d_ob_err, d_Ninvd, d_pr_H, d_lmg_*), whose previous window's pointer would alias another buffer's memory
+    T* checked(const DevBatch& b) const { return (batched && bgen != b.gen) ? nullptr : p; }
+    void expire(const DevBatch& b) { if (batched && bgen != b.gen) drop_batched(); }
     hipError_t alloc(size_t cnt, bool zero = true) {
         if (cnt == 0) cnt = 1;
         if (DevBatch* b = darr_batch()) {
             drop_batched();      // the batch blocks start over with every prepare()
             if (zero && cnt * sizeof(T) <= DevBatch::SMALL)
-                if (void* q = b->take_zero(cnt * sizeof(T))) { release(); p = (T*)q; n = cnt; cls = DevBatch::al(cnt * sizeof(T)); batched = true; return hipSuccess; }
+                if (void* q = b->take_zero(cnt * sizeof(T))) { release(); p = (T*)q; n = cnt; cls = DevBatch::al(cnt * sizeof(T)); batched = true; bgen = b->gen; return hipSuccess; }
         }
         if (!p || cnt * sizeof(T) > cls) {
             release();
@@ -151,7 +157,7 @@ struct DArr {
             void *dev, *host;
             if (!h.empty() && h.size() * sizeof(T) <= DevBatch::SMALL && b->take_upload(h.size() * sizeof(T), &dev, &host)) {
                 drop_batched(); release();
-                p = (T*)dev; n = h.size(); cls = DevBatch::al(h.size() * sizeof(T)); batched = true;
+                p = (T*)dev; n = h.size(); cls = DevBatch::al(h.size() * sizeof(T)); batched = true; bgen = b->gen;
                 memcpy(host, h.data(), h.size() * sizeof(T));
                 return hipSuccess;
             }
@@ -309,7 +315,7 @@ struct plba_problem {
     plba::DArr<double> d_band_L, d_band_y, d_band_mid;
     std::vector<int32_t> h_pidx, h_seg_col, h_alist;      // host copies of the chain maps / assembly list (band measurement)
     // fused landmark-major passes (options.lm_fused; plba_lm_dev.h)
-    bool lm_ok = false;                         // this upload runs them (structure permitting: one GPU, chain path, <= 8 observations per landmark)
+    bool lm_ok = false;                         // this upload runs them (structure permitting: chain path, <= 16 observations per landmark — wide groups for 9 .. 16 —, none twice from one keyframe)
     unsigned long long state_epoch = 1, res_lm_epoch = 0;      // estimates on the device changed | the host mirror of the landmark array is of that epoch
     std::vector<double> res_lm;                 // plba_get_points / plba_get_lines: one read-back per state
     std::vector<double> lm_hist;                // diagnostics (plba_debug_get "lm_groups")

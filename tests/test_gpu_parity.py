@@ -729,3 +729,87 @@ def test_edges_of_a_previous_window_are_refused_not_dereferenced(pkg, hip):
     q = pkg.new_problem(); q.upload_window(wa); sq = q.optimize(2)
     assert st.chi2_final == sq.chi2_final
     p.close(); q.close()
+
+
+def test_two_host_threads_one_problem_each_match_the_serial_runs(pkg, hip):
+    """include/plba.h: "thread-compatible: one thread per plba_problem".  Two host threads, one problem each, their upload / optimize / gate
+    / optimize calls interleaved by a barrier per step — the structure builds of both then run on the ONE host worker pool at the same time
+    (HostPool's job serialisation and its asynchronous table fill) and their launches share the library's stream — must give,
+    bit for bit, what each window gives when it runs alone."""
+    import threading
+    wa = pkg.window.make_config(3, scale=0.5)      # 51 k observations: fused landmark passes, asynchronous table fill on the pool
+    wb = pkg.window.make_window(12, 900, 200, imu=True, seed=12, kf_dt=0.1, track=(6, 12), revisit=0.2)      # record-based passes: pair lists on the pool
+
+    def run(w, step=None):
+        p = pkg.new_problem()
+        sync = step if step is not None else (lambda: None)
+        sync(); p.upload_window(w)
+        sync(); s1 = p.optimize(3)
+        sync(); p.gate_outliers(pkg.window.CHI2_GATE)
+        sync(); s2 = p.optimize(4)
+        sync(); out = (s1.chi2_final, s2.chi2_final, s1.trials + s2.trials, p.get_keyframes(), p.get_points(), p.get_lines())
+        p.close()
+        return out
+
+    serial = [run(wa), run(wb)]
+    for rep in range(3):
+        bar = threading.Barrier(2)
+        res, err = [None, None], []
+
+        def worker(i, w):
+            try:
+                res[i] = run(w, step=lambda: bar.wait(timeout=120))
+            except Exception as e:      # noqa: BLE001
+                err.append(e); bar.abort()
+        th = [threading.Thread(target=worker, args=(i, w)) for i, w in enumerate((wa, wb))]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert not err, err
+        for i in range(2):
+            assert res[i][:3] == serial[i][:3], (rep, i, res[i][:3], serial[i][:3])
+            for k in serial[i][3]: assert np.array_equal(res[i][3][k], serial[i][3][k]), (rep, i, k)
+            assert np.array_equal(res[i][4], serial[i][4]) and np.array_equal(res[i][5], serial[i][5]), (rep, i)
+
+
+def test_line_observations_keep_the_point_levels(pkg, hip):
+    """set_point_obs -> set_levels(POINT) -> set_line_obs used to reset the point levels just set."""
+    w = pkg.window.make_window(6, 120, 30, imu=False, seed=11)
+    p = pkg.new_problem(); p.upload_window(w)
+    lev = np.zeros(len(w["po_pt"]), np.uint8); lev[3:9] = 1
+    p.set_point_obs(w["po_pt"], w["po_kf"], w["po_uv"], w["po_w"])
+    p.set_levels(pkg.abi.EDGE_POINT, lev)
+    p.set_line_obs(w["lo_ln"], w["lo_kf"], w["lo_l"], w["lo_w"])
+    assert np.array_equal(p.get_levels(pkg.abi.EDGE_POINT), lev) and not p.get_levels(pkg.abi.EDGE_LINE).any()
+    p.set_point_obs(w["po_pt"], w["po_kf"], w["po_uv"], w["po_w"])      # new point edges: level 0 again
+    assert not p.get_levels(pkg.abi.EDGE_POINT).any()
+    p.close()
+
+
+def test_dense_solve_product_entry(pkg, hip):
+    """plba_dense_solve (the facade's device solve for host-evaluated graphs beyond 384 dims) = the entry the tests know as plba_debug_dense_solve"""
+    rng = np.random.default_rng(5)
+    n = 400
+    B = rng.standard_normal((n, n)); A = B @ B.T + n * np.eye(n); b = rng.standard_normal(n)
+    p = pkg.new_problem()
+    x, ok = p.dense_solve(A, b)
+    x2, ok2 = p.debug_dense_solve(A, b)
+    p.close()
+    assert ok and ok2 and np.array_equal(x, x2)
+    assert np.abs(x - np.linalg.solve(A, b)).max() < 1e-10 * max(np.abs(x).max(), 1.0)
+
+
+def test_marg_eps_is_settable_like_the_reference_member(pkg, orc, hip):
+    """MarginalizationInfo::eps is a public mutable member (IMU/marginalization.h:99); plba_set_marg_eps carries a caller's value into
+    the thresholds of IMU/marginalization.cpp:353,365-366.  A threshold of 1e3 discards every kept direction below it: compared with
+    the oracle at the same setting (and it must differ from the default's result)."""
+    w = pkg.window.make_window(12, 260, 50, imu=True, seed=21)
+    g, o = _pair(pkg, orc, w)
+    pkg.protocol.local_ba(g); pkg.protocol.local_ba(o)
+    p_def = g.marginalize(0, 50)
+    g.set_marg_eps(1e3); o.set_marg_eps(1e3)
+    pg, po = g.marginalize(0, 50), o.marginalize(0, 50)
+    _marg_compare(pg, po, eps=1e3)
+    assert np.abs(pg["J0"].T @ pg["J0"] - p_def["J0"].T @ p_def["J0"]).max() > 1.0      # directions with 1e-8 < lambda <= 1e3 are gone
+    with pytest.raises(Exception):
+        g.set_marg_eps(float("nan"))
+    g.close(); o.close()
