@@ -202,6 +202,24 @@ def long_track_leg(pkg, stream, iters=60):
     return out
 
 
+def facade_leg(w, reps=5):
+    """One localBundleAdjustmentWithImuAndMarg-shaped call through BOUNDARY 1 — the reference's own call-site code (one `new` per
+    vertex and edge, optimize(5), the gating loop over the edge objects, optimize(10), marginalization, write-back loops) compiled
+    against include/g2o + include/plba_g2o, tools/localba_harness.cpp `time` — lap by lap, best of `reps` fresh optimizers.
+    `facade_ba_call_ms` = optimize + gating + optimize + write-back (what `end_to_end_ba_call_ms` covers through the C ABI);
+    graph construction and teardown (the call site's own object churn) are reported next to it."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import harness_io
+    exe = harness_io.build_harness()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "window.bin")
+        harness_io.write_window(w, path, do_marg=1, max_kf=len(w["kf"]["P"]))
+        out = subprocess.run([exe, "time", path, str(reps)], check=True, capture_output=True, text=True, timeout=300).stdout
+    return json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+
+
 def cpu_baseline(w, pkg, budget_s=24.0):
     """The CPU restatement of the reference's g2o path timed on this box's host cores on a bounded sample of the same window
     (stage-2 LM iterations from the post-gating state), three ways:
@@ -453,6 +471,13 @@ def main():
             e2e = dt2 if e2e is None else min(e2e, dt2)
         out["config"]["end_to_end_ba_call_ms"] = e2e * 1e3
         out["config"]["end_to_end_iterations_per_s"] = (r2["stage1"].iterations + r2["stage2"].iterations) / e2e
+        if rank == 0:
+            try:
+                out["config"].update(facade_leg(w_full))
+                out["config"]["facade_over_c_abi"] = out["config"]["facade_ba_call_ms"] / out["config"]["end_to_end_ba_call_ms"]
+            except Exception as e:      # noqa: BLE001 — a side leg must not lose the line
+                out["config"]["facade_ba_call_ms"] = None
+                out["config"]["facade_error"] = repr(e)[:300]
     if world == 1 and cfg_idx == 3 and not args.no_config5_leg:
         out["config"]["configs4_single_gpu"] = config5_leg(pkg, stream)
         out["config"]["realistic_12kf_window"] = realistic_leg(pkg, stream)

@@ -32,6 +32,7 @@
 #endif
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +41,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -147,9 +149,84 @@ std::unique_ptr<T> make_unique(A&&... a) { return std::unique_ptr<T>(new T(std::
 
 class SparseOptimizer;
 
+// ---- storage of the graph elements (round 5) ----------------------------------------------------------------------------------------
+// The reference's call site `new`s one edge object and one robust kernel per observation (src/mapHandler.cpp:5925-5944) — 120 k of each at
+// BASELINE configs[2] — and deletes them with the optimizer.  Measured through this facade in round 5 (tools/localba_harness.cpp `time`):
+// 18 ms of construction and 14 ms of teardown around 3.5 ms of bundle adjustment, most of it the general-purpose allocator (five blocks per
+// edge: the object, its vertex / information / error vectors, the kernel) and the cache misses of walking objects scattered over the heap.
+// So (a) vertices, edges and kernels come from a size-class slab (class-specific operator new / delete: the call site's `new g2o::Edge...`
+// picks it up unchanged; blocks of one class are handed out in address order, so a loop over the edges in insertion order streams), and
+// (b) the per-edge vectors keep their few elements inside the object.
+struct PlbaSlab {
+    static constexpr size_t GRAN = 64, MAXSZ = 4096, CHUNK = (size_t)1 << 20;
+    struct Cls { std::atomic<bool> lock{false}; void* free_ = nullptr; char* cur = nullptr; char* end = nullptr; };
+    static Cls* classes() { static Cls c[MAXSZ / GRAN + 1]; return c; }
+    static void* get(size_t sz) {
+        if (sz > MAXSZ) return ::operator new(sz);
+        const size_t ci = (std::max<size_t>(sz, 1) + GRAN - 1) / GRAN;
+        Cls& c = classes()[ci];
+        while (c.lock.exchange(true, std::memory_order_acquire)) {}
+        void* r;
+        if (c.free_) { r = c.free_; c.free_ = *static_cast<void**>(r); }
+        else {
+            if (!c.cur || c.cur + ci * GRAN > c.end) { c.cur = static_cast<char*>(::operator new(CHUNK)); c.end = c.cur + CHUNK; }      // (chunks live as long as the process)
+            r = c.cur; c.cur += ci * GRAN;
+        }
+        c.lock.store(false, std::memory_order_release);
+        return r;
+    }
+    static void put(void* p, size_t sz) {
+        if (!p) return;
+        if (sz > MAXSZ) { ::operator delete(p); return; }
+        Cls& c = classes()[(std::max<size_t>(sz, 1) + GRAN - 1) / GRAN];
+        while (c.lock.exchange(true, std::memory_order_acquire)) {}
+        *static_cast<void**>(p) = c.free_; c.free_ = p;
+        c.lock.store(false, std::memory_order_release);
+    }
+};
+#define PLBA_SLAB_ALLOCATED                                                        \
+    static void* operator new(std::size_t sz) { return PlbaSlab::get(sz); }       \
+    static void operator delete(void* p, std::size_t sz) { PlbaSlab::put(p, sz); }
+
+// vector with room for N elements inside the object (std::vector's interface as far as the graph elements use it)
+template <typename T, int N>
+class PlbaSmallVec {
+public:
+    PlbaSmallVec() : p_(in_) {}
+    PlbaSmallVec(const PlbaSmallVec& o) : p_(in_) { assign_range(o.p_, o.n_); }
+    PlbaSmallVec& operator=(const PlbaSmallVec& o) { if (this != &o) assign_range(o.p_, o.n_); return *this; }
+    PlbaSmallVec& operator=(const std::vector<T>& o) { assign_range(o.data(), o.size()); return *this; }
+    ~PlbaSmallVec() { if (p_ != in_) delete[] p_; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    T* data() { return p_; }
+    const T* data() const { return p_; }
+    T& operator[](size_t i) { return p_[i]; }
+    const T& operator[](size_t i) const { return p_[i]; }
+    T* begin() { return p_; }
+    T* end() { return p_ + n_; }
+    const T* begin() const { return p_; }
+    const T* end() const { return p_ + n_; }
+    void assign(size_t n, const T& v) { reserve(n); n_ = n; for (size_t i = 0; i < n; ++i) p_[i] = v; }
+    void resize(size_t n, const T& v = T()) { reserve(n); for (size_t i = n_; i < n; ++i) p_[i] = v; n_ = n; }
+private:
+    void reserve(size_t n) {
+        if (n <= cap_) return;
+        T* q = new T[n];
+        for (size_t i = 0; i < n_; ++i) q[i] = p_[i];
+        if (p_ != in_) delete[] p_;
+        p_ = q; cap_ = n;
+    }
+    void assign_range(const T* src, size_t n) { reserve(n); n_ = n; for (size_t i = 0; i < n; ++i) p_[i] = src[i]; }
+    T* p_;
+    size_t n_ = 0, cap_ = N > 0 ? N : 1;
+    T in_[N > 0 ? N : 1];
+};
+
 // ---- robust kernels ---------------------------------------------------------------------------------------------
 class RobustKernel {
 public:
+    PLBA_SLAB_ALLOCATED
     virtual ~RobustKernel() {}
     virtual void setDelta(double d) { _delta = d; }
     double delta() const { return _delta; }
@@ -167,11 +244,31 @@ public:
 };
 
 // ---- graph elements -----------------------------------------------------------------------------------------------
+class SparseOptimizer;
+// Lazy write-back (round 5): SparseOptimizer::optimize() on the device path leaves the results on the device; the first estimate() /
+// chi2() / isDepthPositive() afterwards fetches the set it belongs to — ONE read-back of the estimates and ONE of the cached errors per
+// call-site need (the gating loop reads chi2 after optimize(5), the write-back loop reads estimates after optimize(10)) instead of
+// seven arrays after each optimize().
+inline void plba_sync_estimates(SparseOptimizer* g);
+inline void plba_sync_chi2(SparseOptimizer* g);
+// Flatten-at-insertion (round 5): addEdge() copies a point / line observation into the graph's SoA arrays while the object is hot, so that
+// optimize() hands contiguous arrays to the C ABI instead of walking 120 k objects; what the call site changes AFTERWARDS reaches the
+// arrays through these hooks (setLevel, setRobustKernel: written through; anything else: the arrays are rebuilt from the objects).
+inline void plba_note_edge_level(SparseOptimizer* g, int kind, int index, int level);
+inline void plba_note_edge_kernel(SparseOptimizer* g, int kind, bool had, bool has);
+inline void plba_note_changed(SparseOptimizer* g);
+// cached e^T Omega e / isDepthPositive of the device path's point and line edges live in graph-owned arrays the read-back lands in
+inline double plba_cached_chi2(const SparseOptimizer* g, int kind, int index, double fallback);
+inline bool plba_cached_depth(const SparseOptimizer* g, int kind, int index, bool fallback);
+inline void plba_store_chi2(SparseOptimizer* g, int kind, int index, double chi2, bool depth);
+// what the device path knows a vertex / edge as: a tag set by the class instead of a chain of dynamic_casts per graph element
+enum { PLBA_V_OTHER = 0, PLBA_V_PVR = 1, PLBA_V_BIAS = 2, PLBA_V_POINT = 3, PLBA_V_LINE = 4 };
 class OptimizableGraph {
 public:
     class Edge;
     class Vertex {
     public:
+        PLBA_SLAB_ALLOCATED
         virtual ~Vertex() {}
         int id() const { return _id; }
         void setId(int i) { _id = i; }
@@ -190,6 +287,8 @@ public:
         virtual void discardTop() {}
         int hessianIndex() const { return _hidx; }
         SparseOptimizer* graph() const { return _graph; }
+        virtual int plbaVertexKind() const { return PLBA_V_OTHER; }
+        const bool* _plba_stale = nullptr;      // the graph's "estimates on the device are newer" flag (null: not in a graph)
         int _plba_index = -1;       // keyframe / point / line index in the flattened arrays
         int _hidx = -1;             // first row of the vertex in the host path's normal equations, -1 = fixed / inactive
     protected:
@@ -200,17 +299,26 @@ public:
     };
     class Edge {
     public:
+        PLBA_SLAB_ALLOCATED
+        typedef PlbaSmallVec<Vertex*, 3> VertexContainer;
         virtual ~Edge() { delete _robust; }
-        void setVertex(size_t i, Vertex* v) { if (i >= _vertices.size()) _vertices.resize(i + 1, nullptr); _vertices[i] = v; }
+        void setVertex(size_t i, Vertex* v) { if (i >= _vertices.size()) _vertices.resize(i + 1, nullptr); _vertices[i] = v; if (_graph) plba_note_changed(_graph); }
         Vertex* vertex(size_t i) const { return _vertices[i]; }
-        const std::vector<Vertex*>& vertices() const { return _vertices; }
+        const VertexContainer& vertices() const { return _vertices; }
         void resize(size_t n) { _vertices.resize(n, nullptr); }
-        void setRobustKernel(RobustKernel* k) { if (k != _robust) delete _robust; _robust = k; }   // takes ownership, 0 removes
+        void setRobustKernel(RobustKernel* k) {      // takes ownership, 0 removes
+            if (_graph) plba_note_edge_kernel(_graph, _plba_kind, _robust != nullptr, k != nullptr);
+            if (k != _robust) delete _robust;
+            _robust = k;
+        }
         RobustKernel* robustKernel() const { return _robust; }
         int level() const { return _level; }
-        void setLevel(int l) { _level = l; _dirty_level = true; }
+        void setLevel(int l) { _level = l; _dirty_level = true; if (_graph) plba_note_edge_level(_graph, _plba_kind, _plba_index, l); }
         int dimension() const { return _dimension; }
-        virtual double chi2() const { return _chi2_cache; }     // e^T Omega e of the last evaluation pass
+        // e^T Omega e of the last evaluation pass
+        virtual double chi2() const { if (_plba_stale && *_plba_stale) plba_sync_chi2(_graph); return _graph ? plba_cached_chi2(_graph, _plba_kind, _plba_index, _chi2_cache) : _chi2_cache; }
+        virtual int plbaEdgeKind() const { return -1; }      // plba_edge_kind of the five local-BA edge types, -1: host-evaluated
+        const bool* _plba_stale = nullptr;      // the graph's "cached errors on the device are newer" flag
         virtual void computeError() {}
         virtual void linearizeOplus() {}
         virtual bool read(std::istream&) { return true; }
@@ -229,7 +337,7 @@ public:
         bool _depth_cache = true, _dirty_level = false;
     protected:
         friend class SparseOptimizer;
-        std::vector<Vertex*> _vertices;
+        VertexContainer _vertices;
         RobustKernel* _robust = nullptr;
         int _level = 0, _dimension = 0;
         SparseOptimizer* _graph = nullptr;
@@ -241,8 +349,9 @@ class BaseVertex : public OptimizableGraph::Vertex {
 public:
     typedef T EstimateType;
     static const int Dimension = D;
-    const T& estimate() const { return _estimate; }
+    const T& estimate() const { if (_plba_stale && *_plba_stale) plba_sync_estimates(_graph); return _estimate; }
     void setEstimate(const T& e) { _estimate = e; }
+    void plbaStoreEstimate(const T& e) { _estimate = e; }      // (the lazy write-back's store)
     int dimension() const override { return D; }
     void setToOriginImpl() override {}
     void push() override { _backup.push_back(_estimate); }
@@ -258,17 +367,20 @@ class BaseEdgeT : public OptimizableGraph::Edge {
 public:
     typedef E Measurement;
     BaseEdgeT() { _dimension = D; if (D > 0) { _info.assign((size_t)D * D, 0.0); _error.assign(D, 0.0); } }
-    void setMeasurement(const E& m) { _measurement = m; }
+    typedef PlbaSmallVec<double, (D > 0 ? D * D : 1)> InfoContainer;      // (D x D inside the object: 4 doubles for a point edge, 81 for the IMU edge)
+    typedef PlbaSmallVec<double, (D > 0 ? D : 1)> ErrorContainer;
+    void setMeasurement(const E& m) { _measurement = m; if (this->_graph) plba_note_changed(this->_graph); }
     const E& measurement() const { return _measurement; }
     template <typename M> void setInformation(const M& m) {
         const int n = (int)m.rows();
         _info.assign((size_t)n * n, 0.0);
         for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) _info[(size_t)i * n + j] = m(i, j);
+        if (this->_graph) plba_note_changed(this->_graph);
     }
-    const std::vector<double>& informationRowMajor() const { return _info; }
-    void setInformationRowMajor(const std::vector<double>& m) { _info = m; }
+    const InfoContainer& informationRowMajor() const { return _info; }
+    void setInformationRowMajor(const std::vector<double>& m) { _info = m; if (this->_graph) plba_note_changed(this->_graph); }
     double* errorData() { return _error.data(); }
-    const std::vector<double>& error() const { return _error; }
+    const ErrorContainer& error() const { return _error; }
     // e^T Omega e of the residual held in _error: what chi2() means for the host-evaluated (API-surface) edge types
     double chi2FromError() const {
         const int n = (int)_error.size();
@@ -298,7 +410,8 @@ protected:
         for (int d : dims) _jac.emplace_back((size_t)(D > 0 ? D : this->_dimension) * d, 0.0);
     }
     E _measurement;
-    std::vector<double> _info, _error;
+    InfoContainer _info;
+    ErrorContainer _error;
     std::vector<std::vector<double>> _jac;
 };
 template <int D, typename E, typename VXi> class BaseUnaryEdge : public BaseEdgeT<D, E> { public: BaseUnaryEdge() { this->resize(1); } };
@@ -398,22 +511,26 @@ namespace g2o {
 
 class VertexLMPointXYZ : public BaseVertex<3, Vector3d> {
 public:
+    int plbaVertexKind() const override { return PLBA_V_POINT; }
     void oplusImpl(const double* u) override { for (int i = 0; i < 3; ++i) _estimate(i) += u[i]; }
     int estimateDimension() const override { return 3; }
 };
 class VertexLine : public BaseVertex<6, Vector6d> {
 public:
+    int plbaVertexKind() const override { return PLBA_V_LINE; }
     void oplusImpl(const double* u) override { for (int i = 0; i < 6; ++i) _estimate(i) += u[i]; }
     int estimateDimension() const override { return 6; }
 };
 class VertexNavStatePVR : public BaseVertex<9, NavState> {
 public:
+    int plbaVertexKind() const override { return PLBA_V_PVR; }
     void oplusImpl(const double* u) override { Vector9d v; for (int i = 0; i < 9; ++i) v(i) = u[i]; _estimate.IncSmallPVR(v); }
     int estimateDimension() const override { return 9; }
     void setToOriginImpl() override { _estimate = NavState(); }
 };
 class VertexNavStateBias : public BaseVertex<6, NavState> {
 public:
+    int plbaVertexKind() const override { return PLBA_V_BIAS; }
     void oplusImpl(const double* u) override { Vector6d v; for (int i = 0; i < 6; ++i) v(i) = u[i]; _estimate.IncSmallBias(v); }
     int estimateDimension() const override { return 6; }
     void setToOriginImpl() override { _estimate = NavState(); }
@@ -436,6 +553,7 @@ inline void plba_est_bias(const NavState& ns, VectorXd& out) {
 class EdgeNavStatePVR : public BaseMultiEdge<9, IMUPreintegrator> {
 public:
     EdgeNavStatePVR() { resize(3); }
+    int plbaEdgeKind() const override { return PLBA_EDGE_IMU_PVR; }
     void SetParams(const Vector3d& gw) { GravityVec = gw; }
     const Vector3d& gravity() const { return GravityVec; }
     void GetJacAddr(std::vector<double*>& addr) { addr.assign(3, nullptr); }
@@ -451,6 +569,7 @@ protected:
 };
 class EdgeNavStateBias : public BaseBinaryEdge<6, IMUPreintegrator, VertexNavStateBias, VertexNavStateBias> {
 public:
+    int plbaEdgeKind() const override { return PLBA_EDGE_IMU_BIAS; }
     void GetJacAddr(std::vector<double*>& addr) { addr.assign(2, nullptr); }
     void GetEstData(std::vector<VectorXd>& data) {
         VectorXd a, b;
@@ -460,12 +579,35 @@ public:
     }
 };
 struct CamParams { double fx = 0, fy = 0, cx = 0, cy = 0, Rbc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Pbc[3] = {0, 0, 0}; bool set = false; };
+// The reference hands every reprojection edge its own copy of the camera (SetParams, IMU/g2otypes.h:280-288): 136 bytes x 120 k edges that
+// are all the same camera.  The two on-path edge classes keep a pointer to an interned copy instead (one per distinct camera, never freed).
+inline const CamParams* plba_no_cam() { static const CamParams none; return &none; }
+inline const CamParams* plba_intern_cam(const CamParams& c) {
+    auto same = [](const CamParams& a, const CamParams& b) {
+        if (a.fx != b.fx || a.fy != b.fy || a.cx != b.cx || a.cy != b.cy || a.set != b.set) return false;
+        for (int i = 0; i < 9; ++i) if (a.Rbc[i] != b.Rbc[i]) return false;
+        for (int i = 0; i < 3; ++i) if (a.Pbc[i] != b.Pbc[i]) return false;
+        return true;
+    };
+    static thread_local const CamParams* last = nullptr;
+    if (last && same(*last, c)) return last;
+    static std::mutex mu;
+    static std::vector<const CamParams*>* all = new std::vector<const CamParams*>;
+    std::lock_guard<std::mutex> g(mu);
+    for (const CamParams* q : *all) if (same(*q, c)) return last = q;
+    all->push_back(new CamParams(c));
+    return last = all->back();
+}
 
 class EdgeNavStatePVRPointXYZ : public BaseBinaryEdge<2, Vector2d, VertexLMPointXYZ, VertexNavStatePVR> {
 public:
+    int plbaEdgeKind() const override { return PLBA_EDGE_POINT; }
     void SetParams(const double& fx_, const double& fy_, const double& cx_, const double& cy_, const Matrix3d& Rbc_, const Vector3d& Pbc_) {
+        CamParams cam;
         cam.fx = fx_; cam.fy = fy_; cam.cx = cx_; cam.cy = cy_; cam.set = true;
         for (int i = 0; i < 3; ++i) { cam.Pbc[i] = Pbc_(i); for (int j = 0; j < 3; ++j) cam.Rbc[i * 3 + j] = Rbc_(i, j); }
+        camp = plba_intern_cam(cam);
+        if (this->_graph) plba_note_changed(this->_graph);
     }
     bool isDepthPositive() { return _depth_cache_fresh(); }
     // `if (e->level() == 1) e->computeError();` of the culling loop (src/mapHandler.cpp:5541-5556): the cached error of a
@@ -479,15 +621,19 @@ public:
         plba_est_pvr(static_cast<VertexNavStatePVR*>(_vertices[1])->estimate(), b);
         data.push_back(a); data.push_back(b);
     }
-    CamParams cam;
+    const CamParams* camp = plba_no_cam();      // interned (plba_intern_cam)
 private:
     inline bool _depth_cache_fresh();
 };
 class EdgeNavStateLine : public BaseBinaryEdge<3, Vector3d, VertexLine, VertexNavStatePVR> {
 public:
+    int plbaEdgeKind() const override { return PLBA_EDGE_LINE; }
     void SetParams(const double& fx_, const double& fy_, const double& cx_, const double& cy_, const Matrix3d& Rbc_, const Vector3d& Pbc_) {
+        CamParams cam;
         cam.fx = fx_; cam.fy = fy_; cam.cx = cx_; cam.cy = cy_; cam.set = true;
         for (int i = 0; i < 3; ++i) { cam.Pbc[i] = Pbc_(i); for (int j = 0; j < 3; ++j) cam.Rbc[i * 3 + j] = Rbc_(i, j); }
+        camp = plba_intern_cam(cam);
+        if (this->_graph) plba_note_changed(this->_graph);
     }
     bool isDepthPositive() { return _depth_cache_fresh(); }
     inline void computeError() override;      // culling loop, src/mapHandler.cpp:5611-5620
@@ -499,7 +645,7 @@ public:
         plba_est_pvr(static_cast<VertexNavStatePVR*>(_vertices[1])->estimate(), b);
         data.push_back(a); data.push_back(b);
     }
-    CamParams cam;
+    const CamParams* camp = plba_no_cam();      // interned (plba_intern_cam)
 private:
     inline bool _depth_cache_fresh();
 };
@@ -791,6 +937,7 @@ private:
 
 class EdgeMarginalization : public BaseMultiEdge<-1, MarginalizationInfo> {
 public:
+    int plbaEdgeKind() const override { return PLBA_EDGE_PRIOR; }
     void setDimension(int d) { _dimension = d; _info.assign((size_t)d * d, 0.0); _error.assign(d, 0.0); }
     void setSize(int vertices) { resize(vertices); }
     void GetJacAddr(std::vector<double*>& addr) { addr.assign(_vertices.size(), nullptr); }
@@ -814,17 +961,69 @@ class SparseOptimizer {
 public:
     SparseOptimizer() {}
     ~SparseOptimizer() {
-        for (auto* e : _edges) delete e;
-        for (auto& kv : _vertices) delete kv.second;
+        for (auto* e : _edges) { e->_graph = nullptr; delete e; }      // (no write-through hooks from ~Edge's setRobustKernel-like paths)
+        for (auto* v : _vseq) delete v;
         delete _algorithm;
         if (_prob) plba_destroy(_prob);
     }
     void setAlgorithm(OptimizationAlgorithm* a) { delete _algorithm; _algorithm = a; }
     void setForceStopFlag(bool* f) { _forceStop = f; }
     void setVerbose(bool v) { _verbose = v; }
-    bool addVertex(OptimizableGraph::Vertex* v) { if (_vertices.count(v->id())) return false; v->_graph = this; _vertices[v->id()] = v; _dirty = true; return true; }
-    bool addEdge(OptimizableGraph::Edge* e) { e->_graph = this; _edges.push_back(e); _dirty = true; return true; }
-    OptimizableGraph::Vertex* vertex(int id) { auto it = _vertices.find(id); return it == _vertices.end() ? nullptr : it->second; }
+    // Vertices: insertion-ordered list + an id index that is a plain array while the ids are small non-negative integers (the call site's
+    // are: 2 * kf_idx, idx + maxKFid + 1 — src/mapHandler.cpp:5810,5902), a std::map beyond; `optimizer.vertex(id)`, called twice per
+    // edge by the call site, is then one load instead of a tree walk.
+    bool addVertex(OptimizableGraph::Vertex* v) {
+        const int id = v->id();
+        if (vertex(id)) return false;
+        if (id >= 0 && id < (1 << 24)) { if ((size_t)id >= _by_id.size()) _by_id.resize(std::max<size_t>((size_t)id + 1, _by_id.size() * 2), nullptr); _by_id[id] = v; }
+        else _by_id_sparse[id] = v;
+        if (!_vseq.empty() && id < _vseq.back()->id()) _ids_ascending = false;
+        _vseq.push_back(v);
+        v->_graph = this; v->_plba_stale = &_stale_est; _dirty = true;
+        // flatten-at-insertion: the device path's arrays want keyframes, points and lines each in ascending id order; as long as the call
+        // site inserts them that way (it does) the index of a vertex is its insertion rank within its kind
+        switch (v->plbaVertexKind()) {
+            case PLBA_V_PVR:
+                if (!_kfs.empty() && id <= _kfs.back().first->id()) _soa_ok = false;
+                v->_plba_index = (int)_kfs.size(); _kfs.push_back({static_cast<VertexNavStatePVR*>(v), nullptr});
+                break;
+            case PLBA_V_BIAS:
+                if (_kfs.empty() || _kfs.back().first->id() != id - 1 || _kfs.back().second) _soa_ok = false;
+                else { _kfs.back().second = static_cast<VertexNavStateBias*>(v); v->_plba_index = (int)_kfs.size() - 1; }
+                break;
+            case PLBA_V_POINT:
+                if (!_pts.empty() && id <= _pts.back()->id()) _soa_ok = false;
+                v->_plba_index = (int)_pts.size(); _pts.push_back(static_cast<VertexLMPointXYZ*>(v));
+                break;
+            case PLBA_V_LINE:
+                if (!_lns.empty() && id <= _lns.back()->id()) _soa_ok = false;
+                v->_plba_index = (int)_lns.size(); _lns.push_back(static_cast<VertexLine*>(v));
+                break;
+            default: break;
+        }
+        return true;
+    }
+    bool addEdge(OptimizableGraph::Edge* e) {
+        e->_graph = this; e->_plba_stale = &_stale_chi; _edges.push_back(e); _dirty = true;
+        const int kind = e->plbaEdgeKind();
+        if (kind < 0) { ++_n_host_edges; return true; }
+        e->_plba_kind = kind;
+        if (e->robustKernel()) ++_n_rk[kind];
+        switch (kind) {
+            case PLBA_EDGE_POINT: captureObservation(static_cast<EdgeNavStatePVRPointXYZ*>(e), _epts, PLBA_V_POINT, _soa.po_pt, _soa.po_kf, _soa.po_uv, 2, _soa.po_w, _soa.lev_pt); break;
+            case PLBA_EDGE_LINE: captureObservation(static_cast<EdgeNavStateLine*>(e), _elns, PLBA_V_LINE, _soa.lo_ln, _soa.lo_kf, _soa.lo_l, 3, _soa.lo_w, _soa.lev_ln); break;
+            case PLBA_EDGE_IMU_PVR: e->_plba_index = (int)_eimu.size(); _eimu.push_back(static_cast<EdgeNavStatePVR*>(e)); break;
+            case PLBA_EDGE_IMU_BIAS: e->_plba_index = (int)_ebias.size(); _ebias.push_back(static_cast<EdgeNavStateBias*>(e)); break;
+            default: if (_eprior) _two_priors = true; _eprior = static_cast<EdgeMarginalization*>(e); e->_plba_index = 0; break;
+        }
+        return true;
+    }
+    OptimizableGraph::Vertex* vertex(int id) {
+        if (id >= 0 && (size_t)id < _by_id.size()) return _by_id[id];
+        if (_by_id_sparse.empty()) return nullptr;
+        auto it = _by_id_sparse.find(id);
+        return it == _by_id_sparse.end() ? nullptr : it->second;
+    }
     bool initializeOptimization(int level = 0) { _level = level; return true; }
     bool terminate() const { return _forceStop && *_forceStop; }
     const char* lastError() const { return _err.c_str(); }
@@ -840,7 +1039,7 @@ public:
         const int rc = plba_optimize(_prob, iterations, reinterpret_cast<const volatile uint8_t*>(_forceStop), &_stats);
         if (rc != PLBA_OK) { _err = plba_last_error(_prob); std::cerr << "[plba g2o facade] " << _err << std::endl; return 0; }
         if (_verbose) std::cerr << "iterations= " << _stats.iterations << "\t chi2= " << _stats.chi2_final << "\t lambda= " << _stats.lambda_final << std::endl;
-        writeBack();
+        _stale_est = true; _stale_chi = true;      // fetched by the first estimate() / chi2() that wants them (syncEstimates / syncChi2)
         return _stats.iterations;
     }
 
@@ -849,12 +1048,7 @@ public:
     // host path: graphs of host-evaluated edge types (IMUInitEstBg, pose-graph optimisation: SURVEY §8f row 4)
     // ================================================================================================================
     // true when every edge belongs to the local-BA family the HIP kernels implement
-    bool onDevicePath() const {
-        for (auto* e : _edges)
-            if (!(dynamic_cast<EdgeNavStatePVRPointXYZ*>(e) || dynamic_cast<EdgeNavStateLine*>(e) || dynamic_cast<EdgeNavStatePVR*>(e) ||
-                  dynamic_cast<EdgeNavStateBias*>(e) || dynamic_cast<EdgeMarginalization*>(e))) return false;
-        return true;
-    }
+    bool onDevicePath() const { return _n_host_edges == 0; }      // (counted in addEdge from the edges' kind tags: no pass over the graph)
     // g2o SparseOptimizer::computeActiveErrors / activeChi2 / activeRobustChi2 on the host-evaluated edges of the active level
     void computeActiveErrors() { if (onDevicePath()) return; collectActive(); for (auto* e : _active) e->computeError(); }
     double activeChi2() { double c = 0.0; for (auto* e : _active) c += edgeChi2(e); return c; }
@@ -901,7 +1095,7 @@ private:
     // Hessian indices: non-fixed vertices of the active edges, non-marginalized first, each group by ascending id (App. A.1)
     bool indexHost() {
         collectActive();
-        for (auto& kv : _vertices) kv.second->_hidx = -1;
+        for (auto* v : _vseq) v->_hidx = -1;
         std::map<int, OptimizableGraph::Vertex*> used;
         for (auto* e : _active) {
             if (!e->plbaHostEvaluable()) return fail("edge type is neither on the device path nor host-evaluable");
@@ -1099,7 +1293,52 @@ public:
 private:
     bool fail(const std::string& m) { _err = m; return false; }
 
-    // graph -> SoA (include/plba.h), in the reference's vertex-id / edge-insertion order
+    // ---- flatten-at-insertion -------------------------------------------------------------------------------------------------------------
+    // The observation arrays of include/plba.h, filled edge by edge in addEdge() (the object was just written by the call site: no cache
+    // miss), plus the per-edge state the call site changes afterwards (level) and reads back (cached chi2 / depth).
+    struct SoA {
+        std::vector<int32_t> po_pt, po_kf, lo_ln, lo_kf;
+        std::vector<double> po_uv, po_w, lo_l, lo_w;
+        std::vector<uint8_t> lev_pt, lev_ln;      // raw g2o levels (setLevel writes through)
+    };
+    template <class E, class V>
+    void captureObservation(E* e, V& list, int lm_kind, std::vector<int32_t>& ob_lm, std::vector<int32_t>& ob_kf, std::vector<double>& meas, int nm,
+                            std::vector<double>& wt, std::vector<uint8_t>& lev) {
+        e->_plba_index = (int)list.size();
+        list.push_back(e);
+        if (!_soa_ok) return;
+        OptimizableGraph::Vertex* a = e->vertices().size() > 0 ? e->vertex(0) : nullptr;
+        OptimizableGraph::Vertex* b = e->vertices().size() > 1 ? e->vertex(1) : nullptr;
+        if (!a || !b || a->_graph != this || b->_graph != this || a->plbaVertexKind() != lm_kind || b->plbaVertexKind() != PLBA_V_PVR || a->_plba_index < 0 ||
+            b->_plba_index < 0 || (!ob_lm.empty() && a->_plba_index < ob_lm.back())) { _soa_ok = false; return; }      // (not the call site's shape: the arrays are built from the objects at optimize())
+        ob_lm.push_back(a->_plba_index); ob_kf.push_back(b->_plba_index);
+        for (int c = 0; c < nm; ++c) meas.push_back(e->measurement()(c));
+        wt.push_back(e->informationRowMajor()[0]);
+        lev.push_back((uint8_t)std::min(std::max(e->level(), 0), 255));
+        if (!_cam && e->camp->set) _cam = e->camp;
+    }
+
+public:
+    // hooks of the graph elements (plba_note_* / plba_cached_* below)
+    void noteEdgeLevel(int kind, int index, int level) {
+        _lv_touched = true;
+        std::vector<uint8_t>* lv = kind == PLBA_EDGE_POINT ? &_soa.lev_pt : kind == PLBA_EDGE_LINE ? &_soa.lev_ln : nullptr;
+        if (lv && index >= 0 && (size_t)index < lv->size()) (*lv)[index] = (uint8_t)std::min(std::max(level, 0), 255);
+    }
+    void noteEdgeKernel(int kind, bool had, bool has) { if (kind >= 0 && kind < 5) { _n_rk[kind] += (long)has - (long)had; _rk_touched = true; } }
+    void noteChanged() { _soa_ok = false; _dirty = true; }      // a captured element was edited after insertion: rebuild from the objects
+    double cachedChi2(int kind, int index, double fallback) const { return (kind >= 0 && kind < 4 && index >= 0 && (size_t)index < _chi[kind].size()) ? _chi[kind][index] : fallback; }
+    bool cachedDepth(int kind, int index, bool fallback) const { return (kind >= 0 && kind < 2 && index >= 0 && (size_t)index < _dp[kind].size()) ? _dp[kind][index] != 0 : fallback; }
+    void storeChi2(int kind, int index, double chi2, bool depth) {
+        if (kind >= 0 && kind < 4 && index >= 0 && (size_t)index < _chi[kind].size()) _chi[kind][index] = chi2;
+        if (kind >= 0 && kind < 2 && index >= 0 && (size_t)index < _dp[kind].size()) _dp[kind][index] = depth ? 1 : 0;
+    }
+
+private:
+    // graph -> SoA (include/plba.h), in the reference's vertex-id / edge-insertion order.  Round 5: when every
+    // element arrived in the call site's shape (keyframes, points, lines in ascending id order; each observation edge after its two
+    // vertices, landmark by landmark) the arrays were filled at insertion and this function walks no edge object at all; otherwise — and
+    // whenever the graph is changed after its first optimize() — they are rebuilt from the objects.
     bool flatten() {
         if (!_prob) {
             plba_options o;
@@ -1109,22 +1348,56 @@ private:
             if (plba_create(&o, &_prob) != PLBA_OK) return fail(plba_last_error(nullptr));
         }
         if (!_dirty) return syncLevelsAndKernels();
-        // keyframes: PVR vertices ascending id; the bias vertex of a keyframe has id pvr+1 (mapHandler.cpp:5802-5826)
-        _kfs.clear(); _pts.clear(); _lns.clear();
-        std::map<int, int> kf_of_vid;
-        for (auto& kv : _vertices) {
-            if (auto* v = dynamic_cast<VertexNavStatePVR*>(kv.second)) { v->_plba_index = (int)_kfs.size(); kf_of_vid[v->id()] = v->_plba_index; _kfs.push_back({v, nullptr}); }
-            else if (auto* p3 = dynamic_cast<VertexLMPointXYZ*>(kv.second)) { p3->_plba_index = (int)_pts.size(); _pts.push_back(p3); }
-            else if (auto* l6 = dynamic_cast<VertexLine*>(kv.second)) { l6->_plba_index = (int)_lns.size(); _lns.push_back(l6); }
-            else if (dynamic_cast<VertexNavStateBias*>(kv.second)) {}
-            else return fail("vertex type not supported by the device path (id " + std::to_string(kv.first) + ")");
-        }
-        for (auto& kv : _vertices)
-            if (auto* b = dynamic_cast<VertexNavStateBias*>(kv.second)) {
-                auto it = kf_of_vid.find(b->id() - 1);
-                if (it == kf_of_vid.end()) return fail("bias vertex " + std::to_string(b->id()) + " has no PVR vertex with id-1");
-                _kfs[it->second].second = b; b->_plba_index = it->second;
+        if (_two_priors) return fail("more than one prior edge");
+        if (_eimu.size() != _ebias.size()) return fail("every EdgeNavStatePVR needs its EdgeNavStateBias (mapHandler.cpp:5842-5885)");
+        const bool fast = _soa_ok && !_uploaded_once;
+        if (!fast) {
+            // keyframes: PVR vertices ascending id; the bias vertex of a keyframe has id pvr+1 (mapHandler.cpp:5802-5826)
+            std::vector<OptimizableGraph::Vertex*> sorted(_vseq);
+            if (!_ids_ascending) std::sort(sorted.begin(), sorted.end(), [](const OptimizableGraph::Vertex* x, const OptimizableGraph::Vertex* y) { return x->id() < y->id(); });
+            _kfs.clear(); _pts.clear(); _lns.clear();
+            for (auto* v : sorted) {      // (ascending id: a bias vertex, id pvr + 1, directly follows its PVR vertex when both exist)
+                switch (v->plbaVertexKind()) {
+                    case PLBA_V_PVR: v->_plba_index = (int)_kfs.size(); _kfs.push_back({static_cast<VertexNavStatePVR*>(v), nullptr}); break;
+                    case PLBA_V_POINT: v->_plba_index = (int)_pts.size(); _pts.push_back(static_cast<VertexLMPointXYZ*>(v)); break;
+                    case PLBA_V_LINE: v->_plba_index = (int)_lns.size(); _lns.push_back(static_cast<VertexLine*>(v)); break;
+                    case PLBA_V_BIAS: {
+                        if (_kfs.empty() || _kfs.back().first->id() != v->id() - 1) return fail("bias vertex " + std::to_string(v->id()) + " has no PVR vertex with id-1");
+                        _kfs.back().second = static_cast<VertexNavStateBias*>(v); v->_plba_index = (int)_kfs.size() - 1;
+                        break;
+                    }
+                    default: return fail("vertex type not supported by the device path (id " + std::to_string(v->id()) + ")");
+                }
             }
+            // observations from the objects, insertion order preserved (_epts / _elns are kept in it by addEdge)
+            const size_t nEp = _epts.size(), nEl = _elns.size();
+            _soa.po_pt.resize(nEp); _soa.po_kf.resize(nEp); _soa.po_uv.resize(2 * nEp); _soa.po_w.resize(nEp); _soa.lev_pt.resize(nEp);
+            _soa.lo_ln.resize(nEl); _soa.lo_kf.resize(nEl); _soa.lo_l.resize(3 * nEl); _soa.lo_w.resize(nEl); _soa.lev_ln.resize(nEl);
+            _cam = nullptr;
+            for (size_t i = 0; i < nEp; ++i) {
+                auto* e = _epts[i];
+                if (!_cam && e->camp->set) _cam = e->camp;
+                e->_plba_index = (int)i;
+                if (e->vertices().size() < 2 || !e->vertex(0) || !e->vertex(1) || e->vertex(0)->plbaVertexKind() != PLBA_V_POINT || e->vertex(1)->plbaVertexKind() != PLBA_V_PVR) return fail("EdgeNavStatePVRPointXYZ: vertex 0 must be a VertexLMPointXYZ, vertex 1 a VertexNavStatePVR");
+                _soa.po_pt[i] = e->vertex(0)->_plba_index; _soa.po_kf[i] = e->vertex(1)->_plba_index;
+                _soa.po_uv[2 * i] = e->measurement()(0); _soa.po_uv[2 * i + 1] = e->measurement()(1);
+                _soa.po_w[i] = e->informationRowMajor()[0];
+                _soa.lev_pt[i] = (uint8_t)std::min(std::max(e->level(), 0), 255);
+            }
+            for (size_t i = 0; i < nEl; ++i) {
+                auto* e = _elns[i];
+                if (!_cam && e->camp->set) _cam = e->camp;
+                e->_plba_index = (int)i;
+                if (e->vertices().size() < 2 || !e->vertex(0) || !e->vertex(1) || e->vertex(0)->plbaVertexKind() != PLBA_V_LINE || e->vertex(1)->plbaVertexKind() != PLBA_V_PVR) return fail("EdgeNavStateLine: vertex 0 must be a VertexLine, vertex 1 a VertexNavStatePVR");
+                _soa.lo_ln[i] = e->vertex(0)->_plba_index; _soa.lo_kf[i] = e->vertex(1)->_plba_index;
+                for (int c = 0; c < 3; ++c) _soa.lo_l[3 * i + c] = e->measurement()(c);
+                _soa.lo_w[i] = e->informationRowMajor()[0];
+                _soa.lev_ln[i] = (uint8_t)std::min(std::max(e->level(), 0), 255);
+            }
+            _soa_ok = false;      // (the arrays now mirror the objects, but later insertions are not appended in step: stay on this path)
+        } else {
+            for (auto* v : _vseq) if (v->plbaVertexKind() == PLBA_V_OTHER) return fail("vertex type not supported by the device path (id " + std::to_string(v->id()) + ")");
+        }
         const int K = (int)_kfs.size();
         if (K == 0) return fail("no VertexNavStatePVR in the graph");
         std::vector<int32_t> vid_pvr(K), vid_bias(K);
@@ -1138,57 +1411,34 @@ private:
             std::memcpy(&bg[3 * k], sb + 10, 24); std::memcpy(&ba[3 * k], sb + 13, 24); std::memcpy(&dbg[3 * k], sb + 16, 24); std::memcpy(&dba[3 * k], sb + 19, 24);
             fp[k] = _kfs[k].first->fixed(); fb[k] = _kfs[k].second ? _kfs[k].second->fixed() : 1;
         }
+        // landmark estimates and fixed flags are read from the objects here (one pass over the landmark vertices, in allocation order): the
+        // call site may set them after addVertex
         std::vector<double> pxyz(3 * _pts.size()), l6(6 * _lns.size());
         std::vector<uint8_t> pfix(_pts.size()), lfix(_lns.size());
-        for (size_t i = 0; i < _pts.size(); ++i) { for (int c = 0; c < 3; ++c) pxyz[3 * i + c] = _pts[i]->estimate()(c); pfix[i] = _pts[i]->fixed(); }
-        for (size_t i = 0; i < _lns.size(); ++i) { for (int c = 0; c < 6; ++c) l6[6 * i + c] = _lns[i]->estimate()(c); lfix[i] = _lns[i]->fixed(); }
-        // edges by kind, insertion order preserved
-        _epts.clear(); _elns.clear(); _eimu.clear(); _ebias.clear(); _eprior = nullptr;
-        for (auto* e : _edges) {
-            if (auto* a = dynamic_cast<EdgeNavStatePVRPointXYZ*>(e)) _epts.push_back(a);
-            else if (auto* b = dynamic_cast<EdgeNavStateLine*>(e)) _elns.push_back(b);
-            else if (auto* c = dynamic_cast<EdgeNavStatePVR*>(e)) _eimu.push_back(c);
-            else if (auto* d = dynamic_cast<EdgeNavStateBias*>(e)) _ebias.push_back(d);
-            else if (auto* m = dynamic_cast<EdgeMarginalization*>(e)) { if (_eprior) return fail("more than one prior edge"); _eprior = m; }
-            else return fail("edge type not supported by the device path");
-        }
-        if (_eimu.size() != _ebias.size()) return fail("every EdgeNavStatePVR needs its EdgeNavStateBias (mapHandler.cpp:5842-5885)");
-        const CamParams* cam = nullptr;
-        std::vector<int32_t> po_pt, po_kf, lo_ln, lo_kf;
-        std::vector<double> po_uv, po_w, lo_l, lo_w;
-        for (size_t i = 0; i < _epts.size(); ++i) {
-            auto* e = _epts[i];
-            if (!cam && e->cam.set) cam = &e->cam;
-            e->_plba_kind = PLBA_EDGE_POINT; e->_plba_index = (int)i;
-            po_pt.push_back(e->vertex(0)->_plba_index); po_kf.push_back(e->vertex(1)->_plba_index);
-            po_uv.push_back(e->measurement()(0)); po_uv.push_back(e->measurement()(1));
-            po_w.push_back(e->informationRowMajor()[0]);
-        }
-        for (size_t i = 0; i < _elns.size(); ++i) {
-            auto* e = _elns[i];
-            if (!cam && e->cam.set) cam = &e->cam;
-            e->_plba_kind = PLBA_EDGE_LINE; e->_plba_index = (int)i;
-            lo_ln.push_back(e->vertex(0)->_plba_index); lo_kf.push_back(e->vertex(1)->_plba_index);
-            for (int c = 0; c < 3; ++c) lo_l.push_back(e->measurement()(c));
-            lo_w.push_back(e->informationRowMajor()[0]);
-        }
+        for (size_t i = 0; i < _pts.size(); ++i) { const Vector3d& e = _pts[i]->estimate(); for (int c = 0; c < 3; ++c) pxyz[3 * i + c] = e(c); pfix[i] = _pts[i]->fixed(); }
+        for (size_t i = 0; i < _lns.size(); ++i) { const Vector6d& e = _lns[i]->estimate(); for (int c = 0; c < 6; ++c) l6[6 * i + c] = e(c); lfix[i] = _lns[i]->fixed(); }
+        const size_t nEp = _epts.size(), nEl = _elns.size();
+        if (_soa.po_pt.size() != nEp || _soa.lo_ln.size() != nEl) return fail("internal: observation arrays out of step with the edge lists");
+        _chi[PLBA_EDGE_POINT].assign(nEp, 0.0); _chi[PLBA_EDGE_LINE].assign(nEl, 0.0); _chi[PLBA_EDGE_IMU_PVR].assign(_eimu.size(), 0.0); _chi[PLBA_EDGE_IMU_BIAS].assign(_ebias.size(), 0.0);
+        _dp[0].assign(nEp, 1); _dp[1].assign(nEl, 1);
         int rc = PLBA_OK;
+        const CamParams* cam = _cam;
         if (cam) rc = plba_set_camera(_prob, cam->fx, cam->fy, cam->cx, cam->cy, cam->Rbc, cam->Pbc);
         else { const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0}; rc = plba_set_camera(_prob, 1, 1, 0, 0, I, z); }
         if (rc) return fail(plba_last_error(_prob));
         if ((rc = plba_set_keyframes(_prob, K, vid_pvr.data(), vid_bias.data(), P.data(), V.data(), q.data(), bg.data(), ba.data(), dbg.data(), dba.data(), fp.data(), fb.data()))) return fail(plba_last_error(_prob));
         if ((rc = plba_set_points(_prob, (int)_pts.size(), pxyz.data(), pfix.data()))) return fail(plba_last_error(_prob));
         if ((rc = plba_set_lines(_prob, (int)_lns.size(), l6.data(), lfix.data()))) return fail(plba_last_error(_prob));
-        if ((rc = plba_set_point_obs(_prob, (int)_epts.size(), po_pt.data(), po_kf.data(), po_uv.data(), po_w.data()))) return fail(plba_last_error(_prob));
-        if ((rc = plba_set_line_obs(_prob, (int)_elns.size(), lo_ln.data(), lo_kf.data(), lo_l.data(), lo_w.data()))) return fail(plba_last_error(_prob));
+        if ((rc = plba_set_point_obs(_prob, (int)nEp, _soa.po_pt.data(), _soa.po_kf.data(), _soa.po_uv.data(), _soa.po_w.data()))) return fail(plba_last_error(_prob));
+        if ((rc = plba_set_line_obs(_prob, (int)nEl, _soa.lo_ln.data(), _soa.lo_kf.data(), _soa.lo_l.data(), _soa.lo_w.data()))) return fail(plba_last_error(_prob));
         // IMU edges (PVR edge m and bias edge m describe the same keyframe pair)
         const int M = (int)_eimu.size();
         std::vector<int32_t> ki(M), kj(M);
         std::vector<double> pre((size_t)M * 142), ipvr((size_t)M * 81), ibias((size_t)M * 36);
         for (int m = 0; m < M; ++m) {
             auto* e = _eimu[m];
-            e->_plba_kind = PLBA_EDGE_IMU_PVR; e->_plba_index = m;
-            _ebias[m]->_plba_kind = PLBA_EDGE_IMU_BIAS; _ebias[m]->_plba_index = m;
+            e->_plba_index = m; _ebias[m]->_plba_index = m;
+            if (e->vertices().size() < 3 || !e->vertex(0) || !e->vertex(1) || e->vertex(0)->plbaVertexKind() != PLBA_V_PVR || e->vertex(1)->plbaVertexKind() != PLBA_V_PVR) return fail("EdgeNavStatePVR: vertices 0 and 1 must be VertexNavStatePVR");
             ki[m] = e->vertex(0)->_plba_index; kj[m] = e->vertex(1)->_plba_index;
             std::memcpy(&pre[(size_t)m * 142], e->measurement().payload(), 142 * 8);
             std::memcpy(&ipvr[(size_t)m * 81], e->informationRowMajor().data(), 81 * 8);
@@ -1198,7 +1448,6 @@ private:
         if ((rc = plba_set_imu_edges(_prob, M, ki.data(), kj.data(), pre.data(), ipvr.data(), ibias.data()))) return fail(plba_last_error(_prob));
         if (_eprior) {
             const MarginalizationInfo& mi = _eprior->measurement();
-            _eprior->_plba_kind = PLBA_EDGE_PRIOR; _eprior->_plba_index = 0;
             const int nv = (int)mi.keep_vertex_id.size(), n = mi.n;
             std::vector<int32_t> vid(nv), size(nv), idx(nv);
             std::vector<double> x0, J0((size_t)n * n), r0(n);
@@ -1210,29 +1459,54 @@ private:
             for (int r = 0; r < n; ++r) r0[r] = mi.linearized_residuals(r);
             if ((rc = plba_set_prior(_prob, n, nv, vid.data(), size.data(), idx.data(), x0.data(), J0.data(), r0.data()))) return fail(plba_last_error(_prob));
         } else if ((rc = plba_set_prior(_prob, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return fail(plba_last_error(_prob));
-        _dirty = false;
+        _dirty = false; _uploaded_once = true;
+        _lv_touched = true; _rk_touched = true;
         return syncLevelsAndKernels();
     }
 
-    // setLevel / setRobustKernel may change between optimize() calls (stage-2 protocol, mapHandler.cpp:6047-6066)
+    // setLevel / setRobustKernel may change between optimize() calls (stage-2 protocol, mapHandler.cpp:6047-6066): both are written
+    // through at the call (noteEdgeLevel / noteEdgeKernel), so this walks no edge object either
     bool syncLevelsAndKernels() {
-        std::vector<uint8_t> lv(_epts.size());
-        for (size_t i = 0; i < _epts.size(); ++i) lv[i] = (uint8_t)(_epts[i]->level() != _level);
-        if (!lv.empty() && plba_set_levels(_prob, PLBA_EDGE_POINT, lv.data())) return fail(plba_last_error(_prob));
-        lv.assign(_elns.size(), 0);
-        for (size_t i = 0; i < _elns.size(); ++i) lv[i] = (uint8_t)(_elns[i]->level() != _level);
-        if (!lv.empty() && plba_set_levels(_prob, PLBA_EDGE_LINE, lv.data())) return fail(plba_last_error(_prob));
-        auto kernel = [&](const std::vector<OptimizableGraph::Edge*>& es, plba_edge_kind kind) -> bool {
-            int with = 0; double delta = 0.0;
-            for (auto* e : es) if (e->robustKernel()) { ++with; delta = e->robustKernel()->delta(); }
-            if (with != 0 && with != (int)es.size()) return fail("robust kernels must be uniform per edge type on the device path");
-            return plba_set_robust(_prob, kind, with != 0, delta) == PLBA_OK;
-        };
-        std::vector<OptimizableGraph::Edge*> a(_epts.begin(), _epts.end()), b(_elns.begin(), _elns.end()), c(_eimu.begin(), _eimu.end()), d(_ebias.begin(), _ebias.end());
-        return kernel(a, PLBA_EDGE_POINT) && kernel(b, PLBA_EDGE_LINE) && kernel(c, PLBA_EDGE_IMU_PVR) && kernel(d, PLBA_EDGE_IMU_BIAS);
+        if (_lv_touched || _level != _level_sent) {
+            auto send = [&](plba_edge_kind kind, const std::vector<uint8_t>& raw) -> bool {
+                if (raw.empty()) return true;
+                if (_level == 0) return plba_set_levels(_prob, kind, raw.data()) == PLBA_OK;      // (level != 0 <=> inactive: the raw levels are the flags)
+                std::vector<uint8_t> lv(raw.size());
+                for (size_t i = 0; i < raw.size(); ++i) lv[i] = (uint8_t)(raw[i] != _level);
+                return plba_set_levels(_prob, kind, lv.data()) == PLBA_OK;
+            };
+            if (!send(PLBA_EDGE_POINT, _soa.lev_pt) || !send(PLBA_EDGE_LINE, _soa.lev_ln)) return fail(plba_last_error(_prob));
+            _lv_touched = false; _level_sent = _level;
+        }
+        if (_rk_touched) {
+            // uniform per kind (the count decides), so one edge that carries a kernel answers for delta — read NOW: the call site sets it
+            // after setRobustKernel (`e->setRobustKernel(rk); rk->setDelta(thHuberMono);`, src/mapHandler.cpp:5937-5939)
+            auto sample = [&](auto& list, plba_edge_kind kind) -> OptimizableGraph::Edge* {
+                if (!_n_rk[kind] || list.empty()) return nullptr;
+                if (list[0]->robustKernel()) return list[0];
+                for (auto* e : list) if (e->robustKernel()) return e;
+                return nullptr;
+            };
+            if (!kernelOne(PLBA_EDGE_POINT, _epts.size(), sample(_epts, PLBA_EDGE_POINT)) || !kernelOne(PLBA_EDGE_LINE, _elns.size(), sample(_elns, PLBA_EDGE_LINE)) ||
+                !kernelOne(PLBA_EDGE_IMU_PVR, _eimu.size(), sample(_eimu, PLBA_EDGE_IMU_PVR)) || !kernelOne(PLBA_EDGE_IMU_BIAS, _ebias.size(), sample(_ebias, PLBA_EDGE_IMU_BIAS))) return false;
+            _rk_touched = false;
+        }
+        return true;
+    }
+    bool kernelOne(plba_edge_kind kind, size_t n, OptimizableGraph::Edge* sample) {
+        const long with = _n_rk[kind];
+        if (with != 0 && with != (long)n) return fail("robust kernels must be uniform per edge type on the device path");
+        const double delta = (with && sample && sample->robustKernel()) ? sample->robustKernel()->delta() : 0.0;
+        if (plba_set_robust(_prob, kind, with != 0, delta) != PLBA_OK) return fail(plba_last_error(_prob));
+        return true;
     }
 
-    void writeBack() {
+public:
+    // the two halves of the reference's read-after-optimize, each fetched when first asked for (plba_sync_estimates / plba_sync_chi2)
+    void syncEstimates() {
+        if (!_stale_est) return;
+        _stale_est = false;      // (first: the loops below read estimate() themselves)
+        if (!_prob) return;
         const int K = (int)_kfs.size();
         std::vector<double> P(3 * K), V(3 * K), q(4 * K), dbg(3 * K), dba(3 * K), pts(3 * _pts.size()), lns(6 * _lns.size());
         plba_get_keyframes(_prob, P.data(), V.data(), q.data(), dbg.data(), dba.data());
@@ -1241,28 +1515,40 @@ private:
         for (int k = 0; k < K; ++k) {
             NavState ns = _kfs[k].first->estimate();
             std::memcpy(ns.raw(), &P[3 * k], 24); std::memcpy(ns.raw() + 3, &V[3 * k], 24); std::memcpy(ns.raw() + 6, &q[4 * k], 32);
-            _kfs[k].first->setEstimate(ns);
+            _kfs[k].first->plbaStoreEstimate(ns);
             if (_kfs[k].second) {
                 NavState nb = _kfs[k].second->estimate();
                 std::memcpy(nb.raw() + 16, &dbg[3 * k], 24); std::memcpy(nb.raw() + 19, &dba[3 * k], 24);
-                _kfs[k].second->setEstimate(nb);
+                _kfs[k].second->plbaStoreEstimate(nb);
             }
         }
-        for (size_t i = 0; i < _pts.size(); ++i) _pts[i]->setEstimate(Vector3d(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
-        for (size_t i = 0; i < _lns.size(); ++i) { Vector6d l; for (int c = 0; c < 6; ++c) l(c) = lns[6 * i + c]; _lns[i]->setEstimate(l); }
-        // cached chi2 / depth for the gating loop of the call site
-        std::vector<double> chi(std::max(_epts.size(), _elns.size()) + 1);
-        std::vector<uint8_t> dp(chi.size());
-        if (!_epts.empty() && plba_get_edge_chi2(_prob, PLBA_EDGE_POINT, chi.data(), dp.data()) == PLBA_OK)
-            for (size_t i = 0; i < _epts.size(); ++i) { _epts[i]->_chi2_cache = chi[i]; _epts[i]->_depth_cache = dp[i] != 0; }
-        if (!_elns.empty() && plba_get_edge_chi2(_prob, PLBA_EDGE_LINE, chi.data(), dp.data()) == PLBA_OK)
-            for (size_t i = 0; i < _elns.size(); ++i) { _elns[i]->_chi2_cache = chi[i]; _elns[i]->_depth_cache = dp[i] != 0; }
-        std::vector<double> ci(_eimu.size() + 1);
-        if (!_eimu.empty() && plba_get_edge_chi2(_prob, PLBA_EDGE_IMU_PVR, ci.data(), nullptr) == PLBA_OK) for (size_t i = 0; i < _eimu.size(); ++i) _eimu[i]->_chi2_cache = ci[i];
-        if (!_ebias.empty() && plba_get_edge_chi2(_prob, PLBA_EDGE_IMU_BIAS, ci.data(), nullptr) == PLBA_OK) for (size_t i = 0; i < _ebias.size(); ++i) _ebias[i]->_chi2_cache = ci[i];
+        for (size_t i = 0; i < _pts.size(); ++i) _pts[i]->plbaStoreEstimate(Vector3d(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+        for (size_t i = 0; i < _lns.size(); ++i) { Vector6d l; for (int c = 0; c < 6; ++c) l(c) = lns[6 * i + c]; _lns[i]->plbaStoreEstimate(l); }
     }
+    // cached chi2 / depth for the gating loop of the call site: the read-backs land in the graph's arrays, which Edge::chi2() /
+    // isDepthPositive() read (no pass over the edge objects)
+    void syncChi2() {
+        if (!_stale_chi) return;
+        _stale_chi = false;
+        if (!_prob) return;
+        if (!_epts.empty()) plba_get_edge_chi2(_prob, PLBA_EDGE_POINT, _chi[PLBA_EDGE_POINT].data(), _dp[0].data());
+        if (!_elns.empty()) plba_get_edge_chi2(_prob, PLBA_EDGE_LINE, _chi[PLBA_EDGE_LINE].data(), _dp[1].data());
+        if (!_eimu.empty()) plba_get_edge_chi2(_prob, PLBA_EDGE_IMU_PVR, _chi[PLBA_EDGE_IMU_PVR].data(), nullptr);
+        if (!_ebias.empty()) plba_get_edge_chi2(_prob, PLBA_EDGE_IMU_BIAS, _chi[PLBA_EDGE_IMU_BIAS].data(), nullptr);
+    }
+private:
+    bool _stale_est = false, _stale_chi = false;
+    size_t _n_host_edges = 0;
+    bool _soa_ok = true, _uploaded_once = false, _ids_ascending = true, _two_priors = false, _lv_touched = true, _rk_touched = true;
+    int _level_sent = -1;
+    long _n_rk[5] = {0, 0, 0, 0, 0};      // edges of each kind that carry a robust kernel (setRobustKernel writes through)
+    SoA _soa;
+    std::vector<double> _chi[4];
+    std::vector<uint8_t> _dp[2];
+    const CamParams* _cam = nullptr;
 
-    std::map<int, OptimizableGraph::Vertex*> _vertices;
+    std::vector<OptimizableGraph::Vertex*> _vseq, _by_id;      // insertion order | by id (dense range)
+    std::map<int, OptimizableGraph::Vertex*> _by_id_sparse;   // ids outside [0, 2^24)
     std::vector<OptimizableGraph::Edge*> _edges;
     std::vector<std::pair<VertexNavStatePVR*, VertexNavStateBias*>> _kfs;
     std::vector<VertexLMPointXYZ*> _pts;
@@ -1282,8 +1568,16 @@ private:
     std::string _err;
 };
 
+inline void plba_note_edge_level(SparseOptimizer* g, int kind, int index, int level) { if (g) g->noteEdgeLevel(kind, index, level); }
+inline void plba_note_edge_kernel(SparseOptimizer* g, int kind, bool had, bool has) { if (g) g->noteEdgeKernel(kind, had, has); }
+inline void plba_note_changed(SparseOptimizer* g) { if (g) g->noteChanged(); }
+inline double plba_cached_chi2(const SparseOptimizer* g, int kind, int index, double fallback) { return g->cachedChi2(kind, index, fallback); }
+inline bool plba_cached_depth(const SparseOptimizer* g, int kind, int index, bool fallback) { return g->cachedDepth(kind, index, fallback); }
+inline void plba_store_chi2(SparseOptimizer* g, int kind, int index, double chi2, bool depth) { g->storeChi2(kind, index, chi2, depth); }
+
 inline void EdgeNavStatePVRPointXYZ::computeError() {
-    const plba::Cam c = plba_make_cam(cam);
+    if (_plba_stale && *_plba_stale) plba_sync_chi2(_graph);      // (a later lazy fetch must not overwrite what is computed here)
+    const plba::Cam c = plba_make_cam(*camp);
     double kc[12], e2[2], Jp[12], Jl[6];
     plba::kfcam_make(c, static_cast<const VertexNavStatePVR*>(_vertices[1])->estimate().raw(), kc);
     const Vector3d& P = static_cast<const VertexLMPointXYZ*>(_vertices[0])->estimate();
@@ -1292,9 +1586,11 @@ inline void EdgeNavStatePVRPointXYZ::computeError() {
     _error[0] = e2[0]; _error[1] = e2[1];
     _chi2_cache = _info[0] * (e2[0] * e2[0] + e2[1] * e2[1]);
     _depth_cache = dpos;
+    if (_graph) plba_store_chi2(_graph, _plba_kind, _plba_index, _chi2_cache, dpos);
 }
 inline void EdgeNavStateLine::computeError() {
-    const plba::Cam c = plba_make_cam(cam);
+    if (_plba_stale && *_plba_stale) plba_sync_chi2(_graph);
+    const plba::Cam c = plba_make_cam(*camp);
     double kc[12], e2[2], Jp[12], Jl[6];
     plba::kfcam_make(c, static_cast<const VertexNavStatePVR*>(_vertices[1])->estimate().raw(), kc);
     const Vector6d& L = static_cast<const VertexLine*>(_vertices[0])->estimate();
@@ -1303,9 +1599,12 @@ inline void EdgeNavStateLine::computeError() {
     _error[0] = e2[0]; _error[1] = e2[1]; _error[2] = 0.0;
     _chi2_cache = _info[0] * (e2[0] * e2[0] + e2[1] * e2[1]);
     _depth_cache = dpos;
+    if (_graph) plba_store_chi2(_graph, _plba_kind, _plba_index, _chi2_cache, dpos);
 }
-inline bool EdgeNavStatePVRPointXYZ::_depth_cache_fresh() { return _depth_cache; }
-inline bool EdgeNavStateLine::_depth_cache_fresh() { return _depth_cache; }
+inline bool EdgeNavStatePVRPointXYZ::_depth_cache_fresh() { if (_plba_stale && *_plba_stale) plba_sync_chi2(_graph); return _graph ? plba_cached_depth(_graph, _plba_kind, _plba_index, _depth_cache) : _depth_cache; }
+inline bool EdgeNavStateLine::_depth_cache_fresh() { if (_plba_stale && *_plba_stale) plba_sync_chi2(_graph); return _graph ? plba_cached_depth(_graph, _plba_kind, _plba_index, _depth_cache) : _depth_cache; }
+inline void plba_sync_estimates(SparseOptimizer* g) { if (g) g->syncEstimates(); }
+inline void plba_sync_chi2(SparseOptimizer* g) { if (g) g->syncChi2(); }
 
 }  // namespace g2o
 

@@ -19,6 +19,8 @@ static void put_se3(const SE3Quat& T, double* q, double* t) {
     t[0] = T.rawTranslation().x; t[1] = T.rawTranslation().y; t[2] = T.rawTranslation().z;
 }
 
+template <class S> static void cp(const S& s, double* d) { if (d) for (size_t i = 0; i < s.size(); ++i) d[i] = s[i]; }
+
 extern "C" {
 
 void shim_se3_exp(const double* u6, double* q, double* t) { Vector6d u; for (int i = 0; i < 6; ++i) u[i] = u6[i]; put_se3(SE3Quat::exp(u), q, t); }
@@ -43,7 +45,7 @@ void shim_eval_se3_edge(int kind, const double* cam, const double* q, const doub
                         double* err, double* Jpoint, double* Jpose, int* depth_pos, double* chi2) {
     VertexSE3Expmap pose; pose.setEstimate(make_se3(q, t)); pose.setId(1);
     VertexSBAPointXYZ pt; pt.setEstimate(Vector3d(X[0], X[1], X[2])); pt.setId(0);
-    auto copy = [](const std::vector<double>& s, double* d) { if (d) for (size_t i = 0; i < s.size(); ++i) d[i] = s[i]; };
+    auto copy = [](const auto& s, double* d) { if (d) for (size_t i = 0; i < s.size(); ++i) d[i] = s[i]; };
     Matrix2d I2; I2.setIdentity();
     Matrix3d I3; I3.setIdentity();
     if (kind == 0) {
@@ -119,7 +121,6 @@ void shim_eval_gyrbias(const double* dRbij, const double* JdRbg, const double* R
 
 
 static void put_nav(const NavState& ns, double* out22) { for (int i = 0; i < 22; ++i) out22[i] = ns.raw()[i]; }
-static void cp(const std::vector<double>& s, double* d) { if (d) for (size_t i = 0; i < s.size(); ++i) d[i] = s[i]; }
 
 void shim_navstate_oplus(const double* nav22, const double* u15, double* out22) {
     VertexNavState v; v.setEstimate(make_nav(nav22)); v.oplusImpl(u15); put_nav(v.estimate(), out22);

@@ -37,6 +37,7 @@
 #include <g2o/types/sba/types_six_dof_expmap.h>
 #include "plba_g2o/g2otypes.h"
 
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <string>
@@ -258,6 +259,7 @@ static int pose_graph(const char* in, const char* out, bool ess_graph = false) {
 }
 
 static int local_ba_with_imu(const char* in, const char* out);
+static int local_ba_with_imu_and_marg(const char* in, const char* out, double* laps);
 
 // ---- MapHandler::tryVioInit, the steps between its g2o graphs (src/mapHandler.cpp:4853-4980) ---------------------------------------
 // in: N | dt (N-1) | dP, dV (3 (N-1)) | JPa, JVa (9 (N-1)) | Rc (9 N), pc (3 N) | Rb (9 N), pb (3 N) | Rcb 9, pcb 3
@@ -297,8 +299,37 @@ int main(int argc, char** argv) {
     if (argc >= 4 && !strcmp(argv[1], "vioinit")) return vio_init(argv[2], argv[3]);
     if (argc >= 4 && !strcmp(argv[1], "nomarg")) return local_ba_with_imu(argv[2], argv[3]);
     if (argc >= 4 && !strcmp(argv[1], "lba")) return visual_lba(argv[2], argv[3]);
-    if (argc < 3) { fprintf(stderr, "usage: %s [nomarg|gyrbias|pgo] window.bin result.bin\n", argv[0]); return 2; }
-    FILE* f = fopen(argv[1], "rb");
+    // `time window.bin reps`: one localBundleAdjustmentWithImuAndMarg-shaped call through Boundary 1, `reps` times on fresh optimizers, lap by lap
+    // (VERDICT r04 item 1b): graph construction | optimize(5) + gating loop + optimize(10) | marginalization | write-back | optimizer teardown.
+    if (argc >= 4 && !strcmp(argv[1], "time")) {
+        const int reps = std::max(1, atoi(argv[3]));
+        double best[8] = {1e300, 1e300, 1e300, 1e300, 1e300, 1e300, 1e300, 1e300};
+        for (int r = 0; r < reps; ++r) {
+            double laps[7] = {0, 0, 0, 0, 0, 0, 0};
+            const int rc = local_ba_with_imu_and_marg(argv[2], nullptr, laps);
+            if (rc) return rc;
+            if (r == 0 && reps > 1) continue;      // (the first call pays for module load and first-touch allocations)
+            double tot = 0.0;
+            for (int i = 0; i < 7; ++i) tot += laps[i];
+            if (tot < best[7]) { for (int i = 0; i < 7; ++i) best[i] = laps[i]; best[7] = tot; }
+        }
+        // facade_ba_call_ms: what end_to_end_ba_call_ms covers through the C ABI (upload + 5 + gating + 10 iterations + write-back); the call
+        // site's own loops over its edge objects (gating: chi2() / isDepthPositive() / setLevel / setRobustKernel(0) per edge) are inside it
+        printf("{\"facade_graph_construction_ms\": %.4f, \"facade_optimize5_ms\": %.4f, \"facade_gating_loop_ms\": %.4f, \"facade_optimize10_ms\": %.4f, "
+               "\"facade_marginalize_ms\": %.4f, \"facade_write_back_ms\": %.4f, \"facade_teardown_ms\": %.4f, \"facade_ba_call_ms\": %.4f, "
+               "\"facade_ba_call_with_graph_construction_ms\": %.4f, \"reps\": %d}\n",
+               best[0], best[1], best[2], best[3], best[4], best[5], best[6], best[1] + best[2] + best[3] + best[5],
+               best[0] + best[1] + best[2] + best[3] + best[5] + best[6], reps);
+        return 0;
+    }
+    if (argc < 3) { fprintf(stderr, "usage: %s [nomarg|gyrbias|pgo|time] window.bin result.bin\n", argv[0]); return 2; }
+    return local_ba_with_imu_and_marg(argv[1], argv[2], nullptr);
+}
+
+// ---- MapHandler::localBundleAdjustmentWithImuAndMarg (src/mapHandler.cpp:5741-6254) ---------------------------------------------------
+// laps (optional, ms): [0] graph construction, [1] optimize(5), [2] the gating loop, [3] optimize(10), [4] marginalization, [5] write-back, [6] teardown
+static int local_ba_with_imu_and_marg(const char* in, const char* out, double* laps) {
+    FILE* f = fopen(in, "rb");
     if (!f) { perror("window"); return 2; }
     auto hdr = rd<int32_t>(f, 8);
     const int K = hdr[0], Np = hdr[1], Nl = hdr[2], Ep = hdr[3], El = hdr[4], M = hdr[5], do_marg = hdr[6], max_kf_in_window = hdr[7];
@@ -315,7 +346,14 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 3; ++i) { tbc(i) = Pbcv[i]; for (int j = 0; j < 3; ++j) Rbc(i, j) = Rbcv[i * 3 + j]; }
     const double fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
     bool abortFlag = false;
-
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(tnow() - t).count(); };
+    auto t_lap = tnow();
+    MarginalizationInfo* new_marg_info = new MarginalizationInfo();
+    int gated_pt = 0, gated_ln = 0, maxKFid = 0, maxPointId = 0;
+    double chi2_final = 0.0;
+    std::vector<double> oP(3 * K), oV(3 * K), oq(4 * K), odbg(3 * K), odba(3 * K), opts(3 * (size_t)Np), olns(6 * (size_t)Nl);
+    {      // (scope of the optimizer: its teardown — one delete per edge and vertex — is part of what a call costs the mapping thread)
     g2o::SparseOptimizer optimizer;
     auto linearSolver = g2o::make_unique<SlamLinearSolver>();
     auto blockSolver = g2o::make_unique<g2o::BlockSolverX>(std::move(linearSolver));
@@ -323,7 +361,6 @@ int main(int argc, char** argv) {
     optimizer.setAlgorithm(algorithm);
     optimizer.setForceStopFlag(&abortFlag);
 
-    int maxKFid = 0;
     for (int k = 0; k < K; ++k) {                                   // :5802-5830
         NavState ns;
         ns.Set_Pos(Vector3d(P[3 * k], P[3 * k + 1], P[3 * k + 2])); ns.Set_Vel(Vector3d(V[3 * k], V[3 * k + 1], V[3 * k + 2]));
@@ -363,7 +400,8 @@ int main(int argc, char** argv) {
     }
     std::vector<g2o::EdgeNavStatePVRPointXYZ*> vpEdgesMono;
     std::vector<int> vpFirstObsKf;                                   // kf_obs_list[0] of the edge's map point
-    int maxPointId = maxKFid, e = 0;
+    int e = 0;
+    maxPointId = maxKFid;
     for (int l = 0; l < Np; ++l) {                                  // :5897-5948
         g2o::VertexLMPointXYZ* vPoint = new g2o::VertexLMPointXYZ();
         vPoint->setEstimate(Vector3d(pts[3 * l], pts[3 * l + 1], pts[3 * l + 2]));
@@ -407,9 +445,10 @@ int main(int argc, char** argv) {
             optimizer.addEdge(ed); vlEdgesMono.push_back(ed); vlFirstObsKf.push_back(kf_idx[lo_kf[e0]]);
         }
     }
+    if (laps) { laps[0] = ms_since(t_lap); t_lap = tnow(); }
     optimizer.initializeOptimization();                              // :6038-6039
     optimizer.optimize(5);
-    int gated_pt = 0, gated_ln = 0;
+    if (laps) { laps[1] = ms_since(t_lap); t_lap = tnow(); }
     if (!abortFlag) {                                                // :6047-6069
         for (size_t i = 0; i < vpEdgesMono.size(); i++) {
             g2o::EdgeNavStatePVRPointXYZ* ed = vpEdgesMono[i];
@@ -421,13 +460,14 @@ int main(int argc, char** argv) {
             if (ed->chi2() > 5.991 || !ed->isDepthPositive()) { ed->setLevel(1); ++gated_ln; }
             ed->setRobustKernel(0);
         }
+        if (laps) { laps[2] = ms_since(t_lap); t_lap = tnow(); }
         optimizer.initializeOptimization(0);
         optimizer.optimize(10);
     }
-    const double chi2_final = optimizer.lastStats().chi2_final;
+    chi2_final = optimizer.lastStats().chi2_final;
+    if (laps) { laps[3] = ms_since(t_lap); t_lap = tnow(); }
     // ---- marginalization of the oldest keyframe (:6075-6199) -------------------------------------------------------
     const int NUM = 50;
-    MarginalizationInfo* new_marg_info = new MarginalizationInfo();
     const int first_kf_idx = kf_idx[0];
     if (do_marg && K >= max_kf_in_window) {
         {
@@ -463,8 +503,8 @@ int main(int argc, char** argv) {
         new_marg_info->preMarginalize();
         new_marg_info->marginalizeWithoutThread();
     }
+    if (laps) { laps[4] = ms_since(t_lap); t_lap = tnow(); }
     // ---- write-back (:6202-6239) -----------------------------------------------------------------------------------------
-    std::vector<double> oP(3 * K), oV(3 * K), oq(4 * K), odbg(3 * K), odba(3 * K), opts(3 * (size_t)Np), olns(6 * (size_t)Nl);
     for (int k = 0; k < K; ++k) {
         g2o::VertexNavStatePVR* vNSPVR = static_cast<g2o::VertexNavStatePVR*>(optimizer.vertex(2 * kf_idx[k]));
         g2o::VertexNavStateBias* vNSBias = static_cast<g2o::VertexNavStateBias*>(optimizer.vertex(2 * kf_idx[k] + 1));
@@ -476,7 +516,11 @@ int main(int argc, char** argv) {
     }
     for (int l = 0; l < Np; ++l) { const Vector3d& p = static_cast<g2o::VertexLMPointXYZ*>(optimizer.vertex(l + maxKFid + 1))->estimate(); for (int i = 0; i < 3; ++i) opts[3 * l + i] = p(i); }
     for (int l = 0; l < Nl; ++l) { const Vector6d& p = static_cast<g2o::VertexLine*>(optimizer.vertex(l + maxPointId + 1))->estimate(); for (int i = 0; i < 6; ++i) olns[6 * l + i] = p(i); }
-    FILE* o = fopen(argv[2], "wb");
+    if (laps) { laps[5] = ms_since(t_lap); t_lap = tnow(); }
+    }
+    if (laps) laps[6] = ms_since(t_lap);
+    if (!out) { delete new_marg_info; return 0; }
+    FILE* o = fopen(out, "wb");
     if (!o) { perror("result"); return 2; }
     std::vector<int32_t> oh{gated_pt, gated_ln, new_marg_info->n, new_marg_info->m, (int32_t)new_marg_info->keep_vertex_id.size()};
     wr(o, oh); wr(o, std::vector<double>{chi2_final});
