@@ -203,6 +203,48 @@ int plba_set_robust(plba_problem* p, plba_edge_kind kind, int enabled, double hu
 int plba_set_levels(plba_problem* p, plba_edge_kind kind, const uint8_t* level);
 int plba_get_levels(plba_problem* p, plba_edge_kind kind, uint8_t* level);
 
+/* ---- sliding window --------------------------------------------------------------------------------------------------
+ * The mapping thread runs one local BA per new keyframe on a window that differs from the previous one by addKeyframeToSW /
+ * deleteKeyframeInSW (src/mapHandler.cpp:1178-1221, 4815-4825): the oldest keyframe(s) leave, one arrives, and the local map is
+ * "every landmark whose FIRST observation lies inside the window" (:5769-5783), so the landmarks first seen from a leaving
+ * keyframe leave with it and every other landmark keeps all of its observations.  plba_slide_window edits the uploaded window
+ * in place instead of setting every array again:
+ *   - the n_drop oldest keyframes (indices 0 .. n_drop-1) leave, with every landmark that has an observation from one of them
+ *     and every IMU edge that touches one of them; further landmarks / observations may be dropped by mask (the map's
+ *     removeBadMapLandmarks and the culling of :5541-5620 between two BA calls);
+ *   - the KEPT keyframes and landmarks keep the estimates the DEVICE holds — the previous plba_optimize's result, i.e. what
+ *     the reference writes back to the map (:6202-6239) and reads again when it builds the next graph; nothing of them
+ *     crosses PCIe;
+ *   - K_add keyframes, Np_add / Nl_add landmarks, M_add IMU edges and Ep_add / El_add observations are appended.  Keyframe
+ *     indices (po_kf, lo_kf, imu_kf_i / _j) are those AFTER the slide (old index - n_drop; the added keyframes follow).
+ *     Landmark indices of the added observations are those BEFORE the slide for landmarks that stay (they must stay) and
+ *     Np_before + i / Nl_before + i for the i-th added one; both lists sorted by that index.  A kept landmark's new
+ *     observations are listed after its old ones, as the reference's kf_obs_list grows.
+ *   - all edges are level 0 again and the prior is kept as set: call plba_set_prior for the new window's prior (or clear it).
+ * point_map[Np_before] / line_map[Nl_before] (optional) receive each old landmark's new index or -1.  The structure the next
+ * plba_optimize builds — and therefore every result, bit for bit — is that of a fresh handle given the same window through
+ * plba_set_* (tests/test_slide_window.py).  One GPU only (a sharded problem takes a fresh upload). */
+typedef struct {
+    int n_drop;
+    const uint8_t* drop_point;      /* [Np_before] 1 = leaves too; may be NULL */
+    const uint8_t* drop_line;       /* [Nl_before] */
+    const uint8_t* drop_point_obs;  /* [Ep_before] 1 = this observation leaves (its landmark may stay); may be NULL */
+    const uint8_t* drop_line_obs;   /* [El_before] */
+    int K_add;                      /* appended keyframes: arrays as in plba_set_keyframes */
+    const int32_t* vid_pvr; const int32_t* vid_bias;
+    const double *P3, *V3, *q_xyzw4, *bg3, *ba3, *dbg3, *dba3;
+    const uint8_t* fixed_pvr;       /* [K_after] fixed flags of the WHOLE new window (the new oldest keyframe becomes fixed, */
+    const uint8_t* fixed_bias;      /*           :5812-5825); NULL = kept keyframes keep theirs, added ones are free          */
+    int M_add;                      /* appended IMU edges: arrays as in plba_set_imu_edges */
+    const int32_t *imu_kf_i, *imu_kf_j;
+    const double *preint142, *info_pvr81, *info_bias36;
+    int Np_add; const double* xyz3; const uint8_t* point_fixed;
+    int Nl_add; const double* sPeP6; const uint8_t* line_fixed;
+    int Ep_add; const int32_t* po_pt; const int32_t* po_kf; const double* uv2; const double* po_inv_sigma2;
+    int El_add; const int32_t* lo_ln; const int32_t* lo_kf; const double* l3; const double* lo_inv_sigma2;
+} plba_slide;
+int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, int32_t* line_map);
+
 /* ---- multi-GPU: this problem holds a landmark shard; pose-side edges are added by rank 0 only */
 int plba_set_shard(plba_problem* p, int rank, int world, plba_allreduce_fn fn, void* user);
 int plba_set_stream(plba_problem* p, void* hip_stream);           /* run on a caller stream (e.g. torch's) */

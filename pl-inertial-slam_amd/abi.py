@@ -56,9 +56,26 @@ class LbaStats(C.Structure):
                 ("lam", C.c_double), ("solver_failed", C.c_int), ("reserved", C.c_int)]
 
 
+class Slide(C.Structure):
+    """plba_slide of include/plba.h"""
+    _fields_ = [("n_drop", C.c_int), ("drop_point", c_uint8_p), ("drop_line", c_uint8_p), ("drop_point_obs", c_uint8_p), ("drop_line_obs", c_uint8_p),
+                ("K_add", C.c_int), ("vid_pvr", c_int32_p), ("vid_bias", c_int32_p),
+                ("P3", c_double_p), ("V3", c_double_p), ("q_xyzw4", c_double_p), ("bg3", c_double_p), ("ba3", c_double_p), ("dbg3", c_double_p), ("dba3", c_double_p),
+                ("fixed_pvr", c_uint8_p), ("fixed_bias", c_uint8_p),
+                ("M_add", C.c_int), ("imu_kf_i", c_int32_p), ("imu_kf_j", c_int32_p), ("preint142", c_double_p), ("info_pvr81", c_double_p), ("info_bias36", c_double_p),
+                ("Np_add", C.c_int), ("xyz3", c_double_p), ("point_fixed", c_uint8_p),
+                ("Nl_add", C.c_int), ("sPeP6", c_double_p), ("line_fixed", c_uint8_p),
+                ("Ep_add", C.c_int), ("po_pt", c_int32_p), ("po_kf", c_int32_p), ("uv2", c_double_p), ("po_inv_sigma2", c_double_p),
+                ("El_add", C.c_int), ("lo_ln", c_int32_p), ("lo_kf", c_int32_p), ("l3", c_double_p), ("lo_inv_sigma2", c_double_p)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 _P = C.c_void_p  # plba_problem*
+
+# entry points of the product that have no counterpart in the reference's algorithm (memory management of the device-resident window): the
+# CPU oracle — a restatement of the reference — does not implement them
+PRODUCT_ONLY = {"slide_window"}
 
 # name -> (restype, argtypes); every symbol plba.h declares
 SIGNATURES = {
@@ -79,6 +96,7 @@ SIGNATURES = {
     "set_robust": (C.c_int, [_P, C.c_int, C.c_int, C.c_double]),
     "set_levels": (C.c_int, [_P, C.c_int, c_uint8_p]),
     "get_levels": (C.c_int, [_P, C.c_int, c_uint8_p]),
+    "slide_window": (C.c_int, [_P, C.POINTER(Slide), c_int32_p, c_int32_p]),
     "set_shard": (C.c_int, [_P, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]),
     "set_stream": (C.c_int, [_P, C.c_void_p]),
     "optimize": (C.c_int, [_P, C.c_int, c_uint8_p, C.POINTER(Stats)]),
@@ -160,6 +178,7 @@ class Lib:
             f.restype = res
             f.argtypes = args
             self.fn[name] = f
+        missing = [m for m in missing if not (prefix != "plba_" and m[len(prefix):] in PRODUCT_ONLY)]
         if missing and not optional:      # (optional: a library that implements a subset — the quad-precision oracle build, oracle/make_quad.py)
             raise PlbaError("%s does not export: %s" % (self.path, ", ".join(missing)))
 
@@ -244,17 +263,20 @@ class Problem:
         pt, kf, uv, w = _i32(pt), _i32(kf), _f64(uv, (-1, 2)), _f64(inv_sigma2)
         self.call("set_point_obs", len(pt), _ip(pt), _ip(kf), _dp(uv), _dp(w))
         self.dims["Ep"] = len(pt)
+        self._po = (pt.copy(), kf.copy())      # (landmark / keyframe of every observation: slide_window keeps the counts in step with the library's merge)
 
     def set_line_obs(self, ln, kf, l3, inv_sigma2=None):
         ln, kf, l3, w = _i32(ln), _i32(kf), _f64(l3, (-1, 3)), _f64(inv_sigma2)
         self.call("set_line_obs", len(ln), _ip(ln), _ip(kf), _dp(l3), _dp(w))
         self.dims["El"] = len(ln)
+        self._lo = (ln.copy(), kf.copy())
 
     def set_imu_edges(self, kf_i, kf_j, preint142, info_pvr, info_bias):
         ki, kj = _i32(kf_i), _i32(kf_j)
         pre, ip, ib = _f64(preint142, (-1, 142)), _f64(info_pvr, (-1, 81)), _f64(info_bias, (-1, 36))
         self.call("set_imu_edges", len(ki), _ip(ki), _ip(kj), _dp(pre), _dp(ip), _dp(ib))
         self.dims["M"] = len(ki)
+        self._imu = (ki.copy(), kj.copy())
 
     def set_prior(self, prior):
         """prior: dict(n, vid, size, idx, x0, J0 (n x n, J0[r, c]), r0) or None to clear."""
@@ -445,6 +467,78 @@ class Problem:
         self.call("preintegrate", M, ss.ctypes.data_as(c_int32_p), lp(t), _dp(gyr), _dp(acc), lp(t_prev), lp(t_curr), _dp(bg), _dp(ba),
                   float(gyr_meas_cov), float(acc_meas_cov), _dp(out))
         return out
+
+    def slide_window(self, d):
+        """plba_slide_window: `d` as window.slide_delta() makes it — n_drop, the appended keyframes / IMU edges / landmarks / observations,
+        optional drop masks and the new window's fixed flags.  Returns (point_map, line_map): each old landmark's new index or -1."""
+        keep = []      # the arrays behind the struct's pointers stay alive until the call returns
+
+        def f64(a, shape=None):
+            if a is None:
+                return None
+            a = _f64(a, shape); keep.append(a); return _dp(a)
+
+        def i32(a):
+            if a is None:
+                return None
+            a = _i32(a); keep.append(a); return _ip(a)
+
+        def u8(a):
+            if a is None:
+                return None
+            a = _u8(a); keep.append(a); return _up(a)
+        s = Slide()
+        s.n_drop = int(d.get("n_drop", 0))
+        s.drop_point, s.drop_line = u8(d.get("drop_point")), u8(d.get("drop_line"))
+        s.drop_point_obs, s.drop_line_obs = u8(d.get("drop_point_obs")), u8(d.get("drop_line_obs"))
+        k = d.get("kf")
+        s.K_add = 0 if k is None else len(k["vid_pvr"])
+        if k is not None:
+            s.vid_pvr, s.vid_bias = i32(k["vid_pvr"]), i32(k.get("vid_bias"))
+            s.P3, s.V3, s.q_xyzw4 = f64(k["P"]), f64(k["V"]), f64(k["q"])
+            s.bg3, s.ba3, s.dbg3, s.dba3 = f64(k.get("bg")), f64(k.get("ba")), f64(k.get("dbg")), f64(k.get("dba"))
+        s.fixed_pvr, s.fixed_bias = u8(d.get("fixed_pvr")), u8(d.get("fixed_bias"))
+        im = d.get("imu")
+        s.M_add = 0 if im is None else len(im["kf_i"])
+        if im is not None:
+            s.imu_kf_i, s.imu_kf_j = i32(im["kf_i"]), i32(im["kf_j"])
+            s.preint142, s.info_pvr81, s.info_bias36 = f64(im["preint"], (-1, 142)), f64(im["info_pvr"], (-1, 81)), f64(im["info_bias"], (-1, 36))
+        pts, lns = d.get("points"), d.get("lines")
+        s.Np_add = 0 if pts is None else len(pts); s.xyz3 = f64(pts, (-1, 3)) if s.Np_add else None; s.point_fixed = u8(d.get("point_fixed"))
+        s.Nl_add = 0 if lns is None else len(lns); s.sPeP6 = f64(lns, (-1, 6)) if s.Nl_add else None; s.line_fixed = u8(d.get("line_fixed"))
+        s.Ep_add = len(d["po_pt"]) if d.get("po_pt") is not None else 0
+        if s.Ep_add:
+            s.po_pt, s.po_kf, s.uv2, s.po_inv_sigma2 = i32(d["po_pt"]), i32(d["po_kf"]), f64(d["po_uv"], (-1, 2)), f64(d.get("po_w"))
+        s.El_add = len(d["lo_ln"]) if d.get("lo_ln") is not None else 0
+        if s.El_add:
+            s.lo_ln, s.lo_kf, s.l3, s.lo_inv_sigma2 = i32(d["lo_ln"]), i32(d["lo_kf"]), f64(d["lo_l"], (-1, 3)), f64(d.get("lo_w"))
+        pm = np.zeros(max(self.dims.get("Np", 0), 1), np.int32); lm = np.zeros(max(self.dims.get("Nl", 0), 1), np.int32)
+        self.call("slide_window", C.byref(s), _ip(pm), _ip(lm))
+        Np0, Nl0 = self.dims.get("Np", 0), self.dims.get("Nl", 0)
+        pm, lm = pm[:Np0].copy(), lm[:Nl0].copy()
+        # the Python-side image of the observation lists (counts for the getters), merged as the library merges them
+        def merged(old, n0, mp, add_lm, add_kf, drop_obs):
+            lm0, kf0 = old
+            keep = mp[lm0] >= 0 if len(lm0) else np.zeros(0, bool)
+            if drop_obs is not None:
+                keep &= ~np.asarray(drop_obs, bool)
+            nkept = int((mp >= 0).sum())
+            a_lm = np.asarray(add_lm if add_lm is not None else [], np.int64)
+            a_new = np.where(a_lm < n0, mp[np.minimum(a_lm, max(n0 - 1, 0))] if n0 else 0, nkept + (a_lm - n0))
+            allm = np.concatenate([mp[lm0[keep]] if len(lm0) else np.zeros(0, np.int64), a_new]).astype(np.int64)
+            allk = np.concatenate([kf0[keep] - s.n_drop if len(kf0) else np.zeros(0, np.int64), np.asarray(add_kf if add_kf is not None else [], np.int64)])
+            o = np.argsort(allm, kind="stable")
+            return allm[o].astype(np.int32), allk[o].astype(np.int32)
+        self._po = merged(getattr(self, "_po", (np.zeros(0, np.int32),) * 2), Np0, pm, d.get("po_pt"), d.get("po_kf"), d.get("drop_point_obs"))
+        self._lo = merged(getattr(self, "_lo", (np.zeros(0, np.int32),) * 2), Nl0, lm, d.get("lo_ln"), d.get("lo_kf"), d.get("drop_line_obs"))
+        ki, kj = getattr(self, "_imu", (np.zeros(0, np.int32),) * 2)
+        kept = (ki >= s.n_drop) & (kj >= s.n_drop)
+        self._imu = (np.concatenate([ki[kept] - s.n_drop, np.asarray(im["kf_i"], np.int32) if im is not None else np.zeros(0, np.int32)]).astype(np.int32),
+                     np.concatenate([kj[kept] - s.n_drop, np.asarray(im["kf_j"], np.int32) if im is not None else np.zeros(0, np.int32)]).astype(np.int32))
+        self.dims["K"] = self.dims["K"] - s.n_drop + s.K_add
+        self.dims["Np"] = int((pm >= 0).sum()) + s.Np_add; self.dims["Nl"] = int((lm >= 0).sum()) + s.Nl_add
+        self.dims["Ep"], self.dims["El"], self.dims["M"] = len(self._po[0]), len(self._lo[0]), len(self._imu[0])
+        return pm, lm
 
     # -- convenience -------------------------------------------------------------------------
     def upload_window(self, w):

@@ -203,6 +203,7 @@ int plba_set_points(plba_problem* p, int Np, const double* xyz, const uint8_t* f
     if (!all_finite(xyz, 3 * (size_t)Np)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite point");
     p->Np = Np;
     p->pts.assign(xyz, xyz + 3 * (size_t)Np);
+    p->carry_pts = false;
     p->pt_fixed.assign(Np, 0);
     if (fixed) p->pt_fixed.assign(fixed, fixed + Np);
     p->dirty = true;
@@ -213,6 +214,7 @@ int plba_set_lines(plba_problem* p, int Nl, const double* l, const uint8_t* fixe
     if (!all_finite(l, 6 * (size_t)Nl)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite line");
     p->Nl = Nl;
     p->lns.assign(l, l + 6 * (size_t)Nl);
+    p->carry_lns = false;
     p->ln_fixed.assign(Nl, 0);
     if (fixed) p->ln_fixed.assign(fixed, fixed + Nl);
     p->dirty = true;
@@ -813,10 +815,17 @@ static int prepare(plba_problem* p) {
         for (int k = 0; k < K; ++k) cntk[k + 1] += cntk[k];
         for (int e = 0; e < E; ++e) { p->ob_pos[e] = cntk[ob_kf[e]]; cntk[ob_kf[e]] += (e < Ep) ? 1 : 2; }
     }
-    p->lm0.assign((size_t)L * 6, 0.0);
+    // (a slid window's landmark estimates stay on the device: plba_slide_window left them in d_lm_carry, and the host copy is not formed)
+    const bool carry_all = (p->carry_pts || Np == 0) && (p->carry_lns || Nl == 0) && (p->carry_pts || p->carry_lns) && p->d_lm_carry.p && p->d_lm_carry.n >= (size_t)L * 6;
+    if ((p->carry_pts || p->carry_lns) && !carry_all) FAIL(p, PLBA_ERR_STATE, "after plba_slide_window set BOTH landmark arrays again (plba_set_points and plba_set_lines) or neither: the kept estimates live on the device");
     p->lm_fixed.assign(L, 0);
-    for (int i = 0; i < Np; ++i) { memcpy(&p->lm0[(size_t)i * 6], &p->pts[(size_t)i * 3], 24); p->lm_fixed[i] = p->pt_fixed[i]; }
-    for (int i = 0; i < Nl; ++i) { memcpy(&p->lm0[(size_t)(Np + i) * 6], &p->lns[(size_t)i * 6], 48); p->lm_fixed[Np + i] = p->ln_fixed[i]; }
+    if (!carry_all) {
+        p->lm0.assign((size_t)L * 6, 0.0);
+        for (int i = 0; i < Np; ++i) memcpy(&p->lm0[(size_t)i * 6], &p->pts[(size_t)i * 3], 24);
+        for (int i = 0; i < Nl; ++i) memcpy(&p->lm0[(size_t)(Np + i) * 6], &p->lns[(size_t)i * 6], 48);
+    }
+    for (int i = 0; i < Np; ++i) p->lm_fixed[i] = p->pt_fixed[i];
+    for (int i = 0; i < Nl; ++i) p->lm_fixed[Np + i] = p->ln_fixed[i];
     lap("index maps, slots");
     if (!p->ctx.lm_host) p->ctx.lm_host = new LmHost;      // (stays with the cached context)
     LmHost& LH = *p->ctx.lm_host;
@@ -938,12 +947,18 @@ static int prepare(plba_problem* p) {
     const size_t sysn = (size_t)(p->Ppad + TILE) * p->ld;
     HIPCK(p, p->d_kf[0].upload(p->kf0)); HIPCK(p, p->d_kf[1].upload(p->kf0)); HIPCK(p, p->d_kf_saved.upload(p->kf0));
     // the landmarks' three images (current, trial, saved): one pass through the staging area, two copies on the device (1.2 MB each at configs[2])
+    if (carry_all) {
+        const size_t nlm = std::max<size_t>((size_t)L * 6, 1);
+        HIPCK(p, p->d_lm[0].alloc(nlm, false)); HIPCK(p, p->d_lm[1].alloc(nlm, false)); HIPCK(p, p->d_lm_saved.alloc(nlm, false));
+        for (double* dst : {p->d_lm[0].p, p->d_lm[1].p, p->d_lm_saved.p}) if (L) HIPCK(p, hipMemcpyAsync(dst, p->d_lm_carry.p, (size_t)L * 48, hipMemcpyDeviceToDevice, p->stream));
+    } else {
     HIPCK(p, p->d_lm[0].upload(p->lm0));
     if (p->lm0.size() * 8 <= DevBatch::SMALL) { HIPCK(p, p->d_lm[1].upload(p->lm0)); HIPCK(p, p->d_lm_saved.upload(p->lm0)); }
     else {
         HIPCK(p, p->d_lm[1].alloc(p->lm0.size(), false)); HIPCK(p, p->d_lm_saved.alloc(p->lm0.size(), false));
         HIPCK(p, hipMemcpyAsync(p->d_lm[1].p, p->d_lm[0].p, p->lm0.size() * 8, hipMemcpyDeviceToDevice, p->stream));
         HIPCK(p, hipMemcpyAsync(p->d_lm_saved.p, p->d_lm[0].p, p->lm0.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+    }
     }
     HIPCK(p, p->d_po_uv.upload(p->po_uv)); HIPCK(p, p->d_lo_l.upload(p->lo_l)); HIPCK(p, p->d_ob_w.upload(ob_w));
     HIPCK(p, p->d_ob_kf.upload(ob_kf)); HIPCK(p, p->d_ob_slot.upload(ob_slot)); HIPCK(p, p->d_lm_start.upload(lm_start));
@@ -2298,6 +2313,181 @@ int plba_restore_state(plba_problem* p) {
     ++p->state_epoch;
     HIPCK(p, hipMemcpyAsync(p->dv.kf[p->cur], p->d_kf_saved.p, (size_t)p->K * KF_STRIDE * 8, hipMemcpyDeviceToDevice, p->stream));
     if (p->L) HIPCK(p, hipMemcpyAsync(p->dv.lm[p->cur], p->d_lm_saved.p, (size_t)p->L * 6 * 8, hipMemcpyDeviceToDevice, p->stream));
+    return PLBA_OK;
+}
+
+// ---- plba_slide_window (include/plba.h) ----------------------------------------------------------------------------------------------
+// new landmark array = kept slots gathered from the current estimates | added slots from the upload (src < 0: -(1 + index into `add`))
+__global__ void k_lm_carry_gather(const double* __restrict__ cur, const double* __restrict__ add, const int32_t* __restrict__ src, int Np_new, int L_new, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L_new * 6) return;
+    const int slot = i / 6, c = i % 6, sidx = src[slot];
+    double v = sidx >= 0 ? cur[(size_t)sidx * 6 + c] : add[(size_t)(-1 - sidx) * 6 + c];
+    if (slot < Np_new && c >= 3) v = 0.0;      // (a point uses the first half of its slot)
+    out[i] = v;
+}
+int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, int32_t* line_map) {
+    if (!p || !s) return PLBA_ERR_INVALID;
+    if (p->world > 1) FAIL(p, PLBA_ERR_STATE, "plba_slide_window: a sharded problem takes a fresh upload");
+    if (p->dirty || !p->K) FAIL(p, PLBA_ERR_STATE, "plba_slide_window: no window is resident on the device (upload one and optimize it first)");
+    const int K0 = p->K, Np0 = p->Np, Nl0 = p->Nl, Ep0 = p->Ep, El0 = p->El, M0 = p->M, nd = s->n_drop;
+    if (nd < 0 || nd >= K0 || s->K_add < 0 || s->M_add < 0 || s->Np_add < 0 || s->Nl_add < 0 || s->Ep_add < 0 || s->El_add < 0) FAIL(p, PLBA_ERR_INVALID, "plba_slide_window: counts out of range (n_drop %d of %d keyframes)", nd, K0);
+    const int K1 = K0 - nd + s->K_add;
+    if (s->K_add && (!s->vid_pvr || !s->P3 || !s->V3 || !s->q_xyzw4)) return PLBA_ERR_INVALID;
+    if ((s->M_add && (!s->imu_kf_i || !s->imu_kf_j || !s->preint142 || !s->info_pvr81 || !s->info_bias36)) || (s->Np_add && !s->xyz3) || (s->Nl_add && !s->sPeP6) ||
+        (s->Ep_add && (!s->po_pt || !s->po_kf || !s->uv2)) || (s->El_add && (!s->lo_ln || !s->lo_kf || !s->l3))) return PLBA_ERR_INVALID;
+    for (int k = 0; k < s->K_add; ++k) {
+        const int prev = k ? s->vid_pvr[k - 1] : p->vid_pvr[K0 - 1];
+        if (s->vid_pvr[k] <= prev) FAIL(p, PLBA_ERR_INVALID, "keyframe vertex ids must be ascending");
+    }
+    if (!all_finite(s->P3, 3 * (size_t)s->K_add) || !all_finite(s->V3, 3 * (size_t)s->K_add) || !all_finite(s->q_xyzw4, 4 * (size_t)s->K_add)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite keyframe state");
+    if (!all_finite(s->xyz3, 3 * (size_t)s->Np_add) || !all_finite(s->sPeP6, 6 * (size_t)s->Nl_add) || !all_finite(s->uv2, 2 * (size_t)s->Ep_add) || !all_finite(s->l3, 3 * (size_t)s->El_add)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite landmark or observation");
+    if (!all_finite(s->preint142, 142 * (size_t)s->M_add) || !all_finite(s->info_pvr81, 81 * (size_t)s->M_add)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite IMU edge");
+    HIPCK(p, hipSetDevice(p->device));
+    // ---- which landmarks / observations stay -------------------------------------------------------------------------------------
+    std::vector<int32_t> pmap(Np0), lmap(Nl0);
+    std::vector<uint8_t> pdrop(Np0, 0), ldrop(Nl0, 0);
+    if (s->drop_point) for (int i = 0; i < Np0; ++i) pdrop[i] = s->drop_point[i] != 0;
+    if (s->drop_line) for (int i = 0; i < Nl0; ++i) ldrop[i] = s->drop_line[i] != 0;
+    for (int e = 0; e < Ep0; ++e) if (p->po_kf[e] < nd) pdrop[p->po_pt[e]] = 1;
+    for (int e = 0; e < El0; ++e) if (p->lo_kf[e] < nd) ldrop[p->lo_ln[e]] = 1;
+    int Np1 = 0, Nl1 = 0;
+    for (int i = 0; i < Np0; ++i) pmap[i] = pdrop[i] ? -1 : Np1++;
+    for (int i = 0; i < Nl0; ++i) lmap[i] = ldrop[i] ? -1 : Nl1++;
+    const int Npk = Np1, Nlk = Nl1;      // kept
+    Np1 += s->Np_add; Nl1 += s->Nl_add;
+    // added observations: landmark index before the slide (must stay) or N_before + i; keyframes in the new numbering
+    auto check_add = [&](int E, const int32_t* lm, const int32_t* kf, int N0, int Nadd, const std::vector<int32_t>& map, const char* what) -> int {
+        for (int e = 0; e < E; ++e) {
+            if (lm[e] < 0 || lm[e] >= N0 + Nadd) FAIL(p, PLBA_ERR_INVALID, "added %s observation %d: landmark index %d out of range", what, e, lm[e]);
+            if (lm[e] < N0 && map[lm[e]] < 0) FAIL(p, PLBA_ERR_INVALID, "added %s observation %d: landmark %d leaves the window with this slide", what, e, lm[e]);
+            if (kf[e] < 0 || kf[e] >= K1) FAIL(p, PLBA_ERR_INVALID, "added %s observation %d: keyframe index %d out of range (new numbering, %d keyframes)", what, e, kf[e], K1);
+            if (e && lm[e] < lm[e - 1]) FAIL(p, PLBA_ERR_INVALID, "added %s observations must be sorted by landmark", what);
+        }
+        return PLBA_OK;
+    };
+    if (int rc = check_add(s->Ep_add, s->po_pt, s->po_kf, Np0, s->Np_add, pmap, "point")) return rc;
+    if (int rc = check_add(s->El_add, s->lo_ln, s->lo_kf, Nl0, s->Nl_add, lmap, "line")) return rc;
+    for (int m = 0; m < s->M_add; ++m) if (s->imu_kf_i[m] < 0 || s->imu_kf_i[m] >= K1 || s->imu_kf_j[m] < 0 || s->imu_kf_j[m] >= K1) FAIL(p, PLBA_ERR_INVALID, "added imu edge %d: keyframe index (new numbering)", m);
+    // ---- host copy of the graph: observations compacted, shifted and merged landmark by landmark (into temporaries: nothing of the problem
+    // is touched before every check has passed) ----------------------------------------------------------------------------------------
+    struct ObsList { std::vector<int32_t> lm, kf; std::vector<double> meas, w; };
+    auto merge = [&](int N0, int Nadd, int E0, int Eadd, const std::vector<int32_t>& map, const std::vector<int32_t>& ob_lm, const std::vector<int32_t>& ob_kf, const std::vector<double>& meas, int nm,
+                     const std::vector<double>& wt, const uint8_t* drop_obs, const int32_t* a_lm, const int32_t* a_kf, const double* a_meas, const double* a_w, ObsList& out) -> int {
+        out.lm.reserve((size_t)E0 + Eadd); out.kf.reserve((size_t)E0 + Eadd); out.meas.reserve(((size_t)E0 + Eadd) * nm); out.w.reserve((size_t)E0 + Eadd);
+        int e = 0, a = 0, kept = 0;
+        for (int l = 0; l < N0 + Nadd; ++l) {
+            const int nl = l < N0 ? map[l] : kept + (l - N0);      // (survivors precede the added landmarks: `kept` is final when l reaches N0)
+            if (l < N0 && nl >= 0) ++kept;
+            for (; e < E0 && ob_lm[e] == l; ++e) {
+                if (nl < 0 || (drop_obs && drop_obs[e])) continue;
+                out.lm.push_back(nl); out.kf.push_back(ob_kf[e] - nd);
+                for (int c = 0; c < nm; ++c) out.meas.push_back(meas[(size_t)e * nm + c]);
+                out.w.push_back(wt[e]);
+            }
+            for (; a < Eadd && a_lm[a] == l; ++a) {
+                out.lm.push_back(nl); out.kf.push_back(a_kf[a]);
+                for (int c = 0; c < nm; ++c) out.meas.push_back(a_meas[(size_t)a * nm + c]);
+                out.w.push_back(a_w ? (double)(float)a_w[a] : 1.0);      // const float& invSigma2 (mapHandler.cpp:5340)
+            }
+        }
+        // two observations of one landmark from one keyframe are refused, as at upload
+        for (size_t x = 0; x < out.lm.size(); ++x)
+            for (size_t y = x + 1; y < out.lm.size() && out.lm[y] == out.lm[x]; ++y)
+                if (out.kf[y] == out.kf[x]) FAIL(p, PLBA_ERR_INVALID, "landmark %d observed twice by keyframe %d", out.lm[x], out.kf[x]);
+        return PLBA_OK;
+    };
+    ObsList npo, nlo;
+    if (int rc = merge(Np0, s->Np_add, Ep0, s->Ep_add, pmap, p->po_pt, p->po_kf, p->po_uv, 2, p->po_w, s->drop_point_obs, s->po_pt, s->po_kf, s->uv2, s->po_inv_sigma2, npo)) return rc;
+    if (int rc = merge(Nl0, s->Nl_add, El0, s->El_add, lmap, p->lo_ln, p->lo_kf, p->lo_l, 3, p->lo_w, s->drop_line_obs, s->lo_ln, s->lo_kf, s->l3, s->lo_inv_sigma2, nlo)) return rc;
+    for (int m = 0; m < s->M_add; ++m) {      // bias vertices of the added edges' keyframes (new numbering: kept ones shifted, added ones from the call)
+        for (int kk : {s->imu_kf_i[m], s->imu_kf_j[m]}) {
+            const int vb = kk < K0 - nd ? p->vid_bias[kk + nd] : (s->vid_bias ? s->vid_bias[kk - (K0 - nd)] : -1);
+            if (vb < 0) FAIL(p, PLBA_ERR_INVALID, "added imu edge %d: keyframe without bias vertex", m);
+        }
+    }
+    // ---- keyframes: the kept ones' current estimates come back from the device (K x 24 doubles), the added ones follow ----------------
+    HIPCK(p, plba_stream_wait(p->stream));
+    {
+        std::vector<double> cur((size_t)K0 * KF_STRIDE);
+        HIPCK(p, plba_d2h(p, cur.data(), p->dv.kf[p->cur], cur.size() * 8));
+        std::vector<double> kf1((size_t)K1 * KF_STRIDE, 0.0);
+        std::vector<int32_t> vp(K1), vb(K1, -1);
+        std::vector<uint8_t> fp(K1, 0), fb(K1, 0);
+        for (int k = nd; k < K0; ++k) {
+            memcpy(&kf1[(size_t)(k - nd) * KF_STRIDE], &cur[(size_t)k * KF_STRIDE], KF_STRIDE * 8);
+            vp[k - nd] = p->vid_pvr[k]; vb[k - nd] = p->vid_bias[k]; fp[k - nd] = p->fix_pvr[k]; fb[k - nd] = p->fix_bias[k];
+        }
+        for (int k = 0; k < s->K_add; ++k) {
+            double* o = &kf1[(size_t)(K0 - nd + k) * KF_STRIDE];
+            memcpy(o, s->P3 + 3 * k, 24); memcpy(o + 3, s->V3 + 3 * k, 24); memcpy(o + 6, s->q_xyzw4 + 4 * k, 32);
+            if (s->bg3) memcpy(o + 10, s->bg3 + 3 * k, 24);
+            if (s->ba3) memcpy(o + 13, s->ba3 + 3 * k, 24);
+            if (s->dbg3) memcpy(o + 16, s->dbg3 + 3 * k, 24);
+            if (s->dba3) memcpy(o + 19, s->dba3 + 3 * k, 24);
+            vp[K0 - nd + k] = s->vid_pvr[k]; vb[K0 - nd + k] = s->vid_bias ? s->vid_bias[k] : -1;
+        }
+        if (s->fixed_pvr) for (int k = 0; k < K1; ++k) fp[k] = s->fixed_pvr[k];
+        if (s->fixed_bias) for (int k = 0; k < K1; ++k) fb[k] = s->fixed_bias[k];
+        p->kf0.swap(kf1); p->vid_pvr.swap(vp); p->vid_bias.swap(vb); p->fix_pvr.swap(fp); p->fix_bias.swap(fb);
+    }
+    // ---- landmarks: the new array is gathered ON THE DEVICE from the current estimates; only the added ones go up ----------------------------
+    {
+        const int L1 = Np1 + Nl1;
+        std::vector<int32_t> src(std::max(L1, 1), 0);
+        for (int i = 0; i < Np0; ++i) if (pmap[i] >= 0) src[pmap[i]] = i;
+        for (int i = 0; i < s->Np_add; ++i) src[Npk + i] = -(1 + i);
+        for (int i = 0; i < Nl0; ++i) if (lmap[i] >= 0) src[Np1 + lmap[i]] = Np0 + i;
+        for (int i = 0; i < s->Nl_add; ++i) src[Np1 + Nlk + i] = -(1 + s->Np_add + i);
+        std::vector<double> add((size_t)std::max(s->Np_add + s->Nl_add, 1) * 6, 0.0);
+        for (int i = 0; i < s->Np_add; ++i) memcpy(&add[(size_t)i * 6], s->xyz3 + 3 * (size_t)i, 24);
+        for (int i = 0; i < s->Nl_add; ++i) memcpy(&add[(size_t)(s->Np_add + i) * 6], s->sPeP6 + 6 * (size_t)i, 48);
+        DArrStreamScope staged(p->stream, p->have_ctx ? p->ctx.stage : nullptr);
+        DArr<double> dadd;
+        HIPCK(p, p->d_lm_carry_src.upload(src)); HIPCK(p, dadd.upload(add));
+        HIPCK(p, p->d_lm_carry.alloc(std::max<size_t>((size_t)L1 * 6, 1), false));
+        if (L1) hipLaunchKernelGGL(k_lm_carry_gather, dim3((L1 * 6 + 255) / 256), dim3(256), 0, p->stream, p->dv.lm[p->cur], dadd.p, p->d_lm_carry_src.p, Np1, L1, p->d_lm_carry.p);
+        HIPCK(p, hipGetLastError());
+        HIPCK(p, plba_stream_wait(p->stream));      // (`src` / `add` / `dadd` end here)
+        p->carry_pts = true; p->carry_lns = true;
+    }
+    p->po_pt.swap(npo.lm); p->po_kf.swap(npo.kf); p->po_uv.swap(npo.meas); p->po_w.swap(npo.w);
+    p->lo_ln.swap(nlo.lm); p->lo_kf.swap(nlo.kf); p->lo_l.swap(nlo.meas); p->lo_w.swap(nlo.w);
+    p->Ep = (int)p->po_pt.size(); p->El = (int)p->lo_ln.size();
+    // fixed flags and the (stale for kept entries: carry_*) estimate arrays follow the new numbering
+    {
+        std::vector<uint8_t> pf(Np1, 0), lf(Nl1, 0);
+        for (int i = 0; i < Np0; ++i) if (pmap[i] >= 0) pf[pmap[i]] = p->pt_fixed[i];
+        for (int i = 0; i < s->Np_add; ++i) pf[Npk + i] = s->point_fixed ? s->point_fixed[i] : 0;
+        for (int i = 0; i < Nl0; ++i) if (lmap[i] >= 0) lf[lmap[i]] = p->ln_fixed[i];
+        for (int i = 0; i < s->Nl_add; ++i) lf[Nlk + i] = s->line_fixed ? s->line_fixed[i] : 0;
+        p->pt_fixed.swap(pf); p->ln_fixed.swap(lf);
+        p->pts.assign((size_t)Np1 * 3, 0.0); p->lns.assign((size_t)Nl1 * 6, 0.0);
+    }
+    // ---- IMU edges: those of the kept keyframes, shifted, then the added ones -------------------------------------------------------------------
+    {
+        std::vector<int32_t> ni, nj; std::vector<double> npre, nip, nib;
+        for (int m = 0; m < M0; ++m) {
+            if (p->imu_i[m] < nd || p->imu_j[m] < nd) continue;
+            ni.push_back(p->imu_i[m] - nd); nj.push_back(p->imu_j[m] - nd);
+            npre.insert(npre.end(), &p->imu_pre[(size_t)m * 142], &p->imu_pre[(size_t)m * 142] + 142);
+            nip.insert(nip.end(), &p->imu_ipvr[(size_t)m * 81], &p->imu_ipvr[(size_t)m * 81] + 81);
+            nib.insert(nib.end(), &p->imu_ibias[(size_t)m * 36], &p->imu_ibias[(size_t)m * 36] + 36);
+        }
+        for (int m = 0; m < s->M_add; ++m) {
+            ni.push_back(s->imu_kf_i[m]); nj.push_back(s->imu_kf_j[m]);
+            npre.insert(npre.end(), s->preint142 + (size_t)m * 142, s->preint142 + (size_t)m * 142 + 142);
+            nip.insert(nip.end(), s->info_pvr81 + (size_t)m * 81, s->info_pvr81 + (size_t)m * 81 + 81);
+            nib.insert(nib.end(), s->info_bias36 + (size_t)m * 36, s->info_bias36 + (size_t)m * 36 + 36);
+        }
+        p->imu_i.swap(ni); p->imu_j.swap(nj); p->imu_pre.swap(npre); p->imu_ipvr.swap(nip); p->imu_ibias.swap(nib);
+        p->M = (int)p->imu_i.size();
+    }
+    p->K = K1; p->Np = Np1; p->Nl = Nl1;
+    p->level.assign((size_t)p->Ep + p->El, 0);      // a new graph: every edge at level 0
+    p->dirty = true;
+    if (point_map) memcpy(point_map, pmap.data(), (size_t)Np0 * 4);
+    if (line_map) memcpy(line_map, lmap.data(), (size_t)Nl0 * 4);
     return PLBA_OK;
 }
 

@@ -275,6 +275,12 @@ struct plba_problem {
     int cur = 0;                          // index of the current estimate buffers
     // ---- device ----------------------------------------------------------------------------------
     plba::DArr<double> d_kf[2], d_kf_saved, d_lm[2], d_lm_saved;
+    // plba_slide_window: the kept landmarks' estimates never leave the device.  d_lm_carry holds the NEW window's landmark array (kept ones
+    // gathered from the previous window's current estimates, added ones uploaded); prepare() copies it on the device instead of uploading
+    // `pts` / `lns`, whose entries for the kept landmarks are stale while carry_pts / carry_lns are set (plba_set_points / _lines clear them)
+    plba::DArr<double> d_lm_carry;
+    plba::DArr<int32_t> d_lm_carry_src;
+    bool carry_pts = false, carry_lns = false;
     plba::DArr<double> d_po_uv, d_lo_l, d_ob_w, d_ob_chi2, d_erec, d_erec2;
     plba::DArr<int32_t> d_ob_kf, d_ob_slot, d_lm_start, d_off_pvr, d_off_bias;
     plba::DArr<uint8_t> d_level, d_lm_fixed, d_lm_active, d_depth;

@@ -484,3 +484,135 @@ def make_visual_window(K=8, Np=300, Nl=60, n_fixed=2, seed=0x1BA, noise_px=0.5, 
                 po_pt=np.array(po_pt, np.int32), po_kf=np.array(po_kf, np.int32), uv=np.array(uv).reshape(-1, 2),
                 lo_ln=np.array(lo_ln, np.int32), lo_kf=np.array(lo_kf, np.int32), l3=np.array(l3).reshape(-1, 3),
                 truth=dict(T=T_true, xyz=xyz_true, pq=pq_true))
+
+
+# ---------------------------------------------------------------------------------------------
+# consecutive sliding windows of one sequence (plba_slide_window; src/mapHandler.cpp:1178-1221, 4815-4825, 5769-5783)
+# ---------------------------------------------------------------------------------------------
+def make_sequence(K, n_windows, Np, Nl, imu=True, seed=0x5EED0051, **kw):
+    """A trajectory of K + n_windows - 1 keyframes with the landmark density of a K-keyframe window of Np points / Nl lines: the
+    material consecutive sliding windows are cut from (window_at)."""
+    Kt = K + n_windows - 1
+    return make_window(Kt, max(1, int(round(Np * Kt / K))), max(1, int(round(Nl * Kt / K))), imu=imu, seed=seed, **kw)
+
+
+def _first_kf(ob_lm, ob_kf, N):
+    f = np.full(N, 1 << 30, np.int64)
+    np.minimum.at(f, ob_lm, ob_kf)
+    return f
+
+
+def window_at(seq, k0, K, prev=None):
+    """The reference's local map for the sliding window of keyframes [k0, k0 + K) of a sequence: every landmark whose FIRST observation is
+    from a window keyframe (src/mapHandler.cpp:5769-5783) and that has been seen at least twice by the newest window keyframe (a map
+    landmark is born from a match), with its observations up to that keyframe.  Landmark order = map order: the landmarks of the previous
+    window `prev` that are still local keep their relative order, the ones that entered the map since follow (ascending sequence index),
+    as MapPoint::idx grows in the reference.  Estimates are the sequence's initial ones; window_from_results() replaces what a previous
+    BA optimised.  `ids` records which sequence keyframes / landmarks the window holds."""
+    k1 = k0 + K
+    out = dict(cam=seq["cam"], gw=seq["gw"], huber=dict(seq["huber"]), prior=None)
+    ks = np.arange(k0, k1)
+    kf = {k: np.ascontiguousarray(v[ks]) for k, v in seq["kf"].items()}
+    fixed = np.zeros(K, np.uint8); fixed[0] = 1      # the oldest window keyframe is fixed (mapHandler.cpp:5812-5825)
+    kf["fixed_pvr"] = fixed; kf["fixed_bias"] = fixed.copy()
+    out["kf"] = kf
+    ids = dict(k0=int(k0), K=int(K))
+    for kind, (lm_key, ob_lm_key, ob_kf_key, meas_key, w_key) in dict(points=("points", "po_pt", "po_kf", "po_uv", "po_w"), lines=("lines", "lo_ln", "lo_kf", "lo_l", "lo_w")).items():
+        ob_lm, ob_kf = seq[ob_lm_key].astype(np.int64), seq[ob_kf_key].astype(np.int64)
+        N = len(seq[lm_key])
+        first = _first_kf(ob_lm, ob_kf, N)
+        inw = (ob_kf >= k0) & (ob_kf < k1)
+        cnt = np.bincount(ob_lm[inw], minlength=N)
+        ok = (first >= k0) & (first < k1) & (cnt >= 2)
+        if prev is not None:
+            pid = prev["ids"][kind]
+            stay = pid[ok[pid]]
+            new = np.setdiff1d(np.flatnonzero(ok), pid, assume_unique=True)
+            sel = np.concatenate([stay, new]).astype(np.int64)
+        else:
+            sel = np.flatnonzero(ok).astype(np.int64)
+        rank = np.full(N, -1, np.int64); rank[sel] = np.arange(len(sel))
+        take = inw & (rank[ob_lm] >= 0)
+        o = np.flatnonzero(take)
+        o = o[np.lexsort((ob_kf[o], rank[ob_lm[o]]))]      # landmark-major in the window's landmark order, keyframes ascending (kf_obs_list order)
+        out[lm_key] = np.ascontiguousarray(seq[lm_key][sel])
+        out[ob_lm_key] = rank[ob_lm[o]].astype(np.int32)
+        out[ob_kf_key] = (ob_kf[o] - k0).astype(np.int32)
+        out[meas_key] = np.ascontiguousarray(seq[meas_key][o])
+        out[w_key] = np.ascontiguousarray(seq[w_key][o])
+        ids[kind] = sel
+        ids[kind + "_obs"] = o
+    if seq.get("imu") is not None:
+        im = seq["imu"]
+        m = np.arange(k0, k1 - 1)      # edge m joins sequence keyframes m, m + 1
+        out["imu"] = dict(kf_i=(im["kf_i"][m] - k0).astype(np.int32), kf_j=(im["kf_j"][m] - k0).astype(np.int32), preint=im["preint"][m], info_pvr=im["info_pvr"][m], info_bias=im["info_bias"][m])
+    else:
+        out["imu"] = None
+    out["ids"] = ids
+    out["meta"] = dict(K=K, Np=len(out["points"]), Nl=len(out["lines"]), Ep=len(out["po_pt"]), El=len(out["lo_ln"]), imu=out["imu"] is not None, seed=seq["meta"]["seed"])
+    return out
+
+
+def window_from_results(w_next, w_prev, res_prev):
+    """What the reference hands the next local BA: the keyframes and landmarks the previous window's BA optimised carry its results (the
+    write-back of src/mapHandler.cpp:6202-6239 — P, V, R, dbg, dba of every window keyframe, every local landmark), everything new keeps
+    its initial estimate.  res_prev: protocol.results() of the previous window's problem."""
+    w = dict(w_next)
+    w["kf"] = {k: np.array(v, copy=True) for k, v in w_next["kf"].items()}
+    sh = w_next["ids"]["k0"] - w_prev["ids"]["k0"]
+    Kp = w_prev["ids"]["K"]
+    n = Kp - sh      # keyframes both windows hold
+    for key in ("P", "V", "q", "dbg", "dba"):
+        w["kf"][key][:n] = np.asarray(res_prev[key])[sh:sh + n]
+    for kind, key in (("points", "points"), ("lines", "lines")):
+        arr = np.array(w_next[key], copy=True)
+        prev_ids = w_prev["ids"][kind]
+        pos = {int(i): j for j, i in enumerate(prev_ids)}
+        for j, i in enumerate(w_next["ids"][kind]):
+            q = pos.get(int(i))
+            if q is not None:
+                arr[j] = np.asarray(res_prev[key])[q]
+        w[key] = arr
+    return w
+
+
+def slide_delta(w_prev, w_next):
+    """The arguments of plba_slide_window (abi.Problem.slide_window) that turn the resident window w_prev into w_next: both from
+    window_at() on one sequence, w_next built with prev=w_prev."""
+    sh = w_next["ids"]["k0"] - w_prev["ids"]["k0"]
+    Kp, Kn = w_prev["ids"]["K"], w_next["ids"]["K"]
+    n_keep = Kp - sh
+    d = dict(n_drop=int(sh))
+    d["kf"] = {k: np.ascontiguousarray(v[n_keep:]) for k, v in w_next["kf"].items() if k not in ("fixed_pvr", "fixed_bias")}
+    d["fixed_pvr"], d["fixed_bias"] = w_next["kf"]["fixed_pvr"], w_next["kf"]["fixed_bias"]
+    if w_next.get("imu") is not None:
+        im = w_next["imu"]
+        new = (im["kf_i"] >= n_keep) | (im["kf_j"] >= n_keep)
+        d["imu"] = {k: np.ascontiguousarray(v[new]) for k, v in im.items()}
+    for kind, (lm_key, ob_lm_key, ob_kf_key, meas_key, w_key, dropkey) in dict(points=("points", "po_pt", "po_kf", "po_uv", "po_w", "drop_point"),
+                                                                                lines=("lines", "lo_ln", "lo_kf", "lo_l", "lo_w", "drop_line")).items():
+        pid, nid = w_prev["ids"][kind], w_next["ids"][kind]
+        pos_prev = {int(i): j for j, i in enumerate(pid)}
+        nstay = sum(1 for i in nid if int(i) in pos_prev)
+        assert all(int(i) in pos_prev for i in nid[:nstay]) and not any(int(i) in pos_prev for i in nid[nstay:]), "w_next must list the staying landmarks first (window_at(prev=...))"
+        N0 = len(pid)
+        # landmarks of the previous window that the next one does not hold and that the slide's own rule (an observation from a dropped
+        # keyframe) would keep: dropped by mask
+        nset = set(int(i) for i in nid)
+        auto = np.zeros(N0, bool)
+        auto[w_prev[ob_lm_key][w_prev[ob_kf_key] < sh]] = True
+        mask = np.array([(int(i) not in nset) for i in pid], np.uint8)
+        mask[auto] = 0
+        d[dropkey] = mask if mask.any() else None
+        d[lm_key] = np.ascontiguousarray(w_next[lm_key][nstay:])
+        # observations the previous window did not hold: those from the added keyframes, and every observation of an added landmark
+        old_obs = set(int(o) for o in w_prev["ids"][kind + "_obs"])
+        isnew = np.array([int(o) not in old_obs for o in w_next["ids"][kind + "_obs"]], bool)
+        lm_next = w_next[ob_lm_key][isnew].astype(np.int64)
+        idx_before = np.where(lm_next < nstay, np.array([pos_prev[int(nid[j])] for j in np.minimum(lm_next, max(nstay - 1, 0))], np.int64) if nstay else 0, N0 + (lm_next - nstay))
+        o = np.argsort(idx_before, kind="stable")
+        d[ob_lm_key] = idx_before[o].astype(np.int32)
+        d[ob_kf_key] = w_next[ob_kf_key][isnew][o].astype(np.int32)
+        d[meas_key] = np.ascontiguousarray(w_next[meas_key][isnew][o])
+        d[w_key] = np.ascontiguousarray(w_next[w_key][isnew][o])
+    return d

@@ -36,7 +36,7 @@ def test_hip_library_exports_every_declared_symbol(pkg):
 
 def test_oracle_exports_the_same_surface(pkg, orc):
     lib = orc.lib()
-    assert set(lib.fn) == set(pkg.abi.SIGNATURES)
+    assert set(lib.fn) == set(pkg.abi.SIGNATURES) - pkg.abi.PRODUCT_ONLY      # (memory management of the device-resident window is not the reference's algorithm)
     assert lib.backend_name() == "cpu-oracle"
 
 
