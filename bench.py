@@ -202,6 +202,55 @@ def long_track_leg(pkg, stream, iters=60):
     return out
 
 
+def slide_leg(pkg, K, Np, Nl, n_slides=4, **wkw):
+    """One reference-shaped BA call on a SLID window: the mapping thread's steady state (src/mapHandler.cpp:1178-1221: one BA per new
+    keyframe on a window that differs from the previous one by one keyframe).  The previous window stays resident; plba_slide_window
+    sends the new keyframe, its observations and the new landmarks (the caller's own bookkeeping — which observations are new — is
+    prepared outside the timed region, as the map holds it); then robust kernels, 5 + 10 iterations with gating, write-back.
+    Best of `n_slides` consecutive slides; next to it the same windows through fresh uploads."""
+    import torch
+    W = pkg.window
+    seq = W.make_sequence(K, n_slides + 1, Np, Nl, seed=0x5EED00E0 + K, **wkw)
+    wins = [W.window_at(seq, 0, K)]
+    for i in range(1, n_slides + 1):
+        wins.append(W.window_at(seq, i, K, prev=wins[-1]))
+    deltas = [W.slide_delta(wins[i], wins[i + 1]) for i in range(n_slides)]
+    p = pkg.new_problem()
+    p.upload_window(wins[0])
+    pkg.protocol.local_ba(p)
+    res = pkg.protocol.results(p)
+    best_slid, best_fresh, its = None, None, 0
+    for i in range(n_slides):
+        w = wins[i + 1]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        p.slide_window(deltas[i])
+        for kind, dlt in w["huber"].items():
+            p.set_robust(kind, True, dlt)
+        r = pkg.protocol.local_ba(p)
+        res_next = pkg.protocol.results(p)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best_slid = dt if best_slid is None else min(best_slid, dt)
+        its = r["stage1"].iterations + r["stage2"].iterations
+        wf = W.window_from_results(w, wins[i], res)
+        t0 = time.perf_counter()
+        q = pkg.new_problem()
+        q.upload_window(wf)
+        pkg.protocol.local_ba(q)
+        pkg.protocol.results(q)
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t0
+        q.close()
+        best_fresh = dtf if best_fresh is None else min(best_fresh, dtf)
+        res = res_next
+    p.close()
+    m = wins[-1]["meta"]
+    return dict(workload="%d KF window slid by one keyframe (sequence windows: %d points / %d lines, %d + %d observations)" % (K, m["Np"], m["Nl"], m["Ep"], m["El"]),
+                slid_window_ba_call_ms=best_slid * 1e3, fresh_upload_ba_call_ms=best_fresh * 1e3, iterations=int(its),
+                added_point_obs=int(len(deltas[-1]["po_pt"])), added_points=int(len(deltas[-1]["points"])))
+
+
 def facade_leg(w, reps=5):
     """One localBundleAdjustmentWithImuAndMarg-shaped call through BOUNDARY 1 — the reference's own call-site code (one `new` per
     vertex and edge, optimize(5), the gating loop over the edge objects, optimize(10), marginalization, write-back loops) compiled
@@ -471,6 +520,9 @@ def main():
             e2e = dt2 if e2e is None else min(e2e, dt2)
         out["config"]["end_to_end_ba_call_ms"] = e2e * 1e3
         out["config"]["end_to_end_iterations_per_s"] = (r2["stage1"].iterations + r2["stage2"].iterations) / e2e
+        if cfg_idx == 3:
+            out["config"]["sliding_window_call"] = slide_leg(pkg, 50, 20000, 4000)
+            out["config"]["sliding_window_call_12kf"] = slide_leg(pkg, 12, 2000, 400, kf_dt=0.1, track=(6, 12), revisit=0.2)
         if rank == 0:
             try:
                 out["config"].update(facade_leg(w_full))

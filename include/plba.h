@@ -244,6 +244,8 @@ typedef struct {
     int El_add; const int32_t* lo_ln; const int32_t* lo_kf; const double* l3; const double* lo_inv_sigma2;
 } plba_slide;
 int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, int32_t* line_map);
+/* sizes of the uploaded window: out6 = [K, Np, Nl, Ep, El, M] (optimizer.vertices().size() / edges().size() by kind) */
+int plba_get_sizes(const plba_problem* p, int32_t* out6);
 
 /* ---- multi-GPU: this problem holds a landmark shard; pose-side edges are added by rank 0 only */
 int plba_set_shard(plba_problem* p, int rank, int world, plba_allreduce_fn fn, void* user);

@@ -75,7 +75,7 @@ _P = C.c_void_p  # plba_problem*
 
 # entry points of the product that have no counterpart in the reference's algorithm (memory management of the device-resident window): the
 # CPU oracle — a restatement of the reference — does not implement them
-PRODUCT_ONLY = {"slide_window"}
+PRODUCT_ONLY = {"slide_window", "get_sizes"}
 
 # name -> (restype, argtypes); every symbol plba.h declares
 SIGNATURES = {
@@ -97,6 +97,7 @@ SIGNATURES = {
     "set_levels": (C.c_int, [_P, C.c_int, c_uint8_p]),
     "get_levels": (C.c_int, [_P, C.c_int, c_uint8_p]),
     "slide_window": (C.c_int, [_P, C.POINTER(Slide), c_int32_p, c_int32_p]),
+    "get_sizes": (C.c_int, [_P, c_int32_p]),
     "set_shard": (C.c_int, [_P, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]),
     "set_stream": (C.c_int, [_P, C.c_void_p]),
     "optimize": (C.c_int, [_P, C.c_int, c_uint8_p, C.POINTER(Stats)]),
@@ -263,20 +264,17 @@ class Problem:
         pt, kf, uv, w = _i32(pt), _i32(kf), _f64(uv, (-1, 2)), _f64(inv_sigma2)
         self.call("set_point_obs", len(pt), _ip(pt), _ip(kf), _dp(uv), _dp(w))
         self.dims["Ep"] = len(pt)
-        self._po = (pt.copy(), kf.copy())      # (landmark / keyframe of every observation: slide_window keeps the counts in step with the library's merge)
 
     def set_line_obs(self, ln, kf, l3, inv_sigma2=None):
         ln, kf, l3, w = _i32(ln), _i32(kf), _f64(l3, (-1, 3)), _f64(inv_sigma2)
         self.call("set_line_obs", len(ln), _ip(ln), _ip(kf), _dp(l3), _dp(w))
         self.dims["El"] = len(ln)
-        self._lo = (ln.copy(), kf.copy())
 
     def set_imu_edges(self, kf_i, kf_j, preint142, info_pvr, info_bias):
         ki, kj = _i32(kf_i), _i32(kf_j)
         pre, ip, ib = _f64(preint142, (-1, 142)), _f64(info_pvr, (-1, 81)), _f64(info_bias, (-1, 36))
         self.call("set_imu_edges", len(ki), _ip(ki), _ip(kj), _dp(pre), _dp(ip), _dp(ib))
         self.dims["M"] = len(ki)
-        self._imu = (ki.copy(), kj.copy())
 
     def set_prior(self, prior):
         """prior: dict(n, vid, size, idx, x0, J0 (n x n, J0[r, c]), r0) or None to clear."""
@@ -514,30 +512,11 @@ class Problem:
             s.lo_ln, s.lo_kf, s.l3, s.lo_inv_sigma2 = i32(d["lo_ln"]), i32(d["lo_kf"]), f64(d["lo_l"], (-1, 3)), f64(d.get("lo_w"))
         pm = np.zeros(max(self.dims.get("Np", 0), 1), np.int32); lm = np.zeros(max(self.dims.get("Nl", 0), 1), np.int32)
         self.call("slide_window", C.byref(s), _ip(pm), _ip(lm))
-        Np0, Nl0 = self.dims.get("Np", 0), self.dims.get("Nl", 0)
-        pm, lm = pm[:Np0].copy(), lm[:Nl0].copy()
-        # the Python-side image of the observation lists (counts for the getters), merged as the library merges them
-        def merged(old, n0, mp, add_lm, add_kf, drop_obs):
-            lm0, kf0 = old
-            keep = mp[lm0] >= 0 if len(lm0) else np.zeros(0, bool)
-            if drop_obs is not None:
-                keep &= ~np.asarray(drop_obs, bool)
-            nkept = int((mp >= 0).sum())
-            a_lm = np.asarray(add_lm if add_lm is not None else [], np.int64)
-            a_new = np.where(a_lm < n0, mp[np.minimum(a_lm, max(n0 - 1, 0))] if n0 else 0, nkept + (a_lm - n0))
-            allm = np.concatenate([mp[lm0[keep]] if len(lm0) else np.zeros(0, np.int64), a_new]).astype(np.int64)
-            allk = np.concatenate([kf0[keep] - s.n_drop if len(kf0) else np.zeros(0, np.int64), np.asarray(add_kf if add_kf is not None else [], np.int64)])
-            o = np.argsort(allm, kind="stable")
-            return allm[o].astype(np.int32), allk[o].astype(np.int32)
-        self._po = merged(getattr(self, "_po", (np.zeros(0, np.int32),) * 2), Np0, pm, d.get("po_pt"), d.get("po_kf"), d.get("drop_point_obs"))
-        self._lo = merged(getattr(self, "_lo", (np.zeros(0, np.int32),) * 2), Nl0, lm, d.get("lo_ln"), d.get("lo_kf"), d.get("drop_line_obs"))
-        ki, kj = getattr(self, "_imu", (np.zeros(0, np.int32),) * 2)
-        kept = (ki >= s.n_drop) & (kj >= s.n_drop)
-        self._imu = (np.concatenate([ki[kept] - s.n_drop, np.asarray(im["kf_i"], np.int32) if im is not None else np.zeros(0, np.int32)]).astype(np.int32),
-                     np.concatenate([kj[kept] - s.n_drop, np.asarray(im["kf_j"], np.int32) if im is not None else np.zeros(0, np.int32)]).astype(np.int32))
-        self.dims["K"] = self.dims["K"] - s.n_drop + s.K_add
-        self.dims["Np"] = int((pm >= 0).sum()) + s.Np_add; self.dims["Nl"] = int((lm >= 0).sum()) + s.Nl_add
-        self.dims["Ep"], self.dims["El"], self.dims["M"] = len(self._po[0]), len(self._lo[0]), len(self._imu[0])
+        pm, lm = pm[:self.dims.get("Np", 0)], lm[:self.dims.get("Nl", 0)]
+        sz = np.zeros(6, np.int32)
+        self.call("get_sizes", _ip(sz))      # (the library merged the lists: its counts serve the getters)
+        for k, v in zip(("K", "Np", "Nl", "Ep", "El", "M"), sz):
+            self.dims[k] = int(v)
         return pm, lm
 
     # -- convenience -------------------------------------------------------------------------

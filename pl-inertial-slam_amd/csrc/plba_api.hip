@@ -242,6 +242,7 @@ int plba_set_point_obs(plba_problem* p, int Ep, const int32_t* pt, const int32_t
     p->po_uv.assign(uv, uv + 2 * (size_t)Ep);
     p->po_w.assign(Ep, 1.0);
     if (w) for (int e = 0; e < Ep; ++e) p->po_w[e] = (double)(float)w[e];   // const float& invSigma2 (mapHandler.cpp:5340)
+    p->carry_po = false;
     p->level.assign((size_t)p->Ep + p->El, 0);      // new edges are level 0 (g2o); a re-used handle does not inherit the previous window's
     p->dirty = true;
     return PLBA_OK;
@@ -257,6 +258,7 @@ int plba_set_line_obs(plba_problem* p, int El, const int32_t* ln, const int32_t*
     p->lo_l.assign(l3, l3 + 3 * (size_t)El);
     p->lo_w.assign(El, 1.0);
     if (w) for (int e = 0; e < El; ++e) p->lo_w[e] = (double)(float)w[e];
+    p->carry_lo = false;
     // the new line edges are level 0; the POINT edges' levels stay (set_point_obs -> set_levels(POINT) -> set_line_obs used
     // to drop them).  plba_set_point_obs still resets both ranges: Ep moves the line range's offset.
     p->level.resize((size_t)p->Ep + p->El);
@@ -468,17 +470,16 @@ static bool lm_structure_fits(const plba_problem* p, const std::vector<int32_t>&
 // which the host worker pool fills WHILE prepare() goes on allocating and uploading (the largest single item of a BA call's host side:
 // 2.5 ms on one thread at configs[2]); lm_groups_finish() joins before they are uploaded.
 static void lm_fill_groups(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf, const std::vector<double>& ob_w, LmHost& H, int t) {
-    const int Ep = p->Ep;
     for (int gi = H.gcut[t]; gi < H.gcut[t + 1]; ++gi) {
         const LmGroup& g = H.grp[gi];
-        const int kind = g.kind & 1, wmax = H.wmax;
+        const int wmax = H.wmax;
         int l = g.lm0, ob = H.span_ob0[gi];
         for (int n = H.span_at[gi]; n < H.span_end[gi]; ++n, ++l) {
             const int s = H.ordall[n];
-            H.lm_slot[l] = s; H.lm_fixed[l] = p->lm_fixed[s]; H.lm_ob0[l] = ob;
+            H.p_lm_slot[l] = s; H.p_lm_fixed[l] = p->lm_fixed[s]; H.p_lm_ob0[l] = ob;
             // the 8 lanes of the landmark's unit(s) ARE the window slots: lane w takes the observation made from keyframe kf[w] (its
             // offset in the landmark's range), or none (0xFF) — so a lane's camera block, operand rows and accumulators never move
-            uint8_t* w8 = &H.lm_ws8[(size_t)l * wmax];
+            uint8_t* w8 = &H.p_lm_ws8[(size_t)l * wmax];
             for (int sl = 0; sl < wmax; ++sl) w8[sl] = 0xFF;
             int nk = 0;
             for (int e = lm_start[s]; e < lm_start[s + 1]; ++e, ++ob, ++nk) {
@@ -486,9 +487,7 @@ static void lm_fill_groups(const plba_problem* p, const std::vector<int32_t>& lm
                 while (g.kf[w] != ob_kf[e]) ++w;      // (<= 8 / 16 window keyframes, all of the landmark's are among them)
                 if (w8[w] != 0xFF) H.bad[t] = 1;      // two observations in one keyframe: not expressible
                 w8[w] = (uint8_t)nk;
-                H.ob_orig[ob] = e; H.ob_wt[ob] = ob_w[e];
-                if (kind == 0) { H.meas_pt[2 * (size_t)ob] = p->po_uv[2 * (size_t)e]; H.meas_pt[2 * (size_t)ob + 1] = p->po_uv[2 * (size_t)e + 1]; }
-                else for (int c = 0; c < 3; ++c) H.meas_ln[3 * (size_t)(ob - Ep) + c] = p->lo_l[3 * (size_t)(e - Ep) + c];
+                H.p_ob_orig[ob] = e;      // (measurement and weight follow on the DEVICE: k_lm_tables gathers them from the landmark-major arrays)
             }
         }
     }
@@ -566,6 +565,7 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     }
     glap("kmin / kmax");
     int nlm = 0, nob = 0;
+    double t_sort = 0.0, t_cut = 0.0;
     for (int kind4 = 0; kind4 < 4; ++kind4) {      // points, wide points, lines, wide lines: every point observation before every line observation (meas_pt / meas_ln)
         const int kind = kind4 >> 1, wide = kind4 & 1, W = wide ? LMF_W2 : LMF_W;
         if (wide && !any_wide) continue;
@@ -584,6 +584,7 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
         }
         const int base = (int)ordall.size();
         size_t at = 0;
+        if (gt) { auto t = std::chrono::steady_clock::now(); t_sort += std::chrono::duration<double, std::milli>(t - g0).count(); g0 = t; }
         while (at < ord.size()) {
             const int gi = (int)H.grp.size();
             int32_t win[LMF_W2];
@@ -636,8 +637,9 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
             at = end;
         }
         ordall.insert(ordall.end(), ord.begin(), ord.end());
+        if (gt) { auto t = std::chrono::steady_clock::now(); t_cut += std::chrono::duration<double, std::milli>(t - g0).count(); g0 = t; }
     }
-    glap("order + boundaries");
+    if (gt) fprintf(stderr, "[prepare]   groups: order (sorts)      %8.3f ms\n[prepare]   groups: cut + pair lists   %8.3f ms\n", t_sort, t_cut);
     // stable counting sorts by key (K * K resp. K buckets): equal keys stay in group order
     {
         std::vector<int32_t>& c2 = H.c2; std::vector<int32_t>& pos = H.pos;
@@ -661,9 +663,19 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     glap("gather lists");
     // ---- phase 3: the tables, group by group, on the worker pool; joined by lm_groups_finish() -------------------------------------------------
     const int ngrp = (int)H.grp.size();
-    H.lm_slot.resize(nlm); H.lm_ob0.resize(nlm + 1); H.lm_ws8.resize((size_t)nlm * H.wmax); H.lm_fixed.resize(nlm); H.ob_orig.resize(nob); H.ob_wt.resize(nob);
-    H.meas_pt.resize(2 * (size_t)Ep); H.meas_ln.resize(3 * (size_t)(E - Ep));
-    H.lm_ob0[nlm] = nob;
+    H.n_lm = (size_t)nlm; H.n_ob = (size_t)nob; H.n_meas_pt = 2 * (size_t)Ep; H.n_meas_ln = 3 * (size_t)(E - Ep);
+    H.staged = false;
+    if (nob > 20000) {      // (small windows: their tables ride in the batched upload block, one copy for all of them)
+        H.p_ob_orig = (int32_t*)stage_take(std::max<size_t>(H.n_ob, 1) * 4);
+        H.p_lm_slot = (int32_t*)stage_take(std::max<size_t>(H.n_lm, 1) * 4); H.p_lm_ob0 = (int32_t*)stage_take((H.n_lm + 1) * 4);
+        H.p_lm_ws8 = (uint8_t*)stage_take(std::max<size_t>(H.n_lm * H.wmax, 1)); H.p_lm_fixed = (uint8_t*)stage_take(std::max<size_t>(H.n_lm, 1));
+        H.staged = H.p_ob_orig && H.p_lm_slot && H.p_lm_ob0 && H.p_lm_ws8 && H.p_lm_fixed;      // (a block taken before the area ran out stays unused until the next scope)
+    }
+    if (!H.staged) {
+        H.lm_slot.resize(nlm); H.lm_ob0.resize(nlm + 1); H.lm_ws8.resize((size_t)nlm * H.wmax); H.lm_fixed.resize(nlm); H.ob_orig.resize(nob);
+        H.p_lm_slot = H.lm_slot.data(); H.p_lm_ob0 = H.lm_ob0.data(); H.p_lm_ws8 = H.lm_ws8.data(); H.p_lm_fixed = H.lm_fixed.data(); H.p_ob_orig = H.ob_orig.data();
+    }
+    H.p_lm_ob0[nlm] = nob;
     // more jobs than threads from 60 k observations on: they are dealt dynamically, and the caller takes what is left when it joins (round 4:
     // with 8 jobs on 8 sleeping workers the join had become the critical path of prepare(), 0.1 ms of waiting at configs[2])
     const int NT = E > 400000 ? 32 : E > 60000 ? 16 : E > 20000 ? 4 : 1;
@@ -710,6 +722,30 @@ static int twin_launch_estimate(int T, int hbt) {
 static int dense_pad(const plba_problem* p, int pd) {
     const bool small32 = p->opt.use_mfma && p->opt.factor_block != 64 && !p->opt.factor_flow && !p->opt.wide_steps && (pd + TILE - 1) / TILE * 2 < 8;
     return small32 ? std::max(32, (pd + 31) / 32 * 32) : ((pd + TILE - 1) / TILE) * TILE;
+}
+// group-order measurement / weight tables of the fused landmark passes from the landmark-major observation arrays: entry g is observation
+// ob_orig[g]; point observations come first in both orders
+__global__ void k_lm_tables(const int32_t* __restrict__ ob_orig, int E, int Ep, const double* __restrict__ po_uv, const double* __restrict__ lo_l, const double* __restrict__ ob_w,
+                            double* __restrict__ meas_pt, double* __restrict__ meas_ln, double* __restrict__ ob_wt) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E) return;
+    const int e = ob_orig[g];
+    ob_wt[g] = ob_w[e];
+    if (g < Ep) { meas_pt[2 * (size_t)g] = po_uv[2 * (size_t)e]; meas_pt[2 * (size_t)g + 1] = po_uv[2 * (size_t)e + 1]; }
+    else for (int c = 0; c < 3; ++c) meas_ln[3 * (size_t)(g - Ep) + c] = lo_l[3 * (size_t)(e - Ep) + c];
+}
+// Hconst[off(a) + c, off(b) + e] = H[idx(a) + c, idx(b) + e] over the prior's kept vertices that are free in this window (H = J0^T J0, n x n)
+__global__ void k_prior_scatter(const double* __restrict__ H, int n, int nv, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, const int32_t* __restrict__ size,
+                                double* __restrict__ Hconst, int ld) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n) return;
+    const int r = t / n, c = t % n;
+    int dr = -1, dc = -1;
+    for (int a = 0; a < nv; ++a) {
+        if (r >= idx[a] && r < idx[a] + size[a] && off[a] >= 0) dr = off[a] + (r - idx[a]);
+        if (c >= idx[a] && c < idx[a] + size[a] && off[a] >= 0) dc = off[a] + (c - idx[a]);
+    }
+    if (dr >= 0 && dc >= 0) Hconst[(size_t)dr * ld + dc] = H[t];
 }
 static int prepare(plba_problem* p) {
     if (!p->dirty) return PLBA_OK;
@@ -777,8 +813,12 @@ static int prepare(plba_problem* p) {
     // ---- unified landmark slots / observation arrays ----------------------------------------------------
     std::vector<int32_t> ob_kf(E), ob_slot(E), lm_start(L + 1, 0);
     std::vector<double> ob_w(E);
-    for (int e = 0; e < Ep; ++e) { ob_kf[e] = p->po_kf[e]; ob_slot[e] = p->po_pt[e]; ob_w[e] = p->po_w[e]; lm_start[p->po_pt[e] + 1]++; }
-    for (int e = 0; e < El; ++e) { ob_kf[Ep + e] = p->lo_kf[e]; ob_slot[Ep + e] = Np + p->lo_ln[e]; ob_w[Ep + e] = p->lo_w[e]; lm_start[Np + p->lo_ln[e] + 1]++; }
+    // (a slid window's measurements and weights are on the device already: plba_slide_window)
+    const bool carry_obs = (p->carry_po || Ep == 0) && (p->carry_lo || El == 0) && (p->carry_po || p->carry_lo);
+    if ((p->carry_po || p->carry_lo) && !carry_obs) FAIL(p, PLBA_ERR_STATE, "after plba_slide_window set BOTH observation arrays again (plba_set_point_obs and plba_set_line_obs) or neither: the kept measurements live on the device");
+    for (int e = 0; e < Ep; ++e) { ob_kf[e] = p->po_kf[e]; ob_slot[e] = p->po_pt[e]; lm_start[p->po_pt[e] + 1]++; }
+    for (int e = 0; e < El; ++e) { ob_kf[Ep + e] = p->lo_kf[e]; ob_slot[Ep + e] = Np + p->lo_ln[e]; lm_start[Np + p->lo_ln[e] + 1]++; }
+    if (!carry_obs) { for (int e = 0; e < Ep; ++e) ob_w[e] = p->po_w[e]; for (int e = 0; e < El; ++e) ob_w[Ep + e] = p->lo_w[e]; }
     for (int s = 0; s < L; ++s) lm_start[s + 1] += lm_start[s];
     // ---- fused landmark-major passes: does the structure fit?  (decided for good once the chain maps exist, below) -----------------
     // lm_fused = 1: from 40 k observations on.  Measured after the third form of the Schur pass (decoupled waves, lane = window slot; ms
@@ -960,7 +1000,11 @@ static int prepare(plba_problem* p) {
         HIPCK(p, hipMemcpyAsync(p->d_lm_saved.p, p->d_lm[0].p, p->lm0.size() * 8, hipMemcpyDeviceToDevice, p->stream));
     }
     }
-    HIPCK(p, p->d_po_uv.upload(p->po_uv)); HIPCK(p, p->d_lo_l.upload(p->lo_l)); HIPCK(p, p->d_ob_w.upload(ob_w));
+    if (carry_obs) {
+        if (p->carry_obs_pending) { p->d_po_uv.swap(p->d_po_uv_c); p->d_lo_l.swap(p->d_lo_l_c); p->d_ob_w.swap(p->d_ob_w_c); p->carry_obs_pending = false;
+            p->d_po_uv_c.drop_batched(); p->d_lo_l_c.drop_batched(); p->d_ob_w_c.drop_batched(); }      // (the old buffers become the next slide's destination — unless they lived in the batch blocks, which start over now)
+        if (p->d_po_uv.n < 2 * (size_t)Ep || p->d_lo_l.n < 3 * (size_t)El || p->d_ob_w.n < (size_t)E) FAIL(p, PLBA_ERR_STATE, "carried observation arrays do not fit the window (internal error)");
+    } else { HIPCK(p, p->d_po_uv.upload(p->po_uv)); HIPCK(p, p->d_lo_l.upload(p->lo_l)); HIPCK(p, p->d_ob_w.upload(ob_w)); }
     HIPCK(p, p->d_ob_kf.upload(ob_kf)); HIPCK(p, p->d_ob_slot.upload(ob_slot)); HIPCK(p, p->d_lm_start.upload(lm_start));
     HIPCK(p, p->d_level.upload(p->level)); HIPCK(p, p->d_lm_fixed.upload(p->lm_fixed));
     const size_t nrec = lm_cand ? 0 : ((size_t)Ep + 2 * (size_t)El) * EREC_UNIT;      // the fused passes write no record table (2 x 70 MB at configs[4])
@@ -1057,6 +1101,52 @@ static int prepare(plba_problem* p) {
     d.Linv = p->d_Linv.p; d.flow_flags = p->d_flow_flags.p; d.LTblk = p->d_LT32.p; d.Linv32 = p->d_LT32.p; d.rdblk = p->d_rd32.p; d.fb = (p->opt.factor_block == 64) ? 64 : 32; d.chol_flags = p->d_chol_flags.p; d.flow = p->opt.factor_flow != 0; d.wide = p->opt.wide_steps != 0 && !d.flow;
     d.chi_part = p->d_chi_part.p; d.scale_part = p->d_scale_part.p; d.maxd_part = p->d_maxd_part.p; d.kfdiag = p->d_kfdiag.p; d.posediag = p->d_posediag.p;
     d.ctrl = p->d_ctrl.p; d.trace = p->d_trace.p; d.trace_cap = TRACE_CAP; d.trace_n = p->d_trace_n.p;
+    // ---- structure cache: is this window's pose structure the previous one's? (plba_problem.h, StructCache) ---------------------------------
+    std::vector<int32_t> skey;
+    {
+        skey.reserve(64 + 2 * (size_t)K + 2 * (size_t)M + 4 * (size_t)p->pr_nv + ((size_t)K * K + 3) / 4 * 2 + K);
+        for (int v : {K, M, p->pr_nv, p->pr_n, (int)lm_cand, p->world, p->rank, p->opt.chain_elim, p->opt.use_mfma, p->opt.factor_block, p->opt.factor_flow, p->opt.wide_steps, p->opt.band_solve,
+                      p->opt.chain_seg, p->opt.twin_max_tiles, (int)(E > 300000), (int)p->lm_disable, p->P}) skey.push_back(v);
+        skey.insert(skey.end(), p->off_pvr.begin(), p->off_pvr.end()); skey.insert(skey.end(), p->off_bias.begin(), p->off_bias.end());
+        skey.insert(skey.end(), p->imu_i.begin(), p->imu_i.end()); skey.insert(skey.end(), p->imu_j.begin(), p->imu_j.end());
+        skey.insert(skey.end(), pr_kf.begin(), pr_kf.end()); skey.insert(skey.end(), pr_isb.begin(), pr_isb.end()); skey.insert(skey.end(), p->pr_size.begin(), p->pr_size.begin() + p->pr_nv); skey.insert(skey.end(), pr_off.begin(), pr_off.end());
+        skey.insert(skey.end(), p->pr_idx.begin(), p->pr_idx.begin() + p->pr_nv);
+        auto pack = [&](const std::vector<uint8_t>& v) { for (size_t i = 0; i < v.size(); i += 4) { int32_t w = 0; for (size_t j = i; j < std::min(i + 4, v.size()); ++j) w |= (int32_t)(v[j] & 0xFF) << (8 * (j - i)); skey.push_back(w); } };
+        pack(cov);
+        if (lm_cand) { pack(LH.cov); skey.insert(skey.end(), LH.row_kf.begin(), LH.row_kf.end()); skey.push_back(LH.wmax); }
+    }
+    const bool sc_hit = p->sc.valid && skey == p->sc.key;
+    struct BatchSwitch {      // the structure's buffers come from a batch of their own, and its zero-filled pool buffers are noted
+        DevBatch* prev; std::vector<std::pair<void*, size_t>>* prevlog;
+        BatchSwitch(DevBatch* b, std::vector<std::pair<void*, size_t>>* log) : prev(darr_batch()), prevlog(darr_zero_log()) { darr_batch() = b; darr_zero_log() = log; }
+        ~BatchSwitch() { darr_batch() = prev; darr_zero_log() = prevlog; }
+    };
+    if (sc_hit) {
+        ++p->sc.hits;
+        // same structure: the buffers stay; what the miss zero-filled is cleared again (epoch-stamped flags, accumulators, W outside the segments' windows)
+        if (p->sbatch.zused) HIPCK(p, hipMemsetAsync(p->sbatch.z, 0, p->sbatch.zused, p->stream));
+        for (const auto& zr : p->sc.zero_log) HIPCK(p, hipMemsetAsync(zr.first, 0, zr.second, p->stream));
+        p->chain_ok = p->sc.chain_ok;
+        d.Ninv = p->sc.Ninv; d.Nwork = p->sc.Nwork; d.dbgbuf = p->sc.dbgbuf; d.alist = p->sc.alist; d.nalist = p->sc.nalist;
+        if (p->chain_ok) {      // the dense system's view: this window's arrays, the cached structure's fields
+            DevBuf& dd = p->dd; const DevBuf& o = p->sc.dd;
+            dd = d;
+            dd.P = o.P; dd.Ppad = o.Ppad; dd.ld = o.ld; dd.sys = o.sys; dd.Lfac = o.Lfac; dd.x = o.x; dd.Linv = o.Linv; dd.LTblk = o.LTblk; dd.Linv32 = o.Linv32; dd.rdblk = o.rdblk;
+            dd.flow_flags = o.flow_flags; dd.chol_flags = o.chol_flags; dd.Ninv = o.Ninv; dd.Nwork = o.Nwork; dd.dbgbuf = d.dbgbuf;
+            dd.band = o.band; dd.twin_m0 = o.twin_m0; dd.twin_fac = o.twin_fac; dd.cs_order = o.cs_order; dd.perm = o.perm; dd.xmap = o.xmap; dd.alt = o.alt; dd.alt2 = o.alt2; dd.wtw = o.wtw;
+        }
+        p->flow_epoch = 0;
+    } else {
+        ++p->sc.misses;
+        p->sc.valid = false; p->sc.zero_log.clear();
+        if (!p->d_sbatch_z.p) { BatchSwitch none(nullptr, nullptr); HIPCK(p, p->d_sbatch_z.alloc(DevBatch::ZCAP, false)); HIPCK(p, p->d_sbatch_u.alloc(DevBatch::UCAP, false)); }
+        DevBatch& b = p->sbatch;
+        b.z = p->d_sbatch_z.p; b.zcap = DevBatch::ZCAP; b.zused = b.zdone = 0; ++b.gen;
+        b.uh = (char*)stage_take(DevBatch::UCAP);
+        b.u = b.uh ? p->d_sbatch_u.p : nullptr; b.ucap = DevBatch::UCAP; b.uused = b.udone = 0; b.n_batched = 0;
+    }
+    if (!sc_hit) {
+    BatchSwitch structure_scope(&p->sbatch, &p->sc.zero_log);
     // ---- chain-variable elimination (plba_chain.hip): index maps and the compact dense system ---------------------------------
     p->chain_ok = false;
     if (p->opt.chain_elim && p->opt.use_mfma && d.fb == 32 && p->P > 0) {
@@ -1322,6 +1412,8 @@ static int prepare(plba_problem* p) {
         d.alist = p->d_alist.p; d.nalist = (int)al.size();
         p->h_alist.swap(al);      // kept on the host: the staged upload reads it until the final wait, and the band measurement below
     }
+    HIPCK(p, darr_flush());
+    }      // (!sc_hit)
     lap("assembly list");
     // ---- fused landmark-major passes: final decision, gather complement of the assembly list, upload --------------------------------
     p->lm_ok = false;
@@ -1345,7 +1437,8 @@ static int prepare(plba_problem* p) {
         return rc2;
     }
     lap("landmark tables joined");
-    if (lm_cand) {
+    if (lm_cand && !sc_hit) {
+        BatchSwitch structure_scope(&p->sbatch, &p->sc.zero_log);
         const int ld = p->ld;
         // the structural assembly list minus what k_lm_gather writes: the 6 x 6 pose blocks of keyframe pairs some group's window holds
         // (LH.cov) and the right-hand-side columns of the observed keyframes
@@ -1364,11 +1457,25 @@ static int prepare(plba_problem* p) {
                 if (!(covr && kc >= 0 && covr[kc])) al2.push_back(idx);
             }
         }
-        HIPCK(p, p->d_lm_grp.upload(LH.grp)); HIPCK(p, p->d_lmg_slot.upload(LH.lm_slot)); HIPCK(p, p->d_lmg_ob0.upload(LH.lm_ob0)); HIPCK(p, p->d_lmg_orig.upload(LH.ob_orig));
-        HIPCK(p, p->d_lmg_ws8.upload(LH.lm_ws8)); HIPCK(p, p->d_lmg_fixed.upload(LH.lm_fixed)); HIPCK(p, p->d_lmg_level.alloc(E)); HIPCK(p, p->d_lmg_meas_pt.upload(LH.meas_pt)); HIPCK(p, p->d_lmg_meas_ln.upload(LH.meas_ln)); HIPCK(p, p->d_lmg_wt.upload(LH.ob_wt));
+        HIPCK(p, p->d_alist2.upload(al2)); HIPCK(p, p->d_col_gather.upload(colg));
+        HIPCK(p, darr_flush());
+        p->sc.alist2 = p->d_alist2.p; p->sc.nalist2 = (int)al2.size(); p->sc.col_gather = p->d_col_gather.p;
+    }
+    if (lm_cand) {
+        HIPCK(p, p->d_lm_grp.upload(LH.grp));
+        if (LH.staged) {      // the tables were filled in the pinned staging area: one asynchronous copy each, no second pass over them
+            HIPCK(p, p->d_lmg_slot.upload_staged(LH.p_lm_slot, LH.n_lm)); HIPCK(p, p->d_lmg_ob0.upload_staged(LH.p_lm_ob0, LH.n_lm + 1)); HIPCK(p, p->d_lmg_orig.upload_staged(LH.p_ob_orig, LH.n_ob));
+            HIPCK(p, p->d_lmg_ws8.upload_staged(LH.p_lm_ws8, LH.n_lm * LH.wmax)); HIPCK(p, p->d_lmg_fixed.upload_staged(LH.p_lm_fixed, LH.n_lm));
+        } else {
+            HIPCK(p, p->d_lmg_slot.upload(LH.lm_slot)); HIPCK(p, p->d_lmg_ob0.upload(LH.lm_ob0)); HIPCK(p, p->d_lmg_orig.upload(LH.ob_orig));
+            HIPCK(p, p->d_lmg_ws8.upload(LH.lm_ws8)); HIPCK(p, p->d_lmg_fixed.upload(LH.lm_fixed));
+        }
+        // measurements and weights in group order: gathered on the device from the landmark-major arrays already there (round 5: 3 MB less to
+        // fill, stage and send per BA call at configs[2]; a slid window's old observations never come back to the host at all)
+        HIPCK(p, p->d_lmg_meas_pt.alloc(std::max<size_t>(LH.n_meas_pt, 1), false)); HIPCK(p, p->d_lmg_meas_ln.alloc(std::max<size_t>(LH.n_meas_ln, 1), false)); HIPCK(p, p->d_lmg_wt.alloc(std::max<size_t>(LH.n_ob, 1), false));
+        HIPCK(p, p->d_lmg_level.alloc(E));
         HIPCK(p, p->d_lmg_blk_ij.upload(LH.blk_ij)); HIPCK(p, p->d_lmg_blk_start.upload(LH.blk_start)); HIPCK(p, p->d_lmg_blk_src.upload(LH.blk_src));
         HIPCK(p, p->d_lmg_row_kf.upload(LH.row_kf)); HIPCK(p, p->d_lmg_row_start.upload(LH.row_start)); HIPCK(p, p->d_lmg_row_src.upload(LH.row_src));
-        HIPCK(p, p->d_alist2.upload(al2)); HIPCK(p, p->d_col_gather.upload(colg));
         HIPCK(p, p->d_lmg_part.alloc(LH.grp.size() * (size_t)(LH.npair * 36 + LH.wmax * 12))); HIPCK(p, p->d_ob_err.alloc(2 * (size_t)E)); HIPCK(p, p->d_lmg_chi.alloc(E));
         LmView& lv = p->lv;
         p->lm_hist.assign(20, 0.0);      // diagnostics: groups by number of workgroup steps (points 1..8 | lines 1..8), window widths
@@ -1377,16 +1484,24 @@ static int prepare(plba_problem* p) {
         lv.meas_pt = p->d_lmg_meas_pt.p; lv.meas_ln = p->d_lmg_meas_ln.p; lv.ob_wt = p->d_lmg_wt.p; lv.part = p->d_lmg_part.p; lv.ob_chi_g = p->d_lmg_chi.p; p->lm_chi_dirty = false;
         lv.nblk = (int)LH.blk_ij.size(); lv.blk_ij = p->d_lmg_blk_ij.p; lv.blk_start = p->d_lmg_blk_start.p; lv.blk_src = p->d_lmg_blk_src.p;
         lv.nrow = (int)LH.row_kf.size(); lv.row_kf = p->d_lmg_row_kf.p; lv.row_start = p->d_lmg_row_start.p; lv.row_src = p->d_lmg_row_src.p;
-        lv.alist2 = p->d_alist2.p; lv.nalist2 = (int)al2.size(); lv.col_gather = p->d_col_gather.p;
+        lv.alist2 = p->sc.alist2; lv.nalist2 = p->sc.nalist2; lv.col_gather = p->sc.col_gather;
         lv.ob_err = nullptr; lv.dbg_out = 0;
         p->lm_ok = lv.ngrp > 0;
         HIPCK(p, darr_flush());
-        if (p->lm_ok) launch_lm_level_sync(d, lv, p->stream);
+        if (p->lm_ok) {
+            if (LH.n_ob != (size_t)E) FAIL(p, PLBA_ERR_STATE, "landmark groups list %zu of %d observations (internal error)", LH.n_ob, E);
+            hipLaunchKernelGGL(k_lm_tables, dim3((E + 255) / 256), dim3(256), 0, p->stream, p->d_lmg_orig.p, E, Ep, p->d_po_uv.p, p->d_lo_l.p, p->d_ob_w.p, p->d_lmg_meas_pt.p, p->d_lmg_meas_ln.p, p->d_lmg_wt.p);
+            HIPCK(p, hipGetLastError());
+            launch_lm_level_sync(d, lv, p->stream);
+        }
     }
     lap("landmark-group upload");
     // ---- structural exchange list of a sharded run (k_list_pack): every lower-triangle entry of the reduced system that can be
     // non-zero before the factorisation.  Everything else is zero on every rank and need not travel.
     d.xlist = nullptr; d.nxlist = 0;
+    if (sc_hit) { d.xlist = p->sc.xlist; d.nxlist = p->sc.nxlist; }
+    if (!sc_hit) {
+    BatchSwitch structure_scope(&p->sbatch, &p->sc.zero_log);
     if (p->world > 1) {
         std::vector<int32_t> xl;
         const int ld = p->ld;
@@ -1644,25 +1759,22 @@ static int prepare(plba_problem* p) {
         if (ptime) fprintf(stderr, "[prepare] dense system: %d dims, %d tiles, band %d sub-diagonal tiles -> %s\n", cv.Pd, T, hbt, p->band_ok ? "banded twisted solve in LDS" : p->twin_ok ? "multi-chain multi-launch factorisation" : "dense path");
         if (ptime && p->twin_ok) fprintf(stderr, "[prepare] %d chains, %d + %d dependent launches\n", p->twinv.nchains, p->twinv.nlaunch, p->twinv.T - p->twinv.m0 - 1);
     }
+    HIPCK(p, darr_flush());
+    // the structure is complete: remember it
+    p->sc.dd = p->dd; p->sc.alist = d.alist; p->sc.nalist = d.nalist; p->sc.xlist = d.xlist; p->sc.nxlist = d.nxlist; p->sc.Ninv = d.Ninv; p->sc.Nwork = d.Nwork; p->sc.dbgbuf = d.dbgbuf;
+    p->sc.chain_ok = p->chain_ok; p->sc.key.swap(skey); p->sc.valid = true;
+    }      // (!sc_hit)
+    if (ptime) fprintf(stderr, "[prepare] pose structure: %s (%ld hits, %ld misses on this handle)\n", sc_hit ? "the previous window's, kept" : "built", p->sc.hits, p->sc.misses);
     lap("exchange list, band");
     // ---- constant part of the pose-side Hessian: prior J0^T J0 scattered over the free kept vertices ----------------------
     if (p->pr_nv > 0 && p->rank == 0) {
+        // (round 5: scattered by a kernel.  It was a stream wait, a read-back of H, a 4.7 MB host image of the pose-side matrix and its upload
+        // through the bounce buffer — about a millisecond of EVERY BA call of the reference's steady state, which carries a prior.)
         const int n = p->pr_n;
         HIPCK(p, p->d_pr_H.alloc((size_t)n * n)); HIPCK(p, darr_flush());
         launch_ata(p->d_pr_J0.p, n, n, p->d_pr_H.p, n, p->stream);
-        std::vector<double> H((size_t)n * n), Hc((size_t)p->Ppad * p->ld, 0.0);
-        HIPCK(p, plba_stream_wait(p->stream));
-        HIPCK(p, plba_d2h(p, H.data(), p->d_pr_H.p, H.size() * 8));
-        for (int a = 0; a < p->pr_nv; ++a) {
-            if (pr_off[a] < 0) continue;
-            for (int b = 0; b < p->pr_nv; ++b) {
-                if (pr_off[b] < 0) continue;
-                for (int c = 0; c < p->pr_size[a]; ++c)
-                    for (int e = 0; e < p->pr_size[b]; ++e)
-                        Hc[(size_t)(pr_off[a] + c) * p->ld + pr_off[b] + e] = H[(size_t)(p->pr_idx[a] + c) * n + p->pr_idx[b] + e];
-            }
-        }
-        HIPCK(p, plba_h2d(p, p->d_Hconst.p, Hc.data(), Hc.size() * 8));
+        hipLaunchKernelGGL(k_prior_scatter, dim3((n * n + 255) / 256), dim3(256), 0, p->stream, p->d_pr_H.p, n, p->pr_nv, p->d_pr_off.p, p->d_pr_idx.p, p->d_pr_size.p, p->d_Hconst.p, p->ld);
+        HIPCK(p, hipGetLastError());
     }
     HIPCK(p, darr_flush());
     HIPCK(p, plba_stream_wait(p->stream));      // the uploads above were queued on the stream from host vectors that end here
@@ -1670,17 +1782,17 @@ static int prepare(plba_problem* p) {
     if (ptime) fprintf(stderr, "[prepare] %zu small buffers in the batch blocks: %.0f KB cleared, %.0f KB copied\n", p->batch.n_batched, p->batch.zused / 1024.0, p->batch.uused / 1024.0);
     // buffers this window did not re-create must not keep a pointer into the batch blocks, which now hold other buffers (the
     // failure class of the re-used-handle fault of round 4): the conditionally allocated ones are dropped when their stamp is old
-    p->d_imu_loc.expire(p->batch); p->d_ob_err.expire(p->batch); p->d_Ninvd.expire(p->batch); p->d_Ninv.expire(p->batch); p->d_pr_H.expire(p->batch);
-    p->d_lm_grp.expire(p->batch); p->d_lmg_slot.expire(p->batch); p->d_lmg_ob0.expire(p->batch); p->d_lmg_orig.expire(p->batch); p->d_lmg_blk_ij.expire(p->batch);
-    p->d_lmg_blk_start.expire(p->batch); p->d_lmg_blk_src.expire(p->batch); p->d_lmg_row_kf.expire(p->batch); p->d_lmg_row_start.expire(p->batch); p->d_lmg_row_src.expire(p->batch);
-    p->d_alist2.expire(p->batch); p->d_lmg_ws8.expire(p->batch); p->d_lmg_fixed.expire(p->batch); p->d_lmg_level.expire(p->batch); p->d_col_gather.expire(p->batch);
-    p->d_lmg_meas_pt.expire(p->batch); p->d_lmg_meas_ln.expire(p->batch); p->d_lmg_wt.expire(p->batch); p->d_lmg_chi.expire(p->batch); p->d_lmg_part.expire(p->batch);
-    p->d_twin_list.expire(p->batch); p->d_twin_perm.expire(p->batch); p->d_twin_xmap.expire(p->batch); p->d_twin_fac.expire(p->batch); p->d_cs_order.expire(p->batch);
-    p->d_xlist.expire(p->batch); p->d_alist.expire(p->batch); p->d_trow.expire(p->batch); p->d_bkf.expire(p->batch); p->d_esrc.expire(p->batch);
-    p->d_cidx.expire(p->batch); p->d_epos.expire(p->batch); p->d_seg_start.expire(p->batch); p->d_seg_col.expire(p->batch); p->d_pidx.expire(p->batch); p->d_ppos.expire(p->batch);
-    p->d_pslot.expire(p->batch); p->d_slotcol.expire(p->batch); p->d_kfpos.expire(p->batch); p->d_ekf.expire(p->batch); p->d_ukf.expire(p->batch);
-    p->d_Ldinv.expire(p->batch); p->d_Lsub.expire(p->batch); p->d_xd.expire(p->batch); p->d_Linvd.expire(p->batch); p->d_rd32d.expire(p->batch); p->d_flow_flagsd.expire(p->batch); p->d_chol_flagsd.expire(p->batch);
-    p->d_band_y.expire(p->batch); p->d_band_mid.expire(p->batch);
+    p->d_imu_loc.expire(); p->d_ob_err.expire(); p->d_Ninvd.expire(); p->d_Ninv.expire(); p->d_pr_H.expire();
+    p->d_lm_grp.expire(); p->d_lmg_slot.expire(); p->d_lmg_ob0.expire(); p->d_lmg_orig.expire(); p->d_lmg_blk_ij.expire();
+    p->d_lmg_blk_start.expire(); p->d_lmg_blk_src.expire(); p->d_lmg_row_kf.expire(); p->d_lmg_row_start.expire(); p->d_lmg_row_src.expire();
+    p->d_alist2.expire(); p->d_lmg_ws8.expire(); p->d_lmg_fixed.expire(); p->d_lmg_level.expire(); p->d_col_gather.expire();
+    p->d_lmg_meas_pt.expire(); p->d_lmg_meas_ln.expire(); p->d_lmg_wt.expire(); p->d_lmg_chi.expire(); p->d_lmg_part.expire();
+    p->d_twin_list.expire(); p->d_twin_perm.expire(); p->d_twin_xmap.expire(); p->d_twin_fac.expire(); p->d_cs_order.expire();
+    p->d_xlist.expire(); p->d_alist.expire(); p->d_trow.expire(); p->d_bkf.expire(); p->d_esrc.expire();
+    p->d_cidx.expire(); p->d_epos.expire(); p->d_seg_start.expire(); p->d_seg_col.expire(); p->d_pidx.expire(); p->d_ppos.expire();
+    p->d_pslot.expire(); p->d_slotcol.expire(); p->d_kfpos.expire(); p->d_ekf.expire(); p->d_ukf.expire();
+    p->d_Ldinv.expire(); p->d_Lsub.expire(); p->d_xd.expire(); p->d_Linvd.expire(); p->d_rd32d.expire(); p->d_flow_flagsd.expire(); p->d_chol_flagsd.expire();
+    p->d_band_y.expire(); p->d_band_mid.expire();
     p->cur = 0;
     p->saved_valid = true;
     p->dirty = false;
@@ -2326,6 +2438,29 @@ __global__ void k_lm_carry_gather(const double* __restrict__ cur, const double* 
     if (slot < Np_new && c >= 3) v = 0.0;      // (a point uses the first half of its slot)
     out[i] = v;
 }
+// new landmark-major measurement / weight arrays: entry g comes from the old arrays (src >= 0) or from the added observations (-(1 + a))
+__global__ void k_obs_carry_gather(const double* __restrict__ po_uv0, const double* __restrict__ lo_l0, const double* __restrict__ ob_w0, int Ep0,
+                                   const double* __restrict__ a_uv, const double* __restrict__ a_wp, const double* __restrict__ a_l, const double* __restrict__ a_wl,
+                                   const int32_t* __restrict__ src, int Ep1, int El1, double* __restrict__ po_uv1, double* __restrict__ lo_l1, double* __restrict__ ob_w1) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= Ep1 + El1) return;
+    const int sidx = src[g];
+    if (g < Ep1) {
+        const double* m = sidx >= 0 ? po_uv0 + 2 * (size_t)sidx : a_uv + 2 * (size_t)(-1 - sidx);
+        po_uv1[2 * (size_t)g] = m[0]; po_uv1[2 * (size_t)g + 1] = m[1];
+        ob_w1[g] = sidx >= 0 ? ob_w0[sidx] : a_wp[-1 - sidx];
+    } else {
+        const int l = g - Ep1;
+        const double* m = sidx >= 0 ? lo_l0 + 3 * (size_t)sidx : a_l + 3 * (size_t)(-1 - sidx);
+        for (int c = 0; c < 3; ++c) lo_l1[3 * (size_t)l + c] = m[c];
+        ob_w1[g] = sidx >= 0 ? ob_w0[(size_t)Ep0 + sidx] : a_wl[-1 - sidx];
+    }
+}
+int plba_get_sizes(const plba_problem* p, int32_t* out6) {
+    if (!p || !out6) return PLBA_ERR_INVALID;
+    out6[0] = p->K; out6[1] = p->Np; out6[2] = p->Nl; out6[3] = p->Ep; out6[4] = p->El; out6[5] = p->M;
+    return PLBA_OK;
+}
 int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, int32_t* line_map) {
     if (!p || !s) return PLBA_ERR_INVALID;
     if (p->world > 1) FAIL(p, PLBA_ERR_STATE, "plba_slide_window: a sharded problem takes a fresh upload");
@@ -2344,6 +2479,9 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
     if (!all_finite(s->xyz3, 3 * (size_t)s->Np_add) || !all_finite(s->sPeP6, 6 * (size_t)s->Nl_add) || !all_finite(s->uv2, 2 * (size_t)s->Ep_add) || !all_finite(s->l3, 3 * (size_t)s->El_add)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite landmark or observation");
     if (!all_finite(s->preint142, 142 * (size_t)s->M_add) || !all_finite(s->info_pvr81, 81 * (size_t)s->M_add)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite IMU edge");
     HIPCK(p, hipSetDevice(p->device));
+    const bool stime = (p->opt.diag & PLBA_DIAG_TIMING) != 0;
+    auto st0 = std::chrono::steady_clock::now();
+    auto slap = [&](const char* what) { if (!stime) return; auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[slide] %-30s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - st0).count()); st0 = t; };
     // ---- which landmarks / observations stay -------------------------------------------------------------------------------------
     std::vector<int32_t> pmap(Np0), lmap(Nl0);
     std::vector<uint8_t> pdrop(Np0, 0), ldrop(Nl0, 0);
@@ -2371,35 +2509,35 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
     for (int m = 0; m < s->M_add; ++m) if (s->imu_kf_i[m] < 0 || s->imu_kf_i[m] >= K1 || s->imu_kf_j[m] < 0 || s->imu_kf_j[m] >= K1) FAIL(p, PLBA_ERR_INVALID, "added imu edge %d: keyframe index (new numbering)", m);
     // ---- host copy of the graph: observations compacted, shifted and merged landmark by landmark (into temporaries: nothing of the problem
     // is touched before every check has passed) ----------------------------------------------------------------------------------------
-    struct ObsList { std::vector<int32_t> lm, kf; std::vector<double> meas, w; };
-    auto merge = [&](int N0, int Nadd, int E0, int Eadd, const std::vector<int32_t>& map, const std::vector<int32_t>& ob_lm, const std::vector<int32_t>& ob_kf, const std::vector<double>& meas, int nm,
-                     const std::vector<double>& wt, const uint8_t* drop_obs, const int32_t* a_lm, const int32_t* a_kf, const double* a_meas, const double* a_w, ObsList& out) -> int {
-        out.lm.reserve((size_t)E0 + Eadd); out.kf.reserve((size_t)E0 + Eadd); out.meas.reserve(((size_t)E0 + Eadd) * nm); out.w.reserve((size_t)E0 + Eadd);
+    // (round 5: only the integer lists — landmark and keyframe of every observation — are rebuilt on the host; `src` says where each new
+    // observation's measurement and weight come from: an index into the OLD device arrays, or -(1 + a) for the a-th added one)
+    struct ObsList { std::vector<int32_t> lm, kf, src; };
+    auto merge = [&](int N0, int Nadd, int E0, int Eadd, const std::vector<int32_t>& map, const std::vector<int32_t>& ob_lm, const std::vector<int32_t>& ob_kf,
+                     const uint8_t* drop_obs, const int32_t* a_lm, const int32_t* a_kf, ObsList& out) -> int {
+        out.lm.resize((size_t)E0 + Eadd); out.kf.resize((size_t)E0 + Eadd); out.src.resize((size_t)E0 + Eadd);
         int e = 0, a = 0, kept = 0;
+        size_t n = 0;
         for (int l = 0; l < N0 + Nadd; ++l) {
             const int nl = l < N0 ? map[l] : kept + (l - N0);      // (survivors precede the added landmarks: `kept` is final when l reaches N0)
             if (l < N0 && nl >= 0) ++kept;
+            const size_t first = n;
             for (; e < E0 && ob_lm[e] == l; ++e) {
                 if (nl < 0 || (drop_obs && drop_obs[e])) continue;
-                out.lm.push_back(nl); out.kf.push_back(ob_kf[e] - nd);
-                for (int c = 0; c < nm; ++c) out.meas.push_back(meas[(size_t)e * nm + c]);
-                out.w.push_back(wt[e]);
+                out.lm[n] = nl; out.kf[n] = ob_kf[e] - nd; out.src[n] = e; ++n;
             }
-            for (; a < Eadd && a_lm[a] == l; ++a) {
-                out.lm.push_back(nl); out.kf.push_back(a_kf[a]);
-                for (int c = 0; c < nm; ++c) out.meas.push_back(a_meas[(size_t)a * nm + c]);
-                out.w.push_back(a_w ? (double)(float)a_w[a] : 1.0);      // const float& invSigma2 (mapHandler.cpp:5340)
-            }
+            for (; a < Eadd && a_lm[a] == l; ++a) { out.lm[n] = nl; out.kf[n] = a_kf[a]; out.src[n] = -(1 + a); ++n; }
+            // two observations of one landmark from one keyframe are refused, as at upload
+            for (size_t x = first; x < n; ++x) for (size_t y = x + 1; y < n; ++y)
+                if (out.kf[y] == out.kf[x]) FAIL(p, PLBA_ERR_INVALID, "landmark %d observed twice by keyframe %d", nl, out.kf[x]);
         }
-        // two observations of one landmark from one keyframe are refused, as at upload
-        for (size_t x = 0; x < out.lm.size(); ++x)
-            for (size_t y = x + 1; y < out.lm.size() && out.lm[y] == out.lm[x]; ++y)
-                if (out.kf[y] == out.kf[x]) FAIL(p, PLBA_ERR_INVALID, "landmark %d observed twice by keyframe %d", out.lm[x], out.kf[x]);
+        out.lm.resize(n); out.kf.resize(n); out.src.resize(n);
         return PLBA_OK;
     };
+    slap("checks, survivors");
     ObsList npo, nlo;
-    if (int rc = merge(Np0, s->Np_add, Ep0, s->Ep_add, pmap, p->po_pt, p->po_kf, p->po_uv, 2, p->po_w, s->drop_point_obs, s->po_pt, s->po_kf, s->uv2, s->po_inv_sigma2, npo)) return rc;
-    if (int rc = merge(Nl0, s->Nl_add, El0, s->El_add, lmap, p->lo_ln, p->lo_kf, p->lo_l, 3, p->lo_w, s->drop_line_obs, s->lo_ln, s->lo_kf, s->l3, s->lo_inv_sigma2, nlo)) return rc;
+    if (int rc = merge(Np0, s->Np_add, Ep0, s->Ep_add, pmap, p->po_pt, p->po_kf, s->drop_point_obs, s->po_pt, s->po_kf, npo)) return rc;
+    if (int rc = merge(Nl0, s->Nl_add, El0, s->El_add, lmap, p->lo_ln, p->lo_kf, s->drop_line_obs, s->lo_ln, s->lo_kf, nlo)) return rc;
+    slap("observation lists merged");
     for (int m = 0; m < s->M_add; ++m) {      // bias vertices of the added edges' keyframes (new numbering: kept ones shifted, added ones from the call)
         for (int kk : {s->imu_kf_i[m], s->imu_kf_j[m]}) {
             const int vb = kk < K0 - nd ? p->vid_bias[kk + nd] : (s->vid_bias ? s->vid_bias[kk - (K0 - nd)] : -1);
@@ -2431,6 +2569,7 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
         if (s->fixed_bias) for (int k = 0; k < K1; ++k) fb[k] = s->fixed_bias[k];
         p->kf0.swap(kf1); p->vid_pvr.swap(vp); p->vid_bias.swap(vb); p->fix_pvr.swap(fp); p->fix_bias.swap(fb);
     }
+    slap("keyframes (read-back)");
     // ---- landmarks: the new array is gathered ON THE DEVICE from the current estimates; only the added ones go up ----------------------------
     {
         const int L1 = Np1 + Nl1;
@@ -2451,8 +2590,34 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
         HIPCK(p, plba_stream_wait(p->stream));      // (`src` / `add` / `dadd` end here)
         p->carry_pts = true; p->carry_lns = true;
     }
-    p->po_pt.swap(npo.lm); p->po_kf.swap(npo.kf); p->po_uv.swap(npo.meas); p->po_w.swap(npo.w);
-    p->lo_ln.swap(nlo.lm); p->lo_kf.swap(nlo.kf); p->lo_l.swap(nlo.meas); p->lo_w.swap(nlo.w);
+    slap("landmark carry");
+    // ---- measurements and weights: gathered on the device from the old landmark-major arrays + the added observations -----------------------
+    {
+        const int Ep1 = (int)npo.lm.size(), El1 = (int)nlo.lm.size(), E1 = Ep1 + El1;
+        std::vector<int32_t> src(std::max(E1, 1));
+        if (Ep1) memcpy(src.data(), npo.src.data(), (size_t)Ep1 * 4);
+        if (El1) memcpy(src.data() + Ep1, nlo.src.data(), (size_t)El1 * 4);
+        std::vector<double> add(std::max<size_t>(3 * (size_t)s->Ep_add + 4 * (size_t)s->El_add, 1));      // [uv (2 Ep_add) | w (Ep_add) | l (3 El_add) | w (El_add)]
+        double* a_uv = add.data(); double* a_wp = a_uv + 2 * (size_t)s->Ep_add; double* a_l = a_wp + s->Ep_add; double* a_wl = a_l + 3 * (size_t)s->El_add;
+        if (s->Ep_add) memcpy(a_uv, s->uv2, 16 * (size_t)s->Ep_add);
+        for (int e = 0; e < s->Ep_add; ++e) a_wp[e] = s->po_inv_sigma2 ? (double)(float)s->po_inv_sigma2[e] : 1.0;      // const float& invSigma2 (mapHandler.cpp:5340)
+        if (s->El_add) memcpy(a_l, s->l3, 24 * (size_t)s->El_add);
+        for (int e = 0; e < s->El_add; ++e) a_wl[e] = s->lo_inv_sigma2 ? (double)(float)s->lo_inv_sigma2[e] : 1.0;
+        DArrStreamScope staged(p->stream, p->have_ctx ? p->ctx.stage : nullptr);
+        DArr<double> dadd;
+        HIPCK(p, p->d_obs_carry_src.upload(src)); HIPCK(p, dadd.upload(add));
+        if (p->carry_obs_pending) FAIL(p, PLBA_ERR_STATE, "plba_slide_window: the previous slide was never built on the device (call plba_optimize between two slides)");
+        HIPCK(p, p->d_po_uv_c.alloc(std::max<size_t>(2 * (size_t)Ep1, 1), false)); HIPCK(p, p->d_lo_l_c.alloc(std::max<size_t>(3 * (size_t)El1, 1), false)); HIPCK(p, p->d_ob_w_c.alloc(std::max<size_t>((size_t)E1, 1), false));
+        const size_t o_wp = 2 * (size_t)s->Ep_add, o_l = o_wp + s->Ep_add, o_wl = o_l + 3 * (size_t)s->El_add;
+        if (E1) hipLaunchKernelGGL(k_obs_carry_gather, dim3((E1 + 255) / 256), dim3(256), 0, p->stream, p->d_po_uv.p, p->d_lo_l.p, p->d_ob_w.p, Ep0, dadd.p, dadd.p + o_wp, dadd.p + o_l, dadd.p + o_wl,
+                                   p->d_obs_carry_src.p, Ep1, El1, p->d_po_uv_c.p, p->d_lo_l_c.p, p->d_ob_w_c.p);
+        HIPCK(p, hipGetLastError());
+        HIPCK(p, plba_stream_wait(p->stream));      // (`src` / `add` / `dadd` end here)
+        p->carry_po = true; p->carry_lo = true; p->carry_obs_pending = true;
+        p->po_uv.resize(2 * (size_t)Ep1); p->po_w.resize(Ep1); p->lo_l.resize(3 * (size_t)El1); p->lo_w.resize(El1);      // (stale: carry_po / carry_lo)
+    }
+    p->po_pt.swap(npo.lm); p->po_kf.swap(npo.kf);
+    p->lo_ln.swap(nlo.lm); p->lo_kf.swap(nlo.kf);
     p->Ep = (int)p->po_pt.size(); p->El = (int)p->lo_ln.size();
     // fixed flags and the (stale for kept entries: carry_*) estimate arrays follow the new numbering
     {
@@ -2483,6 +2648,7 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
         p->imu_i.swap(ni); p->imu_j.swap(nj); p->imu_pre.swap(npre); p->imu_ipvr.swap(nip); p->imu_ibias.swap(nib);
         p->M = (int)p->imu_i.size();
     }
+    slap("observation carry, imu");
     p->K = K1; p->Np = Np1; p->Nl = Nl1;
     p->level.assign((size_t)p->Ep + p->El, 0);      // a new graph: every edge at level 0
     p->dirty = true;

@@ -106,6 +106,9 @@ struct DevBatch {
     bool take_upload(size_t bytes, void** dev, void** host) { const size_t need = al(bytes); if (!u || !uh || uused + need > ucap) return false; *dev = u + uused; *host = uh + uused; uused += need; ++n_batched; return true; }
 };
 inline DevBatch*& darr_batch() { static thread_local DevBatch* b = nullptr; return b; }
+// where the zero-filled (non-batched) buffers of the current scope are noted, so that a window which re-uses the previous window's pose
+// structure (prepare(): structure cache) can clear them again without allocating them again
+inline std::vector<std::pair<void*, size_t>>*& darr_zero_log() { static thread_local std::vector<std::pair<void*, size_t>>* l = nullptr; return l; }
 inline hipError_t darr_flush() {
     DevBatch* b = darr_batch();
     if (!b) return hipSuccess;
@@ -122,17 +125,18 @@ struct DArr {
     size_t cls = 0;          // pool size class of the block behind p (batched: its aligned size)
     bool batched = false;    // p points into the problem's batch blocks (DevBatch), not at a pool block
     unsigned bgen = 0;       // ... of this generation of the blocks (a batched buffer that the next prepare() does not re-create must not stay usable)
+    const DevBatch* bsrc = nullptr;      // ... of this batch (the per-window one or the pose structure's)
     void drop_batched() { if (batched) { p = nullptr; n = 0; cls = 0; batched = false; } }
     // null unless the buffer is a pool block or a batched one of the CURRENT generation: for the conditionally allocated buffers
     // (d_imu_loc, d_ob_err, d_Ninvd, d_pr_H, d_lmg_*), whose previous window's pointer would alias another buffer's memory
-    T* checked(const DevBatch& b) const { return (batched && bgen != b.gen) ? nullptr : p; }
-    void expire(const DevBatch& b) { if (batched && bgen != b.gen) drop_batched(); }
+    T* checked() const { return (batched && bsrc && bgen != bsrc->gen) ? nullptr : p; }
+    void expire() { if (batched && bsrc && bgen != bsrc->gen) drop_batched(); }
     hipError_t alloc(size_t cnt, bool zero = true) {
         if (cnt == 0) cnt = 1;
         if (DevBatch* b = darr_batch()) {
             drop_batched();      // the batch blocks start over with every prepare()
             if (zero && cnt * sizeof(T) <= DevBatch::SMALL)
-                if (void* q = b->take_zero(cnt * sizeof(T))) { release(); p = (T*)q; n = cnt; cls = DevBatch::al(cnt * sizeof(T)); batched = true; bgen = b->gen; return hipSuccess; }
+                if (void* q = b->take_zero(cnt * sizeof(T))) { release(); p = (T*)q; n = cnt; cls = DevBatch::al(cnt * sizeof(T)); batched = true; bgen = b->gen; bsrc = b; return hipSuccess; }
         }
         if (!p || cnt * sizeof(T) > cls) {
             release();
@@ -141,6 +145,7 @@ struct DArr {
         }
         n = cnt;
         if (zero) {
+            if (auto* zl = darr_zero_log()) zl->push_back({(void*)p, n * sizeof(T)});
             if (hipStream_t s = darr_stream()) return hipMemsetAsync(p, 0, n * sizeof(T), s);
             // hipMemset runs on the legacy null stream and may return before it completes; the library's
             // kernels run on a NON-blocking stream that does not order against it, so drain it here.
@@ -157,7 +162,7 @@ struct DArr {
             void *dev, *host;
             if (!h.empty() && h.size() * sizeof(T) <= DevBatch::SMALL && b->take_upload(h.size() * sizeof(T), &dev, &host)) {
                 drop_batched(); release();
-                p = (T*)dev; n = h.size(); cls = DevBatch::al(h.size() * sizeof(T)); batched = true; bgen = b->gen;
+                p = (T*)dev; n = h.size(); cls = DevBatch::al(h.size() * sizeof(T)); batched = true; bgen = b->gen; bsrc = b;
                 memcpy(host, h.data(), h.size() * sizeof(T));
                 return hipSuccess;
             }
@@ -185,6 +190,7 @@ struct DArr {
         return hipMemcpyAsync(p, src, cnt * sizeof(T), hipMemcpyHostToDevice, darr_stream());
     }
     void release() { if (p && !batched) dev_pool().put(p, cls); p = nullptr; n = 0; cls = 0; batched = false; }
+    void swap(DArr& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cls, o.cls); std::swap(batched, o.batched); std::swap(bgen, o.bgen); std::swap(bsrc, o.bsrc); }
     DArr() = default;
     DArr(const DArr&) = delete;
     DArr& operator=(const DArr&) = delete;
@@ -202,6 +208,14 @@ struct LmHost {
     std::vector<int32_t> lm_slot, lm_ob0, ob_orig, blk_ij, blk_start, blk_src, row_kf, row_start, row_src;
     std::vector<uint8_t> lm_ws8, lm_fixed, cov;
     std::vector<double> meas_pt, meas_ln, ob_wt;
+    // where lm_fill_groups writes the per-landmark / per-observation tables: straight into the pinned staging area when it has room (round 5:
+    // the tables were filled into the vectors above and copied to the staging area a second time — 4 MB of memcpy per BA call at configs[2]),
+    // else into the vectors
+    bool staged = false;
+    int32_t *p_lm_slot = nullptr, *p_lm_ob0 = nullptr, *p_ob_orig = nullptr;
+    uint8_t *p_lm_ws8 = nullptr, *p_lm_fixed = nullptr;
+    double *p_meas_pt = nullptr, *p_meas_ln = nullptr, *p_ob_wt = nullptr;
+    size_t n_lm = 0, n_ob = 0, n_meas_pt = 0, n_meas_ln = 0;
     // scratch of the build
     std::vector<int32_t> kmin, kmax, ord, tmp, cnt, ordall, stamp, span_at, span_end, span_ob0, gcut, bad, c2, pos;
     std::vector<std::pair<int64_t, int32_t>> blk_c, row_c;
@@ -242,6 +256,24 @@ struct plba_problem {
     plba::DArr<int32_t> d_twin_perm, d_twin_xmap, d_twin_fac, d_cs_order;
     plba::DArr<char> d_batch_z, d_batch_u;      // the blocks prepare()'s small buffers are bump-allocated from (plba::DevBatch)
     plba::DevBatch batch;
+    // Structure cache (round 5).  Everything prepare() derives from the POSE side of the window — vertex layout, chain elimination maps and
+    // buffers, the structural assembly / exchange lists, the band and the multi-chain plan — is a function of a small key (keyframe
+    // layout, IMU edge topology, prior vertices, the keyframe co-observation map, options).  Consecutive sliding windows have the same
+    // key: the next window then keeps the previous one's device buffers (they live in a batch of their own, `sbatch`, which only starts
+    // over on a miss), clears the zero-initialised ones again and skips 0.3 ms of host work per BA call at configs[2].
+    struct StructCache {
+        bool valid = false;
+        std::vector<int32_t> key;
+        plba::DevBuf dd;                                   // the dense system's view as the miss left it (per-window fields are refreshed)
+        const int32_t *alist = nullptr, *xlist = nullptr, *alist2 = nullptr; int nalist = 0, nxlist = 0, nalist2 = 0;
+        const uint8_t* col_gather = nullptr;
+        double *Ninv = nullptr, *Nwork = nullptr, *dbgbuf = nullptr;
+        bool chain_ok = false;
+        std::vector<std::pair<void*, size_t>> zero_log;     // pool buffers the miss zero-filled
+        long hits = 0, misses = 0;
+    } sc;
+    plba::DArr<char> d_sbatch_z, d_sbatch_u;
+    plba::DevBatch sbatch;
     plba::DArr<double> d_wtw;          // W^T W tiles of the chain Schur complement (fused landmark path, one GPU: formed in the gather launch)
     plba::DArr<double> d_twin_alt;     // ... and so are its landmark blocks and the pose-side assembly     // the next iteration's linearisation is already in the stream (enqueued behind k_decide)
     // ---- host copy of the uploaded graph -------------------------------------------------------
@@ -281,6 +313,12 @@ struct plba_problem {
     plba::DArr<double> d_lm_carry;
     plba::DArr<int32_t> d_lm_carry_src;
     bool carry_pts = false, carry_lns = false;
+    // ... and neither do the kept observations' measurements and weights: the slide gathers the new landmark-major arrays on the device
+    // (into the *_c buffers: `carry_obs_pending`, swapped in by prepare()); po_uv / po_w / lo_l / lo_w on the host are then stale
+    // (carry_po / carry_lo; plba_set_point_obs / plba_set_line_obs clear them)
+    plba::DArr<double> d_po_uv_c, d_lo_l_c, d_ob_w_c;
+    plba::DArr<int32_t> d_obs_carry_src;
+    bool carry_po = false, carry_lo = false, carry_obs_pending = false;
     plba::DArr<double> d_po_uv, d_lo_l, d_ob_w, d_ob_chi2, d_erec, d_erec2;
     plba::DArr<int32_t> d_ob_kf, d_ob_slot, d_lm_start, d_off_pvr, d_off_bias;
     plba::DArr<uint8_t> d_level, d_lm_fixed, d_lm_active, d_depth;
