@@ -179,7 +179,7 @@ int plba_set_keyframes(plba_problem* p, int K, const int32_t* vid_pvr, const int
     if (!p || K <= 0 || !vid_pvr || !P3 || !V3 || !q4) return PLBA_ERR_INVALID;
     for (int k = 1; k < K; ++k) if (vid_pvr[k] <= vid_pvr[k - 1]) FAIL(p, PLBA_ERR_INVALID, "keyframe vertex ids must be ascending");
     if (!all_finite(P3, 3 * (size_t)K) || !all_finite(V3, 3 * (size_t)K) || !all_finite(q4, 4 * (size_t)K)) FAIL(p, PLBA_ERR_NUMERIC, "non-finite keyframe state");
-    p->K = K;
+    p->K = K; p->carry_kf = false;
     p->vid_pvr.assign(vid_pvr, vid_pvr + K);
     p->vid_bias.assign(K, -1);
     p->kf0.assign((size_t)K * KF_STRIDE, 0.0);
@@ -985,7 +985,10 @@ static int prepare(plba_problem* p) {
     }
     // ---- upload ----------------------------------------------------------------------------------------------------
     const size_t sysn = (size_t)(p->Ppad + TILE) * p->ld;
-    HIPCK(p, p->d_kf[0].upload(p->kf0)); HIPCK(p, p->d_kf[1].upload(p->kf0)); HIPCK(p, p->d_kf_saved.upload(p->kf0));
+    if (p->carry_kf) {      // a slid window: the kept keyframes' states never left the device (plba_slide_window)
+        if (p->d_kf_carry.n < (size_t)K * KF_STRIDE) FAIL(p, PLBA_ERR_STATE, "carried keyframe states do not fit the window (internal error)");
+        for (DArr<double>* dst : {&p->d_kf[0], &p->d_kf[1], &p->d_kf_saved}) { HIPCK(p, dst->alloc((size_t)K * KF_STRIDE, false)); HIPCK(p, hipMemcpyAsync(dst->p, p->d_kf_carry.p, (size_t)K * KF_STRIDE * 8, hipMemcpyDeviceToDevice, p->stream)); }
+    } else { HIPCK(p, p->d_kf[0].upload(p->kf0)); HIPCK(p, p->d_kf[1].upload(p->kf0)); HIPCK(p, p->d_kf_saved.upload(p->kf0)); }
     // the landmarks' three images (current, trial, saved): one pass through the staging area, two copies on the device (1.2 MB each at configs[2])
     if (carry_all) {
         const size_t nlm = std::max<size_t>((size_t)L * 6, 1);
@@ -2512,31 +2515,45 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
     // (round 5: only the integer lists — landmark and keyframe of every observation — are rebuilt on the host; `src` says where each new
     // observation's measurement and weight come from: an index into the OLD device arrays, or -(1 + a) for the a-th added one)
     struct ObsList { std::vector<int32_t> lm, kf, src; };
-    auto merge = [&](int N0, int Nadd, int E0, int Eadd, const std::vector<int32_t>& map, const std::vector<int32_t>& ob_lm, const std::vector<int32_t>& ob_kf,
+    // The old list is landmark-major and so is the added one: the merged list is the old one with the dropped landmarks' stretches cut
+    // out and each added run spliced in behind its landmark's last old observation.  Between two splice points the old observations are
+    // copied in one tight loop (new landmark index through the map, keyframe index shifted, source = old position); only a landmark that
+    // RECEIVES observations is checked for a keyframe seeing it twice (the old ones were checked when they were uploaded).
+    auto merge = [&](int N0, int Nadd, int E0, int Eadd, const std::vector<int32_t>& map, int nkept, const std::vector<int32_t>& ob_lm, const std::vector<int32_t>& ob_kf,
                      const uint8_t* drop_obs, const int32_t* a_lm, const int32_t* a_kf, ObsList& out) -> int {
         out.lm.resize((size_t)E0 + Eadd); out.kf.resize((size_t)E0 + Eadd); out.src.resize((size_t)E0 + Eadd);
-        int e = 0, a = 0, kept = 0;
+        int32_t* olm = out.lm.data(); int32_t* okf = out.kf.data(); int32_t* osrc = out.src.data();
+        const int32_t* mp = map.data(); const int32_t* il = ob_lm.data(); const int32_t* ik = ob_kf.data();
         size_t n = 0;
-        for (int l = 0; l < N0 + Nadd; ++l) {
-            const int nl = l < N0 ? map[l] : kept + (l - N0);      // (survivors precede the added landmarks: `kept` is final when l reaches N0)
-            if (l < N0 && nl >= 0) ++kept;
-            const size_t first = n;
-            for (; e < E0 && ob_lm[e] == l; ++e) {
-                if (nl < 0 || (drop_obs && drop_obs[e])) continue;
-                out.lm[n] = nl; out.kf[n] = ob_kf[e] - nd; out.src[n] = e; ++n;
-            }
-            for (; a < Eadd && a_lm[a] == l; ++a) { out.lm[n] = nl; out.kf[n] = a_kf[a]; out.src[n] = -(1 + a); ++n; }
-            // two observations of one landmark from one keyframe are refused, as at upload
-            for (size_t x = first; x < n; ++x) for (size_t y = x + 1; y < n; ++y)
-                if (out.kf[y] == out.kf[x]) FAIL(p, PLBA_ERR_INVALID, "landmark %d observed twice by keyframe %d", nl, out.kf[x]);
+        auto copy_old = [&](int e0, int e1) {      // old observations [e0, e1)
+            if (!drop_obs) { for (int e = e0; e < e1; ++e) { const int nl = mp[il[e]]; olm[n] = nl; okf[n] = ik[e] - nd; osrc[n] = e; n += nl >= 0; } }
+            else for (int e = e0; e < e1; ++e) { const int nl = mp[il[e]]; olm[n] = nl; okf[n] = ik[e] - nd; osrc[n] = e; n += (nl >= 0) & !drop_obs[e]; }
+        };
+        int e = 0, a = 0;
+        while (a < Eadd) {
+            const int l = a_lm[a];
+            int a1 = a;
+            while (a1 < Eadd && a_lm[a1] == l) ++a1;
+            const int nl = l < N0 ? mp[l] : nkept + (l - N0);
+            // old observations up to and including landmark l's (none for an added landmark: those come after every old one)
+            const int e1 = l < N0 ? (int)(std::upper_bound(il + e, il + E0, l) - il) : E0;
+            const size_t before = n;
+            copy_old(e, e1);
+            e = e1;
+            size_t first = n;      // where landmark l's own (kept) observations start in the output
+            while (first > before && olm[first - 1] == nl) --first;
+            for (int q = a; q < a1; ++q) { olm[n] = nl; okf[n] = a_kf[q]; osrc[n] = -(1 + q); ++n; }
+            for (size_t x = first; x < n; ++x) for (size_t y = std::max(x + 1, n - (size_t)(a1 - a)); y < n; ++y)
+                if (okf[y] == okf[x]) FAIL(p, PLBA_ERR_INVALID, "landmark %d observed twice by keyframe %d", nl, okf[x]);
+            a = a1;
         }
+        copy_old(e, E0);
         out.lm.resize(n); out.kf.resize(n); out.src.resize(n);
         return PLBA_OK;
     };
-    slap("checks, survivors");
     ObsList npo, nlo;
-    if (int rc = merge(Np0, s->Np_add, Ep0, s->Ep_add, pmap, p->po_pt, p->po_kf, s->drop_point_obs, s->po_pt, s->po_kf, npo)) return rc;
-    if (int rc = merge(Nl0, s->Nl_add, El0, s->El_add, lmap, p->lo_ln, p->lo_kf, s->drop_line_obs, s->lo_ln, s->lo_kf, nlo)) return rc;
+    if (int rc = merge(Np0, s->Np_add, Ep0, s->Ep_add, pmap, Npk, p->po_pt, p->po_kf, s->drop_point_obs, s->po_pt, s->po_kf, npo)) return rc;
+    if (int rc = merge(Nl0, s->Nl_add, El0, s->El_add, lmap, Nlk, p->lo_ln, p->lo_kf, s->drop_line_obs, s->lo_ln, s->lo_kf, nlo)) return rc;
     slap("observation lists merged");
     for (int m = 0; m < s->M_add; ++m) {      // bias vertices of the added edges' keyframes (new numbering: kept ones shifted, added ones from the call)
         for (int kk : {s->imu_kf_i[m], s->imu_kf_j[m]}) {
@@ -2544,20 +2561,19 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
             if (vb < 0) FAIL(p, PLBA_ERR_INVALID, "added imu edge %d: keyframe without bias vertex", m);
         }
     }
-    // ---- keyframes: the kept ones' current estimates come back from the device (K x 24 doubles), the added ones follow ----------------
-    HIPCK(p, plba_stream_wait(p->stream));
+    // ---- keyframes: the kept ones' current states are copied ON THE DEVICE behind the added ones' upload (round 5: they came back to
+    // the host first — a blocking read-back per slide) -------------------------------------------------------------------------------------
+    DArrStreamScope staged(p->stream, p->have_ctx ? p->ctx.stage : nullptr);      // the slide's uploads share ONE wait, at its end
+    std::vector<double> kf_add((size_t)std::max(s->K_add, 1) * KF_STRIDE, 0.0);
+    DArr<double> d_kf_add, dadd_lm, dadd_ob;
+    std::vector<int32_t> h_src_lm, h_src_ob;      // (function scope: a queued upload that found no staging room reads the host vector until the wait)
+    std::vector<double> h_add_lm, h_add_ob;
     {
-        std::vector<double> cur((size_t)K0 * KF_STRIDE);
-        HIPCK(p, plba_d2h(p, cur.data(), p->dv.kf[p->cur], cur.size() * 8));
-        std::vector<double> kf1((size_t)K1 * KF_STRIDE, 0.0);
         std::vector<int32_t> vp(K1), vb(K1, -1);
         std::vector<uint8_t> fp(K1, 0), fb(K1, 0);
-        for (int k = nd; k < K0; ++k) {
-            memcpy(&kf1[(size_t)(k - nd) * KF_STRIDE], &cur[(size_t)k * KF_STRIDE], KF_STRIDE * 8);
-            vp[k - nd] = p->vid_pvr[k]; vb[k - nd] = p->vid_bias[k]; fp[k - nd] = p->fix_pvr[k]; fb[k - nd] = p->fix_bias[k];
-        }
+        for (int k = nd; k < K0; ++k) { vp[k - nd] = p->vid_pvr[k]; vb[k - nd] = p->vid_bias[k]; fp[k - nd] = p->fix_pvr[k]; fb[k - nd] = p->fix_bias[k]; }
         for (int k = 0; k < s->K_add; ++k) {
-            double* o = &kf1[(size_t)(K0 - nd + k) * KF_STRIDE];
+            double* o = &kf_add[(size_t)k * KF_STRIDE];
             memcpy(o, s->P3 + 3 * k, 24); memcpy(o + 3, s->V3 + 3 * k, 24); memcpy(o + 6, s->q_xyzw4 + 4 * k, 32);
             if (s->bg3) memcpy(o + 10, s->bg3 + 3 * k, 24);
             if (s->ba3) memcpy(o + 13, s->ba3 + 3 * k, 24);
@@ -2567,52 +2583,54 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
         }
         if (s->fixed_pvr) for (int k = 0; k < K1; ++k) fp[k] = s->fixed_pvr[k];
         if (s->fixed_bias) for (int k = 0; k < K1; ++k) fb[k] = s->fixed_bias[k];
-        p->kf0.swap(kf1); p->vid_pvr.swap(vp); p->vid_bias.swap(vb); p->fix_pvr.swap(fp); p->fix_bias.swap(fb);
+        HIPCK(p, p->d_kf_carry.alloc((size_t)K1 * KF_STRIDE, false));
+        HIPCK(p, hipMemcpyAsync(p->d_kf_carry.p, p->dv.kf[p->cur] + (size_t)nd * KF_STRIDE, (size_t)(K0 - nd) * KF_STRIDE * 8, hipMemcpyDeviceToDevice, p->stream));
+        if (s->K_add) { HIPCK(p, d_kf_add.upload(kf_add)); HIPCK(p, hipMemcpyAsync(p->d_kf_carry.p + (size_t)(K0 - nd) * KF_STRIDE, d_kf_add.p, (size_t)s->K_add * KF_STRIDE * 8, hipMemcpyDeviceToDevice, p->stream)); }
+        p->kf0.assign((size_t)K1 * KF_STRIDE, 0.0);      // (stale: carry_kf)
+        p->carry_kf = true;
+        p->vid_pvr.swap(vp); p->vid_bias.swap(vb); p->fix_pvr.swap(fp); p->fix_bias.swap(fb);
     }
-    slap("keyframes (read-back)");
+    slap("keyframes");
     // ---- landmarks: the new array is gathered ON THE DEVICE from the current estimates; only the added ones go up ----------------------------
     {
         const int L1 = Np1 + Nl1;
-        std::vector<int32_t> src(std::max(L1, 1), 0);
+        std::vector<int32_t>& src = h_src_lm; src.assign(std::max(L1, 1), 0);
         for (int i = 0; i < Np0; ++i) if (pmap[i] >= 0) src[pmap[i]] = i;
         for (int i = 0; i < s->Np_add; ++i) src[Npk + i] = -(1 + i);
         for (int i = 0; i < Nl0; ++i) if (lmap[i] >= 0) src[Np1 + lmap[i]] = Np0 + i;
         for (int i = 0; i < s->Nl_add; ++i) src[Np1 + Nlk + i] = -(1 + s->Np_add + i);
-        std::vector<double> add((size_t)std::max(s->Np_add + s->Nl_add, 1) * 6, 0.0);
+        std::vector<double>& add = h_add_lm; add.assign((size_t)std::max(s->Np_add + s->Nl_add, 1) * 6, 0.0);
         for (int i = 0; i < s->Np_add; ++i) memcpy(&add[(size_t)i * 6], s->xyz3 + 3 * (size_t)i, 24);
         for (int i = 0; i < s->Nl_add; ++i) memcpy(&add[(size_t)(s->Np_add + i) * 6], s->sPeP6 + 6 * (size_t)i, 48);
-        DArrStreamScope staged(p->stream, p->have_ctx ? p->ctx.stage : nullptr);
-        DArr<double> dadd;
-        HIPCK(p, p->d_lm_carry_src.upload(src)); HIPCK(p, dadd.upload(add));
+        // (uploads go through the pinned staging area — copied there at once, so `src` / `add` may end with this block; the device buffers
+        // dadd_* live until the slide's one wait at its end)
+        HIPCK(p, p->d_lm_carry_src.upload(src)); HIPCK(p, dadd_lm.upload(add));
         HIPCK(p, p->d_lm_carry.alloc(std::max<size_t>((size_t)L1 * 6, 1), false));
-        if (L1) hipLaunchKernelGGL(k_lm_carry_gather, dim3((L1 * 6 + 255) / 256), dim3(256), 0, p->stream, p->dv.lm[p->cur], dadd.p, p->d_lm_carry_src.p, Np1, L1, p->d_lm_carry.p);
+        if (L1) hipLaunchKernelGGL(k_lm_carry_gather, dim3((L1 * 6 + 255) / 256), dim3(256), 0, p->stream, p->dv.lm[p->cur], dadd_lm.p, p->d_lm_carry_src.p, Np1, L1, p->d_lm_carry.p);
         HIPCK(p, hipGetLastError());
-        HIPCK(p, plba_stream_wait(p->stream));      // (`src` / `add` / `dadd` end here)
         p->carry_pts = true; p->carry_lns = true;
     }
     slap("landmark carry");
     // ---- measurements and weights: gathered on the device from the old landmark-major arrays + the added observations -----------------------
     {
         const int Ep1 = (int)npo.lm.size(), El1 = (int)nlo.lm.size(), E1 = Ep1 + El1;
-        std::vector<int32_t> src(std::max(E1, 1));
+        std::vector<int32_t>& src = h_src_ob; src.resize(std::max(E1, 1));
         if (Ep1) memcpy(src.data(), npo.src.data(), (size_t)Ep1 * 4);
         if (El1) memcpy(src.data() + Ep1, nlo.src.data(), (size_t)El1 * 4);
-        std::vector<double> add(std::max<size_t>(3 * (size_t)s->Ep_add + 4 * (size_t)s->El_add, 1));      // [uv (2 Ep_add) | w (Ep_add) | l (3 El_add) | w (El_add)]
+        std::vector<double>& add = h_add_ob; add.resize(std::max<size_t>(3 * (size_t)s->Ep_add + 4 * (size_t)s->El_add, 1));      // [uv (2 Ep_add) | w (Ep_add) | l (3 El_add) | w (El_add)]
         double* a_uv = add.data(); double* a_wp = a_uv + 2 * (size_t)s->Ep_add; double* a_l = a_wp + s->Ep_add; double* a_wl = a_l + 3 * (size_t)s->El_add;
         if (s->Ep_add) memcpy(a_uv, s->uv2, 16 * (size_t)s->Ep_add);
         for (int e = 0; e < s->Ep_add; ++e) a_wp[e] = s->po_inv_sigma2 ? (double)(float)s->po_inv_sigma2[e] : 1.0;      // const float& invSigma2 (mapHandler.cpp:5340)
         if (s->El_add) memcpy(a_l, s->l3, 24 * (size_t)s->El_add);
         for (int e = 0; e < s->El_add; ++e) a_wl[e] = s->lo_inv_sigma2 ? (double)(float)s->lo_inv_sigma2[e] : 1.0;
-        DArrStreamScope staged(p->stream, p->have_ctx ? p->ctx.stage : nullptr);
-        DArr<double> dadd;
+        DArr<double>& dadd = dadd_ob;
         HIPCK(p, p->d_obs_carry_src.upload(src)); HIPCK(p, dadd.upload(add));
-        if (p->carry_obs_pending) FAIL(p, PLBA_ERR_STATE, "plba_slide_window: the previous slide was never built on the device (call plba_optimize between two slides)");
         HIPCK(p, p->d_po_uv_c.alloc(std::max<size_t>(2 * (size_t)Ep1, 1), false)); HIPCK(p, p->d_lo_l_c.alloc(std::max<size_t>(3 * (size_t)El1, 1), false)); HIPCK(p, p->d_ob_w_c.alloc(std::max<size_t>((size_t)E1, 1), false));
         const size_t o_wp = 2 * (size_t)s->Ep_add, o_l = o_wp + s->Ep_add, o_wl = o_l + 3 * (size_t)s->El_add;
         if (E1) hipLaunchKernelGGL(k_obs_carry_gather, dim3((E1 + 255) / 256), dim3(256), 0, p->stream, p->d_po_uv.p, p->d_lo_l.p, p->d_ob_w.p, Ep0, dadd.p, dadd.p + o_wp, dadd.p + o_l, dadd.p + o_wl,
                                    p->d_obs_carry_src.p, Ep1, El1, p->d_po_uv_c.p, p->d_lo_l_c.p, p->d_ob_w_c.p);
         HIPCK(p, hipGetLastError());
-        HIPCK(p, plba_stream_wait(p->stream));      // (`src` / `add` / `dadd` end here)
+        HIPCK(p, plba_stream_wait(p->stream));      // the slide's ONE wait: every queued copy has left the staging area, the gathers have read dadd_*
         p->carry_po = true; p->carry_lo = true; p->carry_obs_pending = true;
         p->po_uv.resize(2 * (size_t)Ep1); p->po_w.resize(Ep1); p->lo_l.resize(3 * (size_t)El1); p->lo_w.resize(El1);      // (stale: carry_po / carry_lo)
     }

@@ -310,9 +310,9 @@ struct plba_problem {
     // plba_slide_window: the kept landmarks' estimates never leave the device.  d_lm_carry holds the NEW window's landmark array (kept ones
     // gathered from the previous window's current estimates, added ones uploaded); prepare() copies it on the device instead of uploading
     // `pts` / `lns`, whose entries for the kept landmarks are stale while carry_pts / carry_lns are set (plba_set_points / _lines clear them)
-    plba::DArr<double> d_lm_carry;
+    plba::DArr<double> d_lm_carry, d_kf_carry;      // (and the kept keyframes' states: kf0 is stale while carry_kf is set; plba_set_keyframes clears it)
     plba::DArr<int32_t> d_lm_carry_src;
-    bool carry_pts = false, carry_lns = false;
+    bool carry_pts = false, carry_lns = false, carry_kf = false;
     // ... and neither do the kept observations' measurements and weights: the slide gathers the new landmark-major arrays on the device
     // (into the *_c buffers: `carry_obs_pending`, swapped in by prepare()); po_uv / po_w / lo_l / lo_w on the host are then stale
     // (carry_po / carry_lo; plba_set_point_obs / plba_set_line_obs clear them)
