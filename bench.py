@@ -50,12 +50,12 @@ def csrc_sha16():
 
 
 def pmc_traffic(kernel_prefix, config5=False):
-    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r04_pmc_traffic.json for configs[2],
-    r04_config5_pmc_traffic.json for configs[4]: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950
-    correction applied, tools/rocpd_extract.py, tools/collect_profiles_r04.sh).
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r05_pmc_traffic.json for configs[2],
+    r05_config5_pmc_traffic.json for configs[4]: separate rocprofv3 --pmc runs of this same command — FETCH_SIZE, WRITE_SIZE and the L2 read requests by size —, gfx950
+    correction applied, tools/rocpd_extract.py, tools/collect_profiles_r05.sh).
     PMC counters cannot be collected from inside this process, so the file is tied to the build it came from by a hash of
     csrc/: None when the file is absent or was measured on different kernel sources (never a stale number)."""
-    path = os.path.join(ROOT, "profiles", "r04_config5_pmc_traffic.json" if config5 else "r04_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r05_config5_pmc_traffic.json" if config5 else "r05_pmc_traffic.json")
     try:
         js = json.load(open(path))
         ks = js["kernels"]
@@ -523,6 +523,9 @@ def main():
         if cfg_idx == 3:
             out["config"]["sliding_window_call"] = slide_leg(pkg, 50, 20000, 4000)
             out["config"]["sliding_window_call_12kf"] = slide_leg(pkg, 12, 2000, 400, kf_dt=0.1, track=(6, 12), revisit=0.2)
+            # the mapping thread's steady state (one BA per new keyframe): the same call on a window slid by one keyframe (plba_slide_window)
+            out["config"]["end_to_end_slid_window_ba_call_ms"] = out["config"]["sliding_window_call"]["slid_window_ba_call_ms"]
+            out["config"]["end_to_end_slid_window_ba_call_ms_12kf"] = out["config"]["sliding_window_call_12kf"]["slid_window_ba_call_ms"]
         if rank == 0:
             try:
                 out["config"].update(facade_leg(w_full))

@@ -63,9 +63,9 @@ def _worker(rank, world, port, use_hip, out, win=WIN_SMALL, opts=None):
         r = pkg.protocol.local_ba(p, stage1=win[4], stage2=win[5])
         res = pkg.protocol.results(p)
         tr = p.trace()
-        lo, hi = ws["shard"]["pt_range"]
+        pidx = ws["shard"]["pt_index"]
         fused = int(p.debug_get("lm_fused")[0]) if use_hip else 0
-        out.put((rank, res["P"], res["V"], res["q"], res["dbg"], res["points"], (lo, hi), r["gated"], r["stage2"].chi2_final,
+        out.put((rank, res["P"], res["V"], res["q"], res["dbg"], res["points"], pidx, r["gated"], r["stage2"].chi2_final,
                  [t["accepted"] for t in tr], fused))
         p.close()
         dist.barrier()
@@ -110,8 +110,7 @@ def _check(got, pkg, orc, win=WIN_SMALL):
     for g in got:
         assert np.abs(g[1] - res["P"]).max() < 1e-8 and np.abs(g[2] - res["V"]).max() < 1e-8
         assert np.abs(g[3] - res["q"]).max() < 1e-8 and np.abs(g[4] - res["dbg"]).max() < 1e-8
-        lo, hi = g[6]
-        assert np.abs(g[5] - res["points"][lo:hi]).max() < 1e-7
+        assert np.abs(g[5] - res["points"][g[6]]).max() < 1e-7      # (the shard's points: window.shard_window, time-contiguous stretches)
         assert g[8] == pytest.approx(rr["stage2"].chi2_final, rel=1e-8)
     assert got[0][1].tobytes() == got[1][1].tobytes()            # bit-identical pose blocks across ranks
     assert got[0][9] == got[1][9]                                # identical LM decisions
@@ -169,8 +168,14 @@ def test_shard_window_partitions_landmarks(pkg):
     assert sum(len(p["po_pt"]) for p in parts) == len(w["po_pt"])
     for p in parts:
         assert p["imu"] is w["imu"] and (np.diff(p["po_pt"]) >= 0).all()
-        lo, hi = p["shard"]["pt_range"]
-        assert p["po_pt"].max() < hi - lo
+        assert p["po_pt"].max() < len(p["shard"]["pt_index"])
+    allp = np.concatenate([p["shard"]["pt_index"] for p in parts])
+    assert np.array_equal(np.sort(allp), np.arange(101))
+    # time-contiguous: a later rank's points start no earlier than the previous rank's
+    first = pkg.window._first_kf(w["po_pt"].astype(np.int64), w["po_kf"].astype(np.int64), 101)
+    assert first[parts[0]["shard"]["pt_index"]].max() <= first[parts[1]["shard"]["pt_index"]].min() <= first[parts[1]["shard"]["pt_index"]].max() <= first[parts[2]["shard"]["pt_index"]].min()
+    blocks = [pkg.window.shard_window(w, r, 3, by="index") for r in range(3)]
+    assert np.array_equal(np.concatenate([b["shard"]["pt_index"] for b in blocks]), np.arange(101))
 
 
 def _nccl_worker(port, out):

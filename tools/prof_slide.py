@@ -11,7 +11,8 @@ seq = W.make_sequence(K, n + 1, Np, Nl, seed=0x5EED00E0 + K, **kw)
 wins = [W.window_at(seq, 0, K)]
 for i in range(1, n + 1): wins.append(W.window_at(seq, i, K, prev=wins[-1]))
 deltas = [W.slide_delta(wins[i], wins[i + 1]) for i in range(n)]
-p = pkg.new_problem(diag=1 if "--laps" in sys.argv else 0)
+opts = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}      # plba_options knobs, e.g. lm_fused=2
+p = pkg.new_problem(diag=1 if "--laps" in sys.argv else 0, **opts)
 p.upload_window(wins[0]); pkg.protocol.local_ba(p); pkg.protocol.results(p)
 for i in range(n):
     w = wins[i + 1]; t = [time.perf_counter()]
