@@ -662,9 +662,10 @@ def test_ba_call_time_does_not_depend_on_other_problems_alive(pkg, hip):
     solo = min(call() for _ in range(4))
     other = pkg.new_problem(); other.upload_window(w); other.optimize(2)
     call()
-    busy = [call() for _ in range(6)]
+    busy = [call() for _ in range(8)]
     other.close()
-    assert max(busy) < 2.0 * solo + 2e-3, (solo, busy)
+    # (the stall was systematic — every call paid it; a single slow call on a shared box is not it: at most one of eight may exceed the bound)
+    assert sum(b >= 2.0 * solo + 2e-3 for b in busy) <= 1 and sorted(busy)[len(busy) // 2] < 1.5 * solo + 1e-3, (solo, busy)
 
 
 @pytest.mark.parametrize("K", [26, 34, 50, 77, 128, 200])
