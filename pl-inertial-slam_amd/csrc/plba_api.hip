@@ -497,7 +497,8 @@ static bool lm_groups_finish(LmHost& H) {      // false: a keyframe observes a l
     for (int b : H.bad) if (b) return false;
     return true;
 }
-static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf, const std::vector<double>& ob_w, LmHost& H) {
+// have_kminmax: H.kmin / H.kmax / H.kmask were filled by the caller's own pass over the observations (prepare()'s index maps, round 5)
+static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf, const std::vector<double>& ob_w, LmHost& H, bool have_kminmax = false) {
     const int K = p->K, Np = p->Np, Nl = p->Nl, Ep = p->Ep, L = Np + Nl, E = (int)ob_kf.size();
     H.cov.assign((size_t)K * K, 0);
     const bool gt = (p->opt.diag & PLBA_DIAG_TIMING) != 0;
@@ -539,10 +540,11 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     // ---- phase 1 -----------------------------------------------------------------------------------------------------------------------
     std::vector<int32_t>& kmin = H.kmin; std::vector<int32_t>& kmax = H.kmax; std::vector<int32_t>& ord = H.ord; std::vector<int32_t>& tmp = H.tmp;
     std::vector<int32_t>& cnt = H.cnt; std::vector<int32_t>& ordall = H.ordall; std::vector<int32_t>& stamp = H.stamp;
-    kmin.resize(L); kmax.resize(L); cnt.assign(K + 1, 0); stamp.assign(K, -1); ordall.clear();
+    if (!have_kminmax) { kmin.resize(L); kmax.resize(L); }
+    cnt.assign(K + 1, 0); stamp.assign(K, -1); ordall.clear();
     H.grp.clear(); H.span_at.clear(); H.span_end.clear(); H.span_ob0.clear();
     H.blk_c.clear(); H.row_c.clear(); H.blk_ij.clear(); H.blk_start.clear(); H.row_kf.clear(); H.row_start.clear();
-    {
+    if (!have_kminmax) {
         const int NTK = E > 60000 ? 8 : E > 20000 ? 4 : 1;      // (independent per landmark: the worker pool takes it in ranges)
         int32_t* kmn = kmin.data(); int32_t* kmx = kmax.data();
         const int32_t* ls = lm_start.data(); const int32_t* ok = ob_kf.data();
@@ -571,36 +573,45 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
         if (wide && !any_wide) continue;
         const int s0 = kind ? Np : 0, s1 = kind ? L : Np, gmax = (kind ? gln : gpt) / (wide ? 2 : 1);
         // order by (first keyframe, last keyframe, index): two stable counting sorts; landmarks without an edge are not in the graph
-        ord.clear();
-        for (int s = s0; s < s1; ++s) if (kmax[s] >= 0 && (lm_start[s + 1] - lm_start[s] > LMF_W) == (wide != 0)) ord.push_back(s);
+        {   // (raw pointers and a counted fill: the vectors are members of a heap object, whose data pointers the loops would reload)
+            ord.resize((size_t)(s1 - s0));
+            int32_t* o = ord.data(); const int32_t* kx = kmax.data(); const int32_t* lsp = lm_start.data();
+            size_t no = 0;
+            for (int s = s0; s < s1; ++s) { o[no] = s; no += (kx[s] >= 0) & ((lsp[s + 1] - lsp[s] > LMF_W) == (wide != 0)); }
+            ord.resize(no);
+        }
         for (int pass = 0; pass < 2; ++pass) {
-            const std::vector<int32_t>& key = pass ? kmin : kmax;
+            const int32_t* key = (pass ? kmin : kmax).data();
             std::fill(cnt.begin(), cnt.end(), 0);
-            for (int32_t s : ord) cnt[key[s] + 1]++;
-            for (int k = 0; k < K; ++k) cnt[k + 1] += cnt[k];
             tmp.resize(ord.size());
-            for (int32_t s : ord) tmp[cnt[key[s]]++] = s;
+            int32_t* c = cnt.data(); const int32_t* o = ord.data(); int32_t* t2 = tmp.data();
+            const size_t no = ord.size();
+            for (size_t x = 0; x < no; ++x) c[key[o[x]] + 1]++;
+            for (int k = 0; k < K; ++k) c[k + 1] += c[k];
+            for (size_t x = 0; x < no; ++x) { const int32_t s = o[x]; t2[c[key[s]]++] = s; }
             ord.swap(tmp);
         }
         const int base = (int)ordall.size();
         size_t at = 0;
+        const int NWm = (int)(H.kmask.size() / (size_t)std::max(L, 1));
         if (gt) { auto t = std::chrono::steady_clock::now(); t_sort += std::chrono::duration<double, std::milli>(t - g0).count(); g0 = t; }
         while (at < ord.size()) {
             const int gi = (int)H.grp.size();
             int32_t win[LMF_W2];
             int nw = 0, gob = 0;
             size_t end = at;
-            const int NWm = (int)(H.kmask.size() / (size_t)std::max(L, 1));
             if (NWm) {
                 uint64_t gm[4] = {0, 0, 0, 0};
-                while (end < ord.size() && (int)(end - at) < gmax) {
-                    const int s = ord[end];
-                    const uint64_t* m = &H.kmask[(size_t)s * NWm];
+                const int32_t* ordp = ord.data(); const uint64_t* kmp = H.kmask.data(); const int32_t* lsp = lm_start.data();
+                const size_t nord = ord.size();
+                while (end < nord && (int)(end - at) < gmax) {
+                    const int s = ordp[end];
+                    const uint64_t* m = kmp + (size_t)s * NWm;
                     int cntw = 0;
                     for (int q = 0; q < NWm; ++q) cntw += __builtin_popcountll(gm[q] | m[q]);
                     if (cntw > W) break;
                     for (int q = 0; q < NWm; ++q) gm[q] |= m[q];
-                    gob += lm_start[s + 1] - lm_start[s];
+                    gob += lsp[s + 1] - lsp[s];
                     ++end;
                 }
                 for (int q = 0; q < NWm; ++q) for (uint64_t b = gm[q]; b; b &= b - 1) win[nw++] = q * 64 + __builtin_ctzll(b);      // (ascending)
@@ -811,15 +822,23 @@ static int prepare(plba_problem* p) {
     p->Ppad = std::max(TILE, (off + TILE - 1) / TILE * TILE);
     p->ld = p->Ppad;
     // ---- unified landmark slots / observation arrays ----------------------------------------------------
+    if (!p->ctx.lm_host) p->ctx.lm_host = new LmHost;      // (stays with the cached context)
+    LmHost& LH = *p->ctx.lm_host;
+    // (locals on purpose: kept with the cached context instead, these four made the loops below 4 x SLOWER — 0.085 -> 0.34 – 0.44 ms at
+    // configs[2], measured A/B in one process with tools/ab_lib.py; the worker pool reads them asynchronously and they then sit in other cores' caches)
     std::vector<int32_t> ob_kf(E), ob_slot(E), lm_start(L + 1, 0);
     std::vector<double> ob_w(E);
     // (a slid window's measurements and weights are on the device already: plba_slide_window)
     const bool carry_obs = (p->carry_po || Ep == 0) && (p->carry_lo || El == 0) && (p->carry_po || p->carry_lo);
     if ((p->carry_po || p->carry_lo) && !carry_obs) FAIL(p, PLBA_ERR_STATE, "after plba_slide_window set BOTH observation arrays again (plba_set_point_obs and plba_set_line_obs) or neither: the kept measurements live on the device");
-    for (int e = 0; e < Ep; ++e) { ob_kf[e] = p->po_kf[e]; ob_slot[e] = p->po_pt[e]; lm_start[p->po_pt[e] + 1]++; }
-    for (int e = 0; e < El; ++e) { ob_kf[Ep + e] = p->lo_kf[e]; ob_slot[Ep + e] = Np + p->lo_ln[e]; lm_start[Np + p->lo_ln[e] + 1]++; }
-    if (!carry_obs) { for (int e = 0; e < Ep; ++e) ob_w[e] = p->po_w[e]; for (int e = 0; e < El; ++e) ob_w[Ep + e] = p->lo_w[e]; }
-    for (int s = 0; s < L; ++s) lm_start[s + 1] += lm_start[s];
+    {
+        int32_t* okf = ob_kf.data(); int32_t* osl = ob_slot.data(); int32_t* ls = lm_start.data(); double* ow = ob_w.data();
+        const int32_t* ppt = p->po_pt.data(); const int32_t* pkf = p->po_kf.data(); const int32_t* lln = p->lo_ln.data(); const int32_t* lkf = p->lo_kf.data();
+        for (int e = 0; e < Ep; ++e) { okf[e] = pkf[e]; osl[e] = ppt[e]; ls[ppt[e] + 1]++; }
+        for (int e = 0; e < El; ++e) { okf[Ep + e] = lkf[e]; osl[Ep + e] = Np + lln[e]; ls[Np + lln[e] + 1]++; }
+        if (!carry_obs) { if (Ep) memcpy(ow, p->po_w.data(), (size_t)Ep * 8); if (El) memcpy(ow + Ep, p->lo_w.data(), (size_t)El * 8); }
+        for (int s = 0; s < L; ++s) ls[s + 1] += ls[s];
+    }
     // ---- fused landmark-major passes: does the structure fit?  (decided for good once the chain maps exist, below) -----------------
     // lm_fused = 1: from 40 k observations on.  Measured after the third form of the Schur pass (decoupled waves, lane = window slot; ms
     // per LM trial, record-based | fused): configs[0] 9 k observations 0.074 | 0.069, configs[1] 52 k 0.130 | 0.124, configs[2] 103 k
@@ -867,8 +886,6 @@ static int prepare(plba_problem* p) {
     for (int i = 0; i < Np; ++i) p->lm_fixed[i] = p->pt_fixed[i];
     for (int i = 0; i < Nl; ++i) p->lm_fixed[Np + i] = p->ln_fixed[i];
     lap("index maps, slots");
-    if (!p->ctx.lm_host) p->ctx.lm_host = new LmHost;      // (stays with the cached context)
-    LmHost& LH = *p->ctx.lm_host;
     struct PoolJoin { ~PoolJoin() { HostPool::get().finish(); } } join_tables;      // (declared after the vectors the asynchronous fill reads: joined before they go)
     if (lm_cand) build_lm_groups(p, lm_start, ob_kf, ob_w, LH);
     else LH.grp.clear();
@@ -2380,36 +2397,53 @@ int plba_get_keyframes(plba_problem* p, double* P3, double* V3, double* q4, doub
 }
 // the write-back of a BA call reads points AND lines (mapHandler.cpp:6202-6239): the landmark array comes to the host once per state
 // (state_epoch: bumped by every upload, optimize and restore) and both getters are served from that mirror
-static int get_lm(plba_problem* p, const std::vector<double>*& hp) {
+// (round 5: the estimates are packed on the device first — a point uses half of its 48-byte slot —, come back in ONE copy and the
+// requesting call is served straight from the pinned bounce buffer; the other kind's part is kept for its getter.  0.20 -> 0.12 ms per BA call at configs[2])
+__global__ void k_lm_pack(const double* __restrict__ lm, int Np, int Nl, double* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int np3 = 3 * Np;
+    if (t < np3) out[t] = lm[(size_t)(t / 3) * 6 + t % 3];
+    else if (t < np3 + 6 * Nl) out[t] = lm[(size_t)Np * 6 + (t - np3)];
+}
+static int get_lm(plba_problem* p, double* xyz, double* lines) {      // exactly one of the two is requested
     int rc = prepare(p);
     if (rc) return rc;
-    std::vector<double>& h = p->res_lm;
-    hp = &h;
-    if (p->res_lm_epoch == p->state_epoch && h.size() == (size_t)p->L * 6) return PLBA_OK;
-    HIPCK(p, hipSetDevice(p->device));
-    HIPCK(p, plba_stream_wait(p->stream));
-    h.resize((size_t)p->L * 6);
-    if (p->L) HIPCK(p, plba_d2h(p, h.data(), p->dv.lm[p->cur], h.size() * 8));
-    p->res_lm_epoch = p->state_epoch;
+    const size_t np3 = 3 * (size_t)p->Np, nl6 = 6 * (size_t)p->Nl, tot = np3 + nl6;
+    std::vector<double>& h = p->res_lm;      // [points packed | lines packed] of epoch res_lm_epoch
+    if (!(p->res_lm_epoch == p->state_epoch && h.size() == tot)) {
+        HIPCK(p, hipSetDevice(p->device));
+        StageArea* st = p->have_ctx ? p->ctx.stage : nullptr;
+        h.resize(tot);
+        if (tot) {
+            HIPCK(p, p->d_lm_pack.alloc(tot, false));
+            hipLaunchKernelGGL(k_lm_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, p->stream, p->dv.lm[p->cur], p->Np, p->Nl, p->d_lm_pack.p);
+            HIPCK(p, hipGetLastError());
+            if (st && st->base && tot * 8 <= st->xfer_cap()) {
+                HIPCK(p, hipMemcpyAsync(st->xfer(), p->d_lm_pack.p, tot * 8, hipMemcpyDeviceToHost, p->stream));
+                HIPCK(p, plba_stream_wait(p->stream));
+                const double* x = reinterpret_cast<const double*>(st->xfer());
+                // the requested kind goes straight to the caller; the mirror keeps both (a second getter of this state needs no device round trip)
+                if (xyz && np3) memcpy(xyz, x, np3 * 8);
+                if (lines && nl6) memcpy(lines, x + np3, nl6 * 8);
+                memcpy(h.data(), x, tot * 8);
+                p->res_lm_epoch = p->state_epoch;
+                return PLBA_OK;
+            }
+            HIPCK(p, plba_d2h(p, h.data(), p->d_lm_pack.p, tot * 8));
+        }
+        p->res_lm_epoch = p->state_epoch;
+    }
+    if (xyz && np3) memcpy(xyz, h.data(), np3 * 8);
+    if (lines && nl6) memcpy(lines, h.data() + np3, nl6 * 8);
     return PLBA_OK;
 }
 int plba_get_points(plba_problem* p, double* xyz) {
     if (!p || !xyz) return PLBA_ERR_INVALID;
-    const std::vector<double>* hp = nullptr;
-    int rc = get_lm(p, hp);
-    if (rc) return rc;
-    const std::vector<double>& h = *hp;
-    for (int i = 0; i < p->Np; ++i) memcpy(xyz + 3 * (size_t)i, &h[(size_t)i * 6], 24);
-    return PLBA_OK;
+    return get_lm(p, xyz, nullptr);
 }
 int plba_get_lines(plba_problem* p, double* l) {
     if (!p || !l) return PLBA_ERR_INVALID;
-    const std::vector<double>* hp = nullptr;
-    int rc = get_lm(p, hp);
-    if (rc) return rc;
-    const std::vector<double>& h = *hp;
-    for (int i = 0; i < p->Nl; ++i) memcpy(l + 6 * (size_t)i, &h[(size_t)(p->Np + i) * 6], 48);
-    return PLBA_OK;
+    return get_lm(p, nullptr, l);
 }
 int plba_save_state(plba_problem* p) {
     if (!p) return PLBA_ERR_INVALID;
@@ -2514,7 +2548,7 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
     // is touched before every check has passed) ----------------------------------------------------------------------------------------
     // (round 5: only the integer lists — landmark and keyframe of every observation — are rebuilt on the host; `src` says where each new
     // observation's measurement and weight come from: an index into the OLD device arrays, or -(1 + a) for the a-th added one)
-    struct ObsList { std::vector<int32_t> lm, kf, src; };
+    struct ObsList { std::vector<int32_t>& lm; std::vector<int32_t>& kf; std::vector<int32_t>& src; };
     // The old list is landmark-major and so is the added one: the merged list is the old one with the dropped landmarks' stretches cut
     // out and each added run spliced in behind its landmark's last old observation.  Between two splice points the old observations are
     // copied in one tight loop (new landmark index through the map, keyframe index shifted, source = old position); only a landmark that
@@ -2551,7 +2585,7 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
         out.lm.resize(n); out.kf.resize(n); out.src.resize(n);
         return PLBA_OK;
     };
-    ObsList npo, nlo;
+    ObsList npo{p->scr_lm[0], p->scr_kf[0], p->scr_src[0]}, nlo{p->scr_lm[1], p->scr_kf[1], p->scr_src[1]};
     if (int rc = merge(Np0, s->Np_add, Ep0, s->Ep_add, pmap, Npk, p->po_pt, p->po_kf, s->drop_point_obs, s->po_pt, s->po_kf, npo)) return rc;
     if (int rc = merge(Nl0, s->Nl_add, El0, s->El_add, lmap, Nlk, p->lo_ln, p->lo_kf, s->drop_line_obs, s->lo_ln, s->lo_kf, nlo)) return rc;
     slap("observation lists merged");

@@ -219,7 +219,7 @@ struct LmHost {
     // scratch of the build
     std::vector<int32_t> kmin, kmax, ord, tmp, cnt, ordall, stamp, span_at, span_end, span_ob0, gcut, bad, c2, pos;
     std::vector<std::pair<int64_t, int32_t>> blk_c, row_c;
-    std::vector<uint64_t> kmask;
+    std::vector<uint64_t> kmask;             // keyframe bit mask per landmark
 };
 }  // namespace plba
 
@@ -319,6 +319,7 @@ struct plba_problem {
     plba::DArr<double> d_po_uv_c, d_lo_l_c, d_ob_w_c;
     plba::DArr<int32_t> d_obs_carry_src;
     bool carry_po = false, carry_lo = false, carry_obs_pending = false;
+    std::vector<int32_t> scr_lm[2], scr_kf[2], scr_src[2];      // the slide's merged lists are built here and swapped with po_pt / po_kf / lo_ln / lo_kf: no fresh pages per slide
     plba::DArr<double> d_po_uv, d_lo_l, d_ob_w, d_ob_chi2, d_erec, d_erec2;
     plba::DArr<int32_t> d_ob_kf, d_ob_slot, d_lm_start, d_off_pvr, d_off_bias;
     plba::DArr<uint8_t> d_level, d_lm_fixed, d_lm_active, d_depth;
@@ -362,6 +363,7 @@ struct plba_problem {
     bool lm_ok = false;                         // this upload runs them (structure permitting: chain path, <= 16 observations per landmark — wide groups for 9 .. 16 —, none twice from one keyframe)
     unsigned long long state_epoch = 1, res_lm_epoch = 0;      // estimates on the device changed | the host mirror of the landmark array is of that epoch
     std::vector<double> res_lm;                 // plba_get_points / plba_get_lines: one read-back per state
+    plba::DArr<double> d_lm_pack;               // ... of the PACKED estimates (3 doubles per point, 6 per line: k_lm_pack)
     std::vector<double> lm_hist;                // diagnostics (plba_debug_get "lm_groups")
     int seg_launch_est = 0;                     // dependent factorisation launches the chain segment-length choice expected (diagnostics)
     bool lm_chi_dirty = false;                  // the fused passes' group-order chi2 cache is newer than DevBuf::ob_chi2
