@@ -303,23 +303,23 @@ int main(int argc, char** argv) {
     // (VERDICT r04 item 1b): graph construction | optimize(5) + gating loop + optimize(10) | marginalization | write-back | optimizer teardown.
     if (argc >= 4 && !strcmp(argv[1], "time")) {
         const int reps = std::max(1, atoi(argv[3]));
-        double best[8] = {1e300, 1e300, 1e300, 1e300, 1e300, 1e300, 1e300, 1e300};
+        double best[9] = {1e300, 1e300, 1e300, 1e300, 1e300, 1e300, 1e300, 1e300, 1e300};
         for (int r = 0; r < reps; ++r) {
-            double laps[7] = {0, 0, 0, 0, 0, 0, 0};
+            double laps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const int rc = local_ba_with_imu_and_marg(argv[2], nullptr, laps);
             if (rc) return rc;
             if (r == 0 && reps > 1) continue;      // (the first call pays for module load and first-touch allocations)
             double tot = 0.0;
             for (int i = 0; i < 7; ++i) tot += laps[i];
-            if (tot < best[7]) { for (int i = 0; i < 7; ++i) best[i] = laps[i]; best[7] = tot; }
+            if (tot < best[7]) { for (int i = 0; i < 7; ++i) best[i] = laps[i]; best[7] = tot; best[8] = laps[7]; }
         }
         // facade_ba_call_ms: what end_to_end_ba_call_ms covers through the C ABI (upload + 5 + gating + 10 iterations + write-back); the call
         // site's own loops over its edge objects (gating: chi2() / isDepthPositive() / setLevel / setRobustKernel(0) per edge) are inside it
         printf("{\"facade_graph_construction_ms\": %.4f, \"facade_optimize5_ms\": %.4f, \"facade_gating_loop_ms\": %.4f, \"facade_optimize10_ms\": %.4f, "
                "\"facade_marginalize_ms\": %.4f, \"facade_write_back_ms\": %.4f, \"facade_teardown_ms\": %.4f, \"facade_ba_call_ms\": %.4f, "
-               "\"facade_ba_call_with_graph_construction_ms\": %.4f, \"reps\": %d}\n",
+               "\"facade_ba_call_with_graph_construction_ms\": %.4f, \"facade_optimize5_inside_plba_optimize_ms\": %.4f, \"reps\": %d}\n",
                best[0], best[1], best[2], best[3], best[4], best[5], best[6], best[1] + best[2] + best[3] + best[5],
-               best[0] + best[1] + best[2] + best[3] + best[5] + best[6], reps);
+               best[0] + best[1] + best[2] + best[3] + best[5] + best[6], best[8], reps);
         return 0;
     }
     if (argc < 3) { fprintf(stderr, "usage: %s [nomarg|gyrbias|pgo|time] window.bin result.bin\n", argv[0]); return 2; }
@@ -327,7 +327,7 @@ int main(int argc, char** argv) {
 }
 
 // ---- MapHandler::localBundleAdjustmentWithImuAndMarg (src/mapHandler.cpp:5741-6254) ---------------------------------------------------
-// laps (optional, ms): [0] graph construction, [1] optimize(5), [2] the gating loop, [3] optimize(10), [4] marginalization, [5] write-back, [6] teardown
+// laps (optional, ms): [0] graph construction, [1] optimize(5), [2] the gating loop, [3] optimize(10), [4] marginalization, [5] write-back, [6] teardown, [7] plba_optimize(5)'s own ms_total
 static int local_ba_with_imu_and_marg(const char* in, const char* out, double* laps) {
     FILE* f = fopen(in, "rb");
     if (!f) { perror("window"); return 2; }
@@ -448,7 +448,7 @@ static int local_ba_with_imu_and_marg(const char* in, const char* out, double* l
     if (laps) { laps[0] = ms_since(t_lap); t_lap = tnow(); }
     optimizer.initializeOptimization();                              // :6038-6039
     optimizer.optimize(5);
-    if (laps) { laps[1] = ms_since(t_lap); t_lap = tnow(); }
+    if (laps) { laps[1] = ms_since(t_lap); t_lap = tnow(); laps[7] = optimizer.lastStats().ms_total; }
     if (!abortFlag) {                                                // :6047-6069
         for (size_t i = 0; i < vpEdgesMono.size(); i++) {
             g2o::EdgeNavStatePVRPointXYZ* ed = vpEdgesMono[i];
