@@ -1369,7 +1369,17 @@ private:
                     default: return fail("vertex type not supported by the device path (id " + std::to_string(v->id()) + ")");
                 }
             }
-            // observations from the objects, insertion order preserved (_epts / _elns are kept in it by addEdge)
+            // observations from the objects, insertion order preserved (_epts / _elns are kept in it by addEdge) — unless that order is not
+            // landmark-major, which the C ABI asks for (the call site's is: it adds a landmark's edges right behind its vertex): then the
+            // edges are stably sorted by their landmark's index, i.e. a landmark's observations keep their insertion order (round 5: g2o
+            // itself accepts edges in any order; the facade refused such graphs through the library's error before)
+            auto landmark_major = [](auto& list) {
+                auto lm = [](const OptimizableGraph::Edge* e) { return (e->vertices().size() > 0 && e->vertex(0)) ? e->vertex(0)->_plba_index : -1; };
+                bool sorted = true;
+                for (size_t i = 1; i < list.size() && sorted; ++i) sorted = lm(list[i - 1]) <= lm(list[i]);
+                if (!sorted) std::stable_sort(list.begin(), list.end(), [&](const OptimizableGraph::Edge* a, const OptimizableGraph::Edge* b) { return lm(a) < lm(b); });
+            };
+            landmark_major(_epts); landmark_major(_elns);
             const size_t nEp = _epts.size(), nEl = _elns.size();
             _soa.po_pt.resize(nEp); _soa.po_kf.resize(nEp); _soa.po_uv.resize(2 * nEp); _soa.po_w.resize(nEp); _soa.lev_pt.resize(nEp);
             _soa.lo_ln.resize(nEl); _soa.lo_kf.resize(nEl); _soa.lo_l.resize(3 * nEl); _soa.lo_w.resize(nEl); _soa.lev_ln.resize(nEl);

@@ -67,6 +67,29 @@ def test_call_site_protocol_through_the_facade(pkg, orc, hip, tmp_path):
     o.close()
 
 
+@pytest.mark.gpu
+def test_a_graph_built_in_another_order_gives_the_same_results(pkg, hip, tmp_path):
+    """Round 5: the facade fills the C ABI's arrays while the call site inserts (flatten-at-insertion) — valid as long as the graph
+    arrives in the call site's own shape.  `scrambled` builds the SAME graph the way g2o also accepts: landmark vertices in descending id
+    order, every edge after every vertex, the landmarks' edges in descending order too, a measurement set again after addEdge.  The facade
+    must notice, rebuild the arrays from the objects (sorting the observations landmark-major itself) and give the ordered build's
+    results: same landmark indices (rank by id), same observation order within a landmark — bit for bit."""
+    w = pkg.window.make_window(12, 260, 50, imu=True, seed=31)
+    exe = build_harness()
+    win = str(tmp_path / "w.bin")
+    write_window(w, win)
+    out = {}
+    for mode in ("ordered", "scrambled"):
+        res = str(tmp_path / (mode + ".bin"))
+        subprocess.check_call([exe, win, res] if mode == "ordered" else [exe, "scrambled", win, res], timeout=120)
+        out[mode] = read_result(res, 12, len(w["points"]), len(w["lines"]))
+    a, b = out["ordered"], out["scrambled"]
+    assert a["gated"] == b["gated"] and a["chi2"] == b["chi2"]
+    for k in ("P", "V", "q", "dbg", "dba", "points", "lines"):
+        assert np.array_equal(a[k], b[k]), k
+    # (the prior is not compared: the call site's factor selection walks ITS edge list and stops after NUM + 1 — another list order, other factors)
+
+
 def make_nomarg_window(pkg, seed=41, K=12, n_fixed=3):
     """The graph MapHandler::localBundleAdjustmentWithImu (USE_MARG off, src/mapHandler.cpp:5086-5739) builds: keyframes
     [0, n_fixed) are covisible keyframes OUTSIDE the sliding window (fixed PVR vertex, NO bias vertex, :5220-5231), keyframe

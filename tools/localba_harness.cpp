@@ -260,6 +260,10 @@ static int pose_graph(const char* in, const char* out, bool ess_graph = false) {
 
 static int local_ba_with_imu(const char* in, const char* out);
 static int local_ba_with_imu_and_marg(const char* in, const char* out, double* laps);
+// `scrambled`: the same graph as the default mode, built in an order the call site does not use — landmark vertices in DESCENDING id
+// order, every edge after every vertex and the edges of the landmarks in that descending order too, one measurement set again after
+// addEdge: the facade must fall back from its insertion-time arrays to the objects and sort the observations itself
+static bool g_scrambled = false;
 
 // ---- MapHandler::tryVioInit, the steps between its g2o graphs (src/mapHandler.cpp:4853-4980) ---------------------------------------
 // in: N | dt (N-1) | dP, dV (3 (N-1)) | JPa, JVa (9 (N-1)) | Rc (9 N), pc (3 N) | Rb (9 N), pb (3 N) | Rcb 9, pcb 3
@@ -298,6 +302,7 @@ int main(int argc, char** argv) {
     if (argc >= 4 && !strcmp(argv[1], "essgraph")) return pose_graph(argv[2], argv[3], true);
     if (argc >= 4 && !strcmp(argv[1], "vioinit")) return vio_init(argv[2], argv[3]);
     if (argc >= 4 && !strcmp(argv[1], "nomarg")) return local_ba_with_imu(argv[2], argv[3]);
+    if (argc >= 4 && !strcmp(argv[1], "scrambled")) { g_scrambled = true; return local_ba_with_imu_and_marg(argv[2], argv[3], nullptr); }
     if (argc >= 4 && !strcmp(argv[1], "lba")) return visual_lba(argv[2], argv[3]);
     // `time window.bin reps`: one localBundleAdjustmentWithImuAndMarg-shaped call through Boundary 1, `reps` times on fresh optimizers, lap by lap
     // (VERDICT r04 item 1b): graph construction | optimize(5) + gating loop + optimize(10) | marginalization | write-back | optimizer teardown.
@@ -402,12 +407,33 @@ static int local_ba_with_imu_and_marg(const char* in, const char* out, double* l
     std::vector<int> vpFirstObsKf;                                   // kf_obs_list[0] of the edge's map point
     int e = 0;
     maxPointId = maxKFid;
-    for (int l = 0; l < Np; ++l) {                                  // :5897-5948
-        g2o::VertexLMPointXYZ* vPoint = new g2o::VertexLMPointXYZ();
-        vPoint->setEstimate(Vector3d(pts[3 * l], pts[3 * l + 1], pts[3 * l + 2]));
+    std::vector<int> pt_e0(Np + 1, Ep), ln_e0(Nl + 1, El);      // first observation of every landmark (the lists are landmark-major)
+    for (int q = Ep - 1; q >= 0; --q) pt_e0[po_pt[q]] = q;
+    for (int q = El - 1; q >= 0; --q) ln_e0[lo_ln[q]] = q;
+    if (g_scrambled) {      // every landmark vertex first, highest id first
+        for (int l = Nl - 1; l >= 0; --l) {
+            g2o::VertexLine* vLine = new g2o::VertexLine();
+            Vector6d l6; for (int c = 0; c < 6; ++c) l6(c) = lns[6 * l + c];
+            vLine->setEstimate(l6); vLine->setId(l + (Np + maxKFid + 1) + 1); vLine->setMarginalized(true);
+            optimizer.addVertex(vLine);
+        }
+        for (int l = Np - 1; l >= 0; --l) {
+            g2o::VertexLMPointXYZ* vPoint = new g2o::VertexLMPointXYZ();
+            vPoint->setEstimate(Vector3d(pts[3 * l], pts[3 * l + 1], pts[3 * l + 2]));
+            vPoint->setId(l + maxKFid + 1); vPoint->setFixed(false); vPoint->setMarginalized(true);
+            optimizer.addVertex(vPoint);
+        }
+    }
+    for (int lq = 0; lq < Np; ++lq) {                                  // :5897-5948
+        const int l = g_scrambled ? Np - 1 - lq : lq;
         const int id = l + maxKFid + 1;
-        vPoint->setId(id); vPoint->setFixed(false); vPoint->setMarginalized(true);
-        optimizer.addVertex(vPoint);
+        if (!g_scrambled) {
+            g2o::VertexLMPointXYZ* vPoint = new g2o::VertexLMPointXYZ();
+            vPoint->setEstimate(Vector3d(pts[3 * l], pts[3 * l + 1], pts[3 * l + 2]));
+            vPoint->setId(id); vPoint->setFixed(false); vPoint->setMarginalized(true);
+            optimizer.addVertex(vPoint);
+        }
+        e = pt_e0[l];
         const int e0 = e;
         for (; e < Ep && po_pt[e] == l; ++e) {
             g2o::EdgeNavStatePVRPointXYZ* ed = new g2o::EdgeNavStatePVRPointXYZ();
@@ -419,19 +445,24 @@ static int local_ba_with_imu_and_marg(const char* in, const char* out, double* l
             g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber; ed->setRobustKernel(rk); rk->setDelta(hub[0]);
             ed->SetParams(fx, fy, cx, cy, Rbc, tbc);
             optimizer.addEdge(ed); vpEdgesMono.push_back(ed); vpFirstObsKf.push_back(kf_idx[po_kf[e0]]);
+            if (g_scrambled && (e % 7) == 0) ed->setMeasurement(Vector2d(po_uv[2 * e], po_uv[2 * e + 1]));      // edited after insertion (same value)
         }
-        maxPointId = id + 1;
     }
+    maxPointId = Np + maxKFid + 1;
     std::vector<g2o::EdgeNavStateLine*> vlEdgesMono;
     std::vector<int> vlFirstObsKf;
     e = 0;
-    for (int l = 0; l < Nl; ++l) {                                  // :5957-6004
-        g2o::VertexLine* vLine = new g2o::VertexLine();
-        Vector6d l6; for (int c = 0; c < 6; ++c) l6(c) = lns[6 * l + c];
-        vLine->setEstimate(l6);
+    for (int lq = 0; lq < Nl; ++lq) {                                  // :5957-6004
+        const int l = g_scrambled ? Nl - 1 - lq : lq;
         const int id = l + maxPointId + 1;
-        vLine->setId(id); vLine->setMarginalized(true);
-        optimizer.addVertex(vLine);
+        if (!g_scrambled) {
+            g2o::VertexLine* vLine = new g2o::VertexLine();
+            Vector6d l6; for (int c = 0; c < 6; ++c) l6(c) = lns[6 * l + c];
+            vLine->setEstimate(l6);
+            vLine->setId(id); vLine->setMarginalized(true);
+            optimizer.addVertex(vLine);
+        }
+        e = ln_e0[l];
         const int e0 = e;
         for (; e < El && lo_ln[e] == l; ++e) {
             g2o::EdgeNavStateLine* ed = new g2o::EdgeNavStateLine();
