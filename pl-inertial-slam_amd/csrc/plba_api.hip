@@ -2650,9 +2650,25 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
     }
     // ---- keyframes: the kept ones' current states are copied ON THE DEVICE behind the added ones' upload (round 5: they came back to
     // the host first — a blocking read-back per slide) -------------------------------------------------------------------------------------
-    DArrStreamScope staged(p->stream, p->have_ctx ? p->ctx.stage : nullptr);      // the slide's uploads share ONE wait, at its end
+    // the slide's uploads go through a pinned area of their own (sized here; kept with the cached context): the copies and the gather
+    // kernels are queued and the slide returns WITHOUT waiting for them — prepare() re-uses the general staging area at once, and they
+    // overlap its host work.  (No room / no pinned memory: the general area, and one wait at the slide's end.)
+    bool own_stage = false;
+    if (p->have_ctx) {
+        const size_t need = ((size_t)(Np1 + Nl1) * 4 + (size_t)(s->Np_add + s->Nl_add) * 48 + ((size_t)Ep0 + El0 + s->Ep_add + s->El_add) * 4 + (size_t)s->Ep_add * 24 + (size_t)s->El_add * 32 +
+                             (size_t)s->K_add * KF_STRIDE * 8 + 8 * 256 + StageArea::XFER) * 5 / 4;
+        if (!p->ctx.slide_stage) p->ctx.slide_stage = new StageArea;
+        StageArea* ss = p->ctx.slide_stage;
+        if (ss->cap < need) {
+            if (ss->base) { (void)hipHostFree(ss->base); ss->base = nullptr; ss->cap = 0; }
+            const size_t cap = std::max<size_t>((need + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1), (size_t)8 << 20);
+            if (hipHostMalloc((void**)&ss->base, cap, hipHostMallocDefault) == hipSuccess) ss->cap = cap; else ss->base = nullptr;
+        }
+        own_stage = ss->base != nullptr && ss->cap >= need;
+    }
+    DArrStreamScope staged(p->stream, own_stage ? p->ctx.slide_stage : (p->have_ctx ? p->ctx.stage : nullptr));
     std::vector<double> kf_add((size_t)std::max(s->K_add, 1) * KF_STRIDE, 0.0);
-    DArr<double> d_kf_add, dadd_lm, dadd_ob;
+    DArr<double>& d_kf_add = p->d_slide_kf; DArr<double>& dadd_lm = p->d_slide_lm; DArr<double>& dadd_ob = p->d_slide_ob;
     std::vector<int32_t> h_src_lm, h_src_ob;      // (function scope: a queued upload that found no staging room reads the host vector until the wait)
     std::vector<double> h_add_lm, h_add_ob;
     {
@@ -2717,7 +2733,7 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
         if (E1) hipLaunchKernelGGL(k_obs_carry_gather, dim3((E1 + 255) / 256), dim3(256), 0, p->stream, p->d_po_uv.p, p->d_lo_l.p, p->d_ob_w.p, Ep0, dadd.p, dadd.p + o_wp, dadd.p + o_l, dadd.p + o_wl,
                                    p->d_obs_carry_src.p, Ep1, El1, p->d_po_uv_c.p, p->d_lo_l_c.p, p->d_ob_w_c.p);
         HIPCK(p, hipGetLastError());
-        HIPCK(p, plba_stream_wait(p->stream));      // the slide's ONE wait: every queued copy has left the staging area, the gathers have read dadd_*
+        if (!own_stage) HIPCK(p, plba_stream_wait(p->stream));      // (shared staging area: every queued copy must have left it before prepare() writes it again)
         p->carry_po = true; p->carry_lo = true; p->carry_obs_pending = true;
         p->po_uv.resize(2 * (size_t)Ep1); p->po_w.resize(Ep1); p->lo_l.resize(3 * (size_t)El1); p->lo_w.resize(El1);      // (stale: carry_po / carry_lo)
     }

@@ -231,6 +231,7 @@ struct HostCtx {           // per-problem runtime objects, cached across problem
     void* d_mail = nullptr;      // its device address
     plba::StageArea* stage = nullptr;   // pinned upload staging (heap object: HostCtx is copied around by value)
     plba::LmHost* lm_host = nullptr;    // the group tables of the fused passes: megabytes whose pages a fresh problem would fault in again
+    plba::StageArea* slide_stage = nullptr;   // pinned staging of plba_slide_window's uploads: its own area, so that the slide need not wait for them before prepare() re-uses `stage`
 };
 
 
@@ -317,6 +318,7 @@ struct plba_problem {
     // (into the *_c buffers: `carry_obs_pending`, swapped in by prepare()); po_uv / po_w / lo_l / lo_w on the host are then stale
     // (carry_po / carry_lo; plba_set_point_obs / plba_set_line_obs clear them)
     plba::DArr<double> d_po_uv_c, d_lo_l_c, d_ob_w_c;
+    plba::DArr<double> d_slide_kf, d_slide_lm, d_slide_ob;      // the slide's uploaded additions (members: the gathers that read them are only QUEUED when the slide returns)
     plba::DArr<int32_t> d_obs_carry_src;
     bool carry_po = false, carry_lo = false, carry_obs_pending = false;
     std::vector<int32_t> scr_lm[2], scr_kf[2], scr_src[2];      // the slide's merged lists are built here and swapped with po_pt / po_kf / lo_ln / lo_kf: no fresh pages per slide
