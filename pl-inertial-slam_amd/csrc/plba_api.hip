@@ -522,7 +522,7 @@ static bool lm_structure_fits(const plba_problem* p, const std::vector<int32_t>&
 // block — so that neither the lists nor the structure of the reduced system wait for (3) the per-landmark / per-observation tables,
 // which the host worker pool fills WHILE prepare() goes on allocating and uploading (the largest single item of a BA call's host side:
 // 2.5 ms on one thread at configs[2]); lm_groups_finish() joins before they are uploaded.
-static void lm_fill_groups(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf, const std::vector<double>& ob_w, LmHost& H, int t) {
+static void lm_fill_groups(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf, LmHost& H, int t) {
     for (int gi = H.gcut[t]; gi < H.gcut[t + 1]; ++gi) {
         const LmGroup& g = H.grp[gi];
         const int wmax = H.wmax;
@@ -550,8 +550,7 @@ static bool lm_groups_finish(LmHost& H) {      // false: a keyframe observes a l
     for (int b : H.bad) if (b) return false;
     return true;
 }
-// have_kminmax: H.kmin / H.kmax / H.kmask were filled by the caller's own pass over the observations (prepare()'s index maps, round 5)
-static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf, const std::vector<double>& ob_w, LmHost& H, bool have_kminmax = false) {
+static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf, LmHost& H) {
     const int K = p->K, Np = p->Np, Nl = p->Nl, Ep = p->Ep, L = Np + Nl, E = (int)ob_kf.size();
     H.cov.assign((size_t)K * K, 0);
     const bool gt = (p->opt.diag & PLBA_DIAG_TIMING) != 0;
@@ -593,11 +592,10 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     // ---- phase 1 -----------------------------------------------------------------------------------------------------------------------
     std::vector<int32_t>& kmin = H.kmin; std::vector<int32_t>& kmax = H.kmax; std::vector<int32_t>& ord = H.ord; std::vector<int32_t>& tmp = H.tmp;
     std::vector<int32_t>& cnt = H.cnt; std::vector<int32_t>& ordall = H.ordall; std::vector<int32_t>& stamp = H.stamp;
-    if (!have_kminmax) { kmin.resize(L); kmax.resize(L); }
-    cnt.assign(K + 1, 0); stamp.assign(K, -1); ordall.clear();
+    kmin.resize(L); kmax.resize(L); cnt.assign(K + 1, 0); stamp.assign(K, -1); ordall.clear();
     H.grp.clear(); H.span_at.clear(); H.span_end.clear(); H.span_ob0.clear();
     H.blk_c.clear(); H.row_c.clear(); H.blk_ij.clear(); H.blk_start.clear(); H.row_kf.clear(); H.row_start.clear();
-    if (!have_kminmax) {
+    {
         const int NTK = E > 60000 ? 8 : E > 20000 ? 4 : 1;      // (independent per landmark: the worker pool takes it in ranges)
         int32_t* kmn = kmin.data(); int32_t* kmx = kmax.data();
         const int32_t* ls = lm_start.data(); const int32_t* ok = ob_kf.data();
@@ -748,8 +746,8 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     for (int t = 1, g = 0; t < NT; ++t) { while (g < ngrp && H.span_ob0[g] < (int64_t)nob * t / NT) ++g; H.gcut[t] = g; }
     H.bad.assign(NT, 0);
     glap("table allocation");
-    const plba_problem* pp = p; const std::vector<int32_t>* ls = &lm_start; const std::vector<int32_t>* ok = &ob_kf; const std::vector<double>* ow = &ob_w; LmHost* Hp = &H;
-    HostPool::get().start(NT, [pp, ls, ok, ow, Hp](int t) { lm_fill_groups(pp, *ls, *ok, *ow, *Hp, t); });
+    const plba_problem* pp = p; const std::vector<int32_t>* ls = &lm_start; const std::vector<int32_t>* ok = &ob_kf; LmHost* Hp = &H;
+    HostPool::get().start(NT, [pp, ls, ok, Hp](int t) { lm_fill_groups(pp, *ls, *ok, *Hp, t); });
 }
 
 // Dependent launches the multi-chain factorisation needs for T tiles of 32 columns and a band of hbt sub-diagonal tiles: the same
@@ -940,7 +938,7 @@ static int prepare(plba_problem* p) {
     for (int i = 0; i < Nl; ++i) p->lm_fixed[Np + i] = p->ln_fixed[i];
     lap("index maps, slots");
     struct PoolJoin { ~PoolJoin() { HostPool::get().finish(); } } join_tables;      // (declared after the vectors the asynchronous fill reads: joined before they go)
-    if (lm_cand) build_lm_groups(p, lm_start, ob_kf, ob_w, LH);
+    if (lm_cand) build_lm_groups(p, lm_start, ob_kf, LH);
     else LH.grp.clear();
     lap("landmark groups");
     // ---- keyframe-pair lists for the Schur complement --------------------------------------------------

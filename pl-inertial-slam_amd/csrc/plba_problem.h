@@ -207,14 +207,12 @@ struct LmHost {
     int wmax = 8, npair = 36;      // window slots / pose-pair blocks per group in the gather buffer: 16 / 136 when wide groups exist
     std::vector<int32_t> lm_slot, lm_ob0, ob_orig, blk_ij, blk_start, blk_src, row_kf, row_start, row_src;
     std::vector<uint8_t> lm_ws8, lm_fixed, cov;
-    std::vector<double> meas_pt, meas_ln, ob_wt;
     // where lm_fill_groups writes the per-landmark / per-observation tables: straight into the pinned staging area when it has room (round 5:
-    // the tables were filled into the vectors above and copied to the staging area a second time — 4 MB of memcpy per BA call at configs[2]),
-    // else into the vectors
+    // the tables were filled into the vectors above and copied to the staging area a second time), else into the vectors.  The group-order
+    // measurement / weight tables are not built on the host any more: k_lm_tables gathers them on the device (n_meas_*: their sizes)
     bool staged = false;
     int32_t *p_lm_slot = nullptr, *p_lm_ob0 = nullptr, *p_ob_orig = nullptr;
     uint8_t *p_lm_ws8 = nullptr, *p_lm_fixed = nullptr;
-    double *p_meas_pt = nullptr, *p_meas_ln = nullptr, *p_ob_wt = nullptr;
     size_t n_lm = 0, n_ob = 0, n_meas_pt = 0, n_meas_ln = 0;
     // scratch of the build
     std::vector<int32_t> kmin, kmax, ord, tmp, cnt, ordall, stamp, span_at, span_end, span_ob0, gcut, bad, c2, pos;
