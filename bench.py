@@ -49,10 +49,10 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_prefix, config5=False):
+def pmc_traffic(kernel_prefix, config5=False, split=False):
     """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r05_pmc_traffic.json for configs[2],
     r05_config5_pmc_traffic.json for configs[4]: separate rocprofv3 --pmc runs of this same command — FETCH_SIZE, WRITE_SIZE and the L2 read requests by size —, gfx950
-    correction applied, tools/rocpd_extract.py, tools/collect_profiles_r05.sh).
+    correction applied, tools/rocpd_extract.py, tools/collect_profiles_r05.sh).  split: (read bytes, write bytes) instead of their sum.
     PMC counters cannot be collected from inside this process, so the file is tied to the build it came from by a hash of
     csrc/: None when the file is absent or was measured on different kernel sources (never a stale number)."""
     path = os.path.join(ROOT, "profiles", "r05_config5_pmc_traffic.json" if config5 else "r05_pmc_traffic.json")
@@ -65,6 +65,9 @@ def pmc_traffic(kernel_prefix, config5=False):
         return None
     for name, v in ks.items():
         if kernel_prefix in name and "traffic_bytes_per_launch" in v:
+            if split:
+                rd = v.get("fetch_bytes_exact")
+                return (rd, v["traffic_bytes_per_launch"] - rd) if rd is not None else None
             return v["traffic_bytes_per_launch"]
     return None
 
@@ -459,6 +462,9 @@ def main():
                     achieved=bytes_lin / (lin_ms * 1e-3) / 1e9 if lin_ms > 0 else None,
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=(bytes_lin / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if lin_ms > 0 else None,
                     traffic=pmc_traffic(hbm_kernel, config5=(cfg_idx == 5)), algorithmic_bytes_per_launch=bytes_lin, avg_launch_ms=lin_ms, launches_timed=n_lin)
+    rw = pmc_traffic(hbm_kernel, config5=(cfg_idx == 5), split=True)
+    if rw:      # `algorithmic` counts the INPUTS; the writes are the pass's outputs (per-group Schur partials, chi2 per observation)
+        roof_hbm["traffic_read_bytes"], roof_hbm["traffic_write_bytes"] = rw
     kname = "k_chol32" if fb == 32 else "k_chol_step"
     banded = bool(prob.debug_get("band")[0])
     twin = bool(prob.debug_get("twin")[0])

@@ -60,7 +60,7 @@ static void reset_for_reuse(plba_problem* p, const plba_options* opt) {
     p->dirty = true; p->P = p->Ppad = p->ld = p->L = p->E = 0; p->cur = 0;
     p->carry_pts = p->carry_lns = p->carry_kf = p->carry_po = p->carry_lo = p->carry_obs_pending = false;
     p->ob_pos.clear(); p->flow_epoch = 0;
-    p->lm_ok = false; ++p->state_epoch; p->res_lm_epoch = 0; p->res_lm.clear(); p->lm_hist.clear();
+    p->lm_ok = false; p->lm_grouped = false; ++p->state_epoch; p->res_lm_epoch = 0; p->res_lm.clear(); p->lm_hist.clear();
     p->lm_chi_dirty = false; p->back_epoch = 0; p->lm_disable = false; p->lm_spec = false; p->assembled = false;
     memset(&p->lv, 0, sizeof p->lv);
     p->trace.clear(); p->saved_valid = false;
@@ -796,6 +796,17 @@ __global__ void k_lm_tables(const int32_t* __restrict__ ob_orig, int E, int Ep, 
     if (g < Ep) { meas_pt[2 * (size_t)g] = po_uv[2 * (size_t)e]; meas_pt[2 * (size_t)g + 1] = po_uv[2 * (size_t)e + 1]; }
     else for (int c = 0; c < 3; ++c) meas_ln[3 * (size_t)(g - Ep) + c] = lo_l[3 * (size_t)(e - Ep) + c];
 }
+// grouped landmark storage (LmView::lm_grouped): the three state images in GROUP order from a slot-ordered source; ob_slot -> positions
+__global__ void k_lm_permute(const double* __restrict__ src, const int32_t* __restrict__ slot_of_pos, int L, double* __restrict__ out0, double* __restrict__ out1) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L * 6) return;
+    const double v = src[(size_t)slot_of_pos[t / 6] * 6 + t % 6];
+    out0[t] = v; out1[t] = v;
+}
+__global__ void k_remap_slots(int32_t* __restrict__ ob_slot, const int32_t* __restrict__ pos_of_slot, int E) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) ob_slot[e] = pos_of_slot[ob_slot[e]];
+}
 // Hconst[off(a) + c, off(b) + e] = H[idx(a) + c, idx(b) + e] over the prior's kept vertices that are free in this window (H = J0^T J0, n x n)
 __global__ void k_prior_scatter(const double* __restrict__ H, int n, int nv, const int32_t* __restrict__ off, const int32_t* __restrict__ idx, const int32_t* __restrict__ size,
                                 double* __restrict__ Hconst, int ld) {
@@ -1058,6 +1069,7 @@ static int prepare(plba_problem* p) {
         for (DArr<double>* dst : {&p->d_kf[0], &p->d_kf[1], &p->d_kf_saved}) { HIPCK(p, dst->alloc((size_t)K * KF_STRIDE, false)); HIPCK(p, hipMemcpyAsync(dst->p, p->d_kf_carry.p, (size_t)K * KF_STRIDE * 8, hipMemcpyDeviceToDevice, p->stream)); }
     } else { HIPCK(p, p->d_kf[0].upload(p->kf0)); HIPCK(p, p->d_kf[1].upload(p->kf0)); HIPCK(p, p->d_kf_saved.upload(p->kf0)); }
     // the landmarks' three images (current, trial, saved): one pass through the staging area, two copies on the device (1.2 MB each at configs[2])
+    p->lm_grouped = false;      // (slot order until the fused passes' groups are final, below)
     if (carry_all) {
         const size_t nlm = std::max<size_t>((size_t)L * 6, 1);
         HIPCK(p, p->d_lm[0].alloc(nlm, false)); HIPCK(p, p->d_lm[1].alloc(nlm, false)); HIPCK(p, p->d_lm_saved.alloc(nlm, false));
@@ -1559,6 +1571,22 @@ static int prepare(plba_problem* p) {
         lv.ob_err = nullptr; lv.dbg_out = 0;
         p->lm_ok = lv.ngrp > 0;
         HIPCK(p, darr_flush());
+        if (p->lm_ok && L > 0) {
+            // grouped landmark storage: position = place in the group tables (ordall), landmarks without an edge behind them
+            std::vector<int32_t> pos_of_slot(L, -1), slot_of_pos(L, 0);
+            int np = 0;
+            for (size_t n = 0; n < LH.n_lm; ++n) { const int sl = LH.ordall[n]; pos_of_slot[sl] = np; slot_of_pos[np++] = sl; }
+            for (int sl = 0; sl < L; ++sl) if (pos_of_slot[sl] < 0) { pos_of_slot[sl] = np; slot_of_pos[np++] = sl; }
+            HIPCK(p, p->d_lm_pos.upload(pos_of_slot)); HIPCK(p, p->d_lm_ord.upload(slot_of_pos));
+            HIPCK(p, darr_flush());
+            // (d_lm_saved holds the slot-ordered image just uploaded / carried: source of the permutation, then refreshed from the result)
+            hipLaunchKernelGGL(k_lm_permute, dim3((L * 6 + 255) / 256), dim3(256), 0, p->stream, p->d_lm_saved.p, p->d_lm_ord.p, L, p->d_lm[0].p, p->d_lm[1].p);
+            HIPCK(p, hipGetLastError());
+            HIPCK(p, hipMemcpyAsync(p->d_lm_saved.p, p->d_lm[0].p, (size_t)L * 48, hipMemcpyDeviceToDevice, p->stream));
+            if (E) hipLaunchKernelGGL(k_remap_slots, dim3((E + 255) / 256), dim3(256), 0, p->stream, p->d_ob_slot.p, p->d_lm_pos.p, E);
+            HIPCK(p, hipGetLastError());
+            p->lm_grouped = true; lv.lm_grouped = 1;
+        }
         if (p->lm_ok) {
             if (LH.n_ob != (size_t)E) FAIL(p, PLBA_ERR_STATE, "landmark groups list %zu of %d observations (internal error)", LH.n_ob, E);
             hipLaunchKernelGGL(k_lm_tables, dim3((E + 255) / 256), dim3(256), 0, p->stream, p->d_lmg_orig.p, E, Ep, p->d_po_uv.p, p->d_lo_l.p, p->d_ob_w.p, p->d_lmg_meas_pt.p, p->d_lmg_meas_ln.p, p->d_lmg_wt.p);
@@ -2450,11 +2478,11 @@ int plba_get_keyframes(plba_problem* p, double* P3, double* V3, double* q4, doub
 // (state_epoch: bumped by every upload, optimize and restore) and both getters are served from that mirror
 // (round 5: the estimates are packed on the device first — a point uses half of its 48-byte slot —, come back in ONE copy and the
 // requesting call is served straight from the pinned bounce buffer; the other kind's part is kept for its getter.  0.20 -> 0.12 ms per BA call at configs[2])
-__global__ void k_lm_pack(const double* __restrict__ lm, int Np, int Nl, double* __restrict__ out) {
+__global__ void k_lm_pack(const double* __restrict__ lm, const int32_t* __restrict__ pos_of_slot /* null: slot order */, int Np, int Nl, double* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int np3 = 3 * Np;
-    if (t < np3) out[t] = lm[(size_t)(t / 3) * 6 + t % 3];
-    else if (t < np3 + 6 * Nl) out[t] = lm[(size_t)Np * 6 + (t - np3)];
+    if (t < np3) { const int sl = t / 3; out[t] = lm[(size_t)(pos_of_slot ? pos_of_slot[sl] : sl) * 6 + t % 3]; }
+    else if (t < np3 + 6 * Nl) { const int sl = Np + (t - np3) / 6; out[t] = lm[(size_t)(pos_of_slot ? pos_of_slot[sl] : sl) * 6 + (t - np3) % 6]; }
 }
 static int get_lm(plba_problem* p, double* xyz, double* lines) {      // exactly one of the two is requested
     int rc = prepare(p);
@@ -2467,7 +2495,7 @@ static int get_lm(plba_problem* p, double* xyz, double* lines) {      // exactly
         h.resize(tot);
         if (tot) {
             HIPCK(p, p->d_lm_pack.alloc(tot, false));
-            hipLaunchKernelGGL(k_lm_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, p->stream, p->dv.lm[p->cur], p->Np, p->Nl, p->d_lm_pack.p);
+            hipLaunchKernelGGL(k_lm_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, p->stream, p->dv.lm[p->cur], p->lm_grouped ? p->d_lm_pos.p : nullptr, p->Np, p->Nl, p->d_lm_pack.p);
             HIPCK(p, hipGetLastError());
             if (st && st->base && tot * 8 <= st->xfer_cap()) {
                 HIPCK(p, hipMemcpyAsync(st->xfer(), p->d_lm_pack.p, tot * 8, hipMemcpyDeviceToHost, p->stream));
@@ -2518,11 +2546,12 @@ int plba_restore_state(plba_problem* p) {
 
 // ---- plba_slide_window (include/plba.h) ----------------------------------------------------------------------------------------------
 // new landmark array = kept slots gathered from the current estimates | added slots from the upload (src < 0: -(1 + index into `add`))
-__global__ void k_lm_carry_gather(const double* __restrict__ cur, const double* __restrict__ add, const int32_t* __restrict__ src, int Np_new, int L_new, double* __restrict__ out) {
+__global__ void k_lm_carry_gather(const double* __restrict__ cur, const int32_t* __restrict__ cur_pos /* slot -> position in `cur`, null: slot order */, const double* __restrict__ add,
+                                  const int32_t* __restrict__ src, int Np_new, int L_new, double* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L_new * 6) return;
     const int slot = i / 6, c = i % 6, sidx = src[slot];
-    double v = sidx >= 0 ? cur[(size_t)sidx * 6 + c] : add[(size_t)(-1 - sidx) * 6 + c];
+    double v = sidx >= 0 ? cur[(size_t)(cur_pos ? cur_pos[sidx] : sidx) * 6 + c] : add[(size_t)(-1 - sidx) * 6 + c];
     if (slot < Np_new && c >= 3) v = 0.0;      // (a point uses the first half of its slot)
     out[i] = v;
 }
@@ -2707,7 +2736,7 @@ int plba_slide_window(plba_problem* p, const plba_slide* s, int32_t* point_map, 
         // dadd_* live until the slide's one wait at its end)
         HIPCK(p, p->d_lm_carry_src.upload(src)); HIPCK(p, dadd_lm.upload(add));
         HIPCK(p, p->d_lm_carry.alloc(std::max<size_t>((size_t)L1 * 6, 1), false));
-        if (L1) hipLaunchKernelGGL(k_lm_carry_gather, dim3((L1 * 6 + 255) / 256), dim3(256), 0, p->stream, p->dv.lm[p->cur], dadd_lm.p, p->d_lm_carry_src.p, Np1, L1, p->d_lm_carry.p);
+        if (L1) hipLaunchKernelGGL(k_lm_carry_gather, dim3((L1 * 6 + 255) / 256), dim3(256), 0, p->stream, p->dv.lm[p->cur], p->lm_grouped ? p->d_lm_pos.p : nullptr, dadd_lm.p, p->d_lm_carry_src.p, Np1, L1, p->d_lm_carry.p);
         HIPCK(p, hipGetLastError());
         p->carry_pts = true; p->carry_lns = true;
     }

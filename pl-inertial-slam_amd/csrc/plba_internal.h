@@ -186,6 +186,9 @@ struct LmView {
     const uint8_t* col_gather;    // ld: 1 = the gather pass writes this right-hand-side column
     double* ob_err;               // E x 2 residuals, written by the first-iteration pass for the parity tests (null: off)
     int dbg_out;                  // 1: also leave Hll, bl, lm_active, xl where the record-based path leaves them
+    int lm_grouped;               // 1 (round 5): DevBuf::lm[] is stored in GROUP order — landmark gi of the group tables sits at lm + 6 gi — so a group streams
+                                  // its landmarks' estimates instead of gathering 48-byte slots in random order (one 128-byte line each: 3.1 of the
+                                  // 7.3 MB k_lm_schur fetched per launch at configs[2]); ob_slot then holds positions too, lm_slot the true slots (debug outputs)
 };
 
 }  // namespace plba

@@ -180,7 +180,7 @@ DEV void lm_load_idx(const LmView& lv, const LmHead& g, int step, int wv, int la
     x.uvalid = n < g.nlm; x.slot = 0; x.e = 0; x.has = false; x.fixed = true;
     if (!x.uvalid) return;
     const int gi = g.lm0 + n;
-    x.slot = lv.lm_slot[gi];
+    x.slot = lv.lm_grouped ? gi : lv.lm_slot[gi];      // the landmark's place in DevBuf::lm (grouped storage: its place in the group tables)
     const int off = lv.lm_ws8[(size_t)gi * lv.wmax + sub];      // lane = window slot
     x.has = off != 0xFF;
     x.e = lv.lm_ob0[gi] + (x.has ? off : 0);
@@ -289,13 +289,14 @@ DEV void lm_schur_group(const DevBuf& d, const LmView& lv, const int gidx, const
         }
         if (MODE == 1 && lv.ob_err && r.act) lv.ob_err[2 * (size_t)cur.orig + (IS_LINE ? rowsel : 1)] = r.e[NR - 1];
         if (lv.dbg_out && cur.uvalid && sub == 0) {      // diagnostics of the parity tests: Hll, bl in the record-based path's layout
-            double* ho = d.hll + (size_t)cur.slot * 12 + (IS_LINE ? 6 * rowsel : 0);
-            double* bo = d.bl + (size_t)cur.slot * 6 + (IS_LINE ? 3 * rowsel : 0);
+            const int dslot = lv.lm_grouped ? lv.lm_slot[cur.slot] : cur.slot;      // (the true landmark slot)
+            double* ho = d.hll + (size_t)dslot * 12 + (IS_LINE ? 6 * rowsel : 0);
+            double* bo = d.bl + (size_t)dslot * 6 + (IS_LINE ? 3 * rowsel : 0);
 #pragma unroll
             for (int t = 0; t < 6; ++t) ho[t] = h[t];
 #pragma unroll
             for (int t = 0; t < 3; ++t) bo[t] = b[t];
-            if (!IS_LINE || rowsel == 0) d.lm_active[cur.slot] = active ? 1 : 0;
+            if (!IS_LINE || rowsel == 0) d.lm_active[dslot] = active ? 1 : 0;
         }
         if (MODE == 1) {
             if (active && sub == 0) maxd = fmax(maxd, fmax(fmax(fabs(h[0]), fabs(h[3])), fabs(h[5])));
@@ -539,13 +540,14 @@ DEV void lm_schur_group_wide(const DevBuf& d, const LmView& lv, const int gidx, 
         }
         if (MODE == 1 && lv.ob_err && r.act) lv.ob_err[2 * (size_t)cur.orig + (IS_LINE ? rowsel : 1)] = r.e[NR - 1];
         if (lv.dbg_out && cur.uvalid && (lane & 15) == 0) {      // diagnostics of the parity tests: Hll, bl in the record-based path's layout
-            double* ho = d.hll + (size_t)cur.slot * 12 + (IS_LINE ? 6 * rowsel : 0);
-            double* bo = d.bl + (size_t)cur.slot * 6 + (IS_LINE ? 3 * rowsel : 0);
+            const int dslot = lv.lm_grouped ? lv.lm_slot[cur.slot] : cur.slot;      // (the true landmark slot)
+            double* ho = d.hll + (size_t)dslot * 12 + (IS_LINE ? 6 * rowsel : 0);
+            double* bo = d.bl + (size_t)dslot * 6 + (IS_LINE ? 3 * rowsel : 0);
 #pragma unroll
             for (int t = 0; t < 6; ++t) ho[t] = h[t];
 #pragma unroll
             for (int t = 0; t < 3; ++t) bo[t] = b[t];
-            if (!IS_LINE || rowsel == 0) d.lm_active[cur.slot] = active ? 1 : 0;
+            if (!IS_LINE || rowsel == 0) d.lm_active[dslot] = active ? 1 : 0;
         }
         if (MODE == 1) {
             if (active && (lane & 15) == 0) maxd = fmax(maxd, fmax(fmax(fabs(h[0]), fabs(h[3])), fabs(h[5])));
@@ -853,7 +855,7 @@ DEV void lm_trial_group(const DevBuf& d, const LmView& lv, const int gidx, const
             const bool second = IS_LINE && rowsel != 0;
             const double c0 = second ? cur.L[3] : cur.L[0], c1 = second ? cur.L[4] : cur.L[1], c2 = second ? cur.L[5] : cur.L[2];
             Lt[0] = c0 + xl[0]; Lt[1] = c1 + xl[1]; Lt[2] = c2 + xl[2];
-            if (lv.dbg_out) { double* xo = d.xl + (size_t)cur.slot * 6 + (IS_LINE ? 3 * rowsel : 0); xo[0] = xl[0]; xo[1] = xl[1]; xo[2] = xl[2]; }
+            if (lv.dbg_out) { const int dslot = lv.lm_grouped ? lv.lm_slot[cur.slot] : cur.slot; double* xo = d.xl + (size_t)dslot * 6 + (IS_LINE ? 3 * rowsel : 0); xo[0] = xl[0]; xo[1] = xl[1]; xo[2] = xl[2]; }
         }
         // residual of the trial state
         double Ltr[6];

@@ -361,6 +361,10 @@ struct plba_problem {
     std::vector<int32_t> h_pidx, h_seg_col, h_alist;      // host copies of the chain maps / assembly list (band measurement)
     // fused landmark-major passes (options.lm_fused; plba_lm_dev.h)
     bool lm_ok = false;                         // this upload runs them (structure permitting: chain path, <= 16 observations per landmark — wide groups for 9 .. 16 —, none twice from one keyframe)
+    // the landmark state arrays are stored in group order (LmView::lm_grouped): slot -> position (d_lm_pos; the getters, the slide's carry)
+    // and position -> slot (d_lm_ord)
+    bool lm_grouped = false;
+    plba::DArr<int32_t> d_lm_pos, d_lm_ord;
     unsigned long long state_epoch = 1, res_lm_epoch = 0;      // estimates on the device changed | the host mirror of the landmark array is of that epoch
     std::vector<double> res_lm;                 // plba_get_points / plba_get_lines: one read-back per state
     plba::DArr<double> d_lm_pack;               // ... of the PACKED estimates (3 doubles per point, 6 per line: k_lm_pack)
