@@ -517,6 +517,182 @@ MDEV void jacobi2_lds(double* A, int lda, double* V, int n, double tol, double d
         }
     }
 }
+// ---- the same method with ONE barrier per round (the kept block of k_marg_finish, A' and V in LDS, n <= 128) ------------------------
+// jacobi2_lds spends a round as  c, s -> column pairs | barrier | row pairs | barrier.  Here the row phase of round t rides in the column
+// phase of round t + 1: a column is owned by exactly one pair per round, so the owner of (p', q') in round t + 1 first applies round t's
+// row rotations to ITS two columns (every row r has one partner row and one (c, s): per-row tables prt / ca / cb, double-buffered by round
+// parity), now holds the finished columns in registers, takes a_p'p', a_q'q', a_p'q' from them (lane broadcasts, no LDS round trip),
+// rotates the two columns and writes them back in place.  The arithmetic per entry is jacobi2_lds' (c x - s y, s x + c y, same order of
+// the two phases per entry); what changes is one barrier and one dependent LDS round trip less per round: 3.7 k -> 3.3 k cycles
+// at the configs[3] shape (stamps, PLBA_JSTAMPS: tables + columns 0.85 k, c and s 0.65 k, write-back 0.95 k, barrier 0.85 k — the round is bound by
+// the LDS instruction rate of 11 busy waves on one CU, not by the barriers: k_marg_finish 696 -> 610 us).  Columns that left the schedule are not owned by anybody, so their row rotations are not
+// applied; their entries against live indices are restored from the (rotated) rows of the live columns by symmetry before the
+// next sweep's liveness test reads them.  A sweep ends with the pending row rotations applied to every live column.
+struct Jac2sScratch { double2 cs[2][128]; int prt[2][128]; int perm[128]; int live; unsigned char lf[128]; int pad_; };      // (in the kernel's dynamic LDS, behind A' and V)
+template <int MAXIT, int NIT>      // pairs per half-wave and round | rows per lane: ceil(n / 32)
+MDEV void jacobi2s_lds(double* A, int lda, double* V, int n, double tol, double delta0, int max_sweeps, int* s_rot, Jac2sScratch& sc, double* dbg = nullptr) {
+    if (n < 2) return;
+    const int lane = threadIdx.x & 63, hl = lane & 31, hb = lane & 32, nh = (blockDim.x >> 6) * 2, half = (threadIdx.x >> 6) * 2 + (lane >> 5);
+    const double tol2 = tol * tol;
+    int* const s_perm = sc.perm; int& s_live = sc.live; int (*const s_prt)[128] = sc.prt;
+    unsigned char* const s_lf = sc.lf;
+    double2 (*const s_cs)[128] = sc.cs;      // new[r] = cs.x col[r] + cs.y col[prt[r]]
+    double delta = delta0;
+    // finished (row-rotated) entries of a column: rows hl + 32 u
+    // (the row tables are read once per round and lane — both columns of a pair use them: the loop is bound by the LDS instruction rate,
+    // 16 waves on one CU's LDS; stamps: 1.1 k of a round's 3.7 k cycles were this load with the tables read per column)
+    int t_pr[NIT]; double2 t_cs[NIT];
+    auto load_tab = [&](const int tb) {
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) { const int r = hl + 32 * u; t_pr[u] = r < n ? s_prt[tb][r] : 0; t_cs[u] = r < n ? s_cs[tb][r] : make_double2(1.0, 0.0); }
+    };
+    auto load_col = [&](const double* col, const bool pending, double* out) {
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int r = hl + 32 * u;
+            double v = 0.0;
+            if (r < n) {
+                v = col[r];
+                if (pending) v = t_cs[u].x * v + t_cs[u].y * col[t_pr[u]];
+            }
+            out[u] = v;
+        }
+    };
+    auto bcast = [&](const double* a, const int idx) {      // entry `idx` of a column held as above, to every lane of the half-wave
+        double v = a[0];
+#pragma unroll
+        for (int u = 1; u < NIT; ++u) v = ((idx >> 5) == u) ? a[u] : v;
+        return __shfl(v, (idx & 31) | hb);
+    };
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (sweep >= 15) delta *= 2.0;
+        if (threadIdx.x == 0) s_live = 0;
+        if (sweep > 0) {      // columns out of the previous sweep's schedule: entries against the other indices from the rows (symmetry)
+            for (int t = threadIdx.x; t < n * n; t += blockDim.x) { const int j = t / n, k = t % n; if (!s_lf[j] && s_lf[k]) A[(size_t)j * lda + k] = A[(size_t)k * lda + j]; }
+        }
+        __syncthreads();
+        unsigned char mylive[(128 + 1023) / 1024 + 1];
+        {
+            int w = 0;
+            for (int j = threadIdx.x; j < n; j += blockDim.x, ++w) {
+                const double ajj = A[(size_t)j * lda + j];
+                bool live = false;
+                for (int k = 0; k < n; ++k) {
+                    const double v = A[(size_t)k * lda + j], akk = A[(size_t)k * lda + k];
+                    if (k != j && v != 0.0 && fabs(v) > delta + JACOBI2_ANG * fabs(akk - ajj) && v * v > tol2 * fabs(ajj * akk)) { live = true; break; }
+                }
+                mylive[w] = live ? 1 : 0;
+            }
+        }
+        __syncthreads();      // (the symmetrisation above read the previous flags)
+        {
+            int w = 0;
+            for (int j = threadIdx.x; j < n; j += blockDim.x, ++w) s_lf[j] = mylive[w];
+        }
+        for (int r = threadIdx.x; r < n; r += blockDim.x) { s_prt[0][r] = r; s_prt[1][r] = r; s_cs[0][r] = make_double2(1.0, 0.0); s_cs[1][r] = make_double2(1.0, 0.0); }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {      // live columns in index order (deterministic; ordering them by their diagonal entries was tried: more sweeps)
+            if (!s_lf[j]) continue;
+            int rank = 0;
+            for (int k = 0; k < j; ++k) rank += s_lf[k];
+            s_perm[rank] = j;
+            atomicAdd(&s_live, 1);
+        }
+        __syncthreads();
+        const int nl = s_live;
+        if (dbg && threadIdx.x == 0 && sweep < 40) dbg[sweep] = (double)nl;
+        if (threadIdx.x == 0) *s_rot = nl;
+        if (nl < 2) break;
+        const int npad = (nl & 1) ? nl + 1 : nl, mm = npad - 1, npairs = npad / 2;
+        int pr[MAXIT], qr[MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) { const int i = it * nh + half; pr[it] = (i == 0) ? mm : i % mm; qr[it] = (i == 0) ? 0 : (mm - i % mm) % mm; }
+        for (int round = 0; round < mm; ++round) {
+            const bool pending = round > 0;
+            const int tb_prev = (round + 1) & 1, tb = round & 1;
+#ifdef PLBA_JSTAMPS
+            const bool stampme = dbg && threadIdx.x == 64 && sweep == 1 && round == 5;
+            unsigned long long js[6] = {0, 0, 0, 0, 0, 0};
+            if (stampme) js[0] = __builtin_readcyclecounter();
+#define JST(k) do { if (stampme) js[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define JST(k) do {} while (0)
+#endif
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int i = it * nh + half;
+                int p = pr[it], q = qr[it];
+                if (p > q) { const int t = p; p = q; q = t; }
+                const bool have = i < npairs;
+                const bool bye = have && q >= nl;      // the padding index: this round's odd column out (its row rotations are still due)
+                if (have) { p = s_perm[p]; q = bye ? -1 : s_perm[q]; }
+                if (have) {
+                    double* ap_ = A + (size_t)p * lda;
+                    double* aq_ = bye ? ap_ : A + (size_t)q * lda;
+                    double xp[NIT], xq[NIT];
+                    if (pending && it == 0) load_tab(tb_prev);
+                    load_col(ap_, pending, xp);
+                    if (!bye) load_col(aq_, pending, xq);
+                    JST(1);
+                    double c = 1.0, sn = 0.0;
+                    if (!bye) {
+                        const double app = bcast(xp, p), aqq = bcast(xq, q), apq = bcast(xq, p);      // (a_pq: column q, row p — as jacobi2_lds reads it)
+                        if (apq != 0.0 && apq * apq > tol2 * fabs(app * aqq) && fabs(apq) > delta + JACOBI2_ANG * fabs(aqq - app)) {
+                            const double a = aqq - app, bb = 2.0 * apq, fa = fabs(a);
+                            const double h2 = fma(a, a, bb * bb);
+                            const double h = h2 * rsqrt_nr(h2);
+                            const double r = rsqrt_nr(2.0 * h * (h + fa));
+                            c = (fa + h) * r;
+                            sn = ((a * bb >= 0.0) ? fabs(bb) : -fabs(bb)) * r;
+                        }
+                    }
+                    JST(2);
+                    if (hl == 0) {      // this round's row rotation of rows p, q, for the columns' next owners
+                        const bool rot = sn != 0.0;
+                        s_prt[tb][p] = rot ? q : p; s_cs[tb][p] = make_double2(c, -sn);
+                        if (!bye) { s_prt[tb][q] = rot ? p : q; s_cs[tb][q] = make_double2(c, sn); }
+                    }
+                    if (sn != 0.0) {
+                        double* vp = V + (size_t)p * n; double* vq = V + (size_t)q * n;      // (asking for V's columns before the c, s arithmetic was tried: no gain)
+#pragma unroll
+                        for (int u = 0; u < NIT; ++u) {
+                            const int r = hl + 32 * u;
+                            if (r < n) {
+                                const double x = xp[u], y = xq[u], uu = vp[r], w = vq[r];
+                                ap_[r] = c * x - sn * y; aq_[r] = sn * x + c * y;
+                                vp[r] = c * uu - sn * w; vq[r] = sn * uu + c * w;
+                            }
+                        }
+                    } else if (pending) {
+#pragma unroll
+                        for (int u = 0; u < NIT; ++u) { const int r = hl + 32 * u; if (r < n) { ap_[r] = xp[u]; if (!bye) aq_[r] = xq[u]; } }
+                    }
+                }
+                if (i == 0) { qr[it] = (qr[it] + 1 == mm) ? 0 : qr[it] + 1; }
+                else { pr[it] = (pr[it] + 1 == mm) ? 0 : pr[it] + 1; qr[it] = (qr[it] + 1 == mm) ? 0 : qr[it] + 1; }
+            }
+            JST(3);
+            __syncthreads();
+            JST(4);
+#ifdef PLBA_JSTAMPS
+            if (stampme) for (int k = 0; k < 5; ++k) dbg[48 + k] = (double)(js[k] - js[0]);
+#endif
+        }
+        // the last round's row rotations, on every live column
+        {
+            const int tb_last = (mm - 1) & 1;
+            for (int idx = half; idx < nl; idx += nh) {
+                double* col = A + (size_t)s_perm[idx] * lda;
+                double x[NIT];
+                if (idx == half) load_tab(tb_last);
+                load_col(col, true, x);
+#pragma unroll
+                for (int u = 0; u < NIT; ++u) { const int r = hl + 32 * u; if (r < n) col[r] = x[u]; }
+            }
+        }
+        __syncthreads();
+    }
+}
 MDEV double jacobi2_delta(const double* A, int lda, int n, double* s_part) {      // macheps |A|_F / 16  (call with the whole workgroup)
     double f = 0.0;
     for (int t = threadIdx.x; t < n * n; t += blockDim.x) { const double v = A[(size_t)(t / n) * lda + t % n]; f += v * v; }
@@ -579,7 +755,7 @@ __global__ __launch_bounds__(256) void k_pose_pinv(const double* A, int pos, int
 // the STORAGE: n = 105 > 100 put V into global memory and the reference's own window paid 3.2 ms per slide where the configs[3] shape
 // paid 1.2.  The live columns are compacted into an nl x nl problem (75 x 75 there: both A' and V in LDS, 74 instead of 104 rounds per
 // sweep); Vg is only used when even the live part exceeds the in-LDS limit.
-__global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const double* b, int pos, int m, int n, double eps, double* outp, double* Vg, double* dbg) {
+__global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const double* b, int pos, int m, int n, double eps, double* outp, double* Vg, double* dbg, int dyn_bytes) {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     __shared__ int rot, s_nl;
     __shared__ int s_live[JLDS_MAX_N2];
@@ -614,7 +790,13 @@ __global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const dou
     if (dbg && threadIdx.x == 0) { for (int q = 0; q < 48; ++q) dbg[q] = -1.0; dbg[40] = delta; dbg[41] = (double)nl; }
     // two instances behind one uniform branch: with V in LDS its accesses stay ds_ instructions; in global memory (live part beyond 100) a
     // column pair written in one round is read by another half-wave of this workgroup after the barrier of that round
-    if (v_lds) jacobi2_lds<2>(G, lda, Vl, nl, JACOBI2_TOL, delta, 60, &rot, dbg);
+    // the one-barrier form when its row tables fit behind A' and V (always up to 96 live dims)
+    const size_t used = ((size_t)nl * lda + (size_t)nl * nl) * sizeof(double);
+    Jac2sScratch* sc = reinterpret_cast<Jac2sScratch*>(reinterpret_cast<char*>(s_dyn) + used);
+    const bool one_barrier = v_lds && used + sizeof(Jac2sScratch) <= (size_t)dyn_bytes;
+    if (one_barrier && nl <= 64) jacobi2s_lds<1, 2>(G, lda, Vl, nl, JACOBI2_TOL, delta, 60, &rot, *sc, dbg);
+    else if (one_barrier) jacobi2s_lds<2, 4>(G, lda, Vl, nl, JACOBI2_TOL, delta, 60, &rot, *sc, dbg);
+    else if (v_lds) jacobi2_lds<2>(G, lda, Vl, nl, JACOBI2_TOL, delta, 60, &rot, dbg);
     else if (nl <= 128) jacobi2_lds<2>(G, lda, Vg, nl, JACOBI2_TOL, delta, 60, &rot, dbg);
     else jacobi2_lds<3>(G, lda, Vg, nl, JACOBI2_TOL, delta, 60, &rot, dbg);
     __syncthreads();
@@ -1100,10 +1282,13 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
         // larger of the two layouts, and V gets a global buffer whenever n itself is beyond the in-LDS limit
         const bool v_lds = n <= JLDS_MAX_N;
         const size_t nl_max = std::min(n, JLDS_MAX_N);
-        const size_t sh = std::max((size_t)n * (n | 1), nl_max * (nl_max | 1) + nl_max * nl_max) * sizeof(double);
+        size_t sh = std::max((size_t)n * (n | 1), nl_max * (nl_max | 1) + nl_max * nl_max) * sizeof(double);
+        // room for the one-barrier Jacobi's row tables behind A' and V, when the CU's LDS (160 KB less the kernel's static 4 KB) has it
+        const size_t sh_fast = (nl_max * (nl_max | 1) + nl_max * nl_max) * sizeof(double) + sizeof(Jac2sScratch);
+        if (std::max(sh, sh_fast) <= (size_t)163840 - 4096) sh = std::max(sh, sh_fast);
         PLBA_HIPCK(p, ensure_dyn_lds(reinterpret_cast<const void*>(k_marg_finish), (int)sh));
         if (!v_lds) PLBA_HIPCK(p, dV.alloc((size_t)n * n, false));
-        hipLaunchKernelGGL(k_marg_finish, dim3(1), dim3(1024), sh, s, dA.p, db.p, pos, m, n, eps, dOut.p, v_lds ? nullptr : dV.p, d.dbgbuf);
+        hipLaunchKernelGGL(k_marg_finish, dim3(1), dim3(1024), sh, s, dA.p, db.p, pos, m, n, eps, dOut.p, v_lds ? nullptr : dV.p, d.dbgbuf, (int)sh);
     } else {
         // larger kept blocks: G and V in HBM, one launch per round
         PLBA_HIPCK(p, dG.alloc((size_t)n * n, false)); PLBA_HIPCK(p, dV.alloc((size_t)n * n, false));
