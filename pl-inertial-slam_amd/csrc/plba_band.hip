@@ -29,7 +29,7 @@
 //
 // Same arithmetic as the dense path up to the order of the trailing updates, so the parity tests are unchanged.
 #include "plba_internal.h"
-#include "plba_dense_dev.h"
+#include "plba_factor32_dev.h"
 
 namespace plba {
 
@@ -92,9 +92,8 @@ __device__ __forceinline__ void band_step(const DevBuf& dd, int k, int rows, dou
 #else
 #define BSTAMP(i) do {} while (0)
 #endif
-    look32_reset(S, tid);
     __syncthreads();
-    lookahead_factor32<false, true>(dd, k, Akk, S, wv, lane, sLinv);      // (behind a real call it ran at 25.7k cycles instead of 17.3k)
+    factor32_tile<true>(dd, k, Akk, S, wv, lane, sLinv);
     __syncthreads();
     BSTAMP(1);
     if (tid < 32) {

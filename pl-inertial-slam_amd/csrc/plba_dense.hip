@@ -20,7 +20,7 @@
 // wavefront issues an instruction every ~5-8 cycles whatever it is, so the pivot wave must execute as few
 // instructions as possible and everything that is not the pivot recurrence belongs to another wave.
 #include "plba_internal.h"
-#include "plba_dense_dev.h"
+#include "plba_factor32_dev.h"
 
 namespace plba {
 
@@ -306,9 +306,8 @@ __global__ __launch_bounds__(256) void k_potrf0_32(DevBuf d) {
     __shared__ __attribute__((aligned(16))) double sC[32 * LS];
     __shared__ __attribute__((aligned(16))) Look32 S;
     for (int idx = threadIdx.x; idx < 1024; idx += 256) sC[(idx >> 5) * LS + (idx & 31)] = d.sys[(size_t)(idx >> 5) * d.ld + (idx & 31)];
-    look32_reset(S, threadIdx.x);
     __syncthreads();
-    lookahead_factor32<false>(d, 0, sC, S, threadIdx.x >> 6, threadIdx.x & 63);
+    factor32_tile<false>(d, 0, sC, S, threadIdx.x >> 6, threadIdx.x & 63);
 }
 
 // One tile workgroup of block step k.  AUG = false: the tiles of the factorisation proper (trailing update, right-hand-side
@@ -405,10 +404,9 @@ __device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const 
         }
     }
     if (AUG || !lookahead) return;
-    look32_reset(S, threadIdx.x);
     __syncthreads();
     STAMP32(2);
-    lookahead_factor32<false>(d, r, sC, S, wv, lane);
+    factor32_tile<false>(d, r, sC, S, wv, lane);
     STAMP32(3);
 #ifdef PLBA_STAMPS
     if (lane == 0 && blockIdx.x == 0 && k == 5) for (int q = 0; q < 4; ++q) d.maxd_part[4 * wv + q] = (double)(ts[q] - ts[0]);
