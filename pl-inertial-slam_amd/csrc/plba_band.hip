@@ -92,6 +92,7 @@ __device__ __forceinline__ void band_step(const DevBuf& dd, int k, int rows, dou
 #else
 #define BSTAMP(i) do {} while (0)
 #endif
+    factor32_reset(S, tid);
     __syncthreads();
     factor32_tile<true>(dd, k, Akk, S, wv, lane, sLinv);
     __syncthreads();

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void k_chain_schur(DevBuf d, ChainView cv, Dev
     if (fsel < 0 || dd.flow || dd.wide || dd.band) return;
     // tile (0,0) is complete in LDS: run the look-ahead pipeline of the factorisation on it right here (L(0,0) -> dd.Lfac,
     // L(0,0)^-1 -> dd.Linv32[0]) instead of in a launch of its own (k_potrf0_32): the first block step follows directly
+    factor32_reset(S0, threadIdx.x);
     __syncthreads();
     factor32_tile<false>(dd, fsel & 0xffff, sC0, S0, wv, lane);
 }

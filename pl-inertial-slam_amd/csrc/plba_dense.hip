@@ -306,6 +306,7 @@ __global__ __launch_bounds__(256) void k_potrf0_32(DevBuf d) {
     __shared__ __attribute__((aligned(16))) double sC[32 * LS];
     __shared__ __attribute__((aligned(16))) Look32 S;
     for (int idx = threadIdx.x; idx < 1024; idx += 256) sC[(idx >> 5) * LS + (idx & 31)] = d.sys[(size_t)(idx >> 5) * d.ld + (idx & 31)];
+    factor32_reset(S, threadIdx.x);
     __syncthreads();
     factor32_tile<false>(d, 0, sC, S, threadIdx.x >> 6, threadIdx.x & 63);
 }
@@ -404,6 +405,7 @@ __device__ __forceinline__ void chol32_tile(const DevBuf& d, const int k, const 
         }
     }
     if (AUG || !lookahead) return;
+    factor32_reset(S, threadIdx.x);
     __syncthreads();
     STAMP32(2);
     factor32_tile<false>(d, r, sC, S, wv, lane);

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void k_test(DevBuf d, const double* A, double*
     unsigned long long tot = 0;
     for (int rep = 0; rep < reps; ++rep) {
         for (int idx = threadIdx.x; idx < 1024; idx += 256) sC[(idx >> 5) * LS + (idx & 31)] = A[idx];
-        if (MODE == 0) look32_reset(S, threadIdx.x);
+        if (MODE == 0) look32_reset(S, threadIdx.x); else factor32_reset(S, threadIdx.x);
         __syncthreads();
         const unsigned long long t0 = __builtin_readcyclecounter();
         if (MODE == 0) lookahead_factor32<false, true>(d, 0, sC, S, wv, lane, sK);
