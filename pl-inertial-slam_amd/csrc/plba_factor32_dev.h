@@ -29,6 +29,9 @@ template <int J> __device__ __forceinline__ double row_bcast16(double v) {      
     hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + J, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+// (v_fmac_f64_dpp with row_newbcast — the two moves and the FMA of an update as ONE instruction; the 64-bit pipeline takes this DPP control on its
+// VOP2 forms — assembles and was tried through inline assembly: back to back it gives wrong factors, with an s_nop 0 in front of each it is right
+// and exactly as fast as the three instructions, 3.3 k cycles per sweep: the wait states are the hardware's.)
 template <int R> __device__ __forceinline__ double rows_bcast(double v) {       // 16-lane row R of the wave -> all four rows (same position)
     const int l0 = __double2loint(v), h0 = __double2hiint(v);
     // v_permlane32_swap a, a: first result = the low 32 lanes everywhere, second = the high 32 lanes everywhere
