@@ -264,6 +264,7 @@ static int local_ba_with_imu_and_marg(const char* in, const char* out, double* l
 // order, every edge after every vertex and the edges of the landmarks in that descending order too, one measurement set again after
 // addEdge: the facade must fall back from its insertion-time arrays to the objects and sort the observations itself
 static bool g_scrambled = false;
+static bool g_late_estimates = false;      // landmark vertices are inserted with a placeholder estimate; the real one is set after every edge is in
 
 // ---- MapHandler::tryVioInit, the steps between its g2o graphs (src/mapHandler.cpp:4853-4980) ---------------------------------------
 // in: N | dt (N-1) | dP, dV (3 (N-1)) | JPa, JVa (9 (N-1)) | Rc (9 N), pc (3 N) | Rb (9 N), pb (3 N) | Rcb 9, pcb 3
@@ -302,6 +303,7 @@ int main(int argc, char** argv) {
     if (argc >= 4 && !strcmp(argv[1], "essgraph")) return pose_graph(argv[2], argv[3], true);
     if (argc >= 4 && !strcmp(argv[1], "vioinit")) return vio_init(argv[2], argv[3]);
     if (argc >= 4 && !strcmp(argv[1], "nomarg")) return local_ba_with_imu(argv[2], argv[3]);
+    if (argc >= 4 && !strcmp(argv[1], "late")) { g_late_estimates = true; return local_ba_with_imu_and_marg(argv[2], argv[3], nullptr); }
     if (argc >= 4 && !strcmp(argv[1], "scrambled")) { g_scrambled = true; return local_ba_with_imu_and_marg(argv[2], argv[3], nullptr); }
     if (argc >= 4 && !strcmp(argv[1], "lba")) return visual_lba(argv[2], argv[3]);
     // `time window.bin reps`: one localBundleAdjustmentWithImuAndMarg-shaped call through Boundary 1, `reps` times on fresh optimizers, lap by lap
@@ -429,7 +431,7 @@ static int local_ba_with_imu_and_marg(const char* in, const char* out, double* l
         const int id = l + maxKFid + 1;
         if (!g_scrambled) {
             g2o::VertexLMPointXYZ* vPoint = new g2o::VertexLMPointXYZ();
-            vPoint->setEstimate(Vector3d(pts[3 * l], pts[3 * l + 1], pts[3 * l + 2]));
+            vPoint->setEstimate(g_late_estimates ? Vector3d(0, 0, 1) : Vector3d(pts[3 * l], pts[3 * l + 1], pts[3 * l + 2]));
             vPoint->setId(id); vPoint->setFixed(false); vPoint->setMarginalized(true);
             optimizer.addVertex(vPoint);
         }
@@ -474,6 +476,14 @@ static int local_ba_with_imu_and_marg(const char* in, const char* out, double* l
             g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber; ed->setRobustKernel(rk); rk->setDelta(hub[1]);
             ed->SetParams(fx, fy, cx, cy, Rbc, tbc);
             optimizer.addEdge(ed); vlEdgesMono.push_back(ed); vlFirstObsKf.push_back(kf_idx[lo_kf[e0]]);
+        }
+    }
+    if (g_late_estimates) {      // g2o reads a vertex's estimate at optimize(): what is set after addVertex counts (the facade writes it through)
+        for (int l = 0; l < Np; ++l) {
+            g2o::VertexLMPointXYZ* v = dynamic_cast<g2o::VertexLMPointXYZ*>(optimizer.vertex(l + maxKFid + 1));
+            v->setFixed(true);
+            v->setEstimate(Vector3d(pts[3 * l], pts[3 * l + 1], pts[3 * l + 2]));
+            v->setFixed(false);
         }
     }
     if (laps) { laps[0] = ms_since(t_lap); t_lap = tnow(); }
