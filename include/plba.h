@@ -114,11 +114,13 @@ typedef struct {
     int    diag;                /* bit 0: prepare() / plba_lba_visual print their lap timings to stderr; bit 1: plba_marginalize* keeps the
                                    stacked Jacobian and residual for plba_debug_get("marg_J") (the 40-digit fixture's input);
                                    bit 2 (fault injection, tests/test_lm_fused.py): the in-launch wait of k_lm_trial is given a count that
-                                   never comes — the call must fail with PLBA_ERR_DEVICE, not hang                          (0) */
+                                   never comes — the call must fail with PLBA_ERR_DEVICE, not hang; bit 3 (measurement / tests): the
+                                   Jacobi of the marginalization's kept block starts cold, without the tridiagonal pre-rotation    (0) */
 } plba_options;
 #define PLBA_DIAG_TIMING 1
 #define PLBA_DIAG_MARG_DUMP 2
 #define PLBA_DIAG_LEAD_WAIT_FAIL 4
+#define PLBA_DIAG_NO_MARG_PREROTATE 8
 
 void plba_default_options(plba_options* o);
 

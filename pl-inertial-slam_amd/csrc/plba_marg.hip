@@ -693,6 +693,208 @@ MDEV void jacobi2s_lds(double* A, int lda, double* V, int n, double tol, double 
         __syncthreads();
     }
 }
+// ---- pre-rotation of the kept block: Householder tridiagonalisation + implicit QL (round 5) -------------------------------------------
+// The Jacobi above needs ~13 sweeps from a cold start — 7 of them over every live column before anything converges — and a round costs what
+// the CU's LDS can issue: 0.6 ms at 45 live dims, 2.0 ms at the 75 of the reference's own 12-keyframe window, more than the bundle adjustment
+// it follows.  The reference's solver class (Eigen::SelfAdjointEigenSolver, IMU/marginalization.cpp:352,364: tridiagonalisation + implicit
+// QR) gets within n macheps |A| of the answer in O(n^3) flops with a short dependent chain per step; that is not the RELATIVE accuracy the
+// 1e-8 threshold needs while |A'| ~ 1e7, so it is used as what it is good at: V0 with V0^T A' V0 diagonal to ~1e-9 absolute.
+// The Jacobi then starts from (V0^T A' V0, V0) instead of (A', I): every column whose off-diagonal entries already pass its scaled test
+// is out of the schedule at once, what remains are the numerically null / tiny directions (20 - 35 columns, 2 - 4 sweeps), and the
+// result is the Jacobi's own — same criteria, same accuracy class, V = V0 V_jacobi orthogonal as a product of reflections and rotations.
+//   stage 1  A' = Q T Q^T, T tridiagonal (d, e), Q = H_0 H_1 ... accumulated in V: n - 2 steps, every one a matrix-vector product and a
+//            rank-2 update of the trailing block plus the same on V, the whole workgroup on each (three barriers per step)
+//   stage 2  T = Z D Z^T by QL with implicit shifts (EISPACK tql2 / Numerical Recipes tqli, restated): one lane runs the chase — ~17
+//            dependent fp64 operations per rotation — and leaves (c, s) of the pass in LDS; all rows of V take them afterwards, a thread per row
+//   stage 3  G <- V^T A' V with A' streamed from global memory once more (the tridiagonalisation consumed the LDS copy)
+struct TriScratch { double d[128], e[128], c[128], s[128], u[128]; int m[2], go[2]; };      // (m, go: by pass parity — one barrier per pass)
+static_assert(sizeof(TriScratch) <= sizeof(Jac2sScratch), "the pre-rotation's scratch overlays the one-barrier Jacobi's row tables");
+MDEV void tridiag_householder(double* G, const int lda, double* V, const int n, TriScratch& S) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, T = blockDim.x, grp = tid >> 3, part = tid & 7, ngrp = T >> 3;
+    for (int k = 0; k + 2 < n; ++k) {
+        const int mm = n - k - 1;
+        const double* x = G + (size_t)k * lda + k + 1;      // column k below the diagonal (contiguous)
+        // (1) every wave forms the reflector's scalars redundantly (no barrier for them); wave 0 publishes v
+        double st = 0.0;
+        for (int j = lane; j < mm; j += 64) if (j > 0) st += x[j] * x[j];
+        st = wave_sum(st);
+        const double x0 = x[0];
+        const bool reflect = st > 0.0;      // (nothing below the sub-diagonal: H = I)
+        const double alpha = reflect ? -copysign(sqrt(fma(x0, x0, st)), x0) : x0;
+        const double v0 = x0 - alpha;
+        const double beta = reflect ? 2.0 / fma(v0, v0, st) : 0.0;
+        if (wv == 0) for (int j = lane; j < mm; j += 64) S.u[j] = j == 0 ? v0 : x[j];
+        if (tid == 0) { S.d[k] = G[(size_t)k * lda + k]; S.e[k] = alpha; }
+        __syncthreads();
+        if (reflect) {
+            // (2) p = beta G22 u -> S.c, t_r = sum_j V[r][k + 1 + j] u_j -> S.s: eight lanes per entry, fixed order
+            for (int i = grp; i < mm + n; i += ngrp) {
+                double acc = 0.0;
+                if (i < mm) { const double* col = G + (size_t)(k + 1 + i) * lda + k + 1; for (int j = part; j < mm; j += 8) acc = fma(col[j], S.u[j], acc); }      // (row i of the symmetric block = its column i)
+                else { const int r = i - mm; for (int j = part; j < mm; j += 8) acc = fma(V[(size_t)(k + 1 + j) * n + r], S.u[j], acc); }
+                acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+                if (part == 0) { if (i < mm) S.c[i] = beta * acc; else S.s[i - mm] = beta * acc; }
+            }
+            __syncthreads();
+            // (3) K = beta / 2 u^T p (every wave for itself), w = p - K u;  (4) G22 -= u w^T + w u^T,  V[:, k + 1 ..] -= (beta t) u^T
+            double kk = 0.0;
+            for (int j = lane; j < mm; j += 64) kk = fma(S.u[j], S.c[j], kk);
+            kk = 0.5 * beta * wave_sum(kk);
+            for (int t = tid; t < mm * mm; t += T) {
+                const int j = t / mm, i = t % mm;      // entry (row i, column j) of the trailing block
+                const double ui = S.u[i], uj = S.u[j];
+                G[(size_t)(k + 1 + j) * lda + k + 1 + i] -= ui * (S.c[j] - kk * uj) + (S.c[i] - kk * ui) * uj;
+            }
+            for (int t = tid; t < n * mm; t += T) {
+                const int j = t / n, r = t % n;
+                V[(size_t)(k + 1 + j) * n + r] -= S.s[r] * S.u[j];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (n >= 2) { S.d[n - 2] = G[(size_t)(n - 2) * lda + n - 2]; S.e[n - 2] = G[(size_t)(n - 2) * lda + n - 1]; }
+        S.d[n - 1] = G[(size_t)(n - 1) * lda + n - 1]; S.e[n - 1] = 0.0;
+    }
+    __syncthreads();
+}
+// e[i] couples i and i + 1.  Returns (uniform) false when an eigenvalue did not converge in 40 passes: the caller then starts the Jacobi
+// from wherever V stands — it is orthogonal all the same.
+// The chase runs on wave 0 with d and e held ACROSS ITS LANES (lane i: entries i and 64 + i) and moved by v_readlane / v_writelane: the first
+// form kept them in LDS and one lane walked them — every rotation then paid several dependent LDS round trips (a store to e[i + 1] has to land
+// before e[i - 1] may be read: the compiler cannot know better) and the stage cost 0.5 ms at 45 dims, more than the sweeps it saves.
+MDEV double lane_get(const double v, const int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); }
+MDEV void lane_put(double& v, const int l, const double x) { v = ((int)(threadIdx.x & 63) == l) ? x : v; }      // (x uniform: a compare and two selects)
+template <bool HI>
+struct LaneVec {      // up to 64 (HI: 128) doubles over the 64 lanes of a wave (lane i: entries i and 64 + i); index uniform.  No branches: a chase
+    double lo, hi;    // step built from `i < 64 ? ... : ...` branches was 120 executed instructions and 25 jumps, 890 cycles per rotation
+    MDEV double get(const int i) const { const double a = lane_get(lo, i & 63); if (!HI) return a; const double b = lane_get(hi, i & 63); return i < 64 ? a : b; }
+    MDEV void put(const int i, const double x) { const int l = threadIdx.x & 63; lo = (l == i) ? x : lo; if (HI) hi = (l + 64 == i) ? x : hi; }
+};
+template <bool HI>
+MDEV bool tridiag_ql(double* V, const int n, TriScratch& S, double* dbg = nullptr) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    bool ok = true;
+    int n_pass = 0, n_rot = 0;
+    LaneVec<HI> d, e;
+    d.lo = lane < n ? S.d[lane] : 0.0; d.hi = (HI && 64 + lane < n) ? S.d[64 + lane] : 0.0;
+    e.lo = lane < n ? S.e[lane] : 0.0; e.hi = (HI && 64 + lane < n) ? S.e[64 + lane] : 0.0;
+    __syncthreads();      // (S.d / S.e are free from here on: they become the second (c, s) buffer)
+    // The chase of pass k + 1 (wave 0) runs while the rows of V take the rotations of pass k (threads 64 .. 64 + n): two (c, s) buffers,
+    // one barrier per pass.
+    int buf = 0, pend_m = -1, pend_lo = 0, pend_buf = 0, par = 0;
+    const unsigned long long q0 = __builtin_readcyclecounter();
+    for (int l = 0; l <= n; ++l) {      // (l == n: nothing to chase, the last pending pass is applied)
+        for (int iter = 0;; ++iter) {
+            double* const cb = buf ? S.d : S.c; double* const sb = buf ? S.e : S.s;
+            if (tid < 64) {      // wave 0, every lane the same scalars
+                int m = l, go = 0;
+                if (l < n) {
+                    // the first negligible sub-diagonal entry at or after l: every lane tests its own two, one ballot each
+                    const double dn_lo = __shfl_down(d.lo, 1), dn_hi = __shfl_down(d.hi, 1);
+                    const double d64 = HI ? lane_get(d.hi, 0) : 0.0;
+                    const double nx_lo = lane == 63 ? d64 : dn_lo;      // d[i + 1] for i = lane
+                    const bool sm_lo = fabs(e.lo) <= 1.1102230246251565e-16 * (fabs(d.lo) + fabs(nx_lo)), sm_hi = HI && fabs(e.hi) <= 1.1102230246251565e-16 * (fabs(d.hi) + fabs(dn_hi));
+                    const unsigned long long b_lo = __ballot(sm_lo && lane >= l && lane < n - 1), b_hi = HI ? __ballot(sm_hi && 64 + lane >= l && 64 + lane < n - 1) : 0ull;
+                    // (readfirstlane: control flow and lane indices of the chase must be SCALAR for the compiler too)
+                    m = __builtin_amdgcn_readfirstlane(b_lo ? __builtin_ctzll(b_lo) : b_hi ? 64 + __builtin_ctzll(b_hi) : n - 1);
+                    go = (m != l) ? (iter < 40 ? 1 : 2) : 0;
+                }
+                if (go == 1) {
+                    const double dl = d.get(l), el = e.get(l);
+                    double g = (d.get(l + 1) - dl) / (2.0 * el);
+                    double r = sqrt(fma(g, g, 1.0));
+                    g = d.get(m) - dl + el / (g + copysign(r, g));
+                    double sn = 1.0, c = 1.0, p = 0.0;
+                    double d_ip1 = d.get(m);
+                    // (no early exit: f^2 + g^2 = 0 needs an underflow — the pass starts with f = e[m - 1], which the convergence test has
+                    // just found non-negligible, and s = f / r carries on — and a branch in here costs the loop a dozen register copies)
+                    for (int i = m - 1; i >= l; --i) {
+                        const double ei = e.get(i), di = d.get(i);
+                        const double f = sn * ei, bq = c * ei;
+                        const double h2 = fma(f, f, g * g);
+                        const double ri = h2 > 0.0 ? rsqrt_nr(h2) : 0.0;
+                        r = h2 * ri;
+                        e.put(i + 1, r);
+                        sn = f * ri; c = g * ri;
+                        g = d_ip1 - p;
+                        r = fma(di - g, sn, 2.0 * c * bq);
+                        p = sn * r;
+                        d.put(i + 1, g + p);
+                        g = fma(c, r, -bq);
+                        if (lane == 0) { cb[i] = c; sb[i] = sn; }      // rotation of columns i, i + 1 of V, for the rows' pass
+                        d_ip1 = di;
+                    }
+                    d.put(l, d_ip1 - p); e.put(l, g); e.put(m, 0.0);
+                }
+                if (lane == 0) { S.m[par] = m; S.go[par] = go; }
+            } else if (pend_m >= 0 && tid - 64 < n) {      // a row of V takes the PREVIOUS pass's rotations, in the order they were made (m - 1 down to lo)
+                const int row = tid - 64, m = pend_m, lo = pend_lo;
+                const double* const pc = pend_buf ? S.d : S.c; const double* const ps = pend_buf ? S.e : S.s;
+                double hi = V[(size_t)m * n + row];      // V[row][i + 1], carried
+                int i = m - 1;
+                for (; i - 3 >= lo; i -= 4) {      // four rotations' operands asked for at once: the loads do not depend on the carried value
+                    double c4[4], s4[4], z4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { c4[q] = pc[i - q]; s4[q] = ps[i - q]; z4[q] = V[(size_t)(i - q) * n + row]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { V[(size_t)(i - q + 1) * n + row] = fma(s4[q], z4[q], c4[q] * hi); hi = fma(c4[q], z4[q], -s4[q] * hi); }
+                }
+                for (; i >= lo; --i) {
+                    const double c = pc[i], sn = ps[i], z = V[(size_t)i * n + row];
+                    V[(size_t)(i + 1) * n + row] = fma(sn, z, c * hi);
+                    hi = fma(c, z, -sn * hi);
+                }
+                V[(size_t)lo * n + row] = hi;
+            }
+            __syncthreads();
+            const int go = S.go[par], m = S.m[par];      // (the next pass writes the other pair)
+            par ^= 1;
+            pend_m = go == 1 ? m : -1; pend_lo = l; pend_buf = buf;
+            if (go == 1) { buf ^= 1; ++n_pass; n_rot += m - l; }
+            if (go == 2) ok = false;
+            if (go != 1) break;
+        }
+    }
+    if (dbg && tid == 0) { dbg[59] = (double)(__builtin_readcyclecounter() - q0); dbg[60] = 0.0; dbg[61] = n_pass; dbg[62] = n_rot; }
+    return ok;
+}
+// stage 3: G <- V^T A' V (A' = the live part of the kept block, symmetrised, read again from global memory), exactly symmetric on exit.
+// n <= 100 with 1024 threads: at most ten entries per thread, held in registers across the barrier that lets the result replace its operand.
+MDEV void rotate_kept_block(double* G, const int lda, const double* V, const int n, const double* A, const int pos, const int m0, const int* s_live) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    for (int t = tid; t < n * n; t += T) {
+        const int c = t / n, r = t % n, gc = m0 + s_live[c], gr = m0 + s_live[r];
+        G[(size_t)c * lda + r] = 0.5 * (A[(size_t)gr * pos + gc] + A[(size_t)gc * pos + gr]);
+    }
+    __syncthreads();
+    double acc[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {      // W = A' V: W[i][j] = sum_k A'[k][i] V[k][j] (A' symmetric: column i, contiguous)
+        const int t = tid + q * T;
+        double a = 0.0;
+        if (t < n * n) { const int j = t / n, i = t % n; const double* ai = G + (size_t)i * lda; const double* vj = V + (size_t)j * n; for (int k = 0; k < n; ++k) a = fma(ai[k], vj[k], a); }
+        acc[q] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 10; ++q) { const int t = tid + q * T; if (t < n * n) G[(size_t)(t / n) * lda + t % n] = acc[q]; }      // G holds W (column j contiguous)
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {      // G' = V^T W, lower triangle computed, mirrored on the way out
+        const int t = tid + q * T;
+        double a = 0.0;
+        if (t < n * n) { const int j = t / n, i = t % n; if (i >= j) { const double* vi = V + (size_t)i * n; const double* wj = G + (size_t)j * lda; for (int k = 0; k < n; ++k) a = fma(vi[k], wj[k], a); } }
+        acc[q] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        const int t = tid + q * T;
+        if (t < n * n) { const int j = t / n, i = t % n; if (i >= j) { G[(size_t)j * lda + i] = acc[q]; G[(size_t)i * lda + j] = acc[q]; } }
+    }
+    __syncthreads();
+}
 MDEV double jacobi2_delta(const double* A, int lda, int n, double* s_part) {      // macheps |A|_F / 16  (call with the whole workgroup)
     double f = 0.0;
     for (int t = threadIdx.x; t < n * n; t += blockDim.x) { const double v = A[(size_t)(t / n) * lda + t % n]; f += v * v; }
@@ -755,7 +957,7 @@ __global__ __launch_bounds__(256) void k_pose_pinv(const double* A, int pos, int
 // the STORAGE: n = 105 > 100 put V into global memory and the reference's own window paid 3.2 ms per slide where the configs[3] shape
 // paid 1.2.  The live columns are compacted into an nl x nl problem (75 x 75 there: both A' and V in LDS, 74 instead of 104 rounds per
 // sweep); Vg is only used when even the live part exceeds the in-LDS limit.
-__global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const double* b, int pos, int m, int n, double eps, double* outp, double* Vg, double* dbg, int dyn_bytes) {
+__global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const double* b, int pos, int m, int n, double eps, double* outp, double* Vg, double* dbg, int dyn_bytes, int prerotate) {
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     __shared__ int rot, s_nl;
     __shared__ int s_live[JLDS_MAX_N2];
@@ -794,7 +996,19 @@ __global__ __launch_bounds__(1024) void k_marg_finish(const double* A, const dou
     const size_t used = ((size_t)nl * lda + (size_t)nl * nl) * sizeof(double);
     Jac2sScratch* sc = reinterpret_cast<Jac2sScratch*>(reinterpret_cast<char*>(s_dyn) + used);
     const bool one_barrier = v_lds && used + sizeof(Jac2sScratch) <= (size_t)dyn_bytes;
+    if (one_barrier && nl >= 8 && prerotate) {      // (the scratch of the pre-rotation overlays the row tables, which the Jacobi initialises itself)
+        TriScratch& ts = *reinterpret_cast<TriScratch*>(sc);
+        const unsigned long long q0 = __builtin_readcyclecounter();
+        tridiag_householder(G, lda, Vl, nl, ts);
+        const unsigned long long q1 = __builtin_readcyclecounter();
+        if (nl <= 64) tridiag_ql<false>(Vl, nl, ts, dbg); else tridiag_ql<true>(Vl, nl, ts, dbg);
+        const unsigned long long q2 = __builtin_readcyclecounter();
+        rotate_kept_block(G, lda, Vl, nl, A, pos, m, s_live);
+        const unsigned long long q3 = __builtin_readcyclecounter();
+        if (dbg && threadIdx.x == 0) { dbg[56] = (double)(q1 - q0); dbg[57] = (double)(q2 - q1); dbg[58] = (double)(q3 - q2); }
+    }
     if (one_barrier && nl <= 64) jacobi2s_lds<1, 2>(G, lda, Vl, nl, JACOBI2_TOL, delta, 60, &rot, *sc, dbg);
+    else if (one_barrier && nl <= 96) jacobi2s_lds<2, 3>(G, lda, Vl, nl, JACOBI2_TOL, delta, 60, &rot, *sc, dbg);      // (the reference's 12-keyframe window: 75 live dims)
     else if (one_barrier) jacobi2s_lds<2, 4>(G, lda, Vl, nl, JACOBI2_TOL, delta, 60, &rot, *sc, dbg);
     else if (v_lds) jacobi2_lds<2>(G, lda, Vl, nl, JACOBI2_TOL, delta, 60, &rot, dbg);
     else if (nl <= 128) jacobi2_lds<2>(G, lda, Vg, nl, JACOBI2_TOL, delta, 60, &rot, dbg);
@@ -1288,7 +1502,7 @@ int marginalize_factors_device(plba_problem* p, const std::vector<int>& imu_edge
         if (std::max(sh, sh_fast) <= (size_t)163840 - 4096) sh = std::max(sh, sh_fast);
         PLBA_HIPCK(p, ensure_dyn_lds(reinterpret_cast<const void*>(k_marg_finish), (int)sh));
         if (!v_lds) PLBA_HIPCK(p, dV.alloc((size_t)n * n, false));
-        hipLaunchKernelGGL(k_marg_finish, dim3(1), dim3(1024), sh, s, dA.p, db.p, pos, m, n, eps, dOut.p, v_lds ? nullptr : dV.p, d.dbgbuf, (int)sh);
+        hipLaunchKernelGGL(k_marg_finish, dim3(1), dim3(1024), sh, s, dA.p, db.p, pos, m, n, eps, dOut.p, v_lds ? nullptr : dV.p, d.dbgbuf, (int)sh, (p->opt.diag & PLBA_DIAG_NO_MARG_PREROTATE) ? 0 : 1);
     } else {
         // larger kept blocks: G and V in HBM, one launch per round
         PLBA_HIPCK(p, dG.alloc((size_t)n * n, false)); PLBA_HIPCK(p, dV.alloc((size_t)n * n, false));

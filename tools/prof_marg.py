@@ -15,7 +15,7 @@ for rep in range(6):
     torch.cuda.synchronize(); t1 = time.perf_counter()
     print("marginalize %.3f ms (prior dim %d, dropped %d)" % ((t1 - t0) * 1e3, pr["n"], pr["m"]), flush=True)
 print("live columns per sweep:", [int(x) for x in p.debug_get("dbgbuf")[:32]], "noise2 %.3e" % p.debug_get("dbgbuf")[40])
-print("round stamps (cycles):", [int(x) for x in p.debug_get("dbgbuf")[48:56]])
+print("round stamps (cycles):", [int(x) for x in p.debug_get("dbgbuf")[48:56]], "pre-rotation: tridiagonalisation, QL, V^T A V (cycles):", [int(x) for x in p.debug_get("dbgbuf")[56:63]])
 w=np.linalg.eigvalsh(pr["Ar"]); print("eig(A') min %.3e max %.3e, below 1e-8: %d, |A|_F %.3e" % (w.min(), w.max(), (w<=1e-8).sum(), np.linalg.norm(pr["Ar"])))
 print(np.sort(w)[:12])
 p.close()
