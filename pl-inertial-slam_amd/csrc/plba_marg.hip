@@ -311,6 +311,17 @@ MDEV double half_sum(double v, bool upper) {
     const double s1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
     return upper ? s1 : s0;
 }
+// sum over the wave, to every lane: the same DPP steps, both halves' totals by v_readlane (the __shfl_xor form of wave_sum is six dependent
+// ds_bpermute round trips per 32-bit half: ~800 cycles)
+MDEV double wave_sum_dpp(double v) {
+    v += dpp_get<0x111, 0xf>(v);
+    v += dpp_get<0x112, 0xf>(v);
+    v += dpp_get<0x114, 0xf>(v);
+    v += dpp_get<0x118, 0xf>(v);
+    v += dpp_get<0x142, 0xa>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31)) + __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+}
 // A round rotates the npad / 2 disjoint column pairs of the round-robin schedule, one HALF-wave per pair (lane l of the half
 // owns rows l, l + 32, l + 64, l + 96: n <= 128), and ends in one workgroup barrier.  A pair is left alone when
 //   |g_p . g_q| <= tol |g_p| |g_q|                      (orthogonal to the rounding of the dot product), or
@@ -717,7 +728,7 @@ MDEV void tridiag_householder(double* G, const int lda, double* V, const int n, 
         // (1) every wave forms the reflector's scalars redundantly (no barrier for them); wave 0 publishes v
         double st = 0.0;
         for (int j = lane; j < mm; j += 64) if (j > 0) st += x[j] * x[j];
-        st = wave_sum(st);
+        st = wave_sum_dpp(st);
         const double x0 = x[0];
         const bool reflect = st > 0.0;      // (nothing below the sub-diagonal: H = I)
         const double alpha = reflect ? -copysign(sqrt(fma(x0, x0, st)), x0) : x0;
@@ -739,15 +750,16 @@ MDEV void tridiag_householder(double* G, const int lda, double* V, const int n, 
             // (3) K = beta / 2 u^T p (every wave for itself), w = p - K u;  (4) G22 -= u w^T + w u^T,  V[:, k + 1 ..] -= (beta t) u^T
             double kk = 0.0;
             for (int j = lane; j < mm; j += 64) kk = fma(S.u[j], S.c[j], kk);
-            kk = 0.5 * beta * wave_sum(kk);
-            for (int t = tid; t < mm * mm; t += T) {
-                const int j = t / mm, i = t % mm;      // entry (row i, column j) of the trailing block
-                const double ui = S.u[i], uj = S.u[j];
-                G[(size_t)(k + 1 + j) * lda + k + 1 + i] -= ui * (S.c[j] - kk * uj) + (S.c[i] - kk * ui) * uj;
-            }
-            for (int t = tid; t < n * mm; t += T) {
-                const int j = t / n, r = t % n;
-                V[(size_t)(k + 1 + j) * n + r] -= S.s[r] * S.u[j];
+            kk = 0.5 * beta * wave_sum_dpp(kk);
+            // (a 32 x 32 thread tile walks both updates: an index pair from one counter costs two integer divisions by a run-time
+            // divisor per entry — they were half of a step's 8.4 k cycles at 75 dims)
+            const int tx = tid & 31, ty = tid >> 5;
+            for (int j = ty; j < mm; j += 32) {
+                const double uj = S.u[j], wj = S.c[j] - kk * uj;
+                double* col = G + (size_t)(k + 1 + j) * lda + k + 1;
+                for (int i = tx; i < mm; i += 32) { const double ui = S.u[i]; col[i] -= ui * wj + (S.c[i] - kk * ui) * uj; }      // entry (row i, column j) of the trailing block
+                double* vcol = V + (size_t)(k + 1 + j) * n;
+                for (int r = tx; r < n; r += 32) vcol[r] -= S.s[r] * uj;
             }
         }
         __syncthreads();
@@ -770,6 +782,9 @@ struct LaneVec {      // up to 64 (HI: 128) doubles over the 64 lanes of a wave 
     double lo, hi;    // step built from `i < 64 ? ... : ...` branches was 120 executed instructions and 25 jumps, 890 cycles per rotation
     MDEV double get(const int i) const { const double a = lane_get(lo, i & 63); if (!HI) return a; const double b = lane_get(hi, i & 63); return i < 64 ? a : b; }
     MDEV void put(const int i, const double x) { const int l = threadIdx.x & 63; lo = (l == i) ? x : lo; if (HI) hi = (l + 64 == i) ? x : hi; }
+    // one half only, for the stretches of the chase that stay inside it (HALF = 1: index i is entry i of the upper half, i.e. 64 + i)
+    template <int HALF> MDEV double get_h(const int i) const { return lane_get(HALF ? hi : lo, i); }
+    template <int HALF> MDEV void put_h(const int i, const double x) { const int l = threadIdx.x & 63; if (HALF) hi = (l == i) ? x : hi; else lo = (l == i) ? x : lo; }
 };
 template <bool HI>
 MDEV bool tridiag_ql(double* V, const int n, TriScratch& S, double* dbg = nullptr) {
@@ -809,22 +824,33 @@ MDEV bool tridiag_ql(double* V, const int n, TriScratch& S, double* dbg = nullpt
                     double d_ip1 = d.get(m);
                     // (no early exit: f^2 + g^2 = 0 needs an underflow — the pass starts with f = e[m - 1], which the convergence test has
                     // just found non-negligible, and s = f / r carries on — and a branch in here costs the loop a dozen register copies)
-                    for (int i = m - 1; i >= l; --i) {
-                        const double ei = e.get(i), di = d.get(i);
+                    // one rotation; GH / PH: the half of the lane vectors that holds entry i / entry i + 1 (the chase runs in up to three stretches
+                    // — both in the upper half, the crossing at i = 63, both in the lower half — so that no step touches both halves:
+                    // 506 -> ~320 cycles per rotation at 75 dims)
+                    auto rotation = [&](auto GH, auto PH, const int i) {
+                        constexpr int gh = decltype(GH)::value, ph = decltype(PH)::value;
+                        const double ei = e.template get_h<gh>(i - 64 * gh), di = d.template get_h<gh>(i - 64 * gh);
                         const double f = sn * ei, bq = c * ei;
                         const double h2 = fma(f, f, g * g);
                         const double ri = h2 > 0.0 ? rsqrt_nr(h2) : 0.0;
                         r = h2 * ri;
-                        e.put(i + 1, r);
+                        e.template put_h<ph>(i + 1 - 64 * ph, r);
                         sn = f * ri; c = g * ri;
                         g = d_ip1 - p;
                         r = fma(di - g, sn, 2.0 * c * bq);
                         p = sn * r;
-                        d.put(i + 1, g + p);
+                        d.template put_h<ph>(i + 1 - 64 * ph, g + p);
                         g = fma(c, r, -bq);
                         if (lane == 0) { cb[i] = c; sb[i] = sn; }      // rotation of columns i, i + 1 of V, for the rows' pass
                         d_ip1 = di;
+                    };
+                    using H0 = std::integral_constant<int, 0>; using H1 = std::integral_constant<int, 1>;
+                    int i = m - 1;
+                    if (HI) {
+                        for (; i >= l && i >= 64; --i) rotation(H1{}, H1{}, i);
+                        if (i >= l && i == 63) { rotation(H0{}, H1{}, i); --i; }
                     }
+                    for (; i >= l; --i) rotation(H0{}, H0{}, i);
                     d.put(l, d_ip1 - p); e.put(l, g); e.put(m, 0.0);
                 }
                 if (lane == 0) { S.m[par] = m; S.go[par] = go; }

@@ -13,6 +13,7 @@ for rep in range(4):
     pr = p.marginalize(0, 50)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     p0path = p.debug_get("marg_path")[0]
+    stamps = [int(x) for x in p.debug_get("dbgbuf")[56:63]]; live = [int(x) for x in p.debug_get("dbgbuf")[:6]]
     p.close()
     nz = int((np.abs(pr["Ar"]).sum(axis=0) == 0).sum())
-    print("marginalize %.2f ms (prior dim %d, %d exactly zero columns, path %s)" % ((t1 - t0) * 1e3, pr["n"] if "n" in pr else -1, nz, "dense" if p0path else "block-wise"))
+    print("marginalize %.2f ms (prior dim %d, %d exactly zero columns, path %s)" % ((t1 - t0) * 1e3, pr["n"] if "n" in pr else -1, nz, "dense" if p0path else "block-wise"), "pre-rotation cycles [tridiag, QL, rotate, chase, -, passes, rotations]", stamps, "live columns per sweep", live)
