@@ -2454,73 +2454,70 @@ int plba_get_trace(plba_problem* p, plba_trace_row* rows, int cap, int* n) {
     return PLBA_OK;
 }
 
-int plba_get_keyframes(plba_problem* p, double* P3, double* V3, double* q4, double* dbg3, double* dba3) {
-    if (!p) return PLBA_ERR_INVALID;
-    int rc = prepare(p);
-    if (rc) return rc;
-    HIPCK(p, hipSetDevice(p->device));
-    HIPCK(p, plba_stream_wait(p->stream));
-    std::vector<double> h((size_t)p->K * KF_STRIDE);
-    HIPCK(p, plba_d2h(p, h.data(), p->dv.kf[p->cur], h.size() * 8));
-    for (int k = 0; k < p->K; ++k) {
-        const double* s = &h[(size_t)k * KF_STRIDE];
-        if (P3) memcpy(P3 + 3 * k, s, 24);
-        if (V3) memcpy(V3 + 3 * k, s + 3, 24);
-        if (q4) memcpy(q4 + 4 * k, s + 6, 32);
-        if (dbg3) memcpy(dbg3 + 3 * k, s + 16, 24);
-        if (dba3) memcpy(dba3 + 3 * k, s + 19, 24);
-    }
-    return PLBA_OK;
-}
-// the write-back of a BA call reads points AND lines (mapHandler.cpp:6202-6239): the landmark array comes to the host once per state
-// (state_epoch: bumped by every upload, optimize and restore) and both getters are served from that mirror
-// (round 5: the estimates are packed on the device first — a point uses half of its 48-byte slot —, come back in ONE copy and the
-// requesting call is served straight from the pinned bounce buffer; the other kind's part is kept for its getter.  0.20 -> 0.12 ms per BA call at configs[2])
-__global__ void k_lm_pack(const double* __restrict__ lm, const int32_t* __restrict__ pos_of_slot /* null: slot order */, int Np, int Nl, double* __restrict__ out) {
+// The write-back of a BA call reads keyframes, points AND lines (mapHandler.cpp:6202-6239): ONE read-back per state serves the three getters
+// (state_epoch: bumped by every upload, optimize and restore).  The landmark estimates are packed on the device first — a point uses half
+// of its 48-byte slot —, the keyframe states ride behind them, everything comes back in one copy and one wait; the requesting call is served
+// straight from the pinned bounce buffer, the mirror keeps the rest for the other getters.
+// (round 4: three read-backs, 0.20 ms per BA call at configs[2]; round 5: packed landmarks 0.12 ms, with the keyframes in the same copy one
+// more device round trip less)
+__global__ void k_lm_pack(const double* __restrict__ lm, const int32_t* __restrict__ pos_of_slot /* null: slot order */, int Np, int Nl, const double* __restrict__ kf, int nkf, double* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int np3 = 3 * Np;
+    const int np3 = 3 * Np, nl6 = 6 * Nl;
     if (t < np3) { const int sl = t / 3; out[t] = lm[(size_t)(pos_of_slot ? pos_of_slot[sl] : sl) * 6 + t % 3]; }
-    else if (t < np3 + 6 * Nl) { const int sl = Np + (t - np3) / 6; out[t] = lm[(size_t)(pos_of_slot ? pos_of_slot[sl] : sl) * 6 + (t - np3) % 6]; }
+    else if (t < np3 + nl6) { const int sl = Np + (t - np3) / 6; out[t] = lm[(size_t)(pos_of_slot ? pos_of_slot[sl] : sl) * 6 + (t - np3) % 6]; }
+    else if (t < np3 + nl6 + nkf) out[t] = kf[t - np3 - nl6];
 }
-static int get_lm(plba_problem* p, double* xyz, double* lines) {      // exactly one of the two is requested
+// what = 0: keyframes (P3 .. dba3), 1: points (xyz), 2: lines
+static int get_results(plba_problem* p, int what, double* xyz, double* lines, double* P3, double* V3, double* q4, double* dbg3, double* dba3) {
     int rc = prepare(p);
     if (rc) return rc;
-    const size_t np3 = 3 * (size_t)p->Np, nl6 = 6 * (size_t)p->Nl, tot = np3 + nl6;
-    std::vector<double>& h = p->res_lm;      // [points packed | lines packed] of epoch res_lm_epoch
+    const size_t np3 = 3 * (size_t)p->Np, nl6 = 6 * (size_t)p->Nl, nkf = (size_t)p->K * KF_STRIDE, tot = np3 + nl6 + nkf;
+    std::vector<double>& h = p->res_lm;      // [points packed | lines packed | keyframe states] of epoch res_lm_epoch
+    const double* src = nullptr;
     if (!(p->res_lm_epoch == p->state_epoch && h.size() == tot)) {
         HIPCK(p, hipSetDevice(p->device));
         StageArea* st = p->have_ctx ? p->ctx.stage : nullptr;
         h.resize(tot);
         if (tot) {
             HIPCK(p, p->d_lm_pack.alloc(tot, false));
-            hipLaunchKernelGGL(k_lm_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, p->stream, p->dv.lm[p->cur], p->lm_grouped ? p->d_lm_pos.p : nullptr, p->Np, p->Nl, p->d_lm_pack.p);
+            hipLaunchKernelGGL(k_lm_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, p->stream, p->dv.lm[p->cur], p->lm_grouped ? p->d_lm_pos.p : nullptr, p->Np, p->Nl,
+                               p->dv.kf[p->cur], (int)nkf, p->d_lm_pack.p);
             HIPCK(p, hipGetLastError());
             if (st && st->base && tot * 8 <= st->xfer_cap()) {
                 HIPCK(p, hipMemcpyAsync(st->xfer(), p->d_lm_pack.p, tot * 8, hipMemcpyDeviceToHost, p->stream));
                 HIPCK(p, plba_stream_wait(p->stream));
-                const double* x = reinterpret_cast<const double*>(st->xfer());
-                // the requested kind goes straight to the caller; the mirror keeps both (a second getter of this state needs no device round trip)
-                if (xyz && np3) memcpy(xyz, x, np3 * 8);
-                if (lines && nl6) memcpy(lines, x + np3, nl6 * 8);
-                memcpy(h.data(), x, tot * 8);
-                p->res_lm_epoch = p->state_epoch;
-                return PLBA_OK;
-            }
-            HIPCK(p, plba_d2h(p, h.data(), p->d_lm_pack.p, tot * 8));
+                src = reinterpret_cast<const double*>(st->xfer());      // the requested part goes straight to the caller from here
+                memcpy(h.data(), src, tot * 8);
+            } else HIPCK(p, plba_d2h(p, h.data(), p->d_lm_pack.p, tot * 8));
         }
         p->res_lm_epoch = p->state_epoch;
     }
-    if (xyz && np3) memcpy(xyz, h.data(), np3 * 8);
-    if (lines && nl6) memcpy(lines, h.data() + np3, nl6 * 8);
+    if (!src) src = h.data();
+    if (what == 1 && xyz && np3) memcpy(xyz, src, np3 * 8);
+    if (what == 2 && lines && nl6) memcpy(lines, src + np3, nl6 * 8);
+    if (what == 0) {
+        for (int k = 0; k < p->K; ++k) {
+            const double* s = src + np3 + nl6 + (size_t)k * KF_STRIDE;
+            if (P3) memcpy(P3 + 3 * k, s, 24);
+            if (V3) memcpy(V3 + 3 * k, s + 3, 24);
+            if (q4) memcpy(q4 + 4 * k, s + 6, 32);
+            if (dbg3) memcpy(dbg3 + 3 * k, s + 16, 24);
+            if (dba3) memcpy(dba3 + 3 * k, s + 19, 24);
+        }
+    }
     return PLBA_OK;
+}
+int plba_get_keyframes(plba_problem* p, double* P3, double* V3, double* q4, double* dbg3, double* dba3) {
+    if (!p) return PLBA_ERR_INVALID;
+    return get_results(p, 0, nullptr, nullptr, P3, V3, q4, dbg3, dba3);
 }
 int plba_get_points(plba_problem* p, double* xyz) {
     if (!p || !xyz) return PLBA_ERR_INVALID;
-    return get_lm(p, xyz, nullptr);
+    return get_results(p, 1, xyz, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 int plba_get_lines(plba_problem* p, double* l) {
     if (!p || !l) return PLBA_ERR_INVALID;
-    return get_lm(p, nullptr, l);
+    return get_results(p, 2, nullptr, l, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 int plba_save_state(plba_problem* p) {
     if (!p) return PLBA_ERR_INVALID;
