@@ -475,6 +475,9 @@ private:
     void ensure(int workers) {
         while ((int)th_.size() < workers) th_.emplace_back([this] { loop(); });
     }
+    // (polling the job generation for a few hundred microseconds before sleeping, with a wake-up call at the start of prepare(), was tried at
+    // the end of round 5 — the pool is used twice within half a millisecond per BA call and a futex wake costs 30 - 60 us —: no gain in
+    // sequential A/B runs on one box, 3.3 - 3.4 ms per slid call either way; removed)
     void loop() {
         unsigned long long seen = 0;
         for (;;) {
@@ -523,27 +526,38 @@ static bool lm_structure_fits(const plba_problem* p, const std::vector<int32_t>&
 // which the host worker pool fills WHILE prepare() goes on allocating and uploading (the largest single item of a BA call's host side:
 // 2.5 ms on one thread at configs[2]); lm_groups_finish() joins before they are uploaded.
 static void lm_fill_groups(const plba_problem* p, const std::vector<int32_t>& lm_start, const std::vector<int32_t>& ob_kf, LmHost& H, int t) {
+    // (raw pointers: H is a heap object whose vectors' data pointers the loops would reload; keyframe -> window slot through a table per
+    // group — up to 256 keyframes — instead of a search per observation: the fill is what prepare() ends up waiting for)
+    const int32_t* const ordall = H.ordall.data(); const int32_t* const ls = lm_start.data(); const int32_t* const okf = ob_kf.data();
+    const uint8_t* const fixed = p->lm_fixed.data();
+    int32_t* const o_slot = H.p_lm_slot; int32_t* const o_ob0 = H.p_lm_ob0; int32_t* const o_orig = H.p_ob_orig; uint8_t* const o_fixed = H.p_lm_fixed; uint8_t* const o_ws8 = H.p_lm_ws8;
+    const int wmax = H.wmax;
+    const bool use_lut = p->K <= 256;
+    uint8_t lut[256];
+    int bad = 0;
     for (int gi = H.gcut[t]; gi < H.gcut[t + 1]; ++gi) {
         const LmGroup& g = H.grp[gi];
-        const int wmax = H.wmax;
+        if (use_lut) for (int w = 0; w < g.nw; ++w) lut[g.kf[w]] = (uint8_t)w;
         int l = g.lm0, ob = H.span_ob0[gi];
         for (int n = H.span_at[gi]; n < H.span_end[gi]; ++n, ++l) {
-            const int s = H.ordall[n];
-            H.p_lm_slot[l] = s; H.p_lm_fixed[l] = p->lm_fixed[s]; H.p_lm_ob0[l] = ob;
+            const int s = ordall[n];
+            o_slot[l] = s; o_fixed[l] = fixed[s]; o_ob0[l] = ob;
             // the 8 lanes of the landmark's unit(s) ARE the window slots: lane w takes the observation made from keyframe kf[w] (its
             // offset in the landmark's range), or none (0xFF) — so a lane's camera block, operand rows and accumulators never move
-            uint8_t* w8 = &H.p_lm_ws8[(size_t)l * wmax];
-            for (int sl = 0; sl < wmax; ++sl) w8[sl] = 0xFF;
+            uint8_t* w8 = o_ws8 + (size_t)l * wmax;
+            memset(w8, 0xFF, (size_t)wmax);
             int nk = 0;
-            for (int e = lm_start[s]; e < lm_start[s + 1]; ++e, ++ob, ++nk) {
+            for (int e = ls[s]; e < ls[s + 1]; ++e, ++ob, ++nk) {
                 int w = 0;
-                while (g.kf[w] != ob_kf[e]) ++w;      // (<= 8 / 16 window keyframes, all of the landmark's are among them)
-                if (w8[w] != 0xFF) H.bad[t] = 1;      // two observations in one keyframe: not expressible
+                if (use_lut) w = lut[okf[e]];
+                else while (g.kf[w] != okf[e]) ++w;      // (<= 8 / 16 window keyframes, all of the landmark's are among them)
+                bad |= (w8[w] != 0xFF);      // two observations in one keyframe: not expressible
                 w8[w] = (uint8_t)nk;
-                H.p_ob_orig[ob] = e;      // (measurement and weight follow on the DEVICE: k_lm_tables gathers them from the landmark-major arrays)
+                o_orig[ob] = e;      // (measurement and weight follow on the DEVICE: k_lm_tables gathers them from the landmark-major arrays)
             }
         }
     }
+    if (bad) H.bad[t] = 1;
 }
 static bool lm_groups_finish(LmHost& H) {      // false: a keyframe observes a landmark twice (refused at upload; checked all the same)
     HostPool::get().finish();
@@ -684,17 +698,6 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
             for (int q = 0; q < LMF_W2; ++q) { g.kf[q] = q < nw ? win[q] : 0; g.off[q] = q < nw ? p->off_pvr[win[q]] : -1; }
             H.grp.push_back(g);
             H.span_at.push_back(base + (int32_t)at); H.span_end.push_back(base + (int32_t)end); H.span_ob0.push_back(nob);
-            // ---- phase 2 for this group: its window's pose pairs and right-hand-side rows (in group order = the fixed summation order) ----
-            for (int q = 0; q < nw; ++q) {
-                if (g.off[q] < 0) continue;
-                for (int pp = 0; pp <= q; ++pp) {
-                    if (g.off[pp] < 0) continue;
-                    const int i = g.kf[pp], j = g.kf[q];
-                    H.cov[(size_t)i * K + j] = 1; H.cov[(size_t)j * K + i] = 1;
-                    H.blk_c.push_back({(int64_t)i * K + j, gi * H.npair + q * (q + 1) / 2 + pp});
-                }
-                H.row_c.push_back({(int64_t)g.kf[q], gi * H.wmax + q});
-            }
             nlm += (int)(end - at); nob += gob;
             at = end;
         }
@@ -702,27 +705,6 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
         if (gt) { auto t = std::chrono::steady_clock::now(); t_cut += std::chrono::duration<double, std::milli>(t - g0).count(); g0 = t; }
     }
     if (gt) fprintf(stderr, "[prepare]   groups: order (sorts)      %8.3f ms\n[prepare]   groups: cut + pair lists   %8.3f ms\n", t_sort, t_cut);
-    // stable counting sorts by key (K * K resp. K buckets): equal keys stay in group order
-    {
-        std::vector<int32_t>& c2 = H.c2; std::vector<int32_t>& pos = H.pos;
-        c2.assign((size_t)K * K + 1, 0);
-        for (const auto& b : H.blk_c) c2[b.first + 1]++;
-        for (size_t k = 0; k < (size_t)K * K; ++k) c2[k + 1] += c2[k];
-        H.blk_src.resize(H.blk_c.size());
-        for (size_t k = 0; k < (size_t)K * K; ++k) if (c2[k + 1] > c2[k]) { const int i = (int)(k / K), j = (int)(k % K); H.blk_ij.push_back((int32_t)(i | (j << 16))); H.blk_start.push_back(c2[k]); }
-        H.blk_start.push_back((int32_t)H.blk_c.size());
-        pos.assign(c2.begin(), c2.end() - 1);
-        for (const auto& b : H.blk_c) H.blk_src[pos[b.first]++] = b.second;
-        c2.assign(K + 1, 0);
-        for (const auto& r : H.row_c) c2[r.first + 1]++;
-        for (int k = 0; k < K; ++k) c2[k + 1] += c2[k];
-        H.row_src.resize(H.row_c.size());
-        for (int k = 0; k < K; ++k) if (c2[k + 1] > c2[k]) { H.row_kf.push_back(k); H.row_start.push_back(c2[k]); }
-        H.row_start.push_back((int32_t)H.row_c.size());
-        pos.assign(c2.begin(), c2.end() - 1);
-        for (const auto& r : H.row_c) H.row_src[pos[r.first]++] = r.second;
-    }
-    glap("gather lists");
     // ---- phase 3: the tables, group by group, on the worker pool; joined by lm_groups_finish() -------------------------------------------------
     const int ngrp = (int)H.grp.size();
     H.n_lm = (size_t)nlm; H.n_ob = (size_t)nob; H.n_meas_pt = 2 * (size_t)Ep; H.n_meas_ln = 3 * (size_t)(E - Ep);
@@ -748,6 +730,49 @@ static void build_lm_groups(const plba_problem* p, const std::vector<int32_t>& l
     glap("table allocation");
     const plba_problem* pp = p; const std::vector<int32_t>* ls = &lm_start; const std::vector<int32_t>* ok = &ob_kf; LmHost* Hp = &H;
     HostPool::get().start(NT, [pp, ls, ok, Hp](int t) { lm_fill_groups(pp, *ls, *ok, *Hp, t); });
+    // ---- phase 2, while the workers fill the tables (round 5: it sat inside the cut loop, 0.13 ms the pool spent idle and prepare() then
+    // spent waiting for the fill): every group's window's pose pairs and right-hand-side rows, in group order = the fixed summation order
+    {
+        size_t npairs_tot = 0, nrows_tot = 0;
+        for (const LmGroup& g : H.grp) { int nf = 0; for (int q = 0; q < g.nw; ++q) nf += g.off[q] >= 0; npairs_tot += (size_t)nf * (nf + 1) / 2; nrows_tot += nf; }
+        H.blk_c.resize(npairs_tot); H.row_c.resize(nrows_tot);
+        auto* bc = H.blk_c.data(); auto* rc = H.row_c.data();
+        uint8_t* cov = H.cov.data();
+        for (int gi = 0; gi < ngrp; ++gi) {
+            const LmGroup& g = H.grp[gi];
+            for (int q = 0; q < g.nw; ++q) {
+                if (g.off[q] < 0) continue;
+                for (int pp = 0; pp <= q; ++pp) {
+                    if (g.off[pp] < 0) continue;
+                    const int i = g.kf[pp], j = g.kf[q];
+                    cov[(size_t)i * K + j] = 1; cov[(size_t)j * K + i] = 1;
+                    *bc++ = {(int64_t)i * K + j, gi * H.npair + q * (q + 1) / 2 + pp};
+                }
+                *rc++ = {(int64_t)g.kf[q], gi * H.wmax + q};
+            }
+        }
+    }
+    // stable counting sorts by key (K * K resp. K buckets): equal keys stay in group order
+    {
+        std::vector<int32_t>& c2 = H.c2; std::vector<int32_t>& pos = H.pos;
+        c2.assign((size_t)K * K + 1, 0);
+        for (const auto& b : H.blk_c) c2[b.first + 1]++;
+        for (size_t k = 0; k < (size_t)K * K; ++k) c2[k + 1] += c2[k];
+        H.blk_src.resize(H.blk_c.size());
+        for (size_t k = 0; k < (size_t)K * K; ++k) if (c2[k + 1] > c2[k]) { const int i = (int)(k / K), j = (int)(k % K); H.blk_ij.push_back((int32_t)(i | (j << 16))); H.blk_start.push_back(c2[k]); }
+        H.blk_start.push_back((int32_t)H.blk_c.size());
+        pos.assign(c2.begin(), c2.end() - 1);
+        for (const auto& b : H.blk_c) H.blk_src[pos[b.first]++] = b.second;
+        c2.assign(K + 1, 0);
+        for (const auto& r : H.row_c) c2[r.first + 1]++;
+        for (int k = 0; k < K; ++k) c2[k + 1] += c2[k];
+        H.row_src.resize(H.row_c.size());
+        for (int k = 0; k < K; ++k) if (c2[k + 1] > c2[k]) { H.row_kf.push_back(k); H.row_start.push_back(c2[k]); }
+        H.row_start.push_back((int32_t)H.row_c.size());
+        pos.assign(c2.begin(), c2.end() - 1);
+        for (const auto& r : H.row_c) H.row_src[pos[r.first]++] = r.second;
+    }
+    glap("gather lists");
 }
 
 // Dependent launches the multi-chain factorisation needs for T tiles of 32 columns and a band of hbt sub-diagonal tiles: the same
