@@ -150,3 +150,34 @@ def test_slide_refusals_leave_the_window_as_it_was(pkg, hip):
     assert (s1.chi2_final, s1.trials) == (t1.chi2_final, t1.trials)
     p.slide_window(d)      # and the valid slide still goes through
     p.close(); q.close()
+
+
+def test_slide_at_a_200_keyframe_window(pkg, hip):
+    """BASELINE configs[4]'s keyframe count (the four-chain nested factorisation plan, 43 dense tiles) at a third of its landmarks (0.35 M
+    observations: fused passes, landmark estimates stored in group order): two consecutive slides, each bit-identical to a fresh handle
+    given the same window — estimates, chi2 trace and the marginalization prior the next window carries."""
+    W = pkg.window
+    K, nwin = 200, 3
+    seq = W.make_sequence(K, nwin, 66000, 13000, seed=0x511DE200, kf_dt=0.05)
+    slid = pkg.new_problem()
+    w_prev, res_prev, prior = None, None, None
+    for i in range(nwin):
+        w = W.window_at(seq, i, K, prev=w_prev)
+        if i == 0:
+            wf = w
+            slid.upload_window(w)
+        else:
+            wf = W.window_from_results(w, w_prev, res_prev)
+            slid.slide_window(W.slide_delta(w_prev, w))
+        _after_upload(pkg, slid, w, prior)
+        a = _ba(pkg, slid, True)
+        if i > 0:
+            fresh = pkg.new_problem()
+            wf = dict(wf); wf["prior"] = prior
+            fresh.upload_window(wf)
+            b = _ba(pkg, fresh, True)
+            _same(a, b, "window %d" % i)
+            fresh.close()
+        w_prev, res_prev, prior = w, a[1], a[2]
+    assert int(slid.debug_get("lm_fused")[0]) == 1 and int(slid.debug_get("twin")[0]) == 1
+    slid.close()
